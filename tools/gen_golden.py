@@ -1,0 +1,478 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by DRIVING THE REAL REFERENCE CODE in the authoring container.
+
+This script only runs where /root/reference exists (never on the GPU box).  It puts the
+reference on sys.path, installs import-time-only stubs for third-party packages that are not
+installed here (bm25s, more_itertools, sentence_transformers, mashumaro, pytorch_lightning, fire)
+and then calls the reference's own, unmodified functions:
+
+  * mfar.data.index.DenseFlatIndex.retrieve_batch / score_batch   (index.py:181-232)
+  * mfar.modeling.weighting.LinearWeights.forward                 (weighting.py:17-29)
+  * mfar.modeling.contrastive.RetrievalTrainingModule.trec_eval_step (contrastive.py:669-704),
+    called unbound with a SimpleNamespace `self`
+  * mfar.data.schema.resolve_fields                               (schema.py:96-134)
+  * mfar.data.trec.QRes.__str__/from_str                          (trec.py:35-59)
+  * mfar.data.format.format_documents                             (format.py:7-61)
+  * mfar.data.util.MemoryMapDict                                  (data/util.py:28-59)
+  * inspect.signature of mfar.commands.{train,mask_fields}.main   (train.py:25-65, mask_fields.py:20-50)
+
+Outputs: small .npz / .json fixtures under tests/golden/ (inputs + the reference's outputs).
+A fixture is data only; no reference source text is written anywhere.
+
+Usage:  python tools/gen_golden.py [--out tests/golden]
+"""
+import argparse
+import inspect
+import io
+import json
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+
+
+# ----------------------------------------------------------------------------- stubs
+def _install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    class _Anything:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return _Anything()
+
+        def __getattr__(self, name):
+            return _Anything()
+
+    # bm25s
+    mod("bm25s", BM25=_Anything, tokenize=lambda *a, **k: None)
+    mod("Stemmer", Stemmer=_Anything)
+
+    # more_itertools.chunked (needs to really work)
+    def chunked(it, n):
+        buf = []
+        for x in it:
+            buf.append(x)
+            if len(buf) == n:
+                yield buf
+                buf = []
+        if buf:
+            yield buf
+
+    mod("more_itertools", chunked=chunked)
+
+    # sentence_transformers (+ models)
+    st = mod("sentence_transformers", SentenceTransformer=_Anything)
+    st.models = mod("sentence_transformers.models", Normalize=_Anything, Pooling=_Anything, Transformer=_Anything)
+
+    # mashumaro
+    class DataClassJSONMixin:
+        def to_json(self):
+            return json.dumps(self.__dict__)
+
+    mod("mashumaro")
+    mod("mashumaro.mixins")
+    mod("mashumaro.mixins.json", DataClassJSONMixin=DataClassJSONMixin)
+
+    # pytorch_lightning
+    class LightningModule(torch.nn.Module):
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+    class LightningDataModule:
+        pass
+
+    pl = mod("pytorch_lightning", LightningModule=LightningModule, LightningDataModule=LightningDataModule,
+             Trainer=_Anything, seed_everything=lambda *a, **k: None)
+    pl.loggers = mod("pytorch_lightning.loggers", MLFlowLogger=_Anything, WandbLogger=_Anything, Logger=_Anything)
+    pl.strategies = mod("pytorch_lightning.strategies", DDPStrategy=_Anything)
+    pl.callbacks = mod("pytorch_lightning.callbacks", EarlyStopping=_Anything, ModelCheckpoint=_Anything,
+                       LearningRateMonitor=_Anything)
+    mod("pytorch_lightning.callbacks.early_stopping", EarlyStopping=_Anything)
+    mod("pytorch_lightning.callbacks.model_checkpoint", ModelCheckpoint=_Anything)
+    mod("fire", Fire=lambda *a, **k: None)
+    mod("stark_qa", load_skb=_Anything, load_qa=_Anything)
+
+
+# ----------------------------------------------------------------------------- fake encoder
+class LookupEncoder:
+    """Zero-cost stand-in for the SentenceTransformer: text 'q<i>' -> row i of a fixed matrix.
+    The reference only needs .encode(texts, convert_to_tensor=True), __call__(features) and
+    get_max_seq_length() (index.py:187,228; contrastive.py:688-693)."""
+
+    def __init__(self, table: np.ndarray):
+        self.table = torch.from_numpy(np.ascontiguousarray(table))
+
+    def _idx(self, text):
+        return int(text[1:])
+
+    def encode(self, texts, convert_to_tensor=False, convert_to_numpy=False, batch_size=64, **kw):
+        out = torch.stack([self.table[self._idx(t)] for t in texts])
+        if convert_to_numpy and not convert_to_tensor:
+            return out.numpy()
+        return out
+
+    def get_max_seq_length(self):
+        return 512
+
+    def get_sentence_embedding_dimension(self):
+        return self.table.shape[1]
+
+    def __call__(self, feats):
+        # input_ids[0][0] carries the query index
+        i = int(feats["input_ids"][0][0])
+        return {"sentence_embedding": self.table[i].unsqueeze(0)}
+
+
+def canon(ids, scores):
+    """(score desc, id asc) ordering of one result list."""
+    ids = np.asarray(ids, dtype=np.int64)
+    scores = np.asarray(scores, dtype=np.float32)
+    order = np.lexsort((ids, -scores.astype(np.float64)))
+    return ids[order], scores[order]
+
+
+def gauss(rng, shape, mean=0.0, std=1.0):
+    return (mean + std * rng.standard_normal(shape)).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- generators
+def gen_retrieve(out, DenseFlatIndex):
+    cases = {}
+    specs = [
+        # name, D, E, Q, k, chunk, mean (doc mean shifts scores positive/negative)
+        ("g1_basic", 2500, 32, 8, 100, 1048576, 0.3),
+        ("g1_chunked", 2500, 32, 8, 100, 256, 0.3),          # chunk-merge path index.py:194-212
+        ("g1_negative", 1200, 32, 6, 100, 1048576, -0.6),    # mostly negative scores -> zero-sentinel padding
+        ("g1_e768", 200, 768, 4, 100, 128, 0.05),
+        ("g1_smallD", 60, 64, 3, 100, 1048576, 0.5),          # D < k: padded with (row 0, 0.0)
+        ("g1_k10", 700, 64, 5, 10, 300, 0.2),
+    ]
+    for name, D, E, Q, k, chunk, mean in specs:
+        rng = np.random.default_rng(sum(map(ord, name.replace("chunked", "basic"))))
+        mu = gauss(rng, (E,), 0.0, 1.0)
+        mu /= np.linalg.norm(mu)
+        V = gauss(rng, (D, E)) * 0.5 + mean * mu * 4.0
+        q = gauss(rng, (Q, E)) * 0.5 + mu * 2.0
+        V = V.astype(np.float32)
+        q = q.astype(np.float32)
+        keys = [str(i) for i in range(D)]
+        idx = DenseFlatIndex(None, V, keys, {k_: i for i, k_ in enumerate(keys)}, vector_batch_size=chunk)
+        res = idx.retrieve_batch(q, top_k=k)
+        ids = np.array([[int(key) for key, _ in r] for r in res], dtype=np.int64)
+        sc = np.array([[s for _, s in r] for r in res], dtype=np.float32)
+        cases[name] = dict(V=V, q=q, k=np.int64(k), chunk=np.int64(chunk), ids=ids, scores=sc)
+    np.savez_compressed(os.path.join(out, "retrieve_batch.npz"),
+                        **{f"{n}__{k}": v for n, c in cases.items() for k, v in c.items()})
+    return list(cases)
+
+
+def gen_score_batch(out, DenseFlatIndex):
+    rng = np.random.default_rng(1234)
+    D, E, Q = 900, 64, 3
+    V = gauss(rng, (D, E))
+    qtab = gauss(rng, (Q, E))
+    keys = [f"doc{i}" for i in range(D)]
+    enc = LookupEncoder(qtab)
+    idx = DenseFlatIndex(enc, V, keys, {k: i for i, k in enumerate(keys)})
+    cand = rng.choice(D, size=257, replace=False).astype(np.int64)
+    outs = []
+    for qi in range(Q):
+        s = idx.score_batch([f"q{qi}"], [keys[c] for c in cand])
+        assert isinstance(s, torch.Tensor) and tuple(s.shape) == (1, len(cand))
+        outs.append(s.numpy()[0])
+    # unknown key -> KeyError (index.py:229)
+    try:
+        idx.score_batch(["q0"], ["nope"])
+        raised = False
+    except KeyError:
+        raised = True
+    np.savez_compressed(os.path.join(out, "score_batch.npz"), V=V, q=qtab, cand=cand,
+                        scores=np.stack(outs).astype(np.float32), unknown_key_raises=np.bool_(raised))
+
+
+def gen_linear_weights(out, LinearWeights):
+    rng = np.random.default_rng(77)
+    E, F = 64, 5
+    W = gauss(rng, (E, F), std=0.2)
+    d = {}
+    # eval shape: x [C,F] 2-D, q [1,E]  (contrastive.py:694)
+    x2 = gauss(rng, (37, F), std=3.0)
+    q1 = gauss(rng, (1, E))
+    lw = LinearWeights(E, F, query_cond=True)
+    assert torch.equal(lw.weight.data, torch.ones(E, F))  # init ones (weighting.py:14)
+    lw.weight.data = torch.from_numpy(W.copy())
+    with torch.no_grad():
+        d["eval_out"] = lw(torch.from_numpy(x2), torch.from_numpy(q1)).numpy()
+    # train shape: x [B,S,F], q [B,E]
+    x3 = gauss(rng, (4, 9, F), std=3.0)
+    q4 = gauss(rng, (4, E))
+    with torch.no_grad():
+        d["train_out"] = lw(torch.from_numpy(x3), torch.from_numpy(q4)).numpy()
+    # not query-conditioned: LinearWeights(num_fields, 1) (contrastive.py:286-287) -> weight [F,1]
+    lw2 = LinearWeights(F, 1, query_cond=False)
+    w2 = gauss(rng, (F, 1))
+    lw2.weight.data = torch.from_numpy(w2.copy())
+    with torch.no_grad():
+        d["nocond_out"] = lw2(torch.from_numpy(x3), None).numpy()
+    np.savez_compressed(os.path.join(out, "linear_weights.npz"), W=W, x2=x2, q1=q1, x3=x3, q4=q4, w2=w2, **d)
+
+
+def gen_trec_eval_step(out, DenseFlatIndex, LinearWeights, contrastive, FieldType, Query):
+    """Drive the UNMODIFIED RetrievalTrainingModule.trec_eval_step (contrastive.py:669-704)."""
+    torch.Tensor.cuda = lambda self, *a, **k: self  # reference hard-codes .cuda() (contrastive.py:685-686)
+    cases = {}
+    specs = [
+        # name, F, D, E, Q, mean, mask (list of masked field idx), std_W
+        ("t_f1", 1, 900, 32, 4, 0.3, [], 0.05),
+        ("t_f4", 4, 1200, 32, 6, 0.3, [], 0.05),
+        ("t_f4_mask1", 4, 1200, 32, 6, 0.3, [1], 0.05),
+        ("t_f4_maskall_but_one", 4, 1200, 32, 6, 0.3, [0, 1, 3], 0.05),
+        ("t_f8", 8, 700, 32, 5, 0.25, [], 0.1),
+        ("t_f8_neg", 8, 700, 32, 5, -0.4, [2], 0.1),       # zero-sentinel padding flows into stage 2
+        ("t_f3_e768", 3, 160, 768, 3, 0.05, [], 0.02),
+        ("t_f22", 22, 260, 32, 3, 0.3, [5, 7], 0.05),
+    ]
+    for name, F, D, E, Q, mean, masked, stdw in specs:
+        rng = np.random.default_rng(sum(map(ord, name.split("_mask")[0])) + 1000)
+        mu = gauss(rng, (E,))
+        mu /= np.linalg.norm(mu)
+        slab = (gauss(rng, (F, D, E)) * 0.5 + mean * mu * 4.0).astype(np.float32)
+        # planted relevance: a few docs get alpha*q in some fields
+        qtab = (gauss(rng, (Q, E)) * 0.5 + mu * 2.0).astype(np.float32)
+        for qi in range(Q):
+            for _ in range(3):
+                d = int(rng.integers(0, D))
+                for f in rng.choice(F, size=max(1, F // 2), replace=False):
+                    slab[f, d] = (0.6 * qtab[qi] + 0.3 * gauss(rng, (E,))).astype(np.float32)
+        W = gauss(rng, (E, F), std=stdw)
+        keys = [str(i) for i in range(D)]
+        k2n = {k: i for i, k in enumerate(keys)}
+        enc = LookupEncoder(qtab)
+        indices = {f"f{f:02d}_dense": DenseFlatIndex(enc, slab[f], keys, k2n) for f in range(F)}
+        lw = LinearWeights(E, F, query_cond=True)
+        lw.weight.data = torch.from_numpy(W.copy())
+        mask = torch.ones([F, 1])
+        if masked:
+            mask[masked] = 0
+        fake_self = SimpleNamespace(
+            indices_dict=indices, mask=mask, encoder=enc,
+            hybrid_contrastive_loss_fn=SimpleNamespace(mixture_of_fields_layer=lw),
+        )
+        instances = [Query(f"qid{qi}", f"q{qi}") for qi in range(Q)]
+        input_ids = torch.arange(Q).unsqueeze(1).repeat(1, 3)
+        batch = SimpleNamespace(
+            instances=instances,
+            query={FieldType.DENSE: {"input_ids": input_ids, "attention_mask": torch.ones_like(input_ids)}},
+        )
+        buf = io.StringIO()
+        with torch.no_grad():
+            contrastive.RetrievalTrainingModule.trec_eval_step(fake_self, batch, 0, buf)
+        lines = [l for l in buf.getvalue().split("\n") if l]
+        assert len(lines) == Q * 100, (name, len(lines))
+        ids = np.zeros((Q, 100), dtype=np.int64)
+        sc = np.zeros((Q, 100), dtype=np.float32)
+        for li, line in enumerate(lines):
+            qid, _it, doc, _rank, sim, _run = line.split("\t")
+            qi, r = divmod(li, 100)
+            assert qid == f"qid{qi}"
+            ids[qi, r] = int(doc)
+            sc[qi, r] = np.float32(float(sim))
+        for qi in range(Q):
+            ids[qi], sc[qi] = canon(ids[qi], sc[qi])
+        cases[name] = dict(slab=slab, q=qtab, W=W, mask=mask.numpy()[:, 0].astype(np.float32), ids=ids, scores=sc)
+        base = name.split("_mask")[0]
+        if base != name:  # mask variants share the base case's inputs: store them once
+            assert np.array_equal(cases[base]["slab"], slab) and np.array_equal(cases[base]["W"], W)
+            for k_ in ("slab", "q", "W"):
+                del cases[name][k_]
+            cases[name]["base"] = np.array(base)
+        if name == "t_f4":
+            cases[name]["first_line"] = np.array(lines[0])
+    np.savez_compressed(os.path.join(out, "trec_eval_step.npz"),
+                        **{f"{n}__{k}": v for n, c in cases.items() for k, v in c.items()})
+    return list(cases)
+
+
+def gen_schema(out, resolve_fields, FieldType):
+    d = {}
+    for ds in ["mag", "prime", "amazon"]:
+        for spec in ["all_dense", "all_sparse", "all_dense,all_sparse", "single_dense"]:
+            fi = resolve_fields(spec, ds)
+            d[f"{ds}|{spec}"] = [
+                dict(key=k, name=f.name, type=f.field_type.name, max_seq_length=f.max_seq_length, dataset=f.dataset)
+                for k, f in fi.items()
+            ]
+    d["amazon|title_dense,brand_dense"] = [
+        dict(key=k, name=f.name, type=f.field_type.name, max_seq_length=f.max_seq_length, dataset=f.dataset)
+        for k, f in resolve_fields("title_dense,brand_dense", "data/amazon").items()
+    ]
+    # "." -> " " replacement (schema.py:110)
+    d["prime|off-label.use_dense"] = [
+        dict(key=k, name=f.name, type=f.field_type.name, max_seq_length=f.max_seq_length, dataset=f.dataset)
+        for k, f in resolve_fields("off-label.use_dense,name_dense", "prime").items()
+    ]
+    errs = {}
+    try:
+        resolve_fields("all_dense", "nosuchdataset")
+    except NotImplementedError as e:
+        errs["bad_dataset"] = "NotImplementedError"
+    try:
+        resolve_fields("nosuchfield_dense", "mag")
+    except ValueError as e:
+        errs["bad_field"] = "ValueError"
+    d["errors"] = errs
+    with open(os.path.join(out, "schema.json"), "w") as f:
+        json.dump(d, f, indent=1, sort_keys=True)
+
+
+def gen_trec(out, trec):
+    d = {}
+    q = trec.QRes(query_id="q1", doc_id="d7", sim=float(np.float32(12.3456789)))
+    d["qres_str"] = str(q)
+    d["qres_roundtrip"] = str(trec.QRes.from_str(str(q)))
+    r = trec.QRels("q1", "d7", 1.0)
+    d["qrels_str"] = str(r)
+    d["qrels_roundtrip"] = str(trec.QRels.from_str(str(r)))
+    sample = "num_q\tall\t3\nmap\tall\t0.1234\nrecall_20\tall\t0.5000\nrunid\tall\t0\n"
+    d["parse_sample_in"] = sample
+    d["parse_sample_out"] = trec.parse_trec_eval_output(sample)
+    # read_corpus on a small TSV
+    import tempfile
+    rows = ['1\t{"title": "A", "n": 3}', "2\tnot json\textra", "3"]
+    with tempfile.NamedTemporaryFile("w", suffix=".tsv", delete=False) as f:
+        f.write("\n".join(rows) + "\n")
+        path = f.name
+    d["read_corpus_in"] = rows
+    d["read_corpus_out"] = [[a, b] for a, b in trec.read_corpus(path)]
+    os.unlink(path)
+    with open(os.path.join(out, "trec.json"), "w") as f:
+        json.dump(d, f, indent=1, sort_keys=True)
+
+
+def gen_format(out, format_documents):
+    docs = {
+        "amazon": [
+            ("a1", {"title": "Red shoe", "brand": "Acme", "feature": ["light", "durable"], "description": ["nice", "shoe"],
+                    "also_buy": ["B2", "B3"], "review": [{"summary": "good", "reviewText": "I like it"}],
+                    "qa": [{"question": "size?", "answer": "42"}], "price": 3.5}),
+            ("a2", {"title": "Blue hat"}),
+            ("a3", "plain string doc"),
+        ],
+        "mag": [
+            ("m1", {"title": "Paper", "abstract": "We study.", "author___affiliated_with___institution": ["MIT", "CMU"],
+                    "paper___cites___paper": ["P1", "P2"], "paper___has_topic___field_of_study": ["IR"]}),
+            ("m2", {"title": "Other"}),
+        ],
+        "prime": [
+            ("p1", {"name": "aspirin", "type": "drug", "source": "DB", "details": {"desc": "painkiller", "half_life": 3},
+                    "interacts with": {"gene/protein": ["A", "B"]}, "side effect": {"effect/phenotype": ["nausea"]}}),
+            ("p2", {"name": "x"}),
+        ],
+    }
+    fields = {
+        "amazon": ["title", "brand", "feature", "description", "also_buy", "also_view", "review", "qa"],
+        "mag": ["title", "abstract", "author___affiliated_with___institution", "paper___cites___paper",
+                "paper___has_topic___field_of_study"],
+        "prime": ["name", "type", "source", "details", "interacts with", "side effect", "carrier"],
+    }
+    res = {}
+    for ds, corpus in docs.items():
+        for fld in fields[ds]:
+            try:
+                r = format_documents(corpus, fld, ds)
+                res[f"{ds}|{fld}"] = [[a, b] for a, b in r]
+            except Exception as e:  # record the behaviour, whatever it is
+                res[f"{ds}|{fld}"] = {"raises": type(e).__name__}
+    with open(os.path.join(out, "format_documents.json"), "w") as f:
+        json.dump({"docs": docs, "out": res}, f, indent=1, sort_keys=True)
+
+
+def gen_memmap(out, MemoryMapDict):
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "title.npy")
+        open(p, "w").close()
+        keys = ["a", "b", "c"]
+        m = MemoryMapDict(p, keys, (3, 4))
+        m["b"] = np.array([1, 2, 3, 4], dtype=np.float32)
+        m["c"] = np.array([5, 6, 7, 8], dtype=np.float32)
+        m.close()
+        raw = open(p, "rb").read()
+        d = dict(size=len(raw), raw_hex=raw.hex(), len=len(m), contains_b=("b" in m), contains_z=("z" in m),
+                 iter=list(iter(m)), b=m["b"].tolist())
+    with open(os.path.join(out, "memmap.json"), "w") as f:
+        json.dump(d, f, indent=1, sort_keys=True)
+
+
+def gen_cli(out):
+    import importlib
+    d = {}
+    for name in ["train", "mask_fields"]:
+        m = importlib.import_module(f"mfar.commands.{name}")
+        sig = inspect.signature(m.main)
+        params = []
+        for p in sig.parameters.values():
+            default = None if p.default is inspect._empty else p.default
+            params.append(dict(name=p.name, kind=p.kind.name, required=(p.default is inspect._empty),
+                               default=default if isinstance(default, (int, float, str, bool, type(None))) else repr(default)))
+        d[name] = params
+    with open(os.path.join(out, "cli_signatures.json"), "w") as f:
+        json.dump(d, f, indent=1, sort_keys=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    args = ap.parse_args()
+    out = os.path.abspath(args.out)
+    os.makedirs(out, exist_ok=True)
+    if not os.path.isdir(REF):
+        raise SystemExit("reference not present; goldens can only be regenerated in the authoring container")
+    _install_stubs()
+    sys.path.insert(0, REF)
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+
+    from mfar.data.index import DenseFlatIndex
+    from mfar.modeling.weighting import LinearWeights
+    from mfar.data.schema import resolve_fields
+    from mfar.data.typedef import FieldType, Query
+    from mfar.data import trec
+    from mfar.data.format import format_documents
+    from mfar.data.util import MemoryMapDict
+    from mfar.modeling import contrastive
+
+    print("retrieve_batch:", gen_retrieve(out, DenseFlatIndex))
+    gen_score_batch(out, DenseFlatIndex)
+    gen_linear_weights(out, LinearWeights)
+    print("trec_eval_step:", gen_trec_eval_step(out, DenseFlatIndex, LinearWeights, contrastive, FieldType, Query))
+    gen_schema(out, resolve_fields, FieldType)
+    gen_trec(out, trec)
+    gen_format(out, format_documents)
+    gen_memmap(out, MemoryMapDict)
+    try:
+        gen_cli(out)
+    except Exception as e:
+        print("cli signature dump failed:", repr(e))
+    meta = dict(torch=torch.__version__, numpy=np.__version__,
+                note="generated by tools/gen_golden.py from the reference snapshot at /root/reference (2025-05-09)")
+    with open(os.path.join(out, "META.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    for fn in sorted(os.listdir(out)):
+        print(f"{fn:32s} {os.path.getsize(os.path.join(out, fn)):>10d} B")
+
+
+if __name__ == "__main__":
+    main()
