@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec of the mFAR dense multi-field scorer on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W)
+
+Workload (config.workload): the corpus BASELINE.json's metric is quoted on -- 1,000,000 docs x 8 dense fields x 768-d
+fp32, synthetic and STaRK-amazon shaped (mfar/synth.py) -- resident in HBM as the tiled slab, row-sharded over the N
+ranks exactly like the reference shards its corpus encode (reference mfar/modeling/contrastive.py:470).  One step =
+one pass of the hot path over one batch of 64 query embeddings (reference default dev_batch_size, train.py:45):
+per-field exhaustive top-100 -> candidate union -> re-score -> mask -> query-conditioned field-weight softmax ->
+top-100, i.e. RetrievalTrainingModule.trec_eval_step (contrastive.py:669-704) with the encoder forward excluded
+(query embeddings are inputs, already in HBM).  N > 1: per-shard payloads are exchanged with ONE RCCL all-gather and
+merged on every rank.  The corpus is fixed while N grows: strong scaling.
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (stage 1, fp32 MFMA bound) from its
+algorithmic flops (2 * D_local * F * E * 64 per launch) and its HIP-event duration measured on the launch stream.
+`cpu_baseline` times the oracle's torch port of the reference algorithm (same torch ops as the reference's CPU path)
+on a bounded row sample of the same corpus, on this box's host cores (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "multifield-adaptive-retrieval_amd"))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--docs", type=int, default=1_000_000)
+    ap.add_argument("--fields", type=int, default=8)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--wgs-per-cu", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-docs", type=int, default=100_000)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    N = world
+    dist = None
+    if N > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    from mfar import synth
+    from mfar.data import index as idxmod
+
+    D, F, E, Q = args.docs, args.fields, args.dim, args.batch
+    K1 = K2 = 100
+    n_q_total = max(4096, (args.steps + args.warmup) * Q)
+    t_build = time.time()
+    corpus = synth.SyntheticCorpus(D, F, E, n_queries=n_q_total, seed=0xDEADBEEF, device=str(dev))
+    row0, row1 = D * rank // N, D * (rank + 1) // N          # contrastive.py:470
+    ix = corpus.build_index(idxmod, row0=row0, n=row1 - row0)
+    if args.wgs_per_cu:
+        ix.set_wgs_per_cu(args.wgs_per_cu)
+    t_build = time.time() - t_build
+    W = corpus.W
+    mask = torch.ones(F, device=dev)
+
+    out = dict(ids=torch.empty(Q, K2, dtype=torch.int64, device=dev), scores=torch.empty(Q, K2, device=dev),
+               n_valid=torch.empty(Q, dtype=torch.int32, device=dev))
+    if N > 1:
+        pbytes = ix.payload_bytes(Q, K1)
+        payload = torch.empty(pbytes, dtype=torch.uint8, device=dev)
+        gathered = torch.empty(N * pbytes, dtype=torch.uint8, device=dev)
+
+    def step(i):
+        q = corpus.queries(i * Q, Q)
+        if N == 1:
+            return ix.search(q, W, mask, k1=K1, k2=K2, sentinel=True, out=out)
+        ix.search_local(q, k1=K1, sentinel=True, payload=payload)
+        dist.all_gather_into_tensor(gathered, payload)
+        return idxmod.merge_payloads(gathered, N, q, W, mask, n_fields=F, k1=K1, k2=K2, sentinel=True, device=local_rank)
+
+    results = []
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if N > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ix.set_timing(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        r = step(args.warmup + i)
+        results.append((r["ids"].clone(), r["n_valid"].clone()))
+    torch.cuda.synchronize()
+    if N > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    s1_ms, s1_n = ix.stage1_timing()
+    ix.set_timing(False)
+    if N > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # Recall@20 against the synthetic qrels (quality gate named by the metric)
+        rec = []
+        for i, (ids, nv) in enumerate(results):
+            ids = ids.cpu().numpy()
+            rel = corpus.qrels((args.warmup + i) * Q, Q)
+            for j in range(Q):
+                rec.append(len(set(ids[j, :20].tolist()) & rel[j]) / len(rel[j]))
+        recall20 = float(np.mean(rec))
+        qps = args.steps * Q / dt
+        s1_avg_ms = s1_ms / max(1, s1_n)
+        flops_per_launch = 2.0 * (row1 - row0) * F * E * 64      # algorithmic: 2*D*F*E per query x 64 queries
+        bytes_per_launch = float(row1 - row0) * F * E * 4        # slab read once per batch
+        achieved_tf = flops_per_launch / (s1_avg_ms * 1e-3) / 1e12 if s1_avg_ms > 0 else 0.0
+        line = {
+            "metric": "queries/sec (whole node) at Recall@20 parity, 1M-doc x 8-field x 768d corpus",
+            "value": qps, "unit": "queries/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic STaRK-amazon-shaped corpus, {D} docs x {F} dense fields x {E}d fp32, "
+                                   f"row-sharded over {N} GPU(s); two-stage scorer k1=k2=100, zero-sentinel mode",
+                       "docs": D, "fields": F, "dim": E, "query_batch": Q, "k1": K1, "k2": K2,
+                       "parallelism": f"row-shard x{N} + RCCL all-gather merge" if N > 1 else "single shard"},
+            "recall_at_20": recall20,
+            "index_build_s": t_build,
+            "roofline": {"bound": "mfma", "kernel": "mfar_stage1_kernel", "achieved": achieved_tf,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None, "avg_launch_ms": s1_avg_ms, "launches": s1_n,
+                         "algorithmic_flops_per_launch": flops_per_launch,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "hbm_GBps_algorithmic": bytes_per_launch / (s1_avg_ms * 1e-3) / 1e9 if s1_avg_ms > 0 else 0.0,
+                         "hbm_frac_of_8TBps": bytes_per_launch / (s1_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if s1_avg_ms > 0 else 0.0},
+        }
+        if N == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(corpus, ix, idxmod, args, np, torch)
+        print(json.dumps(line), flush=True)
+    if N > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(corpus, ix, idxmod, args, np, torch):
+    """The reference CPU path, restated (oracle torch port = same torch ops as index.py:181-232 + weighting.py:17-29 +
+    contrastive.py:669-704), on the first `cpu_sample_docs` rows of the same corpus, all host cores.  The oracle is
+    only the thing timed/checked here, never part of the GPU path."""
+    from oracle import mfar_oracle as O
+    Ds = min(args.cpu_sample_docs, ix.n_rows)
+    F, E, Q = ix.n_fields, ix.dim, args.batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    slab = np.empty((F, Ds, E), dtype=np.float32)
+    for f in range(F):
+        ix.read_rows(f, 0, Ds, out=slab[f])
+    W = corpus.W.cpu().numpy()
+    mask = np.ones(F, dtype=np.float32)
+    # GPU result on the same sample, for the parity gate
+    sub = idxmod.MultiFieldIndex(Ds, F, E, device=ix.device)
+    for f in range(F):
+        sub.write_rows(f, 0, slab[f])
+    n_batches, t_used, match = 0, 0.0, []
+    while t_used < 12.0 and n_batches < 50:
+        q = corpus.queries(n_batches * Q, Q).cpu().numpy()
+        t0 = time.perf_counter()
+        ci, cs = O.ref_two_stage(slab, q, W, mask)
+        t_used += time.perf_counter() - t0
+        g = sub.search(q, W, mask)
+        match.append(float(np.mean([np.array_equal(g["ids"][i, :20], ci[i, :20]) for i in range(Q)])))
+        n_batches += 1
+    sub.close()
+    qps_sample = n_batches * Q / t_used
+    return {"value": qps_sample * Ds / corpus.D, "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"{n_batches} batches of {Q} queries over the first {Ds} docs x {F} fields x {E}d of the same corpus "
+                      f"({qps_sample:.1f} q/s on the sample, scaled by {Ds}/{corpus.D} to the full corpus; work is linear in docs)",
+            "top20_id_match_vs_gpu": float(np.mean(match))}
+
+
+if __name__ == "__main__":
+    main()

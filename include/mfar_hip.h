@@ -1,0 +1,142 @@
+/*
+ * mfar_hip.h -- C ABI of libmfar_hip.so: the MI355X (gfx950) implementation of mFAR's dense multi-field
+ * scoring path.  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * The reference (microsoft/multifield-adaptive-retrieval, pure Python) has no FFI for this path: the seam is
+ * ordinary method calls.  Each entry point below names the reference interface it stands behind
+ * (file:line relative to the reference root).  The Python classes in
+ * multifield-adaptive-retrieval_amd/mfar/ keep the reference's names and signatures and call these via ctypes;
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns MFAR_OK (0) or a negative MFAR_ERR_* code and never throws;
+ *     mfar_last_error() returns a thread-local description of the last failure on this thread.
+ *   - `on_device` != 0: all data pointers of that call are device pointers on the index's device and the work
+ *     is enqueued on `stream` (a hipStream_t, may be NULL = default stream) without host synchronisation;
+ *     `on_device` == 0: pointers are host pointers, the call copies in/out and synchronises before returning.
+ *   - document ids are GLOBAL row numbers (row_offset + local row) = line order of the corpus TSV
+ *     (contrastive.py:247-248, modeling/util.py:80-81); they must fit 32 bits (row_offset + n_rows < 2^32-1).
+ *   - ordering everywhere: (score descending, doc id ascending)  -- the canonical tie-break; the reference's
+ *     own tie order is unspecified (unstable torch.topk, hash-ordered set: contrastive.py:679,696).
+ *   - calls on one handle must be serialised by the caller (one handle per process per GPU).
+ */
+#ifndef MFAR_HIP_H
+#define MFAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFAR_OK 0
+#define MFAR_ERR_INVALID (-1)     /* bad argument / shape */
+#define MFAR_ERR_HIP (-2)         /* a HIP runtime call failed (no device, launch failure, ...) */
+#define MFAR_ERR_NOMEM (-3)       /* device or host allocation failed */
+#define MFAR_ERR_UNSUPPORTED (-4) /* valid request this build does not implement */
+
+#define MFAR_DTYPE_F32 0
+#define MFAR_DTYPE_BF16 1
+
+#define MFAR_MAX_K 128     /* top-k depth supported by the selection kernels (the reference hard-codes 100) */
+#define MFAR_MAX_FIELDS 32 /* prime = 22, amazon = 8, mag = 5 (schema.py:11-53) */
+
+typedef struct mfar_index mfar_index;
+
+/* library / device probes (no reference counterpart) */
+int mfar_version(void);
+const char* mfar_last_error(void);
+int mfar_device_count(int* n_out);
+
+/*
+ * The on-HBM sharded index: replaces the per-field float32 np.memmap files `{temp_dir}/{field}.npy`
+ * (MemoryMapDict, data/util.py:28-59) and the DenseFlatIndex objects built over them
+ * (read_and_create_indices, modeling/util.py:73-108).  One handle holds rows
+ * [row_offset, row_offset + n_rows_local) of every field -- the same row split the reference uses for
+ * encoding, corpus[n*rank//ws : n*(rank+1)//ws] (contrastive.py:470).
+ * dim must be a multiple of 16; n_fields <= MFAR_MAX_FIELDS.  Rows start zero-filled.
+ */
+int mfar_index_create(mfar_index** out, int device, int64_t n_rows_local, int64_t row_offset, int n_fields, int dim,
+                      int dtype);
+void mfar_index_destroy(mfar_index* idx);
+int mfar_index_info(const mfar_index* idx, int64_t* n_rows_local, int64_t* row_offset, int* n_fields, int* dim,
+                    int* dtype, int64_t* slab_bytes);
+
+/*
+ * Write n row-major fp32 vectors src[n, dim] into field `field`, local rows [local_row0, local_row0 + n).
+ * Replaces MemoryMapDict.__setitem__ (data/util.py:40-41) as driven by on_eval_start (contrastive.py:482-490)
+ * and the external re-assignment of DenseFlatIndex.vectors (contrastive.py:494).
+ */
+int mfar_index_write_rows(mfar_index* idx, int field, int64_t local_row0, int64_t n, const float* src, int on_device,
+                          void* stream);
+/* Read rows back as row-major fp32 == the reference memmap layout (raw [D,E] float32, data/util.py:35). */
+int mfar_index_read_rows(mfar_index* idx, int field, int64_t local_row0, int64_t n, float* dst, int on_device,
+                         void* stream);
+
+/*
+ * Stage 1 == DenseFlatIndex.retrieve_batch (data/index.py:181-222) for ALL fields in one pass
+ * (the loop at contrastive.py:672-674): per (query, field) exhaustive top-k over the shard's rows.
+ *   q            [Q, dim] fp32 query embeddings (index.py:184-185 ndarray branch)
+ *   sentinel     != 0: lists are seeded with k x (doc 0, score 0.0) as index.py:192-193 does, so only strictly
+ *                positive scores enter and short lists are padded with (0, 0.0); == 0: no seed, padding (-1,-inf)
+ *   field_ids    [Q, n_fields, k] int64 global ids, field_scores [Q, n_fields, k] fp32, canonical order
+ */
+int mfar_retrieve_fields(mfar_index* idx, const float* q, int Q, int k, int sentinel, int64_t* field_ids,
+                         float* field_scores, int on_device, void* stream);
+
+/*
+ * Stage 2 == DenseFlatIndex.score_batch (data/index.py:227-232) for all fields (contrastive.py:681-683):
+ * out[Q, C, n_fields] = <q_i, slab[f, cand[i,c]]>.  cand [Q, C] int64 global ids; ids outside this shard
+ * (or < 0) produce NaN (the reference raises KeyError for unknown keys -- the Python wrapper keeps that).
+ */
+int mfar_score_candidates(mfar_index* idx, const float* q, int Q, const int64_t* cand, int C, float* out,
+                          int on_device, void* stream);
+
+/*
+ * Mixer == mask (contrastive.py:686) + LinearWeights.forward (modeling/weighting.py:17-29) + topk (contrastive.py:696).
+ *   cand_scores [Q, C, F], cand_ids [Q, C] (int64, < 0 = empty slot), n_cand [Q] or NULL (= C everywhere)
+ *   q [Q, E]; W [E, F] when query_cond (weight = q @ W) else [F] (weighting.py:24-27); mask [F] or NULL
+ *   ids/scores [Q, k]; n_valid [Q] = min(#candidates, k) (the reference's topk raises when fewer than k
+ *   candidates exist; rows past n_valid are (-1, -inf)).   C <= 4096, F <= MFAR_MAX_FIELDS.
+ */
+int mfar_mix_topk(int device, const float* cand_scores, const int64_t* cand_ids, const int32_t* n_cand, const float* q,
+                  const float* W, int query_cond, const float* mask, int Q, int C, int F, int E, int k, int64_t* ids,
+                  float* scores, int32_t* n_valid, int on_device, void* stream);
+
+/*
+ * The whole per-batch scorer == RetrievalTrainingModule.trec_eval_step (modeling/contrastive.py:669-704) with one
+ * embedding per query: stage 1 -> union of ids (:678-679) -> stage 2 -> mask -> field-weight softmax -> top-k2.
+ * Optional outputs (may be NULL): field_ids/field_scores [Q, F, k1] and n_cand [Q].
+ * Requires n_fields * k1 <= 4096.
+ */
+int mfar_search_two_stage(mfar_index* idx, const float* q, int Q, const float* W, int query_cond, const float* mask,
+                          int k1, int k2, int sentinel, int64_t* ids, float* scores, int32_t* n_valid,
+                          int64_t* field_ids, float* field_scores, int32_t* n_cand, int on_device, void* stream);
+
+/*
+ * Multi-GPU (row shards + one exchange, replaces the file-based exchange of contrastive.py:491-494,519-536):
+ *   mfar_search_local  : stages 1+2 on this shard -> a fixed-size payload (mfar_payload_bytes) holding the shard's
+ *                        per-field lists and the F-score vector of every local candidate;
+ *   mfar_merge_payloads: given the n_shards payloads (all-gathered by the caller over RCCL), merge per-field lists,
+ *                        form the global candidate union, mix and take the final top-k2.  Every rank computes the
+ *                        same answer.  With n_shards == 1 the result equals mfar_search_two_stage.
+ */
+int64_t mfar_payload_bytes(int Q, int n_fields, int k1);
+int mfar_search_local(mfar_index* idx, const float* q, int Q, int k1, int sentinel, void* payload, int on_device,
+                      void* stream);
+int mfar_merge_payloads(int device, const void* payloads, int n_shards, const float* q, int Q, int E, const float* W,
+                        int query_cond, const float* mask, int n_fields, int k1, int k2, int sentinel, int64_t* ids,
+                        float* scores, int32_t* n_valid, int on_device, void* stream);
+
+/* Instrumentation used by bench.py: when enabled, every stage-1 kernel launch on this handle is bracketed by HIP
+ * events recorded on the stream it is launched on.  mfar_set_timing(idx, 1) enables and resets the counters;
+ * mfar_stage1_timing() synchronises the recorded events and returns their summed duration and the launch count. */
+int mfar_set_timing(mfar_index* idx, int enable);
+int mfar_stage1_timing(mfar_index* idx, double* total_ms_out, int* n_launches_out);
+/* Tunable: workgroups per CU for the stage-1 kernel (default 2). */
+int mfar_set_wgs_per_cu(mfar_index* idx, int wgs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFAR_HIP_H */

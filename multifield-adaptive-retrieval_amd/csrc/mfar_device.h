@@ -1,0 +1,133 @@
+// mfar_device.h -- device-side helpers shared by the gfx950 kernels (wave = 64 lanes).
+//
+// Arithmetic contract (mirrored bit for bit by oracle/mfar_oracle.c, which is test infrastructure):
+//   * a query.doc score is ONE fp32 fma chain over the embedding dims; inside every aligned group of 8 dims the
+//     visiting order is 0,4,1,5,2,6,3,7 -- the order in which v_mfma_f32_32x32x2_f32 consumes the fragments
+//     staged by the stage-1 kernel (lanes 0-31 hold dims 8g..8g+3, lanes 32-63 hold 8g+4..8g+7).
+//   * ordering is (score desc, doc id asc): keys are (orderable(score) << 32) | (0xFFFFFFFF - id).
+//   * mfar_exp() is a fixed fma/mul polynomial so the softmax head is reproducible on the host.
+// Build with -ffp-contract=off: the only fusions are the explicit __builtin_fmaf calls.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mfar_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define MFAR_INVALID_ID 0xFFFFFFFFu
+
+// monotone float -> uint map (-0.0 folded onto +0.0 so that float '==' and key '==' agree)
+__device__ __forceinline__ u32 f2ord(float s) {
+    u32 u = __float_as_uint(s);
+    if (s == 0.0f) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(u32 o) {
+    u32 u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ u64 make_key(float s, u32 id) { return ((u64)f2ord(s) << 32) | (u64)(0xFFFFFFFFu - id); }
+__device__ __forceinline__ float key_score(u64 k) { return ord2f((u32)(k >> 32)); }
+__device__ __forceinline__ u32 key_id(u64 k) { return 0xFFFFFFFFu - (u32)(k & 0xFFFFFFFFull); }
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+// number of set bits of `m` below this lane
+__device__ __forceinline__ int mbcnt(u64 m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+}
+
+// Deterministic exp(x) for x <= 0 (same operation sequence as mfar_oracle_exp in the oracle).
+__device__ __forceinline__ float mfar_exp(float x) {
+    if (!(x > -80.0f)) return 0.0f;
+    if (x > 0.0f) x = 0.0f;
+    const float t = x * 1.44269504088896341f;
+    const float n = __builtin_rintf(t);
+    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    r = __builtin_fmaf(n, -1.42860682030941723e-6f, r);
+    float p = 1.0f / 5040.0f;
+    p = __builtin_fmaf(p, r, 1.0f / 720.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 120.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 24.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 6.0f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    const float sc = __uint_as_float((u32)((int)n + 127) << 23);
+    return p * sc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Tiled slab layout ("LDS-image order").  One field of the index is stored as
+//     [n_blk 64-row blocks][n_steps = E/16][64 rows][16 floats]
+// so that the 4 KB a wave needs for one k-step of its 64 rows is ONE contiguous, already bank-swizzled piece:
+// a wave streams its block with four linear 1 KB global_load_lds_dwordx4 per step, and HBM sees purely sequential
+// reads.  Inside a 4 KB tile, the 16-byte granule at (row rr, position p) holds dims 16*step + 4*c .. +3 with
+// c = p ^ ((rr >> 2) & 3): ds_read_b128 of one k-chunk over 16 consecutive rows then touches all 64 banks once.
+// ---------------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ size_t tiled_offset(int64_t n_steps, int64_t row, int e) {
+    const int64_t blk = row >> 6;
+    const int rr = (int)(row & 63);
+    const int step = e >> 4;
+    const int c = (e >> 2) & 3;
+    const int p = c ^ ((rr >> 2) & 3);
+    return (size_t)((blk * n_steps + step) * 1024 + rr * 16 + p * 4 + (e & 3));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Block-level exact top-k of n unique 64-bit keys held in LDS (256 threads).  Result: sel[0..m) sorted descending,
+// m = min(n, k) returned.  `red` is an int[16] LDS scratch, `sel` u64[MFAR_MAX_K] LDS.
+// Radix descent on the key bits (most significant first) finds the k-th largest key, survivors are gathered and
+// ranked by counting.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_count_ge(const u64* keys, int n, u64 cand, volatile int* red, int parity) {
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) c += (keys[i] >= cand) ? 1 : 0;
+    // wave sum
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    const int nw = (blockDim.x + 63) >> 6;
+    if (lane_id() == 0) red[parity * 8 + (threadIdx.x >> 6)] = c;
+    __syncthreads();
+    int tot = 0;
+    for (int w = 0; w < nw; ++w) tot += red[parity * 8 + w];
+    return tot;
+}
+
+__device__ __forceinline__ int block_topk_sorted(const u64* keys, int n, int k, u64* sel, u64* sel_sorted, int* red) {
+    __syncthreads();
+    int m;
+    u64 T = 0;
+    if (n > k) {
+        int parity = 0;
+        for (int bit = 63; bit >= 0; --bit) {
+            const u64 cand = T | (1ull << bit);
+            const int tot = block_count_ge(keys, n, cand, red, parity);
+            parity ^= 1;
+            if (tot >= k) T = cand;
+        }
+        m = k;
+    } else {
+        m = n;
+    }
+    if (threadIdx.x == 0) red[16] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const u64 key = keys[i];
+        if (key >= T) {
+            const int pos = atomicAdd(&red[16], 1);
+            if (pos < k) sel[pos] = key;
+        }
+    }
+    __syncthreads();
+    // rank by counting (keys are unique)
+    if ((int)threadIdx.x < m) {
+        const u64 mine = sel[threadIdx.x];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += (sel[j] > mine) ? 1 : 0;
+        sel_sorted[rank] = mine;
+    }
+    __syncthreads();
+    return m;
+}

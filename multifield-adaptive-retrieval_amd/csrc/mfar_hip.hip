@@ -1,0 +1,720 @@
+// mfar_hip.hip -- host side of libmfar_hip.so: the C ABI declared in include/mfar_hip.h.
+// gfx950 only.  Every entry point returns an error code; nothing throws across the ABI.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "mfar_hip.h"
+#include "mfar_select.h"
+
+#define MFAR_VERSION 100
+#define PAYLOAD_MAGIC 0x6d464152 /* "mFAR" */
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(MFAR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+    } while (0)
+#define RETCHK(expr)            \
+    do {                        \
+        int rc_ = (expr);       \
+        if (rc_ != MFAR_OK) return rc_; \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return MFAR_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + (bytes >> 3) + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(MFAR_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+        }
+        cap = want;
+        return MFAR_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T* as() const { return (T*)p; }
+};
+
+// scratch shared by the handle-less entry points (mfar_mix_topk, mfar_merge_payloads): one per device
+struct DevCtx {
+    std::mutex mu;
+    DevBuf in[8], out[4], lists_ids, lists_sc, cand, ncand, x;
+};
+static DevCtx g_ctx[16];
+static bool g_attr_done[16] = {false};
+
+struct mfar_index {
+    int device = 0;
+    int64_t n_rows = 0, row_offset = 0;
+    int F = 0, E = 0, dtype = 0;
+    int64_t n_blk = 0;  // 64-row blocks per field, multiple of 4
+    int n_steps = 0;
+    float* slab = nullptr;
+    size_t slab_bytes = 0;
+    long long field_stride = 0;  // floats
+    int n_cu = 256;
+    int wgs_per_cu = 2;
+    DevBuf qt, lists, list_cnt, fid, fsc, cand, ncand, x, in[8], out[8];
+    bool timing = false;
+    std::vector<hipEvent_t> ev;  // start/stop pairs
+    int ev_n = 0;
+};
+
+static int set_kernel_attrs(int device) {
+    if (device < 0 || device >= 16) return fail(MFAR_ERR_INVALID, "device index out of range");
+    if (g_attr_done[device]) return MFAR_OK;
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_lists_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_shards_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_mix_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    g_attr_done[device] = true;
+    return MFAR_OK;
+}
+
+extern "C" int mfar_version(void) { return MFAR_VERSION; }
+extern "C" const char* mfar_last_error(void) { return g_err.c_str(); }
+extern "C" int mfar_device_count(int* n_out) {
+    if (!n_out) return fail(MFAR_ERR_INVALID, "n_out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *n_out = 0;
+        return fail(MFAR_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *n_out = n;
+    return MFAR_OK;
+}
+
+extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_local, int64_t row_offset, int n_fields,
+                                 int dim, int dtype) {
+    if (!out) return fail(MFAR_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_rows_local < 0 || row_offset < 0) return fail(MFAR_ERR_INVALID, "negative row count / offset");
+    if (row_offset + n_rows_local >= 0xFFFFFFFELL) return fail(MFAR_ERR_INVALID, "doc ids must fit in 32 bits");
+    if (n_fields <= 0 || n_fields > MFAR_MAX_FIELDS) return fail(MFAR_ERR_INVALID, "n_fields must be in [1, 32]");
+    if (dim <= 0 || (dim & 15)) return fail(MFAR_ERR_INVALID, "dim must be a positive multiple of 16");
+    if (dtype == MFAR_DTYPE_BF16) return fail(MFAR_ERR_UNSUPPORTED, "bf16 slab is not implemented in this build");
+    if (dtype != MFAR_DTYPE_F32) return fail(MFAR_ERR_INVALID, "unknown dtype");
+    int ndev = 0;
+    RETCHK(mfar_device_count(&ndev));
+    if (device < 0 || device >= ndev) return fail(MFAR_ERR_INVALID, "no such device");
+    HIPCHK(hipSetDevice(device));
+    RETCHK(set_kernel_attrs(device));
+    mfar_index* idx = new (std::nothrow) mfar_index();
+    if (!idx) return fail(MFAR_ERR_NOMEM, "host allocation failed");
+    idx->device = device;
+    idx->n_rows = n_rows_local;
+    idx->row_offset = row_offset;
+    idx->F = n_fields;
+    idx->E = dim;
+    idx->dtype = dtype;
+    idx->n_steps = dim / 16;
+    int64_t n_blk = (n_rows_local + 63) / 64;
+    n_blk = ((n_blk + 3) / 4) * 4;
+    if (n_blk == 0) n_blk = 4;
+    idx->n_blk = n_blk;
+    idx->field_stride = (long long)n_blk * 64 * dim;
+    idx->slab_bytes = (size_t)idx->field_stride * 4 * n_fields;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) idx->n_cu = prop.multiProcessorCount;
+    hipError_t e = hipMalloc((void**)&idx->slab, idx->slab_bytes);
+    if (e != hipSuccess) {
+        delete idx;
+        return fail(MFAR_ERR_NOMEM, std::string("hipMalloc(slab ") + std::to_string(idx->slab_bytes) + " B): " + hipGetErrorString(e));
+    }
+    e = hipMemset(idx->slab, 0, idx->slab_bytes);
+    if (e != hipSuccess) {
+        (void)hipFree(idx->slab);
+        delete idx;
+        return fail(MFAR_ERR_HIP, std::string("hipMemset(slab): ") + hipGetErrorString(e));
+    }
+    *out = idx;
+    return MFAR_OK;
+}
+
+extern "C" void mfar_index_destroy(mfar_index* idx) {
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    (void)hipDeviceSynchronize();
+    for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
+    DevBuf* bufs[] = {&idx->qt, &idx->lists, &idx->list_cnt, &idx->fid, &idx->fsc, &idx->cand, &idx->ncand, &idx->x};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& b : idx->in) b.release();
+    for (auto& b : idx->out) b.release();
+    if (idx->slab) (void)hipFree(idx->slab);
+    delete idx;
+}
+
+extern "C" int mfar_index_info(const mfar_index* idx, int64_t* n_rows_local, int64_t* row_offset, int* n_fields, int* dim,
+                               int* dtype, int64_t* slab_bytes) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    if (n_rows_local) *n_rows_local = idx->n_rows;
+    if (row_offset) *row_offset = idx->row_offset;
+    if (n_fields) *n_fields = idx->F;
+    if (dim) *dim = idx->E;
+    if (dtype) *dtype = idx->dtype;
+    if (slab_bytes) *slab_bytes = (int64_t)idx->slab_bytes;
+    return MFAR_OK;
+}
+
+extern "C" int mfar_set_wgs_per_cu(mfar_index* idx, int wgs) {
+    if (!idx || wgs < 1 || wgs > 8) return fail(MFAR_ERR_INVALID, "wgs must be in [1, 8]");
+    idx->wgs_per_cu = wgs;
+    return MFAR_OK;
+}
+
+extern "C" int mfar_set_timing(mfar_index* idx, int enable) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    HIPCHK(hipSetDevice(idx->device));
+    idx->timing = enable != 0;
+    idx->ev_n = 0;
+    return MFAR_OK;
+}
+
+extern "C" int mfar_stage1_timing(mfar_index* idx, double* total_ms_out, int* n_launches_out) {
+    if (!idx || !total_ms_out || !n_launches_out) return fail(MFAR_ERR_INVALID, "NULL argument");
+    HIPCHK(hipSetDevice(idx->device));
+    double tot = 0;
+    for (int i = 0; i < idx->ev_n; ++i) {
+        float ms = 0;
+        HIPCHK(hipEventSynchronize(idx->ev[2 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&ms, idx->ev[2 * i], idx->ev[2 * i + 1]));
+        tot += ms;
+    }
+    *total_ms_out = tot;
+    *n_launches_out = idx->ev_n;
+    return MFAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ rows in / out
+static int check_rows(const mfar_index* idx, int field, int64_t row0, int64_t n, const void* ptr) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    if (field < 0 || field >= idx->F) return fail(MFAR_ERR_INVALID, "field out of range");
+    if (row0 < 0 || n < 0 || row0 + n > idx->n_rows) return fail(MFAR_ERR_INVALID, "row range outside the shard");
+    if (n > 0 && !ptr) return fail(MFAR_ERR_INVALID, "NULL data pointer");
+    return MFAR_OK;
+}
+
+extern "C" int mfar_index_write_rows(mfar_index* idx, int field, int64_t local_row0, int64_t n, const float* src,
+                                     int on_device, void* stream) {
+    RETCHK(check_rows(idx, field, local_row0, n, src));
+    if (n == 0) return MFAR_OK;
+    HIPCHK(hipSetDevice(idx->device));
+    hipStream_t st = (hipStream_t)stream;
+    float* fbase = idx->slab + (size_t)field * idx->field_stride;
+    const int64_t chunk = on_device ? n : std::min<int64_t>(n, (int64_t)(256u << 20) / (idx->E * 4));
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        const int64_t m = std::min(chunk, n - r0);
+        const float* s = src + (size_t)r0 * idx->E;
+        if (!on_device) {
+            RETCHK(idx->in[0].ensure((size_t)m * idx->E * 4));
+            HIPCHK(hipMemcpyAsync(idx->in[0].p, s, (size_t)m * idx->E * 4, hipMemcpyHostToDevice, st));
+            s = idx->in[0].as<float>();
+        }
+        const long long total = m * (idx->E / 4);
+        mfar_tile_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(s, fbase, local_row0 + r0, m, idx->E);
+        HIPCHK(hipGetLastError());
+        if (!on_device) HIPCHK(hipStreamSynchronize(st));
+    }
+    return MFAR_OK;
+}
+
+extern "C" int mfar_index_read_rows(mfar_index* idx, int field, int64_t local_row0, int64_t n, float* dst, int on_device,
+                                    void* stream) {
+    RETCHK(check_rows(idx, field, local_row0, n, dst));
+    if (n == 0) return MFAR_OK;
+    HIPCHK(hipSetDevice(idx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const float* fbase = idx->slab + (size_t)field * idx->field_stride;
+    const int64_t chunk = on_device ? n : std::min<int64_t>(n, (int64_t)(256u << 20) / (idx->E * 4));
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        const int64_t m = std::min(chunk, n - r0);
+        float* d = dst + (size_t)r0 * idx->E;
+        float* dd = d;
+        if (!on_device) {
+            RETCHK(idx->out[0].ensure((size_t)m * idx->E * 4));
+            dd = idx->out[0].as<float>();
+        }
+        const long long total = m * (idx->E / 4);
+        mfar_untile_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(fbase, dd, local_row0 + r0, m, idx->E);
+        HIPCHK(hipGetLastError());
+        if (!on_device) {
+            HIPCHK(hipMemcpyAsync(d, dd, (size_t)m * idx->E * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+    }
+    return MFAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ staging helpers
+// Bring a host input to the device (or pass a device pointer through).
+template <typename T>
+static int stage_in(DevBuf& buf, const T* src, size_t count, int on_device, hipStream_t st, const T** out) {
+    if (!src || count == 0) {
+        *out = src;
+        return MFAR_OK;
+    }
+    if (on_device) {
+        *out = src;
+        return MFAR_OK;
+    }
+    RETCHK(buf.ensure(count * sizeof(T)));
+    HIPCHK(hipMemcpyAsync(buf.p, src, count * sizeof(T), hipMemcpyHostToDevice, st));
+    *out = buf.as<T>();
+    return MFAR_OK;
+}
+template <typename T>
+static int stage_out(DevBuf& buf, T* dst, size_t count, int on_device, T** out) {
+    if (!dst || count == 0) {
+        *out = dst;
+        return MFAR_OK;
+    }
+    if (on_device) {
+        *out = dst;
+        return MFAR_OK;
+    }
+    RETCHK(buf.ensure(count * sizeof(T)));
+    *out = buf.as<T>();
+    return MFAR_OK;
+}
+template <typename T>
+static int copy_back(T* host_dst, const T* dev_src, size_t count, int on_device, hipStream_t st) {
+    if (on_device || !host_dst || count == 0) return MFAR_OK;
+    HIPCHK(hipMemcpyAsync(host_dst, dev_src, count * sizeof(T), hipMemcpyDeviceToHost, st));
+    return MFAR_OK;
+}
+
+static int check_search_common(const mfar_index* idx, const float* q, int Q, int k) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    if (Q < 0) return fail(MFAR_ERR_INVALID, "Q < 0");
+    if (Q > 0 && !q) return fail(MFAR_ERR_INVALID, "q is NULL");
+    if (k <= 0 || k > MFAR_MAX_K) return fail(MFAR_ERR_INVALID, "k must be in [1, 128]");
+    return MFAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ stage 1
+static int stage1_chunks(const mfar_index* idx) {
+    const int n_tiles = (int)(idx->n_blk / 4);
+    long long target = ((long long)idx->wgs_per_cu * idx->n_cu + idx->F / 2) / idx->F;
+    if (target < 1) target = 1;
+    if (target > 128) target = 128;
+    if (target > n_tiles) target = n_tiles;
+    return (int)target;
+}
+
+// all pointers are device pointers; fid/fsc are [Q, F, k]
+static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentinel, long long* fid, float* fsc, hipStream_t st) {
+    const int n_chunks = stage1_chunks(idx);
+    const int n_tiles = (int)(idx->n_blk / 4);
+    RETCHK(idx->qt.ensure((size_t)idx->n_steps * 4096));
+    RETCHK(idx->lists.ensure((size_t)idx->F * n_chunks * 64 * S1_CAP * sizeof(uint2)));
+    RETCHK(idx->list_cnt.ensure((size_t)idx->F * n_chunks * 64 * sizeof(int)));
+    for (int q0 = 0; q0 < Q; q0 += 64) {
+        const int qt_n = std::min(64, Q - q0);
+        const int total = 64 * (idx->E / 4);
+        mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, idx->qt.as<float>(), q0, Q, idx->E);
+        HIPCHK(hipGetLastError());
+        S1Params p;
+        p.slab = idx->slab;
+        p.qt = idx->qt.as<float>();
+        p.lists = idx->lists.as<uint2>();
+        p.list_cnt = idx->list_cnt.as<int>();
+        p.field_stride = idx->field_stride;
+        p.n_rows = (int)idx->n_rows;
+        p.n_steps = idx->n_steps;
+        p.n_tiles = n_tiles;
+        p.n_chunks = n_chunks;
+        p.Q = qt_n;
+        p.k = k;
+        p.tau0 = sentinel ? 0.0f : -INFINITY;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (idx->timing && idx->ev_n < 4096) {
+            if ((int)idx->ev.size() < 2 * (idx->ev_n + 1)) {
+                hipEvent_t a, b;
+                HIPCHK(hipEventCreate(&a));
+                HIPCHK(hipEventCreate(&b));
+                idx->ev.push_back(a);
+                idx->ev.push_back(b);
+            }
+            e0 = idx->ev[2 * idx->ev_n];
+            e1 = idx->ev[2 * idx->ev_n + 1];
+            idx->ev_n++;
+            HIPCHK(hipEventRecord(e0, st));
+        }
+        mfar_stage1_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1_LDS_BYTES, st>>>(p);
+        HIPCHK(hipGetLastError());
+        if (e1) HIPCHK(hipEventRecord(e1, st));
+        MergeParams m;
+        m.lists = p.lists;
+        m.list_cnt = p.list_cnt;
+        m.out_ids = fid;
+        m.out_scores = fsc;
+        m.row_offset = idx->row_offset;
+        m.n_chunks = n_chunks;
+        m.F = idx->F;
+        m.k = k;
+        m.q0 = q0;
+        m.sentinel = sentinel;
+        mfar_merge_lists_kernel<<<dim3(qt_n * idx->F), dim3(256), SEL_LDS_BYTES(n_chunks * k), st>>>(m);
+        HIPCHK(hipGetLastError());
+    }
+    return MFAR_OK;
+}
+
+extern "C" int mfar_retrieve_fields(mfar_index* idx, const float* q, int Q, int k, int sentinel, int64_t* field_ids,
+                                    float* field_scores, int on_device, void* stream) {
+    RETCHK(check_search_common(idx, q, Q, k));
+    if (Q == 0) return MFAR_OK;
+    if (!field_ids || !field_scores) return fail(MFAR_ERR_INVALID, "output pointer is NULL");
+    HIPCHK(hipSetDevice(idx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nl = (size_t)Q * idx->F * k;
+    const float* qd;
+    long long* fid;
+    float* fsc;
+    RETCHK(stage_in(idx->in[0], q, (size_t)Q * idx->E, on_device, st, &qd));
+    RETCHK(stage_out(idx->out[0], (long long*)field_ids, nl, on_device, &fid));
+    RETCHK(stage_out(idx->out[1], field_scores, nl, on_device, &fsc));
+    RETCHK(run_stage1(idx, qd, Q, k, sentinel, fid, fsc, st));
+    RETCHK(copy_back((long long*)field_ids, fid, nl, on_device, st));
+    RETCHK(copy_back(field_scores, fsc, nl, on_device, st));
+    if (!on_device) HIPCHK(hipStreamSynchronize(st));
+    return MFAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ stage 2
+static int run_score(mfar_index* idx, const float* q, int Q, const long long* cand, const int* ncand, int C, float* x,
+                     hipStream_t st) {
+    ScoreParams p;
+    p.slab = idx->slab;
+    p.field_stride = idx->field_stride;
+    p.q = q;
+    p.cand = cand;
+    p.n_cand = ncand;
+    p.out = x;
+    p.row_offset = idx->row_offset;
+    p.n_rows = (int)idx->n_rows;
+    p.n_steps = idx->n_steps;
+    p.E = idx->E;
+    p.F = idx->F;
+    p.C = C;
+    const unsigned gx = (unsigned)(((size_t)C * idx->F + 255) / 256);
+    if (gx == 0 || Q == 0) return MFAR_OK;
+    mfar_score_candidates_kernel<<<dim3(gx, Q), dim3(256), (size_t)idx->E * 4, st>>>(p);
+    HIPCHK(hipGetLastError());
+    return MFAR_OK;
+}
+
+extern "C" int mfar_score_candidates(mfar_index* idx, const float* q, int Q, const int64_t* cand, int C, float* out,
+                                     int on_device, void* stream) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    if (Q < 0 || C < 0) return fail(MFAR_ERR_INVALID, "negative size");
+    if (Q == 0 || C == 0) return MFAR_OK;
+    if (!q || !cand || !out) return fail(MFAR_ERR_INVALID, "NULL pointer");
+    if (idx->E * 4 > 60 * 1024) return fail(MFAR_ERR_UNSUPPORTED, "dim too large for the stage-2 kernel");
+    HIPCHK(hipSetDevice(idx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const float* qd;
+    const long long* cd;
+    float* od;
+    RETCHK(stage_in(idx->in[0], q, (size_t)Q * idx->E, on_device, st, &qd));
+    RETCHK(stage_in(idx->in[1], (const long long*)cand, (size_t)Q * C, on_device, st, &cd));
+    RETCHK(stage_out(idx->out[0], out, (size_t)Q * C * idx->F, on_device, &od));
+    RETCHK(run_score(idx, qd, Q, cd, nullptr, C, od, st));
+    RETCHK(copy_back(out, od, (size_t)Q * C * idx->F, on_device, st));
+    if (!on_device) HIPCHK(hipStreamSynchronize(st));
+    return MFAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ mixer
+static int run_mix(const float* x, const long long* cand, const int* ncand, const float* q, const float* W, int query_cond,
+                   const float* mask, int Q, int C, int F, int E, int k, long long* ids, float* scores, int* n_valid,
+                   hipStream_t st) {
+    MixParams p;
+    p.x = x;
+    p.cand = cand;
+    p.n_cand = ncand;
+    p.q = q;
+    p.W = W;
+    p.mask = mask;
+    p.ids = ids;
+    p.scores = scores;
+    p.n_valid = n_valid;
+    p.C = C;
+    p.F = F;
+    p.E = E;
+    p.k = k;
+    p.query_cond = query_cond;
+    if (Q == 0) return MFAR_OK;
+    mfar_mix_topk_kernel<<<dim3(Q), dim3(256), MIX_LDS_BYTES, st>>>(p);
+    HIPCHK(hipGetLastError());
+    return MFAR_OK;
+}
+
+static int check_mix(int Q, int C, int F, int E, int k, const float* q, const float* W, int query_cond) {
+    if (Q < 0 || C < 0) return fail(MFAR_ERR_INVALID, "negative size");
+    if (C > 4096) return fail(MFAR_ERR_INVALID, "at most 4096 candidates per query");
+    if (F <= 0 || F > MFAR_MAX_FIELDS) return fail(MFAR_ERR_INVALID, "n_fields must be in [1, 32]");
+    if (k <= 0 || k > MFAR_MAX_K) return fail(MFAR_ERR_INVALID, "k must be in [1, 128]");
+    if (!W) return fail(MFAR_ERR_INVALID, "W is NULL");
+    if (query_cond && (!q || E <= 0)) return fail(MFAR_ERR_INVALID, "query-conditioned weights need q and E");
+    return MFAR_OK;
+}
+
+extern "C" int mfar_mix_topk(int device, const float* cand_scores, const int64_t* cand_ids, const int32_t* n_cand,
+                             const float* q, const float* W, int query_cond, const float* mask, int Q, int C, int F, int E,
+                             int k, int64_t* ids, float* scores, int32_t* n_valid, int on_device, void* stream) {
+    RETCHK(check_mix(Q, C, F, E, k, q, W, query_cond));
+    if (Q == 0) return MFAR_OK;
+    if (!ids || !scores || (C > 0 && (!cand_scores || !cand_ids))) return fail(MFAR_ERR_INVALID, "NULL pointer");
+    int ndev = 0;
+    RETCHK(mfar_device_count(&ndev));
+    if (device < 0 || device >= ndev || device >= 16) return fail(MFAR_ERR_INVALID, "no such device");
+    HIPCHK(hipSetDevice(device));
+    RETCHK(set_kernel_attrs(device));
+    hipStream_t st = (hipStream_t)stream;
+    DevCtx& cx = g_ctx[device];
+    std::unique_lock<std::mutex> lk(cx.mu, std::defer_lock);
+    if (!on_device) lk.lock();
+    const float *xd, *qd, *Wd, *md;
+    const long long* cd;
+    const int* nd;
+    long long* idd;
+    float* scd;
+    int* nvd;
+    RETCHK(stage_in(cx.in[0], cand_scores, (size_t)Q * C * F, on_device, st, &xd));
+    RETCHK(stage_in(cx.in[1], (const long long*)cand_ids, (size_t)Q * C, on_device, st, &cd));
+    RETCHK(stage_in(cx.in[2], (const int*)n_cand, (size_t)Q, on_device, st, &nd));
+    RETCHK(stage_in(cx.in[3], q, query_cond ? (size_t)Q * E : 0, on_device, st, &qd));
+    RETCHK(stage_in(cx.in[4], W, query_cond ? (size_t)E * F : (size_t)F, on_device, st, &Wd));
+    RETCHK(stage_in(cx.in[5], mask, (size_t)F, on_device, st, &md));
+    RETCHK(stage_out(cx.out[0], (long long*)ids, (size_t)Q * k, on_device, &idd));
+    RETCHK(stage_out(cx.out[1], scores, (size_t)Q * k, on_device, &scd));
+    RETCHK(stage_out(cx.out[2], (int*)n_valid, (size_t)Q, on_device, &nvd));
+    RETCHK(run_mix(xd, cd, nd, qd, Wd, query_cond, md, Q, C, F, E, k, idd, scd, nvd, st));
+    RETCHK(copy_back((long long*)ids, idd, (size_t)Q * k, on_device, st));
+    RETCHK(copy_back(scores, scd, (size_t)Q * k, on_device, st));
+    RETCHK(copy_back((int*)n_valid, nvd, (size_t)Q, on_device, st));
+    if (!on_device) HIPCHK(hipStreamSynchronize(st));
+    return MFAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ full scorer
+extern "C" int mfar_search_two_stage(mfar_index* idx, const float* q, int Q, const float* W, int query_cond,
+                                     const float* mask, int k1, int k2, int sentinel, int64_t* ids, float* scores,
+                                     int32_t* n_valid, int64_t* field_ids, float* field_scores, int32_t* n_cand,
+                                     int on_device, void* stream) {
+    RETCHK(check_search_common(idx, q, Q, k1));
+    const int F = idx->F, E = idx->E, C = F * k1;
+    RETCHK(check_mix(Q, C, F, E, k2, q, W, query_cond));
+    if (Q == 0) return MFAR_OK;
+    if (!ids || !scores) return fail(MFAR_ERR_INVALID, "output pointer is NULL");
+    if (E * 4 > 60 * 1024) return fail(MFAR_ERR_UNSUPPORTED, "dim too large for the stage-2 kernel");
+    HIPCHK(hipSetDevice(idx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nl = (size_t)Q * F * k1;
+    const float *qd, *Wd, *md;
+    long long *idd, *fid;
+    float *scd, *fsc;
+    int *nvd, *ncd;
+    RETCHK(stage_in(idx->in[0], q, (size_t)Q * E, on_device, st, &qd));
+    RETCHK(stage_in(idx->in[1], W, query_cond ? (size_t)E * F : (size_t)F, on_device, st, &Wd));
+    RETCHK(stage_in(idx->in[2], mask, (size_t)F, on_device, st, &md));
+    RETCHK(stage_out(idx->out[0], (long long*)ids, (size_t)Q * k2, on_device, &idd));
+    RETCHK(stage_out(idx->out[1], scores, (size_t)Q * k2, on_device, &scd));
+    RETCHK(stage_out(idx->out[2], (int*)n_valid, (size_t)Q, on_device, &nvd));
+    // stage-1 lists: caller's buffers when given on the device, else internal
+    if (field_ids && on_device) fid = (long long*)field_ids;
+    else {
+        RETCHK(idx->fid.ensure(nl * 8));
+        fid = idx->fid.as<long long>();
+    }
+    if (field_scores && on_device) fsc = field_scores;
+    else {
+        RETCHK(idx->fsc.ensure(nl * 4));
+        fsc = idx->fsc.as<float>();
+    }
+    if (n_cand && on_device) ncd = (int*)n_cand;
+    else {
+        RETCHK(idx->ncand.ensure((size_t)Q * 4));
+        ncd = idx->ncand.as<int>();
+    }
+    RETCHK(idx->cand.ensure((size_t)Q * C * 8));
+    RETCHK(idx->x.ensure((size_t)Q * C * F * 4));
+    RETCHK(run_stage1(idx, qd, Q, k1, sentinel, fid, fsc, st));
+    mfar_union_kernel<<<dim3(Q), dim3(256), 0, st>>>(fid, F, k1, idx->cand.as<long long>(), ncd);
+    HIPCHK(hipGetLastError());
+    RETCHK(run_score(idx, qd, Q, idx->cand.as<long long>(), ncd, C, idx->x.as<float>(), st));
+    RETCHK(run_mix(idx->x.as<float>(), idx->cand.as<long long>(), ncd, qd, Wd, query_cond, md, Q, C, F, E, k2, idd, scd, nvd, st));
+    RETCHK(copy_back((long long*)ids, idd, (size_t)Q * k2, on_device, st));
+    RETCHK(copy_back(scores, scd, (size_t)Q * k2, on_device, st));
+    RETCHK(copy_back((int*)n_valid, nvd, (size_t)Q, on_device, st));
+    if (!on_device) {
+        RETCHK(copy_back((long long*)field_ids, fid, nl, 0, st));
+        RETCHK(copy_back(field_scores, fsc, nl, 0, st));
+        RETCHK(copy_back((int*)n_cand, ncd, (size_t)Q, 0, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return MFAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ multi-GPU
+struct PayloadLayout {
+    long long hdr, ids, scores, cand, ncand, x, total;
+};
+static PayloadLayout payload_layout(int Q, int F, int k1) {
+    auto up = [](long long v) { return (v + 255) & ~255LL; };
+    PayloadLayout L;
+    const long long C = (long long)F * k1;
+    L.hdr = 0;
+    L.ids = up(sizeof(PayloadHeader));
+    L.scores = up(L.ids + (long long)Q * F * k1 * 8);
+    L.cand = up(L.scores + (long long)Q * F * k1 * 4);
+    L.ncand = up(L.cand + (long long)Q * C * 8);
+    L.x = up(L.ncand + (long long)Q * 4);
+    L.total = up(L.x + (long long)Q * C * F * 4);
+    return L;
+}
+extern "C" int64_t mfar_payload_bytes(int Q, int n_fields, int k1) {
+    if (Q < 0 || n_fields <= 0 || k1 <= 0) return 0;
+    return payload_layout(Q, n_fields, k1).total;
+}
+
+extern "C" int mfar_search_local(mfar_index* idx, const float* q, int Q, int k1, int sentinel, void* payload, int on_device,
+                                 void* stream) {
+    RETCHK(check_search_common(idx, q, Q, k1));
+    if (!payload) return fail(MFAR_ERR_INVALID, "payload is NULL");
+    const int F = idx->F, E = idx->E, C = F * k1;
+    if (C > 4096) return fail(MFAR_ERR_INVALID, "n_fields * k1 must be <= 4096");
+    if (E * 4 > 60 * 1024) return fail(MFAR_ERR_UNSUPPORTED, "dim too large for the stage-2 kernel");
+    HIPCHK(hipSetDevice(idx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const PayloadLayout L = payload_layout(Q, F, k1);
+    const float* qd;
+    char* pd;
+    RETCHK(stage_in(idx->in[0], q, (size_t)Q * E, on_device, st, &qd));
+    RETCHK(stage_out(idx->out[3], (char*)payload, (size_t)L.total, on_device, &pd));
+    PayloadHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = PAYLOAD_MAGIC;
+    h.Q = Q;
+    h.F = F;
+    h.k1 = k1;
+    h.row_offset = idx->row_offset;
+    h.n_rows = idx->n_rows;
+    h.sentinel = sentinel;
+    HIPCHK(hipMemcpyAsync(pd + L.hdr, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // h lives on this stack frame
+    if (Q > 0) {
+        long long* fid = (long long*)(pd + L.ids);
+        float* fsc = (float*)(pd + L.scores);
+        long long* cand = (long long*)(pd + L.cand);
+        int* ncd = (int*)(pd + L.ncand);
+        float* x = (float*)(pd + L.x);
+        RETCHK(run_stage1(idx, qd, Q, k1, sentinel, fid, fsc, st));
+        mfar_union_kernel<<<dim3(Q), dim3(256), 0, st>>>(fid, F, k1, cand, ncd);
+        HIPCHK(hipGetLastError());
+        RETCHK(run_score(idx, qd, Q, cand, ncd, C, x, st));
+    }
+    RETCHK(copy_back((char*)payload, pd, (size_t)L.total, on_device, st));
+    if (!on_device) HIPCHK(hipStreamSynchronize(st));
+    return MFAR_OK;
+}
+
+extern "C" int mfar_merge_payloads(int device, const void* payloads, int n_shards, const float* q, int Q, int E,
+                                   const float* W, int query_cond, const float* mask, int n_fields, int k1, int k2,
+                                   int sentinel, int64_t* ids, float* scores, int32_t* n_valid, int on_device, void* stream) {
+    const int F = n_fields, C = F * k1;
+    if (!payloads || n_shards <= 0 || n_shards > 64) return fail(MFAR_ERR_INVALID, "bad payloads / n_shards");
+    if (k1 <= 0 || k1 > MFAR_MAX_K) return fail(MFAR_ERR_INVALID, "k1 must be in [1, 128]");
+    RETCHK(check_mix(Q, C, F, E, k2, q, W, query_cond));
+    if (Q == 0) return MFAR_OK;
+    if (!ids || !scores) return fail(MFAR_ERR_INVALID, "output pointer is NULL");
+    int ndev = 0;
+    RETCHK(mfar_device_count(&ndev));
+    if (device < 0 || device >= ndev || device >= 16) return fail(MFAR_ERR_INVALID, "no such device");
+    HIPCHK(hipSetDevice(device));
+    RETCHK(set_kernel_attrs(device));
+    hipStream_t st = (hipStream_t)stream;
+    DevCtx& cx = g_ctx[device];
+    std::unique_lock<std::mutex> lk(cx.mu);
+    const PayloadLayout L = payload_layout(Q, F, k1);
+    const char* pd;
+    const float *qd, *Wd, *md;
+    long long* idd;
+    float* scd;
+    int* nvd;
+    RETCHK(stage_in(cx.in[6], (const char*)payloads, (size_t)L.total * n_shards, on_device, st, &pd));
+    RETCHK(stage_in(cx.in[3], q, query_cond ? (size_t)Q * E : 0, on_device, st, &qd));
+    RETCHK(stage_in(cx.in[4], W, query_cond ? (size_t)E * F : (size_t)F, on_device, st, &Wd));
+    RETCHK(stage_in(cx.in[5], mask, (size_t)F, on_device, st, &md));
+    RETCHK(stage_out(cx.out[0], (long long*)ids, (size_t)Q * k2, on_device, &idd));
+    RETCHK(stage_out(cx.out[1], scores, (size_t)Q * k2, on_device, &scd));
+    RETCHK(stage_out(cx.out[2], (int*)n_valid, (size_t)Q, on_device, &nvd));
+    RETCHK(cx.lists_ids.ensure((size_t)Q * F * k1 * 8));
+    RETCHK(cx.lists_sc.ensure((size_t)Q * F * k1 * 4));
+    RETCHK(cx.cand.ensure((size_t)Q * C * 8));
+    RETCHK(cx.ncand.ensure((size_t)Q * 4));
+    RETCHK(cx.x.ensure((size_t)Q * C * F * 4));
+    ShardMergeParams sp;
+    sp.payloads = pd;
+    sp.payload_stride = L.total;
+    sp.ids_off = L.ids;
+    sp.scores_off = L.scores;
+    sp.out_ids = cx.lists_ids.as<long long>();
+    sp.out_scores = cx.lists_sc.as<float>();
+    sp.S = n_shards;
+    sp.F = F;
+    sp.k = k1;
+    sp.sentinel = sentinel;
+    mfar_merge_shards_kernel<<<dim3(Q * F), dim3(256), SEL_LDS_BYTES(n_shards * k1), st>>>(sp);
+    HIPCHK(hipGetLastError());
+    mfar_union_kernel<<<dim3(Q), dim3(256), 0, st>>>(sp.out_ids, F, k1, cx.cand.as<long long>(), cx.ncand.as<int>());
+    HIPCHK(hipGetLastError());
+    LookupParams lp;
+    lp.payloads = pd;
+    lp.payload_stride = L.total;
+    lp.hdr_off = L.hdr;
+    lp.cand_off = L.cand;
+    lp.ncand_off = L.ncand;
+    lp.x_off = L.x;
+    lp.cand = cx.cand.as<long long>();
+    lp.n_cand = cx.ncand.as<int>();
+    lp.out = cx.x.as<float>();
+    lp.S = n_shards;
+    lp.F = F;
+    lp.C = C;
+    mfar_lookup_kernel<<<dim3((C + 255) / 256, Q), dim3(256), 0, st>>>(lp);
+    HIPCHK(hipGetLastError());
+    RETCHK(run_mix(cx.x.as<float>(), cx.cand.as<long long>(), cx.ncand.as<int>(), qd, Wd, query_cond, md, Q, C, F, E, k2, idd,
+                   scd, nvd, st));
+    RETCHK(copy_back((long long*)ids, idd, (size_t)Q * k2, on_device, st));
+    RETCHK(copy_back(scores, scd, (size_t)Q * k2, on_device, st));
+    RETCHK(copy_back((int*)n_valid, nvd, (size_t)Q, on_device, st));
+    // the shared scratch is reused by the next call: finish before releasing the lock
+    HIPCHK(hipStreamSynchronize(st));
+    return MFAR_OK;
+}

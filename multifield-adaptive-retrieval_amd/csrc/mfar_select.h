@@ -1,0 +1,402 @@
+// mfar_select.h -- the small kernels around stage 1: list merge, candidate union, candidate scoring (stage 2),
+// field-weight softmax head + weighted sum + final top-k, and the row-major <-> tiled layout converters.
+#pragma once
+#include "mfar_device.h"
+#include "mfar_stage1.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// Layout converters
+// ---------------------------------------------------------------------------------------------------------
+// src[n, E] row-major fp32 -> tiled slab rows [row0, row0+n) of one field.  One thread per 16-byte granule.
+__global__ void mfar_tile_rows_kernel(const float* __restrict__ src, float* __restrict__ field_base, long long row0,
+                                      long long n, int E) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gpr = E >> 2;  // granules per row
+    if (gid >= n * gpr) return;
+    const long long r = gid / gpr;
+    const int e = (int)(gid - r * gpr) << 2;
+    const f32x4 v = *(const f32x4*)(src + r * E + e);
+    *(f32x4*)(field_base + tiled_offset(E >> 4, row0 + r, e)) = v;
+}
+// inverse: tiled rows -> dst[n, E] row-major
+__global__ void mfar_untile_rows_kernel(const float* __restrict__ field_base, float* __restrict__ dst, long long row0,
+                                        long long n, int E) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gpr = E >> 2;
+    if (gid >= n * gpr) return;
+    const long long r = gid / gpr;
+    const int e = (int)(gid - r * gpr) << 2;
+    *(f32x4*)(dst + r * E + e) = *(const f32x4*)(field_base + tiled_offset(E >> 4, row0 + r, e));
+}
+// queries q[Q, E] (rows q0 .. q0+63, zero beyond Q) -> tiled [n_steps][64][16]
+__global__ void mfar_tile_queries_kernel(const float* __restrict__ q, float* __restrict__ qt, int q0, int Q, int E) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gpr = E >> 2;
+    if (gid >= 64 * gpr) return;
+    const int r = gid / gpr;
+    const int e = (gid - r * gpr) << 2;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q0 + r < Q) v = *(const f32x4*)(q + (size_t)(q0 + r) * E + e);
+    *(f32x4*)(qt + tiled_offset(E >> 4, r, e)) = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K_B: merge the per-workgroup lists of one (query, field) into the final sorted top-k list.
+//   grid = Qt * F workgroups (Qt <= 64 queries of this pass), dynamic LDS = n_chunks * k * 8 bytes.
+// ---------------------------------------------------------------------------------------------------------
+struct MergeParams {
+    const uint2* lists;   // [F * n_chunks * 64][S1_CAP]
+    const int* list_cnt;  // [F * n_chunks * 64]
+    long long* out_ids;   // [Q, F, k] global ids
+    float* out_scores;    // [Q, F, k]
+    long long row_offset;
+    int n_chunks, F, k, q0, sentinel;
+};
+// LDS carve-up shared by the selection kernels (everything in the dynamic region: 16-byte aligned base)
+//   keys[n_keys] u64 | sel[MFAR_MAX_K] u64 | sorted[MFAR_MAX_K] u64 | red[32] int | misc[4] int
+#define SEL_LDS_BYTES(n_keys) ((size_t)(n_keys) * 8 + 2 * MFAR_MAX_K * 8 + 36 * 4)
+#define MIX_LDS_BYTES (SEL_LDS_BYTES(4096) + 3 * MFAR_MAX_FIELDS * 4)
+struct SelLds {
+    u64* keys;
+    u64* sel;
+    u64* sorted;
+    int* red;
+    int* misc;
+};
+__device__ __forceinline__ SelLds sel_lds(char* smem, int n_keys) {
+    SelLds s;
+    s.keys = (u64*)smem;
+    s.sel = s.keys + n_keys;
+    s.sorted = s.sel + MFAR_MAX_K;
+    s.red = (int*)(s.sorted + MFAR_MAX_K);
+    s.misc = s.red + 32;
+    return s;
+}
+
+__global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SelLds L = sel_lds(smem, p.n_chunks * p.k);
+    const int ql = blockIdx.x / p.F, f = blockIdx.x - ql * p.F;
+    if (threadIdx.x == 0) L.misc[0] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.n_chunks * p.k; i += blockDim.x) {
+        const int c = i / p.k, r = i - c * p.k;
+        const size_t li = ((size_t)(f * p.n_chunks + c) * 64 + ql);
+        if (r < min(p.list_cnt[li], p.k)) {
+            const uint2 e = p.lists[li * S1_CAP + r];
+            L.keys[atomicAdd(&L.misc[0], 1)] = make_key(__uint_as_float(e.x), e.y);
+        }
+    }
+    __syncthreads();
+    const int n = L.misc[0];
+    const int m = block_topk_sorted(L.keys, n, p.k, L.sel, L.sorted, L.red);
+    const size_t ob = ((size_t)(p.q0 + ql) * p.F + f) * p.k;
+    for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
+        if (r < m) {
+            p.out_ids[ob + r] = p.row_offset + (long long)key_id(L.sorted[r]);
+            p.out_scores[ob + r] = key_score(L.sorted[r]);
+        } else {
+            p.out_ids[ob + r] = p.sentinel ? 0 : -1;
+            p.out_scores[ob + r] = p.sentinel ? 0.0f : -__builtin_inff();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// M1: merge S shard lists (multi-GPU).  src ids/scores are addressed through a stride so the payload buffers of
+// all shards can be read in place.   grid = Q * F, dynamic LDS = S * k * 8.
+// ---------------------------------------------------------------------------------------------------------
+struct ShardMergeParams {
+    const char* payloads;      // S payloads, `payload_stride` bytes apart
+    long long payload_stride;
+    long long ids_off, scores_off;  // byte offsets of field_ids / field_scores inside a payload
+    long long* out_ids;
+    float* out_scores;
+    int S, F, k, sentinel;
+};
+__global__ void __launch_bounds__(256) mfar_merge_shards_kernel(const ShardMergeParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SelLds L = sel_lds(smem, p.S * p.k);
+    u64* keys = L.keys;
+    u64 *sel = L.sel, *sorted = L.sorted;
+    int* red = L.red;
+    int& n_s = L.misc[0];
+    const int q = blockIdx.x / p.F, f = blockIdx.x - q * p.F;
+    if (threadIdx.x == 0) n_s = 0;
+    __syncthreads();
+    const size_t lb = ((size_t)q * p.F + f) * p.k;
+    for (int i = threadIdx.x; i < p.S * p.k; i += blockDim.x) {
+        const int s = i / p.k, r = i - s * p.k;
+        const char* pl = p.payloads + (size_t)s * p.payload_stride;
+        const long long id = ((const long long*)(pl + p.ids_off))[lb + r];
+        const float sc = ((const float*)(pl + p.scores_off))[lb + r];
+        // padding entries ((0, 0.0) sentinels or (-1, -inf)) are re-created after the selection
+        const bool pad = (id < 0) || (p.sentinel && id == 0 && sc == 0.0f);
+        if (!pad) keys[atomicAdd(&n_s, 1)] = make_key(sc, (u32)id);
+    }
+    __syncthreads();
+    const int n = n_s;
+    const int m = block_topk_sorted(keys, n, p.k, sel, sorted, red);
+    for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
+        if (r < m) {
+            p.out_ids[lb + r] = (long long)key_id(sorted[r]);
+            p.out_scores[lb + r] = key_score(sorted[r]);
+        } else {
+            p.out_ids[lb + r] = p.sentinel ? 0 : -1;
+            p.out_scores[lb + r] = p.sentinel ? 0.0f : -__builtin_inff();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K_C: union of the F per-field id lists of one query (contrastive.py:678-679) -> sorted unique candidate ids.
+//   grid = Q, block 256, LDS u32[4096].  cand [Q, Cmax] (Cmax = F*k), padded with -1.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mfar_union_kernel(const long long* __restrict__ field_ids, int F, int k,
+                                                         long long* __restrict__ cand, int* __restrict__ n_cand) {
+    __shared__ u32 a[4096];
+    __shared__ int wsum[4], total_s;
+    const int q = blockIdx.x;
+    const int n = F * k;
+    int N = 256;
+    while (N < n) N <<= 1;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        u32 v = MFAR_INVALID_ID;
+        if (i < n) {
+            const long long id = field_ids[(size_t)q * n + i];
+            if (id >= 0) v = (u32)id;
+        }
+        a[i] = v;
+    }
+    __syncthreads();
+    // bitonic sort ascending
+    for (int size = 2; size <= N; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < (N >> 1); t += blockDim.x) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const u32 x = a[lo], y = a[hi];
+                if ((x > y) == up) {
+                    a[lo] = y;
+                    a[hi] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // unique + compaction (each thread owns a contiguous run of N/256 elements)
+    const int per = N / 256;
+    const int b = threadIdx.x * per;
+    int mine = 0;
+    for (int i = b; i < b + per; ++i) mine += (a[i] != MFAR_INVALID_ID && (i == 0 || a[i] != a[i - 1])) ? 1 : 0;
+    int incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane_id() >= off) incl += v;
+    }
+    if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int ww = 0; ww < (int)(threadIdx.x >> 6); ++ww) wbase += wsum[ww];
+    if (threadIdx.x == 0) total_s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int pos = wbase + incl - mine;
+    long long* out = cand + (size_t)q * n;
+    for (int i = b; i < b + per; ++i)
+        if (a[i] != MFAR_INVALID_ID && (i == 0 || a[i] != a[i - 1])) out[pos++] = (long long)a[i];
+    __syncthreads();
+    const int C = total_s;
+    for (int i = C + threadIdx.x; i < n; i += blockDim.x) out[i] = -1;
+    if (threadIdx.x == 0) n_cand[q] = C;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K_D: stage 2 == DenseFlatIndex.score_batch for all fields (index.py:227-232; contrastive.py:681-683).
+//   out[q, c, f] = chain-ordered dot(q, slab[f, cand[q,c]]).  One thread per (c, f); query row staged in LDS.
+//   grid = (ceil(C*F/256), Q).
+// ---------------------------------------------------------------------------------------------------------
+struct ScoreParams {
+    const float* slab;
+    long long field_stride;  // floats
+    const float* q;          // [Q, E] row-major
+    const long long* cand;   // [Q, C]
+    const int* n_cand;       // [Q] or nullptr
+    float* out;              // [Q, C, F]
+    long long row_offset;
+    int n_rows, n_steps, E, F, C;
+};
+__global__ void __launch_bounds__(256) mfar_score_candidates_kernel(const ScoreParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qs = (float*)smem;
+    const int qi = blockIdx.y;
+    const int nc = p.n_cand ? p.n_cand[qi] : p.C;
+    const int first = blockIdx.x * blockDim.x;
+    if (first >= nc * p.F) {
+        // slots past the candidate count: define the output (NaN) so downstream never reads garbage
+        const int idx = first + threadIdx.x;
+        if (idx < p.C * p.F) p.out[(size_t)qi * p.C * p.F + idx] = __builtin_nanf("");
+        return;
+    }
+    for (int e = threadIdx.x; e < p.E; e += blockDim.x) qs[e] = p.q[(size_t)qi * p.E + e];
+    __syncthreads();
+    const int idx = first + threadIdx.x;
+    if (idx >= p.C * p.F) return;
+    const int c = idx / p.F, f = idx - c * p.F;
+    float acc = __builtin_nanf("");
+    if (c < nc) {
+        const long long id = p.cand[(size_t)qi * p.C + c] - p.row_offset;
+        if (id >= 0 && id < p.n_rows) {
+            const int rr = (int)(id & 63);
+            const int sw = (rr >> 2) & 3;
+            const float* base = p.slab + (size_t)f * p.field_stride + (size_t)(id >> 6) * p.n_steps * 1024 + rr * 16;
+            acc = 0.0f;
+            for (int s = 0; s < p.n_steps; ++s) {
+                const float* t = base + (size_t)s * 1024;
+                const f32x4 c0 = *(const f32x4*)(t + ((0 ^ sw) << 2));
+                const f32x4 c1 = *(const f32x4*)(t + ((1 ^ sw) << 2));
+                const f32x4 c2 = *(const f32x4*)(t + ((2 ^ sw) << 2));
+                const f32x4 c3 = *(const f32x4*)(t + ((3 ^ sw) << 2));
+                const float* qq = qs + s * 16;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    acc = __builtin_fmaf(qq[x], c0[x], acc);
+                    acc = __builtin_fmaf(qq[4 + x], c1[x], acc);
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    acc = __builtin_fmaf(qq[8 + x], c2[x], acc);
+                    acc = __builtin_fmaf(qq[12 + x], c3[x], acc);
+                }
+            }
+        }
+    }
+    p.out[(size_t)qi * p.C * p.F + idx] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// M3 (multi-GPU): fetch the F-score vector of every global candidate from its owner shard's payload.
+//   grid = (ceil(C/256), Q).  The owner is found from the shard row ranges, the slot by binary search in the owner's
+//   sorted candidate list.
+// ---------------------------------------------------------------------------------------------------------
+struct LookupParams {
+    const char* payloads;
+    long long payload_stride, hdr_off, cand_off, ncand_off, x_off;
+    const long long* cand;  // [Q, C] global union
+    const int* n_cand;      // [Q]
+    float* out;             // [Q, C, F]
+    int S, F, C;
+};
+struct PayloadHeader {  // 64 bytes at the start of every payload
+    int magic, Q, F, k1;
+    long long row_offset, n_rows;
+    int sentinel, pad[7];
+};
+__global__ void __launch_bounds__(256) mfar_lookup_kernel(const LookupParams p) {
+    const int qi = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.C) return;
+    float* o = p.out + ((size_t)qi * p.C + c) * p.F;
+    const int nc = p.n_cand[qi];
+    int owner = -1, slot = -1;
+    if (c < nc) {
+        const long long id = p.cand[(size_t)qi * p.C + c];
+        for (int s = 0; s < p.S; ++s) {
+            const PayloadHeader* h = (const PayloadHeader*)(p.payloads + (size_t)s * p.payload_stride + p.hdr_off);
+            if (id >= h->row_offset && id < h->row_offset + h->n_rows) owner = s;
+        }
+        if (owner >= 0) {
+            const char* pl = p.payloads + (size_t)owner * p.payload_stride;
+            const long long* oc = (const long long*)(pl + p.cand_off) + (size_t)qi * p.C;
+            int lo = 0, hi = ((const int*)(pl + p.ncand_off))[qi] - 1;
+            while (lo <= hi) {
+                const int mid = (lo + hi) >> 1;
+                const long long v = oc[mid];
+                if (v == id) {
+                    slot = mid;
+                    break;
+                }
+                if (v < id) lo = mid + 1; else hi = mid - 1;
+            }
+        }
+    }
+    if (slot >= 0) {
+        const float* x = (const float*)(p.payloads + (size_t)owner * p.payload_stride + p.x_off) + ((size_t)qi * p.C + slot) * p.F;
+        for (int f = 0; f < p.F; ++f) o[f] = x[f];
+    } else {
+        for (int f = 0; f < p.F; ++f) o[f] = __builtin_nanf("");
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K_E: mask (contrastive.py:686) + LinearWeights.forward (weighting.py:17-29) + topk (contrastive.py:696).
+//   grid = Q, block 256.  C <= 4096 candidates per query.
+// ---------------------------------------------------------------------------------------------------------
+struct MixParams {
+    const float* x;         // [Q, C, F]
+    const long long* cand;  // [Q, C]  (< 0 = empty)
+    const int* n_cand;      // [Q] or nullptr
+    const float* q;         // [Q, E]
+    const float* W;         // [E, F] or [F]
+    const float* mask;      // [F] or nullptr
+    long long* ids;         // [Q, k]
+    float* scores;          // [Q, k]
+    int* n_valid;           // [Q] or nullptr
+    int C, F, E, k, query_cond;
+};
+__global__ void __launch_bounds__(256) mfar_mix_topk_kernel(const MixParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SelLds L = sel_lds(smem, 4096);
+    u64* keys = L.keys;
+    u64 *sel = L.sel, *sorted = L.sorted;
+    int* red = L.red;
+    int& n_s = L.misc[0];
+    float* z = (float*)(L.misc + 4);  // z | wgt | msk : 3 * MFAR_MAX_FIELDS floats after the select scratch
+    float* wgt = z + MFAR_MAX_FIELDS;
+    float* msk = wgt + MFAR_MAX_FIELDS;
+    const int qi = blockIdx.x;
+    const int nc = min(p.n_cand ? p.n_cand[qi] : p.C, p.C);
+    // gate logits: natural-order fma chain per field
+    if ((int)threadIdx.x < p.F) {
+        const int f = threadIdx.x;
+        float acc;
+        if (p.query_cond) {
+            acc = 0.0f;
+            const float* qr = p.q + (size_t)qi * p.E;
+            for (int e = 0; e < p.E; ++e) acc = __builtin_fmaf(qr[e], p.W[(size_t)e * p.F + f], acc);
+        } else {
+            acc = p.W[f];
+        }
+        z[f] = acc;
+        msk[f] = p.mask ? p.mask[f] : 1.0f;
+    }
+    if (threadIdx.x == 0) n_s = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {  // softmax over <= 32 fields, fixed order
+        float m = -__builtin_inff();
+        for (int f = 0; f < p.F; ++f) m = z[f] > m ? z[f] : m;
+        float sum = 0.0f;
+        for (int f = 0; f < p.F; ++f) {
+            wgt[f] = mfar_exp(z[f] - m);
+            sum = sum + wgt[f];
+        }
+        for (int f = 0; f < p.F; ++f) wgt[f] = wgt[f] / sum;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < nc; c += blockDim.x) {
+        const long long id = p.cand[(size_t)qi * p.C + c];
+        if (id < 0) continue;
+        const float* xr = p.x + ((size_t)qi * p.C + c) * p.F;
+        float acc = 0.0f;
+        for (int f = 0; f < p.F; ++f) acc = __builtin_fmaf(wgt[f], xr[f] * msk[f], acc);
+        if (acc != acc) continue;  // NaN (candidate not scored) never selected
+        keys[atomicAdd(&n_s, 1)] = make_key(acc, (u32)id);
+    }
+    __syncthreads();
+    const int n = n_s;
+    const int m = block_topk_sorted(keys, n, p.k, sel, sorted, red);
+    for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
+        p.ids[(size_t)qi * p.k + r] = r < m ? (long long)key_id(sorted[r]) : -1;
+        p.scores[(size_t)qi * p.k + r] = r < m ? key_score(sorted[r]) : -__builtin_inff();
+    }
+    if (threadIdx.x == 0 && p.n_valid) p.n_valid[qi] = m;
+}

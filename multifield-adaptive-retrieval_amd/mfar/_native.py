@@ -1,0 +1,88 @@
+"""ctypes binding of libmfar_hip.so (the C ABI in include/mfar_hip.h).
+
+The product path has NO CPU fallback: if the library is missing or a call fails, this module raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # .../multifield-adaptive-retrieval_amd
+LIB_PATH = os.path.join(_PKG, "lib", "libmfar_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+MFAR_OK = 0
+ERR_NAMES = {-1: "MFAR_ERR_INVALID", -2: "MFAR_ERR_HIP", -3: "MFAR_ERR_NOMEM", -4: "MFAR_ERR_UNSUPPORTED"}
+DTYPE_F32, DTYPE_BF16 = 0, 1
+MAX_K, MAX_FIELDS = 128, 32
+
+
+class MfarError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 with hipcc (works without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["make", "-C", CSRC, "-s", "all"])
+    return LIB_PATH
+
+
+_lib = None
+
+_c = ctypes
+_vp, _i, _i64, _f32p = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_void_p
+
+# name -> (restype, argtypes); must list every symbol declared in include/mfar_hip.h
+SIGNATURES = {
+    "mfar_version": (_i, []),
+    "mfar_last_error": (_c.c_char_p, []),
+    "mfar_device_count": (_i, [_c.POINTER(_i)]),
+    "mfar_index_create": (_i, [_c.POINTER(_vp), _i, _i64, _i64, _i, _i, _i]),
+    "mfar_index_destroy": (None, [_vp]),
+    "mfar_index_info": (_i, [_vp, _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i64)]),
+    "mfar_index_write_rows": (_i, [_vp, _i, _i64, _i64, _vp, _i, _vp]),
+    "mfar_index_read_rows": (_i, [_vp, _i, _i64, _i64, _vp, _i, _vp]),
+    "mfar_retrieve_fields": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "mfar_score_candidates": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    "mfar_mix_topk": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "mfar_search_two_stage": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mfar_payload_bytes": (_i64, [_i, _i, _i]),
+    "mfar_search_local": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "mfar_merge_payloads": (_i, [_i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "mfar_set_timing": (_i, [_vp, _i]),
+    "mfar_stage1_timing": (_i, [_vp, _c.POINTER(_c.c_double), _c.POINTER(_i)]),
+    "mfar_set_wgs_per_cu": (_i, [_vp, _i]),
+}
+
+
+def lib():
+    """Load libmfar_hip.so. Raises (loudly) when it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                f"(python -c 'import __graft_entry__ as g; g.build()' or make -C {CSRC})")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != MFAR_OK:
+        raise MfarError(rc, lib().mfar_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    n = _i(0)
+    rc = lib().mfar_device_count(ctypes.byref(n))
+    if rc != MFAR_OK:
+        return 0
+    return n.value

@@ -1,0 +1,386 @@
+"""Index / vector store of the dense multi-field scoring path, MI355X-native.
+
+Mirrors the reference's `mfar.data.index` surface (reference mfar/data/index.py):
+  * `Index`                     index.py:21-37   (abstract retrieve / retrieve_batch)
+  * `DenseFlatIndex`            index.py:160-232 (same constructor, `.vectors` re-assignable, `retrieve_batch`,
+                                                  `score_batch`, KeyError on unknown keys)
+  * `candidate_encoding_stream` index.py:234-258
+and adds `MultiFieldIndex`, the on-HBM row shard of ALL fields that replaces the per-field np.memmap files
+(data/util.py:28-59) and runs the whole of `trec_eval_step` (modeling/contrastive.py:669-704) on the GPU through
+the C ABI of libmfar_hip.so (include/mfar_hip.h).  There is no CPU fallback: without the HIP library these
+classes raise.
+"""
+import ctypes
+from abc import ABC, abstractmethod
+from typing import Dict, Generic, Iterable, Optional, Sequence, Tuple, TypeVar, Union
+
+import numpy as np
+
+from mfar import _native
+
+Key = TypeVar("Key")
+Query = TypeVar("Query")
+
+
+class Index(ABC, Generic[Key, Query]):
+    """Anything that can be searched (reference index.py:21-37)."""
+
+    @abstractmethod
+    def retrieve(self, query: Query, top_k: int) -> Sequence[Tuple[Key, float]]:
+        raise NotImplementedError
+
+    def retrieve_batch(self, queries: Sequence[Query], top_k: int) -> Sequence[Sequence[Tuple[Key, float]]]:
+        return [self.retrieve(q, top_k) for q in queries]
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+class _Arg:
+    """A host (numpy) or device (torch.cuda) buffer handed to the C ABI."""
+
+    def __init__(self, x, dtype, device_index: int, allow_none=False):
+        self.keep = None
+        self.ptr = None
+        self.on_device = None
+        if x is None:
+            if not allow_none:
+                raise ValueError("missing array")
+            return
+        if _is_torch(x):
+            import torch
+            want = {np.float32: torch.float32, np.int64: torch.int64, np.int32: torch.int32, np.uint8: torch.uint8}[dtype]
+            if x.dtype != want:
+                raise TypeError(f"expected {want}, got {x.dtype}")
+            if not x.is_contiguous():
+                raise ValueError("tensor must be contiguous")
+            if x.is_cuda:
+                if x.device.index != device_index:
+                    raise ValueError(f"tensor lives on {x.device}, index is on cuda:{device_index}")
+                self.on_device = True
+                self.keep = x
+                self.ptr = x.data_ptr()
+                return
+            x = x.numpy()
+        a = np.ascontiguousarray(x, dtype=dtype)
+        self.keep = a
+        self.ptr = a.ctypes.data
+        self.on_device = False
+
+
+def _same_side(args):
+    sides = {a.on_device for a in args if a.on_device is not None}
+    if len(sides) > 1:
+        raise ValueError("all arrays of one call must be on the same side (all host or all on the index's GPU)")
+    return bool(sides.pop()) if sides else False
+
+
+def _current_stream(device_index: int, on_device: bool):
+    if not on_device:
+        return None
+    import torch
+    return torch.cuda.current_stream(device_index).cuda_stream
+
+
+def _empty_like_side(on_device, device_index, shape, dtype):
+    if on_device:
+        import torch
+        td = {np.float32: torch.float32, np.int64: torch.int64, np.int32: torch.int32, np.uint8: torch.uint8}[dtype]
+        return torch.empty(shape, dtype=td, device=f"cuda:{device_index}")
+    return np.empty(shape, dtype=dtype)
+
+
+class MultiFieldIndex:
+    """Rows [row_offset, row_offset + n_rows) of every dense field, resident in HBM as one tiled fp32 slab.
+
+    Replaces `read_and_create_indices`' per-field memmaps + DenseFlatIndex objects (reference modeling/util.py:73-108)
+    and the row split of `on_eval_start` (contrastive.py:470).  Arrays may be numpy (host path: copied, synchronous)
+    or torch CUDA tensors on the index's device (device path: zero-copy, asynchronous on torch's current stream).
+    """
+
+    def __init__(self, n_rows: int, n_fields: int, dim: int, device: int = 0, row_offset: int = 0, dtype: str = "f32"):
+        L = _native.lib()
+        h = ctypes.c_void_p()
+        dt = {"f32": _native.DTYPE_F32, "bf16": _native.DTYPE_BF16}[dtype]
+        _native.check(L.mfar_index_create(ctypes.byref(h), int(device), int(n_rows), int(row_offset), int(n_fields), int(dim), dt))
+        self._h = h
+        self.n_rows, self.n_fields, self.dim = int(n_rows), int(n_fields), int(dim)
+        self.device, self.row_offset, self.dtype = int(device), int(row_offset), dtype
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _native.lib().mfar_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def slab_bytes(self) -> int:
+        v = ctypes.c_int64()
+        _native.check(_native.lib().mfar_index_info(self._h, None, None, None, None, None, ctypes.byref(v)))
+        return v.value
+
+    # ---- rows in / out (MemoryMapDict.__setitem__ / .file, data/util.py:37-41) ----
+    def write_rows(self, field: int, local_row0: int, rows) -> None:
+        a = _Arg(rows, np.float32, self.device)
+        shape = tuple(a.keep.shape)
+        if len(shape) != 2 or shape[1] != self.dim:
+            raise ValueError(f"rows must be [n, {self.dim}], got {shape}")
+        _native.check(_native.lib().mfar_index_write_rows(self._h, int(field), int(local_row0), shape[0], a.ptr,
+                                                           int(a.on_device), _current_stream(self.device, a.on_device)))
+
+    def read_rows(self, field: int, local_row0: int = 0, n: Optional[int] = None, out=None):
+        n = self.n_rows - local_row0 if n is None else n
+        if out is None:
+            out = np.empty((n, self.dim), dtype=np.float32)
+        a = _Arg(out, np.float32, self.device)
+        _native.check(_native.lib().mfar_index_read_rows(self._h, int(field), int(local_row0), int(n), a.ptr,
+                                                          int(a.on_device), _current_stream(self.device, a.on_device)))
+        return out
+
+    # ---- stage 1: DenseFlatIndex.retrieve_batch for all fields (index.py:181-222; contrastive.py:672-674) ----
+    def retrieve_fields(self, q, top_k: int = 100, sentinel: bool = True):
+        qa = _Arg(q, np.float32, self.device)
+        Q = qa.keep.shape[0]
+        ids = _empty_like_side(qa.on_device, self.device, (Q, self.n_fields, top_k), np.int64)
+        sc = _empty_like_side(qa.on_device, self.device, (Q, self.n_fields, top_k), np.float32)
+        ia, sa = _Arg(ids, np.int64, self.device), _Arg(sc, np.float32, self.device)
+        _native.check(_native.lib().mfar_retrieve_fields(self._h, qa.ptr, Q, int(top_k), int(bool(sentinel)), ia.ptr, sa.ptr,
+                                                          int(qa.on_device), _current_stream(self.device, qa.on_device)))
+        return ids, sc
+
+    # ---- stage 2: DenseFlatIndex.score_batch for all fields (index.py:227-232) ----
+    def score_candidates(self, q, cand):
+        qa, ca = _Arg(q, np.float32, self.device), _Arg(cand, np.int64, self.device)
+        on_dev = _same_side([qa, ca])
+        Q, C = ca.keep.shape
+        out = _empty_like_side(on_dev, self.device, (Q, C, self.n_fields), np.float32)
+        oa = _Arg(out, np.float32, self.device)
+        _native.check(_native.lib().mfar_score_candidates(self._h, qa.ptr, Q, ca.ptr, C, oa.ptr, int(on_dev),
+                                                           _current_stream(self.device, on_dev)))
+        return out
+
+    # ---- the whole trec_eval_step scorer (contrastive.py:669-704) ----
+    def search(self, q, W, mask=None, k1: int = 100, k2: int = 100, sentinel: bool = True, query_cond: bool = True,
+               return_fields: bool = False, out=None):
+        """Returns dict(ids [Q,k2] int64, scores [Q,k2] f32, n_valid [Q] int32 [, field_ids, field_scores, n_cand]).
+        `out` may carry preallocated ids/scores/n_valid arrays (device path: no allocation in steady state)."""
+        qa, Wa = _Arg(q, np.float32, self.device), _Arg(W, np.float32, self.device)
+        ma = _Arg(mask, np.float32, self.device, allow_none=True)
+        on_dev = _same_side([qa, Wa, ma])
+        Q = qa.keep.shape[0]
+        out = dict(out) if out else {}
+        ids = out.get("ids") if out.get("ids") is not None else _empty_like_side(on_dev, self.device, (Q, k2), np.int64)
+        sc = out.get("scores") if out.get("scores") is not None else _empty_like_side(on_dev, self.device, (Q, k2), np.float32)
+        nv = out.get("n_valid") if out.get("n_valid") is not None else _empty_like_side(on_dev, self.device, (Q,), np.int32)
+        ia, sa, na = _Arg(ids, np.int64, self.device), _Arg(sc, np.float32, self.device), _Arg(nv, np.int32, self.device)
+        fid = fsc = nc = None
+        fa = fs = nca = _Arg(None, np.int64, self.device, allow_none=True)
+        if return_fields:
+            fid = _empty_like_side(on_dev, self.device, (Q, self.n_fields, k1), np.int64)
+            fsc = _empty_like_side(on_dev, self.device, (Q, self.n_fields, k1), np.float32)
+            nc = _empty_like_side(on_dev, self.device, (Q,), np.int32)
+            fa, fs, nca = _Arg(fid, np.int64, self.device), _Arg(fsc, np.float32, self.device), _Arg(nc, np.int32, self.device)
+        _native.check(_native.lib().mfar_search_two_stage(
+            self._h, qa.ptr, Q, Wa.ptr, int(bool(query_cond)), ma.ptr, int(k1), int(k2), int(bool(sentinel)),
+            ia.ptr, sa.ptr, na.ptr, fa.ptr, fs.ptr, nca.ptr, int(on_dev), _current_stream(self.device, on_dev)))
+        res = dict(ids=ids, scores=sc, n_valid=nv)
+        if return_fields:
+            res.update(field_ids=fid, field_scores=fsc, n_cand=nc)
+        return res
+
+    # ---- multi-GPU: local half + merge of all-gathered payloads ----
+    def payload_bytes(self, Q: int, k1: int = 100) -> int:
+        return int(_native.lib().mfar_payload_bytes(int(Q), self.n_fields, int(k1)))
+
+    def search_local(self, q, k1: int = 100, sentinel: bool = True, payload=None):
+        qa = _Arg(q, np.float32, self.device)
+        Q = qa.keep.shape[0]
+        nbytes = self.payload_bytes(Q, k1)
+        if payload is None:
+            payload = _empty_like_side(qa.on_device, self.device, (nbytes,), np.uint8)
+        pa = _Arg(payload, np.uint8, self.device)
+        have = payload.numel() if _is_torch(payload) else pa.keep.size
+        if have < nbytes:
+            raise ValueError("payload buffer too small")
+        _native.check(_native.lib().mfar_search_local(self._h, qa.ptr, Q, int(k1), int(bool(sentinel)), pa.ptr,
+                                                       int(qa.on_device), _current_stream(self.device, qa.on_device)))
+        return payload
+
+    # instrumentation for bench.py
+    def set_timing(self, enable: bool):
+        _native.check(_native.lib().mfar_set_timing(self._h, int(bool(enable))))
+
+    def stage1_timing(self):
+        tot, n = ctypes.c_double(), ctypes.c_int()
+        _native.check(_native.lib().mfar_stage1_timing(self._h, ctypes.byref(tot), ctypes.byref(n)))
+        return tot.value, n.value
+
+    def set_wgs_per_cu(self, n: int):
+        _native.check(_native.lib().mfar_set_wgs_per_cu(self._h, int(n)))
+
+
+def merge_payloads(payloads, n_shards: int, q, W, mask=None, n_fields: int = None, k1: int = 100, k2: int = 100,
+                   sentinel: bool = True, query_cond: bool = True, device: int = 0):
+    """Merge the all-gathered per-shard payloads (concatenated, shard-major) into the final top-k2.
+    Replaces the per-rank .qres files + rank-0 merge of the reference (contrastive.py:519-536, 566-581)."""
+    qa, Wa = _Arg(q, np.float32, device), _Arg(W, np.float32, device)
+    ma = _Arg(mask, np.float32, device, allow_none=True)
+    pa = _Arg(payloads, np.uint8, device)
+    on_dev = _same_side([qa, Wa, ma, pa])
+    Q, E = qa.keep.shape
+    if n_fields is None:
+        n_fields = Wa.keep.shape[-1] if query_cond else int(np.prod(Wa.keep.shape))
+    ids = _empty_like_side(on_dev, device, (Q, k2), np.int64)
+    sc = _empty_like_side(on_dev, device, (Q, k2), np.float32)
+    nv = _empty_like_side(on_dev, device, (Q,), np.int32)
+    ia, sa, na = _Arg(ids, np.int64, device), _Arg(sc, np.float32, device), _Arg(nv, np.int32, device)
+    _native.check(_native.lib().mfar_merge_payloads(
+        int(device), pa.ptr, int(n_shards), qa.ptr, Q, E, Wa.ptr, int(bool(query_cond)), ma.ptr, int(n_fields), int(k1), int(k2),
+        int(bool(sentinel)), ia.ptr, sa.ptr, na.ptr, int(on_dev), _current_stream(device, on_dev)))
+    return dict(ids=ids, scores=sc, n_valid=nv)
+
+
+def mix_topk(cand_scores, cand_ids, q, W, mask=None, n_cand=None, k: int = 100, query_cond: bool = True, device: int = 0):
+    """mask * scores (contrastive.py:686) -> LinearWeights.forward (weighting.py:17-29) -> topk (contrastive.py:696)."""
+    xa, ca = _Arg(cand_scores, np.float32, device), _Arg(cand_ids, np.int64, device)
+    qa = _Arg(q, np.float32, device, allow_none=not query_cond)
+    Wa = _Arg(W, np.float32, device)
+    ma = _Arg(mask, np.float32, device, allow_none=True)
+    na = _Arg(n_cand, np.int32, device, allow_none=True)
+    on_dev = _same_side([xa, ca, qa, Wa, ma, na])
+    Q, C, F = xa.keep.shape
+    E = qa.keep.shape[1] if qa.keep is not None else 0
+    ids = _empty_like_side(on_dev, device, (Q, k), np.int64)
+    sc = _empty_like_side(on_dev, device, (Q, k), np.float32)
+    nv = _empty_like_side(on_dev, device, (Q,), np.int32)
+    ia, sa, nva = _Arg(ids, np.int64, device), _Arg(sc, np.float32, device), _Arg(nv, np.int32, device)
+    _native.check(_native.lib().mfar_mix_topk(int(device), xa.ptr, ca.ptr, na.ptr, qa.ptr, Wa.ptr, int(bool(query_cond)), ma.ptr,
+                                              Q, C, F, E, int(k), ia.ptr, sa.ptr, nva.ptr, int(on_dev),
+                                              _current_stream(device, on_dev)))
+    return dict(ids=ids, scores=sc, n_valid=nv)
+
+
+class DenseFlatIndex(Index[str, str]):
+    """Drop-in for the reference's DenseFlatIndex (index.py:160-232): same constructor arguments, `.vectors` may be
+    re-assigned from outside after the corpus encode (contrastive.py:494), `retrieve_batch` accepts an ndarray of
+    query embeddings or query texts, `score_batch` returns a tensor [len(queries), len(keys)] and raises KeyError
+    for unknown keys.  The arithmetic runs on the GPU: this object is a one-field view of a `MultiFieldIndex`
+    (pass `slab=` and `field_index=` to share one slab between the fields, as read_and_create_indices does here).
+
+    Two documented differences from the reference: ties are broken (score desc, doc index asc) instead of
+    unspecified, and `vector_batch_size` is accepted but irrelevant (there is no chunked CPU matmul).
+    """
+
+    def __init__(self, model, vectors, numeric_ids_to_keys: Sequence[str], keys_to_numeric_ids: Dict[str, int],
+                 device=None, vector_batch_size: int = 1048576, slab: Optional[MultiFieldIndex] = None, field_index: int = 0):
+        self.model = model
+        self.numeric_ids_to_key = numeric_ids_to_keys
+        self.key_to_numeric_ids = keys_to_numeric_ids
+        self.vector_batch_size = vector_batch_size
+        self.field_index = field_index
+        dev_index = 0
+        if device is not None and getattr(device, "type", "cpu") == "cuda" and device.index is not None:
+            dev_index = device.index
+        self.device = device
+        self._slab = slab
+        self._own_slab = slab is None
+        self._dev_index = slab.device if slab is not None else dev_index
+        self._vectors = None
+        if vectors is not None:
+            self.vectors = vectors
+
+    @property
+    def slab(self) -> MultiFieldIndex:
+        if self._slab is None:
+            raise RuntimeError("DenseFlatIndex has no vectors yet")
+        return self._slab
+
+    @property
+    def vectors(self):
+        return self._vectors
+
+    @vectors.setter
+    def vectors(self, v):
+        """(Re-)load this field's [D, E] matrix into the slab -- the reference re-assigns `.vectors` with the reopened
+        memmap after every corpus encode (contrastive.py:492-494)."""
+        self._vectors = v
+        shape = tuple(v.shape)
+        if len(shape) != 2:
+            raise ValueError("vectors must be [D, E]")
+        if self._slab is None:
+            self._slab = MultiFieldIndex(shape[0], 1, shape[1], device=self._dev_index)
+            self.field_index = 0
+        if shape[0] != self._slab.n_rows or shape[1] != self._slab.dim:
+            raise ValueError(f"vectors {shape} do not match the slab [{self._slab.n_rows}, {self._slab.dim}]")
+        step = max(1, (256 << 20) // (shape[1] * 4))
+        for r0 in range(0, shape[0], step):
+            self._slab.write_rows(self.field_index, r0, np.asarray(v[r0:r0 + step], dtype=np.float32)
+                                  if not _is_torch(v) else v[r0:r0 + step].contiguous())
+
+    def _encode(self, queries):
+        if isinstance(queries, np.ndarray):
+            return np.ascontiguousarray(queries, dtype=np.float32)          # index.py:184-185
+        enc = self.model.encode(list(queries), convert_to_tensor=True)       # index.py:187
+        return enc.detach().to("cpu").float().numpy()
+
+    def retrieve(self, query, top_k: int):
+        return self.retrieve_batch([query], top_k)[0]
+
+    def retrieve_batch(self, queries: Union[np.ndarray, Sequence[str]], top_k: int):
+        qe = self._encode(queries)
+        if self.slab.n_fields == 1:
+            ids, sc = self.slab.retrieve_fields(qe, top_k, sentinel=True)
+            ids, sc = ids[:, 0], sc[:, 0]
+        else:
+            ids, sc = self.slab.retrieve_fields(qe, top_k, sentinel=True)
+            ids, sc = ids[:, self.field_index], sc[:, self.field_index]
+        ids_l, sc_l = ids.tolist(), sc.tolist()
+        off = self.slab.row_offset
+        return [list(zip([self.numeric_ids_to_key[j - off if j >= off else j] for j in ids_l[i]], sc_l[i]))
+                for i in range(len(queries))]
+
+    def score(self, query, keys: Sequence[str]):
+        return self.score_batch([query], keys)[0]
+
+    def score_batch(self, queries: Sequence[str], keys: Sequence[str]):
+        import torch
+        qe = self._encode(queries)
+        rows = np.asarray([self.key_to_numeric_ids[k] for k in keys], dtype=np.int64)   # KeyError like index.py:229
+        cand = np.broadcast_to(rows + self.slab.row_offset, (qe.shape[0], rows.size)).copy()
+        x = self.slab.score_candidates(qe, cand)
+        return torch.from_numpy(np.ascontiguousarray(x[:, :, self.field_index]))
+
+
+def candidate_encoding_stream(encoder, corpus: Iterable[Tuple[str, str]], batch_size: int = 64, multiprocess: bool = True,
+                              show_progress: bool = True) -> Iterable[Tuple[str, np.ndarray]]:
+    """(id, text) pairs -> (id, embedding[E]) pairs in chunks of `batch_size` (reference index.py:234-258).
+    `multiprocess` is accepted for signature compatibility; one process drives one GPU here (the reference's eval
+    path always passes multiprocess=False, contrastive.py:487)."""
+    it = corpus
+    if show_progress:
+        try:
+            from tqdm import tqdm
+            it = tqdm(corpus)
+        except ImportError:
+            pass
+    batch = []
+    for item in it:
+        batch.append(item)
+        if len(batch) == batch_size:
+            yield from _encode_batch(encoder, batch, batch_size)
+            batch = []
+    if batch:
+        yield from _encode_batch(encoder, batch, batch_size)
+
+
+def _encode_batch(encoder, batch, batch_size):
+    ids = [i for i, _ in batch]
+    texts = [t for _, t in batch]
+    embs = encoder.encode(texts, batch_size=batch_size, convert_to_numpy=True)
+    return zip(ids, embs)

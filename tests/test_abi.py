@@ -1,0 +1,71 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds for gfx950, loads without a GPU and exports
+every symbol include/mfar_hip.h declares; argument validation that needs no device; the host mirror keeps the
+reference's names and signatures (pinned by tests/golden/cli_signatures.json, schema.json)."""
+import ctypes
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mfar_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mfar_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mfar import _native
+    L = _native.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(L, name), f"libmfar_hip.so does not export {name}"
+    assert sorted(_native.SIGNATURES) == declared, "python binding table and header disagree"
+    assert L.mfar_version() >= 100
+
+
+def test_no_device_fails_loudly_not_silently():
+    """Without a GPU every compute entry point must return an error (and the python layer must raise):
+    there is no CPU fallback."""
+    from mfar import _native
+    from mfar.data.index import MultiFieldIndex
+    if _native.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(_native.MfarError):
+        MultiFieldIndex(10, 1, 32)
+    L = _native.lib()
+    h = ctypes.c_void_p()
+    assert L.mfar_index_create(ctypes.byref(h), 0, 10, 0, 1, 32, 0) != 0
+    assert b"hip" in L.mfar_last_error().lower()
+
+
+def test_argument_validation_without_device():
+    from mfar import _native
+    L = _native.lib()
+    h = ctypes.c_void_p()
+    assert L.mfar_index_create(None, 0, 10, 0, 1, 32, 0) == -1
+    assert L.mfar_index_create(ctypes.byref(h), 0, 10, 0, 1, 33, 0) == -1      # dim % 16
+    assert L.mfar_index_create(ctypes.byref(h), 0, 10, 0, 99, 32, 0) == -1     # n_fields
+    assert L.mfar_index_create(ctypes.byref(h), 0, -1, 0, 1, 32, 0) == -1
+    assert L.mfar_index_create(ctypes.byref(h), 0, 2**32, 0, 1, 32, 0) == -1   # ids must fit 32 bits
+    assert L.mfar_index_create(ctypes.byref(h), 0, 10, 0, 1, 32, 1) == -4      # bf16 not in this build
+    assert L.mfar_payload_bytes(64, 8, 100) > 64 * 800 * 8 * 4
+    assert L.mfar_payload_bytes(-1, 8, 100) == 0
+    assert L.mfar_retrieve_fields(None, None, 1, 100, 1, None, None, 0, None) == -1
+    assert L.mfar_set_wgs_per_cu(None, 2) == -1
+
+
+def test_python_mirror_keeps_reference_signatures():
+    from mfar.data.index import DenseFlatIndex, Index, candidate_encoding_stream
+    p = list(inspect.signature(DenseFlatIndex.__init__).parameters)
+    assert p[:7] == ["self", "model", "vectors", "numeric_ids_to_keys", "keys_to_numeric_ids", "device", "vector_batch_size"]
+    assert inspect.signature(DenseFlatIndex.__init__).parameters["vector_batch_size"].default == 1048576
+    assert list(inspect.signature(DenseFlatIndex.retrieve_batch).parameters) == ["self", "queries", "top_k"]
+    assert list(inspect.signature(DenseFlatIndex.score_batch).parameters) == ["self", "queries", "keys"]
+    assert list(inspect.signature(candidate_encoding_stream).parameters) == ["encoder", "corpus", "batch_size", "multiprocess", "show_progress"]
+    assert inspect.isabstract(Index)
