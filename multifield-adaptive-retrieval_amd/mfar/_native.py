@@ -66,6 +66,11 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} not found: build the HIP extension first "
                 f"(python -c 'import __graft_entry__ as g; g.build()' or make -C {CSRC})")
+        # One HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64/libhsa-runtime64 and a
+        # second runtime initialised later in the same process finds no GPU.  Importing torch first makes the loader
+        # resolve this library's libamdhip64.so.7 dependency to the copy torch already mapped (same SONAME), so device
+        # pointers and streams are shared with torch.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
