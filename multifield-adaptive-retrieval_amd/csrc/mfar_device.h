@@ -39,6 +39,16 @@ __device__ __forceinline__ int mbcnt(u64 m) {
     return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
 }
 
+// LDS atomic add with return, issued and waited for inside one asm statement (hipcc otherwise
+// drains in-flight LDS-DMA before an LDS atomic it can see, and expands atomics on generic pointers)
+__device__ __forceinline__ int lds_add_rtn(int* lds_ptr, int v) {
+    int old;
+    // the low 32 bits of a generic pointer into LDS are the LDS byte offset (flat aperture base lives in the high half)
+    const u32 addr = (u32)(uintptr_t)lds_ptr;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(old) : "v"(addr), "v"(v) : "memory");
+    return old;
+}
+
 // Deterministic exp(x) for x <= 0 (same operation sequence as mfar_oracle_exp in the oracle).
 __device__ __forceinline__ float mfar_exp(float x) {
     if (!(x > -80.0f)) return 0.0f;
@@ -77,47 +87,79 @@ __host__ __device__ __forceinline__ size_t tiled_offset(int64_t n_steps, int64_t
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Block-level exact top-k of n unique 64-bit keys held in LDS (256 threads).  Result: sel[0..m) sorted descending,
-// m = min(n, k) returned.  `red` is an int[16] LDS scratch, `sel` u64[MFAR_MAX_K] LDS.
-// Radix descent on the key bits (most significant first) finds the k-th largest key, survivors are gathered and
-// ranked by counting.
+// Block-level exact top-k of n unique 64-bit keys held in LDS (256 threads, n <= 256 * NPT).
+// Result: sorted[0..m) descending, m = min(n, k) returned.  Every thread keeps its NPT keys in registers, so one
+// radix step is NPT compares + a wave reduction + one barrier.  The descent runs on the score half first (32 steps)
+// and only refines on the id half when the k-th score is tied.  LDS scratch: sel u64[MFAR_MAX_K], red int[32].
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int block_count_ge(const u64* keys, int n, u64 cand, volatile int* red, int parity) {
-    int c = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) c += (keys[i] >= cand) ? 1 : 0;
-    // wave sum
+template <int NPT>
+__device__ __forceinline__ int block_sum(int c, int* red, int parity) {
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-    const int nw = (blockDim.x + 63) >> 6;
     if (lane_id() == 0) red[parity * 8 + (threadIdx.x >> 6)] = c;
     __syncthreads();
     int tot = 0;
+    const int nw = (blockDim.x + 63) >> 6;
     for (int w = 0; w < nw; ++w) tot += red[parity * 8 + w];
     return tot;
 }
 
+template <int NPT>
 __device__ __forceinline__ int block_topk_sorted(const u64* keys, int n, int k, u64* sel, u64* sel_sorted, int* red) {
     __syncthreads();
-    int m;
-    u64 T = 0;
+    u32 hi[NPT], lo[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const u64 key = idx < n ? keys[idx] : 0ull;
+        hi[i] = (u32)(key >> 32);
+        lo[i] = (u32)key;
+    }
+    int m = n;
+    u32 T = 0, TL = 0;
     if (n > k) {
+        m = k;
         int parity = 0;
-        for (int bit = 63; bit >= 0; --bit) {
-            const u64 cand = T | (1ull << bit);
-            const int tot = block_count_ge(keys, n, cand, red, parity);
+        for (int bit = 31; bit >= 0; --bit) {
+            const u32 cand = T | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) c += hi[i] >= cand ? 1 : 0;
+            const int tot = block_sum<NPT>(c, red, parity);
             parity ^= 1;
             if (tot >= k) T = cand;
         }
-        m = k;
-    } else {
-        m = n;
+        int cg = 0, ce = 0;
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            cg += hi[i] > T ? 1 : 0;
+            ce += hi[i] == T ? 1 : 0;
+        }
+        const int tg = block_sum<NPT>(cg, red, parity);
+        parity ^= 1;
+        const int te = block_sum<NPT>(ce, red, parity);
+        parity ^= 1;
+        if (tg + te > k) {  // tie on the k-th score: keep the smallest ids (largest inverted ids)
+            const int need = k - tg;
+            for (int bit = 31; bit >= 0; --bit) {
+                const u32 cand = TL | (1u << bit);
+                int c = 0;
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) c += (hi[i] == T && lo[i] >= cand) ? 1 : 0;
+                const int tot = block_sum<NPT>(c, red, parity);
+                parity ^= 1;
+                if (tot >= need) TL = cand;
+            }
+        }
     }
     if (threadIdx.x == 0) red[16] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const u64 key = keys[i];
-        if (key >= T) {
-            const int pos = atomicAdd(&red[16], 1);
-            if (pos < k) sel[pos] = key;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const bool keep = idx < n && (hi[i] > T || (hi[i] == T && lo[i] >= TL));
+        if (keep) {
+            const int pos = lds_add_rtn(&red[16], 1);
+            if (pos < k) sel[pos] = ((u64)hi[i] << 32) | lo[i];
         }
     }
     __syncthreads();

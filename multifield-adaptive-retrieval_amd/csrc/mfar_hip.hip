@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -77,7 +78,7 @@ struct mfar_index {
     long long field_stride = 0;  // floats
     int n_cu = 256;
     int wgs_per_cu = 2;
-    DevBuf qt, lists, list_cnt, fid, fsc, cand, ncand, x, in[8], out[8];
+    DevBuf qt, lists, list_cnt, gtau, fid, fsc, cand, ncand, x, in[8], out[8];
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
     int ev_n = 0;
@@ -87,9 +88,12 @@ static int set_kernel_attrs(int device) {
     if (device < 0 || device >= 16) return fail(MFAR_ERR_INVALID, "device index out of range");
     if (g_attr_done[device]) return MFAR_OK;
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_lists_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_shards_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)mfar_mix_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_lists_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_lists_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_lists_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_shards_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_shards_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_mix_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     g_attr_done[device] = true;
     return MFAR_OK;
 }
@@ -160,7 +164,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     (void)hipSetDevice(idx->device);
     (void)hipDeviceSynchronize();
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&idx->qt, &idx->lists, &idx->list_cnt, &idx->fid, &idx->fsc, &idx->cand, &idx->ncand, &idx->x};
+    DevBuf* bufs[] = {&idx->qt, &idx->lists, &idx->list_cnt, &idx->gtau, &idx->fid, &idx->fsc, &idx->cand, &idx->ncand, &idx->x};
     for (DevBuf* b : bufs) b->release();
     for (auto& b : idx->in) b.release();
     for (auto& b : idx->out) b.release();
@@ -332,6 +336,7 @@ static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentine
     RETCHK(idx->qt.ensure((size_t)idx->n_steps * 4096));
     RETCHK(idx->lists.ensure((size_t)idx->F * n_chunks * 64 * S1_CAP * sizeof(uint2)));
     RETCHK(idx->list_cnt.ensure((size_t)idx->F * n_chunks * 64 * sizeof(int)));
+    RETCHK(idx->gtau.ensure((size_t)idx->F * 64 * sizeof(float)));
     for (int q0 = 0; q0 < Q; q0 += 64) {
         const int qt_n = std::min(64, Q - q0);
         const int total = 64 * (idx->E / 4);
@@ -350,6 +355,47 @@ static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentine
         p.Q = qt_n;
         p.k = k;
         p.tau0 = sentinel ? 0.0f : -INFINITY;
+        p.gtau = nullptr;
+        p.sample = 0;
+        {
+            const char* dbg = getenv("MFAR_S1_DEBUG");
+            p.dbg = dbg ? atoi(dbg) : 0;
+        }
+        MergeParams m;
+        m.lists = p.lists;
+        m.list_cnt = p.list_cnt;
+        m.row_offset = idx->row_offset;
+        m.n_chunks = n_chunks;
+        m.F = idx->F;
+        m.k = k;
+        m.q0 = q0;
+        m.sentinel = sentinel;
+        const int n_keys = n_chunks * k;
+        auto launch_merge = [&](const MergeParams& mp) -> int {
+            const dim3 grid(qt_n * idx->F), block(256);
+            const size_t lds = SEL_LDS_BYTES(n_keys);
+            if (n_keys <= 8 * 256) mfar_merge_lists_kernel<8><<<grid, block, lds, st>>>(mp);
+            else if (n_keys <= 32 * 256) mfar_merge_lists_kernel<32><<<grid, block, lds, st>>>(mp);
+            else mfar_merge_lists_kernel<64><<<grid, block, lds, st>>>(mp);
+            HIPCHK(hipGetLastError());
+            return MFAR_OK;
+        };
+        // Sample pass: every workgroup scans only the first tile of its chunk; the k-th best score of that sample is
+        // a valid (non-strict) lower bound of the final k-th best, so the full pass starts with a tight threshold and
+        // appends / compacts almost nothing.  Worth it once a chunk is much longer than one tile.
+        const bool use_sample = n_tiles >= 8 * n_chunks && !(p.dbg & 2);
+        if (use_sample) {
+            S1Params ps = p;
+            ps.sample = 1;
+            mfar_stage1_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1_LDS_BYTES, st>>>(ps);
+            HIPCHK(hipGetLastError());
+            MergeParams ms = m;
+            ms.out_ids = nullptr;
+            ms.out_scores = nullptr;
+            ms.tau_out = idx->gtau.as<float>();
+            RETCHK(launch_merge(ms));
+            p.gtau = idx->gtau.as<float>();
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (idx->timing && idx->ev_n < 4096) {
             if ((int)idx->ev.size() < 2 * (idx->ev_n + 1)) {
@@ -367,19 +413,10 @@ static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentine
         mfar_stage1_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1_LDS_BYTES, st>>>(p);
         HIPCHK(hipGetLastError());
         if (e1) HIPCHK(hipEventRecord(e1, st));
-        MergeParams m;
-        m.lists = p.lists;
-        m.list_cnt = p.list_cnt;
         m.out_ids = fid;
         m.out_scores = fsc;
-        m.row_offset = idx->row_offset;
-        m.n_chunks = n_chunks;
-        m.F = idx->F;
-        m.k = k;
-        m.q0 = q0;
-        m.sentinel = sentinel;
-        mfar_merge_lists_kernel<<<dim3(qt_n * idx->F), dim3(256), SEL_LDS_BYTES(n_chunks * k), st>>>(m);
-        HIPCHK(hipGetLastError());
+        m.tau_out = nullptr;
+        RETCHK(launch_merge(m));
     }
     return MFAR_OK;
 }
@@ -469,7 +506,9 @@ static int run_mix(const float* x, const long long* cand, const int* ncand, cons
     p.k = k;
     p.query_cond = query_cond;
     if (Q == 0) return MFAR_OK;
-    mfar_mix_topk_kernel<<<dim3(Q), dim3(256), MIX_LDS_BYTES, st>>>(p);
+    const size_t lds = MIX_LDS_BYTES(query_cond ? E : 0, F);
+    if (lds > 160 * 1024) return fail(MFAR_ERR_UNSUPPORTED, "dim * n_fields too large for the mixer kernel's LDS staging");
+    mfar_mix_topk_kernel<<<dim3(Q), dim3(256), lds, st>>>(p);
     HIPCHK(hipGetLastError());
     return MFAR_OK;
 }
@@ -690,7 +729,8 @@ extern "C" int mfar_merge_payloads(int device, const void* payloads, int n_shard
     sp.F = F;
     sp.k = k1;
     sp.sentinel = sentinel;
-    mfar_merge_shards_kernel<<<dim3(Q * F), dim3(256), SEL_LDS_BYTES(n_shards * k1), st>>>(sp);
+    if (n_shards * k1 <= 8 * 256) mfar_merge_shards_kernel<8><<<dim3(Q * F), dim3(256), SEL_LDS_BYTES(n_shards * k1), st>>>(sp);
+    else mfar_merge_shards_kernel<32><<<dim3(Q * F), dim3(256), SEL_LDS_BYTES(n_shards * k1), st>>>(sp);
     HIPCHK(hipGetLastError());
     mfar_union_kernel<<<dim3(Q), dim3(256), 0, st>>>(sp.out_ids, F, k1, cx.cand.as<long long>(), cx.ncand.as<int>());
     HIPCHK(hipGetLastError());

@@ -47,15 +47,16 @@ __global__ void mfar_tile_queries_kernel(const float* __restrict__ q, float* __r
 struct MergeParams {
     const uint2* lists;   // [F * n_chunks * 64][S1_CAP]
     const int* list_cnt;  // [F * n_chunks * 64]
-    long long* out_ids;   // [Q, F, k] global ids
+    long long* out_ids;   // [Q, F, k] global ids (nullptr: threshold-only pass)
     float* out_scores;    // [Q, F, k]
+    float* tau_out;       // [F, 64] or nullptr: k-th best score of the merged list (-inf when fewer than k entries)
     long long row_offset;
     int n_chunks, F, k, q0, sentinel;
 };
 // LDS carve-up shared by the selection kernels (everything in the dynamic region: 16-byte aligned base)
 //   keys[n_keys] u64 | sel[MFAR_MAX_K] u64 | sorted[MFAR_MAX_K] u64 | red[32] int | misc[4] int
 #define SEL_LDS_BYTES(n_keys) ((size_t)(n_keys) * 8 + 2 * MFAR_MAX_K * 8 + 36 * 4)
-#define MIX_LDS_BYTES (SEL_LDS_BYTES(4096) + 3 * MFAR_MAX_FIELDS * 4)
+#define MIX_LDS_BYTES(E, F) (SEL_LDS_BYTES(4096) + 3 * MFAR_MAX_FIELDS * 4 + (size_t)(E) * 4 + (size_t)(E) * (F) * 4)
 struct SelLds {
     u64* keys;
     u64* sel;
@@ -73,6 +74,7 @@ __device__ __forceinline__ SelLds sel_lds(char* smem, int n_keys) {
     return s;
 }
 
+template <int NPT>
 __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SelLds L = sel_lds(smem, p.n_chunks * p.k);
@@ -89,7 +91,9 @@ __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams
     }
     __syncthreads();
     const int n = L.misc[0];
-    const int m = block_topk_sorted(L.keys, n, p.k, L.sel, L.sorted, L.red);
+    const int m = block_topk_sorted<NPT>(L.keys, n, p.k, L.sel, L.sorted, L.red);
+    if (p.tau_out && threadIdx.x == 0) p.tau_out[f * 64 + ql] = m == p.k ? key_score(L.sorted[p.k - 1]) : -__builtin_inff();
+    if (!p.out_ids) return;
     const size_t ob = ((size_t)(p.q0 + ql) * p.F + f) * p.k;
     for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
         if (r < m) {
@@ -114,6 +118,7 @@ struct ShardMergeParams {
     float* out_scores;
     int S, F, k, sentinel;
 };
+template <int NPT>
 __global__ void __launch_bounds__(256) mfar_merge_shards_kernel(const ShardMergeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SelLds L = sel_lds(smem, p.S * p.k);
@@ -136,7 +141,7 @@ __global__ void __launch_bounds__(256) mfar_merge_shards_kernel(const ShardMerge
     }
     __syncthreads();
     const int n = n_s;
-    const int m = block_topk_sorted(keys, n, p.k, sel, sorted, red);
+    const int m = block_topk_sorted<NPT>(keys, n, p.k, sel, sorted, red);
     for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
         if (r < m) {
             p.out_ids[lb + r] = (long long)key_id(sorted[r]);
@@ -355,14 +360,33 @@ __global__ void __launch_bounds__(256) mfar_mix_topk_kernel(const MixParams p) {
     float* msk = wgt + MFAR_MAX_FIELDS;
     const int qi = blockIdx.x;
     const int nc = min(p.n_cand ? p.n_cand[qi] : p.C, p.C);
-    // gate logits: natural-order fma chain per field
+    // gate logits: natural-order fma chain per field.  q and W are staged in LDS by all threads first, so the F
+    // serial chains read LDS (unrolled by 16) instead of paying a global-memory round trip per element.
+    float* qs = msk + MFAR_MAX_FIELDS;   // [E]
+    float* Ws = qs + p.E;                // [E * F]
+    if (p.query_cond) {
+        const float* qr = p.q + (size_t)qi * p.E;
+        for (int e = threadIdx.x; e < p.E; e += blockDim.x) qs[e] = qr[e];
+        for (int i = threadIdx.x; i < p.E * p.F; i += blockDim.x) Ws[i] = p.W[i];
+    }
+    __syncthreads();
     if ((int)threadIdx.x < p.F) {
         const int f = threadIdx.x;
         float acc;
         if (p.query_cond) {
             acc = 0.0f;
-            const float* qr = p.q + (size_t)qi * p.E;
-            for (int e = 0; e < p.E; ++e) acc = __builtin_fmaf(qr[e], p.W[(size_t)e * p.F + f], acc);
+            int e = 0;
+            for (; e + 16 <= p.E; e += 16) {
+                float qv[16], wv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    qv[i] = qs[e + i];
+                    wv[i] = Ws[(e + i) * p.F + f];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc = __builtin_fmaf(qv[i], wv[i], acc);
+            }
+            for (; e < p.E; ++e) acc = __builtin_fmaf(qs[e], Ws[e * p.F + f], acc);
         } else {
             acc = p.W[f];
         }
@@ -393,7 +417,7 @@ __global__ void __launch_bounds__(256) mfar_mix_topk_kernel(const MixParams p) {
     }
     __syncthreads();
     const int n = n_s;
-    const int m = block_topk_sorted(keys, n, p.k, sel, sorted, red);
+    const int m = block_topk_sorted<16>(keys, n, p.k, sel, sorted, red);
     for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
         p.ids[(size_t)qi * p.k + r] = r < m ? (long long)key_id(sorted[r]) : -1;
         p.scores[(size_t)qi * p.k + r] = r < m ? key_score(sorted[r]) : -__builtin_inff();

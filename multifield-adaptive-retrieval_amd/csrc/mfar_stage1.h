@@ -22,8 +22,10 @@
 #define S1_TILE_ROWS 256                     // rows per workgroup tile (4 waves x 64)
 #define S1_CAP 512                           // list capacity per (workgroup, query)
 #define S1_TRIG (S1_CAP - S1_TILE_ROWS)      // compact when more than this many entries are held
-#define S1_WAVE_LDS 16384                    // 2 buffers x (4 KB doc tile + 4 KB query tile)
-#define S1_LDS_BYTES (4 * S1_WAVE_LDS + 512) // + tau[64] + cnt[64]
+#define S1_STAGES 3                          // LDS ring depth: loads run two k-steps ahead of the MFMAs
+#define S1_D_BYTES (4 * S1_STAGES * 4096)    // per wave: S1_STAGES x 4 KB doc tile (private to the wave)
+#define S1_Q_BYTES (S1_STAGES * 4096)        // per workgroup: S1_STAGES x 4 KB query tile (shared by the 4 waves)
+#define S1_LDS_BYTES (S1_D_BYTES + S1_Q_BYTES + 784)  // + tau[64] + cnt[64] + compaction flag + tg[64]
 
 struct S1Params {
     const float* slab;      // tiled, [F][n_blk][n_steps][64][16]
@@ -38,6 +40,9 @@ struct S1Params {
     int Q;                  // valid queries (<= 64)
     int k;                  // list depth (<= MFAR_MAX_K)
     float tau0;             // 0 (zero sentinel, index.py:192-193) or -inf
+    const float* gtau;      // [F, 64] non-strict lower bounds from the sample pass, or nullptr
+    int sample;             // 1: threshold-estimation pass, every workgroup scans only the first tile of its chunk
+    int dbg;                // profiling only (MFAR_S1_DEBUG): 1 = skip the selection epilogue (results invalid)
 };
 
 // Wave-level compaction of one list: keep the k best of n (k < n <= S1_CAP) entries, return the k-th best score.
@@ -92,21 +97,28 @@ __device__ __forceinline__ float s1_compact(uint2* list, int n, int k) {
     return ord2f(T);
 }
 
-__device__ __forceinline__ void s1_issue(const char* dsrc, const char* qsrc, char* buf) {
+// One k-step of loads for one wave: its own 4 KB doc tile (4 x 1 KB LDS-DMA) and its quarter of the shared query tile.
+__device__ __forceinline__ void s1_issue(const char* dsrc, const char* qsrc, char* dbuf, char* qbuf) {
 #pragma unroll
     for (int p = 0; p < 4; ++p)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc + p * 1024),
-                                         (__attribute__((address_space(3))) void*)(buf + p * 1024), 16, 0, 0);
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc + p * 1024),
-                                         (__attribute__((address_space(3))) void*)(buf + 4096 + p * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(dbuf + p * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)qsrc,
+                                     (__attribute__((address_space(3))) void*)qbuf, 16, 0, 0);
 }
+#define S1_LOADS_PER_STAGE 5
+// A score survives when it beats the workgroup's own running k-th best (strict: later rows lose ties to earlier
+// ones) AND is not below the global lower bound from the sample pass (non-strict: ties with other chunks are
+// decided by the merge).
+#define S1_PASS(v, tq, tg) ((v) > (tq) && (v) >= (tg))
 
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_kernel(const S1Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tau_s = (float*)(smem + 4 * S1_WAVE_LDS);
-    int* cnt_s = (int*)(smem + 4 * S1_WAVE_LDS + 256);
+    char* const qring = smem + S1_D_BYTES;
+    float* tau_s = (float*)(smem + S1_D_BYTES + S1_Q_BYTES);
+    int* cnt_s = (int*)(smem + S1_D_BYTES + S1_Q_BYTES + 256);
+    int* flag_s = (int*)(smem + S1_D_BYTES + S1_Q_BYTES + 512);
+    float* tg_s = (float*)(smem + S1_D_BYTES + S1_Q_BYTES + 528);  // non-strict global lower bounds
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -116,13 +128,16 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_kernel(const S1Para
     const int f = blockIdx.x / p.n_chunks;
     const int chunk = blockIdx.x - f * p.n_chunks;
     const int t0 = (int)(((long long)chunk * p.n_tiles) / p.n_chunks);
-    const int t1 = (int)(((long long)(chunk + 1) * p.n_tiles) / p.n_chunks);
+    int t1 = (int)(((long long)(chunk + 1) * p.n_tiles) / p.n_chunks);
+    if (p.sample) t1 = min(t1, t0 + 1);
     const size_t wgq0 = (size_t)blockIdx.x * 64;
 
     if (tid < 64) {
         tau_s[tid] = tid < p.Q ? p.tau0 : __builtin_inff();
         cnt_s[tid] = 0;
+        tg_s[tid] = p.gtau ? p.gtau[f * 64 + tid] : -__builtin_inff();
     }
+    if (tid == 0) *flag_s = 0;
     __syncthreads();
 
     // fragment read offsets inside a 4 KB tile: row (32*blk + j), dims 8g + 4h .. +3  (chunk c = 2g + h)
@@ -130,37 +145,54 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_kernel(const S1Para
     const int off_g0 = j * 64 + (((0 + h) ^ sw) << 4);
     const int off_g1 = j * 64 + (((2 + h) ^ sw) << 4);
 
-    char* const mybuf = smem + w * S1_WAVE_LDS;
+    char* const dring = smem + w * (S1_STAGES * 4096);
     const size_t step_bytes = 4096;
     const size_t tile_jump = (size_t)3 * p.n_steps * step_bytes;  // from the end of block b to the start of block b+4
-    const char* dptr = (const char*)p.slab + ((size_t)f * (size_t)p.field_stride) * 4 +
-                       ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes + lane * 16;
-    const char* const qbase = (const char*)p.qt + lane * 16;
+    // load cursor (runs two k-steps ahead of the compute cursor)
+    const char* dnext = (const char*)p.slab + ((size_t)f * (size_t)p.field_stride) * 4 +
+                        ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes + lane * 16;
+    const char* const qbase = (const char*)p.qt + w * 1024 + lane * 16;
+    int s_next = 0, st_next = 0;
+    const int total = (t1 - t0) * p.n_steps;
+    int issued = 0;
+#define S1_ISSUE_NEXT()                                                                                   \
+    do {                                                                                                  \
+        s1_issue(dnext, qbase + (size_t)s_next * step_bytes, dring + st_next * 4096,                      \
+                 qring + st_next * 4096 + w * 1024);                                                      \
+        dnext += step_bytes;                                                                              \
+        if (++s_next == p.n_steps) {                                                                      \
+            s_next = 0;                                                                                   \
+            dnext += tile_jump;                                                                           \
+        }                                                                                                 \
+        st_next = (st_next == S1_STAGES - 1) ? 0 : st_next + 1;                                           \
+        ++issued;                                                                                         \
+    } while (0)
+    if (total > 0) S1_ISSUE_NEXT();
+    if (total > 1) S1_ISSUE_NEXT();
 
-    if (t0 < t1) {
-        s1_issue(dptr, qbase, mybuf);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    int it = 0;
+    int it = 0, st_cur = 0;
     for (int t = t0; t < t1; ++t) {
         f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};  // [doc block][query block]
         for (int s = 0; s < p.n_steps; ++s, ++it) {
-            char* cur = mybuf + (it & 1) * 8192;
-            char* nxt = mybuf + ((it + 1) & 1) * 8192;
+            // stage `it` must have landed (own doc tile: counted vmcnt; other waves' query quarters: the barrier).
+            // The S1_LOADS_PER_STAGE newest loads (stage it+1) may stay in flight.
+            if (issued > it + 1)
+                asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            const char* cur = dring + st_cur * 4096;
+            const char* curq = qring + st_cur * 4096;
+            st_cur = (st_cur == S1_STAGES - 1) ? 0 : st_cur + 1;
             const f32x4 d00 = *(const f32x4*)(cur + off_g0);
             const f32x4 d01 = *(const f32x4*)(cur + off_g1);
             const f32x4 d10 = *(const f32x4*)(cur + 2048 + off_g0);
             const f32x4 d11 = *(const f32x4*)(cur + 2048 + off_g1);
-            const f32x4 q00 = *(const f32x4*)(cur + 4096 + off_g0);
-            const f32x4 q01 = *(const f32x4*)(cur + 4096 + off_g1);
-            const f32x4 q10 = *(const f32x4*)(cur + 4096 + 2048 + off_g0);
-            const f32x4 q11 = *(const f32x4*)(cur + 4096 + 2048 + off_g1);
-            const bool last_step = (s == p.n_steps - 1);
-            dptr += step_bytes + (last_step ? tile_jump : 0);
-            if (!(last_step && t == t1 - 1)) {
-                const char* qn = qbase + (last_step ? 0 : (size_t)(s + 1) * step_bytes);
-                s1_issue(dptr, qn, nxt);
-            }
+            const f32x4 q00 = *(const f32x4*)(curq + off_g0);
+            const f32x4 q01 = *(const f32x4*)(curq + off_g1);
+            const f32x4 q10 = *(const f32x4*)(curq + 2048 + off_g0);
+            const f32x4 q11 = *(const f32x4*)(curq + 2048 + off_g1);
+            // every wave has passed the barrier, so stage it-1 (== ring slot of it+2) is no longer being read
+            if (issued < total) S1_ISSUE_NEXT();
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(d00[x], q00[x], acc00, 0, 0, 0);
@@ -175,45 +207,70 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_kernel(const S1Para
                 acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(d11[x], q01[x], acc10, 0, 0, 0);
                 acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(d11[x], q11[x], acc11, 0, 0, 0);
             }
-            // the prefetch issued above has had this whole step of MFMAs to land: wait for it only now
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
         }
 
+        if (p.dbg & 1) {
+            asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11));
+            continue;
+        }
         // ---------------- epilogue: threshold filter + append ----------------
-        __syncthreads();  // compactions of the previous tile are complete: tau / cnt are stable
-        const float tq0 = tau_s[j], tq1 = tau_s[32 + j];
-        bool any = false;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            any = any || (acc00[r] > tq0) || (acc10[r] > tq0) || (acc01[r] > tq1) || (acc11[r] > tq1);
-        if (__any(any)) {
+        if (t * S1_TILE_ROWS + S1_TILE_ROWS > p.n_rows) {  // last tile of the field: padding rows never qualify
             const int row_w = t * S1_TILE_ROWS + w * 64 + 4 * h;
-#define S1_APPEND(ACC, DB, QB, TQ)                                                          \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                        \
-        const float v = ACC[r];                                                             \
-        if (v > TQ) {                                                                       \
-            const int row = row_w + 32 * DB + (r & 3) + 8 * (r >> 2);                       \
-            if (row < p.n_rows) {                                                           \
-                const int qq = 32 * QB + j;                                                 \
-                const int slot = atomicAdd(&cnt_s[qq], 1);                                  \
-                if (slot < S1_CAP)                                                          \
-                    p.lists[(wgq0 + qq) * S1_CAP + slot] = make_uint2(__float_as_uint(v), (u32)row); \
-            }                                                                               \
-        }                                                                                   \
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_w + (r & 3) + 8 * (r >> 2);
+                if (row >= p.n_rows) acc00[r] = acc01[r] = -__builtin_inff();
+                if (row + 32 >= p.n_rows) acc10[r] = acc11[r] = -__builtin_inff();
+            }
+        }
+        // barrier A: the compactions of the previous tile (LDS writes of tau / cnt) are complete
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const float tq0 = tau_s[j], tq1 = tau_s[32 + j];
+        const float tg0 = tg_s[j], tg1 = tg_s[32 + j];
+        int n0 = 0, n1 = 0;  // survivors of this lane for query j / 32 + j
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            n0 += (S1_PASS(acc00[r], tq0, tg0) ? 1 : 0) + (S1_PASS(acc10[r], tq0, tg0) ? 1 : 0);
+            n1 += (S1_PASS(acc01[r], tq1, tg1) ? 1 : 0) + (S1_PASS(acc11[r], tq1, tg1) ? 1 : 0);
+        }
+        if (__any((n0 | n1) != 0)) {
+            // one LDS slot reservation per (lane, query block); inline asm keeps hipcc from draining the
+            // LDS-DMA prefetch (it would wait vmcnt(0) before an LDS atomic it can see)
+            int b0 = 0, b1 = 0;
+            if (n0) b0 = lds_add_rtn(&cnt_s[j], n0);
+            if (n1) b1 = lds_add_rtn(&cnt_s[32 + j], n1);
+            if ((n0 && b0 + n0 > S1_TRIG) || (n1 && b1 + n1 > S1_TRIG)) *flag_s = 1;
+            const int row_w = t * S1_TILE_ROWS + w * 64 + 4 * h;
+            uint2* l0 = p.lists + (wgq0 + j) * S1_CAP;
+            uint2* l1 = p.lists + (wgq0 + 32 + j) * S1_CAP;
+#define S1_APPEND(ACC, DB, TQ, TG, L, B)                                                                         \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                         \
+        const float v = ACC[r];                                                                              \
+        if (S1_PASS(v, TQ, TG)) {                                                                            \
+            if (B < S1_CAP) L[B] = make_uint2(__float_as_uint(v), (u32)(row_w + 32 * DB + (r & 3) + 8 * (r >> 2))); \
+            ++B;                                                                                             \
+        }                                                                                                    \
     }
-            S1_APPEND(acc00, 0, 0, tq0)
-            S1_APPEND(acc10, 1, 0, tq0)
-            S1_APPEND(acc01, 0, 1, tq1)
-            S1_APPEND(acc11, 1, 1, tq1)
+            S1_APPEND(acc00, 0, tq0, tg0, l0, b0)
+            S1_APPEND(acc10, 1, tq0, tg0, l0, b0)
+            S1_APPEND(acc01, 0, tq1, tg1, l1, b1)
+            S1_APPEND(acc11, 1, tq1, tg1, l1, b1)
 #undef S1_APPEND
         }
-        __syncthreads();  // every append of this tile is visible
-        // ---------------- compaction: wave w serves queries 16w .. 16w+15 ----------------
-        for (int qq = 16 * w; qq < 16 * w + 16; ++qq) {
-            const int n = __builtin_amdgcn_readfirstlane(min(cnt_s[qq], S1_CAP));
-            if (n > S1_TRIG) {  // wave-uniform
+        // barrier B: slot counters and the compaction flag of this tile are final
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (__builtin_amdgcn_readfirstlane(*flag_s)) {  // workgroup-uniform, rare after warm-up
+            // every wave's appended entries must be in memory before another wave compacts a list
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (tid == 0) *flag_s = 0;
+            // wave w serves queries 16w .. 16w+15
+            const int nv = lane < 16 ? min(cnt_s[16 * w + lane], S1_CAP) : 0;
+            u64 todo = __ballot(nv > S1_TRIG);
+            while (todo) {
+                const int b = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int qq = 16 * w + b;
+                const int n = __builtin_amdgcn_readlane(nv, b);
                 const float nt = s1_compact(p.lists + (wgq0 + qq) * S1_CAP, n, p.k);
                 if (lane == 0) {
                     tau_s[qq] = nt;
@@ -222,6 +279,7 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_kernel(const S1Para
             }
         }
     }
+#undef S1_ISSUE_NEXT
     // ---------------- flush: leave at most k entries per query, publish the counts ----------------
     __syncthreads();
     for (int qq = 16 * w; qq < 16 * w + 16; ++qq) {
