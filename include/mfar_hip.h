@@ -54,7 +54,7 @@ int mfar_device_count(int* n_out);
  * (read_and_create_indices, modeling/util.py:73-108).  One handle holds rows
  * [row_offset, row_offset + n_rows_local) of every field -- the same row split the reference uses for
  * encoding, corpus[n*rank//ws : n*(rank+1)//ws] (contrastive.py:470).
- * dim must be a multiple of 16; n_fields <= MFAR_MAX_FIELDS.  Rows start zero-filled.
+ * dim must be a multiple of 32; n_fields <= MFAR_MAX_FIELDS.  Rows start zero-filled.
  */
 int mfar_index_create(mfar_index** out, int device, int64_t n_rows_local, int64_t row_offset, int n_fields, int dim,
                       int dtype);

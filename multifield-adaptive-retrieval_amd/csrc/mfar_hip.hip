@@ -93,6 +93,7 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_lists_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_shards_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_shards_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_score_candidates_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_mix_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     g_attr_done[device] = true;
     return MFAR_OK;
@@ -119,7 +120,7 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     if (n_rows_local < 0 || row_offset < 0) return fail(MFAR_ERR_INVALID, "negative row count / offset");
     if (row_offset + n_rows_local >= 0xFFFFFFFELL) return fail(MFAR_ERR_INVALID, "doc ids must fit in 32 bits");
     if (n_fields <= 0 || n_fields > MFAR_MAX_FIELDS) return fail(MFAR_ERR_INVALID, "n_fields must be in [1, 32]");
-    if (dim <= 0 || (dim & 15)) return fail(MFAR_ERR_INVALID, "dim must be a positive multiple of 16");
+    if (dim <= 0 || (dim & 31)) return fail(MFAR_ERR_INVALID, "dim must be a positive multiple of 32");
     if (dtype == MFAR_DTYPE_BF16) return fail(MFAR_ERR_UNSUPPORTED, "bf16 slab is not implemented in this build");
     if (dtype != MFAR_DTYPE_F32) return fail(MFAR_ERR_INVALID, "unknown dtype");
     int ndev = 0;
@@ -460,7 +461,7 @@ static int run_score(mfar_index* idx, const float* q, int Q, const long long* ca
     p.C = C;
     const unsigned gx = (unsigned)(((size_t)C * idx->F + 255) / 256);
     if (gx == 0 || Q == 0) return MFAR_OK;
-    mfar_score_candidates_kernel<<<dim3(gx, Q), dim3(256), (size_t)idx->E * 4, st>>>(p);
+    mfar_score_candidates_kernel<<<dim3(gx, Q), dim3(256), SCORE_LDS_BYTES(idx->E), st>>>(p);
     HIPCHK(hipGetLastError());
     return MFAR_OK;
 }

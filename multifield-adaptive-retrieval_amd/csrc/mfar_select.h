@@ -230,52 +230,98 @@ struct ScoreParams {
     long long row_offset;
     int n_rows, n_steps, E, F, C;
 };
+// Each wave owns 64 (candidate, field) rows, one per lane.  A row of the tiled slab is 64-byte segments 4 KB apart
+// (one per k-step), so the wave gathers them cooperatively -- 4 lanes per segment, 16 segments per 1 KB LDS-DMA
+// instruction -- into a private two-slot LDS ring (2 k-steps per slot), and every lane then walks ITS row's segment
+// from LDS in chain order.  No barriers: the ring is private to the wave, ordered by counted vmcnt waits.
+#define SC_STEPS 2                        // k-steps per ring slot
+#define SC_SLOT_BYTES (SC_STEPS * 64 * 64) // 64 rows x 64 B per k-step
+#define SC_WAVE_BYTES (2 * SC_SLOT_BYTES)
+#define SCORE_LDS_BYTES(E) ((size_t)4 * SC_WAVE_BYTES + (size_t)(E) * 4)
 __global__ void __launch_bounds__(256) mfar_score_candidates_kernel(const ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* qs = (float*)smem;
+    float* qs = (float*)(smem + 4 * SC_WAVE_BYTES);
     const int qi = blockIdx.y;
     const int nc = p.n_cand ? p.n_cand[qi] : p.C;
     const int first = blockIdx.x * blockDim.x;
+    const int idx = first + threadIdx.x;
     if (first >= nc * p.F) {
         // slots past the candidate count: define the output (NaN) so downstream never reads garbage
-        const int idx = first + threadIdx.x;
         if (idx < p.C * p.F) p.out[(size_t)qi * p.C * p.F + idx] = __builtin_nanf("");
         return;
     }
     for (int e = threadIdx.x; e < p.E; e += blockDim.x) qs[e] = p.q[(size_t)qi * p.E + e];
     __syncthreads();
-    const int idx = first + threadIdx.x;
-    if (idx >= p.C * p.F) return;
-    const int c = idx / p.F, f = idx - c * p.F;
-    float acc = __builtin_nanf("");
-    if (c < nc) {
-        const long long id = p.cand[(size_t)qi * p.C + c] - p.row_offset;
-        if (id >= 0 && id < p.n_rows) {
-            const int rr = (int)(id & 63);
-            const int sw = (rr >> 2) & 3;
-            const float* base = p.slab + (size_t)f * p.field_stride + (size_t)(id >> 6) * p.n_steps * 1024 + rr * 16;
-            acc = 0.0f;
-            for (int s = 0; s < p.n_steps; ++s) {
-                const float* t = base + (size_t)s * 1024;
-                const f32x4 c0 = *(const f32x4*)(t + ((0 ^ sw) << 2));
-                const f32x4 c1 = *(const f32x4*)(t + ((1 ^ sw) << 2));
-                const f32x4 c2 = *(const f32x4*)(t + ((2 ^ sw) << 2));
-                const f32x4 c3 = *(const f32x4*)(t + ((3 ^ sw) << 2));
-                const float* qq = qs + s * 16;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    acc = __builtin_fmaf(qq[x], c0[x], acc);
-                    acc = __builtin_fmaf(qq[4 + x], c1[x], acc);
-                }
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    acc = __builtin_fmaf(qq[8 + x], c2[x], acc);
-                    acc = __builtin_fmaf(qq[12 + x], c3[x], acc);
-                }
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* ring = smem + w * SC_WAVE_BYTES;
+    // this lane's row
+    bool valid = false;
+    int sw = 0;
+    const char* rowbase = (const char*)p.slab;  // harmless in-bounds address for invalid rows
+    if (idx < p.C * p.F) {
+        const int c = idx / p.F, f = idx - c * p.F;
+        if (c < nc) {
+            const long long id = p.cand[(size_t)qi * p.C + c] - p.row_offset;
+            if (id >= 0 && id < p.n_rows) {
+                valid = true;
+                const int rr = (int)(id & 63);
+                sw = (rr >> 2) & 3;
+                rowbase = (const char*)(p.slab + (size_t)f * p.field_stride + (size_t)(id >> 6) * p.n_steps * 1024 + rr * 16);
             }
         }
     }
-    p.out[(size_t)qi * p.C * p.F + idx] = acc;
+    // lane l fetches piece (l & 3) of the segments of rows (l >> 2) + 16 * i, i = 0..3
+    const char* src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (lane >> 2) + 16 * i;
+        const unsigned long long b = (unsigned long long)rowbase;
+        const u32 lo = __shfl((int)(u32)b, r), hi = __shfl((int)(u32)(b >> 32), r);
+        src[i] = (const char*)(((unsigned long long)hi << 32) | lo) + (lane & 3) * 16;
+    }
+    const int n_groups = p.n_steps / SC_STEPS;  // n_steps is even (E % 32 == 0 is enforced by the host for this kernel)
+#define SC_ISSUE(G, SLOT)                                                                                          \
+    _Pragma("unroll") for (int s_ = 0; s_ < SC_STEPS; ++s_) _Pragma("unroll") for (int i = 0; i < 4; ++i)          \
+        __builtin_amdgcn_global_load_lds(                                                                         \
+            (const __attribute__((address_space(1))) void*)(src[i] + (size_t)((G) * SC_STEPS + s_) * 4096),       \
+            (__attribute__((address_space(3))) void*)(ring + (SLOT) * SC_SLOT_BYTES + s_ * 4096 + i * 1024), 16, 0, 0)
+    SC_ISSUE(0, 0);
+    float acc = 0.0f;
+    for (int g = 0; g < n_groups; ++g) {
+        const int slot = g & 1;
+        if (g + 1 < n_groups) {
+            SC_ISSUE(g + 1, slot ^ 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // SC_STEPS * 4 newest loads may stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const char* seg = ring + slot * SC_SLOT_BYTES + lane * 64;
+#pragma unroll
+        for (int s_ = 0; s_ < SC_STEPS; ++s_) {
+            const float* t = (const float*)(seg + s_ * 4096);
+            const f32x4 c0 = *(const f32x4*)(t + ((0 ^ sw) << 2));
+            const f32x4 c1 = *(const f32x4*)(t + ((1 ^ sw) << 2));
+            const f32x4 c2 = *(const f32x4*)(t + ((2 ^ sw) << 2));
+            const f32x4 c3 = *(const f32x4*)(t + ((3 ^ sw) << 2));
+            const float* qq = qs + (g * SC_STEPS + s_) * 16;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                acc = __builtin_fmaf(qq[x], c0[x], acc);
+                acc = __builtin_fmaf(qq[4 + x], c1[x], acc);
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                acc = __builtin_fmaf(qq[8 + x], c2[x], acc);
+                acc = __builtin_fmaf(qq[12 + x], c3[x], acc);
+            }
+        }
+        // the LDS reads of this slot have been consumed (their values fed the fma chain) before the slot is re-filled:
+        // the next SC_ISSUE into it is two iterations away in program order and ds_read results are waited for above
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#undef SC_ISSUE
+    if (idx < p.C * p.F) p.out[(size_t)qi * p.C * p.F + idx] = valid ? acc : __builtin_nanf("");
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -49,7 +49,7 @@ def test_argument_validation_without_device():
     L = _native.lib()
     h = ctypes.c_void_p()
     assert L.mfar_index_create(None, 0, 10, 0, 1, 32, 0) == -1
-    assert L.mfar_index_create(ctypes.byref(h), 0, 10, 0, 1, 33, 0) == -1      # dim % 16
+    assert L.mfar_index_create(ctypes.byref(h), 0, 10, 0, 1, 33, 0) == -1      # dim % 32
     assert L.mfar_index_create(ctypes.byref(h), 0, 10, 0, 99, 32, 0) == -1     # n_fields
     assert L.mfar_index_create(ctypes.byref(h), 0, -1, 0, 1, 32, 0) == -1
     assert L.mfar_index_create(ctypes.byref(h), 0, 2**32, 0, 1, 32, 0) == -1   # ids must fit 32 bits

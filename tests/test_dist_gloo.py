@@ -1,0 +1,131 @@
+"""Multi-rank orchestration on CPU (gloo, world_size 2): rank row split (contrastive.py:470), payload all-gather in
+shard-major order, identical merged answer on every rank, equality with the unsharded oracle.
+
+The two device calls (search_local / merge) are replaced by an ORACLE-BACKED TEST DOUBLE with its own payload format;
+the HIP implementations of the same two calls are checked against the same property on the GPU
+(tests/test_gpu_parity.py::test_sharded_search_equals_unsharded).  This file never touches the product kernels."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleShardBackend:
+    """Test double: per-shard lists + candidate score table via the C oracle, numpy merge."""
+
+    def __init__(self, slab, row_offset):
+        self.slab, self.row_offset = slab, row_offset
+        self.F, self.D, self.E = slab.shape
+
+    def search_local(self, q, k1, sentinel, payload=None):
+        from oracle import mfar_oracle as O
+        Q = q.shape[0]
+        ids = np.empty((Q, self.F, k1), np.int64)
+        sc = np.empty((Q, self.F, k1), np.float32)
+        for f in range(self.F):
+            ids[:, f], sc[:, f] = O.c_retrieve(self.slab[f], q, k1, sentinel, row_offset=self.row_offset)
+        C = self.F * k1
+        cand = np.full((Q, C), -1, np.int64)
+        for i in range(Q):
+            u = np.unique(ids[i][ids[i] >= 0])
+            cand[i, :u.size] = u
+        x = O.c_score_candidates(self.slab, q, cand, row_offset=self.row_offset)
+        hdr = np.array([self.row_offset, self.D, Q, self.F, k1], np.int64)
+        blob = np.concatenate([hdr.view(np.uint8), ids.view(np.uint8).ravel(), sc.view(np.uint8).ravel(),
+                               cand.view(np.uint8).ravel(), x.view(np.uint8).ravel()])
+        return torch.from_numpy(blob.copy())
+
+    def merge(self, gathered, n_shards, q, W, mask, k1, k2, sentinel, query_cond):
+        from oracle import mfar_oracle as O
+        g = gathered.numpy()
+        per = g.size // n_shards
+        shards = []
+        for s in range(n_shards):
+            b = g[s * per:(s + 1) * per]
+            ro, D, Q, F, k = b[:40].view(np.int64)
+            o = 40
+            n = Q * F * k
+            ids = b[o:o + n * 8].view(np.int64).reshape(Q, F, k); o += n * 8
+            sc = b[o:o + n * 4].view(np.float32).reshape(Q, F, k); o += n * 4
+            cand = b[o:o + Q * F * k * 8].view(np.int64).reshape(Q, F * k); o += Q * F * k * 8
+            x = b[o:o + Q * F * k * F * 4].view(np.float32).reshape(Q, F * k, F)
+            shards.append((int(ro), int(D), ids, sc, cand, x))
+        Q, F = shards[0][2].shape[:2]
+        out_ids = np.full((Q, k2), -1, np.int64)
+        out_sc = np.full((Q, k2), -np.inf, np.float32)
+        nv = np.zeros(Q, np.int32)
+        for i in range(Q):
+            merged = [O.c_merge_lists(np.stack([sh[2][i, f] for sh in shards]), np.stack([sh[3][i, f] for sh in shards]), sentinel)[0]
+                      for f in range(F)]
+            u = np.unique(np.concatenate(merged))
+            u = u[u >= 0]
+            xs = np.empty((u.size, F), np.float32)
+            for j, d in enumerate(u):
+                owner = [sh for sh in shards if sh[0] <= d < sh[0] + sh[1]][0]
+                slot = int(np.nonzero(owner[4][i] == d)[0][0])
+                xs[j] = owner[5][i, slot]
+            w = O.c_gate(q[i], W, query_cond)
+            ci, cs = O.canon(u, O.c_mix(xs, w, mask))
+            m = min(k2, u.size)
+            out_ids[i, :m], out_sc[i, :m], nv[i] = ci[:m], cs[:m], m
+        return dict(ids=out_ids, scores=out_sc, n_valid=nv)
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "multifield-adaptive-retrieval_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mfar.data.sharded import ShardedSearcher, shard_bounds
+    rng = np.random.default_rng(123)            # same corpus on every rank; each keeps only its slice
+    F, D, E, Q = 3, 901, 32, 5
+    slab = (rng.standard_normal((F, D, E)) * 0.5 + 0.1).astype(np.float32)
+    slab[:, 100:120] = slab[:, 100:101]          # ties across the shard boundary region
+    q = rng.standard_normal((Q, E)).astype(np.float32)
+    W = (rng.standard_normal((E, F)) * 0.1).astype(np.float32)
+    mask = np.array([1, 0, 1], np.float32)
+    r0, r1 = shard_bounds(D, rank, world)
+    searcher = ShardedSearcher(OracleShardBackend(slab[:, r0:r1].copy(), r0))
+    assert searcher.world_size == world and searcher.rank == rank
+    res = searcher.search(q, W, mask, k1=100, k2=100, sentinel=True)
+    np.savez(os.path.join(tmp, f"rank{rank}.npz"), r0=r0, r1=r1, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_cover_corpus_like_reference():
+    from mfar.data.sharded import shard_bounds
+    for n in (0, 1, 7, 1000, 129375, 957192):
+        for ws in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, ws) for r in range(ws)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[r][1] == b[r + 1][0] for r in range(ws - 1))
+            assert all(b[r] == (n * r // ws, n * (r + 1) // ws) for r in range(ws))   # contrastive.py:470
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_sharded_search_equals_unsharded(tmp_path):
+    world, port = 2, 29500 + (os.getpid() % 400)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    from oracle import mfar_oracle as O
+    rng = np.random.default_rng(123)
+    F, D, E, Q = 3, 901, 32, 5
+    slab = (rng.standard_normal((F, D, E)) * 0.5 + 0.1).astype(np.float32)
+    slab[:, 100:120] = slab[:, 100:101]
+    q = rng.standard_normal((Q, E)).astype(np.float32)
+    W = (rng.standard_normal((E, F)) * 0.1).astype(np.float32)
+    mask = np.array([1, 0, 1], np.float32)
+    ref = O.c_two_stage(slab, q, W, mask)
+    outs = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    assert (int(outs[0]["r0"]), int(outs[0]["r1"]), int(outs[1]["r0"]), int(outs[1]["r1"])) == (0, 450, 450, 901)
+    for o in outs:   # every rank computed the same, and it equals the unsharded oracle bit for bit
+        assert np.array_equal(o["ids"], ref["ids"])
+        assert np.array_equal(o["scores"].view(np.uint32), ref["scores"].view(np.uint32))
+        assert np.array_equal(o["n_valid"], ref["n_valid"])

@@ -9,7 +9,7 @@ from mfar.data.index import MultiFieldIndex
 from oracle import mfar_oracle as O
 
 rng = np.random.default_rng(0)
-for (F, D, E, Q, k) in [(1, 64, 16, 4, 64), (1, 256, 32, 64, 100), (2, 1000, 768, 7, 100)]:
+for (F, D, E, Q, k) in [(1, 64, 32, 4, 64), (1, 256, 32, 64, 100), (2, 1000, 768, 7, 100)]:
     slab = rng.standard_normal((F, D, E)).astype(np.float32)
     q = rng.standard_normal((Q, E)).astype(np.float32)
     ix = MultiFieldIndex(D, F, E)
