@@ -114,6 +114,16 @@ int mfar_search_two_stage(mfar_index* idx, const float* q, int Q, const float* W
                           int64_t* field_ids, float* field_scores, int32_t* n_cand, int on_device, void* stream);
 
 /*
+ * Second half of mfar_search_two_stage on its own: union (contrastive.py:678-679) -> stage 2 (:681-683) -> mask, field
+ * weights, top-k2 (:685-696), given the stage-1 lists produced by mfar_retrieve_fields.  Device pointers only, nothing
+ * synchronises.  `slot` (0/1) selects one of two internal workspaces: with mfar_retrieve_fields(batch i+1) on one stream
+ * and mfar_search_stage2(batch i) on another, two batches overlap on the GPU.
+ */
+int mfar_search_stage2(mfar_index* idx, const float* q, int Q, const float* W, int query_cond, const float* mask, int k1,
+                       int k2, const int64_t* field_ids, int slot, int64_t* ids, float* scores, int32_t* n_valid,
+                       int32_t* n_cand, void* stream);
+
+/*
  * Multi-GPU (row shards + one exchange, replaces the file-based exchange of contrastive.py:491-494,519-536):
  *   mfar_search_local  : stages 1+2 on this shard -> a fixed-size payload (mfar_payload_bytes) holding the shard's
  *                        per-field lists and the F-score vector of every local candidate;
@@ -122,11 +132,24 @@ int mfar_search_two_stage(mfar_index* idx, const float* q, int Q, const float* W
  *                        same answer.  With n_shards == 1 the result equals mfar_search_two_stage.
  */
 int64_t mfar_payload_bytes(int Q, int n_fields, int k1);
-int mfar_search_local(mfar_index* idx, const float* q, int Q, int k1, int sentinel, void* payload, int on_device,
-                      void* stream);
+/* phases: 1 = header + stage 1 (per-field lists), 2 = local union + stage 2 (reads the lists from the payload),
+ * 3 = both.  Split phases (device buffers only) let the caller run phase 2, the all-gather and the merge of batch i on a
+ * side stream while phase 1 of batch i+1 runs on the main stream. */
+int mfar_search_local(mfar_index* idx, const float* q, int Q, int k1, int sentinel, void* payload, int phases,
+                      int on_device, void* stream);
+/* workspace: optional caller-owned device scratch of mfar_merge_workspace_bytes() bytes (then the call never
+ * synchronises the stream); NULL = internal scratch shared per device, serialised and synchronised. */
+int64_t mfar_merge_workspace_bytes(int Q, int n_fields, int k1);
 int mfar_merge_payloads(int device, const void* payloads, int n_shards, const float* q, int Q, int E, const float* W,
                         int query_cond, const float* mask, int n_fields, int k1, int k2, int sentinel, int64_t* ids,
-                        float* scores, int32_t* n_valid, int on_device, void* stream);
+                        float* scores, int32_t* n_valid, void* workspace, int64_t workspace_bytes, int on_device,
+                        void* stream);
+
+/* Stream choreography helper for pipelined batches: make `stream` wait until the most recently enqueued FULL stage-1
+ * kernel of this handle is about to start (i.e. until everything enqueued before it, including the sample pass, has
+ * finished).  Work enqueued on `stream` afterwards (the light tail kernels of the previous batch) then runs BESIDE that
+ * long MFMA-bound kernel instead of delaying its start. */
+int mfar_stream_wait_stage1_start(mfar_index* idx, void* stream);
 
 /* Instrumentation used by bench.py: when enabled, every stage-1 kernel launch on this handle is bracketed by HIP
  * events recorded on the stream it is launched on.  mfar_set_timing(idx, 1) enables and resets the counters;

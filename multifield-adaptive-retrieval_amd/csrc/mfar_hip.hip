@@ -78,7 +78,8 @@ struct mfar_index {
     long long field_stride = 0;  // floats
     int n_cu = 256;
     int wgs_per_cu = 2;
-    DevBuf qt, lists, list_cnt, gtau, fid, fsc, cand, ncand, x, in[8], out[8];
+    DevBuf qt, lists, list_cnt, gtau, fid, fsc, cand[2], ncand[2], x[2], in[8], out[8];
+    hipEvent_t mid_ev = nullptr;  // recorded right before the full stage-1 kernel is launched
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
     int ev_n = 0;
@@ -165,7 +166,9 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     (void)hipSetDevice(idx->device);
     (void)hipDeviceSynchronize();
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&idx->qt, &idx->lists, &idx->list_cnt, &idx->gtau, &idx->fid, &idx->fsc, &idx->cand, &idx->ncand, &idx->x};
+    if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
+    DevBuf* bufs[] = {&idx->qt, &idx->lists, &idx->list_cnt, &idx->gtau, &idx->fid, &idx->fsc, &idx->cand[0], &idx->cand[1],
+                      &idx->ncand[0], &idx->ncand[1], &idx->x[0], &idx->x[1]};
     for (DevBuf* b : bufs) b->release();
     for (auto& b : idx->in) b.release();
     for (auto& b : idx->out) b.release();
@@ -188,6 +191,14 @@ extern "C" int mfar_index_info(const mfar_index* idx, int64_t* n_rows_local, int
 extern "C" int mfar_set_wgs_per_cu(mfar_index* idx, int wgs) {
     if (!idx || wgs < 1 || wgs > 8) return fail(MFAR_ERR_INVALID, "wgs must be in [1, 8]");
     idx->wgs_per_cu = wgs;
+    return MFAR_OK;
+}
+
+extern "C" int mfar_stream_wait_stage1_start(mfar_index* idx, void* stream) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    if (!idx->mid_ev) return MFAR_OK;  // no stage-1 launch yet: nothing to wait for
+    HIPCHK(hipSetDevice(idx->device));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, idx->mid_ev, 0));
     return MFAR_OK;
 }
 
@@ -411,6 +422,8 @@ static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentine
             idx->ev_n++;
             HIPCHK(hipEventRecord(e0, st));
         }
+        if (!idx->mid_ev) HIPCHK(hipEventCreateWithFlags(&idx->mid_ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(idx->mid_ev, st));
         mfar_stage1_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1_LDS_BYTES, st>>>(p);
         HIPCHK(hipGetLastError());
         if (e1) HIPCHK(hipEventRecord(e1, st));
@@ -507,7 +520,7 @@ static int run_mix(const float* x, const long long* cand, const int* ncand, cons
     p.k = k;
     p.query_cond = query_cond;
     if (Q == 0) return MFAR_OK;
-    const size_t lds = MIX_LDS_BYTES(query_cond ? E : 0, F);
+    const size_t lds = MIX_LDS_BYTES(C, query_cond ? E : 0, F);
     if (lds > 160 * 1024) return fail(MFAR_ERR_UNSUPPORTED, "dim * n_fields too large for the mixer kernel's LDS staging");
     mfar_mix_topk_kernel<<<dim3(Q), dim3(256), lds, st>>>(p);
     HIPCHK(hipGetLastError());
@@ -563,6 +576,27 @@ extern "C" int mfar_mix_topk(int device, const float* cand_scores, const int64_t
 }
 
 // ------------------------------------------------------------------------------------------------ full scorer
+// union -> stage 2 -> mixer, all pointers on the device; `slot` selects one of two internal workspaces so that two
+// batches can be in flight on different streams
+static int run_stage2_mix(mfar_index* idx, const float* qd, int Q, const float* Wd, int query_cond, const float* md, int k1,
+                          int k2, const long long* fid, int slot, long long* idd, float* scd, int* nvd, int* ncd_out,
+                          hipStream_t st) {
+    const int F = idx->F, E = idx->E, C = F * k1;
+    int* ncd = ncd_out;
+    if (!ncd) {
+        RETCHK(idx->ncand[slot].ensure((size_t)Q * 4));
+        ncd = idx->ncand[slot].as<int>();
+    }
+    RETCHK(idx->cand[slot].ensure((size_t)Q * C * 8));
+    RETCHK(idx->x[slot].ensure((size_t)Q * C * F * 4));
+    mfar_union_kernel<<<dim3(Q), dim3(256), 0, st>>>(fid, F, k1, idx->cand[slot].as<long long>(), ncd);
+    HIPCHK(hipGetLastError());
+    RETCHK(run_score(idx, qd, Q, idx->cand[slot].as<long long>(), ncd, C, idx->x[slot].as<float>(), st));
+    RETCHK(run_mix(idx->x[slot].as<float>(), idx->cand[slot].as<long long>(), ncd, qd, Wd, query_cond, md, Q, C, F, E, k2, idd,
+                   scd, nvd, st));
+    return MFAR_OK;
+}
+
 extern "C" int mfar_search_two_stage(mfar_index* idx, const float* q, int Q, const float* W, int query_cond,
                                      const float* mask, int k1, int k2, int sentinel, int64_t* ids, float* scores,
                                      int32_t* n_valid, int64_t* field_ids, float* field_scores, int32_t* n_cand,
@@ -599,16 +633,11 @@ extern "C" int mfar_search_two_stage(mfar_index* idx, const float* q, int Q, con
     }
     if (n_cand && on_device) ncd = (int*)n_cand;
     else {
-        RETCHK(idx->ncand.ensure((size_t)Q * 4));
-        ncd = idx->ncand.as<int>();
+        RETCHK(idx->ncand[0].ensure((size_t)Q * 4));
+        ncd = idx->ncand[0].as<int>();
     }
-    RETCHK(idx->cand.ensure((size_t)Q * C * 8));
-    RETCHK(idx->x.ensure((size_t)Q * C * F * 4));
     RETCHK(run_stage1(idx, qd, Q, k1, sentinel, fid, fsc, st));
-    mfar_union_kernel<<<dim3(Q), dim3(256), 0, st>>>(fid, F, k1, idx->cand.as<long long>(), ncd);
-    HIPCHK(hipGetLastError());
-    RETCHK(run_score(idx, qd, Q, idx->cand.as<long long>(), ncd, C, idx->x.as<float>(), st));
-    RETCHK(run_mix(idx->x.as<float>(), idx->cand.as<long long>(), ncd, qd, Wd, query_cond, md, Q, C, F, E, k2, idd, scd, nvd, st));
+    RETCHK(run_stage2_mix(idx, qd, Q, Wd, query_cond, md, k1, k2, fid, 0, idd, scd, nvd, ncd, st));
     RETCHK(copy_back((long long*)ids, idd, (size_t)Q * k2, on_device, st));
     RETCHK(copy_back(scores, scd, (size_t)Q * k2, on_device, st));
     RETCHK(copy_back((int*)n_valid, nvd, (size_t)Q, on_device, st));
@@ -619,6 +648,20 @@ extern "C" int mfar_search_two_stage(mfar_index* idx, const float* q, int Q, con
         HIPCHK(hipStreamSynchronize(st));
     }
     return MFAR_OK;
+}
+
+extern "C" int mfar_search_stage2(mfar_index* idx, const float* q, int Q, const float* W, int query_cond, const float* mask,
+                                  int k1, int k2, const int64_t* field_ids, int slot, int64_t* ids, float* scores,
+                                  int32_t* n_valid, int32_t* n_cand, void* stream) {
+    RETCHK(check_search_common(idx, q, Q, k1));
+    const int F = idx->F, E = idx->E, C = F * k1;
+    RETCHK(check_mix(Q, C, F, E, k2, q, W, query_cond));
+    if (Q == 0) return MFAR_OK;
+    if (!ids || !scores || !field_ids) return fail(MFAR_ERR_INVALID, "NULL pointer");
+    if (slot < 0 || slot > 1) return fail(MFAR_ERR_INVALID, "slot must be 0 or 1");
+    HIPCHK(hipSetDevice(idx->device));
+    return run_stage2_mix(idx, q, Q, W, query_cond, mask, k1, k2, (const long long*)field_ids, slot, (long long*)ids, scores,
+                          (int*)n_valid, (int*)n_cand, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------ multi-GPU
@@ -638,15 +681,38 @@ static PayloadLayout payload_layout(int Q, int F, int k1) {
     L.total = up(L.x + (long long)Q * C * F * 4);
     return L;
 }
+struct MergeWsLayout {
+    long long lids, lsc, cand, ncand, x, total;
+};
+static MergeWsLayout merge_ws_layout(int Q, int F, int k1) {
+    auto up = [](long long v) { return (v + 255) & ~255LL; };
+    MergeWsLayout L;
+    const long long C = (long long)F * k1;
+    L.lids = 0;
+    L.lsc = up(L.lids + (long long)Q * F * k1 * 8);
+    L.cand = up(L.lsc + (long long)Q * F * k1 * 4);
+    L.ncand = up(L.cand + (long long)Q * C * 8);
+    L.x = up(L.ncand + (long long)Q * 4);
+    L.total = up(L.x + (long long)Q * C * F * 4);
+    return L;
+}
+extern "C" int64_t mfar_merge_workspace_bytes(int Q, int n_fields, int k1) {
+    if (Q < 0 || n_fields <= 0 || k1 <= 0) return 0;
+    return merge_ws_layout(Q, n_fields, k1).total;
+}
+__global__ void mfar_write_header_kernel(PayloadHeader* dst, const PayloadHeader h) { *dst = h; }
+
 extern "C" int64_t mfar_payload_bytes(int Q, int n_fields, int k1) {
     if (Q < 0 || n_fields <= 0 || k1 <= 0) return 0;
     return payload_layout(Q, n_fields, k1).total;
 }
 
-extern "C" int mfar_search_local(mfar_index* idx, const float* q, int Q, int k1, int sentinel, void* payload, int on_device,
-                                 void* stream) {
+extern "C" int mfar_search_local(mfar_index* idx, const float* q, int Q, int k1, int sentinel, void* payload, int phases,
+                                 int on_device, void* stream) {
     RETCHK(check_search_common(idx, q, Q, k1));
     if (!payload) return fail(MFAR_ERR_INVALID, "payload is NULL");
+    if (phases < 1 || phases > 3) return fail(MFAR_ERR_INVALID, "phases must be 1, 2 or 3");
+    if (phases != 3 && !on_device) return fail(MFAR_ERR_INVALID, "split phases need device buffers");
     const int F = idx->F, E = idx->E, C = F * k1;
     if (C > 4096) return fail(MFAR_ERR_INVALID, "n_fields * k1 must be <= 4096");
     if (E * 4 > 60 * 1024) return fail(MFAR_ERR_UNSUPPORTED, "dim too large for the stage-2 kernel");
@@ -666,18 +732,22 @@ extern "C" int mfar_search_local(mfar_index* idx, const float* q, int Q, int k1,
     h.row_offset = idx->row_offset;
     h.n_rows = idx->n_rows;
     h.sentinel = sentinel;
-    HIPCHK(hipMemcpyAsync(pd + L.hdr, &h, sizeof(h), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));  // h lives on this stack frame
+    if (phases & 1) {
+        mfar_write_header_kernel<<<dim3(1), dim3(1), 0, st>>>((PayloadHeader*)(pd + L.hdr), h);
+        HIPCHK(hipGetLastError());
+    }
     if (Q > 0) {
         long long* fid = (long long*)(pd + L.ids);
         float* fsc = (float*)(pd + L.scores);
         long long* cand = (long long*)(pd + L.cand);
         int* ncd = (int*)(pd + L.ncand);
         float* x = (float*)(pd + L.x);
-        RETCHK(run_stage1(idx, qd, Q, k1, sentinel, fid, fsc, st));
-        mfar_union_kernel<<<dim3(Q), dim3(256), 0, st>>>(fid, F, k1, cand, ncd);
-        HIPCHK(hipGetLastError());
-        RETCHK(run_score(idx, qd, Q, cand, ncd, C, x, st));
+        if (phases & 1) RETCHK(run_stage1(idx, qd, Q, k1, sentinel, fid, fsc, st));
+        if (phases & 2) {
+            mfar_union_kernel<<<dim3(Q), dim3(256), 0, st>>>(fid, F, k1, cand, ncd);
+            HIPCHK(hipGetLastError());
+            RETCHK(run_score(idx, qd, Q, cand, ncd, C, x, st));
+        }
     }
     RETCHK(copy_back((char*)payload, pd, (size_t)L.total, on_device, st));
     if (!on_device) HIPCHK(hipStreamSynchronize(st));
@@ -686,7 +756,8 @@ extern "C" int mfar_search_local(mfar_index* idx, const float* q, int Q, int k1,
 
 extern "C" int mfar_merge_payloads(int device, const void* payloads, int n_shards, const float* q, int Q, int E,
                                    const float* W, int query_cond, const float* mask, int n_fields, int k1, int k2,
-                                   int sentinel, int64_t* ids, float* scores, int32_t* n_valid, int on_device, void* stream) {
+                                   int sentinel, int64_t* ids, float* scores, int32_t* n_valid, void* workspace,
+                                   int64_t workspace_bytes, int on_device, void* stream) {
     const int F = n_fields, C = F * k1;
     if (!payloads || n_shards <= 0 || n_shards > 64) return fail(MFAR_ERR_INVALID, "bad payloads / n_shards");
     if (k1 <= 0 || k1 > MFAR_MAX_K) return fail(MFAR_ERR_INVALID, "k1 must be in [1, 128]");
@@ -700,7 +771,11 @@ extern "C" int mfar_merge_payloads(int device, const void* payloads, int n_shard
     RETCHK(set_kernel_attrs(device));
     hipStream_t st = (hipStream_t)stream;
     DevCtx& cx = g_ctx[device];
-    std::unique_lock<std::mutex> lk(cx.mu);
+    const bool own_ws = workspace != nullptr;
+    if (own_ws && !on_device) return fail(MFAR_ERR_INVALID, "a caller workspace needs device buffers");
+    if (own_ws && workspace_bytes < mfar_merge_workspace_bytes(Q, F, k1)) return fail(MFAR_ERR_INVALID, "workspace too small");
+    std::unique_lock<std::mutex> lk(cx.mu, std::defer_lock);
+    if (!own_ws) lk.lock();
     const PayloadLayout L = payload_layout(Q, F, k1);
     const char* pd;
     const float *qd, *Wd, *md;
@@ -714,18 +789,36 @@ extern "C" int mfar_merge_payloads(int device, const void* payloads, int n_shard
     RETCHK(stage_out(cx.out[0], (long long*)ids, (size_t)Q * k2, on_device, &idd));
     RETCHK(stage_out(cx.out[1], scores, (size_t)Q * k2, on_device, &scd));
     RETCHK(stage_out(cx.out[2], (int*)n_valid, (size_t)Q, on_device, &nvd));
-    RETCHK(cx.lists_ids.ensure((size_t)Q * F * k1 * 8));
-    RETCHK(cx.lists_sc.ensure((size_t)Q * F * k1 * 4));
-    RETCHK(cx.cand.ensure((size_t)Q * C * 8));
-    RETCHK(cx.ncand.ensure((size_t)Q * 4));
-    RETCHK(cx.x.ensure((size_t)Q * C * F * 4));
+    long long *w_lids, *w_cand;
+    float *w_lsc, *w_x;
+    int* w_ncand;
+    if (own_ws) {
+        const MergeWsLayout wl = merge_ws_layout(Q, F, k1);
+        char* wb = (char*)workspace;
+        w_lids = (long long*)(wb + wl.lids);
+        w_lsc = (float*)(wb + wl.lsc);
+        w_cand = (long long*)(wb + wl.cand);
+        w_ncand = (int*)(wb + wl.ncand);
+        w_x = (float*)(wb + wl.x);
+    } else {
+        RETCHK(cx.lists_ids.ensure((size_t)Q * F * k1 * 8));
+        RETCHK(cx.lists_sc.ensure((size_t)Q * F * k1 * 4));
+        RETCHK(cx.cand.ensure((size_t)Q * C * 8));
+        RETCHK(cx.ncand.ensure((size_t)Q * 4));
+        RETCHK(cx.x.ensure((size_t)Q * C * F * 4));
+        w_lids = cx.lists_ids.as<long long>();
+        w_lsc = cx.lists_sc.as<float>();
+        w_cand = cx.cand.as<long long>();
+        w_ncand = cx.ncand.as<int>();
+        w_x = cx.x.as<float>();
+    }
     ShardMergeParams sp;
     sp.payloads = pd;
     sp.payload_stride = L.total;
     sp.ids_off = L.ids;
     sp.scores_off = L.scores;
-    sp.out_ids = cx.lists_ids.as<long long>();
-    sp.out_scores = cx.lists_sc.as<float>();
+    sp.out_ids = w_lids;
+    sp.out_scores = w_lsc;
     sp.S = n_shards;
     sp.F = F;
     sp.k = k1;
@@ -733,7 +826,7 @@ extern "C" int mfar_merge_payloads(int device, const void* payloads, int n_shard
     if (n_shards * k1 <= 8 * 256) mfar_merge_shards_kernel<8><<<dim3(Q * F), dim3(256), SEL_LDS_BYTES(n_shards * k1), st>>>(sp);
     else mfar_merge_shards_kernel<32><<<dim3(Q * F), dim3(256), SEL_LDS_BYTES(n_shards * k1), st>>>(sp);
     HIPCHK(hipGetLastError());
-    mfar_union_kernel<<<dim3(Q), dim3(256), 0, st>>>(sp.out_ids, F, k1, cx.cand.as<long long>(), cx.ncand.as<int>());
+    mfar_union_kernel<<<dim3(Q), dim3(256), 0, st>>>(sp.out_ids, F, k1, w_cand, w_ncand);
     HIPCHK(hipGetLastError());
     LookupParams lp;
     lp.payloads = pd;
@@ -742,20 +835,19 @@ extern "C" int mfar_merge_payloads(int device, const void* payloads, int n_shard
     lp.cand_off = L.cand;
     lp.ncand_off = L.ncand;
     lp.x_off = L.x;
-    lp.cand = cx.cand.as<long long>();
-    lp.n_cand = cx.ncand.as<int>();
-    lp.out = cx.x.as<float>();
+    lp.cand = w_cand;
+    lp.n_cand = w_ncand;
+    lp.out = w_x;
     lp.S = n_shards;
     lp.F = F;
     lp.C = C;
     mfar_lookup_kernel<<<dim3((C + 255) / 256, Q), dim3(256), 0, st>>>(lp);
     HIPCHK(hipGetLastError());
-    RETCHK(run_mix(cx.x.as<float>(), cx.cand.as<long long>(), cx.ncand.as<int>(), qd, Wd, query_cond, md, Q, C, F, E, k2, idd,
-                   scd, nvd, st));
+    RETCHK(run_mix(w_x, w_cand, w_ncand, qd, Wd, query_cond, md, Q, C, F, E, k2, idd, scd, nvd, st));
     RETCHK(copy_back((long long*)ids, idd, (size_t)Q * k2, on_device, st));
     RETCHK(copy_back(scores, scd, (size_t)Q * k2, on_device, st));
     RETCHK(copy_back((int*)n_valid, nvd, (size_t)Q, on_device, st));
     // the shared scratch is reused by the next call: finish before releasing the lock
-    HIPCHK(hipStreamSynchronize(st));
+    if (!own_ws) HIPCHK(hipStreamSynchronize(st));
     return MFAR_OK;
 }

@@ -56,7 +56,7 @@ struct MergeParams {
 // LDS carve-up shared by the selection kernels (everything in the dynamic region: 16-byte aligned base)
 //   keys[n_keys] u64 | sel[MFAR_MAX_K] u64 | sorted[MFAR_MAX_K] u64 | red[32] int | misc[4] int
 #define SEL_LDS_BYTES(n_keys) ((size_t)(n_keys) * 8 + 2 * MFAR_MAX_K * 8 + 36 * 4)
-#define MIX_LDS_BYTES(E, F) (SEL_LDS_BYTES(4096) + 3 * MFAR_MAX_FIELDS * 4 + (size_t)(E) * 4 + (size_t)(E) * (F) * 4)
+#define MIX_LDS_BYTES(C, E, F) (SEL_LDS_BYTES(C) + 3 * MFAR_MAX_FIELDS * 4 + (size_t)(E) * 4 + (size_t)(E) * (F) * 4)
 struct SelLds {
     u64* keys;
     u64* sel;
@@ -234,7 +234,8 @@ struct ScoreParams {
 // (one per k-step), so the wave gathers them cooperatively -- 4 lanes per segment, 16 segments per 1 KB LDS-DMA
 // instruction -- into a private two-slot LDS ring (2 k-steps per slot), and every lane then walks ITS row's segment
 // from LDS in chain order.  No barriers: the ring is private to the wave, ordered by counted vmcnt waits.
-#define SC_STEPS 2                        // k-steps per ring slot
+#define SC_STEPS 1                        // k-steps per ring slot (1 keeps the workgroup at 35 KB of LDS so that it can
+                                          // run beside two resident stage-1 workgroups when batches are pipelined)
 #define SC_SLOT_BYTES (SC_STEPS * 64 * 64) // 64 rows x 64 B per k-step
 #define SC_WAVE_BYTES (2 * SC_SLOT_BYTES)
 #define SCORE_LDS_BYTES(E) ((size_t)4 * SC_WAVE_BYTES + (size_t)(E) * 4)
@@ -292,7 +293,7 @@ __global__ void __launch_bounds__(256) mfar_score_candidates_kernel(const ScoreP
         const int slot = g & 1;
         if (g + 1 < n_groups) {
             SC_ISSUE(g + 1, slot ^ 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // SC_STEPS * 4 newest loads may stay in flight
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // SC_STEPS * 4 newest loads may stay in flight
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -396,7 +397,7 @@ struct MixParams {
 };
 __global__ void __launch_bounds__(256) mfar_mix_topk_kernel(const MixParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const SelLds L = sel_lds(smem, 4096);
+    const SelLds L = sel_lds(smem, p.C);
     u64* keys = L.keys;
     u64 *sel = L.sel, *sorted = L.sorted;
     int* red = L.red;

@@ -198,7 +198,26 @@ class MultiFieldIndex:
     def payload_bytes(self, Q: int, k1: int = 100) -> int:
         return int(_native.lib().mfar_payload_bytes(int(Q), self.n_fields, int(k1)))
 
-    def search_local(self, q, k1: int = 100, sentinel: bool = True, payload=None):
+    def search_stage2(self, q, W, field_ids, mask=None, k1: int = 100, k2: int = 100, query_cond: bool = True, slot: int = 0,
+                      out=None):
+        """Second half of `search` given the stage-1 lists (device tensors only, asynchronous on the current stream)."""
+        qa, Wa = _Arg(q, np.float32, self.device), _Arg(W, np.float32, self.device)
+        ma = _Arg(mask, np.float32, self.device, allow_none=True)
+        fa = _Arg(field_ids, np.int64, self.device)
+        if not _same_side([qa, Wa, ma, fa]):
+            raise ValueError("search_stage2 needs CUDA tensors")
+        Q = qa.keep.shape[0]
+        out = dict(out) if out else {}
+        ids = out.get("ids") if out.get("ids") is not None else _empty_like_side(True, self.device, (Q, k2), np.int64)
+        sc = out.get("scores") if out.get("scores") is not None else _empty_like_side(True, self.device, (Q, k2), np.float32)
+        nv = out.get("n_valid") if out.get("n_valid") is not None else _empty_like_side(True, self.device, (Q,), np.int32)
+        ia, sa, na = _Arg(ids, np.int64, self.device), _Arg(sc, np.float32, self.device), _Arg(nv, np.int32, self.device)
+        _native.check(_native.lib().mfar_search_stage2(
+            self._h, qa.ptr, Q, Wa.ptr, int(bool(query_cond)), ma.ptr, int(k1), int(k2), fa.ptr, int(slot),
+            ia.ptr, sa.ptr, na.ptr, None, _current_stream(self.device, True)))
+        return dict(ids=ids, scores=sc, n_valid=nv)
+
+    def search_local(self, q, k1: int = 100, sentinel: bool = True, payload=None, phases: int = 3):
         qa = _Arg(q, np.float32, self.device)
         Q = qa.keep.shape[0]
         nbytes = self.payload_bytes(Q, k1)
@@ -208,7 +227,7 @@ class MultiFieldIndex:
         have = payload.numel() if _is_torch(payload) else pa.keep.size
         if have < nbytes:
             raise ValueError("payload buffer too small")
-        _native.check(_native.lib().mfar_search_local(self._h, qa.ptr, Q, int(k1), int(bool(sentinel)), pa.ptr,
+        _native.check(_native.lib().mfar_search_local(self._h, qa.ptr, Q, int(k1), int(bool(sentinel)), pa.ptr, int(phases),
                                                        int(qa.on_device), _current_stream(self.device, qa.on_device)))
         return payload
 
@@ -225,8 +244,12 @@ class MultiFieldIndex:
         _native.check(_native.lib().mfar_set_wgs_per_cu(self._h, int(n)))
 
 
+def merge_workspace_bytes(Q: int, n_fields: int, k1: int = 100) -> int:
+    return int(_native.lib().mfar_merge_workspace_bytes(int(Q), int(n_fields), int(k1)))
+
+
 def merge_payloads(payloads, n_shards: int, q, W, mask=None, n_fields: int = None, k1: int = 100, k2: int = 100,
-                   sentinel: bool = True, query_cond: bool = True, device: int = 0):
+                   sentinel: bool = True, query_cond: bool = True, device: int = 0, workspace=None, out=None):
     """Merge the all-gathered per-shard payloads (concatenated, shard-major) into the final top-k2.
     Replaces the per-rank .qres files + rank-0 merge of the reference (contrastive.py:519-536, 566-581)."""
     qa, Wa = _Arg(q, np.float32, device), _Arg(W, np.float32, device)
@@ -236,13 +259,16 @@ def merge_payloads(payloads, n_shards: int, q, W, mask=None, n_fields: int = Non
     Q, E = qa.keep.shape
     if n_fields is None:
         n_fields = Wa.keep.shape[-1] if query_cond else int(np.prod(Wa.keep.shape))
-    ids = _empty_like_side(on_dev, device, (Q, k2), np.int64)
-    sc = _empty_like_side(on_dev, device, (Q, k2), np.float32)
-    nv = _empty_like_side(on_dev, device, (Q,), np.int32)
+    out = dict(out) if out else {}
+    ids = out.get("ids") if out.get("ids") is not None else _empty_like_side(on_dev, device, (Q, k2), np.int64)
+    sc = out.get("scores") if out.get("scores") is not None else _empty_like_side(on_dev, device, (Q, k2), np.float32)
+    nv = out.get("n_valid") if out.get("n_valid") is not None else _empty_like_side(on_dev, device, (Q,), np.int32)
     ia, sa, na = _Arg(ids, np.int64, device), _Arg(sc, np.float32, device), _Arg(nv, np.int32, device)
+    wa = _Arg(workspace, np.uint8, device, allow_none=True)
+    wbytes = int(workspace.numel()) if workspace is not None else 0
     _native.check(_native.lib().mfar_merge_payloads(
         int(device), pa.ptr, int(n_shards), qa.ptr, Q, E, Wa.ptr, int(bool(query_cond)), ma.ptr, int(n_fields), int(k1), int(k2),
-        int(bool(sentinel)), ia.ptr, sa.ptr, na.ptr, int(on_dev), _current_stream(device, on_dev)))
+        int(bool(sentinel)), ia.ptr, sa.ptr, na.ptr, wa.ptr, wbytes, int(on_dev), _current_stream(device, on_dev)))
     return dict(ids=ids, scores=sc, n_valid=nv)
 
 

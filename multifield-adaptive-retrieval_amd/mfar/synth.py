@@ -58,6 +58,9 @@ class SyntheticCorpus:
 
     # ------------------------------------------------------------------ data
     def queries(self, i0: int, n: int) -> torch.Tensor:
+        i0 %= self.NQ
+        if i0 + n <= self.NQ:
+            return self.q_all[i0:i0 + n]       # a view: no copy, no host synchronisation
         idx = (torch.arange(i0, i0 + n) % self.NQ).to(self.device)
         return self.q_all.index_select(0, idx).contiguous()
 

@@ -56,6 +56,7 @@ def test_argument_validation_without_device():
     assert L.mfar_index_create(ctypes.byref(h), 0, 10, 0, 1, 32, 1) == -4      # bf16 not in this build
     assert L.mfar_payload_bytes(64, 8, 100) > 64 * 800 * 8 * 4
     assert L.mfar_payload_bytes(-1, 8, 100) == 0
+    assert L.mfar_merge_workspace_bytes(64, 8, 100) > 64 * 800 * 8 * 4
     assert L.mfar_retrieve_fields(None, None, 1, 100, 1, None, None, 0, None) == -1
     assert L.mfar_set_wgs_per_cu(None, 2) == -1
 

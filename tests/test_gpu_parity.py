@@ -312,3 +312,35 @@ def test_full_size_properties(idxmod):
     # spot check against the oracle on a row subset that contains every returned doc for 2 queries
     for s in shards:
         s.close()
+
+
+def test_pipelined_searcher_equals_plain_search(idxmod):
+    """Two batches in flight on two streams (stage 1 of batch i+1 beside the tail of batch i) must not change a bit."""
+    import torch
+    from mfar.data.pipeline import PipelinedSearcher
+    rng = np.random.default_rng(9)
+    F, D, E, Q = 4, 6000, 64, 32
+    slab, _, W = _mk(rng, F, D, E, 1, mean=0.2, dup=5)
+    ix = _load(idxmod, slab)
+    dev = torch.device("cuda:0")
+    Wd = torch.from_numpy(W).to(dev)
+    mask = torch.tensor([1, 1, 0, 1], dtype=torch.float32, device=dev)
+    qs = [(rng.standard_normal((Q, E)) * 0.5 + 0.3).astype(np.float32) for _ in range(7)]
+    ps = PipelinedSearcher(ix, Wd, mask, max_batch=Q)
+    tickets, got = [], []
+    for i, q in enumerate(qs):
+        tickets.append(ps.submit(torch.from_numpy(q).to(dev)))
+        if i >= 1:
+            r = ps.result(tickets[i - 1])
+            got.append({k: v.clone() for k, v in r.items()})
+    r = ps.result(tickets[-1])
+    got.append({k: v.clone() for k, v in r.items()})
+    torch.cuda.synchronize()
+    for q, g in zip(qs, got):
+        ref = ix.search(q, W, mask.cpu().numpy())
+        assert np.array_equal(g["ids"].cpu().numpy(), ref["ids"])
+        assert np.array_equal(g["scores"].cpu().numpy().view(np.uint32), ref["scores"].view(np.uint32))
+        assert np.array_equal(g["n_valid"].cpu().numpy(), ref["n_valid"])
+    with pytest.raises(ValueError):
+        ps.result(tickets[0])
+    ix.close()
