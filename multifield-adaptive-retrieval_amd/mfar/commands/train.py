@@ -1,0 +1,275 @@
+"""`python -m mfar.commands.train ...` -- contrastive fine-tuning + final TREC evaluation (reference
+mfar/commands/train.py), without PyTorch-Lightning.
+
+Same keyword-only flags as the reference `main` (pinned by tests/golden/cli_signatures.json) and the same output files:
+`{out}/epoch=E-valid_loss=X.ckpt`, `last.ckpt` (Lightning key layout, readable by `mask_fields`), `best.txt`,
+`{rank}.qres`, `final-all-0.qres`, `results_dicts-all-0.jsonl`.  The evaluation after (and, with --trec_val_freq, during)
+training is the accelerated path: corpus encode into the HBM slab + `mfar_search_two_stage`.
+
+Training itself is stock PyTorch-ROCm (out of scope for kernels): one process per GPU, two AdamW optimisers
+(encoder / field weights, contrastive.py:305-374), `HybridContrastiveLoss` with in-batch negatives and the autograd-aware
+all-gather, early stopping on the proxy validation loss (train.py:225-240).  Two documented differences: the hard
+negative of an instance is a random corpus document instead of a BM25-mined one (`bm25s` is not installed and sparse
+indices are out of scope), and `--lexical_index` / `--sparse_scores_path` are accepted but unused.
+"""
+import json
+import os
+import random
+import time
+from typing import *  # noqa: F401,F403
+
+import torch
+
+from mfar.commands._cli import run
+from mfar.commands.mask_fields import init_distributed_from_env
+from mfar.data import trec
+from mfar.data.format import format_documents
+from mfar.data.schema import resolve_fields
+from mfar.data.typedef import FieldType
+from mfar.modeling.contrastive import RetrievalDataModule, RetrievalTrainingModule
+from mfar.modeling.losses import HybridContrastiveLoss
+from mfar.modeling.util import prepare_model, read_and_create_indices
+
+
+def _rank_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _autocast(precision: str, device):
+    if precision.startswith("bf16"):
+        return torch.autocast(device_type="cuda", dtype=torch.bfloat16)
+    if precision.startswith("16"):
+        return torch.autocast(device_type="cuda", dtype=torch.float16)
+    return torch.autocast(device_type="cuda", enabled=False)
+
+
+class _Instances:
+    """(query, positive doc, one negative doc) triples from `<partition>.queries` / `<partition>.qrels`."""
+
+    def __init__(self, queries_path, partition, corpus, seed):
+        self.queries = dict(trec.read_corpus(f"{queries_path}/{partition}.queries"))
+        with open(f"{queries_path}/{partition}.qrels") as f:
+            self.qrels = [r for r in trec.QRels.from_text_io(f) if r.relevance > 0 and r.query_id in self.queries]
+        self.corpus = corpus
+        self.key_to_row = {k: i for i, (k, _) in enumerate(corpus)}
+        self.qrels = [r for r in self.qrels if r.doc_id in self.key_to_row]
+        self.rng = random.Random(seed)
+
+    def batches(self, batch_size, rank, world, shuffle):
+        order = list(range(len(self.qrels)))
+        if shuffle:
+            self.rng.shuffle(order)                      # same seed on every rank -> same order
+        usable = (len(order) // (batch_size * world)) * batch_size * world or len(order)
+        order = order[:usable]
+        for b in range(rank * batch_size, len(order), batch_size * world):
+            rows = [self.qrels[i] for i in order[b:b + batch_size]]
+            if rows:
+                negs = []
+                for r in rows:
+                    n = self.rng.randrange(len(self.corpus))
+                    while self.corpus[n][0] == r.doc_id and len(self.corpus) > 1:
+                        n = self.rng.randrange(len(self.corpus))
+                    negs.append(n)
+                yield rows, negs
+
+
+def _encode_fields(module, tokenizer, docs, max_length, device):
+    """[(id, json)] -> [B, F, E] (one encoder forward per dense field, contrastive.py:412-414)."""
+    outs = []
+    for field in module.field_info.values():
+        if field.field_type != FieldType.DENSE:
+            continue
+        texts = [t for _, t in format_documents(docs, field.name, field.dataset)]
+        if module.prefix:
+            texts = [field.name + ": " + t for t in texts]
+        toks = tokenizer(texts, padding=True, truncation=True, max_length=min(max_length, field.max_seq_length, module.encoder.get_max_seq_length()),
+                         return_tensors="pt")
+        outs.append(module.encoder({k: v.to(device) for k, v in toks.items()})["sentence_embedding"])
+    return torch.stack(outs, dim=1)
+
+
+def _loss_on_batch(module, loss_fn, tokenizer, inst, rows, negs, max_length, device, precision):
+    qt = tokenizer([inst.queries[r.query_id] for r in rows], padding=True, truncation=True,
+                   max_length=module.encoder.get_max_seq_length(), return_tensors="pt")
+    with _autocast(precision, device):
+        q = module.encoder({k: v.to(device) for k, v in qt.items()})["sentence_embedding"]
+        d_pos = _encode_fields(module, tokenizer, [inst.corpus[inst.key_to_row[r.doc_id]] for r in rows], max_length, device)
+        d_neg = _encode_fields(module, tokenizer, [inst.corpus[n] for n in negs], max_length, device).unsqueeze(2)
+    return loss_fn(q.float(), d_pos.float(), d_neg.float())
+
+
+def _sync_grads(params, world):
+    if world == 1:
+        return
+    import torch.distributed as dist
+    for p in params:
+        if p.grad is not None:
+            dist.all_reduce(p.grad)
+            p.grad /= world
+
+
+def main(*,
+         dataset_name: str,
+         lexical_index: str,
+         out: str,
+         temp_dir: str,
+         partition: str = "val",
+         data: Optional[str] = None,
+         queries: Optional[str] = None,
+         corpus: Optional[str] = None,
+         sparse_scores_path: Optional[str] = None,
+         additional_partition: Optional[str] = None,
+         model_name: str = "facebook/contriever-msmarco",
+         model_path: Optional[str] = None,
+         normalize: bool = False,
+         temperature: float = 0.05,
+         negative_sampling_params: Tuple[int, int, int] = (100, 50, 1),
+         encoder_lr: float = 1e-4,
+         weights_lr: Optional[float] = None,
+         regularizer: float = 0.0,
+         train_batch_size: int = 16,
+         dev_batch_size: int = 64,
+         train_max_length: int = 512,
+         dev_max_length: int = 512,
+         max_epochs: int = 50,
+         patience: int = 10,
+         seed: int = 0xdeadbeef,
+         precision: str = "16-mixed",
+         num_gpus: int = -1,
+         dev_by_iter: bool = False,
+         logger: Optional[str] = None,
+         freeze_encoder: bool = False,
+         wandb_name: str = None,
+         wandb_dir: str = None,
+         experiment_name: str = None,
+         field_names: List = None,
+         trec_val_freq: int = 0,
+         query_cond: bool = True,
+         prefix: bool = False,
+         run_one_iteration=False,
+         use_batchnorm: bool = False,
+         ):
+    torch.manual_seed(seed & 0x7FFFFFFF)
+    init_distributed_from_env()
+    rank, world = _rank_world()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device(f"cuda:{local}")
+    field_info = resolve_fields(field_names, dataset_name)
+    if data:
+        queries = corpus = data
+    os.makedirs(out, exist_ok=True)
+    model_name = model_path if model_path else model_name
+    if rank == 0:
+        print(f"Starting training: model={model_name} queries={queries} corpus={corpus} dataset={dataset_name} "
+              f"fields={json.dumps({k: v.__dict__() for k, v in field_info.items()})} prefix={prefix} encoder_lr={encoder_lr} "
+              f"weights_lr={weights_lr} seed={seed} time={time.strftime('%Y-%m-%d %H:%M:%S')}")
+
+    tokenizer, encoder, _ = prepare_model(model_name, normalize=normalize, with_decoder=False, freeze_encoder=freeze_encoder)
+    encoder.to(device)
+    corpus_contents, vectors_dict, indices_dict = read_and_create_indices(f"{corpus}/corpus", dataset_name, field_info, temp_dir, encoder)
+    print(f"Indices are created for all {len(indices_dict)} fields, including {field_info.keys()}")
+    data_module = RetrievalDataModule(
+        tokenizer=tokenizer, queries_path=f"{queries}", corpus=corpus_contents, temp_path=temp_dir, dev_partition=partition,
+        additional_partition=additional_partition, lexical_index=lexical_index, negative_sampling_params=negative_sampling_params,
+        train_batch_size=train_batch_size, dev_batch_size=dev_batch_size, train_max_length=train_max_length,
+        dev_max_length=dev_max_length, dataset_name=dataset_name, field_info=field_info, indices_dict=indices_dict, prefix=prefix,
+        trec_val_freq=trec_val_freq)
+    module = RetrievalTrainingModule(
+        encoder=encoder, model_id=model_name, decoder=None, contrastive_temp=temperature, dev_qrels_path=f"{queries}/{partition}.qrels",
+        additional_qrels_path=f"{queries}/{additional_partition}.qrels" if additional_partition else None,
+        corpus_path=f"{corpus}/corpus", sparse_scores=None, corpus=corpus_contents, dataset_name=dataset_name,
+        encoder_learning_rate=encoder_lr, weights_learning_rate=weights_lr, weight_decay=regularizer, dev_batch_size=dev_batch_size,
+        out_dir=out, field_info=field_info, indices_dict=indices_dict, vectors_dict=vectors_dict, trec_val_freq=trec_val_freq,
+        freeze_encoder=freeze_encoder, query_cond=query_cond, prefix=prefix, use_batchnorm=use_batchnorm)
+    module.to(device)
+    loss_fn = HybridContrastiveLoss(temperature=temperature, mixture_of_fields_layer=module.mixture_of_fields_layer,
+                                    sparse_indices_dict={}, num_fields=len(field_info), use_batchnorm=use_batchnorm).to(device)
+
+    enc_params = [p for p in module.encoder.parameters() if p.requires_grad]
+    lin_params = [p for p in list(module.mixture_of_fields_layer.parameters()) + list(loss_fn.bn.parameters()) if p.requires_grad]
+    opts = []
+    if enc_params:
+        opts.append(torch.optim.AdamW(enc_params, lr=encoder_lr, weight_decay=regularizer))
+    opts.append(torch.optim.AdamW(lin_params, lr=weights_lr))
+    scaler = torch.amp.GradScaler("cuda", enabled=precision.startswith("16"))
+
+    best_path, best_loss, bad_epochs, step = "", float("inf"), 0, 0
+    train_inst = _Instances(queries, "train", corpus_contents, seed) if max_epochs > 0 else None
+    val_inst = _Instances(queries, "val", corpus_contents, seed + 1) if max_epochs > 0 else None
+    print(f"Starting training: {time.strftime('%Y-%m-%d %H:%M:%S')}")
+    for epoch in range(max_epochs):
+        module.train()
+        loss_fn.train()
+        for rows, negs in train_inst.batches(train_batch_size, rank, world, shuffle=True):
+            for o in opts:
+                o.zero_grad(set_to_none=True)
+            loss = _loss_on_batch(module, loss_fn, tokenizer, train_inst, rows, negs, train_max_length, device, precision)
+            scaler.scale(loss).backward()
+            for o in opts:
+                scaler.unscale_(o)
+            _sync_grads(enc_params + lin_params, world)
+            for o in opts:
+                scaler.step(o)
+            scaler.update()
+            step += 1
+            if rank == 0:
+                print(f"Training loss: {loss.item()}")
+            if run_one_iteration:
+                break
+        module.mark_encoder_updated()
+        # proxy validation (contrastive.py:647-667): the same loss on the dev qrels
+        module.eval()
+        loss_fn.eval()
+        tot, cnt = 0.0, 0
+        with torch.no_grad():
+            for rows, negs in val_inst.batches(dev_batch_size if dev_batch_size < 32 else 16, rank, world, shuffle=False):
+                tot += float(_loss_on_batch(module, loss_fn, tokenizer, val_inst, rows, negs, dev_max_length, device, precision))
+                cnt += 1
+                if run_one_iteration:
+                    break
+        t = torch.tensor([tot, cnt], dtype=torch.float64, device=device)
+        if world > 1:
+            torch.distributed.all_reduce(t)
+        valid_loss = float(t[0] / max(1.0, float(t[1])))
+        if rank == 0:
+            print(f"Validation loss: {valid_loss}")
+            ckpt = f"{out}/epoch={epoch}-valid_loss={valid_loss:.3f}.ckpt"
+            module.save_checkpoint(ckpt)
+            module.save_checkpoint(f"{out}/last.ckpt")
+            if valid_loss < best_loss:
+                best_path = ckpt
+        if trec_val_freq > 0 and (epoch + 1) % trec_val_freq == 0:
+            module.test(data_module)
+            if rank == 0 and os.path.exists(f"{out}/final-all-0.qres"):
+                os.replace(f"{out}/final-all-0.qres", f"{out}/epoch-{step}-all-0.qres")      # contrastive.py:525
+        if valid_loss < best_loss:
+            best_loss, bad_epochs = valid_loss, 0
+        else:
+            bad_epochs += 1
+            if bad_epochs >= patience:
+                break
+
+    if world > 1:
+        holder = [best_path]
+        torch.distributed.broadcast_object_list(holder, src=0)
+        best_path = holder[0]
+    if best_path:                                                                            # trainer.test(ckpt_path="best")
+        sd = torch.load(best_path, map_location="cpu", weights_only=False)["state_dict"]
+        module.encoder.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")})
+        module.mixture_of_fields_layer.weight.data.copy_(sd["mixture_of_fields_layer.weight"])
+        module.mark_encoder_updated()
+    elif rank == 0:
+        best_path = f"{out}/last.ckpt"
+        module.save_checkpoint(best_path)
+    module.test(data_module)
+    if rank == 0:
+        with open(f"{out}/best.txt", "w") as f:
+            f.write(str(best_path))
+    return module
+
+
+if __name__ == "__main__":
+    run(main)

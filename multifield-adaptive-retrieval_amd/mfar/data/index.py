@@ -367,9 +367,8 @@ class DenseFlatIndex(Index[str, str]):
             ids, sc = self.slab.retrieve_fields(qe, top_k, sentinel=True)
             ids, sc = ids[:, self.field_index], sc[:, self.field_index]
         ids_l, sc_l = ids.tolist(), sc.tolist()
-        off = self.slab.row_offset
-        return [list(zip([self.numeric_ids_to_key[j - off if j >= off else j] for j in ids_l[i]], sc_l[i]))
-                for i in range(len(queries))]
+        # ids are global row numbers == positions in numeric_ids_to_key (the corpus line order)
+        return [list(zip([self.numeric_ids_to_key[j] for j in ids_l[i]], sc_l[i])) for i in range(len(queries))]
 
     def score(self, query, keys: Sequence[str]):
         return self.score_batch([query], keys)[0]
@@ -378,7 +377,7 @@ class DenseFlatIndex(Index[str, str]):
         import torch
         qe = self._encode(queries)
         rows = np.asarray([self.key_to_numeric_ids[k] for k in keys], dtype=np.int64)   # KeyError like index.py:229
-        cand = np.broadcast_to(rows + self.slab.row_offset, (qe.shape[0], rows.size)).copy()
+        cand = np.broadcast_to(rows, (qe.shape[0], rows.size)).copy()                 # global row numbers
         x = self.slab.score_candidates(qe, cand)
         return torch.from_numpy(np.ascontiguousarray(x[:, :, self.field_index]))
 

@@ -1,0 +1,147 @@
+"""TREC file formats and retrieval metrics (reference mfar/data/trec.py).
+
+`QRels` / `QRes` keep the reference's line formats (trec.py:22-23, 49-50).  The reference shells out to the `trec_eval`
+binary (trec.py:84-93); it is used here too when it is on PATH, otherwise the same metrics are computed in Python from
+their trec_eval definitions (`compute_metrics`) -- the binary exists on neither box, so those values are unpinned."""
+import csv
+import json
+import math
+import shutil
+import subprocess
+import sys
+from collections import defaultdict
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, TextIO, Tuple
+
+csv.field_size_limit(sys.maxsize)
+_TAB = chr(9)
+_NL = chr(10)
+
+
+@dataclass
+class QRels:
+    query_id: str
+    doc_id: str
+    relevance: float
+    _iter: str = "0"
+
+    def __str__(self):
+        return _TAB.join([self.query_id, self._iter, self.doc_id, str(self.relevance)])
+
+    @classmethod
+    def from_str(cls, s: str) -> "QRels":
+        q, it, d, rel = s.split(_TAB)
+        return cls(q, d, float(rel), it)
+
+    @classmethod
+    def from_text_io(cls, f: TextIO) -> List["QRels"]:
+        return [cls.from_str(line.strip()) for line in f]
+
+
+@dataclass
+class QRes:
+    query_id: str
+    doc_id: str
+    sim: float
+    run_id: str = "0"
+    _iter: str = "0"
+    _rank: int = 0
+
+    def __str__(self):
+        return _TAB.join([self.query_id, self._iter, self.doc_id, str(self._rank), str(self.sim), self.run_id])
+
+    @classmethod
+    def from_str(cls, s: str) -> "QRes":
+        q, it, d, rank, sim, run = s.split()
+        return cls(q, d, float(sim), run, it, int(rank))
+
+    @classmethod
+    def from_text_io(cls, f: TextIO) -> List["QRes"]:
+        return [cls.from_str(line.strip()) for line in f]
+
+
+_NOT_METRICS = {"runid", "num_q", "num_ret", "num_rel", "num_rel_ret"}
+
+
+def parse_trec_eval_output(output: str) -> Dict[str, float]:
+    metrics = {}
+    for line in output.split(_NL):
+        if not line:
+            continue
+        name, _, value = line.strip().split(_TAB)
+        name = name.strip()
+        if name not in _NOT_METRICS:
+            metrics[name] = float(value.strip())
+    return metrics
+
+
+def _dcg(gains) -> float:
+    return sum(g / math.log2(i + 2) for i, g in enumerate(gains))
+
+
+def compute_metrics(qrels: Iterable[QRels], qres: Iterable[QRes]) -> Dict[str, float]:
+    """map, recip_rank, Rprec, ndcg, ndcg_cut_k, recall_k, success_k, P_k averaged over the queries that appear in the
+    run and have at least one relevant document (trec_eval's default averaging).  Ranking: sim descending, ties by
+    doc id descending (trec_eval's tie rule); the rank column is ignored like trec_eval does."""
+    rel = defaultdict(dict)
+    for r in qrels:
+        rel[r.query_id][r.doc_id] = r.relevance
+    runs = defaultdict(list)
+    for r in qres:
+        runs[r.query_id].append((r.sim, r.doc_id))
+    cuts = (5, 10, 15, 20, 30, 100, 200, 500, 1000)
+    sums = defaultdict(float)
+    nq = 0
+    for qid, docs in runs.items():
+        pos = {d: g for d, g in rel.get(qid, {}).items() if g > 0}
+        if not pos:
+            continue
+        nq += 1
+        docs = sorted(docs, key=lambda t: t[1], reverse=True)
+        docs.sort(key=lambda t: t[0], reverse=True)
+        ranked = [d for _, d in docs]
+        hits = [1 if d in pos else 0 for d in ranked]
+        R = len(pos)
+        cum, ap, rr = 0, 0.0, 0.0
+        for i, h in enumerate(hits):
+            if h:
+                cum += 1
+                ap += cum / (i + 1)
+                if rr == 0.0:
+                    rr = 1.0 / (i + 1)
+        sums["map"] += ap / R
+        sums["recip_rank"] += rr
+        sums["Rprec"] += sum(hits[:R]) / R
+        ideal = sorted(pos.values(), reverse=True)
+        gains = [pos.get(d, 0.0) for d in ranked]
+        sums["ndcg"] += _dcg(gains) / _dcg(ideal)
+        for k in cuts:
+            top = sum(hits[:k])
+            sums[f"recall_{k}"] += top / R
+            sums[f"P_{k}"] += top / k
+            sums[f"ndcg_cut_{k}"] += _dcg(gains[:k]) / _dcg(ideal[:k])
+        for k in (1, 5, 10):
+            sums[f"success_{k}"] += 1.0 if sum(hits[:k]) > 0 else 0.0
+    return {k: (v / nq if nq else 0.0) for k, v in sums.items()}
+
+
+def call_trec_eval_and_get_metrics(qrels: str, qres: str) -> Dict[str, float]:
+    """trec.py:84-93: `trec_eval -m all_trec qrels qres` when the binary exists, else the Python metrics."""
+    if shutil.which("trec_eval"):
+        proc = subprocess.run(["trec_eval", "-m", "all_trec", qrels, qres], stdout=subprocess.PIPE, check=True)
+        return parse_trec_eval_output(proc.stdout.decode("utf-8"))
+    with open(qrels) as f1, open(qres) as f2:
+        return compute_metrics(QRels.from_text_io(f1), QRes.from_text_io(f2))
+
+
+def read_corpus(path: str) -> Iterable[Tuple[str, object]]:
+    """Tab separated 'id, json' rows (trec.py:96-106): missing body -> "", unparsable body -> the raw remainder."""
+    with open(path, "r") as f:
+        for row in csv.reader(f, delimiter=_TAB):
+            if len(row) < 2:
+                yield row[0], ""
+                continue
+            try:
+                yield row[0], json.loads(row[1])
+            except Exception:
+                yield row[0], _TAB.join(row[1:])

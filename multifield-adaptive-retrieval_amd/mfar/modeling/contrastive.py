@@ -1,0 +1,309 @@
+"""Evaluation orchestration of the path (reference mfar/modeling/contrastive.py), without PyTorch-Lightning.
+
+`RetrievalDataModule` keeps the query-side loading of the reference's data module (contrastive.py:31-96, 119-135);
+`RetrievalTrainingModule` keeps the hooks the CLIs drive -- `on_eval_start` (:465-496), `trec_eval_step` (:669-704),
+`mask_field` (:706-714), `merge_qres_and_score` (:566-613), `on_test_epoch_start/end` (:553-556, 616-631) -- plus
+`test()`, the loop `trainer.test(...)` ran.  What changed underneath:
+
+  * the corpus is encoded ONCE into the on-HBM slab and re-encoded only when the encoder weights changed
+    (`mark_encoder_updated()`); the reference re-encodes the whole corpus for every `trainer.test`, 46 times in a prime
+    mask sweep (contrastive.py:553-554, mask_fields.py:143-170);
+  * each query batch is encoded once (the reference runs 2F+1 encoder forwards per query: index.py:187,228 and
+    contrastive.py:693) and scored by `mfar_search_two_stage` on the GPU;
+  * with several ranks every rank holds a ROW SHARD of the corpus and all ranks score the same query batches
+    (`ShardedSearcher`); rank 0 writes the result lines.  The reference instead shards the queries over ranks and has every
+    rank search the full corpus on its CPU (contrastive.py:184,200,207).  File names and formats are unchanged.
+"""
+import json
+import os
+from types import SimpleNamespace
+from typing import Dict, List, Optional, TextIO, Tuple
+
+import torch
+
+from mfar.data import trec
+from mfar.data.dataset import QueryDataset
+from mfar.data.format import format_documents
+from mfar.data.sharded import HipShardBackend, ShardedSearcher, shard_bounds
+from mfar.data.typedef import Field, FieldType
+from mfar.modeling.weighting import LinearWeights
+
+TOP_K = 100  # hard-coded in the reference for both stages (contrastive.py:673,696)
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+class RetrievalDataModule:
+    """Query / qrels side of the reference's data module.  The BM25 negative sampler and the contrastive training
+    datasets (contrastive.py:71-77, 137-160) are training-data plumbing and are not built here."""
+
+    def __init__(self, tokenizer, queries_path: str, corpus, temp_path: str, dev_partition: str,
+                 additional_partition: Optional[str], lexical_index: str, negative_sampling_params: Tuple[int, int, int],
+                 dataset_name: str, train_batch_size: int = 64, dev_batch_size: int = 64, query_max_length: int = 64,
+                 train_max_length: int = 384, dev_max_length: int = 512, dim: int = 768, field_info: Dict[str, Field] = None,
+                 indices_dict=None, prefix: bool = False, trec_val_freq: int = 0):
+        self.tokenizer, self.queries_path, self.corpus = tokenizer, queries_path, corpus
+        self.dev_partition, self.additional_partition = dev_partition, additional_partition
+        self.lexical_index, self.negative_sampling_params = lexical_index, negative_sampling_params
+        self.train_batch_size, self.dev_batch_size = train_batch_size, dev_batch_size
+        self.query_max_length, self.train_max_length, self.dev_max_length = query_max_length, train_max_length, dev_max_length
+        self.field_info, self.indices_dict, self.prefix, self.trec_val_freq = field_info, indices_dict, prefix, trec_val_freq
+        self.field_types = {f.field_type for f in field_info.values()}
+        self.dev_queries_dict = dict(trec.read_corpus(f"{queries_path}/{dev_partition}.queries"))
+        self.additional_queries_dict = ([dict(trec.read_corpus(f"{queries_path}/{additional_partition}.queries"))]
+                                        if additional_partition else [])
+        self.dev_queries: Optional[QueryDataset] = None
+        self.additional_queries: List[QueryDataset] = []
+
+    def setup(self, stage: str = "test") -> None:
+        mk = lambda d: QueryDataset(tokenizer=self.tokenizer, queries=d, max_length=self.query_max_length, field_types=self.field_types)
+        self.dev_queries = mk(self.dev_queries_dict)
+        self.additional_queries = [mk(d) for d in self.additional_queries_dict]
+
+    @staticmethod
+    def batches(dataset: QueryDataset, batch_size: int):
+        for b in range(0, len(dataset), batch_size):
+            yield dataset.collate([dataset[i] for i in range(b, min(len(dataset), b + batch_size))])
+
+    def test_dataloader(self):
+        return [self.batches(ds, self.dev_batch_size) for ds in [self.dev_queries] + self.additional_queries]
+
+
+class RetrievalTrainingModule(torch.nn.Module):
+    def __init__(self, encoder, model_id: str, decoder, corpus_path: str, corpus: List[Tuple[str, str]], dataset_name: str,
+                 dev_qrels_path: str, out_dir: str, sparse_scores: Optional[Dict] = None, contrastive_temp: float = 0.01,
+                 encoder_learning_rate: float = 1e-5, weights_learning_rate: Optional[float] = None, weight_decay: float = 0.0,
+                 dev_batch_size: int = 32, field_info: Dict = None, indices_dict: Dict = None, vectors_dict: Dict = None,
+                 trec_val_freq: int = 0, freeze_encoder: bool = False, query_cond: bool = True, prefix: bool = False,
+                 additional_qrels_path: Optional[str] = None, use_batchnorm: bool = False):
+        super().__init__()
+        if field_info is None:
+            raise NotImplementedError("No fields passed in!")
+        if weights_learning_rate is None:
+            raise ValueError("Need to specify a learning weight for the weights!")
+        self.encoder, self.model_id, self.decoder = encoder, model_id, decoder
+        self.dataset_name, self.corpus, self.corpus_path = dataset_name, corpus, corpus_path
+        self.numeric_ids_to_keys = [x[0] for x in corpus]
+        self.keys_to_numeric_ids = {k: i for i, k in enumerate(self.numeric_ids_to_keys)}
+        self.indices_dict, self.vectors_dict = indices_dict, vectors_dict
+        self.encoder_learning_rate, self.weights_learning_rate, self.weight_decay = encoder_learning_rate, weights_learning_rate, weight_decay
+        self.contrastive_temp, self.use_batchnorm = contrastive_temp, use_batchnorm
+        self.dev_batch_size, self.dev_qrels_path, self.additional_qrels_path = dev_batch_size, dev_qrels_path, additional_qrels_path
+        self.out_dir, self.n_docs, self.field_info = out_dir, len(corpus), field_info
+        self.trec_val_freq, self.query_cond, self.prefix, self.freeze_encoder = trec_val_freq, query_cond, prefix, freeze_encoder
+        num_fields = len(field_info)
+        if query_cond:
+            self.mixture_of_fields_layer = LinearWeights(encoder.get_sentence_embedding_dimension(), num_fields, query_cond=True)
+        else:
+            self.mixture_of_fields_layer = LinearWeights(num_fields, 1)      # contrastive.py:286-287
+        # the reference reaches the mixer through the loss object (contrastive.py:694); keep that attribute path
+        self.hybrid_contrastive_loss_fn = SimpleNamespace(mixture_of_fields_layer=self.mixture_of_fields_layer)
+        self.mask = torch.ones([num_fields, 1])                                # contrastive.py:270
+        self.masked_fields_string = ""
+        self.best_score = 0.0
+        self.qres_output: Optional[TextIO] = None
+        self.additional_qres_output: Optional[TextIO] = None
+        self._corpus_encoded = False
+        self._searcher = None
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def device(self):
+        return next(self.encoder.parameters()).device
+
+    @property
+    def slab(self):
+        return next(iter(self.indices_dict.values())).slab
+
+    def mark_encoder_updated(self):
+        """Call after the encoder weights changed (a training epoch, a checkpoint load): the next evaluation re-encodes."""
+        self._corpus_encoded = False
+
+    def _weights(self):
+        W = self.mixture_of_fields_layer.weight.detach().float()
+        return (W if self.query_cond else W.reshape(-1)).contiguous().to(self.device)
+
+    # ------------------------------------------------------------------ corpus encode (contrastive.py:465-496)
+    @torch.no_grad()
+    def on_eval_start(self) -> None:
+        rank, n = _dist()
+        os.makedirs(self.out_dir, exist_ok=True)
+        self.qres_output = open(f"{self.out_dir}/{rank}.qres", "w")
+        # only the fields we care about, in field_info order (contrastive.py:496)
+        self.indices_dict = {k: self.indices_dict[k] for k in self.field_info.keys()}
+        if self._corpus_encoded:
+            return      # same weights as the last encode: the slab in HBM is still valid (the mask only changes the mixer)
+        r0, r1 = shard_bounds(self.n_docs, rank, n)                             # contrastive.py:470
+        segment = self.corpus[r0:r1]
+        bs = self.dev_batch_size
+        for key, field in self.field_info.items():
+            if field.field_type != FieldType.DENSE:
+                continue
+            docs = format_documents(segment, field.name, field.dataset)          # contrastive.py:473-475
+            if self.prefix:
+                docs = [(i, field.name + ": " + t) for i, t in docs]            # :476-481
+            vec = self.vectors_dict[key]
+            for b in range(0, len(docs), bs):
+                chunk = docs[b:b + bs]
+                emb = self.encoder.encode([t for _, t in chunk], batch_size=bs, convert_to_tensor=True)
+                vec.write_block(chunk[0][0], emb.float().contiguous())           # straight into the HBM slab
+        torch.cuda.synchronize(self.device)
+        _barrier()                                                               # :491 (no memmap reopen needed)
+        self._corpus_encoded = True
+
+    # ------------------------------------------------------------------ scoring (contrastive.py:669-704)
+    def _get_searcher(self):
+        if self._searcher is None:
+            self._searcher = ShardedSearcher(HipShardBackend(self.slab))
+        return self._searcher
+
+    @torch.no_grad()
+    def trec_eval_step(self, batch, batch_idx: int, qres_output) -> None:
+        data = batch.instances
+        toks = batch.query[FieldType.DENSE]
+        L = self.encoder.get_max_seq_length()
+        feats = {k: v[:, :L].to(self.device) for k, v in toks.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
+        x = self.encoder(feats)["sentence_embedding"].float().contiguous()       # ONE forward per batch
+        mask = self.mask[:, 0].float().contiguous().to(self.device)
+        if _dist()[1] == 1:
+            res = self.slab.search(x, self._weights(), mask, k1=TOP_K, k2=TOP_K, sentinel=True, query_cond=self.query_cond)
+        else:
+            res = self._get_searcher().search(x, self._weights(), mask, k1=TOP_K, k2=TOP_K, sentinel=True,
+                                              query_cond=self.query_cond)
+        n_valid = res["n_valid"].cpu().tolist()
+        if min(n_valid) < TOP_K:                                                 # what torch.topk raises at :696
+            raise RuntimeError(f"selected index k out of range: only {min(n_valid)} candidates for k={TOP_K}")
+        rank, _ = _dist()
+        if rank != 0 or qres_output is None:
+            return
+        ids, sims = res["ids"].cpu().tolist(), res["scores"].cpu().tolist()
+        for q, row_ids, row_sims in zip(data, ids, sims):
+            for d, s in zip(row_ids, row_sims):
+                print(trec.QRes(query_id=q._id, doc_id=self.numeric_ids_to_keys[d], sim=s), file=qres_output)
+
+    def mask_field(self, field_idx_list) -> None:                                # contrastive.py:706-714
+        names = list(self.field_info.keys())
+        masked = [names[i] for i in field_idx_list]
+        if _dist()[0] == 0:
+            print(f"Masking fields: {masked}")
+        self.masked_fields_string = ",".join(masked)
+        mask = torch.ones([len(self.field_info), 1])
+        mask[field_idx_list] = 0
+        self.mask = mask
+
+    # ------------------------------------------------------------------ the test loop (trainer.test)
+    def on_test_epoch_start(self) -> None:
+        self.on_eval_start()
+        self.additional_qres_output = open(f"{self.out_dir}/additional_{_dist()[0]}.qres", "w")
+
+    def test_step(self, batch, batch_idx: int, dataloader_idx: int = 0) -> None:
+        self.trec_eval_step(batch, batch_idx, self.qres_output if dataloader_idx == 0 else self.additional_qres_output)
+
+    def on_test_epoch_end(self) -> None:
+        rank, n = _dist()
+        self.qres_output.close()
+        self.additional_qres_output.close()
+        has_additional = os.path.getsize(f"{self.out_dir}/additional_{rank}.qres") > 0
+        _barrier()
+        self.merge_qres_and_score([f"{self.out_dir}/{i}.qres" for i in range(n)], self.dev_qrels_path)
+        if has_additional:
+            self.merge_qres_and_score([f"{self.out_dir}/additional_{i}.qres" for i in range(n)], self.additional_qrels_path,
+                                      additional="additional-")
+
+    def test(self, data_module: RetrievalDataModule) -> None:
+        """What `trainer.test(module, data_module)` does for this module (train.py:260, mask_fields.py:143-170)."""
+        data_module.setup("test")
+        was_training = self.training
+        self.eval()
+        self.on_test_epoch_start()
+        for li, loader in enumerate(data_module.test_dataloader()):
+            for bi, batch in enumerate(loader):
+                self.test_step(batch, bi, dataloader_idx=li)
+        self.on_test_epoch_end()
+        if was_training:
+            self.train()
+
+    def merge_qres_and_score(self, qres_files, qrels_path, additional=""):       # contrastive.py:566-613
+        rank, _ = _dist()
+        if rank != 0:
+            return None
+        seen = set()
+        merged = f"{self.out_dir}/final-{additional}all-{rank}.qres"
+        with open(merged, "w") as out:
+            for fn in qres_files:
+                if not os.path.exists(fn):
+                    continue
+                with open(fn) as f:
+                    here = set()
+                    for r in trec.QRes.from_text_io(f):
+                        if r.query_id not in seen:                               # first-seen dedup across ranks (:570-581)
+                            here.add(r.query_id)
+                            print(r, file=out)
+                seen.update(here)
+        metrics = trec.call_trec_eval_and_get_metrics(qrels=qrels_path, qres=merged)
+        keys = ["success_1", "success_5", "recall_5", "recall_10", "recall_15", "recall_20", "ndcg", "ndcg_cut_10", "recip_rank", "map"]
+        print("\t".join(keys))
+        print("\t".join(f"{metrics[k]:.3f}" for k in keys))
+        row = {k: f"{metrics[k]:.3f}" for k in keys}
+        row["masked_fields"] = self.masked_fields_string
+        row["additional"] = "test" if additional != "" else "val"
+        line = json.dumps(row)
+        print(line)
+        with open(f"{self.out_dir}/results_dicts-all-{rank}.jsonl", "a") as f:
+            f.write(line + "\n")
+        self.last_metrics = metrics
+        return metrics
+
+    # ------------------------------------------------------------------ checkpoints (Lightning .ckpt key layout)
+    def checkpoint_state(self) -> dict:
+        sd = {f"encoder.{k}": v for k, v in self.encoder.state_dict().items()}
+        w = self.mixture_of_fields_layer.weight.detach()
+        sd["mixture_of_fields_layer.weight"] = w
+        sd["hybrid_contrastive_loss_fn.mixture_of_fields_layer.weight"] = w      # registered twice in the reference (:279-293)
+        hp = dict(model_id=self.model_id, dataset_name=self.dataset_name, corpus_path=self.corpus_path, query_cond=self.query_cond,
+                  prefix=self.prefix, contrastive_temp=self.contrastive_temp, encoder_learning_rate=self.encoder_learning_rate,
+                  weights_learning_rate=self.weights_learning_rate, weight_decay=self.weight_decay, dev_batch_size=self.dev_batch_size,
+                  trec_val_freq=self.trec_val_freq, freeze_encoder=self.freeze_encoder, use_batchnorm=self.use_batchnorm,
+                  field_info={k: f.serialize() for k, f in self.field_info.items()},      # on_save_checkpoint (:634-640)
+                  indices_list=[], vectors_list=[], corpus=[], precomputed_sparse_scores=[])
+        return {"state_dict": sd, "hyper_parameters": hp}
+
+    def save_checkpoint(self, path: str) -> None:
+        torch.save(self.checkpoint_state(), path)
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path: str, **kwargs) -> "RetrievalTrainingModule":
+        """Reads a Lightning-style checkpoint (`state_dict` + `hyper_parameters`), as mask_fields.py:110-121 does."""
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        hp = dict(ckpt.get("hyper_parameters", {}))
+        for drop in ("indices_list", "vectors_list", "corpus", "precomputed_sparse_scores", "field_info"):
+            hp.pop(drop, None)
+        accepted = cls.__init__.__code__.co_varnames[1:cls.__init__.__code__.co_argcount]
+        args = {k: v for k, v in hp.items() if k in accepted}
+        args.update(kwargs)
+        args.setdefault("model_id", hp.get("model_id", ""))
+        args.setdefault("decoder", None)
+        args.setdefault("corpus_path", hp.get("corpus_path", ""))
+        args.setdefault("dataset_name", hp.get("dataset_name", ""))
+        if args.get("weights_learning_rate") is None:
+            args["weights_learning_rate"] = 0.0
+        module = cls(**args)
+        sd = ckpt["state_dict"]
+        enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+        missing, unexpected = module.encoder.load_state_dict(enc, strict=False)
+        if unexpected:
+            raise RuntimeError(f"unexpected encoder keys in checkpoint: {unexpected[:5]}")
+        module.mixture_of_fields_layer.weight.data = sd["mixture_of_fields_layer.weight"].clone().float()
+        module.mark_encoder_updated()
+        return module

@@ -1,0 +1,175 @@
+"""Encoder construction and index creation (reference mfar/modeling/util.py:16-108).
+
+`prepare_model` returns `(tokenizer, encoder, None)` like the reference; the encoder is `SentenceEncoder`, a small
+re-statement of the sentence-transformers stack the reference assembles (`Transformer` -> `Pooling(mean)` [->
+`Normalize`], modeling/util.py:38-52): the HF `AutoModel` forward runs on PyTorch-ROCm (host code, as the north-star
+asks), its state-dict keys (`0.auto_model.*`) match the reference's so Lightning checkpoints load.  sentence-transformers
+itself is not installed on either box and its arithmetic is un-vendored third-party code: encoder parity is
+structural only.
+
+`read_and_create_indices` allocates ONE on-HBM slab for this rank's row shard of all dense fields instead of one
+np.memmap file + CPU DenseFlatIndex per field (modeling/util.py:84-101).
+"""
+import os
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from mfar.data import trec
+from mfar.data.index import DenseFlatIndex, MultiFieldIndex
+from mfar.data.sharded import shard_bounds
+from mfar.data.typedef import FieldType
+from mfar.data.util import HbmFieldVectors
+
+
+class _Transformer(torch.nn.Module):
+    """Holds the HF model as `.auto_model` (the attribute name sentence-transformers uses, so checkpoint keys match)."""
+
+    def __init__(self, auto_model):
+        super().__init__()
+        self.auto_model = auto_model
+
+    def forward(self, features):
+        out = self.auto_model(input_ids=features["input_ids"], attention_mask=features["attention_mask"],
+                              **({"token_type_ids": features["token_type_ids"]} if "token_type_ids" in features else {}))
+        return out[0] if not hasattr(out, "last_hidden_state") else out.last_hidden_state
+
+
+class SentenceEncoder(torch.nn.Sequential):
+    """tokens -> mean-pooled sentence embedding.  Interface used by the path: `.encode(texts, ...)` (index.py:187,257),
+    `__call__(features)["sentence_embedding"]` (contrastive.py:693), `.get_sentence_embedding_dimension()`,
+    `.get_max_seq_length()`, `.tokenizer`."""
+
+    def __init__(self, auto_model, tokenizer, normalize: bool = False, max_seq_length: Optional[int] = None):
+        super().__init__(_Transformer(auto_model))
+        self.tokenizer = tokenizer
+        self.normalize = normalize
+        cfg = auto_model.config
+        limit = getattr(cfg, "max_position_embeddings", 512)
+        self.max_seq_length = min(max_seq_length or limit, limit)
+
+    @property
+    def auto_model(self):
+        return self[0].auto_model
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def get_sentence_embedding_dimension(self) -> int:
+        return int(self.auto_model.config.hidden_size)
+
+    def get_max_seq_length(self) -> int:
+        return int(self.max_seq_length)
+
+    def forward(self, features) -> Dict[str, torch.Tensor]:
+        tok = self[0](features)
+        m = features["attention_mask"].unsqueeze(-1).to(tok.dtype)
+        emb = (tok * m).sum(1) / m.sum(1).clamp(min=1e-9)      # Pooling(mean): sum of unmasked tokens / their count
+        if self.normalize:
+            emb = torch.nn.functional.normalize(emb, p=2, dim=1)
+        return {"token_embeddings": tok, "sentence_embedding": emb, **features}
+
+    def tokenize(self, texts: List[str]):
+        return self.tokenizer(list(texts), padding=True, truncation="longest_first", max_length=self.max_seq_length,
+                              return_tensors="pt")
+
+    @torch.no_grad()
+    def encode(self, sentences, batch_size: int = 32, convert_to_numpy: bool = True, convert_to_tensor: bool = False,
+               show_progress_bar: bool = False, device=None, **_):
+        was_training = self.training
+        self.eval()
+        single = isinstance(sentences, str)
+        if single:
+            sentences = [sentences]
+        dev = torch.device(device) if device is not None else self.device
+        order = np.argsort([-len(s) for s in sentences], kind="stable")      # longest first: less padding per batch
+        out = [None] * len(sentences)
+        for b in range(0, len(sentences), batch_size):
+            idx = order[b:b + batch_size]
+            feats = {k: v.to(dev) for k, v in self.tokenize([sentences[i] for i in idx]).items()}
+            emb = self.forward(feats)["sentence_embedding"].float()
+            for j, i in enumerate(idx):
+                out[i] = emb[j]
+        if was_training:
+            self.train()
+        emb = torch.stack(out) if out else torch.empty(0, self.get_sentence_embedding_dimension(), device=dev)
+        if convert_to_tensor:
+            return emb[0] if single else emb
+        arr = emb.cpu().numpy()
+        return arr[0] if single else arr
+
+
+def _tiny_random_model(spec: str):
+    """'random-init:<hidden>x<layers>' -> a randomly initialised BERT + a character-level WordPiece tokenizer.
+    For plumbing tests and smoke runs on boxes without checkpoints (there is no network)."""
+    import tempfile
+    from transformers import BertConfig, BertModel, BertTokenizerFast
+    dims = spec.split(":", 1)[1] if ":" in spec else "64x2"
+    hidden, layers = (int(x) for x in dims.split("x"))
+    chars = list("abcdefghijklmnopqrstuvwxyz0123456789.,:;!?-_'\"()/")
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + chars + ["##" + c for c in chars]
+    d = tempfile.mkdtemp(prefix="mfar_tok_")
+    with open(os.path.join(d, "vocab.txt"), "w") as f:
+        f.write("\n".join(vocab) + "\n")
+    tok = BertTokenizerFast(vocab_file=os.path.join(d, "vocab.txt"), do_lower_case=True)
+    cfg = BertConfig(vocab_size=len(vocab), hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=max(1, hidden // 32),
+                     intermediate_size=hidden * 4, max_position_embeddings=512)
+    torch.manual_seed(0)
+    return tok, BertModel(cfg).eval()       # from_pretrained() also hands models out in eval mode
+
+
+def prepare_model(model_id: str, with_decoder: bool = False, normalize: bool = False, freeze_encoder: bool = False):
+    """(tokenizer, encoder, decoder|None) -- reference modeling/util.py:16-71.  The contriever branch and the
+    local-directory branch are the same thing here (HF AutoModel + mean pooling); the gtr-t5 branch needs the
+    sentence-transformers model zoo and is not available."""
+    if model_id.startswith("sentence-transformers/gtr-t5"):
+        raise NotImplementedError("the gtr-t5 branch needs sentence-transformers pretrained modules (not installed)")
+    if with_decoder:
+        raise NotImplementedError("with_decoder is only defined for the gtr-t5 branch")
+    if model_id.startswith("random-init"):
+        tokenizer, model = _tiny_random_model(model_id)
+    else:
+        try:
+            from transformers import AutoModel, AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(model_id)
+            model = AutoModel.from_pretrained(model_id)
+        except Exception as e:
+            raise ValueError(f"Unsupported model_id or unable to find: {model_id}") from e
+    if freeze_encoder:
+        for p in model.parameters():
+            p.requires_grad = False
+        model.eval()
+    return tokenizer, SentenceEncoder(model, tokenizer, normalize=normalize), None
+
+
+def _dist_info() -> Tuple[int, int, int]:
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size(), int(os.environ.get("LOCAL_RANK", dist.get_rank()))
+    return 0, 1, int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def read_and_create_indices(corpus_path, dataset_name, field_info, temp_dir, encoder):
+    """-> (corpus [(id, json)], vectors_dict {field_key: HbmFieldVectors}, indices_dict {field_key: DenseFlatIndex}).
+    All dense fields share one `MultiFieldIndex` holding this rank's row shard (contrastive.py:470); the field order
+    inside the slab is the order of `field_info` (schema.py:131-134)."""
+    corpus = list(trec.read_corpus(corpus_path))
+    dense = [k for k, f in field_info.items() if f.field_type == FieldType.DENSE]
+    if any(f.field_type == FieldType.SPARSE for f in field_info.values()):
+        raise NotImplementedError("BM25 sparse fields are outside the dense scoring path (SURVEY.md section 2)")
+    keys = [x[0] for x in corpus]
+    key_to_id = {k: i for i, k in enumerate(keys)}
+    Path(temp_dir).mkdir(parents=True, exist_ok=True)
+    rank, world, local_rank = _dist_info()
+    r0, r1 = shard_bounds(len(corpus), rank, world)
+    slab = MultiFieldIndex(r1 - r0, len(dense), encoder.get_sentence_embedding_dimension(), device=local_rank, row_offset=r0)
+    vectors_dict, indices_dict = {}, {}
+    for fi, key in enumerate(dense):
+        field = field_info[key]
+        vectors_dict[key] = HbmFieldVectors(slab, fi, keys, path=f"{temp_dir}/{field.name}.npy")
+        indices_dict[key] = DenseFlatIndex(encoder, None, numeric_ids_to_keys=keys, keys_to_numeric_ids=key_to_id, slab=slab,
+                                           field_index=fi)
+    return corpus, vectors_dict, indices_dict

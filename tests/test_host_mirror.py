@@ -1,0 +1,190 @@
+"""The host-side mirror of the reference's Python surface, against the golden fixtures captured from the reference
+(tools/gen_golden.py): field resolution/order, TREC line formats, document formatting, memmap layout, CLI signatures,
+training loss."""
+import inspect
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+NL = chr(10)
+
+
+def _j(golden_dir, name):
+    return json.load(open(os.path.join(golden_dir, name)))
+
+
+def test_resolve_fields_golden(golden_dir):
+    from mfar.data.schema import resolve_fields
+    g = _j(golden_dir, "schema.json")
+    for case, want in g.items():
+        if case == "errors":
+            continue
+        ds, spec = case.split("|")
+        if spec == "off-label.use_dense":
+            spec = "off-label.use_dense,name_dense"          # how tools/gen_golden.py produced this case
+        got = resolve_fields(spec, "data/amazon" if "title_dense,brand" in spec else ds)
+        assert [dict(key=k, name=f.name, type=f.field_type.name, max_seq_length=f.max_seq_length, dataset=f.dataset)
+                for k, f in got.items()] == want, case
+    with pytest.raises(NotImplementedError):
+        resolve_fields("all_dense", "nosuchdataset")
+    with pytest.raises(ValueError):
+        resolve_fields("nosuchfield_dense", "mag")
+    assert list(resolve_fields(["all_dense"], "amazon")) == [w["key"] for w in g["amazon|all_dense"]]
+
+
+def test_field_serialisation_roundtrip():
+    from mfar.data.typedef import Field, FieldType
+    f = Field("title_dense", "title", FieldType.DENSE, 64, "mag")
+    assert Field.deserialize(f.serialize()).serialize() == f.serialize()
+    assert f.__dict__() == {"name": "title", "field_type": "DENSE", "max_seq_length": 64}
+    assert json.loads(str(f)) == f.__dict__()
+
+
+def test_trec_formats_golden(golden_dir, tmp_path):
+    from mfar.data import trec
+    g = _j(golden_dir, "trec.json")
+    q = trec.QRes(query_id="q1", doc_id="d7", sim=float(np.float32(12.3456789)))
+    assert str(q) == g["qres_str"] and str(trec.QRes.from_str(str(q))) == g["qres_roundtrip"]
+    r = trec.QRels("q1", "d7", 1.0)
+    assert str(r) == g["qrels_str"] and str(trec.QRels.from_str(str(r))) == g["qrels_roundtrip"]
+    assert trec.parse_trec_eval_output(g["parse_sample_in"]) == g["parse_sample_out"]
+    p = tmp_path / "c.tsv"
+    p.write_text(NL.join(g["read_corpus_in"]) + NL)
+    assert [[a, b] for a, b in trec.read_corpus(str(p))] == g["read_corpus_out"]
+
+
+def test_format_documents_golden(golden_dir):
+    from mfar.data.format import format_documents
+    g = _j(golden_dir, "format_documents.json")
+    for case, want in g["out"].items():
+        ds, fld = case.split("|")
+        corpus = [(a, b) for a, b in g["docs"][ds]]
+        if isinstance(want, dict):
+            with pytest.raises(Exception) as ei:
+                format_documents(corpus, fld, ds)
+            assert type(ei.value).__name__ == want["raises"], case
+        else:
+            assert [[a, b] for a, b in format_documents(corpus, fld, ds)] == want, case
+
+
+def test_memmap_dict_golden(golden_dir, tmp_path):
+    from mfar.data.util import MemoryMapDict
+    g = _j(golden_dir, "memmap.json")
+    p = tmp_path / "title.npy"
+    p.write_bytes(b"")
+    m = MemoryMapDict(str(p), ["a", "b", "c"], (3, 4))
+    m["b"] = np.array([1, 2, 3, 4], dtype=np.float32)
+    m["c"] = np.array([5, 6, 7, 8], dtype=np.float32)
+    m.close()
+    raw = p.read_bytes()
+    assert len(raw) == g["size"] and raw.hex() == g["raw_hex"]      # raw, headerless float32 rows
+    assert len(m) == g["len"] and ("b" in m) == g["contains_b"] and ("z" in m) == g["contains_z"]
+    assert list(iter(m)) == g["iter"] and m["b"].tolist() == g["b"]
+    m.reopen()
+    assert m["c"].tolist() == [5, 6, 7, 8]
+
+
+def test_cli_signatures_golden(golden_dir):
+    from mfar.commands import mask_fields, train
+    g = _j(golden_dir, "cli_signatures.json")
+    for name, mod in (("train", train), ("mask_fields", mask_fields)):
+        sig = inspect.signature(mod.main)
+        got = []
+        for p in sig.parameters.values():
+            default = None if p.default is inspect._empty else p.default
+            got.append(dict(name=p.name, kind=p.kind.name, required=(p.default is inspect._empty),
+                            default=default if isinstance(default, (int, float, str, bool, type(None))) else repr(default)))
+        assert got == g[name], name
+
+
+def test_metrics_definitions():
+    from mfar.data import trec
+    qrels = [trec.QRels("q1", "a", 1.0), trec.QRels("q1", "b", 1.0), trec.QRels("q2", "x", 1.0), trec.QRels("q3", "n", 0.0)]
+    qres = [trec.QRes("q1", d, s) for d, s in [("z", 9.0), ("a", 8.0), ("y", 7.0), ("b", 6.0)]] + \
+           [trec.QRes("q2", d, s) for d, s in [("x", 5.0), ("w", 4.0)]] + [trec.QRes("q3", "n", 1.0)]
+    m = trec.compute_metrics(qrels, qres)
+    assert m["recip_rank"] == pytest.approx((0.5 + 1.0) / 2)
+    assert m["map"] == pytest.approx(((1 / 2 + 2 / 4) / 2 + 1.0) / 2)
+    assert m["recall_5"] == pytest.approx(1.0) and m["success_1"] == pytest.approx(0.5)
+    assert m["Rprec"] == pytest.approx((0.5 + 1.0) / 2)
+    dcg1 = 1 / math.log2(3) + 1 / math.log2(5)
+    idcg1 = 1 + 1 / math.log2(3)
+    assert m["ndcg_cut_10"] == pytest.approx((dcg1 / idcg1 + 1.0) / 2)
+
+
+def test_query_dataset_short_query_rule():
+    from mfar.data.dataset import QueryDataset
+    ds = QueryDataset(tokenizer=None, queries={"1": "hi", "2": "a real query"})
+    assert ds[0].text == "what" and ds[1].text == "a real query" and ds[0]._id == "1" and len(ds) == 2
+
+
+
+
+def test_hybrid_contrastive_loss_golden(golden_dir):
+    """Training-time scorer + loss (losses.py:176-188, 275-360) against loss value and gradients captured from the
+    reference's HybridContrastiveLoss (1-rank group), with and without BatchNorm over fields."""
+    import torch
+    from mfar.modeling.losses import HybridContrastiveLoss
+    from mfar.modeling.weighting import LinearWeights
+    z = np.load(os.path.join(golden_dir, "hybrid_loss.npz"))
+    for name, use_bn in (("plain", False), ("bn", True)):
+        q = torch.tensor(z[f"{name}__q"], requires_grad=True)
+        d_pos = torch.tensor(z[f"{name}__d_pos"], requires_grad=True)
+        d_neg = torch.tensor(z[f"{name}__d_neg"], requires_grad=True)
+        E, F = z[f"{name}__W"].shape
+        lw = LinearWeights(E, F, query_cond=True)
+        lw.weight.data = torch.from_numpy(z[f"{name}__W"].copy())
+        fn = HybridContrastiveLoss(temperature=float(z["temperature"]), mixture_of_fields_layer=lw, sparse_indices_dict={},
+                                   num_fields=F, use_batchnorm=use_bn)
+        fn.train()
+        loss = fn(q, d_pos, d_neg)
+        loss.backward()
+        assert float(loss) == pytest.approx(float(z[f"{name}__loss"]), rel=1e-5, abs=1e-5), name
+        np.testing.assert_allclose(lw.weight.grad.numpy(), z[f"{name}__grad_W"], rtol=1e-4, atol=1e-5, err_msg=name)
+        np.testing.assert_allclose(q.grad.numpy(), z[f"{name}__grad_q"], rtol=1e-4, atol=1e-5, err_msg=name)
+        np.testing.assert_allclose(d_pos.grad.numpy(), z[f"{name}__grad_d_pos"], rtol=1e-4, atol=1e-5, err_msg=name)
+
+
+def test_fire_like_cli_parsing():
+    from mfar.commands._cli import parse
+
+    def main(*, dataset_name: str, out: str, temp_dir: str = "/tmp", dev_batch_size: int = 64, weights_lr=None,
+             negative_sampling_params=(100, 50, 1), query_cond: bool = True, field_names=None):
+        pass
+
+    kw = parse(["--dataset-name", "amazon", "--out=/x", "--temp-dir", "/t", "--dev_batch_size", "32", "--weights_lr=1e-1",
+                "--negative-sampling-params", "(10,5,1)", "--query_cond", "False", "--field_names", "all_dense"], main)
+    assert kw == dict(dataset_name="amazon", out="/x", temp_dir="/t", dev_batch_size=32, weights_lr=0.1,
+                      negative_sampling_params=(10, 5, 1), query_cond=False, field_names="all_dense")
+    with pytest.raises(SystemExit):
+        parse(["--out", "/x"], main)              # missing required flag
+    with pytest.raises(SystemExit):
+        parse(["--dataset_name", "a", "--out", "/x", "--nope", "1"], main)
+
+
+def test_sentence_encoder_structure():
+    """prepare_model's encoder = HF model -> mask-weighted mean pooling (modeling/util.py:38-52); checked against a
+    hand-written pooling on a randomly initialised BERT (no checkpoint can be downloaded: encoder parity is structural)."""
+    import torch
+    from mfar.modeling.util import prepare_model
+    tok, enc, dec = prepare_model("random-init:64x2")
+    assert dec is None and enc.get_sentence_embedding_dimension() == 64 and enc.get_max_seq_length() == 512
+    texts = ["a red shoe", "blue", "", "the quick brown fox jumps over the lazy dog"]
+    emb = enc.encode(texts, batch_size=2, convert_to_numpy=True)
+    assert emb.shape == (4, 64) and emb.dtype == np.float32
+    feats = enc.tokenize(texts)
+    with torch.no_grad():
+        hid = enc.auto_model(**feats).last_hidden_state
+        m = feats["attention_mask"].unsqueeze(-1).float()
+        want = ((hid * m).sum(1) / m.sum(1).clamp(min=1e-9)).numpy()
+        got = enc(feats)["sentence_embedding"].numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(emb, want, rtol=1e-4, atol=1e-5)      # encode() sorts by length and restores the order
+    assert [k for k in enc.state_dict() if k.startswith("0.auto_model.")]      # sentence-transformers key layout
+    _, encn, _ = prepare_model("random-init:64x2", normalize=True)
+    np.testing.assert_allclose(np.linalg.norm(encn.encode(texts[:2]), axis=1), 1.0, rtol=1e-5)
+    with pytest.raises(ValueError):
+        prepare_model("/definitely/not/a/model")

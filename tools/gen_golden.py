@@ -305,6 +305,42 @@ def gen_trec_eval_step(out, DenseFlatIndex, LinearWeights, contrastive, FieldTyp
     return list(cases)
 
 
+def gen_loss(out, LinearWeights):
+    """HybridContrastiveLoss (losses.py:206-360) on tiny tensors, 1-rank gloo group (the reference only binds its
+    gathered variables in the multi-GPU branch, losses.py:254-273), loss value + gradients."""
+    import pickle
+    import torch.distributed as dist
+    from mfar.modeling.losses import HybridContrastiveLoss
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    res = {}
+    for name, use_bn in (("plain", False), ("bn", True)):
+        rng = np.random.default_rng(4242)
+        B, F, E, N = 5, 3, 16, 1
+        q = torch.tensor(gauss(rng, (B, E)), requires_grad=True)
+        d_pos = torch.tensor(gauss(rng, (B, F, E)), requires_grad=True)
+        d_neg = torch.tensor(gauss(rng, (B, F, N, E)), requires_grad=True)
+        W0 = gauss(rng, (E, F), std=0.3)
+        lw = LinearWeights(E, F, query_cond=True)
+        lw.weight.data = torch.from_numpy(W0.copy())
+        loss_fn = HybridContrastiveLoss(temperature=0.05, mixture_of_fields_layer=lw, sparse_indices_dict={}, num_fields=F,
+                                        use_batchnorm=use_bn)
+        loss_fn.train()
+        dumps = lambda x: pickle.dumps(x)
+        loss = loss_fn(q, dumps([f"q{i}" for i in range(B)]), d_pos, dumps([f"p{i}" for i in range(B)]), d_neg,
+                       dumps([f"n{i}" for i in range(B)]), dumps(list(range(B))), {})
+        loss.backward()
+        res.update({f"{name}__q": q.detach().numpy(), f"{name}__d_pos": d_pos.detach().numpy(), f"{name}__d_neg": d_neg.detach().numpy(),
+                    f"{name}__W": W0, f"{name}__loss": np.float32(loss.item()), f"{name}__grad_W": lw.weight.grad.numpy(),
+                    f"{name}__grad_q": q.grad.numpy(), f"{name}__grad_d_pos": d_pos.grad.numpy()})
+    res["temperature"] = np.float32(0.05)
+    np.savez_compressed(os.path.join(out, "hybrid_loss.npz"), **res)
+    dist.destroy_process_group()
+
+
 def gen_schema(out, resolve_fields, FieldType):
     d = {}
     for ds in ["mag", "prime", "amazon"]:
@@ -396,7 +432,7 @@ def gen_format(out, format_documents):
             except Exception as e:  # record the behaviour, whatever it is
                 res[f"{ds}|{fld}"] = {"raises": type(e).__name__}
     with open(os.path.join(out, "format_documents.json"), "w") as f:
-        json.dump({"docs": docs, "out": res}, f, indent=1, sort_keys=True)
+        json.dump({"docs": docs, "out": res}, f, indent=1)      # key order of the documents matters: no sort_keys
 
 
 def gen_memmap(out, MemoryMapDict):
@@ -462,6 +498,11 @@ def main():
     gen_trec(out, trec)
     gen_format(out, format_documents)
     gen_memmap(out, MemoryMapDict)
+    try:
+        gen_loss(out, LinearWeights)
+    except Exception as e:
+        import traceback; traceback.print_exc()
+        print("loss golden failed:", repr(e))
     try:
         gen_cli(out)
     except Exception as e:
