@@ -49,6 +49,7 @@ class SentenceEncoder(torch.nn.Sequential):
         cfg = auto_model.config
         limit = getattr(cfg, "max_position_embeddings", 512)
         self.max_seq_length = min(max_seq_length or limit, limit)
+        self.train(auto_model.training)      # the wrapper starts in the wrapped model's mode (from_pretrained: eval)
 
     @property
     def auto_model(self):
