@@ -61,8 +61,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # MFAR_BENCH_BACKEND=gloo + MFAR_BENCH_SHARE_GPU=1: dry-run of the N > 1 control flow on a one-GPU box (all ranks
+        # on cuda:0, host-staged collectives).  The driver's scaling runs use the default: nccl (= RCCL), one GPU per rank.
+        backend = os.environ.get("MFAR_BENCH_BACKEND", "nccl")
+        if os.environ.get("MFAR_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=N)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
@@ -130,6 +138,13 @@ def main():
             for j in range(Q):
                 rec.append(len(set(ids[j, :20].tolist()) & rel[j]) / len(rel[j]))
         recall20 = float(np.mean(rec))
+        checksum = None
+        if os.environ.get("MFAR_BENCH_DUMP_IDS") == "1":      # used by tests/test_gpu_multirank.py
+            import hashlib
+            h = hashlib.sha256()
+            for ids, _ in results:
+                h.update(ids.cpu().numpy().tobytes())
+            checksum = h.hexdigest()
         qps = args.steps * Q / dt
         s1_avg_ms = s1_ms / max(1, s1_n)
         flops_per_launch = 2.0 * (row1 - row0) * F * E * 64      # algorithmic: 2*D*F*E per query x 64 queries
@@ -145,7 +160,7 @@ def main():
                        "docs": D, "fields": F, "dim": E, "query_batch": Q, "k1": K1, "k2": K2,
                        "parallelism": f"row-shard x{N} + RCCL all-gather merge" if N > 1 else "single shard",
                        "pipeline": "2 batches in flight (stage 1 of batch i+1 overlaps the tail of batch i)"},
-            "recall_at_20": recall20,
+            "recall_at_20": recall20, "ids_checksum": checksum,
             "index_build_s": t_build,
             "roofline": {"bound": "mfma", "kernel": "mfar_stage1_kernel", "achieved": achieved_tf,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,

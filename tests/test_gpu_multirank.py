@@ -1,0 +1,35 @@
+"""The N > 1 path of bench.py end to end on ONE GPU: two ranks share cuda:0 and exchange payloads through gloo
+(RCCL refuses two ranks on one device).  Exercises row sharding, split-phase search_local, the all-gather, the merge with
+a caller workspace and the two-stream pipeline; the result must match the single-rank run of the same corpus."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(n, extra_env):
+    env = dict(os.environ, **extra_env)
+    args = ["--docs", "70000", "--fields", "4", "--dim", "128", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    if n == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + args
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_on_one_gpu_match_single_rank():
+    one = _bench(1, {"MFAR_BENCH_DUMP_IDS": "1"})
+    two = _bench(2, {"MFAR_BENCH_BACKEND": "gloo", "MFAR_BENCH_SHARE_GPU": "1", "MFAR_BENCH_DUMP_IDS": "1"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert one["recall_at_20"] > 0.3 and two["recall_at_20"] == one["recall_at_20"]   # (weak planted signal at dim 128)
+    assert two["ids_checksum"] == one["ids_checksum"]          # same top-100 ids for every query of every step
