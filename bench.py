@@ -150,6 +150,11 @@ def main():
         flops_per_launch = 2.0 * (row1 - row0) * F * E * 64      # algorithmic: 2*D*F*E per query x 64 queries
         bytes_per_launch = float(row1 - row0) * F * E * 4        # slab read once per batch
         achieved_tf = flops_per_launch / (s1_avg_ms * 1e-3) / 1e12 if s1_avg_ms > 0 else 0.0
+        traffic = None          # HBM bytes per stage-1 launch from the committed PMC pass of this same workload
+        tj = os.path.join(ROOT, "profiles", "r01_stage1_traffic.json")
+        if N == 1 and (D, F, E, Q) == (1_000_000, 8, 768, 64) and os.path.exists(tj):
+            t_ = json.load(open(tj))
+            traffic = t_["hbm_read_bytes_per_launch"] + t_["hbm_write_bytes_per_launch"]
         line = {
             "metric": "queries/sec (whole node) at Recall@20 parity, 1M-doc x 8-field x 768d corpus",
             "value": qps, "unit": "queries/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
@@ -164,7 +169,7 @@ def main():
             "index_build_s": t_build,
             "roofline": {"bound": "mfma", "kernel": "mfar_stage1_kernel", "achieved": achieved_tf,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "avg_launch_ms": s1_avg_ms, "launches": s1_n,
+                         "traffic": traffic, "traffic_source": "profiles/r01_stage1_traffic.json (rocprofv3 PMC pass)" if traffic else None, "avg_launch_ms": s1_avg_ms, "launches": s1_n,
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "hbm_GBps_algorithmic": bytes_per_launch / (s1_avg_ms * 1e-3) / 1e9 if s1_avg_ms > 0 else 0.0,
@@ -196,7 +201,20 @@ def cpu_baseline(corpus, ix, idxmod, args, np, torch):
     sub = idxmod.MultiFieldIndex(Ds, F, E, device=ix.device)
     for f in range(F):
         sub.write_rows(f, 0, slab[f])
-    n_batches, t_used, match = 0, 0.0, []
+    # the reference lets torch pick its thread count (= all cores); on many-core hosts the per-query python loop of
+    # small ops runs faster with fewer threads, so time one batch with 32 threads and one with all and keep the faster
+    q0 = corpus.queries(0, Q).cpu().numpy()
+    best_threads, best_t = cores, None
+    for th in sorted({min(32, cores), cores}):
+        torch.set_num_threads(th)
+        t0 = time.perf_counter()
+        O.ref_two_stage(slab, q0, W, mask)
+        dt0 = time.perf_counter() - t0
+        if best_t is None or dt0 < best_t:
+            best_threads, best_t = th, dt0
+    torch.set_num_threads(best_threads)
+    cores = best_threads
+    n_batches, t_used, match, match_tol = 0, 0.0, [], []
     while t_used < 12.0 and n_batches < 50:
         q = corpus.queries(n_batches * Q, Q).cpu().numpy()
         t0 = time.perf_counter()
@@ -204,13 +222,22 @@ def cpu_baseline(corpus, ix, idxmod, args, np, torch):
         t_used += time.perf_counter() - t0
         g = sub.search(q, W, mask)
         match.append(float(np.mean([np.array_equal(g["ids"][i, :20], ci[i, :20]) for i in range(Q)])))
+        ok = 0
+        for i in range(Q):
+            try:
+                O.assert_topk_equivalent(g["ids"][i], g["scores"][i], ci[i], cs[i], tol=1e-4)
+                ok += 1
+            except AssertionError:
+                pass
+        match_tol.append(ok / Q)
         n_batches += 1
     sub.close()
     qps_sample = n_batches * Q / t_used
     return {"value": qps_sample * Ds / corpus.D, "unit": "queries/s", "cores": cores, "kind": "port",
             "sample": f"{n_batches} batches of {Q} queries over the first {Ds} docs x {F} fields x {E}d of the same corpus "
                       f"({qps_sample:.1f} q/s on the sample, scaled by {Ds}/{corpus.D} to the full corpus; work is linear in docs)",
-            "top20_id_match_vs_gpu": float(np.mean(match))}
+            "top20_ids_identical_to_gpu": float(np.mean(match)),
+            "top100_equivalent_to_gpu_within_1e-4": float(np.mean(match_tol))}
 
 
 if __name__ == "__main__":

@@ -89,6 +89,7 @@ static int set_kernel_attrs(int device) {
     if (device < 0 || device >= 16) return fail(MFAR_ERR_INVALID, "device index out of range");
     if (g_attr_done[device]) return MFAR_OK;
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_lists_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_lists_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_lists_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -399,7 +400,7 @@ static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentine
         if (use_sample) {
             S1Params ps = p;
             ps.sample = 1;
-            mfar_stage1_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1_LDS_BYTES, st>>>(ps);
+            mfar_stage1_sample_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1_LDS_BYTES, st>>>(ps);
             HIPCHK(hipGetLastError());
             MergeParams ms = m;
             ms.out_ids = nullptr;

@@ -100,9 +100,10 @@ __device__ __forceinline__ float s1_compact(uint2* list, int n, int k) {
 // One k-step of loads for one wave: its own 4 KB doc tile (4 x 1 KB LDS-DMA) and its quarter of the shared query tile.
 __device__ __forceinline__ void s1_issue(const char* dsrc, const char* qsrc, char* dbuf, char* qbuf) {
 #pragma unroll
+    // aux = 2 (nt): the doc stream is read exactly once per batch, keep it from displacing the query tile in L2
     for (int p = 0; p < 4; ++p)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc + p * 1024),
-                                         (__attribute__((address_space(3))) void*)(dbuf + p * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(dbuf + p * 1024), 16, 0, 2);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)qsrc,
                                      (__attribute__((address_space(3))) void*)qbuf, 16, 0, 0);
 }
@@ -112,7 +113,7 @@ __device__ __forceinline__ void s1_issue(const char* dsrc, const char* qsrc, cha
 // decided by the merge).
 #define S1_PASS(v, tq, tg) ((v) > (tq) && (v) >= (tg))
 
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_kernel(const S1Params p) {
+__device__ __forceinline__ void s1_body(const S1Params& p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const qring = smem + S1_D_BYTES;
     float* tau_s = (float*)(smem + S1_D_BYTES + S1_Q_BYTES);
@@ -291,3 +292,8 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_kernel(const S1Para
         if (lane == 0) p.list_cnt[wgq0 + qq] = n;
     }
 }
+
+// The full pass and the threshold-estimation pass are the same code under two kernel names, so that profiles list them
+// separately (the sample pass scans 1 tile per workgroup and is ~30x shorter).
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_kernel(const S1Params p) { s1_body(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_sample_kernel(const S1Params p) { s1_body(p); }
