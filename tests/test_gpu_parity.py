@@ -344,3 +344,57 @@ def test_pipelined_searcher_equals_plain_search(idxmod):
     with pytest.raises(ValueError):
         ps.result(tickets[0])
     ix.close()
+
+
+@pytest.mark.parametrize("name,D,F,n_shards", [("stark-prime", 129_375, 22, 1), ("stark-mag", 700_244, 5, 1),
+                                               ("stark-amazon-8shards", 957_192, 8, 8)])
+def test_baseline_config_shapes(idxmod, name, D, F, n_shards):
+    """BASELINE.json configs[1..3] at their full shapes (synthetic vectors): size-independent properties, an oracle spot
+    check on a row subset that provably contains every stage-1 winner, and (config 3) the 8-way row-sharded path."""
+    import torch
+    from mfar import synth
+    E, Q = 768, 64
+    need = D * F * E * 4 * (2 if n_shards > 1 else 1) + (8 << 30)
+    if torch.cuda.mem_get_info(0)[0] < need:
+        pytest.skip("not enough free HBM")
+    corpus = synth.SyntheticCorpus(D, F, E, n_queries=Q, seed=0xdeadbeef, device="cuda:0")
+    q, W = corpus.queries(0, Q), corpus.W
+    mask = torch.ones(F, device="cuda:0")
+    mask[F // 2] = 0
+    ix = corpus.build_index(idxmod)
+    r = ix.search(q, W, mask, return_fields=True)
+    torch.cuda.synchronize()
+    ids, sc, fid, fsc = (r[k].cpu().numpy() for k in ("ids", "scores", "field_ids", "field_scores"))
+    assert (r["n_valid"].cpu().numpy() == 100).all()
+    assert (np.diff(sc, axis=1) <= 0).all() and (np.diff(fsc, axis=2) <= 0).all()
+    assert all(len(set(row.tolist())) == 100 for row in ids)
+    rel = corpus.qrels(0, Q)
+    assert np.mean([len(set(ids[i, :20].tolist()) & rel[i]) / len(rel[i]) for i in range(Q)]) > 0.9
+    # oracle spot check for 2 queries: rows = every stage-1 winner of those queries + random rows.  The per-field top-100 of
+    # the full corpus must be the per-field top-100 of that subset, with identical score bits.
+    for qi in (0, Q - 1):
+        rows = np.unique(np.concatenate([fid[qi].ravel(), np.random.default_rng(qi).integers(0, D, 5000)]))
+        # gather the subset rows from the index itself (read_rows is row-major == the reference memmap layout)
+        sub = np.empty((F, rows.size, E), np.float32)
+        for f in range(F):
+            for lo in range(0, rows.size, 512):
+                blk = rows[lo:lo + 512]
+                for j, x in enumerate(blk):
+                    sub[f, lo + j] = ix.read_rows(f, int(x), 1)[0]
+        qq = q[qi:qi + 1].cpu().numpy()
+        for f in range(F):
+            oi, osc = O.c_retrieve(sub[f], qq, 100, True)
+            assert np.array_equal(rows[oi[0]], fid[qi, f]), (name, qi, f)
+            assert np.array_equal(osc[0].view(np.uint32), fsc[qi, f].view(np.uint32)), (name, qi, f)
+    if n_shards > 1:
+        ix.close()
+        bounds = [D * g // n_shards for g in range(n_shards + 1)]
+        shards = [corpus.build_index(idxmod, row0=bounds[g], n=bounds[g + 1] - bounds[g]) for g in range(n_shards)]
+        payloads = torch.cat([s.search_local(q) for s in shards])
+        rm = idxmod.merge_payloads(payloads, n_shards, q, W, mask, n_fields=F)
+        torch.cuda.synchronize()
+        assert np.array_equal(rm["ids"].cpu().numpy(), ids) and np.array_equal(rm["scores"].cpu().numpy().view(np.uint32), sc.view(np.uint32))
+        for s in shards:
+            s.close()
+    else:
+        ix.close()
