@@ -86,6 +86,28 @@ __host__ __device__ __forceinline__ size_t tiled_offset(int64_t n_steps, int64_t
     return (size_t)((blk * n_steps + step) * 1024 + rr * 16 + p * 4 + (e & 3));
 }
 
+// bf16 slab: tile = [64 rows][16 dims] bf16 (2 KB); granule (8 dims) position p = c ^ ((rr >> 3) & 1)
+__host__ __device__ __forceinline__ size_t tiled_offset_bf16(int64_t n_steps, int64_t row, int e) {
+    const int64_t blk = row >> 6;
+    const int rr = (int)(row & 63);
+    const int step = e >> 4;
+    const int c = (e >> 3) & 1;
+    const int p = c ^ ((rr >> 3) & 1);
+    return (size_t)((blk * n_steps + step) * 1024 + rr * 16 + p * 8 + (e & 7));
+}
+// fp32 -> bf16, round to nearest even (same integer formula as the oracle; NaN stays NaN)
+__host__ __device__ __forceinline__ unsigned short f2bf(float x) {
+    union { float f; u32 u; } v;
+    v.f = x;
+    if ((v.u & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0;
+    return (unsigned short)((v.u + 0x7FFFu + ((v.u >> 16) & 1u)) >> 16);
+}
+__host__ __device__ __forceinline__ float bf2f(unsigned short b) {
+    union { float f; u32 u; } v;
+    v.u = (u32)b << 16;
+    return v.f;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Block-level exact top-k of n unique 64-bit keys held in LDS (256 threads, n <= 256 * NPT).
 // Result: sorted[0..m) descending, m = min(n, k) returned.  Every thread keeps its NPT keys in registers, so one

@@ -73,9 +73,10 @@ struct mfar_index {
     int F = 0, E = 0, dtype = 0;
     int64_t n_blk = 0;  // 64-row blocks per field, multiple of 4
     int n_steps = 0;
-    float* slab = nullptr;
+    void* slab = nullptr;         // fp32 or bf16 tiled slab
+    int esize = 4;                // bytes per stored element
     size_t slab_bytes = 0;
-    long long field_stride = 0;  // floats
+    long long field_stride = 0;   // elements between fields
     int n_cu = 256;
     int wgs_per_cu = 2;
     DevBuf qt, lists, list_cnt, gtau, fid, fsc, cand[2], ncand[2], x[2], in[8], out[8];
@@ -95,7 +96,10 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_lists_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_shards_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_shards_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)mfar_score_candidates_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_score_candidates_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_score_candidates_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1B_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1B_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_mix_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     g_attr_done[device] = true;
     return MFAR_OK;
@@ -123,8 +127,7 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     if (row_offset + n_rows_local >= 0xFFFFFFFELL) return fail(MFAR_ERR_INVALID, "doc ids must fit in 32 bits");
     if (n_fields <= 0 || n_fields > MFAR_MAX_FIELDS) return fail(MFAR_ERR_INVALID, "n_fields must be in [1, 32]");
     if (dim <= 0 || (dim & 31)) return fail(MFAR_ERR_INVALID, "dim must be a positive multiple of 32");
-    if (dtype == MFAR_DTYPE_BF16) return fail(MFAR_ERR_UNSUPPORTED, "bf16 slab is not implemented in this build");
-    if (dtype != MFAR_DTYPE_F32) return fail(MFAR_ERR_INVALID, "unknown dtype");
+    if (dtype != MFAR_DTYPE_F32 && dtype != MFAR_DTYPE_BF16) return fail(MFAR_ERR_INVALID, "unknown dtype");
     int ndev = 0;
     RETCHK(mfar_device_count(&ndev));
     if (device < 0 || device >= ndev) return fail(MFAR_ERR_INVALID, "no such device");
@@ -144,10 +147,11 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     if (n_blk == 0) n_blk = 4;
     idx->n_blk = n_blk;
     idx->field_stride = (long long)n_blk * 64 * dim;
-    idx->slab_bytes = (size_t)idx->field_stride * 4 * n_fields;
+    idx->esize = dtype == MFAR_DTYPE_BF16 ? 2 : 4;
+    idx->slab_bytes = (size_t)idx->field_stride * idx->esize * n_fields;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) idx->n_cu = prop.multiProcessorCount;
-    hipError_t e = hipMalloc((void**)&idx->slab, idx->slab_bytes);
+    hipError_t e = hipMalloc(&idx->slab, idx->slab_bytes);
     if (e != hipSuccess) {
         delete idx;
         return fail(MFAR_ERR_NOMEM, std::string("hipMalloc(slab ") + std::to_string(idx->slab_bytes) + " B): " + hipGetErrorString(e));
@@ -241,7 +245,7 @@ extern "C" int mfar_index_write_rows(mfar_index* idx, int field, int64_t local_r
     if (n == 0) return MFAR_OK;
     HIPCHK(hipSetDevice(idx->device));
     hipStream_t st = (hipStream_t)stream;
-    float* fbase = idx->slab + (size_t)field * idx->field_stride;
+    char* fbase = (char*)idx->slab + (size_t)field * idx->field_stride * idx->esize;
     const int64_t chunk = on_device ? n : std::min<int64_t>(n, (int64_t)(256u << 20) / (idx->E * 4));
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
         const int64_t m = std::min(chunk, n - r0);
@@ -251,8 +255,14 @@ extern "C" int mfar_index_write_rows(mfar_index* idx, int field, int64_t local_r
             HIPCHK(hipMemcpyAsync(idx->in[0].p, s, (size_t)m * idx->E * 4, hipMemcpyHostToDevice, st));
             s = idx->in[0].as<float>();
         }
-        const long long total = m * (idx->E / 4);
-        mfar_tile_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(s, fbase, local_row0 + r0, m, idx->E);
+        if (idx->dtype == MFAR_DTYPE_BF16) {
+            const long long total = m * (idx->E / 8);
+            mfar_tile_rows_bf16_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(s, (unsigned short*)fbase,
+                                                                                                     local_row0 + r0, m, idx->E);
+        } else {
+            const long long total = m * (idx->E / 4);
+            mfar_tile_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(s, (float*)fbase, local_row0 + r0, m, idx->E);
+        }
         HIPCHK(hipGetLastError());
         if (!on_device) HIPCHK(hipStreamSynchronize(st));
     }
@@ -265,7 +275,7 @@ extern "C" int mfar_index_read_rows(mfar_index* idx, int field, int64_t local_ro
     if (n == 0) return MFAR_OK;
     HIPCHK(hipSetDevice(idx->device));
     hipStream_t st = (hipStream_t)stream;
-    const float* fbase = idx->slab + (size_t)field * idx->field_stride;
+    const char* fbase = (const char*)idx->slab + (size_t)field * idx->field_stride * idx->esize;
     const int64_t chunk = on_device ? n : std::min<int64_t>(n, (int64_t)(256u << 20) / (idx->E * 4));
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
         const int64_t m = std::min(chunk, n - r0);
@@ -275,8 +285,14 @@ extern "C" int mfar_index_read_rows(mfar_index* idx, int field, int64_t local_ro
             RETCHK(idx->out[0].ensure((size_t)m * idx->E * 4));
             dd = idx->out[0].as<float>();
         }
-        const long long total = m * (idx->E / 4);
-        mfar_untile_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(fbase, dd, local_row0 + r0, m, idx->E);
+        if (idx->dtype == MFAR_DTYPE_BF16) {
+            const long long total = m * (idx->E / 8);
+            mfar_untile_rows_bf16_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>((const unsigned short*)fbase, dd,
+                                                                                                       local_row0 + r0, m, idx->E);
+        } else {
+            const long long total = m * (idx->E / 4);
+            mfar_untile_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>((const float*)fbase, dd, local_row0 + r0, m, idx->E);
+        }
         HIPCHK(hipGetLastError());
         if (!on_device) {
             HIPCHK(hipMemcpyAsync(d, dd, (size_t)m * idx->E * 4, hipMemcpyDeviceToHost, st));
@@ -346,18 +362,24 @@ static int stage1_chunks(const mfar_index* idx) {
 static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentinel, long long* fid, float* fsc, hipStream_t st) {
     const int n_chunks = stage1_chunks(idx);
     const int n_tiles = (int)(idx->n_blk / 4);
-    RETCHK(idx->qt.ensure((size_t)idx->n_steps * 4096));
+    const bool bf16 = idx->dtype == MFAR_DTYPE_BF16;
+    RETCHK(idx->qt.ensure((size_t)idx->n_steps * (bf16 ? 8192 : 4096)));
     RETCHK(idx->lists.ensure((size_t)idx->F * n_chunks * 64 * S1_CAP * sizeof(uint2)));
     RETCHK(idx->list_cnt.ensure((size_t)idx->F * n_chunks * 64 * sizeof(int)));
     RETCHK(idx->gtau.ensure((size_t)idx->F * 64 * sizeof(float)));
     for (int q0 = 0; q0 < Q; q0 += 64) {
         const int qt_n = std::min(64, Q - q0);
-        const int total = 64 * (idx->E / 4);
-        mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, idx->qt.as<float>(), q0, Q, idx->E);
+        if (bf16) {
+            const int total = 64 * (idx->E / 8);
+            mfar_tile_queries_bf16_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, idx->qt.as<unsigned short>(), q0, Q, idx->E);
+        } else {
+            const int total = 64 * (idx->E / 4);
+            mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, idx->qt.as<float>(), q0, Q, idx->E);
+        }
         HIPCHK(hipGetLastError());
         S1Params p;
         p.slab = idx->slab;
-        p.qt = idx->qt.as<float>();
+        p.qt = idx->qt.p;
         p.lists = idx->lists.as<uint2>();
         p.list_cnt = idx->list_cnt.as<int>();
         p.field_stride = idx->field_stride;
@@ -400,7 +422,8 @@ static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentine
         if (use_sample) {
             S1Params ps = p;
             ps.sample = 1;
-            mfar_stage1_sample_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1_LDS_BYTES, st>>>(ps);
+            if (bf16) mfar_stage1_bf16_sample_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1B_LDS_BYTES, st>>>(ps);
+            else mfar_stage1_sample_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1_LDS_BYTES, st>>>(ps);
             HIPCHK(hipGetLastError());
             MergeParams ms = m;
             ms.out_ids = nullptr;
@@ -425,7 +448,8 @@ static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentine
         }
         if (!idx->mid_ev) HIPCHK(hipEventCreateWithFlags(&idx->mid_ev, hipEventDisableTiming));
         HIPCHK(hipEventRecord(idx->mid_ev, st));
-        mfar_stage1_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1_LDS_BYTES, st>>>(p);
+        if (bf16) mfar_stage1_bf16_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1B_LDS_BYTES, st>>>(p);
+        else mfar_stage1_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1_LDS_BYTES, st>>>(p);
         HIPCHK(hipGetLastError());
         if (e1) HIPCHK(hipEventRecord(e1, st));
         m.out_ids = fid;
@@ -475,7 +499,8 @@ static int run_score(mfar_index* idx, const float* q, int Q, const long long* ca
     p.C = C;
     const unsigned gx = (unsigned)(((size_t)C * idx->F + 255) / 256);
     if (gx == 0 || Q == 0) return MFAR_OK;
-    mfar_score_candidates_kernel<<<dim3(gx, Q), dim3(256), SCORE_LDS_BYTES(idx->E), st>>>(p);
+    if (idx->dtype == MFAR_DTYPE_BF16) mfar_score_candidates_kernel<1><<<dim3(gx, Q), dim3(256), SCORE_LDS_BYTES(idx->E), st>>>(p);
+    else mfar_score_candidates_kernel<0><<<dim3(gx, Q), dim3(256), SCORE_LDS_BYTES(idx->E), st>>>(p);
     HIPCHK(hipGetLastError());
     return MFAR_OK;
 }

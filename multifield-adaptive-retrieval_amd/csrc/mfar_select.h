@@ -40,6 +40,64 @@ __global__ void mfar_tile_queries_kernel(const float* __restrict__ q, float* __r
     *(f32x4*)(qt + tiled_offset(E >> 4, r, e)) = v;
 }
 
+// bf16 slab variants: rows are rounded to bf16 (RNE) on the way in and widened exactly on the way out
+__global__ void mfar_tile_rows_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ field_base,
+                                           long long row0, long long n, int E) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gpr = E >> 3;  // 16-byte granules (8 bf16) per row
+    if (gid >= n * gpr) return;
+    const long long r = gid / gpr;
+    const int e = (int)(gid - r * gpr) << 3;
+    const f32x4 a = *(const f32x4*)(src + r * E + e), b = *(const f32x4*)(src + r * E + e + 4);
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[i] = (short)f2bf(a[i]);
+        o[4 + i] = (short)f2bf(b[i]);
+    }
+    *(bf16x8*)(field_base + tiled_offset_bf16(E >> 4, row0 + r, e)) = o;
+}
+__global__ void mfar_untile_rows_bf16_kernel(const unsigned short* __restrict__ field_base, float* __restrict__ dst,
+                                             long long row0, long long n, int E) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gpr = E >> 3;
+    if (gid >= n * gpr) return;
+    const long long r = gid / gpr;
+    const int e = (int)(gid - r * gpr) << 3;
+    const bf16x8 v = *(const bf16x8*)(field_base + tiled_offset_bf16(E >> 4, row0 + r, e));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[r * E + e + i] = bf2f((unsigned short)v[i]);
+}
+// queries q[Q, E] -> per k-step [4][64][16] bf16: three EXACT terms hi + mid + lo = q (bf16 keeps 8 significant bits, the
+// residual of a round-to-nearest split is exactly representable in fp32, and three terms cover fp32's 24 bits), 4th = 0
+__global__ void mfar_tile_queries_bf16_kernel(const float* __restrict__ q, unsigned short* __restrict__ qt, int q0, int Q, int E) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gpr = E >> 3;
+    if (gid >= 64 * gpr) return;
+    const int r = gid / gpr;
+    const int e = (gid - r * gpr) << 3;
+    bf16x8 hi, mid, lo, zero;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float x = (q0 + r < Q) ? q[(size_t)(q0 + r) * E + e + i] : 0.0f;
+        const unsigned short h = f2bf(x);
+        const float r1 = x - bf2f(h);
+        const unsigned short m = f2bf(r1);
+        const float r2 = r1 - bf2f(m);
+        hi[i] = (short)h;
+        mid[i] = (short)m;
+        lo[i] = (short)f2bf(r2);
+        zero[i] = 0;
+    }
+    const int step = e >> 4;
+    const size_t in_tile = tiled_offset_bf16(E >> 4, r, e) - (size_t)step * 1024;   // offset inside one [64][16] tile
+    unsigned short* base = qt + (size_t)step * 4096;                                 // 4 tiles of 1024 bf16 per k-step
+    *(bf16x8*)(base + in_tile) = hi;
+    *(bf16x8*)(base + 1024 + in_tile) = mid;
+    *(bf16x8*)(base + 2048 + in_tile) = lo;
+    *(bf16x8*)(base + 3072 + in_tile) = zero;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K_B: merge the per-workgroup lists of one (query, field) into the final sorted top-k list.
 //   grid = Qt * F workgroups (Qt <= 64 queries of this pass), dynamic LDS = n_chunks * k * 8 bytes.
@@ -221,8 +279,8 @@ __global__ void __launch_bounds__(256) mfar_union_kernel(const long long* __rest
 //   grid = (ceil(C*F/256), Q).
 // ---------------------------------------------------------------------------------------------------------
 struct ScoreParams {
-    const float* slab;
-    long long field_stride;  // floats
+    const void* slab;        // fp32 or bf16 tiled slab
+    long long field_stride;  // elements
     const float* q;          // [Q, E] row-major
     const long long* cand;   // [Q, C]
     const int* n_cand;       // [Q] or nullptr
@@ -234,14 +292,23 @@ struct ScoreParams {
 // (one per k-step), so the wave gathers them cooperatively -- 4 lanes per segment, 16 segments per 1 KB LDS-DMA
 // instruction -- into a private two-slot LDS ring (2 k-steps per slot), and every lane then walks ITS row's segment
 // from LDS in chain order.  No barriers: the ring is private to the wave, ordered by counted vmcnt waits.
-#define SC_STEPS 1                        // k-steps per ring slot (1 keeps the workgroup at 35 KB of LDS so that it can
-                                          // run beside two resident stage-1 workgroups when batches are pipelined)
-#define SC_SLOT_BYTES (SC_STEPS * 64 * 64) // 64 rows x 64 B per k-step
-#define SC_WAVE_BYTES (2 * SC_SLOT_BYTES)
+// fp32 slab: 64-byte segments (16 dims), 4 lanes per segment, ring slot = 1 k-step (4 KB per wave).
+// bf16 slab: 32-byte segments (16 dims), 2 lanes per segment, ring slot = 2 k-steps (4 KB per wave); the chain walks the
+//            dims in natural order and widens bf16 -> fp32 exactly, so scores equal the oracle's bits.
+#define SC_SLOT_BYTES 4096
+#define SC_WAVE_BYTES (2 * SC_SLOT_BYTES)   // two-slot ring; 35 KB per workgroup with the query row: fits beside two
+                                            // resident stage-1 workgroups when batches are pipelined
 #define SCORE_LDS_BYTES(E) ((size_t)4 * SC_WAVE_BYTES + (size_t)(E) * 4)
+template <int DT>
 __global__ void __launch_bounds__(256) mfar_score_candidates_kernel(const ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qs = (float*)(smem + 4 * SC_WAVE_BYTES);
+    constexpr int SEG = DT ? 32 : 64;                 // bytes of one row per k-step
+    constexpr int STEPS = DT ? 2 : 1;                 // k-steps per ring slot
+    constexpr int LPS = SEG / 16;                     // lanes per segment
+    constexpr int RPI = 64 / LPS;                     // rows per load instruction
+    constexpr int IPS = 64 / RPI;                     // load instructions per k-step
+    constexpr size_t STEP_STRIDE = DT ? 2048 : 4096;  // bytes between consecutive k-steps of a block
     const int qi = blockIdx.y;
     const int nc = p.n_cand ? p.n_cand[qi] : p.C;
     const int first = blockIdx.x * blockDim.x;
@@ -258,7 +325,7 @@ __global__ void __launch_bounds__(256) mfar_score_candidates_kernel(const ScoreP
     char* ring = smem + w * SC_WAVE_BYTES;
     // this lane's row
     bool valid = false;
-    int sw = 0;
+    int rr = 0;
     const char* rowbase = (const char*)p.slab;  // harmless in-bounds address for invalid rows
     if (idx < p.C * p.F) {
         const int c = idx / p.F, f = idx - c * p.F;
@@ -266,46 +333,45 @@ __global__ void __launch_bounds__(256) mfar_score_candidates_kernel(const ScoreP
             const long long id = p.cand[(size_t)qi * p.C + c] - p.row_offset;
             if (id >= 0 && id < p.n_rows) {
                 valid = true;
-                const int rr = (int)(id & 63);
-                sw = (rr >> 2) & 3;
-                rowbase = (const char*)(p.slab + (size_t)f * p.field_stride + (size_t)(id >> 6) * p.n_steps * 1024 + rr * 16);
+                rr = (int)(id & 63);
+                rowbase = (const char*)p.slab + ((size_t)f * p.field_stride + (size_t)(id >> 6) * p.n_steps * 1024) * (DT ? 2 : 4) + rr * SEG;
             }
         }
     }
-    // lane l fetches piece (l & 3) of the segments of rows (l >> 2) + 16 * i, i = 0..3
-    const char* src[4];
+    // lane l fetches piece (l % LPS) of the segments of rows (l / LPS) + RPI * i
+    const char* src[IPS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (lane >> 2) + 16 * i;
+    for (int i = 0; i < IPS; ++i) {
+        const int r = lane / LPS + RPI * i;
         const unsigned long long b = (unsigned long long)rowbase;
         const u32 lo = __shfl((int)(u32)b, r), hi = __shfl((int)(u32)(b >> 32), r);
-        src[i] = (const char*)(((unsigned long long)hi << 32) | lo) + (lane & 3) * 16;
+        src[i] = (const char*)(((unsigned long long)hi << 32) | lo) + (lane % LPS) * 16;
     }
-    const int n_groups = p.n_steps / SC_STEPS;  // n_steps is even (E % 32 == 0 is enforced by the host for this kernel)
+    const int n_groups = p.n_steps / STEPS;
 #define SC_ISSUE(G, SLOT)                                                                                          \
-    _Pragma("unroll") for (int s_ = 0; s_ < SC_STEPS; ++s_) _Pragma("unroll") for (int i = 0; i < 4; ++i)          \
+    _Pragma("unroll") for (int s_ = 0; s_ < STEPS; ++s_) _Pragma("unroll") for (int i = 0; i < IPS; ++i)           \
         __builtin_amdgcn_global_load_lds(                                                                         \
-            (const __attribute__((address_space(1))) void*)(src[i] + (size_t)((G) * SC_STEPS + s_) * 4096),       \
-            (__attribute__((address_space(3))) void*)(ring + (SLOT) * SC_SLOT_BYTES + s_ * 4096 + i * 1024), 16, 0, 0)
+            (const __attribute__((address_space(1))) void*)(src[i] + (size_t)((G) * STEPS + s_) * STEP_STRIDE),    \
+            (__attribute__((address_space(3))) void*)(ring + (SLOT) * SC_SLOT_BYTES + s_ * (64 * SEG) + i * 1024), 16, 0, 0)
     SC_ISSUE(0, 0);
     float acc = 0.0f;
     for (int g = 0; g < n_groups; ++g) {
         const int slot = g & 1;
         if (g + 1 < n_groups) {
             SC_ISSUE(g + 1, slot ^ 1);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // SC_STEPS * 4 newest loads may stay in flight
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // the 4 loads of the next slot may stay in flight
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        const char* seg = ring + slot * SC_SLOT_BYTES + lane * 64;
-#pragma unroll
-        for (int s_ = 0; s_ < SC_STEPS; ++s_) {
-            const float* t = (const float*)(seg + s_ * 4096);
+        const char* seg = ring + slot * SC_SLOT_BYTES + lane * SEG;
+        if (DT == 0) {
+            const int sw = (rr >> 2) & 3;
+            const float* t = (const float*)seg;
             const f32x4 c0 = *(const f32x4*)(t + ((0 ^ sw) << 2));
             const f32x4 c1 = *(const f32x4*)(t + ((1 ^ sw) << 2));
             const f32x4 c2 = *(const f32x4*)(t + ((2 ^ sw) << 2));
             const f32x4 c3 = *(const f32x4*)(t + ((3 ^ sw) << 2));
-            const float* qq = qs + (g * SC_STEPS + s_) * 16;
+            const float* qq = qs + g * 16;
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 acc = __builtin_fmaf(qq[x], c0[x], acc);
@@ -316,9 +382,21 @@ __global__ void __launch_bounds__(256) mfar_score_candidates_kernel(const ScoreP
                 acc = __builtin_fmaf(qq[8 + x], c2[x], acc);
                 acc = __builtin_fmaf(qq[12 + x], c3[x], acc);
             }
+        } else {
+            const int swb = (rr >> 3) & 1;
+#pragma unroll
+            for (int s_ = 0; s_ < STEPS; ++s_) {
+                const char* t = seg + s_ * (64 * SEG);
+                const bf16x8 c0 = *(const bf16x8*)(t + ((0 ^ swb) << 4));
+                const bf16x8 c1 = *(const bf16x8*)(t + ((1 ^ swb) << 4));
+                const float* qq = qs + (g * STEPS + s_) * 16;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) acc = __builtin_fmaf(qq[x], bf2f((unsigned short)c0[x]), acc);
+#pragma unroll
+                for (int x = 0; x < 8; ++x) acc = __builtin_fmaf(qq[8 + x], bf2f((unsigned short)c1[x]), acc);
+            }
         }
-        // the LDS reads of this slot have been consumed (their values fed the fma chain) before the slot is re-filled:
-        // the next SC_ISSUE into it is two iterations away in program order and ds_read results are waited for above
+        // the LDS reads of this slot have been consumed before the slot is re-filled two iterations later
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 #undef SC_ISSUE

@@ -5,16 +5,19 @@
 //
 //   * one workgroup = 4 waves = one contiguous chunk of 256-row tiles of ONE field, all 64 queries of the batch;
 //     each wave owns one 64-row block per tile and streams it from the tiled slab (mfar_device.h) with linear
-//     global_load_lds_dwordx4 (LDS-DMA) -- no shared operand, hence no barrier inside the K loop;
-//   * v_mfma_f32_32x32x2_f32: A = doc fragment (32 rows), B = query fragment (32 queries), 2x2 blocks per wave,
-//     K = 16 per step; the accumulation is one fma chain per score in the order the oracle documents;
+//     global_load_lds_dwordx4 (LDS-DMA) into a private LDS ring; only the query tile of a k-step is shared;
+//   * fp32 slab: v_mfma_f32_32x32x2_f32, A = doc fragment (32 rows), B = query fragment (32 queries), 2x2 blocks per
+//     wave, K = 16 per step; one fma chain per score in the order the oracle documents (bit-exact parity);
+//     bf16 slab: v_mfma_f32_32x32x16_bf16 against the query split EXACTLY into three bf16 terms (q = hi + mid + lo),
+//     so every product is exact in fp32 and only the fp32 accumulation order differs from the oracle;
 //   * epilogue: every lane owns ONE query column, its threshold tau (current k-th best of this workgroup's chunk)
 //     sits in a register; survivors (rare after warm-up) are appended to the workgroup's candidate list in HBM
-//     through an LDS slot counter; a list is compacted by a wave-level radix select when it could overflow;
+//     through one LDS slot reservation per lane; a list is compacted by a wave-level radix select when it could
+//     overflow;
 //   * the per-workgroup lists are merged by mfar_merge_lists_kernel (mfar_select.h).
 //
-// The kernel is bound by the fp32 MFMA rate (2*D*F*E flops per query, 157 TFLOP/s peak); at Q = 64 the slab read
-// (D*F*E*4 bytes per batch) needs ~4.9 TB/s at full MFMA rate, so both roofs are close.
+// fp32: bound by the fp32 MFMA rate (2*D*F*E flops per query, 157 TFLOP/s peak; at Q = 64 the slab read needs
+// ~4.9 TB/s at full MFMA rate, so both roofs are close).  bf16: bound by HBM (D*F*E*2 bytes per batch).
 #pragma once
 #include "mfar_device.h"
 
@@ -22,17 +25,24 @@
 #define S1_TILE_ROWS 256                     // rows per workgroup tile (4 waves x 64)
 #define S1_CAP 512                           // list capacity per (workgroup, query)
 #define S1_TRIG (S1_CAP - S1_TILE_ROWS)      // compact when more than this many entries are held
+#define S1_STATE_BYTES 784                   // tau[64] + cnt[64] + compaction flag (16 B) + tg[64]
+// fp32 slab: 4 KB doc tile per (wave, k-step of 16 dims), 4 KB query tile per k-step shared by the workgroup
 #define S1_STAGES 3                          // LDS ring depth: loads run two k-steps ahead of the MFMAs
-#define S1_D_BYTES (4 * S1_STAGES * 4096)    // per wave: S1_STAGES x 4 KB doc tile (private to the wave)
-#define S1_Q_BYTES (S1_STAGES * 4096)        // per workgroup: S1_STAGES x 4 KB query tile (shared by the 4 waves)
-#define S1_LDS_BYTES (S1_D_BYTES + S1_Q_BYTES + 784)  // + tau[64] + cnt[64] + compaction flag + tg[64]
+#define S1_D_BYTES (4 * S1_STAGES * 4096)
+#define S1_Q_BYTES (S1_STAGES * 4096)
+#define S1_LDS_BYTES (S1_D_BYTES + S1_Q_BYTES + S1_STATE_BYTES)
+// bf16 slab: 2 KB doc tile per (wave, k-step of 16 dims); query tile = 3 exact bf16 terms x 2 KB (padded to 8 KB)
+#define S1B_STAGES 5                         // HBM-bound: keep four k-steps of loads in flight per wave
+#define S1B_D_BYTES (4 * S1B_STAGES * 2048)
+#define S1B_Q_BYTES (S1B_STAGES * 8192)
+#define S1B_LDS_BYTES (S1B_D_BYTES + S1B_Q_BYTES + S1_STATE_BYTES)
 
 struct S1Params {
-    const float* slab;      // tiled, [F][n_blk][n_steps][64][16]
-    const float* qt;        // tiled queries [n_steps][64][16] (rows >= Q are zero)
+    const void* slab;       // tiled slab (fp32 or bf16)
+    const void* qt;         // tiled queries: fp32 [n_steps][64][16]; bf16 [n_steps][4][64][16] (terms hi, mid, lo, zero pad)
     uint2* lists;           // [F * n_chunks * 64][S1_CAP]  (score bits, local row)
     int* list_cnt;          // [F * n_chunks * 64]
-    long long field_stride; // floats between fields
+    long long field_stride; // elements between fields
     int n_rows;             // valid rows of this shard
     int n_steps;            // E / 16
     int n_tiles;            // n_blk / 4
@@ -97,29 +107,132 @@ __device__ __forceinline__ float s1_compact(uint2* list, int n, int k) {
     return ord2f(T);
 }
 
-// One k-step of loads for one wave: its own 4 KB doc tile (4 x 1 KB LDS-DMA) and its quarter of the shared query tile.
-__device__ __forceinline__ void s1_issue(const char* dsrc, const char* qsrc, char* dbuf, char* qbuf) {
-#pragma unroll
-    // aux = 2 (nt): the doc stream is read exactly once per batch, keep it from displacing the query tile in L2
-    for (int p = 0; p < 4; ++p)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc + p * 1024),
-                                         (__attribute__((address_space(3))) void*)(dbuf + p * 1024), 16, 0, 2);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)qsrc,
-                                     (__attribute__((address_space(3))) void*)qbuf, 16, 0, 0);
-}
-#define S1_LOADS_PER_STAGE 5
 // A score survives when it beats the workgroup's own running k-th best (strict: later rows lose ties to earlier
 // ones) AND is not below the global lower bound from the sample pass (non-strict: ties with other chunks are
 // decided by the merge).
 #define S1_PASS(v, tq, tg) ((v) > (tq) && (v) >= (tg))
 
-__device__ __forceinline__ void s1_body(const S1Params& p) {
+struct S1State {       // LDS-resident selection state of one workgroup
+    float* tau;        // [64] strict local thresholds
+    int* cnt;          // [64] list fill counts
+    int* flag;         // some list needs compaction this tile
+    float* tg;         // [64] non-strict global lower bounds
+};
+__device__ __forceinline__ S1State s1_state(char* base) {
+    S1State s;
+    s.tau = (float*)base;
+    s.cnt = (int*)(base + 256);
+    s.flag = (int*)(base + 512);
+    s.tg = (float*)(base + 528);
+    return s;
+}
+__device__ __forceinline__ void s1_state_init(const S1State& st, const S1Params& p, int f) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        st.tau[tid] = tid < p.Q ? p.tau0 : __builtin_inff();
+        st.cnt[tid] = 0;
+        st.tg[tid] = p.gtau ? p.gtau[f * 64 + tid] : -__builtin_inff();
+    }
+    if (tid == 0) *st.flag = 0;
+    __syncthreads();
+}
+
+// Selection epilogue of one 256-row tile.  acc[doc block][query block]: lane (j = lane & 31, h = lane >> 5) holds, for
+// query 32*qb + j, the scores of doc rows 32*db + (r & 3) + 8*(r >> 2) + 4*h (the MFMA 32x32 accumulator layout).
+__device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st, int t, int w, size_t wgq0, f32x16& acc00,
+                                            f32x16& acc01, f32x16& acc10, f32x16& acc11) {
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    if (t * S1_TILE_ROWS + S1_TILE_ROWS > p.n_rows) {  // last tile of the field: padding rows never qualify
+        const int row_w = t * S1_TILE_ROWS + w * 64 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_w + (r & 3) + 8 * (r >> 2);
+            if (row >= p.n_rows) acc00[r] = acc01[r] = -__builtin_inff();
+            if (row + 32 >= p.n_rows) acc10[r] = acc11[r] = -__builtin_inff();
+        }
+    }
+    // barrier A: the compactions of the previous tile (LDS writes of tau / cnt) are complete
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const float tq0 = st.tau[j], tq1 = st.tau[32 + j];
+    const float tg0 = st.tg[j], tg1 = st.tg[32 + j];
+    int n0 = 0, n1 = 0;  // survivors of this lane for query j / 32 + j
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        n0 += (S1_PASS(acc00[r], tq0, tg0) ? 1 : 0) + (S1_PASS(acc10[r], tq0, tg0) ? 1 : 0);
+        n1 += (S1_PASS(acc01[r], tq1, tg1) ? 1 : 0) + (S1_PASS(acc11[r], tq1, tg1) ? 1 : 0);
+    }
+    if (__any((n0 | n1) != 0)) {
+        // one LDS slot reservation per (lane, query block); inline asm keeps hipcc from draining the
+        // LDS-DMA prefetch (it would wait vmcnt(0) before an LDS atomic it can see)
+        int b0 = 0, b1 = 0;
+        if (n0) b0 = lds_add_rtn(&st.cnt[j], n0);
+        if (n1) b1 = lds_add_rtn(&st.cnt[32 + j], n1);
+        if ((n0 && b0 + n0 > S1_TRIG) || (n1 && b1 + n1 > S1_TRIG)) *st.flag = 1;
+        const int row_w = t * S1_TILE_ROWS + w * 64 + 4 * h;
+        uint2* l0 = p.lists + (wgq0 + j) * S1_CAP;
+        uint2* l1 = p.lists + (wgq0 + 32 + j) * S1_CAP;
+#define S1_APPEND(ACC, DB, TQ, TG, L, B)                                                                     \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                         \
+        const float v = ACC[r];                                                                              \
+        if (S1_PASS(v, TQ, TG)) {                                                                            \
+            if (B < S1_CAP) L[B] = make_uint2(__float_as_uint(v), (u32)(row_w + 32 * DB + (r & 3) + 8 * (r >> 2))); \
+            ++B;                                                                                             \
+        }                                                                                                    \
+    }
+        S1_APPEND(acc00, 0, tq0, tg0, l0, b0)
+        S1_APPEND(acc10, 1, tq0, tg0, l0, b0)
+        S1_APPEND(acc01, 0, tq1, tg1, l1, b1)
+        S1_APPEND(acc11, 1, tq1, tg1, l1, b1)
+#undef S1_APPEND
+    }
+    // barrier B: slot counters and the compaction flag of this tile are final
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (__builtin_amdgcn_readfirstlane(*st.flag)) {  // workgroup-uniform, rare after warm-up
+        // every wave's appended entries must be in memory before another wave compacts a list
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid == 0) *st.flag = 0;
+        // wave w serves queries 16w .. 16w+15
+        const int nv = lane < 16 ? min(st.cnt[16 * w + lane], S1_CAP) : 0;
+        u64 todo = __ballot(nv > S1_TRIG);
+        while (todo) {
+            const int b = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int qq = 16 * w + b;
+            const int n = __builtin_amdgcn_readlane(nv, b);
+            const float nt = s1_compact(p.lists + (wgq0 + qq) * S1_CAP, n, p.k);
+            if (lane == 0) {
+                st.tau[qq] = nt;
+                st.cnt[qq] = p.k;
+            }
+        }
+    }
+}
+
+// leave at most k entries per query and publish the counts
+__device__ __forceinline__ void s1_flush(const S1Params& p, const S1State& st, int w, size_t wgq0) {
+    const int lane = threadIdx.x & 63;
+    __syncthreads();
+    for (int qq = 16 * w; qq < 16 * w + 16; ++qq) {
+        int n = __builtin_amdgcn_readfirstlane(min(st.cnt[qq], S1_CAP));
+        if (n > p.k) {
+            s1_compact(p.lists + (wgq0 + qq) * S1_CAP, n, p.k);
+            n = p.k;
+        }
+        if (lane == 0) p.list_cnt[wgq0 + qq] = n;
+    }
+}
+
+#define S1_GLDS(SRC, DST, AUX)                                                                    \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),        \
+                                     (__attribute__((address_space(3))) void*)(DST), 16, 0, AUX)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 slab
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void s1_body_f32(const S1Params& p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const qring = smem + S1_D_BYTES;
-    float* tau_s = (float*)(smem + S1_D_BYTES + S1_Q_BYTES);
-    int* cnt_s = (int*)(smem + S1_D_BYTES + S1_Q_BYTES + 256);
-    int* flag_s = (int*)(smem + S1_D_BYTES + S1_Q_BYTES + 512);
-    float* tg_s = (float*)(smem + S1_D_BYTES + S1_Q_BYTES + 528);  // non-strict global lower bounds
+    const S1State st = s1_state(smem + S1_D_BYTES + S1_Q_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -132,14 +245,7 @@ __device__ __forceinline__ void s1_body(const S1Params& p) {
     int t1 = (int)(((long long)(chunk + 1) * p.n_tiles) / p.n_chunks);
     if (p.sample) t1 = min(t1, t0 + 1);
     const size_t wgq0 = (size_t)blockIdx.x * 64;
-
-    if (tid < 64) {
-        tau_s[tid] = tid < p.Q ? p.tau0 : __builtin_inff();
-        cnt_s[tid] = 0;
-        tg_s[tid] = p.gtau ? p.gtau[f * 64 + tid] : -__builtin_inff();
-    }
-    if (tid == 0) *flag_s = 0;
-    __syncthreads();
+    s1_state_init(st, p, f);
 
     // fragment read offsets inside a 4 KB tile: row (32*blk + j), dims 8g + 4h .. +3  (chunk c = 2g + h)
     const int sw = (j >> 2) & 3;
@@ -156,10 +262,12 @@ __device__ __forceinline__ void s1_body(const S1Params& p) {
     int s_next = 0, st_next = 0;
     const int total = (t1 - t0) * p.n_steps;
     int issued = 0;
+    // one k-step of loads: the wave's own 4 KB doc tile (nt: read once per batch) + its quarter of the shared query tile
 #define S1_ISSUE_NEXT()                                                                                   \
     do {                                                                                                  \
-        s1_issue(dnext, qbase + (size_t)s_next * step_bytes, dring + st_next * 4096,                      \
-                 qring + st_next * 4096 + w * 1024);                                                      \
+        char* db_ = dring + st_next * 4096;                                                               \
+        _Pragma("unroll") for (int pc = 0; pc < 4; ++pc) S1_GLDS(dnext + pc * 1024, db_ + pc * 1024, 2);   \
+        S1_GLDS(qbase + (size_t)s_next * step_bytes, qring + st_next * 4096 + w * 1024, 0);               \
         dnext += step_bytes;                                                                              \
         if (++s_next == p.n_steps) {                                                                      \
             s_next = 0;                                                                                   \
@@ -176,7 +284,7 @@ __device__ __forceinline__ void s1_body(const S1Params& p) {
         f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};  // [doc block][query block]
         for (int s = 0; s < p.n_steps; ++s, ++it) {
             // stage `it` must have landed (own doc tile: counted vmcnt; other waves' query quarters: the barrier).
-            // The S1_LOADS_PER_STAGE newest loads (stage it+1) may stay in flight.
+            // The 5 newest loads (stage it+1) may stay in flight.
             if (issued > it + 1)
                 asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
             else
@@ -209,91 +317,119 @@ __device__ __forceinline__ void s1_body(const S1Params& p) {
                 acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(d11[x], q11[x], acc11, 0, 0, 0);
             }
         }
-
         if (p.dbg & 1) {
             asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11));
             continue;
         }
-        // ---------------- epilogue: threshold filter + append ----------------
-        if (t * S1_TILE_ROWS + S1_TILE_ROWS > p.n_rows) {  // last tile of the field: padding rows never qualify
-            const int row_w = t * S1_TILE_ROWS + w * 64 + 4 * h;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row_w + (r & 3) + 8 * (r >> 2);
-                if (row >= p.n_rows) acc00[r] = acc01[r] = -__builtin_inff();
-                if (row + 32 >= p.n_rows) acc10[r] = acc11[r] = -__builtin_inff();
-            }
-        }
-        // barrier A: the compactions of the previous tile (LDS writes of tau / cnt) are complete
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const float tq0 = tau_s[j], tq1 = tau_s[32 + j];
-        const float tg0 = tg_s[j], tg1 = tg_s[32 + j];
-        int n0 = 0, n1 = 0;  // survivors of this lane for query j / 32 + j
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            n0 += (S1_PASS(acc00[r], tq0, tg0) ? 1 : 0) + (S1_PASS(acc10[r], tq0, tg0) ? 1 : 0);
-            n1 += (S1_PASS(acc01[r], tq1, tg1) ? 1 : 0) + (S1_PASS(acc11[r], tq1, tg1) ? 1 : 0);
-        }
-        if (__any((n0 | n1) != 0)) {
-            // one LDS slot reservation per (lane, query block); inline asm keeps hipcc from draining the
-            // LDS-DMA prefetch (it would wait vmcnt(0) before an LDS atomic it can see)
-            int b0 = 0, b1 = 0;
-            if (n0) b0 = lds_add_rtn(&cnt_s[j], n0);
-            if (n1) b1 = lds_add_rtn(&cnt_s[32 + j], n1);
-            if ((n0 && b0 + n0 > S1_TRIG) || (n1 && b1 + n1 > S1_TRIG)) *flag_s = 1;
-            const int row_w = t * S1_TILE_ROWS + w * 64 + 4 * h;
-            uint2* l0 = p.lists + (wgq0 + j) * S1_CAP;
-            uint2* l1 = p.lists + (wgq0 + 32 + j) * S1_CAP;
-#define S1_APPEND(ACC, DB, TQ, TG, L, B)                                                                         \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                         \
-        const float v = ACC[r];                                                                              \
-        if (S1_PASS(v, TQ, TG)) {                                                                            \
-            if (B < S1_CAP) L[B] = make_uint2(__float_as_uint(v), (u32)(row_w + 32 * DB + (r & 3) + 8 * (r >> 2))); \
-            ++B;                                                                                             \
-        }                                                                                                    \
-    }
-            S1_APPEND(acc00, 0, tq0, tg0, l0, b0)
-            S1_APPEND(acc10, 1, tq0, tg0, l0, b0)
-            S1_APPEND(acc01, 0, tq1, tg1, l1, b1)
-            S1_APPEND(acc11, 1, tq1, tg1, l1, b1)
-#undef S1_APPEND
-        }
-        // barrier B: slot counters and the compaction flag of this tile are final
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (__builtin_amdgcn_readfirstlane(*flag_s)) {  // workgroup-uniform, rare after warm-up
-            // every wave's appended entries must be in memory before another wave compacts a list
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            if (tid == 0) *flag_s = 0;
-            // wave w serves queries 16w .. 16w+15
-            const int nv = lane < 16 ? min(cnt_s[16 * w + lane], S1_CAP) : 0;
-            u64 todo = __ballot(nv > S1_TRIG);
-            while (todo) {
-                const int b = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const int qq = 16 * w + b;
-                const int n = __builtin_amdgcn_readlane(nv, b);
-                const float nt = s1_compact(p.lists + (wgq0 + qq) * S1_CAP, n, p.k);
-                if (lane == 0) {
-                    tau_s[qq] = nt;
-                    cnt_s[qq] = p.k;
-                }
-            }
-        }
+        s1_epilogue(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
 #undef S1_ISSUE_NEXT
-    // ---------------- flush: leave at most k entries per query, publish the counts ----------------
-    __syncthreads();
-    for (int qq = 16 * w; qq < 16 * w + 16; ++qq) {
-        int n = __builtin_amdgcn_readfirstlane(min(cnt_s[qq], S1_CAP));
-        if (n > p.k) {
-            s1_compact(p.lists + (wgq0 + qq) * S1_CAP, n, p.k);
-            n = p.k;
+    s1_flush(p, st, w, wgq0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 slab.  Tile = [64 rows][16 dims] bf16 = 2 KB; the 16-byte granule (8 dims) at (row rr, position p) holds dims
+// 16*step + 8c .. +7 with c = p ^ ((rr >> 3) & 1).  v_mfma_f32_32x32x16_bf16: lane (r = lane & 31, h = lane >> 5) supplies
+// A[row r][k = 8h .. 8h+7] and B[k = 8h .. 8h+7][col r], i.e. exactly one granule per operand per k-step.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void s1_body_bf16(const S1Params& p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const qring = smem + S1B_D_BYTES;
+    const S1State st = s1_state(smem + S1B_D_BYTES + S1B_Q_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    const int f = blockIdx.x / p.n_chunks;
+    const int chunk = blockIdx.x - f * p.n_chunks;
+    const int t0 = (int)(((long long)chunk * p.n_tiles) / p.n_chunks);
+    int t1 = (int)(((long long)(chunk + 1) * p.n_tiles) / p.n_chunks);
+    if (p.sample) t1 = min(t1, t0 + 1);
+    const size_t wgq0 = (size_t)blockIdx.x * 64;
+    s1_state_init(st, p, f);
+
+    // granule of row (32*blk + j), k-half h inside a 2 KB tile (rows are 32 B)
+    const int off = j * 32 + ((h ^ ((j >> 3) & 1)) << 4);
+
+    char* const dring = smem + w * (S1B_STAGES * 2048);
+    const size_t step_bytes = 2048;
+    const size_t tile_jump = (size_t)3 * p.n_steps * step_bytes;
+    const char* dnext = (const char*)p.slab + ((size_t)f * (size_t)p.field_stride) * 2 +
+                        ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes + lane * 16;
+    const char* const qbase = (const char*)p.qt + w * 2048 + lane * 16;   // wave w loads pieces 2w, 2w+1 of the 8 KB query tile
+    int s_next = 0, st_next = 0;
+    const int total = (t1 - t0) * p.n_steps;
+    int issued = 0;
+#define S1B_ISSUE_NEXT()                                                                                  \
+    do {                                                                                                  \
+        char* db_ = dring + st_next * 2048;                                                               \
+        S1_GLDS(dnext, db_, 2);                                                                           \
+        S1_GLDS(dnext + 1024, db_ + 1024, 2);                                                             \
+        const char* qs_ = qbase + (size_t)s_next * 8192;                                                  \
+        char* qd_ = qring + st_next * 8192 + w * 2048;                                                    \
+        S1_GLDS(qs_, qd_, 0);                                                                             \
+        S1_GLDS(qs_ + 1024, qd_ + 1024, 0);                                                               \
+        dnext += step_bytes;                                                                              \
+        if (++s_next == p.n_steps) {                                                                      \
+            s_next = 0;                                                                                   \
+            dnext += tile_jump;                                                                           \
+        }                                                                                                 \
+        st_next = (st_next == S1B_STAGES - 1) ? 0 : st_next + 1;                                          \
+        ++issued;                                                                                         \
+    } while (0)
+    for (int i = 0; i < S1B_STAGES - 1; ++i)
+        if (total > i) S1B_ISSUE_NEXT();
+
+    int it = 0, st_cur = 0;
+    for (int t = t0; t < t1; ++t) {
+        f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+        for (int s = 0; s < p.n_steps; ++s, ++it) {
+            // stage `it` landed; up to S1B_STAGES - 2 newer stages (4 loads each) may stay in flight
+            const int ahead = issued - it - 1;
+            if (ahead >= 3) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            const char* cur = dring + st_cur * 2048;
+            const char* curq = qring + st_cur * 8192;
+            st_cur = (st_cur == S1B_STAGES - 1) ? 0 : st_cur + 1;
+            const bf16x8 d0 = *(const bf16x8*)(cur + off);
+            const bf16x8 d1 = *(const bf16x8*)(cur + 1024 + off);
+            const bf16x8 qh0 = *(const bf16x8*)(curq + off), qh1 = *(const bf16x8*)(curq + 1024 + off);
+            const bf16x8 qm0 = *(const bf16x8*)(curq + 2048 + off), qm1 = *(const bf16x8*)(curq + 3072 + off);
+            const bf16x8 ql0 = *(const bf16x8*)(curq + 4096 + off), ql1 = *(const bf16x8*)(curq + 5120 + off);
+            if (issued < total) S1B_ISSUE_NEXT();
+            // smallest terms first: lo, mid, hi (all products are exact; this keeps the fp32 accumulation tight)
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, ql0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, ql1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, ql0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, ql1, acc11, 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qm0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qm1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qm0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qm1, acc11, 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qh0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qh1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qh0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qh1, acc11, 0, 0, 0);
         }
-        if (lane == 0) p.list_cnt[wgq0 + qq] = n;
+        if (p.dbg & 1) {
+            asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11));
+            continue;
+        }
+        s1_epilogue(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
+#undef S1B_ISSUE_NEXT
+    s1_flush(p, st, w, wgq0);
 }
 
 // The full pass and the threshold-estimation pass are the same code under two kernel names, so that profiles list them
 // separately (the sample pass scans 1 tile per workgroup and is ~30x shorter).
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_kernel(const S1Params p) { s1_body(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_sample_kernel(const S1Params p) { s1_body(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_kernel(const S1Params p) { s1_body_f32(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_sample_kernel(const S1Params p) { s1_body_f32(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16_kernel(const S1Params p) { s1_body_bf16(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16_sample_kernel(const S1Params p) { s1_body_bf16(p); }

@@ -96,10 +96,10 @@ class SyntheticCorpus:
             r += m
         return out
 
-    def build_index(self, idxmod, row0: int = 0, n: int = None):
+    def build_index(self, idxmod, row0: int = 0, n: int = None, dtype: str = "f32"):
         """A MultiFieldIndex holding rows [row0, row0+n) of every field (row_offset = row0)."""
         n = self.D - row0 if n is None else n
-        ix = idxmod.MultiFieldIndex(n, self.F, self.E, device=self.device.index or 0, row_offset=row0)
+        ix = idxmod.MultiFieldIndex(n, self.F, self.E, device=self.device.index or 0, row_offset=row0, dtype=dtype)
         for f in range(self.F):
             r = row0
             while r < row0 + n:

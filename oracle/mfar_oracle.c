@@ -38,11 +38,17 @@
 #define MFAR_ORACLE_VERSION 1
 
 static const int CHAIN_PERM[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+/* 0: the fp32-slab contract above (MFMA order).  1: natural dim order -- the contract of the bf16 slab, whose stage-2
+ * kernel walks the dims in order over bf16 values widened exactly to fp32 (feed this oracle the bf16-ROUNDED corpus:
+ * mfar_oracle_bf16_round). */
+static int g_chain_natural = 0;
+void mfar_oracle_set_chain(int natural) { g_chain_natural = natural; }
 
 int mfar_oracle_version(void) { return MFAR_ORACLE_VERSION; }
 
 /* position p in the chain -> dim index */
 static inline int chain_dim(int p, int E) {
+    if (g_chain_natural) return p;
     int g = p >> 3;
     if ((g << 3) + 8 <= E) return (g << 3) + CHAIN_PERM[p & 7];
     return p; /* ragged tail (E % 8 != 0): natural order; the GPU path rejects such E */
@@ -82,6 +88,17 @@ void mfar_oracle_scores(const float* V, int64_t D, int E, const float* q, int Q,
         free(acc);
     }
     free(qT);
+}
+
+/* fp32 -> bf16 -> fp32, round to nearest even: what the bf16 slab stores (same integer formula as the HIP kernel) */
+void mfar_oracle_bf16_round(const float* src, float* dst, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        union { float f; uint32_t u; } v;
+        v.f = src[i];
+        if ((v.u & 0x7FFFFFFFu) > 0x7F800000u) v.u = 0x7FC00000u;
+        else v.u = ((v.u + 0x7FFFu + ((v.u >> 16) & 1u)) >> 16) << 16;
+        dst[i] = v.f;
+    }
 }
 
 /* canonical order: a ranks before b */

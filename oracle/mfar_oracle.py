@@ -55,6 +55,10 @@ def lib():
         L.mfar_oracle_two_stage.restype = ctypes.c_int
         L.mfar_oracle_two_stage.argtypes = [f32p, ctypes.c_int, i64, ctypes.c_int, f32p, ctypes.c_int, f32p, ctypes.c_int, f32p,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, i64p, f32p, i32p, i64p, f32p, i32p]
+        L.mfar_oracle_set_chain.restype = None
+        L.mfar_oracle_set_chain.argtypes = [ctypes.c_int]
+        L.mfar_oracle_bf16_round.restype = None
+        L.mfar_oracle_bf16_round.argtypes = [f32p, f32p, i64]
         L.mfar_oracle_merge_lists.restype = ctypes.c_int
         L.mfar_oracle_merge_lists.argtypes = [i64p, f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, i64p, f32p]
         _LIB = L
@@ -70,6 +74,28 @@ def _p(a, t):
 
 
 # ----------------------------------------------------------------------------- C oracle bindings
+class chain:
+    """`with chain("natural"):` switches the dot-product order to the bf16-slab contract (natural dim order); the default
+    is the fp32-slab contract (the MFMA order documented in mfar_oracle.c)."""
+
+    def __init__(self, mode: str):
+        self.natural = {"mfma_f32": 0, "natural": 1}[mode]
+
+    def __enter__(self):
+        lib().mfar_oracle_set_chain(self.natural)
+
+    def __exit__(self, *a):
+        lib().mfar_oracle_set_chain(0)
+
+
+def bf16_round(a):
+    """fp32 -> bf16 (round to nearest even) -> fp32: the values a bf16 slab holds."""
+    a = _f32(a)
+    out = np.empty_like(a)
+    lib().mfar_oracle_bf16_round(_p(a, ctypes.c_float), _p(out, ctypes.c_float), a.size)
+    return out
+
+
 def c_exp(x: float) -> np.float32:
     return np.float32(lib().mfar_oracle_exp(ctypes.c_float(x)))
 

@@ -53,7 +53,7 @@ def test_argument_validation_without_device():
     assert L.mfar_index_create(ctypes.byref(h), 0, 10, 0, 99, 32, 0) == -1     # n_fields
     assert L.mfar_index_create(ctypes.byref(h), 0, -1, 0, 1, 32, 0) == -1
     assert L.mfar_index_create(ctypes.byref(h), 0, 2**32, 0, 1, 32, 0) == -1   # ids must fit 32 bits
-    assert L.mfar_index_create(ctypes.byref(h), 0, 10, 0, 1, 32, 1) == -4      # bf16 not in this build
+    assert L.mfar_index_create(ctypes.byref(h), 0, 10, 0, 1, 32, 7) == -1      # unknown dtype
     assert L.mfar_payload_bytes(64, 8, 100) > 64 * 800 * 8 * 4
     assert L.mfar_payload_bytes(-1, 8, 100) == 0
     assert L.mfar_merge_workspace_bytes(64, 8, 100) > 64 * 800 * 8 * 4

@@ -398,3 +398,104 @@ def test_baseline_config_shapes(idxmod, name, D, F, n_shards):
             s.close()
     else:
         ix.close()
+
+
+# ------------------------------------------------------------------------------------------------ bf16 slab
+def _load_bf16(idxmod, slab, row_offset=0):
+    F, D, E = slab.shape
+    ix = idxmod.MultiFieldIndex(D, F, E, device=0, row_offset=row_offset, dtype="bf16")
+    for f in range(F):
+        ix.write_rows(f, 0, slab[f])
+    return ix
+
+
+def test_bf16_slab_rows_are_rne_rounded(idxmod):
+    rng = np.random.default_rng(20)
+    slab = (rng.standard_normal((2, 300, 64)) * 3).astype(np.float32)
+    ix = _load_bf16(idxmod, slab)
+    assert ix.slab_bytes < 2 * 320 * 64 * 4      # half of an fp32 slab (rows padded to 256)
+    for f in range(2):
+        assert np.array_equal(ix.read_rows(f).view(np.uint32), O.bf16_round(slab[f]).view(np.uint32))
+    ix.close()
+
+
+def test_bf16_two_stage_vs_oracle(idxmod):
+    """bf16 slab (BASELINE.json configs[4]): docs are stored RNE-rounded; stage 1 runs v_mfma_f32_32x32x16_bf16 against
+    the query split exactly into three bf16 terms, so its scores equal the natural-order fp32 chain over the rounded docs
+    up to fp32 summation order (<= 1e-4, tolerant id check); stage 2 and the mixer walk that chain exactly -> final
+    scores are BIT-IDENTICAL to the oracle whenever the candidate sets agree."""
+    rng = np.random.default_rng(21)
+    exact_final = 0
+    cases = [(1, 700, 32, 5, 0.3), (4, 3000, 64, 9, 0.3), (3, 2500, 768, 66, 0.05), (8, 900, 96, 7, -0.4)]
+    for F, D, E, Q, mean in cases:
+        slab, q, W = _mk(rng, F, D, E, Q, mean=mean, dup=5)
+        mask = np.ones(F, np.float32)
+        if F > 2:
+            mask[1] = 0
+        ix = _load_bf16(idxmod, slab)
+        rs = O.bf16_round(slab)
+        for sentinel in (True, False):
+            r = ix.search(q, W, mask, sentinel=sentinel, return_fields=True)
+            with O.chain("natural"):
+                o = O.c_two_stage(rs, q, W, mask, sentinel=sentinel)
+            for f in range(F):
+                O.assert_topk_equivalent(r["field_ids"][:, f], r["field_scores"][:, f], o["field_ids"][:, f], o["field_scores"][:, f],
+                                         tol=TOL, what=f"bf16 stage1 F{F} D{D} f{f}")
+            O.assert_topk_equivalent(r["ids"], r["scores"], o["ids"], o["scores"], tol=TOL, what=f"bf16 final F{F} D{D}")
+            if np.array_equal(r["field_ids"], o["field_ids"]):
+                assert np.array_equal(r["ids"], o["ids"])
+                assert np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32))
+                exact_final += 1
+        # stage 2 alone: bit-exact
+        cand = rng.integers(0, D, size=(Q, 40)).astype(np.int64)
+        with O.chain("natural"):
+            ox = O.c_score_candidates(rs, q, cand)
+        assert np.array_equal(ix.score_candidates(q, cand).view(np.uint32), ox.view(np.uint32))
+        ix.close()
+    assert exact_final >= 6      # near-ties at a list boundary are rare on this data
+
+
+def test_bf16_sharded_equals_unsharded(idxmod):
+    rng = np.random.default_rng(22)
+    F, D, E, Q = 4, 2600, 64, 9
+    slab, q, W = _mk(rng, F, D, E, Q, mean=0.2, dup=7)
+    full = _load_bf16(idxmod, slab)
+    ref = full.search(q, W, None)
+    full.close()
+    for S in (2, 8):
+        bounds = [D * g // S for g in range(S + 1)]
+        shards = [_load_bf16(idxmod, slab[:, bounds[g]:bounds[g + 1]], row_offset=bounds[g]) for g in range(S)]
+        payloads = np.concatenate([sh.search_local(q) for sh in shards])
+        r = idxmod.merge_payloads(payloads, S, q, W, None)
+        assert np.array_equal(r["ids"], ref["ids"]) and np.array_equal(r["scores"].view(np.uint32), ref["scores"].view(np.uint32))
+        for sh in shards:
+            sh.close()
+
+
+def test_bf16_stress_shape_per_gpu(idxmod):
+    """BASELINE.json configs[4] (10M docs x 16 fields x 768d bf16 over 8 GPUs) at its PER-GPU shape: 1.25M x 16 x 768 bf16
+    = 30.7 GB.  Size-independent properties + re-sharding invariance."""
+    import torch
+    from mfar import synth
+    D, F, E, Q = 1_250_000, 16, 768, 64
+    if torch.cuda.mem_get_info(0)[0] < 80 << 30:
+        pytest.skip("needs ~70 GB of free HBM")
+    corpus = synth.SyntheticCorpus(D, F, E, n_queries=Q, seed=0xdeadbeef, device="cuda:0")
+    ix = corpus.build_index(idxmod, dtype="bf16")
+    q, W = corpus.queries(0, Q), corpus.W
+    r1 = ix.search(q, W, None, return_fields=True)
+    r2 = ix.search(q, W, None)
+    torch.cuda.synchronize()
+    assert torch.equal(r1["ids"], r2["ids"]) and torch.equal(r1["scores"], r2["scores"])
+    sc = r1["scores"].cpu().numpy()
+    assert (np.diff(sc, axis=1) <= 0).all() and (r1["n_valid"].cpu().numpy() == 100).all()
+    rel = corpus.qrels(0, Q)
+    assert np.mean([len(set(r1["ids"][i, :20].tolist()) & rel[i]) / len(rel[i]) for i in range(Q)]) > 0.9
+    ix.close()
+    half = D // 2
+    shards = [corpus.build_index(idxmod, row0=0, n=half, dtype="bf16"), corpus.build_index(idxmod, row0=half, n=D - half, dtype="bf16")]
+    rm = idxmod.merge_payloads(torch.cat([s.search_local(q) for s in shards]), 2, q, W, None, n_fields=F)
+    torch.cuda.synchronize()
+    assert torch.equal(rm["ids"], r1["ids"]) and torch.equal(rm["scores"], r1["scores"])
+    for s in shards:
+        s.close()
