@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--wgs-per-cu", type=int, default=0)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="slab storage (default: the exact fp32 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-docs", type=int, default=100_000)
     args = ap.parse_args()
@@ -84,7 +85,7 @@ def main():
     t_build = time.time()
     corpus = synth.SyntheticCorpus(D, F, E, n_queries=n_q_total, seed=0xDEADBEEF, device=str(dev))
     row0, row1 = D * rank // N, D * (rank + 1) // N          # contrastive.py:470
-    ix = corpus.build_index(idxmod, row0=row0, n=row1 - row0)
+    ix = corpus.build_index(idxmod, row0=row0, n=row1 - row0, dtype=args.dtype)
     if args.wgs_per_cu:
         ix.set_wgs_per_cu(args.wgs_per_cu)
     t_build = time.time() - t_build
@@ -148,27 +149,31 @@ def main():
         qps = args.steps * Q / dt
         s1_avg_ms = s1_ms / max(1, s1_n)
         flops_per_launch = 2.0 * (row1 - row0) * F * E * 64      # algorithmic: 2*D*F*E per query x 64 queries
-        bytes_per_launch = float(row1 - row0) * F * E * 4        # slab read once per batch
+        esize = 2 if args.dtype == "bf16" else 4
+        bytes_per_launch = float(row1 - row0) * F * E * esize    # slab read once per batch
         achieved_tf = flops_per_launch / (s1_avg_ms * 1e-3) / 1e12 if s1_avg_ms > 0 else 0.0
         traffic = None          # HBM bytes per stage-1 launch from the committed PMC pass of this same workload
         tj = os.path.join(ROOT, "profiles", "r01_stage1_traffic.json")
-        if N == 1 and (D, F, E, Q) == (1_000_000, 8, 768, 64) and os.path.exists(tj):
+        if N == 1 and args.dtype == "f32" and (D, F, E, Q) == (1_000_000, 8, 768, 64) and os.path.exists(tj):
             t_ = json.load(open(tj))
             traffic = t_["hbm_read_bytes_per_launch"] + t_["hbm_write_bytes_per_launch"]
         line = {
             "metric": "queries/sec (whole node) at Recall@20 parity, 1M-doc x 8-field x 768d corpus",
             "value": qps, "unit": "queries/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic STaRK-amazon-shaped corpus, {D} docs x {F} dense fields x {E}d fp32, "
+            "dtype": "f32" if args.dtype == "f32" else "bf16 docs x fp32 queries (3 exact bf16 terms), fp32 accumulate", "data": "synthetic",
+            "config": {"workload": f"synthetic STaRK-amazon-shaped corpus, {D} docs x {F} dense fields x {E}d {args.dtype}, "
                                    f"row-sharded over {N} GPU(s); two-stage scorer k1=k2=100, zero-sentinel mode",
                        "docs": D, "fields": F, "dim": E, "query_batch": Q, "k1": K1, "k2": K2,
                        "parallelism": f"row-shard x{N} + RCCL all-gather merge" if N > 1 else "single shard",
                        "pipeline": "2 batches in flight (stage 1 of batch i+1 overlaps the tail of batch i)"},
             "recall_at_20": recall20, "ids_checksum": checksum,
             "index_build_s": t_build,
-            "roofline": {"bound": "mfma", "kernel": "mfar_stage1_kernel", "achieved": achieved_tf,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
+            "roofline": ({"bound": "mfma", "kernel": "mfar_stage1_kernel", "achieved": achieved_tf,
+                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS}
+                         if args.dtype == "f32" else
+                         {"bound": "hbm", "kernel": "mfar_stage1_bf16_kernel", "achieved": bytes_per_launch / (s1_avg_ms * 1e-3) / 1e9,
+                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_per_launch / (s1_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}) | {
                          "traffic": traffic, "traffic_source": "profiles/r01_stage1_traffic.json (rocprofv3 PMC pass)" if traffic else None, "avg_launch_ms": s1_avg_ms, "launches": s1_n,
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "algorithmic_bytes_per_launch": bytes_per_launch,

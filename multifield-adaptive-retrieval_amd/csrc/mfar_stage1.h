@@ -31,10 +31,12 @@
 #define S1_D_BYTES (4 * S1_STAGES * 4096)
 #define S1_Q_BYTES (S1_STAGES * 4096)
 #define S1_LDS_BYTES (S1_D_BYTES + S1_Q_BYTES + S1_STATE_BYTES)
-// bf16 slab: 2 KB doc tile per (wave, k-step of 16 dims); query tile = 3 exact bf16 terms x 2 KB (padded to 8 KB)
+// bf16 slab: 2 KB doc tile per (wave, k-step of 16 dims); query tile = 3 exact bf16 terms x 2 KB = 6 KB in LDS
+// (8 KB per k-step in memory, the 4th quarter is padding): 72 KB per workgroup -> two workgroups per CU
 #define S1B_STAGES 5                         // HBM-bound: keep four k-steps of loads in flight per wave
 #define S1B_D_BYTES (4 * S1B_STAGES * 2048)
-#define S1B_Q_BYTES (S1B_STAGES * 8192)
+#define S1B_Q_STAGE 6144
+#define S1B_Q_BYTES (S1B_STAGES * S1B_Q_STAGE)
 #define S1B_LDS_BYTES (S1B_D_BYTES + S1B_Q_BYTES + S1_STATE_BYTES)
 
 struct S1Params {
@@ -360,7 +362,10 @@ __device__ __forceinline__ void s1_body_bf16(const S1Params& p) {
     const size_t tile_jump = (size_t)3 * p.n_steps * step_bytes;
     const char* dnext = (const char*)p.slab + ((size_t)f * (size_t)p.field_stride) * 2 +
                         ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes + lane * 16;
-    const char* const qbase = (const char*)p.qt + w * 2048 + lane * 16;   // wave w loads pieces 2w, 2w+1 of the 8 KB query tile
+    // the 6 KB query tile is 6 pieces of 1 KB: waves 0-1 load pieces {2w, 2w+1}, waves 2-3 load piece 2+w (twice, so that
+    // every wave issues the same number of loads per stage and the counted vmcnt waits stay uniform)
+    const int qp0 = w < 2 ? 2 * w : 2 + w, qp1 = w < 2 ? 2 * w + 1 : 2 + w;
+    const char* const qbase = (const char*)p.qt + lane * 16;
     int s_next = 0, st_next = 0;
     const int total = (t1 - t0) * p.n_steps;
     int issued = 0;
@@ -370,9 +375,9 @@ __device__ __forceinline__ void s1_body_bf16(const S1Params& p) {
         S1_GLDS(dnext, db_, 2);                                                                           \
         S1_GLDS(dnext + 1024, db_ + 1024, 2);                                                             \
         const char* qs_ = qbase + (size_t)s_next * 8192;                                                  \
-        char* qd_ = qring + st_next * 8192 + w * 2048;                                                    \
-        S1_GLDS(qs_, qd_, 0);                                                                             \
-        S1_GLDS(qs_ + 1024, qd_ + 1024, 0);                                                               \
+        char* qd_ = qring + st_next * S1B_Q_STAGE;                                                        \
+        S1_GLDS(qs_ + qp0 * 1024, qd_ + qp0 * 1024, 0);                                                   \
+        S1_GLDS(qs_ + qp1 * 1024, qd_ + qp1 * 1024, 0);                                                   \
         dnext += step_bytes;                                                                              \
         if (++s_next == p.n_steps) {                                                                      \
             s_next = 0;                                                                                   \
@@ -395,7 +400,7 @@ __device__ __forceinline__ void s1_body_bf16(const S1Params& p) {
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             const char* cur = dring + st_cur * 2048;
-            const char* curq = qring + st_cur * 8192;
+            const char* curq = qring + st_cur * S1B_Q_STAGE;
             st_cur = (st_cur == S1B_STAGES - 1) ? 0 : st_cur + 1;
             const bf16x8 d0 = *(const bf16x8*)(cur + off);
             const bf16x8 d1 = *(const bf16x8*)(cur + 1024 + off);
