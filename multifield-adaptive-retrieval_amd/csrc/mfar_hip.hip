@@ -125,6 +125,7 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     *out = nullptr;
     if (n_rows_local < 0 || row_offset < 0) return fail(MFAR_ERR_INVALID, "negative row count / offset");
     if (row_offset + n_rows_local >= 0xFFFFFFFELL) return fail(MFAR_ERR_INVALID, "doc ids must fit in 32 bits");
+    if (n_rows_local > 0x7FFFFC00LL) return fail(MFAR_ERR_INVALID, "at most 2^31 - 1024 rows per shard");
     if (n_fields <= 0 || n_fields > MFAR_MAX_FIELDS) return fail(MFAR_ERR_INVALID, "n_fields must be in [1, 32]");
     if (dim <= 0 || (dim & 31)) return fail(MFAR_ERR_INVALID, "dim must be a positive multiple of 32");
     if (dtype != MFAR_DTYPE_F32 && dtype != MFAR_DTYPE_BF16) return fail(MFAR_ERR_INVALID, "unknown dtype");

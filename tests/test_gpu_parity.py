@@ -499,3 +499,29 @@ def test_bf16_stress_shape_per_gpu(idxmod):
     assert torch.equal(rm["ids"], r1["ids"]) and torch.equal(rm["scores"], r1["scores"])
     for s in shards:
         s.close()
+
+
+def test_empty_and_degenerate_inputs(idxmod):
+    """Empty shard, empty query batch, a single row, k = 1: the edge cases of index.py:181-222 / contrastive.py:669-704."""
+    rng = np.random.default_rng(30)
+    E = 32
+    q = rng.standard_normal((3, E)).astype(np.float32)
+    W = rng.standard_normal((E, 2)).astype(np.float32)
+    ix = idxmod.MultiFieldIndex(0, 2, E)                      # no rows at all
+    ids, sc = ix.retrieve_fields(q, 100, sentinel=True)
+    assert (ids == 0).all() and (sc == 0).all()               # lists are pure sentinel padding
+    ids, sc = ix.retrieve_fields(q, 100, sentinel=False)
+    assert (ids == -1).all() and np.isneginf(sc).all()
+    r = ix.search(q, W, None, sentinel=False)
+    assert (r["n_valid"] == 0).all() and (r["ids"] == -1).all()
+    r = ix.search(q[:0], W, None)                             # empty batch
+    assert r["ids"].shape == (0, 100)
+    ix.close()
+    one = np.abs(rng.standard_normal((2, 1, E))).astype(np.float32)
+    ix = _load(idxmod, one)
+    qq = np.abs(q)
+    r = ix.search(qq, W, None, k1=1, k2=1, return_fields=True)
+    o = O.c_two_stage(one, qq, W, None, k1=1, k2=1)
+    assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32))
+    assert (r["n_valid"] == 1).all() and (r["field_ids"] == 0).all()
+    ix.close()
