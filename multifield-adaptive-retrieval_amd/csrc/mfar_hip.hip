@@ -79,7 +79,7 @@ struct mfar_index {
     long long field_stride = 0;   // elements between fields
     int n_cu = 256;
     int wgs_per_cu = 2;
-    DevBuf qt, lists, list_cnt, gtau, fid, fsc, cand[2], ncand[2], x[2], in[8], out[8];
+    DevBuf qt, lists, list_cnt, gtau, fid, fsc, cand[2], ncand[2], x[2], own[2], in[8], out[8];
     hipEvent_t mid_ev = nullptr;  // recorded right before the full stage-1 kernel is launched
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -94,6 +94,8 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_lists_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_lists_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_lists_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_topk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_topk_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_shards_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_shards_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_score_candidates_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -174,7 +176,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
     DevBuf* bufs[] = {&idx->qt, &idx->lists, &idx->list_cnt, &idx->gtau, &idx->fid, &idx->fsc, &idx->cand[0], &idx->cand[1],
-                      &idx->ncand[0], &idx->ncand[1], &idx->x[0], &idx->x[1]};
+                      &idx->ncand[0], &idx->ncand[1], &idx->x[0], &idx->x[1], &idx->own[0], &idx->own[1]};
     for (DevBuf* b : bufs) b->release();
     for (auto& b : idx->in) b.release();
     for (auto& b : idx->out) b.release();
@@ -878,3 +880,129 @@ extern "C" int mfar_merge_payloads(int device, const void* payloads, int n_shard
     if (!own_ws) HIPCHK(hipStreamSynchronize(st));
     return MFAR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ lists-first exchange
+struct ListsLayout {
+    long long ids, scores, total;
+};
+static ListsLayout lists_layout(int Q, int F, int k1) {
+    auto up = [](long long v) { return (v + 255) & ~255LL; };
+    ListsLayout L;
+    L.ids = 0;
+    L.scores = up((long long)Q * F * k1 * 8);
+    L.total = up(L.scores + (long long)Q * F * k1 * 4);
+    return L;
+}
+struct TopkLayout {
+    long long ids, scores, ncand, total;
+};
+static TopkLayout topk_layout(int Q, int k2) {
+    auto up = [](long long v) { return (v + 255) & ~255LL; };
+    TopkLayout L;
+    L.ids = 0;
+    L.scores = up((long long)Q * k2 * 8);
+    L.ncand = up(L.scores + (long long)Q * k2 * 4);
+    L.total = up(L.ncand + (long long)Q * 4);
+    return L;
+}
+extern "C" int64_t mfar_lists_bytes(int Q, int n_fields, int k1) {
+    if (Q < 0 || n_fields <= 0 || k1 <= 0) return 0;
+    return lists_layout(Q, n_fields, k1).total;
+}
+extern "C" int64_t mfar_topk_bytes(int Q, int k2) {
+    if (Q < 0 || k2 <= 0) return 0;
+    return topk_layout(Q, k2).total;
+}
+
+extern "C" int mfar_retrieve_lists(mfar_index* idx, const float* q, int Q, int k1, int sentinel, void* lists, void* stream) {
+    RETCHK(check_search_common(idx, q, Q, k1));
+    if (!lists) return fail(MFAR_ERR_INVALID, "lists is NULL");
+    HIPCHK(hipSetDevice(idx->device));
+    if (Q == 0) return MFAR_OK;
+    const ListsLayout L = lists_layout(Q, idx->F, k1);
+    return run_stage1(idx, q, Q, k1, sentinel, (long long*)((char*)lists + L.ids), (float*)((char*)lists + L.scores), (hipStream_t)stream);
+}
+
+extern "C" int mfar_search_owned(mfar_index* idx, const void* gathered_lists, int n_shards, const float* q, int Q, const float* W,
+                                 int query_cond, const float* mask, int k1, int k2, int sentinel, int slot, void* topk,
+                                 void* stream) {
+    RETCHK(check_search_common(idx, q, Q, k1));
+    const int F = idx->F, E = idx->E, C = F * k1;
+    RETCHK(check_mix(Q, C, F, E, k2, q, W, query_cond));
+    if (!gathered_lists || !topk || n_shards <= 0 || n_shards > 64) return fail(MFAR_ERR_INVALID, "bad lists / topk / n_shards");
+    if (slot < 0 || slot > 1) return fail(MFAR_ERR_INVALID, "slot must be 0 or 1");
+    if (Q == 0) return MFAR_OK;
+    HIPCHK(hipSetDevice(idx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const ListsLayout LL = lists_layout(Q, F, k1);
+    const TopkLayout TL = topk_layout(Q, k2);
+    const size_t nl = (size_t)Q * F * k1;
+    // per-slot scratch: merged lists (ids | scores), global union, owned run, counts, owned score vectors
+    DevBuf& ws = idx->own[slot];
+    const size_t off_lids = 0, off_lsc = off_lids + nl * 8, off_cand = off_lsc + ((nl * 4 + 255) & ~(size_t)255),
+                 off_owned = off_cand + (size_t)Q * C * 8, off_ncand = off_owned + (size_t)Q * C * 8,
+                 off_nowned = off_ncand + (((size_t)Q * 4 + 255) & ~(size_t)255), off_x = off_nowned + (((size_t)Q * 4 + 255) & ~(size_t)255);
+    RETCHK(ws.ensure(off_x + (size_t)Q * C * F * 4));
+    char* wb = ws.as<char>();
+    long long* lids = (long long*)(wb + off_lids);
+    float* lsc = (float*)(wb + off_lsc);
+    long long* cand = (long long*)(wb + off_cand);
+    long long* owned = (long long*)(wb + off_owned);
+    int* ncand = (int*)(wb + off_ncand);
+    int* nowned = (int*)(wb + off_nowned);
+    float* x = (float*)(wb + off_x);
+    ShardMergeParams sp;
+    sp.payloads = (const char*)gathered_lists;
+    sp.payload_stride = LL.total;
+    sp.ids_off = LL.ids;
+    sp.scores_off = LL.scores;
+    sp.out_ids = lids;
+    sp.out_scores = lsc;
+    sp.S = n_shards;
+    sp.F = F;
+    sp.k = k1;
+    sp.sentinel = sentinel;
+    if (n_shards * k1 <= 8 * 256) mfar_merge_shards_kernel<8><<<dim3(Q * F), dim3(256), SEL_LDS_BYTES(n_shards * k1), st>>>(sp);
+    else mfar_merge_shards_kernel<32><<<dim3(Q * F), dim3(256), SEL_LDS_BYTES(n_shards * k1), st>>>(sp);
+    HIPCHK(hipGetLastError());
+    mfar_union_kernel<<<dim3(Q), dim3(256), 0, st>>>(lids, F, k1, cand, ncand);
+    HIPCHK(hipGetLastError());
+    mfar_filter_owned_kernel<<<dim3(Q), dim3(64), 0, st>>>(cand, ncand, C, idx->row_offset, idx->row_offset + idx->n_rows, owned, nowned);
+    HIPCHK(hipGetLastError());
+    RETCHK(run_score(idx, q, Q, owned, nowned, C, x, st));
+    char* tb = (char*)topk;
+    RETCHK(run_mix(x, owned, nowned, q, W, query_cond, mask, Q, C, F, E, k2, (long long*)(tb + TL.ids), (float*)(tb + TL.scores),
+                   nullptr, st));
+    HIPCHK(hipMemcpyAsync(tb + TL.ncand, ncand, (size_t)Q * 4, hipMemcpyDeviceToDevice, st));
+    return MFAR_OK;
+}
+
+extern "C" int mfar_merge_topk(int device, const void* gathered_topk, int n_shards, int Q, int k2, int64_t* ids, float* scores,
+                               int32_t* n_valid, void* stream) {
+    if (!gathered_topk || !ids || !scores || n_shards <= 0 || n_shards > 64) return fail(MFAR_ERR_INVALID, "bad arguments");
+    if (k2 <= 0 || k2 > MFAR_MAX_K || Q < 0) return fail(MFAR_ERR_INVALID, "bad k2 / Q");
+    if (Q == 0) return MFAR_OK;
+    int ndev = 0;
+    RETCHK(mfar_device_count(&ndev));
+    if (device < 0 || device >= ndev || device >= 16) return fail(MFAR_ERR_INVALID, "no such device");
+    HIPCHK(hipSetDevice(device));
+    RETCHK(set_kernel_attrs(device));
+    const TopkLayout TL = topk_layout(Q, k2);
+    TopkMergeParams p;
+    p.payloads = (const char*)gathered_topk;
+    p.stride = TL.total;
+    p.ids_off = TL.ids;
+    p.scores_off = TL.scores;
+    p.ncand_off = TL.ncand;
+    p.ids = (long long*)ids;
+    p.scores = scores;
+    p.n_valid = (int*)n_valid;
+    p.S = n_shards;
+    p.k = k2;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_shards * k2 <= 8 * 256) mfar_merge_topk_kernel<8><<<dim3(Q), dim3(256), SEL_LDS_BYTES(n_shards * k2), st>>>(p);
+    else mfar_merge_topk_kernel<32><<<dim3(Q), dim3(256), SEL_LDS_BYTES(n_shards * k2), st>>>(p);
+    HIPCHK(hipGetLastError());
+    return MFAR_OK;
+}
+

@@ -549,3 +549,67 @@ __global__ void __launch_bounds__(256) mfar_mix_topk_kernel(const MixParams p) {
     }
     if (threadIdx.x == 0 && p.n_valid) p.n_valid[qi] = m;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Lists-first multi-GPU exchange (two small collectives instead of one large one):
+//   every rank all-gathers only its stage-1 LISTS; then every rank merges them, forms the same global candidate union,
+//   re-scores and mixes ONLY the candidates whose rows it owns, and the ranks exchange their local top-k.
+// mfar_filter_owned_kernel: the union is sorted, so the candidates of rows [row_lo, row_hi) are one contiguous run.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) mfar_filter_owned_kernel(const long long* __restrict__ cand, const int* __restrict__ n_cand,
+                                                               int C, long long row_lo, long long row_hi,
+                                                               long long* __restrict__ owned, int* __restrict__ n_owned) {
+    const int q = blockIdx.x;
+    const long long* c = cand + (size_t)q * C;
+    const int n = n_cand[q];
+    int lo = 0, hi = n;                      // first index with c[i] >= row_lo
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (c[mid] < row_lo) lo = mid + 1; else hi = mid;
+    }
+    const int lb = lo;
+    hi = n;                                  // first index with c[i] >= row_hi
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (c[mid] < row_hi) lo = mid + 1; else hi = mid;
+    }
+    const int m = lo - lb;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) owned[(size_t)q * C + i] = i < m ? c[lb + i] : -1;
+    if (threadIdx.x == 0) n_owned[q] = m;
+}
+
+// final merge of the per-rank local top-k lists: [S][Q][k] (ids, scores) -> top-k; n_valid = min(global candidates, k)
+struct TopkMergeParams {
+    const char* payloads;        // S payloads, `stride` bytes apart: ids[Q,k] int64 | scores[Q,k] f32 | n_cand_global[Q] int32
+    long long stride, ids_off, scores_off, ncand_off;
+    long long* ids;
+    float* scores;
+    int* n_valid;
+    int S, k;
+};
+template <int NPT>
+__global__ void __launch_bounds__(256) mfar_merge_topk_kernel(const TopkMergeParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SelLds L = sel_lds(smem, p.S * p.k);
+    const int q = blockIdx.x;
+    if (threadIdx.x == 0) L.misc[0] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.S * p.k; i += blockDim.x) {
+        const int s = i / p.k, r = i - s * p.k;
+        const char* pl = p.payloads + (size_t)s * p.stride;
+        const long long id = ((const long long*)(pl + p.ids_off))[(size_t)q * p.k + r];
+        if (id >= 0) L.keys[lds_add_rtn(&L.misc[0], 1)] = make_key(((const float*)(pl + p.scores_off))[(size_t)q * p.k + r], (u32)id);
+    }
+    __syncthreads();
+    const int n = L.misc[0];
+    const int m = block_topk_sorted<NPT>(L.keys, n, p.k, L.sel, L.sorted, L.red);
+    for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
+        p.ids[(size_t)q * p.k + r] = r < m ? (long long)key_id(L.sorted[r]) : -1;
+        p.scores[(size_t)q * p.k + r] = r < m ? key_score(L.sorted[r]) : -__builtin_inff();
+    }
+    if (threadIdx.x == 0 && p.n_valid) {
+        const int ng = ((const int*)(p.payloads + p.ncand_off))[q];      // every rank derived the same global union
+        p.n_valid[q] = min(ng, p.k);
+    }
+}
+

@@ -54,6 +54,11 @@ SIGNATURES = {
     "mfar_search_local": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "mfar_merge_workspace_bytes": (_i64, [_i, _i, _i]),
     "mfar_merge_payloads": (_i, [_i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    "mfar_lists_bytes": (_i64, [_i, _i, _i]),
+    "mfar_topk_bytes": (_i64, [_i, _i]),
+    "mfar_retrieve_lists": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "mfar_search_owned": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "mfar_merge_topk": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mfar_stream_wait_stage1_start": (_i, [_vp, _vp]),
     "mfar_set_timing": (_i, [_vp, _i]),
     "mfar_stage1_timing": (_i, [_vp, _c.POINTER(_c.c_double), _c.POINTER(_i)]),

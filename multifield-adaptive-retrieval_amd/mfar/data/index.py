@@ -231,6 +231,36 @@ class MultiFieldIndex:
                                                        int(qa.on_device), _current_stream(self.device, qa.on_device)))
         return payload
 
+    # ---- lists-first exchange (two small collectives; see include/mfar_hip.h) ----
+    def lists_bytes(self, Q: int, k1: int = 100) -> int:
+        return int(_native.lib().mfar_lists_bytes(int(Q), self.n_fields, int(k1)))
+
+    @staticmethod
+    def topk_bytes(Q: int, k2: int = 100) -> int:
+        return int(_native.lib().mfar_topk_bytes(int(Q), int(k2)))
+
+    def retrieve_lists(self, q, lists, k1: int = 100, sentinel: bool = True):
+        """Stage 1 into a flat uint8 CUDA buffer of lists_bytes() (the unit of the first all-gather)."""
+        qa, la = _Arg(q, np.float32, self.device), _Arg(lists, np.uint8, self.device)
+        if not _same_side([qa, la]):
+            raise ValueError("retrieve_lists needs CUDA tensors")
+        _native.check(_native.lib().mfar_retrieve_lists(self._h, qa.ptr, qa.keep.shape[0], int(k1), int(bool(sentinel)), la.ptr,
+                                                         _current_stream(self.device, True)))
+        return lists
+
+    def search_owned(self, gathered_lists, n_shards: int, q, W, topk, mask=None, k1: int = 100, k2: int = 100, sentinel: bool = True,
+                     query_cond: bool = True, slot: int = 0):
+        """Merge the gathered lists, score + mix the candidates this shard owns, write the local top-k2 payload."""
+        qa, Wa = _Arg(q, np.float32, self.device), _Arg(W, np.float32, self.device)
+        ma = _Arg(mask, np.float32, self.device, allow_none=True)
+        ga, ta = _Arg(gathered_lists, np.uint8, self.device), _Arg(topk, np.uint8, self.device)
+        if not _same_side([qa, Wa, ma, ga, ta]):
+            raise ValueError("search_owned needs CUDA tensors")
+        _native.check(_native.lib().mfar_search_owned(self._h, ga.ptr, int(n_shards), qa.ptr, qa.keep.shape[0], Wa.ptr,
+                                                       int(bool(query_cond)), ma.ptr, int(k1), int(k2), int(bool(sentinel)), int(slot),
+                                                       ta.ptr, _current_stream(self.device, True)))
+        return topk
+
     # instrumentation for bench.py
     def set_timing(self, enable: bool):
         _native.check(_native.lib().mfar_set_timing(self._h, int(bool(enable))))
@@ -269,6 +299,21 @@ def merge_payloads(payloads, n_shards: int, q, W, mask=None, n_fields: int = Non
     _native.check(_native.lib().mfar_merge_payloads(
         int(device), pa.ptr, int(n_shards), qa.ptr, Q, E, Wa.ptr, int(bool(query_cond)), ma.ptr, int(n_fields), int(k1), int(k2),
         int(bool(sentinel)), ia.ptr, sa.ptr, na.ptr, wa.ptr, wbytes, int(on_dev), _current_stream(device, on_dev)))
+    return dict(ids=ids, scores=sc, n_valid=nv)
+
+
+def merge_topk(gathered_topk, n_shards: int, Q: int, k2: int = 100, device: int = 0, out=None):
+    """Final merge of the all-gathered local top-k payloads (lists-first exchange)."""
+    ga = _Arg(gathered_topk, np.uint8, device)
+    if not ga.on_device:
+        raise ValueError("merge_topk needs CUDA tensors")
+    out = dict(out) if out else {}
+    ids = out.get("ids") if out.get("ids") is not None else _empty_like_side(True, device, (Q, k2), np.int64)
+    sc = out.get("scores") if out.get("scores") is not None else _empty_like_side(True, device, (Q, k2), np.float32)
+    nv = out.get("n_valid") if out.get("n_valid") is not None else _empty_like_side(True, device, (Q,), np.int32)
+    ia, sa, na = _Arg(ids, np.int64, device), _Arg(sc, np.float32, device), _Arg(nv, np.int32, device)
+    _native.check(_native.lib().mfar_merge_topk(int(device), ga.ptr, int(n_shards), int(Q), int(k2), ia.ptr, sa.ptr, na.ptr,
+                                                _current_stream(device, True)))
     return dict(ids=ids, scores=sc, n_valid=nv)
 
 

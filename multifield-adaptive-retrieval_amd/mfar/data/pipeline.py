@@ -41,11 +41,12 @@ class PipelinedSearcher:
             if self.world == 1:
                 s["fid"] = torch.empty(self.Qmax, F, k1, dtype=torch.int64, device=self.dev)
                 s["fsc"] = torch.empty(self.Qmax, F, k1, device=self.dev)
-            else:
-                nb = index.payload_bytes(self.Qmax, k1)
-                s["payload"] = torch.empty(nb, dtype=torch.uint8, device=self.dev)
-                s["gathered"] = torch.empty(nb * self.world, dtype=torch.uint8, device=self.dev)
-                s["ws"] = torch.empty(_index.merge_workspace_bytes(self.Qmax, F, k1), dtype=torch.uint8, device=self.dev)
+            else:       # lists-first exchange: two small all-gathers per batch (include/mfar_hip.h)
+                nl, nt = index.lists_bytes(self.Qmax, k1), index.topk_bytes(self.Qmax, k2)
+                s["lists"] = torch.empty(nl, dtype=torch.uint8, device=self.dev)
+                s["lists_all"] = torch.empty(nl * self.world, dtype=torch.uint8, device=self.dev)
+                s["topk"] = torch.empty(nt, dtype=torch.uint8, device=self.dev)
+                s["topk_all"] = torch.empty(nt * self.world, dtype=torch.uint8, device=self.dev)
             s["done"].record(torch.cuda.current_stream(self.dev))
             self.slots.append(s)
         self.n_submitted = 0
@@ -67,11 +68,12 @@ class PipelinedSearcher:
             if self.world == 1:
                 self.ix.search_stage2(qk, self.W, s["fid"][:Q], self.mask, self.k1, self.k2, self.query_cond, slot=t & 1, out=out)
             else:
-                self.ix.search_local(qk, k1=self.k1, sentinel=self.sentinel, payload=s["payload"], phases=2)
-                torch.distributed.all_gather_into_tensor(s["gathered"], s["payload"], group=self.group)
-                _index.merge_payloads(s["gathered"], self.world, qk, self.W, self.mask, n_fields=self.ix.n_fields, k1=self.k1,
-                                      k2=self.k2, sentinel=self.sentinel, query_cond=self.query_cond, device=self.ix.device,
-                                      workspace=s["ws"], out=out)
+                dist = torch.distributed
+                dist.all_gather_into_tensor(s["lists_all"], s["lists"], group=self.group)
+                self.ix.search_owned(s["lists_all"], self.world, qk, self.W, s["topk"], self.mask, self.k1, self.k2, self.sentinel,
+                                     self.query_cond, slot=t & 1)
+                dist.all_gather_into_tensor(s["topk_all"], s["topk"], group=self.group)
+                _index.merge_topk(s["topk_all"], self.world, Q, self.k2, device=self.ix.device, out=out)
             s["done"].record(self.side)
 
     def submit(self, q) -> int:
@@ -96,7 +98,7 @@ class PipelinedSearcher:
                     self.ix._h, qk.data_ptr(), Q, int(self.k1), int(bool(self.sentinel)), s["fid"].data_ptr(), s["fsc"].data_ptr(), 1,
                     self.main.cuda_stream))
             else:
-                self.ix.search_local(qk, k1=self.k1, sentinel=self.sentinel, payload=s["payload"], phases=1)
+                self.ix.retrieve_lists(qk, s["lists"], self.k1, self.sentinel)
             s["stage1"].record(self.main)
         s["tail_pending"] = True
         if t >= 1:

@@ -525,3 +525,37 @@ def test_empty_and_degenerate_inputs(idxmod):
     assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32))
     assert (r["n_valid"] == 1).all() and (r["field_ids"] == 0).all()
     ix.close()
+
+
+def test_lists_first_exchange_equals_unsharded(idxmod):
+    """The two-collective multi-GPU path (mfar_retrieve_lists -> gather -> mfar_search_owned -> gather -> mfar_merge_topk)
+    with 1/2/4/8 in-process shards on one GPU: bitwise the unsharded search, fp32 and bf16 slabs, both sentinel modes."""
+    import torch
+    rng = np.random.default_rng(40)
+    F, D, E, Q = 4, 2700, 64, 11
+    slab, q, W = _mk(rng, F, D, E, Q, mean=0.2, dup=9)
+    mask = np.array([1, 0, 1, 1], np.float32)
+    dev = torch.device("cuda:0")
+    qd, Wd, md = (torch.from_numpy(a).to(dev) for a in (q, W, mask))
+    for dtype, loader in (("f32", _load), ("bf16", _load_bf16)):
+        for sentinel in (True, False):
+            full = loader(idxmod, slab)
+            ref = full.search(q, W, mask, sentinel=sentinel)
+            full.close()
+            for S in (1, 2, 4, 8):
+                bounds = [D * g // S for g in range(S + 1)]
+                shards = [loader(idxmod, slab[:, bounds[g]:bounds[g + 1]], row_offset=bounds[g]) for g in range(S)]
+                nl, nt = shards[0].lists_bytes(Q), shards[0].topk_bytes(Q)
+                lists_all = torch.empty(S * nl, dtype=torch.uint8, device=dev)
+                for g, sh in enumerate(shards):
+                    sh.retrieve_lists(qd, lists_all[g * nl:(g + 1) * nl], 100, sentinel)
+                topk_all = torch.empty(S * nt, dtype=torch.uint8, device=dev)
+                for g, sh in enumerate(shards):
+                    sh.search_owned(lists_all, S, qd, Wd, topk_all[g * nt:(g + 1) * nt], md, sentinel=sentinel)
+                r = idxmod.merge_topk(topk_all, S, Q)
+                torch.cuda.synchronize()
+                assert np.array_equal(r["ids"].cpu().numpy(), ref["ids"]), (dtype, sentinel, S)
+                assert np.array_equal(r["scores"].cpu().numpy().view(np.uint32), ref["scores"].view(np.uint32)), (dtype, sentinel, S)
+                assert np.array_equal(r["n_valid"].cpu().numpy(), ref["n_valid"]), (dtype, sentinel, S)
+                for sh in shards:
+                    sh.close()
