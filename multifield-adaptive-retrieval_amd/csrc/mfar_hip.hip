@@ -79,7 +79,7 @@ struct mfar_index {
     long long field_stride = 0;   // elements between fields
     int n_cu = 256;
     int wgs_per_cu = 2;
-    DevBuf qt, lists, list_cnt, gtau, fid, fsc, cand[2], ncand[2], x[2], own[2], in[8], out[8];
+    DevBuf qt, lists, list_cnt, gtau, samp, fid, fsc, cand[2], ncand[2], x[2], own[2], in[8], out[8];
     hipEvent_t mid_ev = nullptr;  // recorded right before the full stage-1 kernel is launched
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -175,7 +175,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     (void)hipDeviceSynchronize();
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
-    DevBuf* bufs[] = {&idx->qt, &idx->lists, &idx->list_cnt, &idx->gtau, &idx->fid, &idx->fsc, &idx->cand[0], &idx->cand[1],
+    DevBuf* bufs[] = {&idx->qt, &idx->lists, &idx->list_cnt, &idx->gtau, &idx->samp, &idx->fid, &idx->fsc, &idx->cand[0], &idx->cand[1],
                       &idx->ncand[0], &idx->ncand[1], &idx->x[0], &idx->x[1], &idx->own[0], &idx->own[1]};
     for (DevBuf* b : bufs) b->release();
     for (auto& b : idx->in) b.release();
@@ -395,6 +395,7 @@ static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentine
         p.tau0 = sentinel ? 0.0f : -INFINITY;
         p.gtau = nullptr;
         p.sample = 0;
+        p.samp_out = nullptr;
         {
             const char* dbg = getenv("MFAR_S1_DEBUG");
             p.dbg = dbg ? atoi(dbg) : 0;
@@ -421,8 +422,24 @@ static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentine
         // Sample pass: every workgroup scans only the first tile of its chunk; the k-th best score of that sample is
         // a valid (non-strict) lower bound of the final k-th best, so the full pass starts with a tight threshold and
         // appends / compacts almost nothing.  Worth it once a chunk is much longer than one tile.
-        const bool use_sample = n_tiles >= 8 * n_chunks && !(p.dbg & 2);
-        if (use_sample) {
+        static const int sample_min_tiles = getenv("MFAR_SAMPLE_MIN_TILES") ? atoi(getenv("MFAR_SAMPLE_MIN_TILES")) : 3;
+        const bool use_sample = n_tiles >= sample_min_tiles * n_chunks && !(p.dbg & 2);
+        const int n_wave_blocks = 4 * n_chunks;
+        const bool light_sample = use_sample && 2 * n_wave_blocks >= 2 * k && 2 * n_wave_blocks <= 2048;
+        if (light_sample) {
+            // every wave publishes the 2 best scores per query of its 64 sampled rows; tau = k-th largest of those
+            S1Params ps = p;
+            ps.sample = 2;
+            RETCHK(idx->samp.ensure((size_t)idx->F * n_wave_blocks * 128 * sizeof(float)));
+            ps.samp_out = idx->samp.as<float>();
+            if (bf16) mfar_stage1_bf16_sample_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1B_LDS_BYTES, st>>>(ps);
+            else mfar_stage1_sample_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1_LDS_BYTES, st>>>(ps);
+            HIPCHK(hipGetLastError());
+            mfar_sample_tau_kernel<<<dim3(64 * idx->F), dim3(256), SEL_LDS_BYTES(2 * n_wave_blocks), st>>>(
+                ps.samp_out, n_wave_blocks, idx->F, k, p.tau0, idx->gtau.as<float>());
+            HIPCHK(hipGetLastError());
+            p.gtau = idx->gtau.as<float>();
+        } else if (use_sample) {
             S1Params ps = p;
             ps.sample = 1;
             if (bf16) mfar_stage1_bf16_sample_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1B_LDS_BYTES, st>>>(ps);

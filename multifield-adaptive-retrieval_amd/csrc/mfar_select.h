@@ -164,6 +164,26 @@ __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams
     }
 }
 
+// tau[f][q] = k-th largest of the n_vals scores published by the light sample pass for (q, f), or -inf when fewer than k
+// of them beat the starting threshold tau0 (then there is no bound).  grid = 64 * F, block 256, n_vals <= 2048.
+__global__ void __launch_bounds__(256) mfar_sample_tau_kernel(const float* __restrict__ samp, int n_wave_blocks, int F, int k,
+                                                              float tau0, float* __restrict__ tau_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n_vals = n_wave_blocks * 2;
+    const SelLds L = sel_lds(smem, n_vals);
+    const int q = blockIdx.x / F, f = blockIdx.x - q * F;
+    if (threadIdx.x == 0) L.misc[0] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_vals; i += blockDim.x) {
+        const float v = samp[((size_t)f * n_wave_blocks + (i >> 1)) * 128 + q * 2 + (i & 1)];
+        if (v > tau0) L.keys[lds_add_rtn(&L.misc[0], 1)] = make_key(v, (u32)i);
+    }
+    __syncthreads();
+    const int n = L.misc[0];
+    const int m = block_topk_sorted<8>(L.keys, n, k, L.sel, L.sorted, L.red);
+    if (threadIdx.x == 0) tau_out[f * 64 + q] = m == k ? key_score(L.sorted[k - 1]) : -__builtin_inff();
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // M1: merge S shard lists (multi-GPU).  src ids/scores are addressed through a stride so the payload buffers of
 // all shards can be read in place.   grid = Q * F, dynamic LDS = S * k * 8.

@@ -53,7 +53,9 @@ struct S1Params {
     int k;                  // list depth (<= MFAR_MAX_K)
     float tau0;             // 0 (zero sentinel, index.py:192-193) or -inf
     const float* gtau;      // [F, 64] non-strict lower bounds from the sample pass, or nullptr
-    int sample;             // 1: threshold-estimation pass, every workgroup scans only the first tile of its chunk
+    int sample;             // 1/2: threshold-estimation pass, every workgroup scans only the first tile of its chunk;
+                            //      2 = light form: no lists, every wave publishes the 2 best scores per query of its 64 rows
+    float* samp_out;        // [F][n_chunks * 4][64][2] (sample == 2)
     int dbg;                // profiling only (MFAR_S1_DEBUG): 1 = skip the selection epilogue (results invalid)
 };
 
@@ -210,6 +212,50 @@ __device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st
     }
 }
 
+// Light threshold-estimation epilogue (sample == 2): per (wave, query) the two best scores among the wave's 64 rows.
+// They are scores of distinct real rows, so the k-th largest of all published values is a valid (non-strict) lower
+// bound of the final k-th best (mfar_sample_tau_kernel).
+__device__ __forceinline__ void s1_sample_top2(const S1Params& p, int f, int chunk, int t, int w, f32x16& acc00, f32x16& acc01,
+                                               f32x16& acc10, f32x16& acc11) {
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    if (t * S1_TILE_ROWS + S1_TILE_ROWS > p.n_rows) {  // padding rows never qualify
+        const int row_w = t * S1_TILE_ROWS + w * 64 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_w + (r & 3) + 8 * (r >> 2);
+            if (row >= p.n_rows) acc00[r] = acc01[r] = -__builtin_inff();
+            if (row + 32 >= p.n_rows) acc10[r] = acc11[r] = -__builtin_inff();
+        }
+    }
+    float a1 = -__builtin_inff(), a2 = a1, b1 = a1, b2 = a1;   // query j: (a1 >= a2), query 32 + j: (b1 >= b2)
+#define S1_TOP2(V, M1, M2)                    \
+    {                                         \
+        const float v_ = (V);                 \
+        const float lo_ = fminf(v_, M1);      \
+        M1 = fmaxf(v_, M1);                   \
+        M2 = fmaxf(M2, lo_);                  \
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        S1_TOP2(acc00[r], a1, a2)
+        S1_TOP2(acc10[r], a1, a2)
+        S1_TOP2(acc01[r], b1, b2)
+        S1_TOP2(acc11[r], b1, b2)
+    }
+#undef S1_TOP2
+    // the other half-wave holds the other 32 rows of the same queries
+    const float oa1 = __shfl_xor(a1, 32), oa2 = __shfl_xor(a2, 32), ob1 = __shfl_xor(b1, 32), ob2 = __shfl_xor(b2, 32);
+    const float ra1 = fmaxf(a1, oa1), ra2 = fmaxf(fminf(a1, oa1), fmaxf(a2, oa2));
+    const float rb1 = fmaxf(b1, ob1), rb2 = fmaxf(fminf(b1, ob1), fmaxf(b2, ob2));
+    if (h == 0) {
+        float* o = p.samp_out + ((size_t)(f * p.n_chunks + chunk) * 4 + w) * 128;
+        o[j * 2] = ra1;
+        o[j * 2 + 1] = ra2;
+        o[(32 + j) * 2] = rb1;
+        o[(32 + j) * 2 + 1] = rb2;
+    }
+}
+
 // leave at most k entries per query and publish the counts
 __device__ __forceinline__ void s1_flush(const S1Params& p, const S1State& st, int w, size_t wgq0) {
     const int lane = threadIdx.x & 63;
@@ -323,10 +369,14 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
             asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11));
             continue;
         }
+        if (p.sample == 2) {
+            s1_sample_top2(p, f, chunk, t, w, acc00, acc01, acc10, acc11);
+            continue;
+        }
         s1_epilogue(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
 #undef S1_ISSUE_NEXT
-    s1_flush(p, st, w, wgq0);
+    if (p.sample != 2) s1_flush(p, st, w, wgq0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -426,10 +476,14 @@ __device__ __forceinline__ void s1_body_bf16(const S1Params& p) {
             asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11));
             continue;
         }
+        if (p.sample == 2) {
+            s1_sample_top2(p, f, chunk, t, w, acc00, acc01, acc10, acc11);
+            continue;
+        }
         s1_epilogue(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
 #undef S1B_ISSUE_NEXT
-    s1_flush(p, st, w, wgq0);
+    if (p.sample != 2) s1_flush(p, st, w, wgq0);
 }
 
 // The full pass and the threshold-estimation pass are the same code under two kernel names, so that profiles list them
