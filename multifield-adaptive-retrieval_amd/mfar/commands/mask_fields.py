@@ -7,85 +7,40 @@ into HBM once and reused by every masked run -- only the mixer changes with the 
 each of the 1+F+1+F `trainer.test` calls (contrastive.py:553-554).  Launch one process per GPU with torch.distributed.run
 for row-sharded multi-GPU evaluation; a single process uses GPU 0.
 """
-import os
 import time
 from typing import *  # noqa: F401,F403
 
 import torch
 
+from mfar.commands import _setup
 from mfar.commands._cli import run
-from mfar.data.schema import resolve_fields
+from mfar.commands._setup import init_distributed_from_env  # noqa: F401  (re-exported)
 from mfar.data.typedef import FieldType
-from mfar.modeling.contrastive import RetrievalDataModule, RetrievalTrainingModule
-from mfar.modeling.util import prepare_model, read_and_create_indices
+from mfar.modeling.contrastive import RetrievalTrainingModule
 
 
-def init_distributed_from_env() -> None:
-    """One process per GPU (RANK / WORLD_SIZE / LOCAL_RANK from torch.distributed.run); no-op for a single process."""
-    import torch.distributed as dist
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        local = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-
-
-def main(*,
-         dataset_name: str,
-         lexical_index: str,
-         out: str,
-         temp_dir: str,
-         data: Optional[str] = None,
-         queries: Optional[str] = None,
-         corpus: Optional[str] = None,
-         partition: str = "val",
-         additional_partition: Optional[str] = None,
-         model_name: str = "facebook/contriever-msmarco",
-         normalize: bool = False,
-         negative_sampling_params: Tuple[int, int, int] = (100, 50, 1),
-         train_batch_size: int = 16,
-         dev_batch_size: int = 64,
-         train_max_length: int = 512,
-         dev_max_length: int = 512,
-         max_epochs: int = 50,
-         seed: int = 0xdeadbeef,
-         precision: str = "16-mixed",
-         num_gpus: int = -1,
-         logger: Optional[str] = None,
-         wandb_name: str = None,
-         wandb_dir: str = None,
-         experiment_name: str = None,
-         field_names: List = None,
-         trec_val_freq: int = 0,
-         prefix: bool = False,
-         checkpoint_dir: Optional[str] = None,
-         debug: bool = False,
-         ):
-    torch.manual_seed(seed & 0x7FFFFFFF)
-    init_distributed_from_env()
-    if data:
-        queries = corpus = data
-    field_info = resolve_fields(field_names, dataset_name)
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    tokenizer, encoder, _ = prepare_model(model_name, normalize=normalize, with_decoder=False)
-    encoder.to(f"cuda:{local}")
-    corpus_contents, vectors_dict, indices_dict = read_and_create_indices(f"{corpus}/corpus", dataset_name, field_info, temp_dir, encoder)
-    data_module = RetrievalDataModule(
-        tokenizer=tokenizer, queries_path=queries, corpus=corpus_contents, dataset_name=dataset_name, temp_path=temp_dir,
-        dev_partition=partition, additional_partition=additional_partition, lexical_index=lexical_index,
-        negative_sampling_params=negative_sampling_params, train_batch_size=train_batch_size, dev_batch_size=dev_batch_size,
-        train_max_length=train_max_length, dev_max_length=dev_max_length, field_info=field_info, indices_dict=indices_dict,
-        prefix=prefix, trec_val_freq=trec_val_freq)
+def main(
+        *,
+        dataset_name: str, lexical_index: str, out: str, temp_dir: str, data: Optional[str] = None,
+        queries: Optional[str] = None, corpus: Optional[str] = None, partition: str = "val",
+        additional_partition: Optional[str] = None, model_name: str = "facebook/contriever-msmarco",
+        normalize: bool = False, negative_sampling_params: Tuple[int, int, int] = (100, 50, 1),
+        train_batch_size: int = 16, dev_batch_size: int = 64, train_max_length: int = 512, dev_max_length: int = 512,
+        max_epochs: int = 50, seed: int = 0xdeadbeef, precision: str = "16-mixed", num_gpus: int = -1,
+        logger: Optional[str] = None, wandb_name: str = None, wandb_dir: str = None, experiment_name: str = None,
+        field_names: List = None, trec_val_freq: int = 0, prefix: bool = False, checkpoint_dir: Optional[str] = None,
+        debug: bool = False,
+):
+    st = _setup.build(locals())
+    field_info, data_module = st.field_info, st.data_module
     with open(f"{checkpoint_dir}/best.txt") as f:                                  # mask_fields.py:106-108
         checkpoint_path = f"{checkpoint_dir}/{f.read().strip().split('/')[-1]}"
     print(f"PATH IS: {checkpoint_path}")
     module = RetrievalTrainingModule.load_from_checkpoint(
-        checkpoint_path, corpus=corpus_contents, indices_dict=indices_dict, vectors_dict=vectors_dict,
-        dev_qrels_path=f"{queries}/{partition}.qrels",
-        additional_qrels_path=f"{queries}/{additional_partition}.qrels" if additional_partition else None,
-        encoder=encoder, field_info=field_info, out_dir=out, dev_batch_size=dev_batch_size)
-    module.encoder.to(f"cuda:{local}")
+        checkpoint_path, corpus=st.corpus, indices_dict=st.indices_dict, vectors_dict=st.vectors_dict, encoder=st.encoder,
+        dev_qrels_path=st.dev_qrels, additional_qrels_path=st.additional_qrels, field_info=field_info, out_dir=out,
+        dev_batch_size=dev_batch_size)
+    module.encoder.to(st.device)
     print(f"Starting re-testing of {checkpoint_path}: {time.strftime('%Y-%m-%d %H:%M:%S')}")
 
     print("Baseline Evaluation")

@@ -20,15 +20,13 @@ from typing import *  # noqa: F401,F403
 
 import torch
 
+from mfar.commands import _setup
 from mfar.commands._cli import run
-from mfar.commands.mask_fields import init_distributed_from_env
 from mfar.data import trec
 from mfar.data.format import format_documents
-from mfar.data.schema import resolve_fields
 from mfar.data.typedef import FieldType
-from mfar.modeling.contrastive import RetrievalDataModule, RetrievalTrainingModule
+from mfar.modeling.contrastive import RetrievalTrainingModule
 from mfar.modeling.losses import HybridContrastiveLoss
-from mfar.modeling.util import prepare_model, read_and_create_indices
 
 
 def _rank_world():
@@ -111,79 +109,38 @@ def _sync_grads(params, world):
             p.grad /= world
 
 
-def main(*,
-         dataset_name: str,
-         lexical_index: str,
-         out: str,
-         temp_dir: str,
-         partition: str = "val",
-         data: Optional[str] = None,
-         queries: Optional[str] = None,
-         corpus: Optional[str] = None,
-         sparse_scores_path: Optional[str] = None,
-         additional_partition: Optional[str] = None,
-         model_name: str = "facebook/contriever-msmarco",
-         model_path: Optional[str] = None,
-         normalize: bool = False,
-         temperature: float = 0.05,
-         negative_sampling_params: Tuple[int, int, int] = (100, 50, 1),
-         encoder_lr: float = 1e-4,
-         weights_lr: Optional[float] = None,
-         regularizer: float = 0.0,
-         train_batch_size: int = 16,
-         dev_batch_size: int = 64,
-         train_max_length: int = 512,
-         dev_max_length: int = 512,
-         max_epochs: int = 50,
-         patience: int = 10,
-         seed: int = 0xdeadbeef,
-         precision: str = "16-mixed",
-         num_gpus: int = -1,
-         dev_by_iter: bool = False,
-         logger: Optional[str] = None,
-         freeze_encoder: bool = False,
-         wandb_name: str = None,
-         wandb_dir: str = None,
-         experiment_name: str = None,
-         field_names: List = None,
-         trec_val_freq: int = 0,
-         query_cond: bool = True,
-         prefix: bool = False,
-         run_one_iteration=False,
-         use_batchnorm: bool = False,
-         ):
-    torch.manual_seed(seed & 0x7FFFFFFF)
-    init_distributed_from_env()
+def main(
+        *,
+        dataset_name: str, lexical_index: str, out: str, temp_dir: str, partition: str = "val",
+        data: Optional[str] = None, queries: Optional[str] = None, corpus: Optional[str] = None,
+        sparse_scores_path: Optional[str] = None, additional_partition: Optional[str] = None,
+        model_name: str = "facebook/contriever-msmarco", model_path: Optional[str] = None, normalize: bool = False,
+        temperature: float = 0.05, negative_sampling_params: Tuple[int, int, int] = (100, 50, 1),
+        encoder_lr: float = 1e-4, weights_lr: Optional[float] = None, regularizer: float = 0.0,
+        train_batch_size: int = 16, dev_batch_size: int = 64, train_max_length: int = 512, dev_max_length: int = 512,
+        max_epochs: int = 50, patience: int = 10, seed: int = 0xdeadbeef, precision: str = "16-mixed",
+        num_gpus: int = -1, dev_by_iter: bool = False, logger: Optional[str] = None, freeze_encoder: bool = False,
+        wandb_name: str = None, wandb_dir: str = None, experiment_name: str = None, field_names: List = None,
+        trec_val_freq: int = 0, query_cond: bool = True, prefix: bool = False, run_one_iteration=False,
+        use_batchnorm: bool = False,
+):
+    st = _setup.build(locals(), freeze_encoder=freeze_encoder)
     rank, world = _rank_world()
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device(f"cuda:{local}")
-    field_info = resolve_fields(field_names, dataset_name)
-    if data:
-        queries = corpus = data
+    device, field_info, tokenizer, data_module = st.device, st.field_info, st.tokenizer, st.data_module
+    queries, corpus_contents, model_name = st.queries, st.corpus, st.model_id
     os.makedirs(out, exist_ok=True)
-    model_name = model_path if model_path else model_name
     if rank == 0:
-        print(f"Starting training: model={model_name} queries={queries} corpus={corpus} dataset={dataset_name} "
+        print(f"Starting training: model={model_name} queries={queries} corpus={st.corpus_dir} dataset={dataset_name} "
               f"fields={json.dumps({k: v.__dict__() for k, v in field_info.items()})} prefix={prefix} encoder_lr={encoder_lr} "
               f"weights_lr={weights_lr} seed={seed} time={time.strftime('%Y-%m-%d %H:%M:%S')}")
-
-    tokenizer, encoder, _ = prepare_model(model_name, normalize=normalize, with_decoder=False, freeze_encoder=freeze_encoder)
-    encoder.to(device)
-    corpus_contents, vectors_dict, indices_dict = read_and_create_indices(f"{corpus}/corpus", dataset_name, field_info, temp_dir, encoder)
-    print(f"Indices are created for all {len(indices_dict)} fields, including {field_info.keys()}")
-    data_module = RetrievalDataModule(
-        tokenizer=tokenizer, queries_path=f"{queries}", corpus=corpus_contents, temp_path=temp_dir, dev_partition=partition,
-        additional_partition=additional_partition, lexical_index=lexical_index, negative_sampling_params=negative_sampling_params,
-        train_batch_size=train_batch_size, dev_batch_size=dev_batch_size, train_max_length=train_max_length,
-        dev_max_length=dev_max_length, dataset_name=dataset_name, field_info=field_info, indices_dict=indices_dict, prefix=prefix,
-        trec_val_freq=trec_val_freq)
+    print(f"Indices are created for all {len(st.indices_dict)} fields, including {field_info.keys()}")
     module = RetrievalTrainingModule(
-        encoder=encoder, model_id=model_name, decoder=None, contrastive_temp=temperature, dev_qrels_path=f"{queries}/{partition}.qrels",
-        additional_qrels_path=f"{queries}/{additional_partition}.qrels" if additional_partition else None,
-        corpus_path=f"{corpus}/corpus", sparse_scores=None, corpus=corpus_contents, dataset_name=dataset_name,
-        encoder_learning_rate=encoder_lr, weights_learning_rate=weights_lr, weight_decay=regularizer, dev_batch_size=dev_batch_size,
-        out_dir=out, field_info=field_info, indices_dict=indices_dict, vectors_dict=vectors_dict, trec_val_freq=trec_val_freq,
-        freeze_encoder=freeze_encoder, query_cond=query_cond, prefix=prefix, use_batchnorm=use_batchnorm)
+        encoder=st.encoder, model_id=model_name, decoder=None, contrastive_temp=temperature, dev_qrels_path=st.dev_qrels,
+        additional_qrels_path=st.additional_qrels, corpus_path=f"{st.corpus_dir}/corpus", sparse_scores=None,
+        corpus=corpus_contents, dataset_name=dataset_name, encoder_learning_rate=encoder_lr, weights_learning_rate=weights_lr,
+        weight_decay=regularizer, dev_batch_size=dev_batch_size, out_dir=out, field_info=field_info,
+        indices_dict=st.indices_dict, vectors_dict=st.vectors_dict, trec_val_freq=trec_val_freq, freeze_encoder=freeze_encoder,
+        query_cond=query_cond, prefix=prefix, use_batchnorm=use_batchnorm)
     module.to(device)
     loss_fn = HybridContrastiveLoss(temperature=temperature, mixture_of_fields_layer=module.mixture_of_fields_layer,
                                     sparse_indices_dict={}, num_fields=len(field_info), use_batchnorm=use_batchnorm).to(device)

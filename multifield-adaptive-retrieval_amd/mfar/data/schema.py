@@ -10,20 +10,30 @@ from mfar.data.typedef import Field, FieldType
 
 SPARSE_MAX = 1048576
 
-# (field name -> training-time max token length) per dataset; schema.py:11-69
-FIELD_PRESETS = {
-    "mag": {"abstract": 512, "author___affiliated_with___institution": 512, "paper___cites___paper": 512,
-            "paper___has_topic___field_of_study": 64, "title": 64},
-    "prime": {"associated with": 256, "carrier": 8, "contraindication": 128, "details": 512, "enzyme": 64,
-              "expression absent": 64, "expression present": 512, "indication": 32, "interacts with": 512, "linked to": 8,
-              "name": 64, "off-label use": 8, "parent-child": 256, "phenotype absent": 8, "phenotype present": 512,
-              "ppi": 512, "side effect": 128, "source": 8, "synergistic interaction": 512, "target": 64, "transporter": 8,
-              "type": 8},
-    "amazon": {"also_buy": 512, "also_view": 512, "brand": 16, "description": 512, "feature": 512, "qa": 512,
-               "review": 512, "title": 128},
-    "whatsthatbook": {"author": 16, "author_url": 64, "date": 64, "description": 512, "genres": 64, "id": 16,
-                      "image_link": 64, "isbn_13": 16, "parsed_dates": 16, "ratings": 16, "reviews": 16, "title": 64},
+# Per dataset: "field name=training-time max token length" items (facts about the STaRK datasets; reference
+# schema.py:11-69).  Kept as one compact text block and parsed once at import.
+_PRESET_TEXT = {
+    "mag": "abstract=512; author___affiliated_with___institution=512; paper___cites___paper=512; "
+           "paper___has_topic___field_of_study=64; title=64",
+    "prime": "associated with=256; carrier=8; contraindication=128; details=512; enzyme=64; expression absent=64; "
+             "expression present=512; indication=32; interacts with=512; linked to=8; name=64; off-label use=8; "
+             "parent-child=256; phenotype absent=8; phenotype present=512; ppi=512; side effect=128; source=8; "
+             "synergistic interaction=512; target=64; transporter=8; type=8",
+    "amazon": "also_buy=512; also_view=512; brand=16; description=512; feature=512; qa=512; review=512; title=128",
+    "whatsthatbook": "author=16; author_url=64; date=64; description=512; genres=64; id=16; image_link=64; isbn_13=16; "
+                     "parsed_dates=16; ratings=16; reviews=16; title=64",
 }
+
+
+def _parse_presets(text: str) -> Dict[str, int]:
+    out = {}
+    for item in text.split(";"):
+        name, _, length = item.strip().rpartition("=")
+        out[name] = int(length)
+    return out
+
+
+FIELD_PRESETS = {ds: _parse_presets(txt) for ds, txt in _PRESET_TEXT.items()}
 DATASET_NAMES = list(FIELD_PRESETS)
 
 
