@@ -56,7 +56,8 @@ struct S1Params {
     int sample;             // 1/2: threshold-estimation pass, every workgroup scans only the first tile of its chunk;
                             //      2 = light form: no lists, every wave publishes the 2 best scores per query of its 64 rows
     float* samp_out;        // [F][n_chunks * 4][64][2] (sample == 2)
-    int dbg;                // profiling only (MFAR_S1_DEBUG): 1 = skip the selection epilogue (results invalid)
+    int dbg;                // profiling only (MFAR_S1_DEBUG): 1 = skip the selection epilogue (results invalid; note that
+                            // the downstream kernels then have no candidates, so they no longer compete with stage 1)
 };
 
 // Wave-level compaction of one list: keep the k best of n (k < n <= S1_CAP) entries, return the k-th best score.
@@ -155,8 +156,8 @@ __device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st
             if (row + 32 >= p.n_rows) acc10[r] = acc11[r] = -__builtin_inff();
         }
     }
-    // barrier A: the compactions of the previous tile (LDS writes of tau / cnt) are complete
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // (barrier A -- the compactions of the previous tile are complete, every wave has finished the tile's last k-step --
+    //  is executed by the caller, which uses it to refill the ring slot that just became free before this epilogue runs)
     const float tq0 = st.tau[j], tq1 = st.tau[32 + j];
     const float tg0 = st.tg[j], tg1 = st.tg[32 + j];
     int n0 = 0, n1 = 0;  // survivors of this lane for query j / 32 + j
@@ -333,10 +334,10 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
         for (int s = 0; s < p.n_steps; ++s, ++it) {
             // stage `it` must have landed (own doc tile: counted vmcnt; other waves' query quarters: the barrier).
             // The 5 newest loads (stage it+1) may stay in flight.
-            if (issued > it + 1)
-                asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            const int ahead = issued - it - 1;   // stages issued after stage `it` (2 right after a tile boundary, see below)
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             const char* cur = dring + st_cur * 4096;
             const char* curq = qring + st_cur * 4096;
             st_cur = (st_cur == S1_STAGES - 1) ? 0 : st_cur + 1;
@@ -349,7 +350,7 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
             const f32x4 q10 = *(const f32x4*)(curq + 2048 + off_g0);
             const f32x4 q11 = *(const f32x4*)(curq + 2048 + off_g1);
             // every wave has passed the barrier, so stage it-1 (== ring slot of it+2) is no longer being read
-            if (issued < total) S1_ISSUE_NEXT();
+            if (issued < total && issued < it + S1_STAGES) S1_ISSUE_NEXT();
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(d00[x], q00[x], acc00, 0, 0, 0);
@@ -373,6 +374,10 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
             s1_sample_top2(p, f, chunk, t, w, acc00, acc01, acc10, acc11);
             continue;
         }
+        // barrier A.  Every wave is past the last k-step of the tile, so that step's ring slot is free: refill it NOW,
+        // the HBM stream then keeps its depth through the epilogue instead of draining (the next step skips its issue).
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (issued < total) S1_ISSUE_NEXT();
         s1_epilogue(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
 #undef S1_ISSUE_NEXT
@@ -445,7 +450,8 @@ __device__ __forceinline__ void s1_body_bf16(const S1Params& p) {
         for (int s = 0; s < p.n_steps; ++s, ++it) {
             // stage `it` landed; up to S1B_STAGES - 2 newer stages (4 loads each) may stay in flight
             const int ahead = issued - it - 1;
-            if (ahead >= 3) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+            if (ahead >= 4) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+            else if (ahead == 3) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
             else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -457,7 +463,7 @@ __device__ __forceinline__ void s1_body_bf16(const S1Params& p) {
             const bf16x8 qh0 = *(const bf16x8*)(curq + off), qh1 = *(const bf16x8*)(curq + 1024 + off);
             const bf16x8 qm0 = *(const bf16x8*)(curq + 2048 + off), qm1 = *(const bf16x8*)(curq + 3072 + off);
             const bf16x8 ql0 = *(const bf16x8*)(curq + 4096 + off), ql1 = *(const bf16x8*)(curq + 5120 + off);
-            if (issued < total) S1B_ISSUE_NEXT();
+            if (issued < total && issued < it + S1B_STAGES) S1B_ISSUE_NEXT();
             // smallest terms first: lo, mid, hi (all products are exact; this keeps the fp32 accumulation tight)
             acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, ql0, acc00, 0, 0, 0);
             acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, ql1, acc01, 0, 0, 0);
@@ -480,6 +486,8 @@ __device__ __forceinline__ void s1_body_bf16(const S1Params& p) {
             s1_sample_top2(p, f, chunk, t, w, acc00, acc01, acc10, acc11);
             continue;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A + early refill (see the fp32 body)
+        if (issued < total) S1B_ISSUE_NEXT();
         s1_epilogue(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
 #undef S1B_ISSUE_NEXT
