@@ -176,6 +176,23 @@ int mfar_stage1_timing(mfar_index* idx, double* total_ms_out, int* n_launches_ou
 /* Tunable: workgroups per CU for the stage-1 kernel (default 2). */
 int mfar_set_wgs_per_cu(mfar_index* idx, int wgs);
 
+/*
+ * Certified fp16 screening of an fp32 index (no reference counterpart; the outputs of every entry point above are
+ * bit-identical with and without it).  Stage 1 of an fp32 index is bound by the fp32 MFMA rate; with the screen it
+ * scans a half-size fp16 copy of the rows for the k + 64 best approximate scores per (query, field), re-scores those
+ * rows exactly from the fp32 slab, and PROVES from a rigorous error bound that no other row can enter or tie into
+ * the exact top-k; a field whose proof fails is re-done by the exact fp32 pass on the device (csrc/mfar_screen.h).
+ * The screen slab (+50 % HBM) is built lazily by the first search after rows were written.
+ *   mode      0 = off, 1 = auto (default; fp32 indexes with >= 16384 rows, k <= 192), 2 = whenever the shapes allow.
+ *             Environment default: MFAR_SCREEN.
+ *   eps_mult  multiplies the error bound of the proof; 1 = rigorous.  Test knob: a huge value makes every proof fail
+ *             (exercises the exact fall-back), 0 disables the proof (NOT exact any more).
+ * mfar_screen_stats synchronises the device: built = the screen slab is current, screen_bytes = its size,
+ * n_checked / n_failed = (query, field) lists certified / sent to the exact fall-back since the handle was created.
+ */
+int mfar_set_screen(mfar_index* idx, int mode, float eps_mult);
+int mfar_screen_stats(mfar_index* idx, int* built, int64_t* screen_bytes, int64_t* n_checked, int64_t* n_failed);
+
 #ifdef __cplusplus
 }
 #endif

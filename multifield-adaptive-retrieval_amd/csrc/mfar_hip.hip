@@ -12,6 +12,7 @@
 
 #include "mfar_hip.h"
 #include "mfar_select.h"
+#include "mfar_screen.h"
 
 #define MFAR_VERSION 100
 #define PAYLOAD_MAGIC 0x6d464152 /* "mFAR" */
@@ -80,6 +81,14 @@ struct mfar_index {
     int n_cu = 256;
     int wgs_per_cu = 2;
     DevBuf qt, lists, list_cnt, gtau, samp, fid, fsc, cand[2], ncand[2], x[2], own[2], in[8], out[8];
+    // certified fp16 screen of an fp32 index (mfar_screen.h)
+    int screen_mode = 1;          // 0 off, 1 auto, 2 always (when the shapes allow)
+    float screen_eps_mult = 1.0f; // test knob: scales the certificate's error bound
+    void* screen = nullptr;       // fp16 tiled slab, same element offsets as the fp32 slab
+    bool screen_dirty = true;     // rows were written since the screen was built
+    bool screen_nomem = false;
+    long long screen_checked = 0; // (query, field) lists certified so far    // the screen slab could not be allocated: stay on the exact pass
+    DevBuf s_stats, s_field, s_qinfo, s_eps, s_base, s_fail, s_qt, s_ids, s_sc, s_cnt, s_x;
     hipEvent_t mid_ev = nullptr;  // recorded right before the full stage-1 kernel is launched
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -103,6 +112,8 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1B_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1B_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_mix_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1H_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1H_LDS_BYTES));
     g_attr_done[device] = true;
     return MFAR_OK;
 }
@@ -152,6 +163,8 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     idx->field_stride = (long long)n_blk * 64 * dim;
     idx->esize = dtype == MFAR_DTYPE_BF16 ? 2 : 4;
     idx->slab_bytes = (size_t)idx->field_stride * idx->esize * n_fields;
+    if (const char* e = getenv("MFAR_SCREEN")) idx->screen_mode = atoi(e);
+    if (const char* e = getenv("MFAR_SCREEN_EPS_MULT")) idx->screen_eps_mult = (float)atof(e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) idx->n_cu = prop.multiProcessorCount;
     hipError_t e = hipMalloc(&idx->slab, idx->slab_bytes);
@@ -176,11 +189,13 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
     DevBuf* bufs[] = {&idx->qt, &idx->lists, &idx->list_cnt, &idx->gtau, &idx->samp, &idx->fid, &idx->fsc, &idx->cand[0], &idx->cand[1],
-                      &idx->ncand[0], &idx->ncand[1], &idx->x[0], &idx->x[1], &idx->own[0], &idx->own[1]};
+                      &idx->ncand[0], &idx->ncand[1], &idx->x[0], &idx->x[1], &idx->own[0], &idx->own[1], &idx->s_stats, &idx->s_field,
+                      &idx->s_qinfo, &idx->s_eps, &idx->s_base, &idx->s_fail, &idx->s_qt, &idx->s_ids, &idx->s_sc, &idx->s_cnt, &idx->s_x};
     for (DevBuf* b : bufs) b->release();
     for (auto& b : idx->in) b.release();
     for (auto& b : idx->out) b.release();
     if (idx->slab) (void)hipFree(idx->slab);
+    if (idx->screen) (void)hipFree(idx->screen);
     delete idx;
 }
 
@@ -247,6 +262,7 @@ extern "C" int mfar_index_write_rows(mfar_index* idx, int field, int64_t local_r
     RETCHK(check_rows(idx, field, local_row0, n, src));
     if (n == 0) return MFAR_OK;
     HIPCHK(hipSetDevice(idx->device));
+    idx->screen_dirty = true;
     hipStream_t st = (hipStream_t)stream;
     char* fbase = (char*)idx->slab + (size_t)field * idx->field_stride * idx->esize;
     const int64_t chunk = on_device ? n : std::min<int64_t>(n, (int64_t)(256u << 20) / (idx->E * 4));
@@ -352,107 +368,130 @@ static int check_search_common(const mfar_index* idx, const float* q, int Q, int
 }
 
 // ------------------------------------------------------------------------------------------------ stage 1
-static int stage1_chunks(const mfar_index* idx) {
+static int stage1_chunks(const mfar_index* idx, int k) {
     const int n_tiles = (int)(idx->n_blk / 4);
     long long target = ((long long)idx->wgs_per_cu * idx->n_cu + idx->F / 2) / idx->F;
     if (target < 1) target = 1;
     if (target > 128) target = 128;
+    if (target * k > 64 * 256) target = (64 * 256) / k;   // the list merge holds n_chunks * k keys in registers
     if (target > n_tiles) target = n_tiles;
     return (int)target;
 }
 
-// all pointers are device pointers; fid/fsc are [Q, F, k]
-static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentinel, long long* fid, float* fsc, hipStream_t st) {
-    const int n_chunks = stage1_chunks(idx);
+// One stage-1 pass over one slab for one block of <= 64 queries: [sample pass] -> full pass -> list merge.
+struct S1Out {
+    long long* ids;   // [., F, k]
+    float* sc;
+    int* cnt;         // [qt_n * F] or nullptr
+    int q0;           // first output query row
+    int sentinel;     // padding convention of the output lists
+};
+enum { S1_F32 = 0, S1_BF16 = 1, S1_F16 = 2 };
+static int launch_s1(int kind, bool sample, unsigned grid, hipStream_t st, const S1Params& p) {
+    const dim3 g(grid), b(S1_THREADS);
+    if (kind == S1_F32) {
+        if (sample) mfar_stage1_sample_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
+        else mfar_stage1_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
+    } else if (kind == S1_BF16) {
+        if (sample) mfar_stage1_bf16_sample_kernel<<<g, b, S1B_LDS_BYTES, st>>>(p);
+        else mfar_stage1_bf16_kernel<<<g, b, S1B_LDS_BYTES, st>>>(p);
+    } else {
+        if (sample) mfar_stage1_f16_sample_kernel<<<g, b, S1H_LDS_BYTES, st>>>(p);
+        else mfar_stage1_f16_kernel<<<g, b, S1H_LDS_BYTES, st>>>(p);
+    }
+    HIPCHK(hipGetLastError());
+    return MFAR_OK;
+}
+
+//   tau0       strict starting threshold (0 = zero sentinel of index.py:192-193, -inf = none)
+//   tau_base   [F, 64] non-strict starting thresholds or nullptr (screened pass)
+//   only_failed  [F] device flags or nullptr: restrict the pass to flagged fields (screen fall-back)
+//   record     this is the pass the pipelining event and the timing events bracket
+static int stage1_pass(mfar_index* idx, int kind, const void* slab, const void* qt, int qt_n, int k, float tau0,
+                       const float* tau_base, const int* only_failed, bool record, const S1Out& o, hipStream_t st) {
+    const int n_chunks = stage1_chunks(idx, k);
     const int n_tiles = (int)(idx->n_blk / 4);
-    const bool bf16 = idx->dtype == MFAR_DTYPE_BF16;
-    RETCHK(idx->qt.ensure((size_t)idx->n_steps * (bf16 ? 8192 : 4096)));
     RETCHK(idx->lists.ensure((size_t)idx->F * n_chunks * 64 * S1_CAP * sizeof(uint2)));
     RETCHK(idx->list_cnt.ensure((size_t)idx->F * n_chunks * 64 * sizeof(int)));
     RETCHK(idx->gtau.ensure((size_t)idx->F * 64 * sizeof(float)));
-    for (int q0 = 0; q0 < Q; q0 += 64) {
-        const int qt_n = std::min(64, Q - q0);
-        if (bf16) {
-            const int total = 64 * (idx->E / 8);
-            mfar_tile_queries_bf16_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, idx->qt.as<unsigned short>(), q0, Q, idx->E);
-        } else {
-            const int total = 64 * (idx->E / 4);
-            mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, idx->qt.as<float>(), q0, Q, idx->E);
-        }
+    S1Params p = {};
+    p.slab = slab;
+    p.qt = qt;
+    p.lists = idx->lists.as<uint2>();
+    p.list_cnt = idx->list_cnt.as<int>();
+    p.field_stride = idx->field_stride;
+    p.n_rows = (int)idx->n_rows;
+    p.n_steps = idx->n_steps;
+    p.n_tiles = n_tiles;
+    p.n_chunks = n_chunks;
+    p.Q = qt_n;
+    p.k = k;
+    p.tau0 = tau0;
+    p.gtau = tau_base;
+    p.sample = 0;
+    p.samp_out = nullptr;
+    p.only_failed = only_failed;
+    {
+        const char* dbg = getenv("MFAR_S1_DEBUG");
+        p.dbg = dbg ? atoi(dbg) : 0;
+    }
+    MergeParams m = {};
+    m.lists = p.lists;
+    m.list_cnt = p.list_cnt;
+    m.row_offset = idx->row_offset;
+    m.n_chunks = n_chunks;
+    m.F = idx->F;
+    m.k = k;
+    m.q0 = o.q0;
+    m.sentinel = o.sentinel;
+    m.cnt_out = nullptr;
+    m.only_failed = only_failed;
+    const int n_keys = n_chunks * k;
+    auto launch_merge = [&](const MergeParams& mp) -> int {
+        const dim3 grid(qt_n * idx->F), block(256);
+        const size_t lds = SEL_LDS_BYTES(n_keys);
+        if (n_keys <= 8 * 256) mfar_merge_lists_kernel<8><<<grid, block, lds, st>>>(mp);
+        else if (n_keys <= 32 * 256) mfar_merge_lists_kernel<32><<<grid, block, lds, st>>>(mp);
+        else mfar_merge_lists_kernel<64><<<grid, block, lds, st>>>(mp);
         HIPCHK(hipGetLastError());
-        S1Params p;
-        p.slab = idx->slab;
-        p.qt = idx->qt.p;
-        p.lists = idx->lists.as<uint2>();
-        p.list_cnt = idx->list_cnt.as<int>();
-        p.field_stride = idx->field_stride;
-        p.n_rows = (int)idx->n_rows;
-        p.n_steps = idx->n_steps;
-        p.n_tiles = n_tiles;
-        p.n_chunks = n_chunks;
-        p.Q = qt_n;
-        p.k = k;
-        p.tau0 = sentinel ? 0.0f : -INFINITY;
-        p.gtau = nullptr;
-        p.sample = 0;
-        p.samp_out = nullptr;
-        {
-            const char* dbg = getenv("MFAR_S1_DEBUG");
-            p.dbg = dbg ? atoi(dbg) : 0;
+        return MFAR_OK;
+    };
+    const unsigned grid = (unsigned)(idx->F * n_chunks);
+    // Sample pass: every workgroup scans only the first tile of its chunk; the k-th best score of that sample is
+    // a valid (non-strict) lower bound of the final k-th best, so the full pass starts with a tight threshold and
+    // appends / compacts almost nothing.  Worth it once a chunk is much longer than one tile.
+    static const int sample_min_tiles = getenv("MFAR_SAMPLE_MIN_TILES") ? atoi(getenv("MFAR_SAMPLE_MIN_TILES")) : 3;
+    const bool use_sample = n_tiles >= sample_min_tiles * n_chunks && !(p.dbg & 2) && !only_failed;
+    const int n_wave_blocks = 4 * n_chunks;
+    const bool light_sample = use_sample && 2 * n_wave_blocks >= 2 * k && 2 * n_wave_blocks <= 2048;
+    if (light_sample) {
+        // every wave publishes the 2 best scores per query of its 64 sampled rows; tau = k-th largest of those
+        S1Params ps = p;
+        ps.sample = 2;
+        RETCHK(idx->samp.ensure((size_t)idx->F * n_wave_blocks * 128 * sizeof(float)));
+        ps.samp_out = idx->samp.as<float>();
+        RETCHK(launch_s1(kind, true, grid, st, ps));
+        mfar_sample_tau_kernel<<<dim3(64 * idx->F), dim3(256), SEL_LDS_BYTES(2 * n_wave_blocks), st>>>(
+            ps.samp_out, n_wave_blocks, idx->F, k, p.tau0, idx->gtau.as<float>());
+        HIPCHK(hipGetLastError());
+        if (tau_base) {
+            mfar_screen_tau_max_kernel<<<dim3((64 * idx->F + 255) / 256), dim3(256), 0, st>>>(idx->gtau.as<float>(), tau_base, 64 * idx->F);
+            HIPCHK(hipGetLastError());
         }
-        MergeParams m;
-        m.lists = p.lists;
-        m.list_cnt = p.list_cnt;
-        m.row_offset = idx->row_offset;
-        m.n_chunks = n_chunks;
-        m.F = idx->F;
-        m.k = k;
-        m.q0 = q0;
-        m.sentinel = sentinel;
-        const int n_keys = n_chunks * k;
-        auto launch_merge = [&](const MergeParams& mp) -> int {
-            const dim3 grid(qt_n * idx->F), block(256);
-            const size_t lds = SEL_LDS_BYTES(n_keys);
-            if (n_keys <= 8 * 256) mfar_merge_lists_kernel<8><<<grid, block, lds, st>>>(mp);
-            else if (n_keys <= 32 * 256) mfar_merge_lists_kernel<32><<<grid, block, lds, st>>>(mp);
-            else mfar_merge_lists_kernel<64><<<grid, block, lds, st>>>(mp);
-            HIPCHK(hipGetLastError());
-            return MFAR_OK;
-        };
-        // Sample pass: every workgroup scans only the first tile of its chunk; the k-th best score of that sample is
-        // a valid (non-strict) lower bound of the final k-th best, so the full pass starts with a tight threshold and
-        // appends / compacts almost nothing.  Worth it once a chunk is much longer than one tile.
-        static const int sample_min_tiles = getenv("MFAR_SAMPLE_MIN_TILES") ? atoi(getenv("MFAR_SAMPLE_MIN_TILES")) : 3;
-        const bool use_sample = n_tiles >= sample_min_tiles * n_chunks && !(p.dbg & 2);
-        const int n_wave_blocks = 4 * n_chunks;
-        const bool light_sample = use_sample && 2 * n_wave_blocks >= 2 * k && 2 * n_wave_blocks <= 2048;
-        if (light_sample) {
-            // every wave publishes the 2 best scores per query of its 64 sampled rows; tau = k-th largest of those
-            S1Params ps = p;
-            ps.sample = 2;
-            RETCHK(idx->samp.ensure((size_t)idx->F * n_wave_blocks * 128 * sizeof(float)));
-            ps.samp_out = idx->samp.as<float>();
-            if (bf16) mfar_stage1_bf16_sample_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1B_LDS_BYTES, st>>>(ps);
-            else mfar_stage1_sample_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1_LDS_BYTES, st>>>(ps);
-            HIPCHK(hipGetLastError());
-            mfar_sample_tau_kernel<<<dim3(64 * idx->F), dim3(256), SEL_LDS_BYTES(2 * n_wave_blocks), st>>>(
-                ps.samp_out, n_wave_blocks, idx->F, k, p.tau0, idx->gtau.as<float>());
-            HIPCHK(hipGetLastError());
-            p.gtau = idx->gtau.as<float>();
-        } else if (use_sample) {
-            S1Params ps = p;
-            ps.sample = 1;
-            if (bf16) mfar_stage1_bf16_sample_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1B_LDS_BYTES, st>>>(ps);
-            else mfar_stage1_sample_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1_LDS_BYTES, st>>>(ps);
-            HIPCHK(hipGetLastError());
-            MergeParams ms = m;
-            ms.out_ids = nullptr;
-            ms.out_scores = nullptr;
-            ms.tau_out = idx->gtau.as<float>();
-            RETCHK(launch_merge(ms));
-            p.gtau = idx->gtau.as<float>();
-        }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
+        p.gtau = idx->gtau.as<float>();
+    } else if (use_sample && !tau_base) {
+        S1Params ps = p;
+        ps.sample = 1;
+        RETCHK(launch_s1(kind, true, grid, st, ps));
+        MergeParams ms = m;
+        ms.out_ids = nullptr;
+        ms.out_scores = nullptr;
+        ms.tau_out = idx->gtau.as<float>();
+        RETCHK(launch_merge(ms));
+        p.gtau = idx->gtau.as<float>();
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (record) {
         if (idx->timing && idx->ev_n < 4096) {
             if ((int)idx->ev.size() < 2 * (idx->ev_n + 1)) {
                 hipEvent_t a, b;
@@ -468,14 +507,174 @@ static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentine
         }
         if (!idx->mid_ev) HIPCHK(hipEventCreateWithFlags(&idx->mid_ev, hipEventDisableTiming));
         HIPCHK(hipEventRecord(idx->mid_ev, st));
-        if (bf16) mfar_stage1_bf16_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1B_LDS_BYTES, st>>>(p);
-        else mfar_stage1_kernel<<<dim3(idx->F * n_chunks), dim3(S1_THREADS), S1_LDS_BYTES, st>>>(p);
+    }
+    RETCHK(launch_s1(kind, false, grid, st, p));
+    if (e1) HIPCHK(hipEventRecord(e1, st));
+    m.out_ids = o.ids;
+    m.out_scores = o.sc;
+    m.tau_out = nullptr;
+    m.cnt_out = o.cnt;
+    RETCHK(launch_merge(m));
+    return MFAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ fp16 screen
+static bool screen_wanted(const mfar_index* idx, int k) {
+    if (idx->dtype != MFAR_DTYPE_F32 || idx->screen_mode == 0 || idx->screen_nomem) return false;
+    if (k + SCREEN_EXTRA > SCREEN_MAX_KP) return false;
+    if (idx->E * 4 > 60 * 1024) return false;   // the re-scoring kernel stages a query row in LDS
+    return idx->screen_mode >= 2 || idx->n_rows >= 16384;
+}
+
+// (re)build the screen slab from the fp32 slab when rows changed; false = not available (allocation failed)
+static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
+    *ok = false;
+    if (!idx->screen) {
+        hipError_t e = hipMalloc(&idx->screen, (size_t)idx->field_stride * 2 * idx->F);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            idx->screen = nullptr;
+            idx->screen_nomem = true;
+            return MFAR_OK;
+        }
+        idx->screen_dirty = true;
+    }
+    if (idx->screen_dirty) {
+        RETCHK(idx->s_stats.ensure((size_t)idx->F * 2 * sizeof(u32)));
+        RETCHK(idx->s_field.ensure((size_t)idx->F * sizeof(ScreenField)));
+        HIPCHK(hipMemsetAsync(idx->s_stats.p, 0, (size_t)idx->F * 2 * sizeof(u32), st));
+        mfar_screen_stats_kernel<<<dim3((unsigned)idx->n_blk, idx->F), dim3(256), 0, st>>>((const float*)idx->slab, idx->field_stride,
+                                                                                            idx->n_steps, idx->s_stats.as<u32>());
         HIPCHK(hipGetLastError());
-        if (e1) HIPCHK(hipEventRecord(e1, st));
-        m.out_ids = fid;
-        m.out_scores = fsc;
-        m.tau_out = nullptr;
-        RETCHK(launch_merge(m));
+        mfar_screen_scale_kernel<<<dim3(1), dim3(64), 0, st>>>(idx->s_stats.as<u32>(), idx->F, idx->s_field.as<ScreenField>());
+        HIPCHK(hipGetLastError());
+        const long long n_gran = (long long)idx->n_blk * idx->n_steps * 128;
+        mfar_screen_build_kernel<<<dim3((unsigned)((n_gran + 255) / 256), idx->F), dim3(256), 0, st>>>(
+            (const float*)idx->slab, (_Float16*)idx->screen, idx->field_stride, n_gran, idx->s_field.as<ScreenField>());
+        HIPCHK(hipGetLastError());
+        idx->screen_dirty = false;
+    }
+    *ok = true;
+    return MFAR_OK;
+}
+
+// all pointers are device pointers; fid/fsc are [Q, F, k]
+static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentinel, long long* fid, float* fsc, hipStream_t st) {
+    const float tau0 = sentinel ? 0.0f : -INFINITY;
+    bool screened = false;
+    if (screen_wanted(idx, k)) RETCHK(ensure_screen(idx, st, &screened));
+    const bool bf16 = idx->dtype == MFAR_DTYPE_BF16;
+    RETCHK(idx->qt.ensure((size_t)idx->n_steps * (bf16 ? 8192 : 4096)));
+    const int F = idx->F, kp = k + SCREEN_EXTRA;
+    if (screened) {
+        RETCHK(idx->s_qt.ensure((size_t)idx->n_steps * 4096));
+        RETCHK(idx->s_qinfo.ensure(64 * sizeof(ScreenQuery)));
+        RETCHK(idx->s_eps.ensure((size_t)F * 64 * 4));
+        RETCHK(idx->s_base.ensure((size_t)F * 64 * 4));
+        if (!idx->s_fail.p) {
+            RETCHK(idx->s_fail.ensure((size_t)(MFAR_MAX_FIELDS + 2) * 4));
+            HIPCHK(hipMemsetAsync(idx->s_fail.p, 0, (size_t)(MFAR_MAX_FIELDS + 2) * 4, st));
+        }
+        RETCHK(idx->s_ids.ensure((size_t)64 * F * kp * 8));
+        RETCHK(idx->s_sc.ensure((size_t)64 * F * kp * 4));
+        RETCHK(idx->s_x.ensure((size_t)64 * F * kp * 4));
+        RETCHK(idx->s_cnt.ensure((size_t)64 * F * 4));
+    }
+    for (int q0 = 0; q0 < Q; q0 += 64) {
+        const int qt_n = std::min(64, Q - q0);
+        if (!screened) {
+            if (bf16) {
+                const int total = 64 * (idx->E / 8);
+                mfar_tile_queries_bf16_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, idx->qt.as<unsigned short>(), q0, Q, idx->E);
+            } else {
+                const int total = 64 * (idx->E / 4);
+                mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, idx->qt.as<float>(), q0, Q, idx->E);
+            }
+            HIPCHK(hipGetLastError());
+            const S1Out o = {fid, fsc, nullptr, q0, sentinel};
+            RETCHK(stage1_pass(idx, bf16 ? S1_BF16 : S1_F32, idx->slab, idx->qt.p, qt_n, k, tau0, nullptr, nullptr, true, o, st));
+            continue;
+        }
+        // 1. screened pass on the fp16 slab: the k' best approximate scores per (query, field)
+        int* fflags = idx->s_fail.as<int>();
+        HIPCHK(hipMemsetAsync(fflags, 0, (size_t)(F + 1) * 4, st));   // field flags + "any"; [F+1] accumulates statistics
+        mfar_screen_queries_kernel<<<dim3(64), dim3(256), 0, st>>>(q, (_Float16*)idx->s_qt.p, idx->s_qinfo.as<ScreenQuery>(),
+                                                                   idx->s_field.as<ScreenField>(), idx->s_eps.as<float>(),
+                                                                   idx->s_base.as<float>(), q0, Q, idx->E, F, sentinel,
+                                                                   idx->screen_eps_mult);
+        HIPCHK(hipGetLastError());
+        const S1Out so = {idx->s_ids.as<long long>(), idx->s_sc.as<float>(), idx->s_cnt.as<int>(), 0, 0};
+        RETCHK(stage1_pass(idx, S1_F16, idx->screen, idx->s_qt.p, qt_n, kp, -INFINITY, idx->s_base.as<float>(), nullptr, true, so, st));
+        // 2. exact scores of those rows (the contract's fma chain over the fp32 slab)
+        ScoreParams sp = {};
+        sp.slab = idx->slab;
+        sp.field_stride = idx->field_stride;
+        sp.q = q + (size_t)q0 * idx->E;
+        sp.cand = idx->s_ids.as<long long>();
+        sp.n_cand = nullptr;
+        sp.out = idx->s_x.as<float>();
+        sp.row_offset = idx->row_offset;
+        sp.n_rows = (int)idx->n_rows;
+        sp.n_steps = idx->n_steps;
+        sp.E = idx->E;
+        sp.F = F;
+        sp.C = kp;
+        sp.per_field = 1;
+        mfar_score_candidates_kernel<0><<<dim3((unsigned)((kp * F + 255) / 256), qt_n), dim3(256), SCORE_LDS_BYTES(idx->E), st>>>(sp);
+        HIPCHK(hipGetLastError());
+        // 3. exact top-k + certificate
+        CertifyParams cp = {};
+        cp.sid = idx->s_ids.as<long long>();
+        cp.ssc = idx->s_sc.as<float>();
+        cp.scnt = idx->s_cnt.as<int>();
+        cp.sx = idx->s_x.as<float>();
+        cp.sf = idx->s_field.as<ScreenField>();
+        cp.qinfo = idx->s_qinfo.as<ScreenQuery>();
+        cp.eps = idx->s_eps.as<float>();
+        cp.out_ids = fid;
+        cp.out_scores = fsc;
+        cp.fail = fflags;
+        cp.F = F;
+        cp.k = k;
+        cp.kp = kp;
+        cp.q0 = q0;
+        cp.sentinel = sentinel;
+        mfar_screen_certify_kernel<<<dim3(qt_n * F), dim3(256), 0, st>>>(cp);
+        HIPCHK(hipGetLastError());
+        idx->screen_checked += (long long)qt_n * F;
+        // 4. fall-back: the exact fp32 pass for fields whose certificate failed (workgroups of other fields exit at once)
+        {
+            const int total = 64 * (idx->E / 4);
+            mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, idx->qt.as<float>(), q0, Q, idx->E);
+            HIPCHK(hipGetLastError());
+            const S1Out o = {fid, fsc, nullptr, q0, sentinel};
+            RETCHK(stage1_pass(idx, S1_F32, idx->slab, idx->qt.p, qt_n, k, tau0, nullptr, fflags, false, o, st));
+        }
+    }
+    return MFAR_OK;
+}
+
+extern "C" int mfar_set_screen(mfar_index* idx, int mode, float eps_mult) {
+    if (!idx || mode < 0 || mode > 2 || !(eps_mult >= 0.0f)) return fail(MFAR_ERR_INVALID, "mode must be 0, 1 or 2 and eps_mult >= 0");
+    idx->screen_mode = mode;
+    idx->screen_eps_mult = eps_mult;
+    return MFAR_OK;
+}
+
+extern "C" int mfar_screen_stats(mfar_index* idx, int* built, int64_t* screen_bytes, int64_t* n_checked, int64_t* n_failed) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    HIPCHK(hipSetDevice(idx->device));
+    if (built) *built = (idx->screen && !idx->screen_dirty) ? 1 : 0;
+    if (screen_bytes) *screen_bytes = idx->screen ? (int64_t)idx->field_stride * 2 * idx->F : 0;
+    if (n_checked) *n_checked = idx->screen_checked;
+    if (n_failed) {
+        *n_failed = 0;
+        if (idx->s_fail.p) {
+            HIPCHK(hipDeviceSynchronize());
+            int v = 0;
+            HIPCHK(hipMemcpy(&v, idx->s_fail.as<int>() + idx->F + 1, 4, hipMemcpyDeviceToHost));
+            *n_failed = v;
+        }
     }
     return MFAR_OK;
 }
@@ -504,7 +703,7 @@ extern "C" int mfar_retrieve_fields(mfar_index* idx, const float* q, int Q, int 
 // ------------------------------------------------------------------------------------------------ stage 2
 static int run_score(mfar_index* idx, const float* q, int Q, const long long* cand, const int* ncand, int C, float* x,
                      hipStream_t st) {
-    ScoreParams p;
+    ScoreParams p = {};
     p.slab = idx->slab;
     p.field_stride = idx->field_stride;
     p.q = q;
@@ -550,7 +749,7 @@ extern "C" int mfar_score_candidates(mfar_index* idx, const float* q, int Q, con
 static int run_mix(const float* x, const long long* cand, const int* ncand, const float* q, const float* W, int query_cond,
                    const float* mask, int Q, int C, int F, int E, int k, long long* ids, float* scores, int* n_valid,
                    hipStream_t st) {
-    MixParams p;
+    MixParams p = {};
     p.x = x;
     p.cand = cand;
     p.n_cand = ncand;
@@ -858,7 +1057,7 @@ extern "C" int mfar_merge_payloads(int device, const void* payloads, int n_shard
         w_ncand = cx.ncand.as<int>();
         w_x = cx.x.as<float>();
     }
-    ShardMergeParams sp;
+    ShardMergeParams sp = {};
     sp.payloads = pd;
     sp.payload_stride = L.total;
     sp.ids_off = L.ids;
@@ -874,7 +1073,7 @@ extern "C" int mfar_merge_payloads(int device, const void* payloads, int n_shard
     HIPCHK(hipGetLastError());
     mfar_union_kernel<<<dim3(Q), dim3(256), 0, st>>>(sp.out_ids, F, k1, w_cand, w_ncand);
     HIPCHK(hipGetLastError());
-    LookupParams lp;
+    LookupParams lp = {};
     lp.payloads = pd;
     lp.payload_stride = L.total;
     lp.hdr_off = L.hdr;
@@ -968,7 +1167,7 @@ extern "C" int mfar_search_owned(mfar_index* idx, const void* gathered_lists, in
     int* ncand = (int*)(wb + off_ncand);
     int* nowned = (int*)(wb + off_nowned);
     float* x = (float*)(wb + off_x);
-    ShardMergeParams sp;
+    ShardMergeParams sp = {};
     sp.payloads = (const char*)gathered_lists;
     sp.payload_stride = LL.total;
     sp.ids_off = LL.ids;
@@ -1005,7 +1204,7 @@ extern "C" int mfar_merge_topk(int device, const void* gathered_topk, int n_shar
     HIPCHK(hipSetDevice(device));
     RETCHK(set_kernel_attrs(device));
     const TopkLayout TL = topk_layout(Q, k2);
-    TopkMergeParams p;
+    TopkMergeParams p = {};
     p.payloads = (const char*)gathered_topk;
     p.stride = TL.total;
     p.ids_off = TL.ids;

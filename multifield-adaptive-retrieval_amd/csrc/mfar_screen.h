@@ -1,0 +1,264 @@
+// mfar_screen.h -- certified fp16 screening for fp32 indexes.
+//
+// Stage 1 on an fp32 slab is bound by the fp32 MFMA rate.  The screen turns it into an HBM-bound pass at half the bytes
+// WITHOUT changing a single output bit:
+//
+//   1. the index keeps a second, fp16 copy of its rows (the "screen slab", same tiled layout as the bf16 slab), scaled per
+//      field by a power of two so that the field's largest |value| lands in [2^13, 2^14);
+//   2. stage 1 runs on the screen slab (v_mfma_f32_32x32x16_f16, queries scaled per query by a power of two and split into
+//      two fp16 terms) and keeps the k' = k + 64 best APPROXIMATE scores per (query, field);
+//   3. those k' rows are re-scored from the fp32 slab with the exact fma chain of the arithmetic contract
+//      (mfar_score_candidates_kernel, per-field mode) and the exact top-k is taken from them;
+//   4. the result is CERTIFIED: with eps(q, f) a rigorous bound of |approx - exact| for every row of the field, every row
+//      outside the k' has exact score <= approx_k' + eps; when that is < the exact k-th best, no outside row can enter
+//      or tie into the top-k, so the list equals the exhaustive fp32 result bit for bit.  Otherwise the field is flagged
+//      and the exact fp32 MFMA pass (mfar_stage1_kernel) re-runs for that field only -- always launched, its workgroups
+//      exit at once when the flag is clear, so there is no host round trip.
+//
+// Error bound (K = dim, u16 = 2^-11, u32 = 2^-24; scaled operands Qi = qi * sq, Di = di * sf, powers of two = exact):
+//   doc rounding      |fp16(Di) - Di| <= u16 |Di| + 2^-25            (normal / subnormal fp16)
+//   query split       Qi = A + B + r,  |r| <= u16^2 |Qi| + 2^-25
+//   accumulation      the MFMA sums 2K exact products in fp32; we allow 2 u32 per addition in ANY order: (4K + 64) u32
+//   exact chain       the contract's fma chain itself: K u32
+//   => |approx - exact| <= [1.02 u16 + (5K + 64) u32] * sum|qi||di|  +  2^-24 (|q|_1 / sf + |d|_1 / sq)
+//   with sum|qi||di| <= |q|_2 |d|_2,  |x|_1 <= sqrt(K) |x|_2,  |d|_2 <= the field's largest row norm.
+// The constant is multiplied by SCREEN_SLACK for margin; tests measure the real error (about 30x below the bound).
+#pragma once
+#include "mfar_device.h"
+#include "mfar_stage1.h"
+
+#define SCREEN_EXTRA 64          // k' = k + SCREEN_EXTRA
+#define SCREEN_MAX_KP S1_TRIG    // the stage-1 lists compact to k', which must leave room for one tile of appends
+#define SCREEN_SLACK 1.25f
+
+struct ScreenField {     // per field, written by mfar_screen_scale_kernel
+    float scale;         // sf = 2^e: fp16 value = fp32 value * sf
+    float inv_scale;
+    float dnorm_max;     // largest row 2-norm of the field (inf / NaN when the field holds non-finite values)
+    float pad;
+};
+struct ScreenQuery {     // per query of the current 64-query block
+    float scale, inv_scale, norm, pad;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Build: per-field statistics of the fp32 slab, then the conversion.  grid = (n_blk, F), block 256.
+// stats[2f] = max |value| bits, stats[2f+1] = max row norm^2 bits (non-negative floats order like their bit patterns;
+// NaN bits are above inf bits, so a non-finite value poisons the field's maximum as intended).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mfar_screen_stats_kernel(const float* __restrict__ slab, long long field_stride, int n_steps,
+                                                                u32* __restrict__ stats) {
+    const int f = blockIdx.y;
+    const float* tile = slab + (size_t)f * field_stride + (size_t)blockIdx.x * n_steps * 1024 + threadIdx.x * 4;
+    float amax = 0.0f, ss = 0.0f;
+    for (int s = 0; s < n_steps; ++s) {
+        const f32x4 v = *(const f32x4*)(tile + (size_t)s * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            amax = fmaxf(amax, fabsf(v[i]));
+            ss = __builtin_fmaf(v[i], v[i], ss);
+        }
+    }
+    // threads 4r .. 4r+3 hold the four 16-byte pieces of row r
+    ss += __shfl_xor(ss, 1);
+    ss += __shfl_xor(ss, 2);
+    u32 a = __float_as_uint(amax), n = __float_as_uint(ss) & 0x7FFFFFFFu;
+    for (int off = 32; off > 0; off >>= 1) {
+        a = max(a, (u32)__shfl_xor((int)a, off));
+        n = max(n, (u32)__shfl_xor((int)n, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&stats[2 * f], a);
+        atomicMax(&stats[2 * f + 1], n);
+    }
+}
+
+// power-of-two scale that puts `amax` into [2^13, 2^14); 1 for zero / non-finite input
+__device__ __forceinline__ float screen_pow2_scale(float amax) {
+    const u32 b = __float_as_uint(amax) & 0x7FFFFFFFu;
+    if (b == 0u || b >= 0x7F800000u) return 1.0f;
+    int e = 13 - ((int)(b >> 23) - 127);
+    e = max(-100, min(100, e));
+    return __uint_as_float((u32)(e + 127) << 23);
+}
+
+__global__ void mfar_screen_scale_kernel(const u32* __restrict__ stats, int F, ScreenField* __restrict__ sf) {
+    const int f = threadIdx.x;
+    if (f >= F) return;
+    const float amax = __uint_as_float(stats[2 * f]);
+    const float n2 = __uint_as_float(stats[2 * f + 1]);
+    ScreenField o;
+    o.scale = screen_pow2_scale(amax);
+    o.inv_scale = 1.0f / o.scale;
+    // sqrt rounded up a little: the bound must not shrink
+    o.dnorm_max = sqrtf(n2) * 1.000001f;
+    o.pad = 0.0f;
+    sf[f] = o;
+}
+
+// fp32 tiled slab -> fp16 tiled screen slab.  One thread per 16-byte output granule (8 dims).
+// grid = (ceil(n_blk * n_steps * 128 / 256), F)
+__global__ void __launch_bounds__(256) mfar_screen_build_kernel(const float* __restrict__ slab, _Float16* __restrict__ screen,
+                                                                long long field_stride, long long n_granules,
+                                                                const ScreenField* __restrict__ sf) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_granules) return;
+    const int f = blockIdx.y;
+    const float sc = sf[f].scale;
+    const long long tile = g >> 7;           // 128 granules per [64][16] tile
+    const int rr = (int)(g >> 1) & 63, c8 = (int)g & 1;
+    const int sw = (rr >> 2) & 3;
+    const float* src = slab + (size_t)f * field_stride + (size_t)tile * 1024 + rr * 16;
+    const f32x4 a = *(const f32x4*)(src + (((2 * c8) ^ sw) << 2));
+    const f32x4 b = *(const f32x4*)(src + (((2 * c8 + 1) ^ sw) << 2));
+    f16x8 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[i] = (_Float16)(a[i] * sc);
+        o[4 + i] = (_Float16)(b[i] * sc);
+    }
+    *(f16x8*)(screen + (size_t)f * field_stride + (size_t)tile * 1024 + rr * 16 + ((c8 ^ ((rr >> 3) & 1)) << 3)) = o;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Queries of one 64-query block: per-query scale + norm, two-term fp16 split tiles [n_steps][2][64][16], and per
+// (field, query): eps (real units) and the starting threshold of the screened pass (scaled units).
+//   grid = 64 (one workgroup per query row), block 256.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* __restrict__ q, _Float16* __restrict__ qt,
+                                                                  ScreenQuery* __restrict__ qinfo, const ScreenField* __restrict__ sf,
+                                                                  float* __restrict__ eps, float* __restrict__ tau_base, int q0,
+                                                                  int Q, int E, int F, int sentinel, float eps_mult) {
+    __shared__ float red_a[4], red_s[4];
+    const int r = blockIdx.x;
+    const bool live = q0 + r < Q;
+    const float* row = q + (size_t)(q0 + (live ? r : 0)) * E;
+    float amax = 0.0f, ss = 0.0f;
+    if (live)
+        for (int e = threadIdx.x; e < E; e += blockDim.x) {
+            const float v = row[e];
+            amax = fmaxf(amax, fabsf(v));
+            ss = __builtin_fmaf(v, v, ss);
+        }
+    for (int off = 32; off > 0; off >>= 1) {
+        amax = fmaxf(amax, __shfl_xor(amax, off));
+        ss += __shfl_xor(ss, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red_a[threadIdx.x >> 6] = amax;
+        red_s[threadIdx.x >> 6] = ss;
+    }
+    __syncthreads();
+    amax = fmaxf(fmaxf(red_a[0], red_a[1]), fmaxf(red_a[2], red_a[3]));
+    ss = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
+    const float sq = screen_pow2_scale(amax);
+    const float qn = sqrtf(ss) * 1.00001f;   // the block sum is not correctly rounded: lean up
+    // split tiles
+    const int gpr = E >> 3;
+    for (int g = threadIdx.x; g < gpr; g += blockDim.x) {
+        const int e = g << 3;
+        f16x8 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float x = live ? row[e + i] * sq : 0.0f;
+            const _Float16 a = (_Float16)x;
+            hi[i] = a;
+            lo[i] = (_Float16)(x - (float)a);
+        }
+        const int step = e >> 4;
+        const size_t in_tile = tiled_offset_bf16(E >> 4, r, e) - (size_t)step * 1024;
+        _Float16* base = qt + (size_t)step * 2048;   // 2 tiles of 1024 halves per k-step
+        *(f16x8*)(base + in_tile) = hi;
+        *(f16x8*)(base + 1024 + in_tile) = lo;
+    }
+    if (threadIdx.x == 0) {
+        ScreenQuery o;
+        o.scale = sq;
+        o.inv_scale = 1.0f / sq;
+        o.norm = qn;
+        o.pad = 0.0f;
+        qinfo[r] = o;
+    }
+    if ((int)threadIdx.x < F) {
+        const int f = threadIdx.x;
+        const ScreenField s = sf[f];
+        const float K = (float)E;
+        const float c_rel = 1.02f * 4.8828125e-4f + (5.0f * K + 64.0f) * 5.9604645e-8f;
+        const float c_abs = 5.9604645e-8f * sqrtf(K) * 1.0001f;
+        float e_ = SCREEN_SLACK * (c_rel * qn * s.dnorm_max + c_abs * (qn * s.inv_scale + s.dnorm_max / sq));
+        e_ *= eps_mult;
+        if (!live) e_ = 0.0f;
+        eps[f * 64 + r] = e_;
+        // rows whose approximate score is below -eps have exact score < 0 and can never beat the zero sentinel
+        // (index.py:192-193); NaN eps (non-finite data) -> -inf: keep everything, the certificate fails anyway
+        float tb = -__builtin_inff();
+        if (sentinel && live && e_ == e_) tb = -(e_ * sq * s.scale) * 1.0001f;
+        tau_base[f * 64 + r] = live ? tb : __builtin_inff();
+    }
+}
+
+// raise the light sample pass's thresholds to at least the base thresholds: tau = max(tau, base)
+__global__ void mfar_screen_tau_max_kernel(float* __restrict__ tau, const float* __restrict__ base, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) tau[i] = fmaxf(tau[i], base[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Certify: exact top-k of the k' re-scored rows of one (query, field) + the certificate.  grid = Qt * F, block 256.
+// ---------------------------------------------------------------------------------------------------------
+struct CertifyParams {
+    const long long* sid;     // [64, F, kp] global ids of the screened lists (-1 = empty)
+    const float* ssc;         // [64, F, kp] approximate scores (scaled units), descending
+    const int* scnt;          // [64 * F] entries per screened list
+    const float* sx;          // [64, F, kp] exact scores of those rows (NaN = not scored)
+    const ScreenField* sf;
+    const ScreenQuery* qinfo;
+    const float* eps;         // [F, 64]
+    long long* out_ids;       // [Q, F, k]
+    float* out_scores;
+    int* fail;                // [F] field flags, [F] = any, [F+1] = failed (query, field) pairs (statistics)
+    int F, k, kp, q0, sentinel;
+};
+__global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyParams p) {
+    __shared__ u64 keys[256], sel[256], sorted[256];
+    __shared__ int red[36];
+    const int ql = blockIdx.x / p.F, f = blockIdx.x - ql * p.F;
+    const size_t lb = ((size_t)ql * p.F + f) * p.kp;
+    const int cnt = min(p.scnt[ql * p.F + f], p.kp);
+    const float tau0 = p.sentinel ? 0.0f : -__builtin_inff();
+    if (threadIdx.x == 0) red[32] = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < cnt) {
+        const long long id = p.sid[lb + threadIdx.x];
+        const float s = p.sx[lb + threadIdx.x];
+        if (id >= 0 && s > tau0) keys[lds_add_rtn(&red[32], 1)] = make_key(s, (u32)id);
+    }
+    __syncthreads();
+    const int n = red[32];
+    const int m = block_topk_sorted<1>(keys, n, p.k, sel, sorted, red);
+    // certificate
+    if (threadIdx.x == 0) {
+        bool ok = true;
+        if (cnt == p.kp) {  // the list is full: rows outside it exist
+            const float a_real = (p.ssc[lb + p.kp - 1] * p.qinfo[ql].inv_scale) * p.sf[f].inv_scale;
+            const float bound = a_real + p.eps[f * 64 + ql];       // every outside row scores <= bound (exactly)
+            if (m == p.k) ok = bound < key_score(sorted[p.k - 1]); // ... strictly below the exact k-th best
+            else ok = bound <= tau0;                               // ... or cannot pass the sentinel at all
+        }
+        if (!ok) {
+            atomicOr(&p.fail[f], 1);
+            atomicOr(&p.fail[p.F], 1);
+            atomicAdd(&p.fail[p.F + 1], 1);
+        }
+    }
+    const size_t ob = ((size_t)(p.q0 + ql) * p.F + f) * p.k;
+    for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
+        if (r < m) {
+            p.out_ids[ob + r] = (long long)key_id(sorted[r]);
+            p.out_scores[ob + r] = key_score(sorted[r]);
+        } else {
+            p.out_ids[ob + r] = p.sentinel ? 0 : -1;
+            p.out_scores[ob + r] = p.sentinel ? 0.0f : -__builtin_inff();
+        }
+    }
+}

@@ -108,12 +108,15 @@ struct MergeParams {
     long long* out_ids;   // [Q, F, k] global ids (nullptr: threshold-only pass)
     float* out_scores;    // [Q, F, k]
     float* tau_out;       // [F, 64] or nullptr: k-th best score of the merged list (-inf when fewer than k entries)
+    int* cnt_out;         // [Qt * F] or nullptr: entries of the merged list
+    const int* only_failed;  // [F] or nullptr: only fields whose flag is set are merged (screen fall-back pass)
     long long row_offset;
     int n_chunks, F, k, q0, sentinel;
 };
 // LDS carve-up shared by the selection kernels (everything in the dynamic region: 16-byte aligned base)
-//   keys[n_keys] u64 | sel[MFAR_MAX_K] u64 | sorted[MFAR_MAX_K] u64 | red[32] int | misc[4] int
-#define SEL_LDS_BYTES(n_keys) ((size_t)(n_keys) * 8 + 2 * MFAR_MAX_K * 8 + 36 * 4)
+//   keys[n_keys] u64 | sel[SEL_MAX_K] u64 | sorted[SEL_MAX_K] u64 | red[32] int | misc[4] int
+#define SEL_MAX_K 256   // internal depth limit (the screened stage-1 pass keeps k + 64 rows; the ABI limit is MFAR_MAX_K)
+#define SEL_LDS_BYTES(n_keys) ((size_t)(n_keys) * 8 + 2 * SEL_MAX_K * 8 + 36 * 4)
 #define MIX_LDS_BYTES(C, E, F) (SEL_LDS_BYTES(C) + 3 * MFAR_MAX_FIELDS * 4 + (size_t)(E) * 4 + (size_t)(E) * (F) * 4)
 struct SelLds {
     u64* keys;
@@ -126,8 +129,8 @@ __device__ __forceinline__ SelLds sel_lds(char* smem, int n_keys) {
     SelLds s;
     s.keys = (u64*)smem;
     s.sel = s.keys + n_keys;
-    s.sorted = s.sel + MFAR_MAX_K;
-    s.red = (int*)(s.sorted + MFAR_MAX_K);
+    s.sorted = s.sel + SEL_MAX_K;
+    s.red = (int*)(s.sorted + SEL_MAX_K);
     s.misc = s.red + 32;
     return s;
 }
@@ -137,6 +140,7 @@ __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SelLds L = sel_lds(smem, p.n_chunks * p.k);
     const int ql = blockIdx.x / p.F, f = blockIdx.x - ql * p.F;
+    if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
     if (threadIdx.x == 0) L.misc[0] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < p.n_chunks * p.k; i += blockDim.x) {
@@ -151,6 +155,7 @@ __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams
     const int n = L.misc[0];
     const int m = block_topk_sorted<NPT>(L.keys, n, p.k, L.sel, L.sorted, L.red);
     if (p.tau_out && threadIdx.x == 0) p.tau_out[f * 64 + ql] = m == p.k ? key_score(L.sorted[p.k - 1]) : -__builtin_inff();
+    if (p.cnt_out && threadIdx.x == 0) p.cnt_out[ql * p.F + f] = m;
     if (!p.out_ids) return;
     const size_t ob = ((size_t)(p.q0 + ql) * p.F + f) * p.k;
     for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
@@ -307,6 +312,7 @@ struct ScoreParams {
     float* out;              // [Q, C, F]
     long long row_offset;
     int n_rows, n_steps, E, F, C;
+    int per_field;           // != 0: cand is [Q, F, C] (one list per field), out is [Q, F, C]: row (f, c) is scored for field f only
 };
 // Each wave owns 64 (candidate, field) rows, one per lane.  A row of the tiled slab is 64-byte segments 4 KB apart
 // (one per k-step), so the wave gathers them cooperatively -- 4 lanes per segment, 16 segments per 1 KB LDS-DMA
@@ -348,9 +354,10 @@ __global__ void __launch_bounds__(256) mfar_score_candidates_kernel(const ScoreP
     int rr = 0;
     const char* rowbase = (const char*)p.slab;  // harmless in-bounds address for invalid rows
     if (idx < p.C * p.F) {
-        const int c = idx / p.F, f = idx - c * p.F;
+        const int c = p.per_field ? idx % p.C : idx / p.F;
+        const int f = p.per_field ? idx / p.C : idx - c * p.F;
         if (c < nc) {
-            const long long id = p.cand[(size_t)qi * p.C + c] - p.row_offset;
+            const long long id = p.cand[p.per_field ? ((size_t)qi * p.F + f) * p.C + c : (size_t)qi * p.C + c] - p.row_offset;
             if (id >= 0 && id < p.n_rows) {
                 valid = true;
                 rr = (int)(id & 63);

@@ -34,10 +34,10 @@
 // bf16 slab: 2 KB doc tile per (wave, k-step of 16 dims); query tile = 3 exact bf16 terms x 2 KB = 6 KB in LDS
 // (8 KB per k-step in memory, the 4th quarter is padding): 72 KB per workgroup -> two workgroups per CU
 #define S1B_STAGES 5                         // HBM-bound: keep four k-steps of loads in flight per wave
-#define S1B_D_BYTES (4 * S1B_STAGES * 2048)
-#define S1B_Q_STAGE 6144
-#define S1B_Q_BYTES (S1B_STAGES * S1B_Q_STAGE)
-#define S1B_LDS_BYTES (S1B_D_BYTES + S1B_Q_BYTES + S1_STATE_BYTES)
+#define S1B_LDS_BYTES (4 * S1B_STAGES * 2048 + S1B_STAGES * 6144 + S1_STATE_BYTES)
+// fp16 screen slab (mfar_screen.h): 2 KB doc tile, query tile = 2 fp16 terms x 2 KB
+#define S1H_STAGES 5
+#define S1H_LDS_BYTES (4 * S1H_STAGES * 2048 + S1H_STAGES * 4096 + S1_STATE_BYTES)
 
 struct S1Params {
     const void* slab;       // tiled slab (fp32 or bf16)
@@ -50,12 +50,13 @@ struct S1Params {
     int n_tiles;            // n_blk / 4
     int n_chunks;           // workgroups per field
     int Q;                  // valid queries (<= 64)
-    int k;                  // list depth (<= MFAR_MAX_K)
+    int k;                  // list depth (<= S1_TRIG)
     float tau0;             // 0 (zero sentinel, index.py:192-193) or -inf
     const float* gtau;      // [F, 64] non-strict lower bounds from the sample pass, or nullptr
     int sample;             // 1/2: threshold-estimation pass, every workgroup scans only the first tile of its chunk;
                             //      2 = light form: no lists, every wave publishes the 2 best scores per query of its 64 rows
     float* samp_out;        // [F][n_chunks * 4][64][2] (sample == 2)
+    const int* only_failed; // [F] or nullptr: workgroups of fields whose flag is 0 exit at once (screen fall-back pass)
     int dbg;                // profiling only (MFAR_S1_DEBUG): 1 = skip the selection epilogue (results invalid; note that
                             // the downstream kernels then have no candidates, so they no longer compete with stage 1)
 };
@@ -289,6 +290,7 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
     const int j = lane & 31, h = lane >> 5;
 
     const int f = blockIdx.x / p.n_chunks;
+    if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
     const int chunk = blockIdx.x - f * p.n_chunks;
     const int t0 = (int)(((long long)chunk * p.n_tiles) / p.n_chunks);
     int t1 = (int)(((long long)(chunk + 1) * p.n_tiles) / p.n_chunks);
@@ -385,16 +387,37 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// bf16 slab.  Tile = [64 rows][16 dims] bf16 = 2 KB; the 16-byte granule (8 dims) at (row rr, position p) holds dims
-// 16*step + 8c .. +7 with c = p ^ ((rr >> 3) & 1).  v_mfma_f32_32x32x16_bf16: lane (r = lane & 31, h = lane >> 5) supplies
-// A[row r][k = 8h .. 8h+7] and B[k = 8h .. 8h+7][col r], i.e. exactly one granule per operand per k-step.
+// 16-bit slabs.  Tile = [64 rows][16 dims] x 2 bytes = 2 KB; the 16-byte granule (8 dims) at (row rr, position p) holds dims
+// 16*step + 8c .. +7 with c = p ^ ((rr >> 3) & 1).  v_mfma_f32_32x32x16_{bf16,f16}: lane (r = lane & 31, h = lane >> 5)
+// supplies A[row r][k = 8h .. 8h+7] and B[k = 8h .. 8h+7][col r], i.e. exactly one granule per operand per k-step.
+//   MODE 0: bf16 slab (MFAR_DTYPE_BF16), queries split exactly into three bf16 terms;
+//   MODE 1: fp16 SCREEN slab of an fp32 index (mfar_screen.h), queries split into two fp16 terms.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void s1_body_bf16(const S1Params& p) {
+template <int MODE>
+struct S1X {
+    static constexpr int TERMS = MODE ? 2 : 3;
+    static constexpr int STAGES = MODE ? S1H_STAGES : S1B_STAGES;
+    static constexpr int Q_STAGE = TERMS * 2048;           // bytes of query tile per ring stage in LDS
+    static constexpr int Q_STEP_MEM = MODE ? 4096 : 8192;  // bytes of query tile per k-step in memory
+    static constexpr int LOADS = MODE ? 3 : 4;             // LDS-DMA instructions per wave per stage
+    static constexpr int D_BYTES = 4 * STAGES * 2048;
+    static constexpr int LDS_BYTES = D_BYTES + STAGES * Q_STAGE + S1_STATE_BYTES;
+};
+
+template <int N>
+__device__ __forceinline__ void s1_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int MODE>
+__device__ __forceinline__ void s1_body_x16(const S1Params& p) {
+    typedef S1X<MODE> X;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const qring = smem + S1B_D_BYTES;
-    const S1State st = s1_state(smem + S1B_D_BYTES + S1B_Q_BYTES);
+    char* const qring = smem + X::D_BYTES;
+    const S1State st = s1_state(smem + X::D_BYTES + X::STAGES * X::Q_STAGE);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -402,6 +425,7 @@ __device__ __forceinline__ void s1_body_bf16(const S1Params& p) {
     const int j = lane & 31, h = lane >> 5;
 
     const int f = blockIdx.x / p.n_chunks;
+    if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
     const int chunk = blockIdx.x - f * p.n_chunks;
     const int t0 = (int)(((long long)chunk * p.n_tiles) / p.n_chunks);
     int t1 = (int)(((long long)(chunk + 1) * p.n_tiles) / p.n_chunks);
@@ -412,71 +436,90 @@ __device__ __forceinline__ void s1_body_bf16(const S1Params& p) {
     // granule of row (32*blk + j), k-half h inside a 2 KB tile (rows are 32 B)
     const int off = j * 32 + ((h ^ ((j >> 3) & 1)) << 4);
 
-    char* const dring = smem + w * (S1B_STAGES * 2048);
+    char* const dring = smem + w * (X::STAGES * 2048);
     const size_t step_bytes = 2048;
     const size_t tile_jump = (size_t)3 * p.n_steps * step_bytes;
     const char* dnext = (const char*)p.slab + ((size_t)f * (size_t)p.field_stride) * 2 +
                         ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes + lane * 16;
-    // the 6 KB query tile is 6 pieces of 1 KB: waves 0-1 load pieces {2w, 2w+1}, waves 2-3 load piece 2+w (twice, so that
-    // every wave issues the same number of loads per stage and the counted vmcnt waits stay uniform)
-    const int qp0 = w < 2 ? 2 * w : 2 + w, qp1 = w < 2 ? 2 * w + 1 : 2 + w;
+    // bf16: the 6 KB query tile is 6 pieces of 1 KB: waves 0-1 load pieces {2w, 2w+1}, waves 2-3 load piece 2+w (twice, so
+    // that every wave issues the same number of loads per stage and the counted vmcnt waits stay uniform).
+    // fp16: 4 pieces, wave w loads piece w.
+    const int qp0 = MODE ? w : (w < 2 ? 2 * w : 2 + w), qp1 = w < 2 ? 2 * w + 1 : 2 + w;
     const char* const qbase = (const char*)p.qt + lane * 16;
     int s_next = 0, st_next = 0;
     const int total = (t1 - t0) * p.n_steps;
     int issued = 0;
-#define S1B_ISSUE_NEXT()                                                                                  \
+#define S1X_ISSUE_NEXT()                                                                                  \
     do {                                                                                                  \
         char* db_ = dring + st_next * 2048;                                                               \
         S1_GLDS(dnext, db_, 2);                                                                           \
         S1_GLDS(dnext + 1024, db_ + 1024, 2);                                                             \
-        const char* qs_ = qbase + (size_t)s_next * 8192;                                                  \
-        char* qd_ = qring + st_next * S1B_Q_STAGE;                                                        \
+        const char* qs_ = qbase + (size_t)s_next * X::Q_STEP_MEM;                                         \
+        char* qd_ = qring + st_next * X::Q_STAGE;                                                         \
         S1_GLDS(qs_ + qp0 * 1024, qd_ + qp0 * 1024, 0);                                                   \
-        S1_GLDS(qs_ + qp1 * 1024, qd_ + qp1 * 1024, 0);                                                   \
+        if (MODE == 0) S1_GLDS(qs_ + qp1 * 1024, qd_ + qp1 * 1024, 0);                                    \
         dnext += step_bytes;                                                                              \
         if (++s_next == p.n_steps) {                                                                      \
             s_next = 0;                                                                                   \
             dnext += tile_jump;                                                                           \
         }                                                                                                 \
-        st_next = (st_next == S1B_STAGES - 1) ? 0 : st_next + 1;                                          \
+        st_next = (st_next == X::STAGES - 1) ? 0 : st_next + 1;                                           \
         ++issued;                                                                                         \
     } while (0)
-    for (int i = 0; i < S1B_STAGES - 1; ++i)
-        if (total > i) S1B_ISSUE_NEXT();
+    for (int i = 0; i < X::STAGES - 1; ++i)
+        if (total > i) S1X_ISSUE_NEXT();
 
     int it = 0, st_cur = 0;
     for (int t = t0; t < t1; ++t) {
         f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
         for (int s = 0; s < p.n_steps; ++s, ++it) {
-            // stage `it` landed; up to S1B_STAGES - 2 newer stages (4 loads each) may stay in flight
+            // stage `it` landed; up to STAGES - 1 newer stages (LOADS loads each) may stay in flight
             const int ahead = issued - it - 1;
-            if (ahead >= 4) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-            else if (ahead == 3) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
-            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            static_assert(X::STAGES <= 6, "extend the wait ladder");
+            if (ahead >= 5) s1_wait_barrier<5 * X::LOADS>();
+            else if (ahead == 4) s1_wait_barrier<4 * X::LOADS>();
+            else if (ahead == 3) s1_wait_barrier<3 * X::LOADS>();
+            else if (ahead == 2) s1_wait_barrier<2 * X::LOADS>();
+            else if (ahead == 1) s1_wait_barrier<1 * X::LOADS>();
+            else s1_wait_barrier<0>();
             const char* cur = dring + st_cur * 2048;
-            const char* curq = qring + st_cur * S1B_Q_STAGE;
-            st_cur = (st_cur == S1B_STAGES - 1) ? 0 : st_cur + 1;
-            const bf16x8 d0 = *(const bf16x8*)(cur + off);
-            const bf16x8 d1 = *(const bf16x8*)(cur + 1024 + off);
-            const bf16x8 qh0 = *(const bf16x8*)(curq + off), qh1 = *(const bf16x8*)(curq + 1024 + off);
-            const bf16x8 qm0 = *(const bf16x8*)(curq + 2048 + off), qm1 = *(const bf16x8*)(curq + 3072 + off);
-            const bf16x8 ql0 = *(const bf16x8*)(curq + 4096 + off), ql1 = *(const bf16x8*)(curq + 5120 + off);
-            if (issued < total && issued < it + S1B_STAGES) S1B_ISSUE_NEXT();
-            // smallest terms first: lo, mid, hi (all products are exact; this keeps the fp32 accumulation tight)
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, ql0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, ql1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, ql0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, ql1, acc11, 0, 0, 0);
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qm0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qm1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qm0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qm1, acc11, 0, 0, 0);
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qh0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qh1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qh0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qh1, acc11, 0, 0, 0);
+            const char* curq = qring + st_cur * X::Q_STAGE;
+            st_cur = (st_cur == X::STAGES - 1) ? 0 : st_cur + 1;
+            if (MODE == 0) {
+                const bf16x8 d0 = *(const bf16x8*)(cur + off);
+                const bf16x8 d1 = *(const bf16x8*)(cur + 1024 + off);
+                const bf16x8 qh0 = *(const bf16x8*)(curq + off), qh1 = *(const bf16x8*)(curq + 1024 + off);
+                const bf16x8 qm0 = *(const bf16x8*)(curq + 2048 + off), qm1 = *(const bf16x8*)(curq + 3072 + off);
+                const bf16x8 ql0 = *(const bf16x8*)(curq + 4096 + off), ql1 = *(const bf16x8*)(curq + 5120 + off);
+                if (issued < total && issued < it + X::STAGES) S1X_ISSUE_NEXT();
+                // smallest terms first: lo, mid, hi (all products are exact; this keeps the fp32 accumulation tight)
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, ql0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, ql1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, ql0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, ql1, acc11, 0, 0, 0);
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qm0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qm1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qm0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qm1, acc11, 0, 0, 0);
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qh0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qh1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qh0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qh1, acc11, 0, 0, 0);
+            } else {
+                const f16x8 d0 = *(const f16x8*)(cur + off);
+                const f16x8 d1 = *(const f16x8*)(cur + 1024 + off);
+                const f16x8 qh0 = *(const f16x8*)(curq + off), qh1 = *(const f16x8*)(curq + 1024 + off);
+                const f16x8 ql0 = *(const f16x8*)(curq + 2048 + off), ql1 = *(const f16x8*)(curq + 3072 + off);
+                if (issued < total && issued < it + X::STAGES) S1X_ISSUE_NEXT();
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d0, ql0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d0, ql1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1, ql0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1, ql1, acc11, 0, 0, 0);
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d0, qh0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d0, qh1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1, qh0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1, qh1, acc11, 0, 0, 0);
+            }
         }
         if (p.dbg & 1) {
             asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11));
@@ -487,10 +530,10 @@ __device__ __forceinline__ void s1_body_bf16(const S1Params& p) {
             continue;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A + early refill (see the fp32 body)
-        if (issued < total) S1B_ISSUE_NEXT();
+        if (issued < total) S1X_ISSUE_NEXT();
         s1_epilogue(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
-#undef S1B_ISSUE_NEXT
+#undef S1X_ISSUE_NEXT
     if (p.sample != 2) s1_flush(p, st, w, wgq0);
 }
 
@@ -498,5 +541,7 @@ __device__ __forceinline__ void s1_body_bf16(const S1Params& p) {
 // separately (the sample pass scans 1 tile per workgroup and is ~30x shorter).
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_kernel(const S1Params p) { s1_body_f32(p); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_sample_kernel(const S1Params p) { s1_body_f32(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16_kernel(const S1Params p) { s1_body_bf16(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16_sample_kernel(const S1Params p) { s1_body_bf16(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16_kernel(const S1Params p) { s1_body_x16<0>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16_sample_kernel(const S1Params p) { s1_body_x16<0>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16_kernel(const S1Params p) { s1_body_x16<1>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16_sample_kernel(const S1Params p) { s1_body_x16<1>(p); }

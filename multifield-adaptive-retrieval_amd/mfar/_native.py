@@ -63,6 +63,8 @@ SIGNATURES = {
     "mfar_set_timing": (_i, [_vp, _i]),
     "mfar_stage1_timing": (_i, [_vp, _c.POINTER(_c.c_double), _c.POINTER(_i)]),
     "mfar_set_wgs_per_cu": (_i, [_vp, _i]),
+    "mfar_set_screen": (_i, [_vp, _i, _c.c_float]),
+    "mfar_screen_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
 }
 
 

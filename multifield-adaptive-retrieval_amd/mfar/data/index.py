@@ -273,6 +273,17 @@ class MultiFieldIndex:
     def set_wgs_per_cu(self, n: int):
         _native.check(_native.lib().mfar_set_wgs_per_cu(self._h, int(n)))
 
+    def set_screen(self, mode: int = 1, eps_mult: float = 1.0):
+        """Certified fp16 screening of an fp32 index (include/mfar_hip.h): 0 off, 1 auto, 2 whenever possible.
+        Outputs are bit-identical in every mode; `eps_mult` is a test knob (1 = rigorous proof)."""
+        _native.check(_native.lib().mfar_set_screen(self._h, int(mode), float(eps_mult)))
+
+    def screen_stats(self) -> dict:
+        built, nbytes, chk, bad = ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _native.check(_native.lib().mfar_screen_stats(self._h, ctypes.byref(built), ctypes.byref(nbytes), ctypes.byref(chk),
+                                                      ctypes.byref(bad)))
+        return dict(built=bool(built.value), screen_bytes=nbytes.value, n_checked=chk.value, n_failed=bad.value)
+
 
 def merge_workspace_bytes(Q: int, n_fields: int, k1: int = 100) -> int:
     return int(_native.lib().mfar_merge_workspace_bytes(int(Q), int(n_fields), int(k1)))

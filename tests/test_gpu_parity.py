@@ -283,8 +283,8 @@ def test_full_size_properties(idxmod):
     """BASELINE.json's headline shape (1M docs x 8 fields x 768) is checked through size-independent properties:
     planted documents are found, lists are sorted, results are reproducible and invariant under re-sharding."""
     import torch
-    if torch.cuda.mem_get_info(0)[0] < 60 << 30:
-        pytest.skip("needs ~55 GB of free HBM")
+    if torch.cuda.mem_get_info(0)[0] < 90 << 30:
+        pytest.skip("needs ~80 GB of free HBM")
     from mfar import synth
     D, F, E, Q = 1_000_000, 8, 768, 64
     corpus = synth.SyntheticCorpus(D, F, E, n_queries=Q, seed=0xdeadbeef, device="cuda:0")
@@ -301,6 +301,15 @@ def test_full_size_properties(idxmod):
     rel = corpus.qrels(0, Q)
     hit = np.mean([len(set(r1["ids"][i, :20].tolist()) & rel[i]) / len(rel[i]) for i in range(Q)])
     assert hit > 0.9, hit                                                                          # planted docs found
+    # the fp16 screen is on by default at this size: every list certified, and switching it off changes no bit
+    st = ix.screen_stats()
+    assert st["built"] and st["n_checked"] == 2 * Q * F and st["n_failed"] == 0, st
+    ix.set_screen(0)
+    r0 = ix.search(q, W, None, return_fields=True)
+    torch.cuda.synchronize()
+    for key in ("ids", "scores", "field_ids", "field_scores", "n_cand"):
+        assert torch.equal(r0[key], r1[key]), key
+    ix.set_screen(1)
     # re-sharding invariance at full size: two half-shards + merge == one shard
     half = D // 2
     shards = [corpus.build_index(idxmod, row0=0, n=half), corpus.build_index(idxmod, row0=half, n=D - half)]
@@ -559,3 +568,96 @@ def test_lists_first_exchange_equals_unsharded(idxmod):
                 assert np.array_equal(r["n_valid"].cpu().numpy(), ref["n_valid"]), (dtype, sentinel, S)
                 for sh in shards:
                     sh.close()
+
+
+# ------------------------------------------------------------------------------------------------ certified fp16 screen
+def _check_stage1(ix, slab, q, k, sentinel, tag):
+    ids, sc = ix.retrieve_fields(q, k, sentinel)
+    for f in range(slab.shape[0]):
+        oi, osc = O.c_retrieve(slab[f], q, k, sentinel)
+        assert np.array_equal(ids[:, f], oi), (tag, f)
+        assert np.array_equal(sc[:, f].view(np.uint32), osc.view(np.uint32)), (tag, f)
+
+
+def test_screen_bit_exact_vs_oracle(idxmod):
+    """Stage 1 through the fp16 screen (csrc/mfar_screen.h) is bit-identical to the oracle's exhaustive fp32 result:
+    ragged shapes, both sentinel modes, mostly-negative scores (the zero sentinel cuts the lists short), exact ties."""
+    rng = np.random.default_rng(11)
+    cases = [(1, 300, 32, 3, 100), (2, 5000, 64, 65, 100), (3, 20000, 96, 7, 100), (8, 4097, 768, 9, 100), (2, 9000, 32, 130, 128),
+             (4, 2500, 256, 64, 1), (1, 150, 32, 5, 100)]
+    for F, D, E, Q, k in cases:
+        for sentinel in (True, False):
+            for mean, dup in ((0.3, 0), (-0.4, 7), (-0.05, 0)):
+                slab, q, _ = _mk(rng, F, D, E, Q, mean=mean, dup=dup)
+                ix = _load(idxmod, slab)
+                ix.set_screen(2)
+                _check_stage1(ix, slab, q, k, sentinel, (F, D, E, Q, k, sentinel, mean, dup))
+                st = ix.screen_stats()
+                assert st["built"] and st["n_checked"] == Q * F and st["screen_bytes"] > 0
+                if dup == 0 and D >= 2000:
+                    assert st["n_failed"] == 0, st        # random data: every list is certified by the screen alone
+                ix.close()
+
+
+def test_screen_fallback_and_slack(idxmod):
+    """eps_mult = 1e9 makes every certificate fail: all fields go through the exact fall-back pass and the result must
+    not change.  eps_mult = 1/16 still certifies everything on random data: the real error is far below the bound."""
+    rng = np.random.default_rng(12)
+    F, D, E, Q, k = 3, 30000, 128, 70, 100
+    slab, q, W = _mk(rng, F, D, E, Q)
+    ix = _load(idxmod, slab)
+    ix.set_screen(2, 1e9)
+    _check_stage1(ix, slab, q, k, True, "forced fall-back")
+    st = ix.screen_stats()
+    assert st["n_failed"] == st["n_checked"] == Q * F, st
+    ix.set_screen(2, 1.0 / 16)
+    _check_stage1(ix, slab, q, k, True, "eps/16")
+    st2 = ix.screen_stats()
+    assert st2["n_failed"] == st["n_failed"], (st, st2)
+    # the whole scorer on top of the screened stage 1
+    ix.set_screen(2, 1.0)
+    r = ix.search(q, W, None, return_fields=True)
+    o = O.c_two_stage(slab, q, W, None)
+    assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32))
+    ix.set_screen(0)
+    r0 = ix.search(q, W, None, return_fields=True)
+    for key in ("ids", "scores", "field_ids", "field_scores", "n_cand"):
+        assert np.array_equal(np.asarray(r[key]).view(np.uint8), np.asarray(r0[key]).view(np.uint8)), key
+    ix.close()
+
+
+def test_screen_massive_ties_and_huge_values(idxmod):
+    """Thousands of identical rows at the top of every list (the shared 'empty field' vector, format.py:58-59) defeat the
+    certificate -- the k'-th approximate score equals the k-th exact one -- so the exact pass must take over and the
+    canonical tie-break (doc id ascending) must hold.  A row with huge finite values overflows the norm statistics."""
+    rng = np.random.default_rng(13)
+    F, D, E, Q, k = 2, 20000, 64, 9, 100
+    slab, q, _ = _mk(rng, F, D, E, Q)
+    top = q.mean(0) * 3.0
+    rows = rng.choice(D, size=3000, replace=False)
+    slab[0, rows] = top                                    # field 0: 3000-way tie at the very top
+    ix = _load(idxmod, slab)
+    ix.set_screen(2)
+    _check_stage1(ix, slab, q, k, True, "ties")
+    st = ix.screen_stats()
+    assert st["n_failed"] >= Q, st                         # field 0 fell back for every query
+    slab[1, 17] *= np.float32(1e25)                        # field 1: row norm^2 overflows fp32
+    ix.write_rows(1, 17, slab[1, 17:18])
+    _check_stage1(ix, slab, q, k, False, "huge")
+    ix.close()
+
+
+def test_screen_follows_row_updates(idxmod):
+    rng = np.random.default_rng(14)
+    F, D, E, Q, k = 2, 18000, 96, 5, 100
+    slab, q, _ = _mk(rng, F, D, E, Q)
+    ix = _load(idxmod, slab)                               # auto mode: >= 16384 rows
+    _check_stage1(ix, slab, q, k, True, "before")
+    assert ix.screen_stats()["built"]
+    new = (q[:3] * 5.0).astype(np.float32)                 # three rows that become everybody's best match
+    slab[1, 100:103] = new
+    ix.write_rows(1, 100, new)
+    assert not ix.screen_stats()["built"]                  # stale until the next search rebuilds it
+    _check_stage1(ix, slab, q, k, True, "after")
+    assert ix.screen_stats()["built"]
+    ix.close()
