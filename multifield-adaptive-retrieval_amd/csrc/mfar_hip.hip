@@ -462,8 +462,16 @@ static int stage1_pass(mfar_index* idx, int kind, const void* slab, const void* 
     // appends / compacts almost nothing.  Worth it once a chunk is much longer than one tile.
     static const int sample_min_tiles = getenv("MFAR_SAMPLE_MIN_TILES") ? atoi(getenv("MFAR_SAMPLE_MIN_TILES")) : 3;
     const bool use_sample = n_tiles >= sample_min_tiles * n_chunks && !(p.dbg & 2) && !only_failed;
-    const int n_wave_blocks = 4 * n_chunks;
+    // tiles per workgroup in the sample pass: more tiles = tighter starting thresholds = fewer appends in the full pass,
+    // at the price of reading those tiles twice; at most 1/12 of a chunk and 2048 published values per (query, field)
+    // (measured: 2 tiles pay off for the HBM-bound 16-bit passes, 1 for the MFMA-bound fp32 pass)
+    static const int sample_tiles_env = getenv("MFAR_SAMPLE_TILES") ? atoi(getenv("MFAR_SAMPLE_TILES")) : 0;
+    const int sample_tiles_max = sample_tiles_env > 0 ? sample_tiles_env : (kind == S1_F32 ? 1 : 2);
+    int sample_tiles = std::max(1, std::min(sample_tiles_max, n_tiles / n_chunks / 12));
+    while (sample_tiles > 1 && 8 * n_chunks * sample_tiles > 2048) --sample_tiles;
+    const int n_wave_blocks = 4 * n_chunks * sample_tiles;
     const bool light_sample = use_sample && 2 * n_wave_blocks >= 2 * k && 2 * n_wave_blocks <= 2048;
+    p.sample_tiles = light_sample ? sample_tiles : 1;
     if (light_sample) {
         // every wave publishes the 2 best scores per query of its 64 sampled rows; tau = k-th largest of those
         S1Params ps = p;

@@ -27,7 +27,9 @@
 #include "mfar_device.h"
 #include "mfar_stage1.h"
 
+#ifndef SCREEN_EXTRA
 #define SCREEN_EXTRA 64          // k' = k + SCREEN_EXTRA
+#endif
 #define SCREEN_MAX_KP S1_TRIG    // the stage-1 lists compact to k', which must leave room for one tile of appends
 #define SCREEN_SLACK 1.25f
 

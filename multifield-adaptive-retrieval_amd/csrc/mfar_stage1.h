@@ -36,7 +36,9 @@
 #define S1B_STAGES 5                         // HBM-bound: keep four k-steps of loads in flight per wave
 #define S1B_LDS_BYTES (4 * S1B_STAGES * 2048 + S1B_STAGES * 6144 + S1_STATE_BYTES)
 // fp16 screen slab (mfar_screen.h): 2 KB doc tile, query tile = 2 fp16 terms x 2 KB
-#define S1H_STAGES 5
+#ifndef S1H_STAGES
+#define S1H_STAGES 6                         // 74.5 KB per workgroup, two per CU; measured 7 % faster than 5
+#endif
 #define S1H_LDS_BYTES (4 * S1H_STAGES * 2048 + S1H_STAGES * 4096 + S1_STATE_BYTES)
 
 struct S1Params {
@@ -55,7 +57,8 @@ struct S1Params {
     const float* gtau;      // [F, 64] non-strict lower bounds from the sample pass, or nullptr
     int sample;             // 1/2: threshold-estimation pass, every workgroup scans only the first tile of its chunk;
                             //      2 = light form: no lists, every wave publishes the 2 best scores per query of its 64 rows
-    float* samp_out;        // [F][n_chunks * 4][64][2] (sample == 2)
+    int sample_tiles;       // tiles per workgroup scanned by the sample pass (>= 1, <= tiles of the shortest chunk)
+    float* samp_out;        // [F][n_chunks * sample_tiles * 4][64][2] (sample == 2)
     const int* only_failed; // [F] or nullptr: workgroups of fields whose flag is 0 exit at once (screen fall-back pass)
     int dbg;                // profiling only (MFAR_S1_DEBUG): 1 = skip the selection epilogue (results invalid; note that
                             // the downstream kernels then have no candidates, so they no longer compete with stage 1)
@@ -117,6 +120,14 @@ __device__ __forceinline__ float s1_compact(uint2* list, int n, int k) {
 // ones) AND is not below the global lower bound from the sample pass (non-strict: ties with other chunks are
 // decided by the merge).
 #define S1_PASS(v, tq, tg) ((v) > (tq) && (v) >= (tg))
+// the same test as ONE compare: v > tq  <=>  v >= nextup(tq) for non-NaN v, so thr = max(nextup(tq), tg)
+__device__ __forceinline__ float s1_nextup(float x) {
+    if (!(x < __builtin_inff())) return x;                    // +inf (and NaN) stay
+    if (x == 0.0f) return __uint_as_float(1u);                // +-0 -> smallest positive subnormal
+    const u32 b = __float_as_uint(x);
+    return __uint_as_float((b & 0x80000000u) ? b - 1u : b + 1u);
+}
+#define S1_PASS1(v, thr) ((v) >= (thr))
 
 struct S1State {       // LDS-resident selection state of one workgroup
     float* tau;        // [64] strict local thresholds
@@ -159,13 +170,13 @@ __device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st
     }
     // (barrier A -- the compactions of the previous tile are complete, every wave has finished the tile's last k-step --
     //  is executed by the caller, which uses it to refill the ring slot that just became free before this epilogue runs)
-    const float tq0 = st.tau[j], tq1 = st.tau[32 + j];
-    const float tg0 = st.tg[j], tg1 = st.tg[32 + j];
+    const float th0 = fmaxf(s1_nextup(st.tau[j]), st.tg[j]);
+    const float th1 = fmaxf(s1_nextup(st.tau[32 + j]), st.tg[32 + j]);
     int n0 = 0, n1 = 0;  // survivors of this lane for query j / 32 + j
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        n0 += (S1_PASS(acc00[r], tq0, tg0) ? 1 : 0) + (S1_PASS(acc10[r], tq0, tg0) ? 1 : 0);
-        n1 += (S1_PASS(acc01[r], tq1, tg1) ? 1 : 0) + (S1_PASS(acc11[r], tq1, tg1) ? 1 : 0);
+        n0 += (S1_PASS1(acc00[r], th0) ? 1 : 0) + (S1_PASS1(acc10[r], th0) ? 1 : 0);
+        n1 += (S1_PASS1(acc01[r], th1) ? 1 : 0) + (S1_PASS1(acc11[r], th1) ? 1 : 0);
     }
     if (__any((n0 | n1) != 0)) {
         // one LDS slot reservation per (lane, query block); inline asm keeps hipcc from draining the
@@ -177,18 +188,18 @@ __device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st
         const int row_w = t * S1_TILE_ROWS + w * 64 + 4 * h;
         uint2* l0 = p.lists + (wgq0 + j) * S1_CAP;
         uint2* l1 = p.lists + (wgq0 + 32 + j) * S1_CAP;
-#define S1_APPEND(ACC, DB, TQ, TG, L, B)                                                                     \
+#define S1_APPEND(ACC, DB, TH, L, B)                                                                         \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                         \
         const float v = ACC[r];                                                                              \
-        if (S1_PASS(v, TQ, TG)) {                                                                            \
+        if (S1_PASS1(v, TH)) {                                                                               \
             if (B < S1_CAP) L[B] = make_uint2(__float_as_uint(v), (u32)(row_w + 32 * DB + (r & 3) + 8 * (r >> 2))); \
             ++B;                                                                                             \
         }                                                                                                    \
     }
-        S1_APPEND(acc00, 0, tq0, tg0, l0, b0)
-        S1_APPEND(acc10, 1, tq0, tg0, l0, b0)
-        S1_APPEND(acc01, 0, tq1, tg1, l1, b1)
-        S1_APPEND(acc11, 1, tq1, tg1, l1, b1)
+        S1_APPEND(acc00, 0, th0, l0, b0)
+        S1_APPEND(acc10, 1, th0, l0, b0)
+        S1_APPEND(acc01, 0, th1, l1, b1)
+        S1_APPEND(acc11, 1, th1, l1, b1)
 #undef S1_APPEND
     }
     // barrier B: slot counters and the compaction flag of this tile are final
@@ -217,7 +228,7 @@ __device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st
 // Light threshold-estimation epilogue (sample == 2): per (wave, query) the two best scores among the wave's 64 rows.
 // They are scores of distinct real rows, so the k-th largest of all published values is a valid (non-strict) lower
 // bound of the final k-th best (mfar_sample_tau_kernel).
-__device__ __forceinline__ void s1_sample_top2(const S1Params& p, int f, int chunk, int t, int w, f32x16& acc00, f32x16& acc01,
+__device__ __forceinline__ void s1_sample_top2(const S1Params& p, int f, int chunk, int tl, int t, int w, f32x16& acc00, f32x16& acc01,
                                                f32x16& acc10, f32x16& acc11) {
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     if (t * S1_TILE_ROWS + S1_TILE_ROWS > p.n_rows) {  // padding rows never qualify
@@ -250,7 +261,7 @@ __device__ __forceinline__ void s1_sample_top2(const S1Params& p, int f, int chu
     const float ra1 = fmaxf(a1, oa1), ra2 = fmaxf(fminf(a1, oa1), fmaxf(a2, oa2));
     const float rb1 = fmaxf(b1, ob1), rb2 = fmaxf(fminf(b1, ob1), fmaxf(b2, ob2));
     if (h == 0) {
-        float* o = p.samp_out + ((size_t)(f * p.n_chunks + chunk) * 4 + w) * 128;
+        float* o = p.samp_out + (((size_t)(f * p.n_chunks + chunk) * p.sample_tiles + tl) * 4 + w) * 128;
         o[j * 2] = ra1;
         o[j * 2 + 1] = ra2;
         o[(32 + j) * 2] = rb1;
@@ -294,7 +305,7 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
     const int chunk = blockIdx.x - f * p.n_chunks;
     const int t0 = (int)(((long long)chunk * p.n_tiles) / p.n_chunks);
     int t1 = (int)(((long long)(chunk + 1) * p.n_tiles) / p.n_chunks);
-    if (p.sample) t1 = min(t1, t0 + 1);
+    if (p.sample) t1 = min(t1, t0 + p.sample_tiles);
     const size_t wgq0 = (size_t)blockIdx.x * 64;
     s1_state_init(st, p, f);
 
@@ -373,7 +384,7 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
             continue;
         }
         if (p.sample == 2) {
-            s1_sample_top2(p, f, chunk, t, w, acc00, acc01, acc10, acc11);
+            s1_sample_top2(p, f, chunk, t - t0, t, w, acc00, acc01, acc10, acc11);
             continue;
         }
         // barrier A.  Every wave is past the last k-step of the tile, so that step's ring slot is free: refill it NOW,
@@ -429,7 +440,7 @@ __device__ __forceinline__ void s1_body_x16(const S1Params& p) {
     const int chunk = blockIdx.x - f * p.n_chunks;
     const int t0 = (int)(((long long)chunk * p.n_tiles) / p.n_chunks);
     int t1 = (int)(((long long)(chunk + 1) * p.n_tiles) / p.n_chunks);
-    if (p.sample) t1 = min(t1, t0 + 1);
+    if (p.sample) t1 = min(t1, t0 + p.sample_tiles);
     const size_t wgq0 = (size_t)blockIdx.x * 64;
     s1_state_init(st, p, f);
 
@@ -526,7 +537,7 @@ __device__ __forceinline__ void s1_body_x16(const S1Params& p) {
             continue;
         }
         if (p.sample == 2) {
-            s1_sample_top2(p, f, chunk, t, w, acc00, acc01, acc10, acc11);
+            s1_sample_top2(p, f, chunk, t - t0, t, w, acc00, acc01, acc10, acc11);
             continue;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A + early refill (see the fp32 body)

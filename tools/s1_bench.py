@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Stage-1-only timing (no overlapped tail kernels): python tools/s1_bench.py [--dtype f32|bf16] [--screen 0|1] [--docs N]"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "multifield-adaptive-retrieval_amd"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--docs", type=int, default=1_000_000)
+    ap.add_argument("--fields", type=int, default=8)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--screen", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--k", type=int, default=100)
+    a = ap.parse_args()
+    import torch
+    from mfar import synth
+    from mfar.data import index as idxmod
+    corpus = synth.SyntheticCorpus(a.docs, a.fields, a.dim, n_queries=4096, seed=0xDEADBEEF, device="cuda:0")
+    ix = corpus.build_index(idxmod, dtype=a.dtype)
+    ix.set_screen(a.screen)
+    for i in range(3):
+        ix.retrieve_fields(corpus.queries(i * 64, 64), a.k, True)
+    torch.cuda.synchronize()
+    ix.set_timing(True)
+    t0 = time.perf_counter()
+    for i in range(a.iters):
+        ix.retrieve_fields(corpus.queries((3 + i) * 64, 64), a.k, True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.iters * 1e3
+    ms, n = ix.stage1_timing()
+    print(f"dtype={a.dtype} screen={a.screen} dbg={os.environ.get('MFAR_S1_DEBUG', '0')} stage1_total_ms={dt:.3f} main_kernel_ms={ms / max(n, 1):.3f} "
+          f"stats={ix.screen_stats()}")
+
+
+if __name__ == "__main__":
+    main()
