@@ -13,8 +13,10 @@ top-100, i.e. RetrievalTrainingModule.trec_eval_step (contrastive.py:669-704) wi
 (query embeddings are inputs, already in HBM).  N > 1: per-shard payloads are exchanged with ONE RCCL all-gather and
 merged on every rank.  The corpus is fixed while N grows: strong scaling.
 
-Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (stage 1, fp32 MFMA bound) from its
-algorithmic flops (2 * D_local * F * E * 64 per launch) and its HIP-event duration measured on the launch stream.
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel from its HIP-event duration measured on the
+launch stream.  Default (fp32 index, certified fp16 screen on): `mfar_stage1_f16_kernel`, HBM-bound, algorithmic bytes =
+D_local * F * E * 2 per launch (the fp16 screen slab is read once per batch).  `--screen off`: `mfar_stage1_kernel`,
+fp32-MFMA-bound, algorithmic flops = 2 * D_local * F * E * 64 per launch.  The results are bit-identical in both modes.
 `cpu_baseline` times the oracle's torch port of the reference algorithm (same torch ops as the reference's CPU path)
 on a bounded row sample of the same corpus, on this box's host cores (N = 1 only).
 """
@@ -43,6 +45,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--wgs-per-cu", type=int, default=0)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="slab storage (default: the exact fp32 path)")
+    ap.add_argument("--screen", choices=["auto", "off"], default="auto",
+                    help="f32 only: certified fp16 screening of stage 1 (bit-identical results; csrc/mfar_screen.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-docs", type=int, default=100_000)
     args = ap.parse_args()
@@ -88,6 +92,8 @@ def main():
     ix = corpus.build_index(idxmod, row0=row0, n=row1 - row0, dtype=args.dtype)
     if args.wgs_per_cu:
         ix.set_wgs_per_cu(args.wgs_per_cu)
+    if args.screen == "off":
+        ix.set_screen(0)
     t_build = time.time() - t_build
     W = corpus.W
     mask = torch.ones(F, device=dev)
@@ -149,14 +155,18 @@ def main():
         qps = args.steps * Q / dt
         s1_avg_ms = s1_ms / max(1, s1_n)
         flops_per_launch = 2.0 * (row1 - row0) * F * E * 64      # algorithmic: 2*D*F*E per query x 64 queries
-        esize = 2 if args.dtype == "bf16" else 4
-        bytes_per_launch = float(row1 - row0) * F * E * esize    # slab read once per batch
+        scr = ix.screen_stats()
+        screened = args.dtype == "f32" and scr["built"]          # stage 1 ran on the fp16 screen slab of the fp32 index
+        esize = 2 if (args.dtype == "bf16" or screened) else 4
+        bytes_per_launch = float(row1 - row0) * F * E * esize    # the scanned slab is read once per batch
+        s1_kernel = "mfar_stage1_bf16_kernel" if args.dtype == "bf16" else ("mfar_stage1_f16_kernel" if screened else "mfar_stage1_kernel")
         achieved_tf = flops_per_launch / (s1_avg_ms * 1e-3) / 1e12 if s1_avg_ms > 0 else 0.0
         traffic = None          # HBM bytes per stage-1 launch from the committed PMC pass of this same workload
-        tj = os.path.join(ROOT, "profiles", "r01_stage1_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r01_stage1_f16_traffic.json" if screened else "r01_stage1_traffic.json")
         if N == 1 and args.dtype == "f32" and (D, F, E, Q) == (1_000_000, 8, 768, 64) and os.path.exists(tj):
             t_ = json.load(open(tj))
-            traffic = t_["hbm_read_bytes_per_launch"] + t_["hbm_write_bytes_per_launch"]
+            if t_.get("kernel") == s1_kernel:
+                traffic = t_["hbm_read_bytes_per_launch"] + t_["hbm_write_bytes_per_launch"]
         line = {
             "metric": "queries/sec (whole node) at Recall@20 parity, 1M-doc x 8-field x 768d corpus",
             "value": qps, "unit": "queries/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
@@ -167,14 +177,19 @@ def main():
                        "docs": D, "fields": F, "dim": E, "query_batch": Q, "k1": K1, "k2": K2,
                        "parallelism": f"row-shard x{N} + RCCL all-gather merge" if N > 1 else "single shard",
                        "pipeline": "2 batches in flight (stage 1 of batch i+1 overlaps the tail of batch i)"},
+            "stage1": ("certified fp16 screen of the fp32 slab (k+64 rows per list re-scored with the exact fp32 chain, top-k proven "
+                       "or redone by the exact fp32 pass per field): outputs bit-identical to the plain fp32 pass" if screened else
+                       ("exact fp32 MFMA pass" if args.dtype == "f32" else "bf16 slab pass")),
+            "screen": ({"lists_certified": scr["n_checked"] - scr["n_failed"], "lists_redone_exactly": scr["n_failed"],
+                        "screen_slab_bytes": scr["screen_bytes"]} if screened else None),
             "recall_at_20": recall20, "ids_checksum": checksum,
             "index_build_s": t_build,
-            "roofline": ({"bound": "mfma", "kernel": "mfar_stage1_kernel", "achieved": achieved_tf,
+            "roofline": ({"bound": "mfma", "kernel": s1_kernel, "achieved": achieved_tf,
                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS}
-                         if args.dtype == "f32" else
-                         {"bound": "hbm", "kernel": "mfar_stage1_bf16_kernel", "achieved": bytes_per_launch / (s1_avg_ms * 1e-3) / 1e9,
+                         if esize == 4 else
+                         {"bound": "hbm", "kernel": s1_kernel, "achieved": bytes_per_launch / (s1_avg_ms * 1e-3) / 1e9,
                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_per_launch / (s1_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}) | {
-                         "traffic": traffic, "traffic_source": "profiles/r01_stage1_traffic.json (rocprofv3 PMC pass)" if traffic else None, "avg_launch_ms": s1_avg_ms, "launches": s1_n,
+                         "traffic": traffic, "traffic_source": os.path.relpath(tj, ROOT) + " (rocprofv3 PMC pass)" if traffic else None, "avg_launch_ms": s1_avg_ms, "launches": s1_n,
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "hbm_GBps_algorithmic": bytes_per_launch / (s1_avg_ms * 1e-3) / 1e9 if s1_avg_ms > 0 else 0.0,

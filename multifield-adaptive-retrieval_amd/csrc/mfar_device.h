@@ -49,6 +49,18 @@ __device__ __forceinline__ int lds_add_rtn(int* lds_ptr, int v) {
     return old;
 }
 
+// Wave-aggregated slot reservation in an LDS counter: every lane of the wave must call it (convergent); lanes with
+// `pred` get distinct consecutive slots, one LDS atomic per wave.
+__device__ __forceinline__ int wave_reserve(int* counter, bool pred) {
+    const u64 m = __ballot(pred);
+    if (!m) return 0;
+    const int leader = __builtin_ctzll(m);
+    int base = 0;
+    if (lane_id() == leader) base = lds_add_rtn(counter, __popcll(m));
+    base = __shfl(base, leader);
+    return base + mbcnt(m);
+}
+
 // Deterministic exp(x) for x <= 0 (same operation sequence as mfar_oracle_exp in the oracle).
 __device__ __forceinline__ float mfar_exp(float x) {
     if (!(x > -80.0f)) return 0.0f;

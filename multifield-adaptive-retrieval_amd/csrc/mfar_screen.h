@@ -92,8 +92,8 @@ __global__ void mfar_screen_scale_kernel(const u32* __restrict__ stats, int F, S
     ScreenField o;
     o.scale = screen_pow2_scale(amax);
     o.inv_scale = 1.0f / o.scale;
-    // sqrt rounded up a little: the bound must not shrink
-    o.dnorm_max = sqrtf(n2) * 1.000001f;
+    // the fp32 sum of squares can be low by K u32 relative: lean up, the bound must not shrink
+    o.dnorm_max = sqrtf(n2) * 1.0001f;
     o.pad = 0.0f;
     sf[f] = o;
 }
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
     amax = fmaxf(fmaxf(red_a[0], red_a[1]), fmaxf(red_a[2], red_a[3]));
     ss = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
     const float sq = screen_pow2_scale(amax);
-    const float qn = sqrtf(ss) * 1.00001f;   // the block sum is not correctly rounded: lean up
+    const float qn = sqrtf(ss) * 1.0001f;   // the fp32 sum of squares can be low by K u32 relative: lean up
     // split tiles
     const int gpr = E >> 3;
     for (int g = threadIdx.x; g < gpr; g += blockDim.x) {

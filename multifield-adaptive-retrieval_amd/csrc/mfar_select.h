@@ -141,19 +141,39 @@ __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams
     const SelLds L = sel_lds(smem, p.n_chunks * p.k);
     const int ql = blockIdx.x / p.F, f = blockIdx.x - ql * p.F;
     if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
+    // chunk counts first (LDS), then the entries eight chunks at a time: the global loads of a round are independent,
+    // so their latencies overlap instead of adding up
+    int* cnts = (int*)L.sel;   // the selection scratch is free until block_topk_sorted runs
+    for (int c = threadIdx.x; c < p.n_chunks; c += blockDim.x) cnts[c] = min(p.list_cnt[(size_t)(f * p.n_chunks + c) * 64 + ql], p.k);
     if (threadIdx.x == 0) L.misc[0] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < p.n_chunks * p.k; i += blockDim.x) {
-        const int c = i / p.k, r = i - c * p.k;
-        const size_t li = ((size_t)(f * p.n_chunks + c) * 64 + ql);
-        if (r < min(p.list_cnt[li], p.k)) {
-            const uint2 e = p.lists[li * S1_CAP + r];
-            L.keys[atomicAdd(&L.misc[0], 1)] = make_key(__uint_as_float(e.x), e.y);
+    for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
+        for (int c0 = 0; c0 < p.n_chunks; c0 += 8) {
+            uint2 e[8];
+            bool ok[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u;
+                ok[u] = c < p.n_chunks && r < cnts[c < p.n_chunks ? c : 0];
+                e[u] = make_uint2(0u, 0u);
+                if (ok[u]) e[u] = p.lists[((size_t)(f * p.n_chunks + c) * 64 + ql) * S1_CAP + r];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int pos = wave_reserve(&L.misc[0], ok[u]);
+                if (ok[u]) L.keys[pos] = make_key(__uint_as_float(e[u].x), e[u].y);
+            }
         }
     }
     __syncthreads();
     const int n = L.misc[0];
-    const int m = block_topk_sorted<NPT>(L.keys, n, p.k, L.sel, L.sorted, L.red);
+    // the lists are usually far from full (the sample pass's threshold keeps most chunks short): pick the register
+    // budget of the selection by the ACTUAL key count (workgroup-uniform)
+    int m;
+    if (NPT > 8 && n <= 8 * 256) m = block_topk_sorted<8>(L.keys, n, p.k, L.sel, L.sorted, L.red);
+    else if (NPT > 16 && n <= 16 * 256) m = block_topk_sorted<16>(L.keys, n, p.k, L.sel, L.sorted, L.red);
+    else if (NPT > 32 && n <= 32 * 256) m = block_topk_sorted<32>(L.keys, n, p.k, L.sel, L.sorted, L.red);
+    else m = block_topk_sorted<NPT>(L.keys, n, p.k, L.sel, L.sorted, L.red);
     if (p.tau_out && threadIdx.x == 0) p.tau_out[f * 64 + ql] = m == p.k ? key_score(L.sorted[p.k - 1]) : -__builtin_inff();
     if (p.cnt_out && threadIdx.x == 0) p.cnt_out[ql * p.F + f] = m;
     if (!p.out_ids) return;

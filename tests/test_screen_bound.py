@@ -1,0 +1,51 @@
+"""The error bound behind the fp16 screen's certificate (csrc/mfar_screen.h), checked on the CPU against a numpy emulation
+of the screen arithmetic: power-of-two scaling, fp16 rounding of the rows, two-term fp16 split of the query, products
+summed without further error (float64) -- i.e. every error source except the MFMA's own fp32 accumulation, which the bound
+budgets separately with (4K + 64) u32.  The exact side is the oracle's fma chain (the arithmetic contract)."""
+import numpy as np
+import pytest
+
+from oracle import mfar_oracle as O
+
+U16, U32, SLACK = 2.0 ** -11, 2.0 ** -24, 1.25
+
+
+def _pow2_scale(amax):
+    if amax == 0 or not np.isfinite(amax):
+        return 1.0
+    e = 13 - int(np.floor(np.log2(amax)))
+    return float(2.0 ** max(-100, min(100, e)))
+
+
+def _eps(qn, dn, sq, sf, K):
+    c_rel = 1.02 * U16 + (5.0 * K + 64.0) * U32
+    c_abs = U32 * np.sqrt(K) * 1.0001
+    return SLACK * (c_rel * qn * dn + c_abs * (qn / sf + dn / sq))
+
+
+@pytest.mark.parametrize("E,scale,seed", [(32, 1.0, 0), (768, 1.0, 1), (768, 1e-3, 2), (256, 3e4, 3), (96, 1e-20, 4)])
+def test_screen_error_bound_holds(E, scale, seed):
+    rng = np.random.default_rng(seed)
+    D, Q = 4000, 16
+    docs = (rng.standard_normal((D, E)) * rng.lognormal(0, 1.5, (D, 1)) * scale).astype(np.float32)
+    docs[::97] *= np.float32(1e-4)                      # rows deep in the fp16 subnormal range after scaling
+    docs[5] = 0
+    q = (rng.standard_normal((Q, E)) * rng.lognormal(0, 1, (Q, 1))).astype(np.float32)
+    q[3, ::2] *= np.float32(1e-6)
+    exact = O.c_scores(docs, q)
+    sf = _pow2_scale(float(np.abs(docs).max()))
+    dn = float(np.sqrt((docs.astype(np.float64) ** 2).sum(1).max()))
+    d16 = (docs * np.float32(sf)).astype(np.float16).astype(np.float64)
+    worst = 0.0
+    for i in range(Q):
+        sq = _pow2_scale(float(np.abs(q[i]).max()))
+        qs = q[i] * np.float32(sq)
+        a = qs.astype(np.float16)
+        b = (qs - a.astype(np.float32)).astype(np.float16)
+        approx = (d16 @ (a.astype(np.float64) + b.astype(np.float64))) / (sq * sf)
+        qn = float(np.sqrt((q[i].astype(np.float64) ** 2).sum()))
+        eps = _eps(qn, dn, sq, sf, E)
+        err = np.abs(approx - exact[i].astype(np.float64)).max()
+        assert err <= eps, (i, err, eps)
+        worst = max(worst, err / eps)
+    assert worst < 0.5            # the rigorous bound is comfortably loose on real numbers

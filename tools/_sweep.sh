@@ -1,7 +1,5 @@
-L=multifield-adaptive-retrieval_amd/lib
-cp $L/var_st6/libmfar_hip.so $L/libmfar_hip.so
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -2
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d /tmp/kt -o r1 --output-format csv -- python $GRAFT_REPO_ROOT/tools/s1_bench.py > /tmp/s1.log 2>&1
 tail -1 /tmp/s1.log
-python $GRAFT_REPO_ROOT/tools/prof_summary.py /tmp/kt | grep -v "^==" | head -70
-python $GRAFT_REPO_ROOT/tools/trace_timeline.py /tmp/kt 2>/dev/null | tail -40
+python $GRAFT_REPO_ROOT/tools/prof_summary.py /tmp/kt | grep -E "avg_us" | grep -E "merge|stage1|score|certify|sample|queries"

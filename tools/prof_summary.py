@@ -36,19 +36,20 @@ for d in [a for a in sys.argv[1:] if not a.startswith('--') and os.path.isdir(a)
             print(f"{k:60s} n={len(v):4d} avg_us={sum(v)/len(v)/1e3:10.1f} min_us={min(v)/1e3:10.1f} max_us={max(v)/1e3:10.1f} vgpr/agpr/sgpr/lds/grid/wg={meta[k]}")
 
 
-# optional: --traffic-json <out.json> <fetch_dir> <write_dir>  -> per-launch HBM bytes of mfar_stage1_kernel
+# optional: --traffic-json <out.json> <fetch_dir> <write_dir> [kernel name prefix]  -> per-launch HBM bytes of that kernel
 if "--traffic-json" in sys.argv:
     import json
     i = sys.argv.index("--traffic-json")
     out, fdir, wdir = sys.argv[i + 1], sys.argv[i + 2], sys.argv[i + 3]
+    kern = sys.argv[i + 4] if len(sys.argv) > i + 4 else "mfar_stage1_kernel"
     def avg(d, counter):
         fn = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))[0]
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(fn))
-                if r["Kernel_Name"].startswith("mfar_stage1_kernel") and r["Counter_Name"] == counter]
+                if r["Kernel_Name"].startswith(kern) and r["Counter_Name"] == counter]
         return sum(vals) / len(vals), len(vals)
     f, nf = avg(fdir, "FETCH_SIZE")
     w, nw = avg(wdir, "WRITE_SIZE")
-    json.dump({"kernel": "mfar_stage1_kernel", "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "launches": [nf, nw],
+    json.dump({"kernel": kern, "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "launches": [nf, nw],
                "hbm_read_bytes_per_launch": 2.0 * f * 1024, "hbm_write_bytes_per_launch": w * 1024,
                "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; on gfx950 FETCH_SIZE reports half "
                        "the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM section): read bytes = 2 x FETCH_SIZE x 1024"},
