@@ -137,17 +137,11 @@ __device__ __forceinline__ int block_sum(int c, int* red, int parity) {
     return tot;
 }
 
+// Core: every thread holds NPT keys in registers (hi = orderable score, lo = inverted id; hi == lo == 0 marks an empty slot,
+// which no real key can be), n = number of non-empty slots in the workgroup.
 template <int NPT>
-__device__ __forceinline__ int block_topk_sorted(const u64* keys, int n, int k, u64* sel, u64* sel_sorted, int* red) {
-    __syncthreads();
-    u32 hi[NPT], lo[NPT];
-#pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-        const int idx = threadIdx.x + i * 256;
-        const u64 key = idx < n ? keys[idx] : 0ull;
-        hi[i] = (u32)(key >> 32);
-        lo[i] = (u32)key;
-    }
+__device__ __forceinline__ int block_topk_regs(const u32 (&hi)[NPT], const u32 (&lo)[NPT], int n, int k, u64* sel, u64* sel_sorted,
+                                               int* red) {
     int m = n;
     u32 T = 0, TL = 0;
     if (n > k) {
@@ -166,7 +160,7 @@ __device__ __forceinline__ int block_topk_sorted(const u64* keys, int n, int k, 
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             cg += hi[i] > T ? 1 : 0;
-            ce += hi[i] == T ? 1 : 0;
+            ce += (hi[i] == T && (hi[i] | lo[i]) != 0u) ? 1 : 0;
         }
         const int tg = block_sum<NPT>(cg, red, parity);
         parity ^= 1;
@@ -189,12 +183,9 @@ __device__ __forceinline__ int block_topk_sorted(const u64* keys, int n, int k, 
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-        const int idx = threadIdx.x + i * 256;
-        const bool keep = idx < n && (hi[i] > T || (hi[i] == T && lo[i] >= TL));
-        if (keep) {
-            const int pos = lds_add_rtn(&red[16], 1);
-            if (pos < k) sel[pos] = ((u64)hi[i] << 32) | lo[i];
-        }
+        const bool keep = (hi[i] | lo[i]) != 0u && (hi[i] > T || (hi[i] == T && lo[i] >= TL));
+        const int pos = wave_reserve(&red[16], keep);
+        if (keep && pos < k) sel[pos] = ((u64)hi[i] << 32) | lo[i];
     }
     __syncthreads();
     // rank by counting (keys are unique)
@@ -206,4 +197,18 @@ __device__ __forceinline__ int block_topk_sorted(const u64* keys, int n, int k, 
     }
     __syncthreads();
     return m;
+}
+
+template <int NPT>
+__device__ __forceinline__ int block_topk_sorted(const u64* keys, int n, int k, u64* sel, u64* sel_sorted, int* red) {
+    __syncthreads();
+    u32 hi[NPT], lo[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const u64 key = idx < n ? keys[idx] : 0ull;
+        hi[i] = (u32)(key >> 32);
+        lo[i] = (u32)key;
+    }
+    return block_topk_regs<NPT>(hi, lo, n, k, sel, sel_sorted, red);
 }

@@ -449,6 +449,15 @@ static int stage1_pass(mfar_index* idx, int kind, const void* slab, const void* 
     const int n_keys = n_chunks * k;
     auto launch_merge = [&](const MergeParams& mp) -> int {
         const dim3 grid(qt_n * idx->F), block(256);
+        if (k <= SEL_MAX_K && n_chunks <= 128 && n_keys <= 64 * 256) {   // keys stay in registers: no LDS staging
+            if (n_keys <= 8 * 256) mfar_merge_lists_regs_kernel<8><<<grid, block, 0, st>>>(mp);
+            else if (n_keys <= 16 * 256) mfar_merge_lists_regs_kernel<16><<<grid, block, 0, st>>>(mp);
+            else if (n_keys <= 32 * 256) mfar_merge_lists_regs_kernel<32><<<grid, block, 0, st>>>(mp);
+            else if (n_keys <= 48 * 256) mfar_merge_lists_regs_kernel<48><<<grid, block, 0, st>>>(mp);
+            else mfar_merge_lists_regs_kernel<64><<<grid, block, 0, st>>>(mp);
+            HIPCHK(hipGetLastError());
+            return MFAR_OK;
+        }
         const size_t lds = SEL_LDS_BYTES(n_keys);
         if (n_keys <= 8 * 256) mfar_merge_lists_kernel<8><<<grid, block, lds, st>>>(mp);
         else if (n_keys <= 32 * 256) mfar_merge_lists_kernel<32><<<grid, block, lds, st>>>(mp);
@@ -479,13 +488,9 @@ static int stage1_pass(mfar_index* idx, int kind, const void* slab, const void* 
         RETCHK(idx->samp.ensure((size_t)idx->F * n_wave_blocks * 128 * sizeof(float)));
         ps.samp_out = idx->samp.as<float>();
         RETCHK(launch_s1(kind, true, grid, st, ps));
-        mfar_sample_tau_kernel<<<dim3(64 * idx->F), dim3(256), SEL_LDS_BYTES(2 * n_wave_blocks), st>>>(
-            ps.samp_out, n_wave_blocks, idx->F, k, p.tau0, idx->gtau.as<float>());
+        mfar_sample_tau_kernel<<<dim3(64 * idx->F), dim3(256), 0, st>>>(ps.samp_out, n_wave_blocks, idx->F, k, p.tau0, tau_base,
+                                                                      idx->gtau.as<float>());
         HIPCHK(hipGetLastError());
-        if (tau_base) {
-            mfar_screen_tau_max_kernel<<<dim3((64 * idx->F + 255) / 256), dim3(256), 0, st>>>(idx->gtau.as<float>(), tau_base, 64 * idx->F);
-            HIPCHK(hipGetLastError());
-        }
         p.gtau = idx->gtau.as<float>();
     } else if (use_sample && !tau_base) {
         S1Params ps = p;

@@ -199,12 +199,6 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
     }
 }
 
-// raise the light sample pass's thresholds to at least the base thresholds: tau = max(tau, base)
-__global__ void mfar_screen_tau_max_kernel(float* __restrict__ tau, const float* __restrict__ base, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) tau[i] = fmaxf(tau[i], base[i]);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Certify: exact top-k of the k' re-scored rows of one (query, field) + the certificate.  grid = Qt * F, block 256.
 // ---------------------------------------------------------------------------------------------------------

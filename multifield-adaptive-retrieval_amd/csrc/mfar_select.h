@@ -189,24 +189,89 @@ __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams
     }
 }
 
-// tau[f][q] = k-th largest of the n_vals scores published by the light sample pass for (q, f), or -inf when fewer than k
-// of them beat the starting threshold tau0 (then there is no bound).  grid = 64 * F, block 256, n_vals <= 2048.
-__global__ void __launch_bounds__(256) mfar_sample_tau_kernel(const float* __restrict__ samp, int n_wave_blocks, int F, int k,
-                                                              float tau0, float* __restrict__ tau_out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int n_vals = n_wave_blocks * 2;
-    const SelLds L = sel_lds(smem, n_vals);
-    const int q = blockIdx.x / F, f = blockIdx.x - q * F;
-    if (threadIdx.x == 0) L.misc[0] = 0;
+// Register-resident variant for n_chunks * k <= 256 * NPT and n_chunks <= 128: slot s = c * k + r of the concatenated lists
+// goes to thread s % 256, register s / 256, so the keys never pass through LDS (5 KB of static LDS instead of
+// n_chunks * k * 8 bytes) and all loads of a thread are independent.  Same results as mfar_merge_lists_kernel.
+template <int NPT>
+__global__ void __launch_bounds__(256) mfar_merge_lists_regs_kernel(const MergeParams p) {
+    __shared__ u64 sel[SEL_MAX_K], sorted[SEL_MAX_K];
+    __shared__ int red[36], cnts[128];
+    const int ql = blockIdx.x / p.F, f = blockIdx.x - ql * p.F;
+    if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
+    if (threadIdx.x < 128)
+        cnts[threadIdx.x] = (int)threadIdx.x < p.n_chunks ? min(p.list_cnt[(size_t)(f * p.n_chunks + threadIdx.x) * 64 + ql], p.k) : 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n_vals; i += blockDim.x) {
-        const float v = samp[((size_t)f * n_wave_blocks + (i >> 1)) * 128 + q * 2 + (i & 1)];
-        if (v > tau0) L.keys[lds_add_rtn(&L.misc[0], 1)] = make_key(v, (u32)i);
+    const int total = p.n_chunks * p.k;
+    // unconditional loads (clamped slot: always inside the list buffer), so that all NPT of them are in flight together;
+    // validity is applied afterwards
+    uint2 e[NPT];
+    int cc[NPT], rr[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int s_ = (int)threadIdx.x + 256 * i;
+        const int sl = s_ < total ? s_ : 0;
+        cc[i] = sl / p.k;
+        rr[i] = s_ < total ? sl - cc[i] * p.k : 0x7FFFFFFF;
+        e[i] = p.lists[((size_t)(f * p.n_chunks + cc[i]) * 64 + ql) * S1_CAP + (sl - cc[i] * p.k)];
     }
+    u32 hi[NPT], lo[NPT];
+    int mine = 0;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const bool ok = rr[i] < cnts[cc[i]];
+        hi[i] = ok ? f2ord(__uint_as_float(e[i].x)) : 0u;
+        lo[i] = ok ? 0xFFFFFFFFu - e[i].y : 0u;
+        asm volatile("" : "+v"(hi[i]), "+v"(lo[i]));   // keep the keys materialised: the selection re-reads them 34 times
+        mine += ok ? 1 : 0;
+    }
+    const int n = block_sum<NPT>(mine, red, 0);
+    __syncthreads();   // red[] is reused by the selection
+    const int m = block_topk_regs<NPT>(hi, lo, n, p.k, sel, sorted, red);
+    if (p.tau_out && threadIdx.x == 0) p.tau_out[f * 64 + ql] = m == p.k ? key_score(sorted[p.k - 1]) : -__builtin_inff();
+    if (p.cnt_out && threadIdx.x == 0) p.cnt_out[ql * p.F + f] = m;
+    if (!p.out_ids) return;
+    const size_t ob = ((size_t)(p.q0 + ql) * p.F + f) * p.k;
+    for (int i = threadIdx.x; i < p.k; i += blockDim.x) {
+        if (i < m) {
+            p.out_ids[ob + i] = p.row_offset + (long long)key_id(sorted[i]);
+            p.out_scores[ob + i] = key_score(sorted[i]);
+        } else {
+            p.out_ids[ob + i] = p.sentinel ? 0 : -1;
+            p.out_scores[ob + i] = p.sentinel ? 0.0f : -__builtin_inff();
+        }
+    }
+}
+
+// tau[f][q] = max(base[f][q], k-th largest of the n_vals scores published by the light sample pass for (q, f)); the k-th
+// largest counts only scores above tau0 and is -inf when there are fewer than k of them (then the sample gives no bound).
+// grid = 64 * F, block 256, n_vals <= 2048: every thread holds 8 values in registers.
+__global__ void __launch_bounds__(256) mfar_sample_tau_kernel(const float* __restrict__ samp, int n_wave_blocks, int F, int k,
+                                                              float tau0, const float* __restrict__ base,
+                                                              float* __restrict__ tau_out) {
+    __shared__ u64 sel[SEL_MAX_K], sorted[SEL_MAX_K];
+    __shared__ int red[36];
+    const int n_vals = n_wave_blocks * 2;
+    const int q = blockIdx.x / F, f = blockIdx.x - q * F;
+    u32 hi[8], lo[8];
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = threadIdx.x + j * 256;
+        const int ii = i < n_vals ? i : 0;
+        const float v = samp[((size_t)f * n_wave_blocks + (ii >> 1)) * 128 + q * 2 + (ii & 1)];
+        const bool ok = i < n_vals && v > tau0;
+        hi[j] = ok ? f2ord(v) : 0u;
+        lo[j] = ok ? 0xFFFFFFFFu - (u32)i : 0u;
+        mine += ok ? 1 : 0;
+    }
+    const int n = block_sum<8>(mine, red, 0);
     __syncthreads();
-    const int n = L.misc[0];
-    const int m = block_topk_sorted<8>(L.keys, n, k, L.sel, L.sorted, L.red);
-    if (threadIdx.x == 0) tau_out[f * 64 + q] = m == k ? key_score(L.sorted[k - 1]) : -__builtin_inff();
+    const int m = block_topk_regs<8>(hi, lo, n, k, sel, sorted, red);
+    if (threadIdx.x == 0) {
+        float t = m == k ? key_score(sorted[k - 1]) : -__builtin_inff();
+        if (base) t = fmaxf(t, base[f * 64 + q]);
+        tau_out[f * 64 + q] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
