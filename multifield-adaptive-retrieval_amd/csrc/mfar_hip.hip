@@ -449,12 +449,11 @@ static int stage1_pass(mfar_index* idx, int kind, const void* slab, const void* 
     const int n_keys = n_chunks * k;
     auto launch_merge = [&](const MergeParams& mp) -> int {
         const dim3 grid(qt_n * idx->F), block(256);
-        if (k <= SEL_MAX_K && n_chunks <= 128 && n_keys <= 64 * 256) {   // keys stay in registers: no LDS staging
+        if (k <= SEL_MAX_K && n_chunks <= 128 && n_keys <= 48 * 256) {   // keys stay in registers: no LDS staging
             if (n_keys <= 8 * 256) mfar_merge_lists_regs_kernel<8><<<grid, block, 0, st>>>(mp);
             else if (n_keys <= 16 * 256) mfar_merge_lists_regs_kernel<16><<<grid, block, 0, st>>>(mp);
             else if (n_keys <= 32 * 256) mfar_merge_lists_regs_kernel<32><<<grid, block, 0, st>>>(mp);
-            else if (n_keys <= 48 * 256) mfar_merge_lists_regs_kernel<48><<<grid, block, 0, st>>>(mp);
-            else mfar_merge_lists_regs_kernel<64><<<grid, block, 0, st>>>(mp);
+            else mfar_merge_lists_regs_kernel<48><<<grid, block, 0, st>>>(mp);
             HIPCHK(hipGetLastError());
             return MFAR_OK;
         }

@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams
 // goes to thread s % 256, register s / 256, so the keys never pass through LDS (5 KB of static LDS instead of
 // n_chunks * k * 8 bytes) and all loads of a thread are independent.  Same results as mfar_merge_lists_kernel.
 template <int NPT>
-__global__ void __launch_bounds__(256) mfar_merge_lists_regs_kernel(const MergeParams p) {
+__global__ void __launch_bounds__(256, 2) mfar_merge_lists_regs_kernel(const MergeParams p) {
     __shared__ u64 sel[SEL_MAX_K], sorted[SEL_MAX_K];
     __shared__ int red[36], cnts[128];
     const int ql = blockIdx.x / p.F, f = blockIdx.x - ql * p.F;
