@@ -49,6 +49,18 @@ __device__ __forceinline__ int lds_add_rtn(int* lds_ptr, int v) {
     return old;
 }
 
+// Global stores the compiler does not track.  gfx9-family vmcnt counts loads AND stores, which may retire out of order
+// with respect to each other, so hipcc answers any pending store with a full vmcnt(0) drain in front of the next use of a
+// loaded register.  The stage-1 loops keep several k-steps of loads in flight across the selection epilogue; their few
+// stores go through these helpers.  Safe: an untracked store only adds to what a counted wait has to drain (a wait for
+// "at most N younger loads outstanding" still implies that every older load has landed, loads retire in order).
+__device__ __forceinline__ void store_untracked_b64(void* ptr, u64 v) {
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(ptr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_untracked_b32(void* ptr, u32 v) {
+    asm volatile("global_store_dword %0, %1, off" ::"v"(ptr), "v"(v) : "memory");
+}
+
 // Wave-aggregated slot reservation in an LDS counter: every lane of the wave must call it (convergent); lanes with
 // `pred` get distinct consecutive slots, one LDS atomic per wave.
 __device__ __forceinline__ int wave_reserve(int* counter, bool pred) {

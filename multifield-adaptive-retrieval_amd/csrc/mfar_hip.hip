@@ -392,12 +392,21 @@ static int launch_s1(int kind, bool sample, unsigned grid, hipStream_t st, const
     if (kind == S1_F32) {
         if (sample) mfar_stage1_sample_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
         else mfar_stage1_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
-    } else if (kind == S1_BF16) {
-        if (sample) mfar_stage1_bf16_sample_kernel<<<g, b, S1B_LDS_BYTES, st>>>(p);
-        else mfar_stage1_bf16_kernel<<<g, b, S1B_LDS_BYTES, st>>>(p);
     } else {
-        if (sample) mfar_stage1_f16_sample_kernel<<<g, b, S1H_LDS_BYTES, st>>>(p);
-        else mfar_stage1_f16_kernel<<<g, b, S1H_LDS_BYTES, st>>>(p);
+        // register-ring variants (docs straight into VGPRs, 25 / 37 KB of LDS) when the k-steps divide into the 6 register slots
+        static const bool regring = !(getenv("MFAR_S1_REGRING") && atoi(getenv("MFAR_S1_REGRING")) == 0);
+        const bool rr = regring && p.n_steps % 6 == 0;
+        if (kind == S1_BF16) {
+            if (rr && sample) mfar_stage1_bf16r_sample_kernel<<<g, b, S1BR_LDS_BYTES, st>>>(p);
+            else if (rr) mfar_stage1_bf16r_kernel<<<g, b, S1BR_LDS_BYTES, st>>>(p);
+            else if (sample) mfar_stage1_bf16_sample_kernel<<<g, b, S1B_LDS_BYTES, st>>>(p);
+            else mfar_stage1_bf16_kernel<<<g, b, S1B_LDS_BYTES, st>>>(p);
+        } else {
+            if (rr && sample) mfar_stage1_f16r_sample_kernel<<<g, b, S1HR_LDS_BYTES, st>>>(p);
+            else if (rr) mfar_stage1_f16r_kernel<<<g, b, S1HR_LDS_BYTES, st>>>(p);
+            else if (sample) mfar_stage1_f16_sample_kernel<<<g, b, S1H_LDS_BYTES, st>>>(p);
+            else mfar_stage1_f16_kernel<<<g, b, S1H_LDS_BYTES, st>>>(p);
+        }
     }
     HIPCHK(hipGetLastError());
     return MFAR_OK;

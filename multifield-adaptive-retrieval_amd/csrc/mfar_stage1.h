@@ -109,7 +109,7 @@ __device__ __forceinline__ float s1_compact(uint2* list, int n, int k) {
         const u64 m = __ballot(keep);
         if (keep) {
             const int pos = base + mbcnt(m);
-            if (pos < S1_CAP) list[pos] = make_uint2(__float_as_uint(ord2f(hi[j])), 0xFFFFFFFFu - lo[j]);
+            if (pos < S1_CAP) store_untracked_b64(&list[pos], ((u64)(0xFFFFFFFFu - lo[j]) << 32) | __float_as_uint(ord2f(hi[j])));
         }
         base += __popcll(m);
     }
@@ -192,7 +192,7 @@ __device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                         \
         const float v = ACC[r];                                                                              \
         if (S1_PASS1(v, TH)) {                                                                               \
-            if (B < S1_CAP) L[B] = make_uint2(__float_as_uint(v), (u32)(row_w + 32 * DB + (r & 3) + 8 * (r >> 2))); \
+            if (B < S1_CAP) store_untracked_b64(&L[B], ((u64)(u32)(row_w + 32 * DB + (r & 3) + 8 * (r >> 2)) << 32) | __float_as_uint(v)); \
             ++B;                                                                                             \
         }                                                                                                    \
     }
@@ -262,10 +262,8 @@ __device__ __forceinline__ void s1_sample_top2(const S1Params& p, int f, int chu
     const float rb1 = fmaxf(b1, ob1), rb2 = fmaxf(fminf(b1, ob1), fmaxf(b2, ob2));
     if (h == 0) {
         float* o = p.samp_out + (((size_t)(f * p.n_chunks + chunk) * p.sample_tiles + tl) * 4 + w) * 128;
-        o[j * 2] = ra1;
-        o[j * 2 + 1] = ra2;
-        o[(32 + j) * 2] = rb1;
-        o[(32 + j) * 2 + 1] = rb2;
+        store_untracked_b64(&o[j * 2], ((u64)__float_as_uint(ra2) << 32) | __float_as_uint(ra1));
+        store_untracked_b64(&o[(32 + j) * 2], ((u64)__float_as_uint(rb2) << 32) | __float_as_uint(rb1));
     }
 }
 
@@ -548,6 +546,147 @@ __device__ __forceinline__ void s1_body_x16(const S1Params& p) {
     if (p.sample != 2) s1_flush(p, st, w, wgq0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Register-ring variant of the 16-bit pass ("x16r").  A doc row is consumed by exactly one lane pair, and the MFMA A operand
+// lives in VGPRs anyway, so the doc tiles do not need LDS at all: every lane loads ITS 16-byte granule of the 2 KB tile
+// straight into registers (the wave's 64 granules of a 32-row half tile are one contiguous KB: fully coalesced), R k-steps
+// ahead.  Only the query tile -- shared by the four waves -- still goes through an LDS ring.  LDS per workgroup drops from
+// 74.5 KB to R * 4 KB + state (25 KB for fp16, R = 6), which leaves > 100 KB per CU to the small kernels of the previous /
+// next batch that run beside this pass.  Needs n_steps % R == 0 (register slots are compile-time indices); the host
+// falls back to the LDS-ring kernel otherwise.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MODE, int R>
+struct S1XR {
+    static constexpr int TERMS = MODE ? 2 : 3;
+    static constexpr int Q_STAGE = TERMS * 2048;
+    static constexpr int Q_STEP_MEM = MODE ? 4096 : 8192;
+    static constexpr int LOADS = MODE ? 3 : 4;             // vm instructions per wave per stage: 2 doc loads + query pieces
+    static constexpr int LDS_BYTES = R * Q_STAGE + S1_STATE_BYTES;
+};
+
+template <int MODE, int R>
+__device__ __forceinline__ void s1_body_x16r(const S1Params& p) {
+    typedef S1XR<MODE, R> X;
+    typedef short vec8 __attribute__((ext_vector_type(8)));   // 16 bytes of bf16 / fp16 bits
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const qring = smem;
+    const S1State st = s1_state(smem + R * X::Q_STAGE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    const int f = blockIdx.x / p.n_chunks;
+    if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
+    const int chunk = blockIdx.x - f * p.n_chunks;
+    const int t0 = (int)(((long long)chunk * p.n_tiles) / p.n_chunks);
+    int t1 = (int)(((long long)(chunk + 1) * p.n_tiles) / p.n_chunks);
+    if (p.sample) t1 = min(t1, t0 + p.sample_tiles);
+    const size_t wgq0 = (size_t)blockIdx.x * 64;
+    s1_state_init(st, p, f);
+
+    // granule of row (32*blk + j), k-half h inside a 2 KB tile: the same offset in memory (docs) and in LDS (queries)
+    const int off = j * 32 + ((h ^ ((j >> 3) & 1)) << 4);
+    const size_t step_bytes = 2048;
+    const size_t tile_jump = (size_t)3 * p.n_steps * step_bytes;
+    const char* dnext = (const char*)p.slab + ((size_t)f * (size_t)p.field_stride) * 2 +
+                        ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes + off;
+    const int qp0 = MODE ? w : (w < 2 ? 2 * w : 2 + w), qp1 = w < 2 ? 2 * w + 1 : 2 + w;
+    const char* const qbase = (const char*)p.qt + lane * 16;
+    int s_next = 0;
+    // Every k-step issues exactly one stage, unconditionally: the R - 1 stages past the end of the chunk re-read the
+    // chunk's last stage (clamped address) and are never consumed.  A constant issue pattern keeps the compiler's own
+    // waitcnt insertion for the doc registers precise (with conditional issues it has to assume the worst path and
+    // drains the queue once per R steps).
+    const char* const dlast = (const char*)p.slab + ((size_t)f * (size_t)p.field_stride) * 2 +
+                              ((size_t)(4 * (t1 - 1) + w) * p.n_steps + (p.n_steps - 1)) * step_bytes + off;
+    vec8 dr0[R], dr1[R];
+    // the query-piece LDS-DMA goes through inline asm: hipcc treats a visible global_load_lds and plain global loads as
+    // two event kinds on one counter and answers the mix with vmcnt(0) in front of every use of a loaded register
+#define S1R_QDMA(S, D)                                                                                           \
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(S), "s"(__builtin_amdgcn_readfirstlane((int)(u32)(uintptr_t)(D))) : "memory", "m0")
+#define S1R_ISSUE(SLOT)                                                                                   \
+    do {                                                                                                  \
+        asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(dr0[SLOT]) : "v"(dnext) : "memory");    \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024 nt" : "=&v"(dr1[SLOT]) : "v"(dnext) : "memory"); \
+        const char* qs_ = qbase + (size_t)s_next * X::Q_STEP_MEM;                                         \
+        char* qd_ = qring + (SLOT) * X::Q_STAGE;                                                          \
+        S1R_QDMA(qs_ + qp0 * 1024, qd_ + qp0 * 1024);                                                     \
+        if (MODE == 0) S1R_QDMA(qs_ + qp1 * 1024, qd_ + qp1 * 1024);                                      \
+        const char* nx_ = dnext + step_bytes;                                                             \
+        if (++s_next == p.n_steps) {                                                                      \
+            s_next = 0;                                                                                   \
+            nx_ += tile_jump;                                                                             \
+        }                                                                                                 \
+        dnext = (unsigned long long)nx_ <= (unsigned long long)dlast ? nx_ : dlast;                       \
+    } while (0)
+    // prologue: R - 1 stages in flight (slots 0 .. R-2)
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) S1R_ISSUE(i);
+
+    for (int t = t0; t < t1; ++t) {
+        f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+        for (int s0 = 0; s0 < p.n_steps; s0 += R) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                // query tile of this stage landed (own piece: counted vmcnt -- R - 2 younger stages may stay in flight;
+                // other waves' pieces: the barrier); the stage's doc registers were loaded before that piece
+                // (the doc registers are in/out operands of the wait: nothing that reads them can be scheduled above it)
+                asm volatile("s_waitcnt vmcnt(%2)\n\ts_barrier" : "+v"(dr0[u]), "+v"(dr1[u]) : "n"((R - 2) * X::LOADS) : "memory");
+                const char* curq = qring + u * X::Q_STAGE;
+                const vec8 d0 = dr0[u], d1 = dr1[u];
+                if (MODE == 0) {
+                    const bf16x8 qh0 = *(const bf16x8*)(curq + off), qh1 = *(const bf16x8*)(curq + 1024 + off);
+                    const bf16x8 qm0 = *(const bf16x8*)(curq + 2048 + off), qm1 = *(const bf16x8*)(curq + 3072 + off);
+                    const bf16x8 ql0 = *(const bf16x8*)(curq + 4096 + off), ql1 = *(const bf16x8*)(curq + 5120 + off);
+                    // every wave is past the barrier: slot (u + R - 1) % R (the previous stage) is free
+                    S1R_ISSUE((u + R - 1) % R);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, ql0, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, ql1, acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, ql0, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, ql1, acc11, 0, 0, 0);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qm0, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qm1, acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qm0, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qm1, acc11, 0, 0, 0);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qh0, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qh1, acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qh0, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qh1, acc11, 0, 0, 0);
+                } else {
+                    const f16x8 qh0 = *(const f16x8*)(curq + off), qh1 = *(const f16x8*)(curq + 1024 + off);
+                    const f16x8 ql0 = *(const f16x8*)(curq + 2048 + off), ql1 = *(const f16x8*)(curq + 3072 + off);
+                    const f16x8 e0 = __builtin_bit_cast(f16x8, d0), e1 = __builtin_bit_cast(f16x8, d1);
+                    S1R_ISSUE((u + R - 1) % R);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, ql0, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, ql1, acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, ql0, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, ql1, acc11, 0, 0, 0);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qh0, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qh1, acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, qh0, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, qh1, acc11, 0, 0, 0);
+                }
+            }
+        }
+        if (p.dbg & 1) {
+            asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11));
+            continue;
+        }
+        if (p.sample == 2) {
+            s1_sample_top2(p, f, chunk, t - t0, t, w, acc00, acc01, acc10, acc11);
+            continue;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A (see the fp32 body)
+        s1_epilogue(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
+    }
+#undef S1R_ISSUE
+    // the stages issued past the end are still in flight: no LDS-DMA write may land after the workgroup has left
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.sample != 2) s1_flush(p, st, w, wgq0);
+}
+
 // The full pass and the threshold-estimation pass are the same code under two kernel names, so that profiles list them
 // separately (the sample pass scans 1 tile per workgroup and is ~30x shorter).
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_kernel(const S1Params p) { s1_body_f32(p); }
@@ -556,3 +695,9 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16_kernel(const S
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16_sample_kernel(const S1Params p) { s1_body_x16<0>(p); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16_kernel(const S1Params p) { s1_body_x16<1>(p); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16_sample_kernel(const S1Params p) { s1_body_x16<1>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r_kernel(const S1Params p) { s1_body_x16r<1, 6>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r_sample_kernel(const S1Params p) { s1_body_x16r<1, 6>(p); }
+#define S1HR_LDS_BYTES (6 * 4096 + S1_STATE_BYTES)
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r_kernel(const S1Params p) { s1_body_x16r<0, 6>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r_sample_kernel(const S1Params p) { s1_body_x16r<0, 6>(p); }
+#define S1BR_LDS_BYTES (6 * 6144 + S1_STATE_BYTES)

@@ -10,6 +10,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -o r1 --output-format csv -
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -o r1 --output-format csv -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT -d /tmp/ps -o r1 --output-format csv -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/kt /tmp/pf /tmp/pw /tmp/ps > $O/rocprofv3_summary.txt
-python $R/tools/prof_summary.py --traffic-json $O/stage1_f16_traffic.json /tmp/pf /tmp/pw mfar_stage1_f16_kernel
+python $R/tools/prof_summary.py --traffic-json $O/stage1_f16_traffic.json /tmp/pf /tmp/pw mfar_stage1_f16r_kernel
 python $R/tools/trace_timeline.py /tmp/kt > $O/timeline.txt 2>/dev/null
 tail -c 600 $O/bench.json
