@@ -168,6 +168,27 @@ int mfar_merge_topk(int device, const void* gathered_topk, int n_shards, int Q, 
  * long MFMA-bound kernel instead of delaying its start. */
 int mfar_stream_wait_stage1_start(mfar_index* idx, void* stream);
 
+/*
+ * Split-phase stage 1 for pipelined callers (device pointers, Q <= 64, asynchronous on `stream`).
+ *   mfar_stage1_begin   query preparation, sample pass, the long scan and the list merge of batch `slot` (two slots,
+ *                       0 / 1).  Without the fp16 screen this already leaves the final lists in field_ids / field_scores.
+ *   mfar_stage1_finish  with the screen: exact re-scoring of the k + 64 screened rows per list and the certificate ->
+ *                       field_ids / field_scores [Q, n_fields, k], exactly what mfar_retrieve_fields returns; without:
+ *                       nothing.  May run on another stream than begin (the caller orders finish after begin with an
+ *                       event) and beside the begin of the OTHER slot -- its kernels are small enough to be resident next
+ *                       to the scan.  A slot may be begun again once its finish has completed.
+ *   any_fail            NULL: a failed certificate is repaired inside finish (the exact fp32 pass is launched and idles
+ *                       when nothing failed).  Non-NULL (device int32): finish only reports -- *any_fail != 0 means the
+ *                       lists of this batch are NOT final and the caller must redo the batch with mfar_retrieve_fields
+ *                       after mfar_set_screen(idx, 0, ...).  This keeps the fp32 kernel, which cannot be co-resident
+ *                       with the other slot's scan, off the stream in the common case.
+ * Same arguments (q, Q, k, sentinel, outputs) must be passed to both calls of a batch.
+ */
+int mfar_stage1_begin(mfar_index* idx, const float* q, int Q, int k, int sentinel, int slot, int64_t* field_ids,
+                      float* field_scores, void* stream);
+int mfar_stage1_finish(mfar_index* idx, const float* q, int Q, int k, int sentinel, int slot, int64_t* field_ids,
+                       float* field_scores, int32_t* any_fail, void* stream);
+
 /* Instrumentation used by bench.py: when enabled, every stage-1 kernel launch on this handle is bracketed by HIP
  * events recorded on the stream it is launched on.  mfar_set_timing(idx, 1) enables and resets the counters;
  * mfar_stage1_timing() synchronises the recorded events and returns their summed duration and the launch count. */
@@ -191,6 +212,7 @@ int mfar_set_wgs_per_cu(mfar_index* idx, int wgs);
  * n_checked / n_failed = (query, field) lists certified / sent to the exact fall-back since the handle was created.
  */
 int mfar_set_screen(mfar_index* idx, int mode, float eps_mult);
+int mfar_get_screen(const mfar_index* idx, int* mode, float* eps_mult);
 int mfar_screen_stats(mfar_index* idx, int* built, int64_t* screen_bytes, int64_t* n_checked, int64_t* n_failed);
 
 #ifdef __cplusplus

@@ -141,11 +141,11 @@ __host__ __device__ __forceinline__ float bf2f(unsigned short b) {
 template <int NPT>
 __device__ __forceinline__ int block_sum(int c, int* red, int parity) {
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-    if (lane_id() == 0) red[parity * 8 + (threadIdx.x >> 6)] = c;
+    if (lane_id() == 0) red[parity * 12 + (threadIdx.x >> 6)] = c;   // up to 12 waves per workgroup
     __syncthreads();
     int tot = 0;
     const int nw = (blockDim.x + 63) >> 6;
-    for (int w = 0; w < nw; ++w) tot += red[parity * 8 + w];
+    for (int w = 0; w < nw; ++w) tot += red[parity * 12 + w];
     return tot;
 }
 
@@ -191,12 +191,12 @@ __device__ __forceinline__ int block_topk_regs(const u32 (&hi)[NPT], const u32 (
             }
         }
     }
-    if (threadIdx.x == 0) red[16] = 0;
+    if (threadIdx.x == 0) red[24] = 0;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
         const bool keep = (hi[i] | lo[i]) != 0u && (hi[i] > T || (hi[i] == T && lo[i] >= TL));
-        const int pos = wave_reserve(&red[16], keep);
+        const int pos = wave_reserve(&red[24], keep);
         if (keep && pos < k) sel[pos] = ((u64)hi[i] << 32) | lo[i];
     }
     __syncthreads();

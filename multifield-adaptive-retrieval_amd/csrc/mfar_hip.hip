@@ -80,7 +80,14 @@ struct mfar_index {
     long long field_stride = 0;   // elements between fields
     int n_cu = 256;
     int wgs_per_cu = 2;
-    DevBuf qt, lists, list_cnt, gtau, samp, fid, fsc, cand[2], ncand[2], x[2], own[2], in[8], out[8];
+    // stage-1 scratch, two slots: the pipelined caller finishes batch i (merge, re-score, certify) on one stream while
+    // batch i+1 scans on another (mfar_stage1_begin / mfar_stage1_finish)
+    struct S1Slot {
+        DevBuf qt, lists, list_cnt, gtau, samp;                          // any pass
+        DevBuf qt16, qinfo, eps, base, fail, sids, ssc, scnt, sx;        // fp16 screen
+        bool screened = false;                                          // decided by the begin phase of the batch
+    } s1[2];
+    DevBuf fid, fsc, cand[2], ncand[2], x[2], own[2], in[8], out[8];
     // certified fp16 screen of an fp32 index (mfar_screen.h)
     int screen_mode = 1;          // 0 off, 1 auto, 2 always (when the shapes allow)
     float screen_eps_mult = 1.0f; // test knob: scales the certificate's error bound
@@ -88,7 +95,7 @@ struct mfar_index {
     bool screen_dirty = true;     // rows were written since the screen was built
     bool screen_nomem = false;
     long long screen_checked = 0; // (query, field) lists certified so far    // the screen slab could not be allocated: stay on the exact pass
-    DevBuf s_stats, s_field, s_qinfo, s_eps, s_base, s_fail, s_qt, s_ids, s_sc, s_cnt, s_x;
+    DevBuf s_stats, s_field;
     hipEvent_t mid_ev = nullptr;  // recorded right before the full stage-1 kernel is launched
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -188,10 +195,14 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     (void)hipDeviceSynchronize();
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
-    DevBuf* bufs[] = {&idx->qt, &idx->lists, &idx->list_cnt, &idx->gtau, &idx->samp, &idx->fid, &idx->fsc, &idx->cand[0], &idx->cand[1],
-                      &idx->ncand[0], &idx->ncand[1], &idx->x[0], &idx->x[1], &idx->own[0], &idx->own[1], &idx->s_stats, &idx->s_field,
-                      &idx->s_qinfo, &idx->s_eps, &idx->s_base, &idx->s_fail, &idx->s_qt, &idx->s_ids, &idx->s_sc, &idx->s_cnt, &idx->s_x};
+    DevBuf* bufs[] = {&idx->fid, &idx->fsc, &idx->cand[0], &idx->cand[1], &idx->ncand[0], &idx->ncand[1], &idx->x[0], &idx->x[1],
+                      &idx->own[0], &idx->own[1], &idx->s_stats, &idx->s_field};
     for (DevBuf* b : bufs) b->release();
+    for (auto& sl : idx->s1) {
+        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
+                        &sl.ssc, &sl.scnt, &sl.sx};
+        for (DevBuf* b : sb) b->release();
+    }
     for (auto& b : idx->in) b.release();
     for (auto& b : idx->out) b.release();
     if (idx->slab) (void)hipFree(idx->slab);
@@ -416,18 +427,22 @@ static int launch_s1(int kind, bool sample, unsigned grid, hipStream_t st, const
 //   tau_base   [F, 64] non-strict starting thresholds or nullptr (screened pass)
 //   only_failed  [F] device flags or nullptr: restrict the pass to flagged fields (screen fall-back)
 //   record     this is the pass the pipelining event and the timing events bracket
-static int stage1_pass(mfar_index* idx, int kind, const void* slab, const void* qt, int qt_n, int k, float tau0,
-                       const float* tau_base, const int* only_failed, bool record, const S1Out& o, hipStream_t st) {
+//   phases     S1_PREPARE (sample pass + thresholds) | S1_SCAN (the full pass) | S1_FINISH (list merge); the three may be
+//              issued by separate calls on different streams (ordered by the caller), all with the same arguments
+enum { S1_PREPARE = 1, S1_SCAN = 2, S1_FINISH = 4, S1_CERTIFY = 8, S1_ALL = 15 };   // S1_CERTIFY: stage1_block only
+static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, int phases, int kind, const void* slab, const void* qt, int qt_n,
+                       int k, float tau0, const float* tau_base, const int* only_failed, bool record, const S1Out& o,
+                       hipStream_t st) {
     const int n_chunks = stage1_chunks(idx, k);
     const int n_tiles = (int)(idx->n_blk / 4);
-    RETCHK(idx->lists.ensure((size_t)idx->F * n_chunks * 64 * S1_CAP * sizeof(uint2)));
-    RETCHK(idx->list_cnt.ensure((size_t)idx->F * n_chunks * 64 * sizeof(int)));
-    RETCHK(idx->gtau.ensure((size_t)idx->F * 64 * sizeof(float)));
+    RETCHK(sl.lists.ensure((size_t)idx->F * n_chunks * 64 * S1_CAP * sizeof(uint2)));
+    RETCHK(sl.list_cnt.ensure((size_t)idx->F * n_chunks * 64 * sizeof(int)));
+    RETCHK(sl.gtau.ensure((size_t)idx->F * 64 * sizeof(float)));
     S1Params p = {};
     p.slab = slab;
     p.qt = qt;
-    p.lists = idx->lists.as<uint2>();
-    p.list_cnt = idx->list_cnt.as<int>();
+    p.lists = sl.lists.as<uint2>();
+    p.list_cnt = sl.list_cnt.as<int>();
     p.field_stride = idx->field_stride;
     p.n_rows = (int)idx->n_rows;
     p.n_steps = idx->n_steps;
@@ -491,28 +506,32 @@ static int stage1_pass(mfar_index* idx, int kind, const void* slab, const void* 
     p.sample_tiles = light_sample ? sample_tiles : 1;
     if (light_sample) {
         // every wave publishes the 2 best scores per query of its 64 sampled rows; tau = k-th largest of those
-        S1Params ps = p;
-        ps.sample = 2;
-        RETCHK(idx->samp.ensure((size_t)idx->F * n_wave_blocks * 128 * sizeof(float)));
-        ps.samp_out = idx->samp.as<float>();
-        RETCHK(launch_s1(kind, true, grid, st, ps));
-        mfar_sample_tau_kernel<<<dim3(64 * idx->F), dim3(256), 0, st>>>(ps.samp_out, n_wave_blocks, idx->F, k, p.tau0, tau_base,
-                                                                      idx->gtau.as<float>());
-        HIPCHK(hipGetLastError());
-        p.gtau = idx->gtau.as<float>();
+        if (phases & S1_PREPARE) {
+            S1Params ps = p;
+            ps.sample = 2;
+            RETCHK(sl.samp.ensure((size_t)idx->F * n_wave_blocks * 128 * sizeof(float)));
+            ps.samp_out = sl.samp.as<float>();
+            RETCHK(launch_s1(kind, true, grid, st, ps));
+            mfar_sample_tau_kernel<<<dim3(64 * idx->F), dim3(256), 0, st>>>(ps.samp_out, n_wave_blocks, idx->F, k, p.tau0, tau_base,
+                                                                          sl.gtau.as<float>());
+            HIPCHK(hipGetLastError());
+        }
+        p.gtau = sl.gtau.as<float>();
     } else if (use_sample && !tau_base) {
-        S1Params ps = p;
-        ps.sample = 1;
-        RETCHK(launch_s1(kind, true, grid, st, ps));
-        MergeParams ms = m;
-        ms.out_ids = nullptr;
-        ms.out_scores = nullptr;
-        ms.tau_out = idx->gtau.as<float>();
-        RETCHK(launch_merge(ms));
-        p.gtau = idx->gtau.as<float>();
+        if (phases & S1_PREPARE) {
+            S1Params ps = p;
+            ps.sample = 1;
+            RETCHK(launch_s1(kind, true, grid, st, ps));
+            MergeParams ms = m;
+            ms.out_ids = nullptr;
+            ms.out_scores = nullptr;
+            ms.tau_out = sl.gtau.as<float>();
+            RETCHK(launch_merge(ms));
+        }
+        p.gtau = sl.gtau.as<float>();
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (record) {
+    if (record && (phases & S1_SCAN)) {
         if (idx->timing && idx->ev_n < 4096) {
             if ((int)idx->ev.size() < 2 * (idx->ev_n + 1)) {
                 hipEvent_t a, b;
@@ -529,13 +548,15 @@ static int stage1_pass(mfar_index* idx, int kind, const void* slab, const void* 
         if (!idx->mid_ev) HIPCHK(hipEventCreateWithFlags(&idx->mid_ev, hipEventDisableTiming));
         HIPCHK(hipEventRecord(idx->mid_ev, st));
     }
-    RETCHK(launch_s1(kind, false, grid, st, p));
+    if (phases & S1_SCAN) RETCHK(launch_s1(kind, false, grid, st, p));
     if (e1) HIPCHK(hipEventRecord(e1, st));
-    m.out_ids = o.ids;
-    m.out_scores = o.sc;
-    m.tau_out = nullptr;
-    m.cnt_out = o.cnt;
-    RETCHK(launch_merge(m));
+    if (phases & S1_FINISH) {
+        m.out_ids = o.ids;
+        m.out_scores = o.sc;
+        m.tau_out = nullptr;
+        m.cnt_out = o.cnt;
+        RETCHK(launch_merge(m));
+    }
     return MFAR_OK;
 }
 
@@ -579,106 +600,155 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
     return MFAR_OK;
 }
 
-// all pointers are device pointers; fid/fsc are [Q, F, k]
-static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentinel, long long* fid, float* fsc, hipStream_t st) {
+// One block of <= 64 queries (rows q0 .. of q) through stage 1.  all pointers are device pointers; fid/fsc are [Q, F, k].
+//   any_fail_out  nullptr: a failed certificate is repaired here by the exact pass (always launched, idle when nothing
+//                 failed); non-null (device int): only report -- the caller re-runs the batch exactly when it reads != 0
+static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, int Q, int q0, int k, int sentinel, long long* fid,
+                        float* fsc, int* any_fail_out, hipStream_t st) {
+    mfar_index::S1Slot& sl = idx->s1[slot];
     const float tau0 = sentinel ? 0.0f : -INFINITY;
-    bool screened = false;
-    if (screen_wanted(idx, k)) RETCHK(ensure_screen(idx, st, &screened));
-    const bool bf16 = idx->dtype == MFAR_DTYPE_BF16;
-    RETCHK(idx->qt.ensure((size_t)idx->n_steps * (bf16 ? 8192 : 4096)));
     const int F = idx->F, kp = k + SCREEN_EXTRA;
-    if (screened) {
-        RETCHK(idx->s_qt.ensure((size_t)idx->n_steps * 4096));
-        RETCHK(idx->s_qinfo.ensure(64 * sizeof(ScreenQuery)));
-        RETCHK(idx->s_eps.ensure((size_t)F * 64 * 4));
-        RETCHK(idx->s_base.ensure((size_t)F * 64 * 4));
-        if (!idx->s_fail.p) {
-            RETCHK(idx->s_fail.ensure((size_t)(MFAR_MAX_FIELDS + 2) * 4));
-            HIPCHK(hipMemsetAsync(idx->s_fail.p, 0, (size_t)(MFAR_MAX_FIELDS + 2) * 4, st));
-        }
-        RETCHK(idx->s_ids.ensure((size_t)64 * F * kp * 8));
-        RETCHK(idx->s_sc.ensure((size_t)64 * F * kp * 4));
-        RETCHK(idx->s_x.ensure((size_t)64 * F * kp * 4));
-        RETCHK(idx->s_cnt.ensure((size_t)64 * F * 4));
+    const int qt_n = std::min(64, Q - q0);
+    const bool bf16 = idx->dtype == MFAR_DTYPE_BF16;
+    if (phases & S1_PREPARE) {
+        bool screened = false;
+        if (screen_wanted(idx, k)) RETCHK(ensure_screen(idx, st, &screened));
+        sl.screened = screened;
     }
-    for (int q0 = 0; q0 < Q; q0 += 64) {
-        const int qt_n = std::min(64, Q - q0);
-        if (!screened) {
+    RETCHK(sl.qt.ensure((size_t)idx->n_steps * (bf16 ? 8192 : 4096)));
+    if (!sl.screened) {
+        if (phases & S1_PREPARE) {
             if (bf16) {
                 const int total = 64 * (idx->E / 8);
-                mfar_tile_queries_bf16_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, idx->qt.as<unsigned short>(), q0, Q, idx->E);
+                mfar_tile_queries_bf16_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, sl.qt.as<unsigned short>(), q0, Q, idx->E);
             } else {
                 const int total = 64 * (idx->E / 4);
-                mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, idx->qt.as<float>(), q0, Q, idx->E);
+                mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, sl.qt.as<float>(), q0, Q, idx->E);
             }
             HIPCHK(hipGetLastError());
-            const S1Out o = {fid, fsc, nullptr, q0, sentinel};
-            RETCHK(stage1_pass(idx, bf16 ? S1_BF16 : S1_F32, idx->slab, idx->qt.p, qt_n, k, tau0, nullptr, nullptr, true, o, st));
-            continue;
         }
-        // 1. screened pass on the fp16 slab: the k' best approximate scores per (query, field)
-        int* fflags = idx->s_fail.as<int>();
+        const S1Out o = {fid, fsc, nullptr, q0, sentinel};
+        RETCHK(stage1_pass(idx, sl, phases, bf16 ? S1_BF16 : S1_F32, idx->slab, sl.qt.p, qt_n, k, tau0, nullptr, nullptr, true, o, st));
+        if ((phases & S1_CERTIFY) && any_fail_out) HIPCHK(hipMemsetAsync(any_fail_out, 0, 4, st));
+        return MFAR_OK;
+    }
+    RETCHK(sl.qt16.ensure((size_t)idx->n_steps * 4096));
+    RETCHK(sl.qinfo.ensure(64 * sizeof(ScreenQuery)));
+    RETCHK(sl.eps.ensure((size_t)F * 64 * 4));
+    RETCHK(sl.base.ensure((size_t)F * 64 * 4));
+    if (!sl.fail.p) {
+        RETCHK(sl.fail.ensure((size_t)(MFAR_MAX_FIELDS + 2) * 4));
+        HIPCHK(hipMemsetAsync(sl.fail.p, 0, (size_t)(MFAR_MAX_FIELDS + 2) * 4, st));
+    }
+    RETCHK(sl.sids.ensure((size_t)64 * F * kp * 8));
+    RETCHK(sl.ssc.ensure((size_t)64 * F * kp * 4));
+    RETCHK(sl.sx.ensure((size_t)64 * F * kp * 4));
+    RETCHK(sl.scnt.ensure((size_t)64 * F * 4));
+    int* fflags = sl.fail.as<int>();
+    // 1. screened pass on the fp16 slab: the k' best approximate scores per (query, field)
+    if (phases & S1_PREPARE) {
         HIPCHK(hipMemsetAsync(fflags, 0, (size_t)(F + 1) * 4, st));   // field flags + "any"; [F+1] accumulates statistics
-        mfar_screen_queries_kernel<<<dim3(64), dim3(256), 0, st>>>(q, (_Float16*)idx->s_qt.p, idx->s_qinfo.as<ScreenQuery>(),
-                                                                   idx->s_field.as<ScreenField>(), idx->s_eps.as<float>(),
-                                                                   idx->s_base.as<float>(), q0, Q, idx->E, F, sentinel,
-                                                                   idx->screen_eps_mult);
+        mfar_screen_queries_kernel<<<dim3(64), dim3(256), 0, st>>>(q, (_Float16*)sl.qt16.p, sl.qinfo.as<ScreenQuery>(),
+                                                                   idx->s_field.as<ScreenField>(), sl.eps.as<float>(), sl.base.as<float>(),
+                                                                   q0, Q, idx->E, F, sentinel, idx->screen_eps_mult);
         HIPCHK(hipGetLastError());
-        const S1Out so = {idx->s_ids.as<long long>(), idx->s_sc.as<float>(), idx->s_cnt.as<int>(), 0, 0};
-        RETCHK(stage1_pass(idx, S1_F16, idx->screen, idx->s_qt.p, qt_n, kp, -INFINITY, idx->s_base.as<float>(), nullptr, true, so, st));
-        // 2. exact scores of those rows (the contract's fma chain over the fp32 slab)
-        ScoreParams sp = {};
-        sp.slab = idx->slab;
-        sp.field_stride = idx->field_stride;
-        sp.q = q + (size_t)q0 * idx->E;
-        sp.cand = idx->s_ids.as<long long>();
-        sp.n_cand = nullptr;
-        sp.out = idx->s_x.as<float>();
-        sp.row_offset = idx->row_offset;
-        sp.n_rows = (int)idx->n_rows;
-        sp.n_steps = idx->n_steps;
-        sp.E = idx->E;
-        sp.F = F;
-        sp.C = kp;
-        sp.per_field = 1;
-        mfar_score_candidates_kernel<0><<<dim3((unsigned)((kp * F + 255) / 256), qt_n), dim3(256), SCORE_LDS_BYTES(idx->E), st>>>(sp);
+    }
+    const S1Out so = {sl.sids.as<long long>(), sl.ssc.as<float>(), sl.scnt.as<int>(), 0, 0};
+    RETCHK(stage1_pass(idx, sl, phases, S1_F16, idx->screen, sl.qt16.p, qt_n, kp, -INFINITY, sl.base.as<float>(), nullptr, true, so, st));
+    if (!(phases & S1_CERTIFY)) return MFAR_OK;
+    // 2. exact scores of those rows (the contract's fma chain over the fp32 slab)
+    ScoreParams sp = {};
+    sp.slab = idx->slab;
+    sp.field_stride = idx->field_stride;
+    sp.q = q + (size_t)q0 * idx->E;
+    sp.cand = sl.sids.as<long long>();
+    sp.n_cand = nullptr;
+    sp.out = sl.sx.as<float>();
+    sp.row_offset = idx->row_offset;
+    sp.n_rows = (int)idx->n_rows;
+    sp.n_steps = idx->n_steps;
+    sp.E = idx->E;
+    sp.F = F;
+    sp.C = kp;
+    sp.per_field = 1;
+    mfar_score_candidates_kernel<0><<<dim3((unsigned)((kp * F + 255) / 256), qt_n), dim3(256), SCORE_LDS_BYTES(idx->E), st>>>(sp);
+    HIPCHK(hipGetLastError());
+    // 3. exact top-k + certificate
+    CertifyParams cp = {};
+    cp.sid = sl.sids.as<long long>();
+    cp.ssc = sl.ssc.as<float>();
+    cp.scnt = sl.scnt.as<int>();
+    cp.sx = sl.sx.as<float>();
+    cp.sf = idx->s_field.as<ScreenField>();
+    cp.qinfo = sl.qinfo.as<ScreenQuery>();
+    cp.eps = sl.eps.as<float>();
+    cp.out_ids = fid;
+    cp.out_scores = fsc;
+    cp.fail = fflags;
+    cp.F = F;
+    cp.k = k;
+    cp.kp = kp;
+    cp.q0 = q0;
+    cp.sentinel = sentinel;
+    mfar_screen_certify_kernel<<<dim3(qt_n * F), dim3(256), 0, st>>>(cp);
+    HIPCHK(hipGetLastError());
+    idx->screen_checked += (long long)qt_n * F;
+    if (any_fail_out) {   // report only: the caller repairs
+        HIPCHK(hipMemcpyAsync(any_fail_out, fflags + F, 4, hipMemcpyDeviceToDevice, st));
+        return MFAR_OK;
+    }
+    // 4. fall-back: the exact fp32 pass for fields whose certificate failed (workgroups of other fields exit at once)
+    {
+        const int total = 64 * (idx->E / 4);
+        mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, sl.qt.as<float>(), q0, Q, idx->E);
         HIPCHK(hipGetLastError());
-        // 3. exact top-k + certificate
-        CertifyParams cp = {};
-        cp.sid = idx->s_ids.as<long long>();
-        cp.ssc = idx->s_sc.as<float>();
-        cp.scnt = idx->s_cnt.as<int>();
-        cp.sx = idx->s_x.as<float>();
-        cp.sf = idx->s_field.as<ScreenField>();
-        cp.qinfo = idx->s_qinfo.as<ScreenQuery>();
-        cp.eps = idx->s_eps.as<float>();
-        cp.out_ids = fid;
-        cp.out_scores = fsc;
-        cp.fail = fflags;
-        cp.F = F;
-        cp.k = k;
-        cp.kp = kp;
-        cp.q0 = q0;
-        cp.sentinel = sentinel;
-        mfar_screen_certify_kernel<<<dim3(qt_n * F), dim3(256), 0, st>>>(cp);
-        HIPCHK(hipGetLastError());
-        idx->screen_checked += (long long)qt_n * F;
-        // 4. fall-back: the exact fp32 pass for fields whose certificate failed (workgroups of other fields exit at once)
-        {
-            const int total = 64 * (idx->E / 4);
-            mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, idx->qt.as<float>(), q0, Q, idx->E);
-            HIPCHK(hipGetLastError());
-            const S1Out o = {fid, fsc, nullptr, q0, sentinel};
-            RETCHK(stage1_pass(idx, S1_F32, idx->slab, idx->qt.p, qt_n, k, tau0, nullptr, fflags, false, o, st));
-        }
+        const S1Out o = {fid, fsc, nullptr, q0, sentinel};
+        RETCHK(stage1_pass(idx, sl, S1_ALL, S1_F32, idx->slab, sl.qt.p, qt_n, k, tau0, nullptr, fflags, false, o, st));
     }
     return MFAR_OK;
+}
+
+static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentinel, long long* fid, float* fsc, hipStream_t st) {
+    for (int q0 = 0; q0 < Q; q0 += 64) RETCHK(stage1_block(idx, 0, S1_ALL, q, Q, q0, k, sentinel, fid, fsc, nullptr, st));
+    return MFAR_OK;
+}
+
+static int check_split(const mfar_index* idx, const float* q, int Q, int k, int slot) {
+    RETCHK(check_search_common(idx, q, Q, k));
+    if (Q > 64) return fail(MFAR_ERR_INVALID, "the split-phase entry points take at most 64 queries");
+    if (slot < 0 || slot > 1) return fail(MFAR_ERR_INVALID, "slot must be 0 or 1");
+    return MFAR_OK;
+}
+extern "C" int mfar_stage1_begin(mfar_index* idx, const float* q, int Q, int k, int sentinel, int slot, int64_t* field_ids,
+                                 float* field_scores, void* stream) {
+    RETCHK(check_split(idx, q, Q, k, slot));
+    if (Q == 0) return MFAR_OK;
+    HIPCHK(hipSetDevice(idx->device));
+    if (!field_ids || !field_scores) return fail(MFAR_ERR_INVALID, "output pointer is NULL");
+    return stage1_block(idx, slot, S1_PREPARE | S1_SCAN | S1_FINISH, q, Q, 0, k, sentinel, (long long*)field_ids, field_scores, nullptr,
+                        (hipStream_t)stream);
+}
+extern "C" int mfar_stage1_finish(mfar_index* idx, const float* q, int Q, int k, int sentinel, int slot, int64_t* field_ids,
+                                  float* field_scores, int32_t* any_fail, void* stream) {
+    RETCHK(check_split(idx, q, Q, k, slot));
+    if (Q == 0) return MFAR_OK;
+    if (!field_ids || !field_scores) return fail(MFAR_ERR_INVALID, "output pointer is NULL");
+    HIPCHK(hipSetDevice(idx->device));
+    return stage1_block(idx, slot, S1_CERTIFY, q, Q, 0, k, sentinel, (long long*)field_ids, field_scores, (int*)any_fail,
+                        (hipStream_t)stream);
 }
 
 extern "C" int mfar_set_screen(mfar_index* idx, int mode, float eps_mult) {
     if (!idx || mode < 0 || mode > 2 || !(eps_mult >= 0.0f)) return fail(MFAR_ERR_INVALID, "mode must be 0, 1 or 2 and eps_mult >= 0");
     idx->screen_mode = mode;
     idx->screen_eps_mult = eps_mult;
+    return MFAR_OK;
+}
+
+extern "C" int mfar_get_screen(const mfar_index* idx, int* mode, float* eps_mult) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    if (mode) *mode = idx->screen_mode;
+    if (eps_mult) *eps_mult = idx->screen_eps_mult;
     return MFAR_OK;
 }
 
@@ -690,12 +760,13 @@ extern "C" int mfar_screen_stats(mfar_index* idx, int* built, int64_t* screen_by
     if (n_checked) *n_checked = idx->screen_checked;
     if (n_failed) {
         *n_failed = 0;
-        if (idx->s_fail.p) {
-            HIPCHK(hipDeviceSynchronize());
-            int v = 0;
-            HIPCHK(hipMemcpy(&v, idx->s_fail.as<int>() + idx->F + 1, 4, hipMemcpyDeviceToHost));
-            *n_failed = v;
-        }
+        for (auto& sl : idx->s1)
+            if (sl.fail.p) {
+                HIPCHK(hipDeviceSynchronize());
+                int v = 0;
+                HIPCHK(hipMemcpy(&v, sl.fail.as<int>() + idx->F + 1, 4, hipMemcpyDeviceToHost));
+                *n_failed += v;
+            }
     }
     return MFAR_OK;
 }

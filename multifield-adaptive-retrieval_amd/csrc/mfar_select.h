@@ -192,8 +192,8 @@ __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams
 // Register-resident variant for n_chunks * k <= 256 * NPT and n_chunks <= 128: slot s = c * k + r of the concatenated lists
 // goes to thread s % 256, register s / 256, so the keys never pass through LDS (5 KB of static LDS instead of
 // n_chunks * k * 8 bytes) and all loads of a thread are independent.  Same results as mfar_merge_lists_kernel.
-template <int NPT>
-__global__ void __launch_bounds__(256, 2) mfar_merge_lists_regs_kernel(const MergeParams p) {
+template <int NPT, int TPB>
+__device__ __forceinline__ void merge_lists_regs_body(const MergeParams& p) {
     __shared__ u64 sel[SEL_MAX_K], sorted[SEL_MAX_K];
     __shared__ int red[36], cnts[128];
     const int ql = blockIdx.x / p.F, f = blockIdx.x - ql * p.F;
@@ -205,20 +205,21 @@ __global__ void __launch_bounds__(256, 2) mfar_merge_lists_regs_kernel(const Mer
     // unconditional loads (clamped slot: always inside the list buffer), so that all NPT of them are in flight together;
     // validity is applied afterwards
     uint2 e[NPT];
-    int cc[NPT], rr[NPT];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-        const int s_ = (int)threadIdx.x + 256 * i;
+        const int s_ = (int)threadIdx.x + TPB * i;
         const int sl = s_ < total ? s_ : 0;
-        cc[i] = sl / p.k;
-        rr[i] = s_ < total ? sl - cc[i] * p.k : 0x7FFFFFFF;
-        e[i] = p.lists[((size_t)(f * p.n_chunks + cc[i]) * 64 + ql) * S1_CAP + (sl - cc[i] * p.k)];
+        const int c = sl / p.k;
+        e[i] = p.lists[((size_t)(f * p.n_chunks + c) * 64 + ql) * S1_CAP + (sl - c * p.k)];
     }
     u32 hi[NPT], lo[NPT];
     int mine = 0;
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-        const bool ok = rr[i] < cnts[cc[i]];
+        const int s_ = (int)threadIdx.x + TPB * i;
+        const int sl = s_ < total ? s_ : 0;
+        const int c = sl / p.k;
+        const bool ok = s_ < total && (sl - c * p.k) < cnts[c];
         hi[i] = ok ? f2ord(__uint_as_float(e[i].x)) : 0u;
         lo[i] = ok ? 0xFFFFFFFFu - e[i].y : 0u;
         asm volatile("" : "+v"(hi[i]), "+v"(lo[i]));   // keep the keys materialised: the selection re-reads them 34 times
@@ -241,7 +242,8 @@ __global__ void __launch_bounds__(256, 2) mfar_merge_lists_regs_kernel(const Mer
         }
     }
 }
-
+template <int NPT>
+__global__ void __launch_bounds__(256, 2) mfar_merge_lists_regs_kernel(const MergeParams p) { merge_lists_regs_body<NPT, 256>(p); }
 // tau[f][q] = max(base[f][q], k-th largest of the n_vals scores published by the light sample pass for (q, f)); the k-th
 // largest counts only scores above tau0 and is -inf when there are fewer than k of them (then the sample gives no bound).
 // grid = 64 * F, block 256, n_vals <= 2048: every thread holds 8 values in registers.

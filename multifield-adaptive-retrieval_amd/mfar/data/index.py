@@ -76,6 +76,11 @@ def _same_side(args):
     return bool(sides.pop()) if sides else False
 
 
+def _dev_ptr(x):
+    """CUDA tensor -> its device address; an int is taken as a device address already."""
+    return int(x) if isinstance(x, int) else int(x.data_ptr())
+
+
 def _current_stream(device_index: int, on_device: bool):
     if not on_device:
         return None
@@ -248,6 +253,24 @@ class MultiFieldIndex:
                                                          _current_stream(self.device, True)))
         return lists
 
+    # ---- split-phase stage 1 (two slots; see include/mfar_hip.h).  q is a CUDA tensor, field_ids / field_scores are CUDA
+    # tensors or raw device addresses (the lists-first exchange passes offsets into its flat payload buffer)
+    def stage1_begin(self, q, slot: int, field_ids, field_scores, k1: int = 100, sentinel: bool = True):
+        qa = _Arg(q, np.float32, self.device)
+        if not qa.on_device:
+            raise ValueError("stage1_begin needs CUDA tensors")
+        _native.check(_native.lib().mfar_stage1_begin(self._h, qa.ptr, qa.keep.shape[0], int(k1), int(bool(sentinel)), int(slot),
+                                                       _dev_ptr(field_ids), _dev_ptr(field_scores), _current_stream(self.device, True)))
+
+    def stage1_finish(self, q, slot: int, field_ids, field_scores, k1: int = 100, sentinel: bool = True, any_fail=None):
+        qa = _Arg(q, np.float32, self.device)
+        if not qa.on_device:
+            raise ValueError("stage1_finish needs CUDA tensors")
+        _native.check(_native.lib().mfar_stage1_finish(self._h, qa.ptr, qa.keep.shape[0], int(k1), int(bool(sentinel)), int(slot),
+                                                        _dev_ptr(field_ids), _dev_ptr(field_scores),
+                                                        None if any_fail is None else _dev_ptr(any_fail),
+                                                        _current_stream(self.device, True)))
+
     def search_owned(self, gathered_lists, n_shards: int, q, W, topk, mask=None, k1: int = 100, k2: int = 100, sentinel: bool = True,
                      query_cond: bool = True, slot: int = 0):
         """Merge the gathered lists, score + mix the candidates this shard owns, write the local top-k2 payload."""
@@ -277,6 +300,13 @@ class MultiFieldIndex:
         """Certified fp16 screening of an fp32 index (include/mfar_hip.h): 0 off, 1 auto, 2 whenever possible.
         Outputs are bit-identical in every mode; `eps_mult` is a test knob (1 = rigorous proof)."""
         _native.check(_native.lib().mfar_set_screen(self._h, int(mode), float(eps_mult)))
+
+    @property
+    def screen_setting(self):
+        """(mode, eps_mult) currently in force."""
+        mode, mult = ctypes.c_int(), ctypes.c_float()
+        _native.check(_native.lib().mfar_get_screen(self._h, ctypes.byref(mode), ctypes.byref(mult)))
+        return mode.value, mult.value
 
     def screen_stats(self) -> dict:
         built, nbytes, chk, bad = ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()

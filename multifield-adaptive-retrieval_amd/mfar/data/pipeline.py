@@ -1,16 +1,21 @@
 """Two-deep software pipeline over query batches (HIP streams + events through torch).
 
 The reference scores one batch at a time, synchronously (reference mfar/modeling/contrastive.py:559-563 -> 669-704).
-On the GPU the per-batch work splits into a long MFMA-bound part (stage 1: per-field exhaustive top-k) and a short
-memory/latency-bound tail (candidate union, stage-2 re-scoring, mixer; with several GPUs also the payload all-gather
-and the merge).  `PipelinedSearcher` runs the tail of batch i on a side stream BESIDE the full stage-1 kernel of batch
-i+1 (high-priority stream): the tail kernels are small enough in LDS to be co-resident with the two stage-1 workgroups
-of a CU.  Results are identical to `MultiFieldIndex.search` / `ShardedSearcher.search`.
+On the GPU the per-batch work is one long scan (stage 1: per-field exhaustive top-k) and a chain of short, latency- or
+gather-bound kernels around it.  `PipelinedSearcher` keeps the scans of consecutive batches back to back on a
+high-priority stream (`mfar_stage1_begin`: query prep, sample pass, scan, list merge) and runs everything that follows a
+scan -- exact re-scoring + certificate of the screened lists (`mfar_stage1_finish`), candidate union, stage 2, mixer;
+with several GPUs the two small all-gathers, `mfar_search_owned` and `mfar_merge_topk` -- on a side stream BESIDE the
+next batch's scan: the 16-bit scan kernels keep their doc tiles in registers, so those small kernels fit next to them
+on every CU.  Results are identical to `MultiFieldIndex.search` / `ShardedSearcher.search`.
 
     ps = PipelinedSearcher(index, W, mask)
     t0 = ps.submit(q0)            # returns immediately (everything is enqueued asynchronously)
-    t1 = ps.submit(q1)            # ... the tail of batch 0 is enqueued here, next to stage 1 of batch 1
+    t1 = ps.submit(q1)
     r0 = ps.result(t0)            # dict(ids, scores, n_valid): valid until two more batches have been submitted
+
+A screened batch whose certificate failed (include/mfar_hip.h, `any_fail`) is detected in `result()` and redone there
+with the screen switched off, so what `result()` returns is always the exact answer.
 """
 import torch
 
@@ -27,17 +32,22 @@ class PipelinedSearcher:
         dist = torch.distributed
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.dev = torch.device(f"cuda:{index.device}")
-        self.main = torch.cuda.Stream(device=self.dev, priority=-1)   # stage 1: dispatched ahead of the tail kernels
+        self.main = torch.cuda.Stream(device=self.dev, priority=-1)   # the scans: dispatched ahead of the small kernels
         self.side = torch.cuda.Stream(device=self.dev)
         self.Qmax = int(max_batch)
+        if self.Qmax > 64:
+            raise ValueError("the split-phase stage 1 takes at most 64 queries per batch")
         F, E = index.n_fields, index.dim
+        self.n_redone = 0             # batches whose screen certificate failed and that were redone exactly
         self.slots = []
         for _ in range(2):
             s = dict(q=torch.empty(self.Qmax, E, device=self.dev),
                      ids=torch.empty(self.Qmax, k2, dtype=torch.int64, device=self.dev),
                      scores=torch.empty(self.Qmax, k2, device=self.dev),
                      n_valid=torch.empty(self.Qmax, dtype=torch.int32, device=self.dev),
-                     stage1=torch.cuda.Event(), done=torch.cuda.Event(), Q=0, tail_pending=False)
+                     fail=torch.zeros(1, dtype=torch.int32, device=self.dev),
+                     fail_host=torch.zeros(1, dtype=torch.int32).pin_memory(),
+                     stage1=torch.cuda.Event(), done=torch.cuda.Event(), Q=0, checked=True)
             if self.world == 1:
                 s["fid"] = torch.empty(self.Qmax, F, k1, dtype=torch.int64, device=self.dev)
                 s["fsc"] = torch.empty(self.Qmax, F, k1, device=self.dev)
@@ -51,65 +61,94 @@ class PipelinedSearcher:
             self.slots.append(s)
         self.n_submitted = 0
 
-    # ---- the tail of one batch, on the side stream ----
-    def _enqueue_tail(self, t: int, beside_next_stage1: bool):
-        s = self.slots[t & 1]
-        if not s["tail_pending"]:
-            return
-        s["tail_pending"] = False
+    # where stage 1 leaves the per-field lists of a slot: (ids, scores) as tensors or raw device addresses
+    def _list_targets(self, s):
+        if self.world == 1:
+            Q = s["Q"]
+            return s["fid"][:Q], s["fsc"][:Q]
+        base = s["lists"].data_ptr()                     # lists layout: ids | scores (256-byte aligned), include/mfar_hip.h
+        ids_bytes = self.Qmax * self.ix.n_fields * self.k1 * 8
+        return base, base + ((ids_bytes + 255) & ~255)
+
+    # everything after the lists of a batch are final, on the current stream
+    def _tail(self, s, slot: int):
         Q = s["Q"]
         qk = s["q"][:Q]
-        with torch.cuda.stream(self.side):
-            if beside_next_stage1:
-                # start when the NEXT batch's full stage-1 kernel starts, so this tail runs beside it
-                _native.check(_native.lib().mfar_stream_wait_stage1_start(self.ix._h, self.side.cuda_stream))
-            self.side.wait_event(s["stage1"])
-            out = dict(ids=s["ids"][:Q], scores=s["scores"][:Q], n_valid=s["n_valid"][:Q])
-            if self.world == 1:
-                self.ix.search_stage2(qk, self.W, s["fid"][:Q], self.mask, self.k1, self.k2, self.query_cond, slot=t & 1, out=out)
-            else:
-                dist = torch.distributed
-                dist.all_gather_into_tensor(s["lists_all"], s["lists"], group=self.group)
-                self.ix.search_owned(s["lists_all"], self.world, qk, self.W, s["topk"], self.mask, self.k1, self.k2, self.sentinel,
-                                     self.query_cond, slot=t & 1)
-                dist.all_gather_into_tensor(s["topk_all"], s["topk"], group=self.group)
-                _index.merge_topk(s["topk_all"], self.world, Q, self.k2, device=self.ix.device, out=out)
-            s["done"].record(self.side)
+        out = dict(ids=s["ids"][:Q], scores=s["scores"][:Q], n_valid=s["n_valid"][:Q])
+        if self.world == 1:
+            self.ix.search_stage2(qk, self.W, s["fid"][:Q], self.mask, self.k1, self.k2, self.query_cond, slot=slot, out=out)
+        else:
+            dist = torch.distributed
+            dist.all_gather_into_tensor(s["lists_all"], s["lists"], group=self.group)
+            self.ix.search_owned(s["lists_all"], self.world, qk, self.W, s["topk"], self.mask, self.k1, self.k2, self.sentinel,
+                                 self.query_cond, slot=slot)
+            dist.all_gather_into_tensor(s["topk_all"], s["topk"], group=self.group)
+            _index.merge_topk(s["topk_all"], self.world, Q, self.k2, device=self.ix.device, out=out)
 
     def submit(self, q) -> int:
         """q: [Q, E] float32 CUDA tensor (Q == max_batch for the sharded path: fixed payload size)."""
         t = self.n_submitted
-        self.n_submitted += 1
-        s = self.slots[t & 1]
+        slot = t & 1
+        s = self.slots[slot]
         Q = q.shape[0]
         if Q > self.Qmax or (self.world > 1 and Q != self.Qmax):
             raise ValueError("batch size does not fit the pipeline's buffers")
-        if t >= 2:
-            self._enqueue_tail(t - 2, False)          # normally already enqueued by submit(t - 1)
+        if not s["checked"]:
+            self._check(t - 2)                        # the slot's previous batch must be verified before its buffers go
+        self.n_submitted += 1
         cur = torch.cuda.current_stream(self.dev)
         self.main.wait_stream(cur)                    # q may have been produced on the caller's stream
         self.main.wait_event(s["done"])               # the slot's previous tail has finished with these buffers
         s["Q"] = Q
+        s["checked"] = False
         with torch.cuda.stream(self.main):
             qk = s["q"][:Q]
             qk.copy_(q)
+            fid, fsc = self._list_targets(s)
+            self.ix.stage1_begin(qk, slot, fid, fsc, self.k1, self.sentinel)
+            s["stage1"].record(self.main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(s["stage1"])
+            self.ix.stage1_finish(qk, slot, fid, fsc, self.k1, self.sentinel, any_fail=s["fail"])
+            if self.world > 1:                        # every rank must take the same decision about a redo
+                torch.distributed.all_reduce(s["fail"], op=torch.distributed.ReduceOp.MAX, group=self.group)
+            self._tail(s, slot)
+            s["fail_host"].copy_(s["fail"], non_blocking=True)
+            s["done"].record(self.side)
+        return t
+
+    # host side of the certificate: wait for the batch, redo it exactly if its screen could not be proven
+    def _check(self, ticket: int):
+        slot = ticket & 1
+        s = self.slots[slot]
+        if s["checked"]:
+            return
+        s["done"].synchronize()
+        s["checked"] = True
+        if int(s["fail_host"][0]) == 0:
+            return
+        self.n_redone += 1
+        torch.cuda.synchronize(self.dev)              # the redo uses the index's slot-0 scratch: nothing else may be in flight
+        prev = self.ix.screen_setting
+        self.ix.set_screen(0, prev[1])
+        try:
+            Q = s["Q"]
+            qk = s["q"][:Q]
             if self.world == 1:
                 _native.check(_native.lib().mfar_retrieve_fields(
                     self.ix._h, qk.data_ptr(), Q, int(self.k1), int(bool(self.sentinel)), s["fid"].data_ptr(), s["fsc"].data_ptr(), 1,
-                    self.main.cuda_stream))
+                    torch.cuda.current_stream(self.dev).cuda_stream))
             else:
                 self.ix.retrieve_lists(qk, s["lists"], self.k1, self.sentinel)
-            s["stage1"].record(self.main)
-        s["tail_pending"] = True
-        if t >= 1:
-            self._enqueue_tail(t - 1, True)           # previous batch's tail runs beside this batch's stage 1
-        return t
+            self._tail(s, slot)
+            torch.cuda.current_stream(self.dev).synchronize()
+        finally:
+            self.ix.set_screen(*prev)
 
     def result(self, ticket: int):
         if ticket < self.n_submitted - 2 or ticket >= self.n_submitted:
             raise ValueError("ticket is no longer (or not yet) in flight")
-        self._enqueue_tail(ticket, False)
+        self._check(ticket)
         s = self.slots[ticket & 1]
-        torch.cuda.current_stream(self.dev).wait_event(s["done"])
         Q = s["Q"]
         return dict(ids=s["ids"][:Q], scores=s["scores"][:Q], n_valid=s["n_valid"][:Q])

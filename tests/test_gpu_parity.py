@@ -661,3 +661,36 @@ def test_screen_follows_row_updates(idxmod):
     _check_stage1(ix, slab, q, k, True, "after")
     assert ix.screen_stats()["built"]
     ix.close()
+
+
+def test_pipelined_searcher_with_screen_and_redo(idxmod):
+    """The split-phase pipeline over a screened index: certified batches flow through; with an impossible proof
+    (eps_mult = 1e9) every batch reports a failed certificate and result() redoes it exactly -- same bits either way."""
+    import torch
+    from mfar.data.pipeline import PipelinedSearcher
+    rng = np.random.default_rng(15)
+    F, D, E, Q = 3, 20000, 96, 64
+    slab, _, W = _mk(rng, F, D, E, 1, mean=0.2, dup=5)
+    ix = _load(idxmod, slab)
+    dev = torch.device("cuda:0")
+    Wd = torch.from_numpy(W).to(dev)
+    qs = [(rng.standard_normal((Q if i != 3 else 17, E)) * 0.5 + 0.3).astype(np.float32) for i in range(6)]
+    ix.set_screen(0)
+    want = [ix.search(q, W, None) for q in qs]
+    for eps_mult, expect_redo in ((1.0, False), (1e9, True)):
+        ix.set_screen(2, eps_mult)
+        ps = PipelinedSearcher(ix, Wd, None, max_batch=Q)
+        tickets, got = [], []
+        for i, q in enumerate(qs):
+            tickets.append(ps.submit(torch.from_numpy(q).to(dev)))
+            if i >= 1:
+                got.append({k: v.clone() for k, v in ps.result(tickets[i - 1]).items()})
+        got.append({k: v.clone() for k, v in ps.result(tickets[-1]).items()})
+        torch.cuda.synchronize()
+        assert (ps.n_redone == len(qs)) if expect_redo else (ps.n_redone == 0), ps.n_redone
+        assert ix.screen_setting == (2, pytest.approx(eps_mult))
+        for w, g in zip(want, got):
+            assert np.array_equal(g["ids"].cpu().numpy(), w["ids"])
+            assert np.array_equal(g["scores"].cpu().numpy().view(np.uint32), w["scores"].view(np.uint32))
+            assert np.array_equal(g["n_valid"].cpu().numpy(), w["n_valid"])
+    ix.close()
