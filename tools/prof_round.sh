@@ -1,7 +1,7 @@
-# on the GPU box: rocprofv3 evidence for the screened (default) bench -> gpurun_out/prof_e/
+# on the GPU box: rocprofv3 evidence for the screened (default) bench -> gpurun_out/prof_round/
 set -x
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_e; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_round; mkdir -p $O
 python $R/bench.py > $O/bench.json 2> $O/bench.err
 python $R/bench.py --screen off --no-cpu-baseline > $O/bench_screen_off.json 2>> $O/bench.err
 python $R/bench.py --dtype bf16 --no-cpu-baseline > $O/bench_bf16.json 2>> $O/bench.err
