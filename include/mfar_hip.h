@@ -204,7 +204,7 @@ int mfar_set_wgs_per_cu(mfar_index* idx, int wgs);
  * rows exactly from the fp32 slab, and PROVES from a rigorous error bound that no other row can enter or tie into
  * the exact top-k; a field whose proof fails is re-done by the exact fp32 pass on the device (csrc/mfar_screen.h).
  * The screen slab (+50 % HBM) is built lazily by the first search after rows were written.
- *   mode      0 = off, 1 = auto (default; fp32 indexes with >= 16384 rows, k <= 192), 2 = whenever the shapes allow.
+ *   mode      0 = off, 1 = auto (default; fp32 indexes with >= 16384 rows, k <= 128), 2 = whenever the shapes allow.
  *             Environment default: MFAR_SCREEN.
  *   eps_mult  multiplies the error bound of the proof; 1 = rigorous.  Test knob: a huge value makes every proof fail
  *             (exercises the exact fall-back), 0 disables the proof (NOT exact any more).

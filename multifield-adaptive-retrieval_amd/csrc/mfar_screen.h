@@ -30,7 +30,7 @@
 #ifndef SCREEN_EXTRA
 #define SCREEN_EXTRA 64          // k' = k + SCREEN_EXTRA
 #endif
-#define SCREEN_MAX_KP S1_TRIG    // the stage-1 lists compact to k', which must leave room for one tile of appends
+#define SCREEN_MAX_KP S1_MAX_DEPTH   // the stage-1 lists compact to k', which must leave room for one tile of appends
 #define SCREEN_SLACK 1.25f
 
 struct ScreenField {     // per field, written by mfar_screen_scale_kernel

@@ -25,7 +25,21 @@
 #define S1_TILE_ROWS 256                     // rows per workgroup tile (4 waves x 64)
 #define S1_CAP 512                           // list capacity per (workgroup, query)
 #define S1_TRIG (S1_CAP - S1_TILE_ROWS)      // compact when more than this many entries are held
-#define S1_STATE_BYTES 784                   // tau[64] + cnt[64] + compaction flag (16 B) + tg[64]
+// selection state: tau[64] | cnt[64] | compaction flag (16 B) | tg[64] | staged counts[64] | staging area [64][SCAP] x 8 B
+#define S1_STATE_BYTES_(SCAP) (1040 + 512 * (SCAP))
+#define S1_SCAP_F32 0                        // fp32 pass: survivors are stored straight to the lists (MFMA-bound, LDS is tight)
+#define S1_SCAP_LDS 8                        // 16-bit LDS-ring passes: what fits beside two 74 KB rings
+#ifndef S1_SCAP_REG
+#define S1_SCAP_REG 64                       // 16-bit register-ring passes (measured: 16 -> 2.06, 32 -> 2.00, 64 -> 1.95 ms per pass)
+#endif
+#ifndef S1_DRAIN_NUM
+#define S1_DRAIN_NUM 2                        // drain a query once it holds SCAP * S1_DRAIN_NUM / 4 staged entries
+#endif
+#define S1_STATE_BYTES S1_STATE_BYTES_(S1_SCAP_F32)
+// A list is compacted once it holds more than S1_TRIG_(SCAP) entries: before a tile it then holds at most that many, fewer
+// than SCAP/2 more are staged, and the tile adds at most 256 -- never more than S1_CAP.  The list depth k must not exceed it.
+#define S1_TRIG_(SCAP) (S1_TRIG - (SCAP))
+#define S1_MAX_DEPTH S1_TRIG_(S1_SCAP_REG)   // 192: deepest list any pass supports (the screen keeps k + 64 <= 192)
 // fp32 slab: 4 KB doc tile per (wave, k-step of 16 dims), 4 KB query tile per k-step shared by the workgroup
 #define S1_STAGES 3                          // LDS ring depth: loads run two k-steps ahead of the MFMAs
 #define S1_D_BYTES (4 * S1_STAGES * 4096)
@@ -34,12 +48,12 @@
 // bf16 slab: 2 KB doc tile per (wave, k-step of 16 dims); query tile = 3 exact bf16 terms x 2 KB = 6 KB in LDS
 // (8 KB per k-step in memory, the 4th quarter is padding): 72 KB per workgroup -> two workgroups per CU
 #define S1B_STAGES 5                         // HBM-bound: keep four k-steps of loads in flight per wave
-#define S1B_LDS_BYTES (4 * S1B_STAGES * 2048 + S1B_STAGES * 6144 + S1_STATE_BYTES)
+#define S1B_LDS_BYTES (4 * S1B_STAGES * 2048 + S1B_STAGES * 6144 + S1_STATE_BYTES_(S1_SCAP_LDS))
 // fp16 screen slab (mfar_screen.h): 2 KB doc tile, query tile = 2 fp16 terms x 2 KB
 #ifndef S1H_STAGES
 #define S1H_STAGES 6                         // 74.5 KB per workgroup, two per CU; measured 7 % faster than 5
 #endif
-#define S1H_LDS_BYTES (4 * S1H_STAGES * 2048 + S1H_STAGES * 4096 + S1_STATE_BYTES)
+#define S1H_LDS_BYTES (4 * S1H_STAGES * 2048 + S1H_STAGES * 4096 + S1_STATE_BYTES_(S1_SCAP_LDS))
 
 struct S1Params {
     const void* slab;       // tiled slab (fp32 or bf16)
@@ -52,7 +66,7 @@ struct S1Params {
     int n_tiles;            // n_blk / 4
     int n_chunks;           // workgroups per field
     int Q;                  // valid queries (<= 64)
-    int k;                  // list depth (<= S1_TRIG)
+    int k;                  // list depth (<= S1_MAX_DEPTH)
     float tau0;             // 0 (zero sentinel, index.py:192-193) or -inf
     const float* gtau;      // [F, 64] non-strict lower bounds from the sample pass, or nullptr
     int sample;             // 1/2: threshold-estimation pass, every workgroup scans only the first tile of its chunk;
@@ -119,7 +133,6 @@ __device__ __forceinline__ float s1_compact(uint2* list, int n, int k) {
 // A score survives when it beats the workgroup's own running k-th best (strict: later rows lose ties to earlier
 // ones) AND is not below the global lower bound from the sample pass (non-strict: ties with other chunks are
 // decided by the merge).
-#define S1_PASS(v, tq, tg) ((v) > (tq) && (v) >= (tg))
 // the same test as ONE compare: v > tq  <=>  v >= nextup(tq) for non-NaN v, so thr = max(nextup(tq), tg)
 __device__ __forceinline__ float s1_nextup(float x) {
     if (!(x < __builtin_inff())) return x;                    // +inf (and NaN) stay
@@ -134,6 +147,8 @@ struct S1State {       // LDS-resident selection state of one workgroup
     int* cnt;          // [64] list fill counts
     int* flag;         // some list needs compaction this tile
     float* tg;         // [64] non-strict global lower bounds
+    int* scnt;         // [64] entries reserved in the staging area since the last drain (may exceed SCAP: the excess went direct)
+    u32 stage;         // LDS byte address of the staging area [64][SCAP] x (score bits, row)
 };
 __device__ __forceinline__ S1State s1_state(char* base) {
     S1State s;
@@ -141,6 +156,8 @@ __device__ __forceinline__ S1State s1_state(char* base) {
     s.cnt = (int*)(base + 256);
     s.flag = (int*)(base + 512);
     s.tg = (float*)(base + 528);
+    s.scnt = (int*)(base + 784);
+    s.stage = (u32)(uintptr_t)(base + 1040);
     return s;
 }
 __device__ __forceinline__ void s1_state_init(const S1State& st, const S1Params& p, int f) {
@@ -149,13 +166,53 @@ __device__ __forceinline__ void s1_state_init(const S1State& st, const S1Params&
         st.tau[tid] = tid < p.Q ? p.tau0 : __builtin_inff();
         st.cnt[tid] = 0;
         st.tg[tid] = p.gtau ? p.gtau[f * 64 + tid] : -__builtin_inff();
+        st.scnt[tid] = 0;
     }
     if (tid == 0) *st.flag = 0;
     __syncthreads();
 }
 
+// LDS accesses of the staging area through inline asm (hipcc would drain the in-flight LDS-DMA in front of LDS accesses it
+// can see next to it)
+__device__ __forceinline__ void lds_write_b64(u32 addr, u64 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ u64 lds_read_b64(u32 addr) {
+    u64 v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+// Move the staged survivors of this wave's 16 queries (16w .. 16w+15) to their lists in HBM: one coalesced store per
+// drained query.  Queries with fewer than `min_staged` staged entries keep them.  Called by all lanes of every wave.
+template <int SCAP>
+__device__ __forceinline__ void s1_drain(const S1Params& p, const S1State& st, int w, size_t wgq0, int min_staged) {
+    const int lane = threadIdx.x & 63;
+    const int sc = lane < 16 ? min(st.scnt[16 * w + lane], SCAP) : 0;
+    u64 todo = __ballot(sc >= min_staged && sc > 0);
+    while (todo) {
+        const int b = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int qq = 16 * w + b;
+        const int n = __builtin_amdgcn_readlane(sc, b);
+        const int g = __builtin_amdgcn_readfirstlane(st.cnt[qq]);
+        if (lane < n && g + lane < S1_CAP)
+            store_untracked_b64(p.lists + (wgq0 + qq) * S1_CAP + g + lane, lds_read_b64(st.stage + (u32)(qq * SCAP + lane) * 8u));
+        if (lane == 0) {
+            st.cnt[qq] = g + n;
+            st.scnt[qq] = 0;
+            if (g + n > S1_TRIG_(SCAP)) *st.flag = 1;
+        }
+    }
+}
+
 // Selection epilogue of one 256-row tile.  acc[doc block][query block]: lane (j = lane & 31, h = lane >> 5) holds, for
 // query 32*qb + j, the scores of doc rows 32*db + (r & 3) + 8*(r >> 2) + 4*h (the MFMA 32x32 accumulator layout).
+//
+// SCAP > 0: survivors are STAGED in LDS ([64 queries][SCAP] entries) and moved to the lists in HBM by s1_drain once a
+// query holds SCAP/2 of them.  Every vector store issued here sits in the same vmcnt queue as the k-loop's prefetch, and a
+// counted wait behind a pending store has to drain deeper than it needs (measured: the ~20 scattered 8-byte stores per
+// wave and tile of the direct path cost 14 % of the 16-bit pass); staging turns them into about one coalesced store per
+// wave and tile.  Entries that do not fit the staging area (a lane with many survivors in one tile) go straight to the list.
+template <int SCAP>
 __device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st, int t, int w, size_t wgq0, f32x16& acc00,
                                             f32x16& acc01, f32x16& acc10, f32x16& acc11) {
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
@@ -182,35 +239,49 @@ __device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st
         // one LDS slot reservation per (lane, query block); inline asm keeps hipcc from draining the
         // LDS-DMA prefetch (it would wait vmcnt(0) before an LDS atomic it can see)
         int b0 = 0, b1 = 0;
-        if (n0) b0 = lds_add_rtn(&st.cnt[j], n0);
-        if (n1) b1 = lds_add_rtn(&st.cnt[32 + j], n1);
-        if ((n0 && b0 + n0 > S1_TRIG) || (n1 && b1 + n1 > S1_TRIG)) *st.flag = 1;
+        if (n0) b0 = lds_add_rtn(SCAP ? &st.scnt[j] : &st.cnt[j], n0);
+        if (n1) b1 = lds_add_rtn(SCAP ? &st.scnt[32 + j] : &st.cnt[32 + j], n1);
+        if (!SCAP && ((n0 && b0 + n0 > S1_TRIG) || (n1 && b1 + n1 > S1_TRIG))) *st.flag = 1;
         const int row_w = t * S1_TILE_ROWS + w * 64 + 4 * h;
         uint2* l0 = p.lists + (wgq0 + j) * S1_CAP;
         uint2* l1 = p.lists + (wgq0 + 32 + j) * S1_CAP;
-#define S1_APPEND(ACC, DB, TH, L, B)                                                                         \
+        const u32 s0 = st.stage + (u32)(j * SCAP) * 8u, s1 = st.stage + (u32)((32 + j) * SCAP) * 8u;
+#define S1_APPEND(ACC, DB, TH, L, B, SB, QI)                                                                 \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                         \
         const float v = ACC[r];                                                                              \
         if (S1_PASS1(v, TH)) {                                                                               \
-            if (B < S1_CAP) store_untracked_b64(&L[B], ((u64)(u32)(row_w + 32 * DB + (r & 3) + 8 * (r >> 2)) << 32) | __float_as_uint(v)); \
+            const u64 e_ = ((u64)(u32)(row_w + 32 * DB + (r & 3) + 8 * (r >> 2)) << 32) | __float_as_uint(v); \
+            if (SCAP) {                                                                                      \
+                if (B < SCAP) lds_write_b64(SB + (u32)B * 8u, e_);                                           \
+                else {                                                                                       \
+                    const int g_ = lds_add_rtn(&st.cnt[QI], 1);                                              \
+                    if (g_ + 1 > S1_TRIG_(SCAP)) *st.flag = 1;                                                      \
+                    if (g_ < S1_CAP) store_untracked_b64(&L[g_], e_);                                        \
+                }                                                                                            \
+            } else if (B < S1_CAP) store_untracked_b64(&L[B], e_);                                           \
             ++B;                                                                                             \
         }                                                                                                    \
     }
-        S1_APPEND(acc00, 0, th0, l0, b0)
-        S1_APPEND(acc10, 1, th0, l0, b0)
-        S1_APPEND(acc01, 0, th1, l1, b1)
-        S1_APPEND(acc11, 1, th1, l1, b1)
+        S1_APPEND(acc00, 0, th0, l0, b0, s0, j)
+        S1_APPEND(acc10, 1, th0, l0, b0, s0, j)
+        S1_APPEND(acc01, 0, th1, l1, b1, s1, 32 + j)
+        S1_APPEND(acc11, 1, th1, l1, b1, s1, 32 + j)
 #undef S1_APPEND
     }
-    // barrier B: slot counters and the compaction flag of this tile are final
+    // barrier B: slot counters (and, on the direct path, the compaction flag) of this tile are final
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (SCAP) {
+        s1_drain<SCAP>(p, st, w, wgq0, SCAP * S1_DRAIN_NUM / 4);
+        // barrier C: list counts and the compaction flag are final
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     if (__builtin_amdgcn_readfirstlane(*st.flag)) {  // workgroup-uniform, rare after warm-up
         // every wave's appended entries must be in memory before another wave compacts a list
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (tid == 0) *st.flag = 0;
         // wave w serves queries 16w .. 16w+15
         const int nv = lane < 16 ? min(st.cnt[16 * w + lane], S1_CAP) : 0;
-        u64 todo = __ballot(nv > S1_TRIG);
+        u64 todo = __ballot(nv > S1_TRIG_(SCAP));
         while (todo) {
             const int b = __builtin_ctzll(todo);
             todo &= todo - 1;
@@ -268,9 +339,14 @@ __device__ __forceinline__ void s1_sample_top2(const S1Params& p, int f, int chu
 }
 
 // leave at most k entries per query and publish the counts
+template <int SCAP>
 __device__ __forceinline__ void s1_flush(const S1Params& p, const S1State& st, int w, size_t wgq0) {
     const int lane = threadIdx.x & 63;
     __syncthreads();
+    if (SCAP) {   // everything still staged goes to the lists (this wave drains exactly the queries it flushes below)
+        s1_drain<SCAP>(p, st, w, wgq0, 1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
     for (int qq = 16 * w; qq < 16 * w + 16; ++qq) {
         int n = __builtin_amdgcn_readfirstlane(min(st.cnt[qq], S1_CAP));
         if (n > p.k) {
@@ -389,10 +465,10 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
         // the HBM stream then keeps its depth through the epilogue instead of draining (the next step skips its issue).
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (issued < total) S1_ISSUE_NEXT();
-        s1_epilogue(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
+        s1_epilogue<S1_SCAP_F32>(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
 #undef S1_ISSUE_NEXT
-    if (p.sample != 2) s1_flush(p, st, w, wgq0);
+    if (p.sample != 2) s1_flush<S1_SCAP_F32>(p, st, w, wgq0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -413,7 +489,7 @@ struct S1X {
     static constexpr int Q_STEP_MEM = MODE ? 4096 : 8192;  // bytes of query tile per k-step in memory
     static constexpr int LOADS = MODE ? 3 : 4;             // LDS-DMA instructions per wave per stage
     static constexpr int D_BYTES = 4 * STAGES * 2048;
-    static constexpr int LDS_BYTES = D_BYTES + STAGES * Q_STAGE + S1_STATE_BYTES;
+    static constexpr int LDS_BYTES = D_BYTES + STAGES * Q_STAGE + S1_STATE_BYTES_(S1_SCAP_LDS);
 };
 
 template <int N>
@@ -540,10 +616,10 @@ __device__ __forceinline__ void s1_body_x16(const S1Params& p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A + early refill (see the fp32 body)
         if (issued < total) S1X_ISSUE_NEXT();
-        s1_epilogue(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
+        s1_epilogue<S1_SCAP_LDS>(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
 #undef S1X_ISSUE_NEXT
-    if (p.sample != 2) s1_flush(p, st, w, wgq0);
+    if (p.sample != 2) s1_flush<S1_SCAP_LDS>(p, st, w, wgq0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -561,7 +637,7 @@ struct S1XR {
     static constexpr int Q_STAGE = TERMS * 2048;
     static constexpr int Q_STEP_MEM = MODE ? 4096 : 8192;
     static constexpr int LOADS = MODE ? 3 : 4;             // vm instructions per wave per stage: 2 doc loads + query pieces
-    static constexpr int LDS_BYTES = R * Q_STAGE + S1_STATE_BYTES;
+    static constexpr int LDS_BYTES = R * Q_STAGE + S1_STATE_BYTES_(S1_SCAP_REG);
 };
 
 template <int MODE, int R>
@@ -679,12 +755,12 @@ __device__ __forceinline__ void s1_body_x16r(const S1Params& p) {
             continue;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A (see the fp32 body)
-        s1_epilogue(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
+        s1_epilogue<S1_SCAP_REG>(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
 #undef S1R_ISSUE
     // the stages issued past the end are still in flight: no LDS-DMA write may land after the workgroup has left
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (p.sample != 2) s1_flush(p, st, w, wgq0);
+    if (p.sample != 2) s1_flush<S1_SCAP_REG>(p, st, w, wgq0);
 }
 
 // The full pass and the threshold-estimation pass are the same code under two kernel names, so that profiles list them
@@ -697,7 +773,7 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16_kernel(const S1
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16_sample_kernel(const S1Params p) { s1_body_x16<1>(p); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r_kernel(const S1Params p) { s1_body_x16r<1, 6>(p); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r_sample_kernel(const S1Params p) { s1_body_x16r<1, 6>(p); }
-#define S1HR_LDS_BYTES (6 * 4096 + S1_STATE_BYTES)
+#define S1HR_LDS_BYTES (6 * 4096 + S1_STATE_BYTES_(S1_SCAP_REG))
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r_kernel(const S1Params p) { s1_body_x16r<0, 6>(p); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r_sample_kernel(const S1Params p) { s1_body_x16r<0, 6>(p); }
-#define S1BR_LDS_BYTES (6 * 6144 + S1_STATE_BYTES)
+#define S1BR_LDS_BYTES (6 * 6144 + S1_STATE_BYTES_(S1_SCAP_REG))
