@@ -121,6 +121,10 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_mix_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1H_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1H_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16r_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HR_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16r_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HR_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16r_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BR_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16r_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BR_LDS_BYTES));
     g_attr_done[device] = true;
     return MFAR_OK;
 }

@@ -637,7 +637,8 @@ struct S1XR {
     static constexpr int Q_STAGE = TERMS * 2048;
     static constexpr int Q_STEP_MEM = MODE ? 4096 : 8192;
     static constexpr int LOADS = MODE ? 3 : 4;             // vm instructions per wave per stage: 2 doc loads + query pieces
-    static constexpr int LDS_BYTES = R * Q_STAGE + S1_STATE_BYTES_(S1_SCAP_REG);
+    static constexpr int SCAP = MODE ? S1_SCAP_REG : S1_SCAP_REG / 2;   // bf16: 6 KB query stages, keep 50 KB per CU free
+    static constexpr int LDS_BYTES = R * Q_STAGE + S1_STATE_BYTES_(SCAP);
 };
 
 template <int MODE, int R>
@@ -755,12 +756,12 @@ __device__ __forceinline__ void s1_body_x16r(const S1Params& p) {
             continue;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A (see the fp32 body)
-        s1_epilogue<S1_SCAP_REG>(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
+        s1_epilogue<X::SCAP>(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
 #undef S1R_ISSUE
     // the stages issued past the end are still in flight: no LDS-DMA write may land after the workgroup has left
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (p.sample != 2) s1_flush<S1_SCAP_REG>(p, st, w, wgq0);
+    if (p.sample != 2) s1_flush<X::SCAP>(p, st, w, wgq0);
 }
 
 // The full pass and the threshold-estimation pass are the same code under two kernel names, so that profiles list them
@@ -776,4 +777,4 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r_sample_kernel(
 #define S1HR_LDS_BYTES (6 * 4096 + S1_STATE_BYTES_(S1_SCAP_REG))
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r_kernel(const S1Params p) { s1_body_x16r<0, 6>(p); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r_sample_kernel(const S1Params p) { s1_body_x16r<0, 6>(p); }
-#define S1BR_LDS_BYTES (6 * 6144 + S1_STATE_BYTES_(S1_SCAP_REG))
+#define S1BR_LDS_BYTES (6 * 6144 + S1_STATE_BYTES_(S1_SCAP_REG / 2))
