@@ -77,23 +77,28 @@ def test_stage1_bit_exact_vs_oracle(idxmod):
 
 
 def test_stage1_many_workgroups_and_compactions(idxmod):
-    """Ascending scores force every element through the append path (worst case for the running threshold);
-    several chunks per field exercise the cross-workgroup merge."""
+    """Ascending scores force every element through the append path (worst case for the running threshold: the LDS
+    staging area overflows into the direct path and the lists compact every tile); several chunks per field exercise the
+    cross-workgroup merge.  Both 16-bit scan kernels (LDS ring: 2 k-steps, register ring: 6 k-steps), the exact fp32 pass,
+    and the deepest list the ABI allows (k = 128 -> 192 screened entries)."""
     rng = np.random.default_rng(2)
-    F, D, E, Q, k = 2, 40000, 32, 64, 100
-    slab, q, _ = _mk(rng, F, D, E, Q)
-    # make field 1 scores increase with the row index for query 0
-    ramp = np.linspace(0.0, 3.0, D, dtype=np.float32)[:, None] * (q[0] / np.dot(q[0], q[0]))[None, :]
-    slab[1] = (slab[1] * 0.01 + ramp).astype(np.float32)
-    ix = _load(idxmod, slab)
-    for wgs in (1, 2, 4):
-        ix.set_wgs_per_cu(wgs)
-        ids, sc = ix.retrieve_fields(q, k, True)
-        for f in range(F):
-            oi, osc = O.c_retrieve(slab[f], q, k, True)
-            assert np.array_equal(ids[:, f], oi), (wgs, f)
-            assert np.array_equal(sc[:, f].view(np.uint32), osc.view(np.uint32)), (wgs, f)
-    ix.close()
+    for E, k in ((32, 100), (96, 100), (96, 128)):
+        F, D, Q = 2, 40000, 64
+        slab, q, _ = _mk(rng, F, D, E, Q)
+        # make field 1 scores increase with the row index for query 0
+        ramp = np.linspace(0.0, 3.0, D, dtype=np.float32)[:, None] * (q[0] / np.dot(q[0], q[0]))[None, :]
+        slab[1] = (slab[1] * 0.01 + ramp).astype(np.float32)
+        ix = _load(idxmod, slab)
+        want = [O.c_retrieve(slab[f], q, k, True) for f in range(F)]
+        for screen in (0, 2):
+            ix.set_screen(screen)
+            for wgs in (1, 2, 4):
+                ix.set_wgs_per_cu(wgs)
+                ids, sc = ix.retrieve_fields(q, k, True)
+                for f in range(F):
+                    assert np.array_equal(ids[:, f], want[f][0]), (E, k, screen, wgs, f)
+                    assert np.array_equal(sc[:, f].view(np.uint32), want[f][1].view(np.uint32)), (E, k, screen, wgs, f)
+        ix.close()
 
 
 def test_stage1_golden_reference(golden_dir, idxmod):
