@@ -38,6 +38,8 @@ class SyntheticCorpus:
         n_rel = rng.integers(1, 6, size=self.NQ)
         self._rel = []
         rows, fields, qidx = [], [], []
+        if int(n_rel.sum()) > self.D // 2:
+            raise ValueError(f"{self.NQ} queries need {int(n_rel.sum())} distinct planted documents: too many for {self.D} docs")
         used = set()
         for qi in range(self.NQ):
             docs = set()
