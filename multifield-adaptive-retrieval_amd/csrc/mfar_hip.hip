@@ -503,7 +503,8 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, int phases, int 
     // (measured: 2 tiles pay off for the HBM-bound 16-bit passes, 1 for the MFMA-bound fp32 pass)
     static const int sample_tiles_env = getenv("MFAR_SAMPLE_TILES") ? atoi(getenv("MFAR_SAMPLE_TILES")) : 0;
     const int sample_tiles_max = sample_tiles_env > 0 ? sample_tiles_env : (kind == S1_F32 ? 1 : 2);
-    int sample_tiles = std::max(1, std::min(sample_tiles_max, n_tiles / n_chunks / 12));
+    static const int sample_div = getenv("MFAR_SAMPLE_DIV") ? atoi(getenv("MFAR_SAMPLE_DIV")) : 12;
+    int sample_tiles = std::max(1, std::min(sample_tiles_max, n_tiles / n_chunks / sample_div));
     while (sample_tiles > 1 && 8 * n_chunks * sample_tiles > 2048) --sample_tiles;
     const int n_wave_blocks = 4 * n_chunks * sample_tiles;
     const bool light_sample = use_sample && 2 * n_wave_blocks >= 2 * k && 2 * n_wave_blocks <= 2048;
