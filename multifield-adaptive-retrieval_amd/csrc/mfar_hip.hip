@@ -84,7 +84,7 @@ struct mfar_index {
     // batch i+1 scans on another (mfar_stage1_begin / mfar_stage1_finish)
     struct S1Slot {
         DevBuf qt, lists, list_cnt, gtau, samp;                          // any pass
-        DevBuf qt16, qinfo, eps, base, fail, sids, ssc, scnt, sx;        // fp16 screen
+        DevBuf qt16, qinfo, eps, base, qm, fail, sids, ssc, scnt, sx;    // fp16 screen
         bool screened = false;                                          // decided by the begin phase of the batch
     } s1[2];
     DevBuf fid, fsc, cand[2], ncand[2], x[2], own[2], in[8], out[8];
@@ -95,7 +95,7 @@ struct mfar_index {
     bool screen_dirty = true;     // rows were written since the screen was built
     bool screen_nomem = false;
     long long screen_checked = 0; // (query, field) lists certified so far    // the screen slab could not be allocated: stay on the exact pass
-    DevBuf s_stats, s_field;
+    DevBuf s_stats, s_field, s_mean;
     hipEvent_t mid_ev = nullptr;  // recorded right before the full stage-1 kernel is launched
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -200,10 +200,10 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
     DevBuf* bufs[] = {&idx->fid, &idx->fsc, &idx->cand[0], &idx->cand[1], &idx->ncand[0], &idx->ncand[1], &idx->x[0], &idx->x[1],
-                      &idx->own[0], &idx->own[1], &idx->s_stats, &idx->s_field};
+                      &idx->own[0], &idx->own[1], &idx->s_stats, &idx->s_field, &idx->s_mean};
     for (DevBuf* b : bufs) b->release();
     for (auto& sl : idx->s1) {
-        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
+        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.qm, &sl.fail, &sl.sids,
                         &sl.ssc, &sl.scnt, &sl.sx};
         for (DevBuf* b : sb) b->release();
     }
@@ -589,15 +589,25 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
     if (idx->screen_dirty) {
         RETCHK(idx->s_stats.ensure((size_t)idx->F * 2 * sizeof(u32)));
         RETCHK(idx->s_field.ensure((size_t)idx->F * sizeof(ScreenField)));
+        RETCHK(idx->s_mean.ensure((size_t)idx->F * idx->E * sizeof(float)));
         HIPCHK(hipMemsetAsync(idx->s_stats.p, 0, (size_t)idx->F * 2 * sizeof(u32), st));
-        mfar_screen_stats_kernel<<<dim3((unsigned)idx->n_blk, idx->F), dim3(256), 0, st>>>((const float*)idx->slab, idx->field_stride,
-                                                                                            idx->n_steps, idx->s_stats.as<u32>());
+        HIPCHK(hipMemsetAsync(idx->s_mean.p, 0, (size_t)idx->F * idx->E * sizeof(float), st));
+        mfar_screen_mean_kernel<<<dim3((unsigned)((idx->n_blk + 7) / 8), idx->F), dim3(256), 0, st>>>(
+            (const float*)idx->slab, idx->field_stride, idx->n_steps, idx->n_blk, idx->n_rows, idx->s_mean.as<float>());
         HIPCHK(hipGetLastError());
-        mfar_screen_scale_kernel<<<dim3(1), dim3(64), 0, st>>>(idx->s_stats.as<u32>(), idx->F, idx->s_field.as<ScreenField>());
+        mfar_screen_mean_finish_kernel<<<dim3((idx->F * idx->E + 255) / 256), dim3(256), 0, st>>>(idx->s_mean.as<float>(), idx->F * idx->E,
+                                                                                                idx->n_rows);
+        HIPCHK(hipGetLastError());
+        mfar_screen_stats_kernel<<<dim3((unsigned)idx->n_blk, idx->F), dim3(256), 0, st>>>(
+            (const float*)idx->slab, idx->field_stride, idx->n_steps, idx->n_rows, idx->s_mean.as<float>(), idx->s_stats.as<u32>());
+        HIPCHK(hipGetLastError());
+        mfar_screen_scale_kernel<<<dim3(1), dim3(64), 0, st>>>(idx->s_stats.as<u32>(), idx->s_mean.as<float>(), idx->F, idx->E,
+                                                             idx->s_field.as<ScreenField>());
         HIPCHK(hipGetLastError());
         const long long n_gran = (long long)idx->n_blk * idx->n_steps * 128;
         mfar_screen_build_kernel<<<dim3((unsigned)((n_gran + 255) / 256), idx->F), dim3(256), 0, st>>>(
-            (const float*)idx->slab, (_Float16*)idx->screen, idx->field_stride, n_gran, idx->s_field.as<ScreenField>());
+            (const float*)idx->slab, (_Float16*)idx->screen, idx->field_stride, n_gran, idx->n_steps, idx->s_mean.as<float>(),
+            idx->s_field.as<ScreenField>());
         HIPCHK(hipGetLastError());
         idx->screen_dirty = false;
     }
@@ -641,6 +651,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     RETCHK(sl.qinfo.ensure(64 * sizeof(ScreenQuery)));
     RETCHK(sl.eps.ensure((size_t)F * 64 * 4));
     RETCHK(sl.base.ensure((size_t)F * 64 * 4));
+    RETCHK(sl.qm.ensure((size_t)F * 64 * 4));
     if (!sl.fail.p) {
         RETCHK(sl.fail.ensure((size_t)(MFAR_MAX_FIELDS + 2) * 4));
         HIPCHK(hipMemsetAsync(sl.fail.p, 0, (size_t)(MFAR_MAX_FIELDS + 2) * 4, st));
@@ -654,8 +665,9 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     if (phases & S1_PREPARE) {
         HIPCHK(hipMemsetAsync(fflags, 0, (size_t)(F + 1) * 4, st));   // field flags + "any"; [F+1] accumulates statistics
         mfar_screen_queries_kernel<<<dim3(64), dim3(256), 0, st>>>(q, (_Float16*)sl.qt16.p, sl.qinfo.as<ScreenQuery>(),
-                                                                   idx->s_field.as<ScreenField>(), sl.eps.as<float>(), sl.base.as<float>(),
-                                                                   q0, Q, idx->E, F, sentinel, idx->screen_eps_mult);
+                                                                   idx->s_field.as<ScreenField>(), idx->s_mean.as<float>(), sl.eps.as<float>(),
+                                                                   sl.base.as<float>(), sl.qm.as<float>(), q0, Q, idx->E, F, sentinel,
+                                                                   idx->screen_eps_mult);
         HIPCHK(hipGetLastError());
     }
     const S1Out so = {sl.sids.as<long long>(), sl.ssc.as<float>(), sl.scnt.as<int>(), 0, 0};
@@ -687,6 +699,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     cp.sf = idx->s_field.as<ScreenField>();
     cp.qinfo = sl.qinfo.as<ScreenQuery>();
     cp.eps = sl.eps.as<float>();
+    cp.qm = sl.qm.as<float>();
     cp.out_ids = fid;
     cp.out_scores = fsc;
     cp.fail = fflags;

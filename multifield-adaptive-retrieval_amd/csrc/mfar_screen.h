@@ -3,8 +3,10 @@
 // Stage 1 on an fp32 slab is bound by the fp32 MFMA rate.  The screen turns it into an HBM-bound pass at half the bytes
 // WITHOUT changing a single output bit:
 //
-//   1. the index keeps a second, fp16 copy of its rows (the "screen slab", same tiled layout as the bf16 slab), scaled per
-//      field by a power of two so that the field's largest |value| lands in [2^13, 2^14);
+//   1. the index keeps a second, fp16 copy of its rows (the "screen slab", same tiled layout as the bf16 slab): per field
+//      the rows are CENTRED on the field's mean vector m (real embeddings share a large common component; q.m shifts every
+//      score of the field by the same amount, so it cannot change the ranking, and the error bound then scales with
+//      |d - m| instead of |d|) and scaled by a power of two so that the largest |d_i - m_i| lands in [2^13, 2^14);
 //   2. stage 1 runs on the screen slab (v_mfma_f32_32x32x16_f16, queries scaled per query by a power of two and split into
 //      two fp16 terms) and keeps the k' = k + 64 best APPROXIMATE scores per (query, field);
 //   3. those k' rows are re-scored from the fp32 slab with the exact fma chain of the arithmetic contract
@@ -15,13 +17,16 @@
 //      and the exact fp32 MFMA pass (mfar_stage1_kernel) re-runs for that field only -- always launched, its workgroups
 //      exit at once when the flag is clear, so there is no host round trip.
 //
-// Error bound (K = dim, u16 = 2^-11, u32 = 2^-24; scaled operands Qi = qi * sq, Di = di * sf, powers of two = exact):
+// Error bound (K = dim, u16 = 2^-11, u32 = 2^-24; c = fl(d - m) the centred row, any vector m is valid; scaled operands
+// Qi = qi * sq, Di = ci * sf, powers of two = exact; approx = q.m (fp32) + MFMA sum / (sq sf)):
+//   centring          |fl(di - mi) - (di - mi)| <= u32 |ci|;  q.m computed in fp32: K u32 sum|qi||mi|
 //   doc rounding      |fp16(Di) - Di| <= u16 |Di| + 2^-25            (normal / subnormal fp16)
 //   query split       Qi = A + B + r,  |r| <= u16^2 |Qi| + 2^-25
 //   accumulation      the MFMA sums 2K exact products in fp32; we allow 2 u32 per addition in ANY order: (4K + 64) u32
 //   exact chain       the contract's fma chain itself: K u32
-//   => |approx - exact| <= [1.02 u16 + (5K + 64) u32] * sum|qi||di|  +  2^-24 (|q|_1 / sf + |d|_1 / sq)
-//   with sum|qi||di| <= |q|_2 |d|_2,  |x|_1 <= sqrt(K) |x|_2,  |d|_2 <= the field's largest row norm.
+//   => |approx - exact| <= [1.02 u16 + (4K + 66) u32] * sum|qi||ci| + K u32 (sum|qi||di| + sum|qi||mi|)
+//                          + 2^-24 (|q|_1 / sf + |c|_1 / sq)
+//   with sum|qi||xi| <= |q|_2 |x|_2,  |x|_1 <= sqrt(K) |x|_2,  |c|_2 <= the field's largest centred row norm,  |d| <= |c| + |m|.
 // The constant is multiplied by SCREEN_SLACK for margin; tests measure the real error (about 30x below the bound).
 #pragma once
 #include "mfar_device.h"
@@ -34,33 +39,63 @@
 #define SCREEN_SLACK 1.25f
 
 struct ScreenField {     // per field, written by mfar_screen_scale_kernel
-    float scale;         // sf = 2^e: fp16 value = fp32 value * sf
+    float scale;         // sf = 2^e: fp16 value = (fp32 value - mean) * sf
     float inv_scale;
-    float dnorm_max;     // largest row 2-norm of the field (inf / NaN when the field holds non-finite values)
-    float pad;
+    float dnorm_max;     // largest 2-norm of a centred row of the field (inf / NaN when the field holds non-finite values)
+    float mnorm;         // 2-norm of the field's mean vector
 };
 struct ScreenQuery {     // per query of the current 64-query block
     float scale, inv_scale, norm, pad;
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// Build: per-field statistics of the fp32 slab, then the conversion.  grid = (n_blk, F), block 256.
+// Build, step 1: the per-field mean vector (row-major [F][E]).  Its exact value is irrelevant for correctness -- ANY
+// vector m works, it only has to be the same one everywhere -- so plain float atomics are fine.
+//   grid = (ceil(n_blk / 8), F), block 256; thread eq owns dims 4 eq .. 4 eq + 3 and walks the rows of 8 blocks.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mfar_screen_mean_kernel(const float* __restrict__ slab, long long field_stride, int n_steps,
+                                                               long long n_blk, long long n_rows, float* __restrict__ acc) {
+    const int f = blockIdx.y, E = n_steps * 16;
+    const long long b0 = (long long)blockIdx.x * 8, b1 = b0 + 8 < n_blk ? b0 + 8 : n_blk;
+    for (int eq = threadIdx.x; eq < E / 4; eq += blockDim.x) {
+        const int e = eq * 4;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (long long b = b0; b < b1; ++b) {
+            const long long nr = n_rows - b * 64 < 64 ? n_rows - b * 64 : 64;
+            for (int rr = 0; rr < nr; ++rr) sum += *(const f32x4*)(slab + (size_t)f * field_stride + tiled_offset(n_steps, b * 64 + rr, e));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(&acc[(size_t)f * E + e + i], sum[i]);
+    }
+}
+__global__ void mfar_screen_mean_finish_kernel(float* __restrict__ acc, int n, long long n_rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] = n_rows > 0 ? acc[i] / (float)n_rows : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Build, step 2: per-field statistics of the CENTRED rows, then the conversion.  grid = (n_blk, F), block 256.
 // stats[2f] = max |value| bits, stats[2f+1] = max row norm^2 bits (non-negative floats order like their bit patterns;
 // NaN bits are above inf bits, so a non-finite value poisons the field's maximum as intended).
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) mfar_screen_stats_kernel(const float* __restrict__ slab, long long field_stride, int n_steps,
+                                                                long long n_rows, const float* __restrict__ mean,
                                                                 u32* __restrict__ stats) {
     const int f = blockIdx.y;
+    const int rr = threadIdx.x >> 2, pp = threadIdx.x & 3;
+    const bool live = (long long)blockIdx.x * 64 + rr < n_rows;   // padding rows are not part of the field
     const float* tile = slab + (size_t)f * field_stride + (size_t)blockIdx.x * n_steps * 1024 + threadIdx.x * 4;
+    const float* mrow = mean + (size_t)f * n_steps * 16 + ((pp ^ ((rr >> 2) & 3)) << 2);
     float amax = 0.0f, ss = 0.0f;
-    for (int s = 0; s < n_steps; ++s) {
-        const f32x4 v = *(const f32x4*)(tile + (size_t)s * 1024);
+    if (live)
+        for (int s = 0; s < n_steps; ++s) {
+            const f32x4 v = *(const f32x4*)(tile + (size_t)s * 1024) - *(const f32x4*)(mrow + s * 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            amax = fmaxf(amax, fabsf(v[i]));
-            ss = __builtin_fmaf(v[i], v[i], ss);
+            for (int i = 0; i < 4; ++i) {
+                amax = fmaxf(amax, fabsf(v[i]));
+                ss = __builtin_fmaf(v[i], v[i], ss);
+            }
         }
-    }
     // threads 4r .. 4r+3 hold the four 16-byte pieces of row r
     ss += __shfl_xor(ss, 1);
     ss += __shfl_xor(ss, 2);
@@ -84,25 +119,28 @@ __device__ __forceinline__ float screen_pow2_scale(float amax) {
     return __uint_as_float((u32)(e + 127) << 23);
 }
 
-__global__ void mfar_screen_scale_kernel(const u32* __restrict__ stats, int F, ScreenField* __restrict__ sf) {
+__global__ void mfar_screen_scale_kernel(const u32* __restrict__ stats, const float* __restrict__ mean, int F, int E,
+                                         ScreenField* __restrict__ sf) {
     const int f = threadIdx.x;
     if (f >= F) return;
     const float amax = __uint_as_float(stats[2 * f]);
     const float n2 = __uint_as_float(stats[2 * f + 1]);
+    float m2 = 0.0f;
+    for (int e = 0; e < E; ++e) m2 = __builtin_fmaf(mean[(size_t)f * E + e], mean[(size_t)f * E + e], m2);
     ScreenField o;
     o.scale = screen_pow2_scale(amax);
     o.inv_scale = 1.0f / o.scale;
-    // the fp32 sum of squares can be low by K u32 relative: lean up, the bound must not shrink
+    // the fp32 sums of squares can be low by K u32 relative: lean up, the bound must not shrink
     o.dnorm_max = sqrtf(n2) * 1.0001f;
-    o.pad = 0.0f;
+    o.mnorm = sqrtf(m2) * 1.0001f;
     sf[f] = o;
 }
 
-// fp32 tiled slab -> fp16 tiled screen slab.  One thread per 16-byte output granule (8 dims).
+// fp32 tiled slab -> fp16 tiled screen slab (centred, scaled).  One thread per 16-byte output granule (8 dims).
 // grid = (ceil(n_blk * n_steps * 128 / 256), F)
 __global__ void __launch_bounds__(256) mfar_screen_build_kernel(const float* __restrict__ slab, _Float16* __restrict__ screen,
-                                                                long long field_stride, long long n_granules,
-                                                                const ScreenField* __restrict__ sf) {
+                                                                long long field_stride, long long n_granules, int n_steps,
+                                                                const float* __restrict__ mean, const ScreenField* __restrict__ sf) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_granules) return;
     const int f = blockIdx.y;
@@ -110,9 +148,11 @@ __global__ void __launch_bounds__(256) mfar_screen_build_kernel(const float* __r
     const long long tile = g >> 7;           // 128 granules per [64][16] tile
     const int rr = (int)(g >> 1) & 63, c8 = (int)g & 1;
     const int sw = (rr >> 2) & 3;
+    const int step = (int)(tile % n_steps);
     const float* src = slab + (size_t)f * field_stride + (size_t)tile * 1024 + rr * 16;
-    const f32x4 a = *(const f32x4*)(src + (((2 * c8) ^ sw) << 2));
-    const f32x4 b = *(const f32x4*)(src + (((2 * c8 + 1) ^ sw) << 2));
+    const float* m = mean + (size_t)f * n_steps * 16 + step * 16 + c8 * 8;
+    const f32x4 a = *(const f32x4*)(src + (((2 * c8) ^ sw) << 2)) - *(const f32x4*)m;
+    const f32x4 b = *(const f32x4*)(src + (((2 * c8 + 1) ^ sw) << 2)) - *(const f32x4*)(m + 4);
     f16x8 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -129,9 +169,10 @@ __global__ void __launch_bounds__(256) mfar_screen_build_kernel(const float* __r
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* __restrict__ q, _Float16* __restrict__ qt,
                                                                   ScreenQuery* __restrict__ qinfo, const ScreenField* __restrict__ sf,
-                                                                  float* __restrict__ eps, float* __restrict__ tau_base, int q0,
+                                                                  const float* __restrict__ mean, float* __restrict__ eps,
+                                                                  float* __restrict__ tau_base, float* __restrict__ qm_out, int q0,
                                                                   int Q, int E, int F, int sentinel, float eps_mult) {
-    __shared__ float red_a[4], red_s[4];
+    __shared__ float red_a[4], red_s[4], red_m[4 * MFAR_MAX_FIELDS];
     const int r = blockIdx.x;
     const bool live = q0 + r < Q;
     const float* row = q + (size_t)(q0 + (live ? r : 0)) * E;
@@ -173,6 +214,15 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
         *(f16x8*)(base + in_tile) = hi;
         *(f16x8*)(base + 1024 + in_tile) = lo;
     }
+    // q . mean of every field (any summation order: it is part of the approximation, its error is budgeted in eps)
+    for (int f = 0; f < F; ++f) {
+        float pm = 0.0f;
+        if (live)
+            for (int e = threadIdx.x; e < E; e += blockDim.x) pm = __builtin_fmaf(row[e], mean[(size_t)f * E + e], pm);
+        for (int off = 32; off > 0; off >>= 1) pm += __shfl_xor(pm, off);
+        if ((threadIdx.x & 63) == 0) red_m[4 * f + (threadIdx.x >> 6)] = pm;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         ScreenQuery o;
         o.scale = sq;
@@ -184,17 +234,23 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
     if ((int)threadIdx.x < F) {
         const int f = threadIdx.x;
         const ScreenField s = sf[f];
-        const float K = (float)E;
-        const float c_rel = 1.02f * 4.8828125e-4f + (5.0f * K + 64.0f) * 5.9604645e-8f;
-        const float c_abs = 5.9604645e-8f * sqrtf(K) * 1.0001f;
-        float e_ = SCREEN_SLACK * (c_rel * qn * s.dnorm_max + c_abs * (qn * s.inv_scale + s.dnorm_max / sq));
+        const float K = (float)E, u32f = 5.9604645e-8f;
+        const float qm = (red_m[4 * f] + red_m[4 * f + 1]) + (red_m[4 * f + 2] + red_m[4 * f + 3]);
+        const float c_rel = 1.02f * 4.8828125e-4f + (4.0f * K + 66.0f) * u32f;
+        const float c_abs = u32f * sqrtf(K) * 1.0001f;
+        float e_ = SCREEN_SLACK * (c_rel * qn * s.dnorm_max + K * u32f * qn * (s.dnorm_max + 2.0f * s.mnorm) +
+                                   c_abs * (qn * s.inv_scale + s.dnorm_max / sq));
         e_ *= eps_mult;
         if (!live) e_ = 0.0f;
         eps[f * 64 + r] = e_;
-        // rows whose approximate score is below -eps have exact score < 0 and can never beat the zero sentinel
-        // (index.py:192-193); NaN eps (non-finite data) -> -inf: keep everything, the certificate fails anyway
+        qm_out[f * 64 + r] = live ? qm : 0.0f;
+        // rows with (approximate score + q.m) below -eps have exact score < 0 and can never beat the zero sentinel
+        // (index.py:192-193); NaN (non-finite data) -> -inf: keep everything, the certificate fails anyway
         float tb = -__builtin_inff();
-        if (sentinel && live && e_ == e_) tb = -(e_ * sq * s.scale) * 1.0001f;
+        if (sentinel && live && e_ == e_ && qm == qm) {
+            const float t_real = -qm - e_;                                 // threshold for the centred part, real units
+            tb = (t_real - fabsf(t_real) * 1e-4f - 1e-30f) * sq * s.scale;
+        }
         tau_base[f * 64 + r] = live ? tb : __builtin_inff();
     }
 }
@@ -210,6 +266,7 @@ struct CertifyParams {
     const ScreenField* sf;
     const ScreenQuery* qinfo;
     const float* eps;         // [F, 64]
+    const float* qm;          // [F, 64]  q . mean(field): added back to the centred approximate scores
     long long* out_ids;       // [Q, F, k]
     float* out_scores;
     int* fail;                // [F] field flags, [F] = any, [F+1] = failed (query, field) pairs (statistics)
@@ -236,7 +293,7 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
     if (threadIdx.x == 0) {
         bool ok = true;
         if (cnt == p.kp) {  // the list is full: rows outside it exist
-            const float a_real = (p.ssc[lb + p.kp - 1] * p.qinfo[ql].inv_scale) * p.sf[f].inv_scale;
+            const float a_real = (p.ssc[lb + p.kp - 1] * p.qinfo[ql].inv_scale) * p.sf[f].inv_scale + p.qm[f * 64 + ql];
             const float bound = a_real + p.eps[f * 64 + ql];       // every outside row scores <= bound (exactly)
             if (m == p.k) ok = bound < key_score(sorted[p.k - 1]); // ... strictly below the exact k-th best
             else ok = bound <= tau0;                               // ... or cannot pass the sentinel at all

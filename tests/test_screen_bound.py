@@ -1,5 +1,5 @@
 """The error bound behind the fp16 screen's certificate (csrc/mfar_screen.h), checked on the CPU against a numpy emulation
-of the screen arithmetic: power-of-two scaling, fp16 rounding of the rows, two-term fp16 split of the query, products
+of the screen arithmetic: centring on the field mean, power-of-two scaling, fp16 rounding of the rows, two-term fp16 split of the query, products
 summed without further error (float64) -- i.e. every error source except the MFMA's own fp32 accumulation, which the bound
 budgets separately with (4K + 64) u32.  The exact side is the oracle's fma chain (the arithmetic contract)."""
 import numpy as np
@@ -17,34 +17,42 @@ def _pow2_scale(amax):
     return float(2.0 ** max(-100, min(100, e)))
 
 
-def _eps(qn, dn, sq, sf, K):
-    c_rel = 1.02 * U16 + (5.0 * K + 64.0) * U32
+def _eps(qn, dn, mn, sq, sf, K):
+    c_rel = 1.02 * U16 + (4.0 * K + 66.0) * U32
     c_abs = U32 * np.sqrt(K) * 1.0001
-    return SLACK * (c_rel * qn * dn + c_abs * (qn / sf + dn / sq))
+    return SLACK * (c_rel * qn * dn + K * U32 * qn * (dn + 2.0 * mn) + c_abs * (qn / sf + dn / sq))
 
 
-@pytest.mark.parametrize("E,scale,seed", [(32, 1.0, 0), (768, 1.0, 1), (768, 1e-3, 2), (256, 3e4, 3), (96, 1e-20, 4)])
-def test_screen_error_bound_holds(E, scale, seed):
+@pytest.mark.parametrize("E,scale,seed,shift", [(32, 1.0, 0, 0.0), (768, 1.0, 1, 0.0), (768, 1e-3, 2, 5.0), (256, 3e4, 3, 0.3),
+                                                 (96, 1e-20, 4, 0.0), (768, 1.0, 5, 40.0)])
+def test_screen_error_bound_holds(E, scale, seed, shift):
     rng = np.random.default_rng(seed)
     D, Q = 4000, 16
-    docs = (rng.standard_normal((D, E)) * rng.lognormal(0, 1.5, (D, 1)) * scale).astype(np.float32)
+    common = rng.standard_normal(E) * shift                 # a large shared component, like real sentence embeddings
+    docs = ((rng.standard_normal((D, E)) * rng.lognormal(0, 1.5, (D, 1)) + common) * scale).astype(np.float32)
     docs[::97] *= np.float32(1e-4)                      # rows deep in the fp16 subnormal range after scaling
     docs[5] = 0
     q = (rng.standard_normal((Q, E)) * rng.lognormal(0, 1, (Q, 1))).astype(np.float32)
     q[3, ::2] *= np.float32(1e-6)
     exact = O.c_scores(docs, q)
-    sf = _pow2_scale(float(np.abs(docs).max()))
-    dn = float(np.sqrt((docs.astype(np.float64) ** 2).sum(1).max()))
-    d16 = (docs * np.float32(sf)).astype(np.float16).astype(np.float64)
+    m = docs.mean(0, dtype=np.float32)                      # any vector works; the kernels use the field's mean
+    c = (docs - m).astype(np.float32)                       # fl(d - m)
+    sf = _pow2_scale(float(np.abs(c).max()))
+    dn = float(np.sqrt((c.astype(np.float64) ** 2).sum(1).max()))
+    mn = float(np.sqrt((m.astype(np.float64) ** 2).sum()))
+    d16 = (c * np.float32(sf)).astype(np.float16).astype(np.float64)
     worst = 0.0
     for i in range(Q):
         sq = _pow2_scale(float(np.abs(q[i]).max()))
         qs = q[i] * np.float32(sq)
         a = qs.astype(np.float16)
         b = (qs - a.astype(np.float32)).astype(np.float16)
-        approx = (d16 @ (a.astype(np.float64) + b.astype(np.float64))) / (sq * sf)
+        qm = np.float32(0)
+        for e in range(E):                                  # q . m in fp32, some summation order
+            qm = np.float32(qm + np.float32(q[i, e] * m[e]))
+        approx = (d16 @ (a.astype(np.float64) + b.astype(np.float64))) / (sq * sf) + float(qm)
         qn = float(np.sqrt((q[i].astype(np.float64) ** 2).sum()))
-        eps = _eps(qn, dn, sq, sf, E)
+        eps = _eps(qn, dn, mn, sq, sf, E)
         err = np.abs(approx - exact[i].astype(np.float64)).max()
         assert err <= eps, (i, err, eps)
         worst = max(worst, err / eps)
