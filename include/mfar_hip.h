@@ -172,7 +172,7 @@ int mfar_stream_wait_stage1_start(mfar_index* idx, void* stream);
  * Split-phase stage 1 for pipelined callers (device pointers, Q <= 64, asynchronous on `stream`).
  *   mfar_stage1_begin   query preparation, sample pass, the long scan and the list merge of batch `slot` (two slots,
  *                       0 / 1).  Without the fp16 screen this already leaves the final lists in field_ids / field_scores.
- *   mfar_stage1_finish  with the screen: exact re-scoring of the k + 64 screened rows per list and the certificate ->
+ *   mfar_stage1_finish  with the screen: exact re-scoring of the min(k + 92, 192) screened rows per list and the certificate ->
  *                       field_ids / field_scores [Q, n_fields, k], exactly what mfar_retrieve_fields returns; without:
  *                       nothing.  May run on another stream than begin (the caller orders finish after begin with an
  *                       event) and beside the begin of the OTHER slot -- its kernels are small enough to be resident next
@@ -200,7 +200,7 @@ int mfar_set_wgs_per_cu(mfar_index* idx, int wgs);
 /*
  * Certified fp16 screening of an fp32 index (no reference counterpart; the outputs of every entry point above are
  * bit-identical with and without it).  Stage 1 of an fp32 index is bound by the fp32 MFMA rate; with the screen it
- * scans a half-size fp16 copy of the rows for the k + 64 best approximate scores per (query, field), re-scores those
+ * scans a half-size fp16 copy of the rows for the min(k + 92, 192) best approximate scores per (query, field), re-scores those
  * rows exactly from the fp32 slab, and PROVES from a rigorous error bound that no other row can enter or tie into
  * the exact top-k; a field whose proof fails is re-done by the exact fp32 pass on the device (csrc/mfar_screen.h).
  * The screen slab (+50 % HBM) is built lazily by the first search after rows were written.

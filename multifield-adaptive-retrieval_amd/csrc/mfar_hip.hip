@@ -568,7 +568,7 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, int phases, int 
 // ------------------------------------------------------------------------------------------------ fp16 screen
 static bool screen_wanted(const mfar_index* idx, int k) {
     if (idx->dtype != MFAR_DTYPE_F32 || idx->screen_mode == 0 || idx->screen_nomem) return false;
-    if (k + SCREEN_EXTRA > SCREEN_MAX_KP) return false;
+    if (k + SCREEN_EXTRA_MIN > SCREEN_MAX_KP) return false;
     if (idx->E * 4 > 60 * 1024) return false;   // the re-scoring kernel stages a query row in LDS
     return idx->screen_mode >= 2 || idx->n_rows >= 16384;
 }
@@ -622,7 +622,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
                         float* fsc, int* any_fail_out, hipStream_t st) {
     mfar_index::S1Slot& sl = idx->s1[slot];
     const float tau0 = sentinel ? 0.0f : -INFINITY;
-    const int F = idx->F, kp = k + SCREEN_EXTRA;
+    const int F = idx->F, kp = std::min(k + SCREEN_EXTRA, SCREEN_MAX_KP);
     const int qt_n = std::min(64, Q - q0);
     const bool bf16 = idx->dtype == MFAR_DTYPE_BF16;
     if (phases & S1_PREPARE) {

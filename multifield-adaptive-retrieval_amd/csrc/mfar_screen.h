@@ -8,7 +8,7 @@
 //      score of the field by the same amount, so it cannot change the ranking, and the error bound then scales with
 //      |d - m| instead of |d|) and scaled by a power of two so that the largest |d_i - m_i| lands in [2^13, 2^14);
 //   2. stage 1 runs on the screen slab (v_mfma_f32_32x32x16_f16, queries scaled per query by a power of two and split into
-//      two fp16 terms) and keeps the k' = k + 64 best APPROXIMATE scores per (query, field);
+//      two fp16 terms) and keeps the k' = min(k + 92, 192) best APPROXIMATE scores per (query, field);
 //   3. those k' rows are re-scored from the fp32 slab with the exact fma chain of the arithmetic contract
 //      (mfar_score_candidates_kernel, per-field mode) and the exact top-k is taken from them;
 //   4. the result is CERTIFIED: with eps(q, f) a rigorous bound of |approx - exact| for every row of the field, every row
@@ -32,9 +32,9 @@
 #include "mfar_device.h"
 #include "mfar_stage1.h"
 
-#ifndef SCREEN_EXTRA
-#define SCREEN_EXTRA 64          // k' = k + SCREEN_EXTRA
-#endif
+#define SCREEN_EXTRA_MIN 64       // the screen is used only when at least this margin fits: k + 64 <= SCREEN_MAX_KP
+#define SCREEN_EXTRA 92          // k' = min(k + SCREEN_EXTRA, SCREEN_MAX_KP): 192 for the reference's k = 100 (a wider margin
+                                 // costs ~1 % and makes a failed certificate -- a 0.9 ms exact pass per field -- rarer)
 #define SCREEN_MAX_KP S1_MAX_DEPTH   // the stage-1 lists compact to k', which must leave room for one tile of appends
 #define SCREEN_SLACK 1.25f
 
