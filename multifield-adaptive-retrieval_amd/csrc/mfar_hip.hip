@@ -84,7 +84,7 @@ struct mfar_index {
     // batch i+1 scans on another (mfar_stage1_begin / mfar_stage1_finish)
     struct S1Slot {
         DevBuf qt, lists, list_cnt, gtau, samp;                          // any pass
-        DevBuf qt16, qinfo, eps, base, qm, fail, sids, ssc, scnt, sx;    // fp16 screen
+        DevBuf qt16, qinfo, eps, base, fail, sids, ssc, scnt, sx;        // fp16 screen
         bool screened = false;                                          // decided by the begin phase of the batch
     } s1[2];
     DevBuf fid, fsc, cand[2], ncand[2], x[2], own[2], in[8], out[8];
@@ -203,7 +203,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
                       &idx->own[0], &idx->own[1], &idx->s_stats, &idx->s_field, &idx->s_mean};
     for (DevBuf* b : bufs) b->release();
     for (auto& sl : idx->s1) {
-        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.qm, &sl.fail, &sl.sids,
+        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
                         &sl.ssc, &sl.scnt, &sl.sx};
         for (DevBuf* b : sb) b->release();
     }
@@ -651,7 +651,6 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     RETCHK(sl.qinfo.ensure(64 * sizeof(ScreenQuery)));
     RETCHK(sl.eps.ensure((size_t)F * 64 * 4));
     RETCHK(sl.base.ensure((size_t)F * 64 * 4));
-    RETCHK(sl.qm.ensure((size_t)F * 64 * 4));
     if (!sl.fail.p) {
         RETCHK(sl.fail.ensure((size_t)(MFAR_MAX_FIELDS + 2) * 4));
         HIPCHK(hipMemsetAsync(sl.fail.p, 0, (size_t)(MFAR_MAX_FIELDS + 2) * 4, st));
@@ -665,9 +664,8 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     if (phases & S1_PREPARE) {
         HIPCHK(hipMemsetAsync(fflags, 0, (size_t)(F + 1) * 4, st));   // field flags + "any"; [F+1] accumulates statistics
         mfar_screen_queries_kernel<<<dim3(64), dim3(256), 0, st>>>(q, (_Float16*)sl.qt16.p, sl.qinfo.as<ScreenQuery>(),
-                                                                   idx->s_field.as<ScreenField>(), idx->s_mean.as<float>(), sl.eps.as<float>(),
-                                                                   sl.base.as<float>(), sl.qm.as<float>(), q0, Q, idx->E, F, sentinel,
-                                                                   idx->screen_eps_mult);
+                                                                   idx->s_field.as<ScreenField>(), sl.eps.as<float>(), sl.base.as<float>(),
+                                                                   q0, Q, idx->E, F, idx->screen_eps_mult);
         HIPCHK(hipGetLastError());
     }
     const S1Out so = {sl.sids.as<long long>(), sl.ssc.as<float>(), sl.scnt.as<int>(), 0, 0};
@@ -699,7 +697,9 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     cp.sf = idx->s_field.as<ScreenField>();
     cp.qinfo = sl.qinfo.as<ScreenQuery>();
     cp.eps = sl.eps.as<float>();
-    cp.qm = sl.qm.as<float>();
+    cp.q = q + (size_t)q0 * idx->E;
+    cp.mean = idx->s_mean.as<float>();
+    cp.E = idx->E;
     cp.out_ids = fid;
     cp.out_scores = fsc;
     cp.fail = fflags;

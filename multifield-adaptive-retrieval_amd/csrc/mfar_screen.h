@@ -169,17 +169,35 @@ __global__ void __launch_bounds__(256) mfar_screen_build_kernel(const float* __r
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* __restrict__ q, _Float16* __restrict__ qt,
                                                                   ScreenQuery* __restrict__ qinfo, const ScreenField* __restrict__ sf,
-                                                                  const float* __restrict__ mean, float* __restrict__ eps,
-                                                                  float* __restrict__ tau_base, float* __restrict__ qm_out, int q0,
-                                                                  int Q, int E, int F, int sentinel, float eps_mult) {
-    __shared__ float red_a[4], red_s[4], red_m[4 * MFAR_MAX_FIELDS];
+                                                                  float* __restrict__ eps, float* __restrict__ tau_base, int q0, int Q,
+                                                                  int E, int F, float eps_mult) {
+    __shared__ float red_a[4], red_s[4];
     const int r = blockIdx.x;
     const bool live = q0 + r < Q;
     const float* row = q + (size_t)(q0 + (live ? r : 0)) * E;
+    // ONE round of global loads (this kernel opens a batch on the critical path, usually while the previous batch's gathers
+    // saturate the memory system: every dependent round trip costs tens of microseconds there): each thread keeps its up to
+    // 8 granules of 8 query values in registers, the field constants are fetched alongside
+    constexpr int NG = 8;   // dim <= 8 * 256 * NG
+    const int gpr = E >> 3;
+    f32x4 va[NG][2];
+    ScreenField fld = {};
+    if ((int)threadIdx.x < F) fld = sf[threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int g = (int)threadIdx.x + 256 * i;
+        va[i][0] = va[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (live && g < gpr) {
+            va[i][0] = *(const f32x4*)(row + g * 8);
+            va[i][1] = *(const f32x4*)(row + g * 8 + 4);
+        }
+    }
     float amax = 0.0f, ss = 0.0f;
-    if (live)
-        for (int e = threadIdx.x; e < E; e += blockDim.x) {
-            const float v = row[e];
+#pragma unroll
+    for (int i = 0; i < NG; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = va[i][j >> 2][j & 3];
             amax = fmaxf(amax, fabsf(v));
             ss = __builtin_fmaf(v, v, ss);
         }
@@ -197,16 +215,18 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
     const float sq = screen_pow2_scale(amax);
     const float qn = sqrtf(ss) * 1.0001f;   // the fp32 sum of squares can be low by K u32 relative: lean up
     // split tiles
-    const int gpr = E >> 3;
-    for (int g = threadIdx.x; g < gpr; g += blockDim.x) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int g = (int)threadIdx.x + 256 * i;
+        if (g >= gpr) continue;
         const int e = g << 3;
         f16x8 hi, lo;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float x = live ? row[e + i] * sq : 0.0f;
+        for (int j = 0; j < 8; ++j) {
+            const float x = va[i][j >> 2][j & 3] * sq;
             const _Float16 a = (_Float16)x;
-            hi[i] = a;
-            lo[i] = (_Float16)(x - (float)a);
+            hi[j] = a;
+            lo[j] = (_Float16)(x - (float)a);
         }
         const int step = e >> 4;
         const size_t in_tile = tiled_offset_bf16(E >> 4, r, e) - (size_t)step * 1024;
@@ -214,15 +234,6 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
         *(f16x8*)(base + in_tile) = hi;
         *(f16x8*)(base + 1024 + in_tile) = lo;
     }
-    // q . mean of every field (any summation order: it is part of the approximation, its error is budgeted in eps)
-    for (int f = 0; f < F; ++f) {
-        float pm = 0.0f;
-        if (live)
-            for (int e = threadIdx.x; e < E; e += blockDim.x) pm = __builtin_fmaf(row[e], mean[(size_t)f * E + e], pm);
-        for (int off = 32; off > 0; off >>= 1) pm += __shfl_xor(pm, off);
-        if ((threadIdx.x & 63) == 0) red_m[4 * f + (threadIdx.x >> 6)] = pm;
-    }
-    __syncthreads();
     if (threadIdx.x == 0) {
         ScreenQuery o;
         o.scale = sq;
@@ -233,9 +244,8 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
     }
     if ((int)threadIdx.x < F) {
         const int f = threadIdx.x;
-        const ScreenField s = sf[f];
+        const ScreenField s = fld;
         const float K = (float)E, u32f = 5.9604645e-8f;
-        const float qm = (red_m[4 * f] + red_m[4 * f + 1]) + (red_m[4 * f + 2] + red_m[4 * f + 3]);
         const float c_rel = 1.02f * 4.8828125e-4f + (4.0f * K + 66.0f) * u32f;
         const float c_abs = u32f * sqrtf(K) * 1.0001f;
         float e_ = SCREEN_SLACK * (c_rel * qn * s.dnorm_max + K * u32f * qn * (s.dnorm_max + 2.0f * s.mnorm) +
@@ -243,15 +253,10 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
         e_ *= eps_mult;
         if (!live) e_ = 0.0f;
         eps[f * 64 + r] = e_;
-        qm_out[f * 64 + r] = live ? qm : 0.0f;
-        // rows with (approximate score + q.m) below -eps have exact score < 0 and can never beat the zero sentinel
-        // (index.py:192-193); NaN (non-finite data) -> -inf: keep everything, the certificate fails anyway
-        float tb = -__builtin_inff();
-        if (sentinel && live && e_ == e_ && qm == qm) {
-            const float t_real = -qm - e_;                                 // threshold for the centred part, real units
-            tb = (t_real - fabsf(t_real) * 1e-4f - 1e-30f) * sq * s.scale;
-        }
-        tau_base[f * 64 + r] = live ? tb : __builtin_inff();
+        // starting threshold of the screened pass: none for live queries (the zero sentinel of index.py:192-193 is applied
+        // to the EXACT scores by the certify kernel; deciding it here would need q.m on the critical path), +inf for the
+        // padding queries of a short batch so that they append nothing
+        tau_base[f * 64 + r] = live ? -__builtin_inff() : __builtin_inff();
     }
 }
 
@@ -266,7 +271,9 @@ struct CertifyParams {
     const ScreenField* sf;
     const ScreenQuery* qinfo;
     const float* eps;         // [F, 64]
-    const float* qm;          // [F, 64]  q . mean(field): added back to the centred approximate scores
+    const float* q;           // [Qt, E] the block's queries (row-major)
+    const float* mean;        // [F, E] field means: q . mean is added back to the centred approximate scores
+    int E;
     long long* out_ids;       // [Q, F, k]
     float* out_scores;
     int* fail;                // [F] field flags, [F] = any, [F+1] = failed (query, field) pairs (statistics)
@@ -289,11 +296,19 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
     __syncthreads();
     const int n = red[32];
     const int m = block_topk_sorted<1>(keys, n, p.k, sel, sorted, red);
+    // q . mean(field) (any summation order: part of the approximation, budgeted in eps)
+    float pm = 0.0f;
+    for (int e = threadIdx.x; e < p.E; e += blockDim.x) pm = __builtin_fmaf(p.q[(size_t)ql * p.E + e], p.mean[(size_t)f * p.E + e], pm);
+    for (int off = 32; off > 0; off >>= 1) pm += __shfl_xor(pm, off);
+    __shared__ float qm_s[4];
+    if ((threadIdx.x & 63) == 0) qm_s[threadIdx.x >> 6] = pm;
+    __syncthreads();
     // certificate
     if (threadIdx.x == 0) {
         bool ok = true;
         if (cnt == p.kp) {  // the list is full: rows outside it exist
-            const float a_real = (p.ssc[lb + p.kp - 1] * p.qinfo[ql].inv_scale) * p.sf[f].inv_scale + p.qm[f * 64 + ql];
+            const float qm = (qm_s[0] + qm_s[1]) + (qm_s[2] + qm_s[3]);
+            const float a_real = (p.ssc[lb + p.kp - 1] * p.qinfo[ql].inv_scale) * p.sf[f].inv_scale + qm;
             const float bound = a_real + p.eps[f * 64 + ql];       // every outside row scores <= bound (exactly)
             if (m == p.k) ok = bound < key_score(sorted[p.k - 1]); // ... strictly below the exact k-th best
             else ok = bound <= tau0;                               // ... or cannot pass the sentinel at all
