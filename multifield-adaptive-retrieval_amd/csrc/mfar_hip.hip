@@ -410,7 +410,7 @@ static int launch_s1(int kind, bool sample, unsigned grid, hipStream_t st, const
     } else {
         // register-ring variants (docs straight into VGPRs, 25 / 37 KB of LDS) when the k-steps divide into the 6 register slots
         static const bool regring = !(getenv("MFAR_S1_REGRING") && atoi(getenv("MFAR_S1_REGRING")) == 0);
-        const bool rr = regring && p.n_steps % 6 == 0;
+        const bool rr = regring && p.n_steps % 6 == 0 && (kind != S1_F16 || p.n_steps % S1HR_R == 0);
         if (kind == S1_BF16) {
             if (rr && sample) mfar_stage1_bf16r_sample_kernel<<<g, b, S1BR_LDS_BYTES, st>>>(p);
             else if (rr) mfar_stage1_bf16r_kernel<<<g, b, S1BR_LDS_BYTES, st>>>(p);

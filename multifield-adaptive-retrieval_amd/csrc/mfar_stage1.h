@@ -772,9 +772,12 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16_kernel(const S
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16_sample_kernel(const S1Params p) { s1_body_x16<0>(p); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16_kernel(const S1Params p) { s1_body_x16<1>(p); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16_sample_kernel(const S1Params p) { s1_body_x16<1>(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r_kernel(const S1Params p) { s1_body_x16r<1, 6>(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r_sample_kernel(const S1Params p) { s1_body_x16r<1, 6>(p); }
-#define S1HR_LDS_BYTES (6 * 4096 + S1_STATE_BYTES_(S1_SCAP_REG))
+#ifndef S1HR_R
+#define S1HR_R 6
+#endif
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r_kernel(const S1Params p) { s1_body_x16r<1, S1HR_R>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r_sample_kernel(const S1Params p) { s1_body_x16r<1, S1HR_R>(p); }
+#define S1HR_LDS_BYTES (S1HR_R * 4096 + S1_STATE_BYTES_(S1_SCAP_REG))
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r_kernel(const S1Params p) { s1_body_x16r<0, 6>(p); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r_sample_kernel(const S1Params p) { s1_body_x16r<0, 6>(p); }
 #define S1BR_LDS_BYTES (6 * 6144 + S1_STATE_BYTES_(S1_SCAP_REG / 2))
