@@ -69,6 +69,21 @@ def main():
                     ok = False
                     print("MISMATCH", dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, dtype=dtype, kind=int(kind), screen=screen, f=f,
                                            seed=seed, n=n), flush=True)
+        if ok and dtype == "f32" and D * F * E * Q < 3e9 and F * k <= 4096:    # the whole scorer, both stage-1 paths
+            W = (rng.standard_normal((E, F)) * 0.05).astype(np.float32)
+            mask = (rng.random(F) < 0.8).astype(np.float32)
+            o = O.c_two_stage(slab, q, W, mask, k1=k, k2=k, sentinel=sentinel)
+            for screen in (0, 2):
+                ix.set_screen(screen)
+                try:
+                    r = ix.search(q, W, mask, k1=k, k2=k, sentinel=sentinel)
+                except Exception as e:      # fewer than k2 candidates raises like torch.topk: compare the valid prefix instead
+                    r = None
+                if r is not None and not (np.array_equal(r["ids"], o["ids"]) and
+                                          np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32))):
+                    ok = False
+                    print("MISMATCH two-stage", dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, kind=int(kind), screen=screen,
+                                                     seed=seed, n=n), flush=True)
         st = ix.screen_stats() if dtype == "f32" else {}
         ix.close()
         n += 1
