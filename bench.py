@@ -166,7 +166,7 @@ def main():
         esize = 2 if (args.dtype == "bf16" or screened) else 4
         bytes_per_launch = float(row1 - row0) * F * E * esize    # the scanned slab is read once per batch
         # 16-bit passes: the register-ring kernels ("...r") run when dim / 16 divides into their 6 register slots
-        rr = "r" if (E // 16) % 6 == 0 and os.environ.get("MFAR_S1_REGRING", "1") != "0" else ""
+        rr = "" if os.environ.get("MFAR_S1_REGRING", "1") == "0" else ("r" if (E // 16) % 6 == 0 else ("r4" if (E // 16) % 4 == 0 else ""))
         s1_kernel = f"mfar_stage1_bf16{rr}_kernel" if args.dtype == "bf16" else (f"mfar_stage1_f16{rr}_kernel" if screened else "mfar_stage1_kernel")
         achieved_tf = flops_per_launch / (s1_avg_ms * 1e-3) / 1e12 if s1_avg_ms > 0 else 0.0
         traffic = None          # HBM bytes per stage-1 launch from the committed PMC pass of this same workload

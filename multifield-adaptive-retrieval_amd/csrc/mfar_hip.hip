@@ -125,6 +125,10 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16r_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HR_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16r_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BR_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16r_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BR_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16r4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HR4_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16r4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HR4_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16r4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BR4_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16r4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BR4_LDS_BYTES));
     g_attr_done[device] = true;
     return MFAR_OK;
 }
@@ -410,15 +414,19 @@ static int launch_s1(int kind, bool sample, unsigned grid, hipStream_t st, const
     } else {
         // register-ring variants (docs straight into VGPRs, 25 / 37 KB of LDS) when the k-steps divide into the 6 register slots
         static const bool regring = !(getenv("MFAR_S1_REGRING") && atoi(getenv("MFAR_S1_REGRING")) == 0);
-        const bool rr = regring && p.n_steps % 6 == 0 && (kind != S1_F16 || p.n_steps % S1HR_R == 0);
+        const int R = !regring ? 0 : (p.n_steps % 6 == 0 && (kind != S1_F16 || S1HR_R == 6) ? 6 : (p.n_steps % 4 == 0 ? 4 : 0));
         if (kind == S1_BF16) {
-            if (rr && sample) mfar_stage1_bf16r_sample_kernel<<<g, b, S1BR_LDS_BYTES, st>>>(p);
-            else if (rr) mfar_stage1_bf16r_kernel<<<g, b, S1BR_LDS_BYTES, st>>>(p);
+            if (R == 6 && sample) mfar_stage1_bf16r_sample_kernel<<<g, b, S1BR_LDS_BYTES, st>>>(p);
+            else if (R == 6) mfar_stage1_bf16r_kernel<<<g, b, S1BR_LDS_BYTES, st>>>(p);
+            else if (R == 4 && sample) mfar_stage1_bf16r4_sample_kernel<<<g, b, S1BR4_LDS_BYTES, st>>>(p);
+            else if (R == 4) mfar_stage1_bf16r4_kernel<<<g, b, S1BR4_LDS_BYTES, st>>>(p);
             else if (sample) mfar_stage1_bf16_sample_kernel<<<g, b, S1B_LDS_BYTES, st>>>(p);
             else mfar_stage1_bf16_kernel<<<g, b, S1B_LDS_BYTES, st>>>(p);
         } else {
-            if (rr && sample) mfar_stage1_f16r_sample_kernel<<<g, b, S1HR_LDS_BYTES, st>>>(p);
-            else if (rr) mfar_stage1_f16r_kernel<<<g, b, S1HR_LDS_BYTES, st>>>(p);
+            if (R == 6 && sample) mfar_stage1_f16r_sample_kernel<<<g, b, S1HR_LDS_BYTES, st>>>(p);
+            else if (R == 6) mfar_stage1_f16r_kernel<<<g, b, S1HR_LDS_BYTES, st>>>(p);
+            else if (R == 4 && sample) mfar_stage1_f16r4_sample_kernel<<<g, b, S1HR4_LDS_BYTES, st>>>(p);
+            else if (R == 4) mfar_stage1_f16r4_kernel<<<g, b, S1HR4_LDS_BYTES, st>>>(p);
             else if (sample) mfar_stage1_f16_sample_kernel<<<g, b, S1H_LDS_BYTES, st>>>(p);
             else mfar_stage1_f16_kernel<<<g, b, S1H_LDS_BYTES, st>>>(p);
         }

@@ -781,3 +781,12 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r_sample_kernel(
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r_kernel(const S1Params p) { s1_body_x16r<0, 6>(p); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r_sample_kernel(const S1Params p) { s1_body_x16r<0, 6>(p); }
 #define S1BR_LDS_BYTES (6 * 6144 + S1_STATE_BYTES_(S1_SCAP_REG / 2))
+// 4-slot twins for dims whose k-steps divide by 4 but not by 6 (64, 128, 256, 512, 1024, ...): measured equal to the 6-slot
+// ring; without them those dims would fall to the LDS ring, beside which nothing else fits on a CU
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r4_kernel(const S1Params p) { s1_body_x16r<1, 4>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r4_sample_kernel(const S1Params p) { s1_body_x16r<1, 4>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r4_kernel(const S1Params p) { s1_body_x16r<0, 4>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r4_sample_kernel(const S1Params p) { s1_body_x16r<0, 4>(p); }
+#define S1HR4_LDS_BYTES (4 * 4096 + S1_STATE_BYTES_(S1_SCAP_REG))
+#define S1BR4_LDS_BYTES (4 * 6144 + S1_STATE_BYTES_(S1_SCAP_REG / 2))
+
