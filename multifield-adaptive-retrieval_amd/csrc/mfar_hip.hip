@@ -525,8 +525,10 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, int phases, int 
             RETCHK(sl.samp.ensure((size_t)idx->F * n_wave_blocks * 128 * sizeof(float)));
             ps.samp_out = sl.samp.as<float>();
             RETCHK(launch_s1(kind, true, grid, st, ps));
-            mfar_sample_tau_kernel<<<dim3(64 * idx->F), dim3(256), 0, st>>>(ps.samp_out, n_wave_blocks, idx->F, k, p.tau0, tau_base,
-                                                                          sl.gtau.as<float>());
+            const dim3 tg((64 * idx->F + 3) / 4), tb(256);
+            if (2 * n_wave_blocks <= 512) mfar_sample_tau_kernel<8><<<tg, tb, 0, st>>>(ps.samp_out, n_wave_blocks, idx->F, k, p.tau0, tau_base, sl.gtau.as<float>());
+            else if (2 * n_wave_blocks <= 1024) mfar_sample_tau_kernel<16><<<tg, tb, 0, st>>>(ps.samp_out, n_wave_blocks, idx->F, k, p.tau0, tau_base, sl.gtau.as<float>());
+            else mfar_sample_tau_kernel<32><<<tg, tb, 0, st>>>(ps.samp_out, n_wave_blocks, idx->F, k, p.tau0, tau_base, sl.gtau.as<float>());
             HIPCHK(hipGetLastError());
         }
         p.gtau = sl.gtau.as<float>();

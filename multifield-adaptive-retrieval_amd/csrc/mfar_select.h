@@ -246,31 +246,40 @@ template <int NPT>
 __global__ void __launch_bounds__(256, 2) mfar_merge_lists_regs_kernel(const MergeParams p) { merge_lists_regs_body<NPT, 256>(p); }
 // tau[f][q] = max(base[f][q], k-th largest of the n_vals scores published by the light sample pass for (q, f)); the k-th
 // largest counts only scores above tau0 and is -inf when there are fewer than k of them (then the sample gives no bound).
-// grid = 64 * F, block 256, n_vals <= 2048: every thread holds 8 values in registers.
+// One WAVE per (query, field), NV values per lane (n_vals <= 64 * NV): the 32-step radix descent on the score bits is
+// NV ballots + scalar popcounts per step, no LDS and no barriers.  grid = ceil(64 * F / 4), block 256.
+template <int NV>
 __global__ void __launch_bounds__(256) mfar_sample_tau_kernel(const float* __restrict__ samp, int n_wave_blocks, int F, int k,
                                                               float tau0, const float* __restrict__ base,
                                                               float* __restrict__ tau_out) {
-    __shared__ u64 sel[SEL_MAX_K], sorted[SEL_MAX_K];
-    __shared__ int red[36];
     const int n_vals = n_wave_blocks * 2;
-    const int q = blockIdx.x / F, f = blockIdx.x - q * F;
-    u32 hi[8], lo[8];
-    int mine = 0;
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pair >= 64 * F) return;   // wave-uniform
+    const int q = pair / F, f = pair - q * F;
+    u32 hi[NV];
+    int n = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = threadIdx.x + j * 256;
+    for (int j = 0; j < NV; ++j) {
+        const int i = lane + j * 64;
         const int ii = i < n_vals ? i : 0;
         const float v = samp[((size_t)f * n_wave_blocks + (ii >> 1)) * 128 + q * 2 + (ii & 1)];
         const bool ok = i < n_vals && v > tau0;
-        hi[j] = ok ? f2ord(v) : 0u;
-        lo[j] = ok ? 0xFFFFFFFFu - (u32)i : 0u;
-        mine += ok ? 1 : 0;
+        hi[j] = ok ? f2ord(v) : 0u;     // 0 = empty: below every real score's key
+        n += __popcll(__ballot(ok));
     }
-    const int n = block_sum<8>(mine, red, 0);
-    __syncthreads();
-    const int m = block_topk_regs<8>(hi, lo, n, k, sel, sorted, red);
-    if (threadIdx.x == 0) {
-        float t = m == k ? key_score(sorted[k - 1]) : -__builtin_inff();
+    float t = -__builtin_inff();
+    if (n >= k) {
+        u32 T = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const u32 cand = T | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) c += __popcll(__ballot(hi[j] >= cand));
+            if (c >= k) T = cand;
+        }
+        t = ord2f(T);
+    }
+    if (lane == 0) {
         if (base) t = fmaxf(t, base[f * 64 + q]);
         tau_out[f * 64 + q] = t;
     }
