@@ -214,6 +214,11 @@ int mfar_set_wgs_per_cu(mfar_index* idx, int wgs);
 int mfar_set_screen(mfar_index* idx, int mode, float eps_mult);
 int mfar_get_screen(const mfar_index* idx, int* mode, float* eps_mult);
 int mfar_screen_stats(mfar_index* idx, int* built, int64_t* screen_bytes, int64_t* n_checked, int64_t* n_failed);
+/* The duplicate group of a field found when the screen was built (synchronises the device): a field that a document lacks
+ * is encoded from the empty string (format.py:58-59), so corpora hold one large group of bit-identical rows per field.  The
+ * screened pass scans only the group's lowest row (rep_row, a global id; -1 = no group of >= 64 rows) and the certify step
+ * re-inserts the n_masked others -- same score, ids ascending -- when that row is among the k best. */
+int mfar_screen_dup_group(mfar_index* idx, int field, int64_t* rep_row, int64_t* n_masked);
 
 #ifdef __cplusplus
 }

@@ -95,7 +95,8 @@ struct mfar_index {
     bool screen_dirty = true;     // rows were written since the screen was built
     bool screen_nomem = false;
     long long screen_checked = 0; // (query, field) lists certified so far    // the screen slab could not be allocated: stay on the exact pass
-    DevBuf s_stats, s_field, s_mean;
+    DevBuf s_stats, s_field, s_mean, s_dupmask, s_dupgrp;   // + duplicate groups: row bitmap [F][n_blk * 2], DupGroup [F]
+    bool screen_dedup = true;     // mask the field's big duplicate group out of the screened pass (MFAR_SCREEN_DEDUP=0: off)
     hipEvent_t mid_ev = nullptr;  // recorded right before the full stage-1 kernel is launched
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -180,6 +181,7 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     idx->slab_bytes = (size_t)idx->field_stride * idx->esize * n_fields;
     if (const char* e = getenv("MFAR_SCREEN")) idx->screen_mode = atoi(e);
     if (const char* e = getenv("MFAR_SCREEN_EPS_MULT")) idx->screen_eps_mult = (float)atof(e);
+    if (const char* e = getenv("MFAR_SCREEN_DEDUP")) idx->screen_dedup = atoi(e) != 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) idx->n_cu = prop.multiProcessorCount;
     hipError_t e = hipMalloc(&idx->slab, idx->slab_bytes);
@@ -204,7 +206,8 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
     DevBuf* bufs[] = {&idx->fid, &idx->fsc, &idx->cand[0], &idx->cand[1], &idx->ncand[0], &idx->ncand[1], &idx->x[0], &idx->x[1],
-                      &idx->own[0], &idx->own[1], &idx->s_stats, &idx->s_field, &idx->s_mean};
+                      &idx->own[0], &idx->own[1], &idx->s_stats, &idx->s_field, &idx->s_mean, &idx->s_dupmask,
+                      &idx->s_dupgrp};
     for (DevBuf* b : bufs) b->release();
     for (auto& sl : idx->s1) {
         DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
@@ -467,6 +470,10 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, int phases, int 
     p.sample = 0;
     p.samp_out = nullptr;
     p.only_failed = only_failed;
+    if (kind == S1_F16) {   // the screened pass skips the masked members of the fields' duplicate groups
+        p.dup_mask = idx->s_dupmask.as<u32>();
+        p.dup_words = idx->n_blk * 2;
+    }
     {
         const char* dbg = getenv("MFAR_S1_DEBUG");
         p.dbg = dbg ? atoi(dbg) : 0;
@@ -619,6 +626,20 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
             (const float*)idx->slab, (_Float16*)idx->screen, idx->field_stride, n_gran, idx->n_steps, idx->s_mean.as<float>(),
             idx->s_field.as<ScreenField>());
         HIPCHK(hipGetLastError());
+        // duplicate groups (mfar_screen.h): always computed, so the bitmap and the group table are defined
+        const long long dw = idx->n_blk * 2;
+        RETCHK(idx->s_dupmask.ensure((size_t)idx->F * dw * sizeof(u32)));
+        RETCHK(idx->s_dupgrp.ensure((size_t)idx->F * sizeof(DupGroup)));
+        HIPCHK(hipMemsetAsync(idx->s_dupmask.p, 0, (size_t)idx->F * dw * sizeof(u32), st));
+        mfar_dup_sample_kernel<<<dim3(idx->F), dim3(256), DUP_SAMPLES * 8, st>>>((const float*)idx->slab, idx->field_stride, idx->n_steps,
+                                                                                   idx->screen_dedup ? idx->n_rows : 0,
+                                                                                   idx->s_dupgrp.as<DupGroup>());
+        HIPCHK(hipGetLastError());
+        mfar_dup_compare_kernel<<<dim3((unsigned)idx->n_blk, idx->F), dim3(256), 0, st>>>(
+            (const float*)idx->slab, idx->field_stride, idx->n_steps, idx->n_rows, idx->s_dupgrp.as<DupGroup>(), idx->s_dupmask.as<u32>(), dw);
+        HIPCHK(hipGetLastError());
+        mfar_dup_finish_kernel<<<dim3(idx->F), dim3(64), 0, st>>>(idx->s_dupgrp.as<DupGroup>(), idx->s_dupmask.as<u32>(), dw);
+        HIPCHK(hipGetLastError());
         idx->screen_dirty = false;
     }
     *ok = true;
@@ -713,6 +734,8 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     cp.out_ids = fid;
     cp.out_scores = fsc;
     cp.fail = fflags;
+    cp.grp = idx->s_dupgrp.as<DupGroup>();
+    cp.row_offset = idx->row_offset;
     cp.F = F;
     cp.k = k;
     cp.kp = kp;
@@ -777,6 +800,22 @@ extern "C" int mfar_get_screen(const mfar_index* idx, int* mode, float* eps_mult
     if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
     if (mode) *mode = idx->screen_mode;
     if (eps_mult) *eps_mult = idx->screen_eps_mult;
+    return MFAR_OK;
+}
+
+extern "C" int mfar_screen_dup_group(mfar_index* idx, int field, int64_t* rep_row, int64_t* n_masked) {
+    if (!idx || field < 0 || field >= idx->F) return fail(MFAR_ERR_INVALID, "bad idx / field");
+    HIPCHK(hipSetDevice(idx->device));
+    if (rep_row) *rep_row = -1;
+    if (n_masked) *n_masked = 0;
+    if (!idx->screen || idx->screen_dirty || !idx->s_dupgrp.p) return MFAR_OK;
+    HIPCHK(hipDeviceSynchronize());
+    DupGroup g;
+    HIPCHK(hipMemcpy(&g, idx->s_dupgrp.as<DupGroup>() + field, sizeof(DupGroup), hipMemcpyDeviceToHost));
+    if (g.rep >= 0) {
+        if (rep_row) *rep_row = idx->row_offset + g.rep;
+        if (n_masked) *n_masked = g.n_masked;
+    }
     return MFAR_OK;
 }
 

@@ -163,6 +163,169 @@ __global__ void __launch_bounds__(256) mfar_screen_build_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Duplicate rows.  A field that a document lacks is encoded from the empty string (format.py:58-59), so real corpora hold
+// one huge group of IDENTICAL rows per field.  When that group reaches the top of a list, equal approximate scores cannot
+// separate the k-th from the k'-th entry and every certificate of the field would fail.  The screen therefore finds the
+// field's largest group of bit-identical rows at build time, scans only its lowest-id member (the others are masked out of
+// the screened pass by a row bitmap) and re-inserts the masked members -- same exact score, ids ascending -- when the
+// representative makes it into the exact top-k (mfar_screen_certify_kernel).  Masked rows can never be missed: they score
+// exactly what their representative scores and lose every tie against it.
+//   1. mfar_dup_sample_kernel   hashes DUP_SAMPLES pseudo-random rows of the field; the most frequent hash names a candidate row
+//   2. mfar_dup_compare_kernel  compares EVERY row with the candidate bit for bit -> bitmap of equal rows, their count, the lowest id
+//   3. mfar_dup_finish_kernel   drops groups below DUP_MIN_GROUP, clears the representative's bit, lists the DUP_MEMBERS lowest masked ids
+// ---------------------------------------------------------------------------------------------------------
+#define DUP_SAMPLES 4096
+#define DUP_MIN_GROUP 64
+#define DUP_MEMBERS 128        // >= MFAR_MAX_K: a list can never need more members than its depth
+struct DupGroup {              // per field
+    int rep;                   // local row of the lowest-id member, -1 = no group
+    int n_masked;              // masked members (all of them, not only the listed ones)
+    int cand;                  // scratch: the sampled candidate row
+    int count;                 // scratch: rows equal to the candidate
+    int members[DUP_MEMBERS];  // the lowest masked local rows, ascending; -1 padded
+};
+
+__device__ __forceinline__ u64 dup_mix(u64 x) {
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// grid = F, block 256, dynamic LDS = DUP_SAMPLES * 8
+__global__ void __launch_bounds__(256) mfar_dup_sample_kernel(const float* __restrict__ slab, long long field_stride, int n_steps,
+                                                              long long n_rows, DupGroup* __restrict__ grp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* keys = (u64*)smem;   // (hash with the low 12 bits replaced by the sample index)
+    const int f = blockIdx.x, E = n_steps * 16;
+    for (int i = threadIdx.x; i < DUP_SAMPLES; i += blockDim.x) {
+        const long long row = n_rows > 0 ? (long long)(((u64)i * 0x9E3779B97F4A7C15ull) % (u64)n_rows) : 0;
+        u64 h = 0;
+        for (int e = 0; e < E; e += 4) {
+            const f32x4 v = *(const f32x4*)(slab + (size_t)f * field_stride + tiled_offset(n_steps, row, e));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h += dup_mix((u64)__float_as_uint(v[j]) + (u64)(e + j + 1) * 0x9E3779B97F4A7C15ull);
+        }
+        keys[i] = (h & ~0xFFFull) | (u64)i;
+    }
+    __syncthreads();
+    for (int size = 2; size <= DUP_SAMPLES; size <<= 1)      // bitonic sort ascending
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < DUP_SAMPLES / 2; t += blockDim.x) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const u64 x = keys[lo], y = keys[hi];
+                if ((x > y) == up) {
+                    keys[lo] = y;
+                    keys[hi] = x;
+                }
+            }
+            __syncthreads();
+        }
+    // longest run of equal hashes (thread t looks at runs starting at positions t, t + 256, ...)
+    __shared__ unsigned long long best;   // (run length << 32) | start
+    if (threadIdx.x == 0) best = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < DUP_SAMPLES; i += blockDim.x) {
+        const u64 hk = keys[i] >> 12;
+        if (i > 0 && (keys[i - 1] >> 12) == hk) continue;   // not a run start
+        int j = i + 1;
+        while (j < DUP_SAMPLES && (keys[j] >> 12) == hk) ++j;
+        atomicMax(&best, ((unsigned long long)(j - i) << 32) | (unsigned)i);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int len = (int)(best >> 32), start = (int)(best & 0xFFFFFFFFu);
+        DupGroup* g = grp + f;
+        g->rep = 0x7FFFFFFF;
+        g->n_masked = 0;
+        g->count = 0;
+        g->cand = -1;
+        if (len >= 2 && n_rows >= DUP_MIN_GROUP) {
+            const int si = (int)(keys[start] & 0xFFFull);
+            g->cand = (int)(((u64)si * 0x9E3779B97F4A7C15ull) % (u64)n_rows);
+        }
+    }
+}
+
+// grid = (n_blk, F), block 256 (thread layout of mfar_screen_stats_kernel).  eq: [F][n_blk * 2] words, zeroed by the host.
+__global__ void __launch_bounds__(256) mfar_dup_compare_kernel(const float* __restrict__ slab, long long field_stride, int n_steps,
+                                                               long long n_rows, DupGroup* __restrict__ grp, u32* __restrict__ eq,
+                                                               long long words_per_field) {
+    const int f = blockIdx.y;
+    const int cand = grp[f].cand;
+    if (cand < 0) return;   // workgroup-uniform
+    const int rr = threadIdx.x >> 2, pp = threadIdx.x & 3;
+    const long long row = (long long)blockIdx.x * 64 + rr;
+    const float* tile = slab + (size_t)f * field_stride + (size_t)blockIdx.x * n_steps * 1024 + threadIdx.x * 4;
+    const int e0 = (pp ^ ((rr >> 2) & 3)) << 2;   // this thread's dims inside a k-step
+    bool same = row < n_rows;
+    for (int s = 0; s < n_steps; ++s) {
+        if (!__any(same)) break;   // wave-uniform
+        const f32x4 a = *(const f32x4*)(tile + (size_t)s * 1024);
+        const f32x4 b = *(const f32x4*)(slab + (size_t)f * field_stride + tiled_offset(n_steps, cand, s * 16 + e0));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) same = same && __float_as_uint(a[i]) == __float_as_uint(b[i]);
+    }
+    // threads 4r .. 4r+3 hold the four pieces of row r
+    same = (__shfl_xor((int)same, 1) & (int)same) != 0;
+    same = (__shfl_xor((int)same, 2) & (int)same) != 0;
+    const u64 m = __ballot(same && pp == 0);   // bit 4r set: row r of this wave's 16 rows equals the candidate
+    if ((threadIdx.x & 63) == 0 && m) {
+        u32 bits = 0;
+        for (int r = 0; r < 16; ++r) bits |= (u32)((m >> (4 * r)) & 1ull) << r;
+        const int wv = threadIdx.x >> 6;                                     // wave: rows 16 wv .. 16 wv + 15 of the block
+        atomicOr(&eq[(size_t)f * words_per_field + blockIdx.x * 2 + (wv >> 1)], bits << (16 * (wv & 1)));
+        atomicAdd(&grp[f].count, __popc(bits));
+        atomicMin(&grp[f].rep, (int)(blockIdx.x * 64 + wv * 16 + __builtin_ctz(bits)));
+    }
+}
+
+// grid = F, block 64
+__global__ void __launch_bounds__(64) mfar_dup_finish_kernel(DupGroup* __restrict__ grp, u32* __restrict__ eq, long long words_per_field) {
+    const int f = blockIdx.x, lane = threadIdx.x;
+    DupGroup* g = grp + f;
+    u32* w = eq + (size_t)f * words_per_field;
+    const bool have = g->cand >= 0 && g->count >= DUP_MIN_GROUP;
+    if (!have) {
+        for (long long i = lane; i < words_per_field; i += 64) w[i] = 0u;
+        if (lane == 0) {
+            g->rep = -1;
+            g->n_masked = 0;
+        }
+        for (int i = lane; i < DUP_MEMBERS; i += 64) g->members[i] = -1;
+        return;
+    }
+    const int rep = g->rep;
+    if (lane == 0) {
+        w[rep >> 5] &= ~(1u << (rep & 31));   // the representative stays in the scan
+        g->n_masked = g->count - 1;
+    }
+    __syncthreads();
+    // the DUP_MEMBERS lowest masked rows, ascending: walk the bitmap 64 words at a time
+    int found = 0;
+    for (long long base = 0; base < words_per_field && found < DUP_MEMBERS; base += 64) {
+        const u32 word = base + lane < words_per_field ? w[base + lane] : 0u;
+        const int cnt = __popc(word);
+        int incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        int pos = found + incl - cnt;
+        u32 bitsw = word;
+        while (bitsw && pos < DUP_MEMBERS) {
+            const int b = __builtin_ctz(bitsw);
+            bitsw &= bitsw - 1;
+            g->members[pos++] = (int)((base + lane) * 32 + b);
+        }
+        found += __shfl(incl, 63);
+    }
+    for (int i = (found < DUP_MEMBERS ? found : DUP_MEMBERS) + lane; i < DUP_MEMBERS; i += 64) g->members[i] = -1;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Queries of one 64-query block: per-query scale + norm, two-term fp16 split tiles [n_steps][2][64][16], and per
 // (field, query): eps (real units) and the starting threshold of the screened pass (scaled units).
 //   grid = 64 (one workgroup per query row), block 256.
@@ -277,6 +440,8 @@ struct CertifyParams {
     long long* out_ids;       // [Q, F, k]
     float* out_scores;
     int* fail;                // [F] field flags, [F] = any, [F+1] = failed (query, field) pairs (statistics)
+    const DupGroup* grp;      // [F] duplicate groups (local rows) or nullptr
+    long long row_offset;
     int F, k, kp, q0, sentinel;
 };
 __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyParams p) {
@@ -319,9 +484,29 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
             atomicAdd(&p.fail[p.F + 1], 1);
         }
     }
+    // duplicate group: when its representative is among the k best, the masked members (same exact score, higher ids) take
+    // their canonical places right behind it -- select the k best of (the k selected) + (the group's lowest masked members)
+    int m_out = m;
+    if (p.grp && p.grp[f].rep >= 0 && m > 0) {
+        const DupGroup* g = p.grp + f;
+        const u32 rep_id = (u32)(p.row_offset + g->rep);
+        __shared__ int hit;
+        if (threadIdx.x == 0) hit = -1;
+        __syncthreads();
+        if ((int)threadIdx.x < m && key_id(sorted[threadIdx.x]) == rep_id) hit = threadIdx.x;
+        __syncthreads();
+        if (hit >= 0) {   // workgroup-uniform
+            const float s_rep = key_score(sorted[hit]);
+            const int n_add = min(min(g->n_masked, DUP_MEMBERS), p.k);
+            if ((int)threadIdx.x < m) keys[threadIdx.x] = sorted[threadIdx.x];
+            if ((int)threadIdx.x < n_add) keys[m + threadIdx.x] = make_key(s_rep, (u32)(p.row_offset + g->members[threadIdx.x]));
+            __syncthreads();
+            m_out = block_topk_sorted<1>(keys, m + n_add, p.k, sel, sorted, red);
+        }
+    }
     const size_t ob = ((size_t)(p.q0 + ql) * p.F + f) * p.k;
     for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
-        if (r < m) {
+        if (r < m_out) {
             p.out_ids[ob + r] = (long long)key_id(sorted[r]);
             p.out_scores[ob + r] = key_score(sorted[r]);
         } else {

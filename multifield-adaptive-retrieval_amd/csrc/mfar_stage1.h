@@ -74,6 +74,8 @@ struct S1Params {
     int sample_tiles;       // tiles per workgroup scanned by the sample pass (>= 1, <= tiles of the shortest chunk)
     float* samp_out;        // [F][n_chunks * sample_tiles * 4][64][2] (sample == 2)
     const int* only_failed; // [F] or nullptr: workgroups of fields whose flag is 0 exit at once (screen fall-back pass)
+    const u32* dup_mask;    // [F][dup_words] or nullptr: rows whose bit is set are skipped (masked duplicates, mfar_screen.h)
+    long long dup_words;    // words per field = n_blk * 2
     int dbg;                // profiling only (MFAR_S1_DEBUG): 1 = skip the selection epilogue (results invalid; note that
                             // the downstream kernels then have no candidates, so they no longer compete with stage 1)
 };
@@ -172,6 +174,41 @@ __device__ __forceinline__ void s1_state_init(const S1State& st, const S1Params&
     __syncthreads();
 }
 
+// Rows that must never qualify, for both epilogues: the padding rows behind the field's last row, and (screened pass) the
+// masked members of the field's duplicate group.  acc layout: see s1_epilogue.
+__device__ __forceinline__ void s1_mask_rows(const S1Params& p, int f, int t, int w, f32x16& acc00, f32x16& acc01, f32x16& acc10,
+                                             f32x16& acc11) {
+    const int h = (threadIdx.x & 63) >> 5;
+    if (t * S1_TILE_ROWS + S1_TILE_ROWS > p.n_rows) {  // last tile of the field
+        const int row_w = t * S1_TILE_ROWS + w * 64 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_w + (r & 3) + 8 * (r >> 2);
+            if (row >= p.n_rows) acc00[r] = acc01[r] = -__builtin_inff();
+            if (row + 32 >= p.n_rows) acc10[r] = acc11[r] = -__builtin_inff();
+        }
+    }
+    if (p.dup_mask) {
+        // the wave's 64 rows are two words of the bitmap (wave-uniform loads)
+        // (a scalar load through inline asm: a vector load the compiler can see would make it drain the k-loop's prefetch
+        //  queue -- vmcnt(0) -- in front of the first use)
+        const unsigned long long ma = (unsigned long long)(p.dup_mask + (size_t)f * p.dup_words + (size_t)t * 8 + w * 2);
+        const unsigned long long ms = ((unsigned long long)(u32)__builtin_amdgcn_readfirstlane((int)(ma >> 32)) << 32) |
+                                      (u32)__builtin_amdgcn_readfirstlane((int)(u32)ma);
+        unsigned long long mm;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mm) : "s"(ms) : "memory");
+        const u32 m0 = (u32)mm, m1 = (u32)(mm >> 32);
+        if (m0 | m1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rw = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if ((m0 >> rw) & 1u) acc00[r] = acc01[r] = -__builtin_inff();
+                if ((m1 >> rw) & 1u) acc10[r] = acc11[r] = -__builtin_inff();
+            }
+        }
+    }
+}
+
 // LDS accesses of the staging area through inline asm (hipcc would drain the in-flight LDS-DMA in front of LDS accesses it
 // can see next to it)
 __device__ __forceinline__ void lds_write_b64(u32 addr, u64 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
@@ -213,18 +250,10 @@ __device__ __forceinline__ void s1_drain(const S1Params& p, const S1State& st, i
 // wave and tile of the direct path cost 14 % of the 16-bit pass); staging turns them into about one coalesced store per
 // wave and tile.  Entries that do not fit the staging area (a lane with many survivors in one tile) go straight to the list.
 template <int SCAP>
-__device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st, int t, int w, size_t wgq0, f32x16& acc00,
+__device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st, int f, int t, int w, size_t wgq0, f32x16& acc00,
                                             f32x16& acc01, f32x16& acc10, f32x16& acc11) {
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
-    if (t * S1_TILE_ROWS + S1_TILE_ROWS > p.n_rows) {  // last tile of the field: padding rows never qualify
-        const int row_w = t * S1_TILE_ROWS + w * 64 + 4 * h;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row_w + (r & 3) + 8 * (r >> 2);
-            if (row >= p.n_rows) acc00[r] = acc01[r] = -__builtin_inff();
-            if (row + 32 >= p.n_rows) acc10[r] = acc11[r] = -__builtin_inff();
-        }
-    }
+    s1_mask_rows(p, f, t, w, acc00, acc01, acc10, acc11);
     // (barrier A -- the compactions of the previous tile are complete, every wave has finished the tile's last k-step --
     //  is executed by the caller, which uses it to refill the ring slot that just became free before this epilogue runs)
     const float th0 = fmaxf(s1_nextup(st.tau[j]), st.tg[j]);
@@ -302,15 +331,7 @@ __device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st
 __device__ __forceinline__ void s1_sample_top2(const S1Params& p, int f, int chunk, int tl, int t, int w, f32x16& acc00, f32x16& acc01,
                                                f32x16& acc10, f32x16& acc11) {
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    if (t * S1_TILE_ROWS + S1_TILE_ROWS > p.n_rows) {  // padding rows never qualify
-        const int row_w = t * S1_TILE_ROWS + w * 64 + 4 * h;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row_w + (r & 3) + 8 * (r >> 2);
-            if (row >= p.n_rows) acc00[r] = acc01[r] = -__builtin_inff();
-            if (row + 32 >= p.n_rows) acc10[r] = acc11[r] = -__builtin_inff();
-        }
-    }
+    s1_mask_rows(p, f, t, w, acc00, acc01, acc10, acc11);
     float a1 = -__builtin_inff(), a2 = a1, b1 = a1, b2 = a1;   // query j: (a1 >= a2), query 32 + j: (b1 >= b2)
 #define S1_TOP2(V, M1, M2)                    \
     {                                         \
@@ -465,7 +486,7 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
         // the HBM stream then keeps its depth through the epilogue instead of draining (the next step skips its issue).
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (issued < total) S1_ISSUE_NEXT();
-        s1_epilogue<S1_SCAP_F32>(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
+        s1_epilogue<S1_SCAP_F32>(p, st, f, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
 #undef S1_ISSUE_NEXT
     if (p.sample != 2) s1_flush<S1_SCAP_F32>(p, st, w, wgq0);
@@ -616,7 +637,7 @@ __device__ __forceinline__ void s1_body_x16(const S1Params& p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A + early refill (see the fp32 body)
         if (issued < total) S1X_ISSUE_NEXT();
-        s1_epilogue<S1_SCAP_LDS>(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
+        s1_epilogue<S1_SCAP_LDS>(p, st, f, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
 #undef S1X_ISSUE_NEXT
     if (p.sample != 2) s1_flush<S1_SCAP_LDS>(p, st, w, wgq0);
@@ -756,7 +777,7 @@ __device__ __forceinline__ void s1_body_x16r(const S1Params& p) {
             continue;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A (see the fp32 body)
-        s1_epilogue<X::SCAP>(p, st, t, w, wgq0, acc00, acc01, acc10, acc11);
+        s1_epilogue<X::SCAP>(p, st, f, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
 #undef S1R_ISSUE
     // the stages issued past the end are still in flight: no LDS-DMA write may land after the workgroup has left

@@ -67,6 +67,7 @@ SIGNATURES = {
     "mfar_stage1_finish": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mfar_set_screen": (_i, [_vp, _i, _c.c_float]),
     "mfar_get_screen": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_float)]),
+    "mfar_screen_dup_group": (_i, [_vp, _i, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "mfar_screen_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
 }
 

@@ -301,6 +301,12 @@ class MultiFieldIndex:
         Outputs are bit-identical in every mode; `eps_mult` is a test knob (1 = rigorous proof)."""
         _native.check(_native.lib().mfar_set_screen(self._h, int(mode), float(eps_mult)))
 
+    def screen_dup_group(self, field: int):
+        """(representative global row or -1, number of masked duplicates) of the field's duplicate group (include/mfar_hip.h)."""
+        rep, n = ctypes.c_int64(), ctypes.c_int64()
+        _native.check(_native.lib().mfar_screen_dup_group(self._h, int(field), ctypes.byref(rep), ctypes.byref(n)))
+        return rep.value, n.value
+
     @property
     def screen_setting(self):
         """(mode, eps_mult) currently in force."""

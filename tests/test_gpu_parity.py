@@ -632,18 +632,20 @@ def test_screen_fallback_and_slack(idxmod):
 
 
 def test_screen_massive_ties_and_huge_values(idxmod):
-    """Thousands of identical rows at the top of every list (the shared 'empty field' vector, format.py:58-59) defeat the
-    certificate -- the k'-th approximate score equals the k-th exact one -- so the exact pass must take over and the
-    canonical tie-break (doc id ascending) must hold.  A row with huge finite values overflows the norm statistics."""
+    """Thousands of NEAR-identical rows at the top of every list (the same vector up to the last bits, as batched encoder
+    forwards of one text produce) are no duplicate group, and their approximate scores cannot separate the k-th from the
+    k'-th entry: the certificate must fail, the exact pass must take over, and the canonical tie-break must hold.
+    Bit-identical rows, in contrast, are masked and re-inserted (test_screen_duplicate_group_is_masked_and_reinserted).
+    A row with huge finite values overflows the norm statistics."""
     rng = np.random.default_rng(13)
     F, D, E, Q, k = 2, 20000, 64, 9, 100
     slab, q, _ = _mk(rng, F, D, E, Q)
     top = q.mean(0) * 3.0
     rows = rng.choice(D, size=3000, replace=False)
-    slab[0, rows] = top                                    # field 0: 3000-way tie at the very top
+    slab[0, rows] = top * (1.0 + rng.integers(-2, 3, size=(3000, 1)).astype(np.float32) * np.float32(2.0 ** -22))
     ix = _load(idxmod, slab)
     ix.set_screen(2)
-    _check_stage1(ix, slab, q, k, True, "ties")
+    _check_stage1(ix, slab, q, k, True, "near ties")
     st = ix.screen_stats()
     assert st["n_failed"] >= Q, st                         # field 0 fell back for every query
     slab[1, 17] *= np.float32(1e25)                        # field 1: row norm^2 overflows fp32
@@ -720,3 +722,46 @@ def test_screen_anisotropic_embeddings_are_certified(idxmod):
     # negative common component: every score is far below zero, the zero sentinel empties the lists
     _check_stage1(ix, slab, -q, k, True, "all negative")
     ix.close()
+
+
+def test_screen_duplicate_group_is_masked_and_reinserted(idxmod):
+    """A field missing from a document is encoded from the empty string (format.py:58-59): one large group of IDENTICAL rows
+    per field.  Such a group defeats the certificate when it reaches the top of a list (equal approximate scores); the
+    screen scans only its lowest row and the certify step re-inserts the others (same score, ids ascending).  Here the
+    shared vector is every query's best match in field 0 and mediocre in field 1: no list may fall back, every bit must
+    match the oracle, also across shards (each shard handles its own part of the group)."""
+    rng = np.random.default_rng(17)
+    F, D, E, Q, k = 3, 24000, 96, 40, 100
+    slab, q, W = _mk(rng, F, D, E, Q)
+    top = (q.mean(0) * 3.0).astype(np.float32)
+    g0 = np.sort(rng.choice(D, size=9000, replace=False))
+    slab[0, g0] = top                                        # field 0: 9000 identical rows, best match of every query
+    g1 = np.sort(rng.choice(D, size=5000, replace=False))
+    slab[1, g1] = slab[1, g1[0]]                             # field 1: 5000 identical ordinary rows
+    ix = _load(idxmod, slab)
+    ix.set_screen(2)
+    for sentinel in (True, False):
+        _check_stage1(ix, slab, q, k, sentinel, ("dup group", sentinel))
+    assert ix.screen_dup_group(0) == (int(g0[0]), 8999) and ix.screen_dup_group(1) == (int(g1[0]), 4999)
+    assert ix.screen_dup_group(2)[0] == -1
+    st = ix.screen_stats()
+    assert st["n_failed"] == 0, st                           # no exact fall-back despite the 9000-way tie at the top
+    r = ix.search(q, W, None)
+    o = O.c_two_stage(slab, q, W, None)
+    assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32))
+    ix.close()
+    # sharded: the group is split over the shards, each shard masks / re-inserts its own members
+    bounds = [0, 7001, 15000, D]
+    shards = [_load(idxmod, slab[:, bounds[i]:bounds[i + 1]], row_offset=bounds[i]) for i in range(3)]
+    import torch
+    qd = torch.from_numpy(q).cuda()
+    for s_ in shards:
+        s_.set_screen(2)
+    payloads = torch.cat([s_.search_local(qd) for s_ in shards])
+    rm = idxmod.merge_payloads(payloads, 3, qd, torch.from_numpy(W).cuda(), None, n_fields=F)
+    torch.cuda.synchronize()
+    assert np.array_equal(rm["ids"].cpu().numpy(), o["ids"])
+    assert np.array_equal(rm["scores"].cpu().numpy().view(np.uint32), o["scores"].view(np.uint32))
+    assert all(s_.screen_stats()["n_failed"] == 0 for s_ in shards)
+    for s_ in shards:
+        s_.close()
