@@ -16,6 +16,7 @@
 """
 import json
 import os
+from collections import Counter
 from types import SimpleNamespace
 from typing import Dict, List, Optional, TextIO, Tuple
 
@@ -154,10 +155,22 @@ class RetrievalTrainingModule(torch.nn.Module):
             if self.prefix:
                 docs = [(i, field.name + ": " + t) for i, t in docs]            # :476-481
             vec = self.vectors_dict[key]
+            # A text that occurs more than once in the field (above all "": documents that lack the field, format.py:58-59)
+            # is encoded ONCE and its embedding re-used: less encoder work, and the rows are bit-identical, which lets the
+            # index treat them as one duplicate group (csrc/mfar_screen.h) instead of thousands of near-ties.
+            counts = Counter(t for _, t in docs)
+            shared: Dict[str, torch.Tensor] = {}
             for b in range(0, len(docs), bs):
                 chunk = docs[b:b + bs]
-                emb = self.encoder.encode([t for _, t in chunk], batch_size=bs, convert_to_tensor=True)
-                vec.write_block(chunk[0][0], emb.float().contiguous())           # straight into the HBM slab
+                texts = [t for _, t in chunk]
+                todo = list(dict.fromkeys(t for t in texts if t not in shared))   # distinct, first-seen order
+                fresh = {}
+                if todo:
+                    enc = self.encoder.encode(todo, batch_size=bs, convert_to_tensor=True).float()
+                    fresh = {t: enc[i] for i, t in enumerate(todo)}
+                    shared.update({t: v.clone() for t, v in fresh.items() if counts[t] > 1})
+                emb = torch.stack([shared[t] if t in shared else fresh[t] for t in texts])
+                vec.write_block(chunk[0][0], emb.contiguous())                   # straight into the HBM slab
         torch.cuda.synchronize(self.device)
         _barrier()                                                               # :491 (no memmap reopen needed)
         self._corpus_encoded = True

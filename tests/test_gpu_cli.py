@@ -71,7 +71,9 @@ def test_train_then_mask_fields(tmp_path):
         sims = np.array([s for _, s in got[qid]], dtype=np.float32)
         # the CLI encodes the query inside a padded batch, the check encodes it alone: scores agree to fp32 noise
         np.testing.assert_allclose(sims, o["scores"][i], rtol=1e-4, atol=1e-4)
-        assert len(set(ids) & set(o["ids"][i].tolist())) >= 95
+        # (documents that share a text now share one embedding bit for bit, so this tiny corpus has many exact score ties;
+        #  the two query embeddings differ in the last bits and resolve a few more boundary near-ties differently)
+        assert len(set(ids) & set(o["ids"][i].tolist())) >= 90
 
     out2 = str(tmp_path / "out2")
     m2 = mask_fields.main(dataset_name="amazon", lexical_index="unused", out=out2, temp_dir=tmp, data=data,
