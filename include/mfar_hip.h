@@ -180,7 +180,7 @@ int mfar_stream_wait_stage1_start(mfar_index* idx, void* stream);
  *   any_fail            NULL: a failed certificate is repaired inside finish (the exact fp32 pass is launched and idles
  *                       when nothing failed).  Non-NULL (device int32): finish only reports -- *any_fail != 0 means the
  *                       lists of this batch are NOT final and the caller must redo the batch with mfar_retrieve_fields
- *                       after mfar_set_screen(idx, 0, ...).  This keeps the fp32 kernel, which cannot be co-resident
+ *                       (which repairs failed fields itself).  This keeps the fp32 kernel, which cannot be co-resident
  *                       with the other slot's scan, off the stream in the common case.
  * Same arguments (q, Q, k, sentinel, outputs) must be passed to both calls of a batch.
  */

@@ -15,7 +15,8 @@ on every CU.  Results are identical to `MultiFieldIndex.search` / `ShardedSearch
     r0 = ps.result(t0)            # dict(ids, scores, n_valid): valid until two more batches have been submitted
 
 A screened batch whose certificate failed (include/mfar_hip.h, `any_fail`) is detected in `result()` and redone there
-with the screen switched off, so what `result()` returns is always the exact answer.
+through the non-split entry points (which repair the failed fields with the exact pass), so what `result()` returns is
+always the exact answer.
 """
 import torch
 
@@ -129,21 +130,18 @@ class PipelinedSearcher:
             return
         self.n_redone += 1
         torch.cuda.synchronize(self.dev)              # the redo uses the index's slot-0 scratch: nothing else may be in flight
-        prev = self.ix.screen_setting
-        self.ix.set_screen(0, prev[1])
-        try:
-            Q = s["Q"]
-            qk = s["q"][:Q]
-            if self.world == 1:
-                _native.check(_native.lib().mfar_retrieve_fields(
-                    self.ix._h, qk.data_ptr(), Q, int(self.k1), int(bool(self.sentinel)), s["fid"].data_ptr(), s["fsc"].data_ptr(), 1,
-                    torch.cuda.current_stream(self.dev).cuda_stream))
-            else:
-                self.ix.retrieve_lists(qk, s["lists"], self.k1, self.sentinel)
-            self._tail(s, slot)
-            torch.cuda.current_stream(self.dev).synchronize()
-        finally:
-            self.ix.set_screen(*prev)
+        # the non-split entry points repair a failed certificate themselves: screened pass again, then the exact fp32 pass
+        # for the failed fields only (cheaper than switching the screen off for the whole batch)
+        Q = s["Q"]
+        qk = s["q"][:Q]
+        if self.world == 1:
+            _native.check(_native.lib().mfar_retrieve_fields(
+                self.ix._h, qk.data_ptr(), Q, int(self.k1), int(bool(self.sentinel)), s["fid"].data_ptr(), s["fsc"].data_ptr(), 1,
+                torch.cuda.current_stream(self.dev).cuda_stream))
+        else:
+            self.ix.retrieve_lists(qk, s["lists"], self.k1, self.sentinel)
+        self._tail(s, slot)
+        torch.cuda.current_stream(self.dev).synchronize()
 
     def result(self, ticket: int):
         if ticket < self.n_submitted - 2 or ticket >= self.n_submitted:
