@@ -40,6 +40,8 @@ class PipelinedSearcher:
             raise ValueError("the split-phase stage 1 takes at most 64 queries per batch")
         F, E = index.n_fields, index.dim
         self.n_redone = 0             # batches whose screen certificate failed and that were redone exactly
+        self._recent = []             # 1 = redone, over the last 16 checked batches
+        self.inline_repair = False    # many failures: let finish() repair on the device instead of reporting (see _check)
         self.slots = []
         for _ in range(2):
             s = dict(q=torch.empty(self.Qmax, E, device=self.dev),
@@ -110,9 +112,13 @@ class PipelinedSearcher:
             s["stage1"].record(self.main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(s["stage1"])
-            self.ix.stage1_finish(qk, slot, fid, fsc, self.k1, self.sentinel, any_fail=s["fail"])
-            if self.world > 1:                        # every rank must take the same decision about a redo
-                torch.distributed.all_reduce(s["fail"], op=torch.distributed.ReduceOp.MAX, group=self.group)
+            if self.inline_repair:                    # failed fields are redone by the exact pass inside finish()
+                self.ix.stage1_finish(qk, slot, fid, fsc, self.k1, self.sentinel, any_fail=None)
+                s["fail"].zero_()
+            else:
+                self.ix.stage1_finish(qk, slot, fid, fsc, self.k1, self.sentinel, any_fail=s["fail"])
+                if self.world > 1:                    # every rank must take the same decision about a redo
+                    torch.distributed.all_reduce(s["fail"], op=torch.distributed.ReduceOp.MAX, group=self.group)
             self._tail(s, slot)
             s["fail_host"].copy_(s["fail"], non_blocking=True)
             s["done"].record(self.side)
@@ -126,7 +132,14 @@ class PipelinedSearcher:
             return
         s["done"].synchronize()
         s["checked"] = True
-        if int(s["fail_host"][0]) == 0:
+        failed = int(s["fail_host"][0]) != 0
+        # A redo costs a pipeline drain plus a second pass.  When certificates fail often on this data (a quarter of the last
+        # 16 batches), stop reporting and let finish() repair on the device: the exact kernel then stalls the side stream
+        # until the next scan is through, but nothing is done twice.  (Same decision on every rank: the flags are all-reduced.)
+        self._recent = (self._recent + [1 if failed else 0])[-16:]
+        if sum(self._recent) >= 4:
+            self.inline_repair = True
+        if not failed:
             return
         self.n_redone += 1
         torch.cuda.synchronize(self.dev)              # the redo uses the index's slot-0 scratch: nothing else may be in flight
