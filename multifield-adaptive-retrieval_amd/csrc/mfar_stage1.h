@@ -703,7 +703,7 @@ __device__ __forceinline__ void s1_body_x16r(const S1Params& p) {
     // the query-piece LDS-DMA goes through inline asm: hipcc treats a visible global_load_lds and plain global loads as
     // two event kinds on one counter and answers the mix with vmcnt(0) in front of every use of a loaded register
 #define S1R_QDMA(S, D)                                                                                           \
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(S), "s"(__builtin_amdgcn_readfirstlane((int)(u32)(uintptr_t)(D))) : "memory", "m0")
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(S), "s"(__builtin_amdgcn_readfirstlane((int)(u32)(uintptr_t)(D))) : "memory")   // (m0 is reserved: hipcc re-loads it in front of every instruction of its own that reads it)
 #define S1R_ISSUE(SLOT)                                                                                   \
     do {                                                                                                  \
         asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(dr0[SLOT]) : "v"(dnext) : "memory");    \
