@@ -16,7 +16,6 @@
 """
 import json
 import os
-from collections import Counter
 from types import SimpleNamespace
 from typing import Dict, List, Optional, TextIO, Tuple
 
@@ -155,22 +154,24 @@ class RetrievalTrainingModule(torch.nn.Module):
             if self.prefix:
                 docs = [(i, field.name + ": " + t) for i, t in docs]            # :476-481
             vec = self.vectors_dict[key]
-            # A text that occurs more than once in the field (above all "": documents that lack the field, format.py:58-59)
-            # is encoded ONCE and its embedding re-used: less encoder work, and the rows are bit-identical, which lets the
-            # index treat them as one duplicate group (csrc/mfar_screen.h) instead of thousands of near-ties.
-            counts = Counter(t for _, t in docs)
-            shared: Dict[str, torch.Tensor] = {}
-            for b in range(0, len(docs), bs):
-                chunk = docs[b:b + bs]
-                texts = [t for _, t in chunk]
-                todo = list(dict.fromkeys(t for t in texts if t not in shared))   # distinct, first-seen order
-                fresh = {}
-                if todo:
-                    enc = self.encoder.encode(todo, batch_size=bs, convert_to_tensor=True).float()
-                    fresh = {t: enc[i] for i, t in enumerate(todo)}
-                    shared.update({t: v.clone() for t, v in fresh.items() if counts[t] > 1})
-                emb = torch.stack([shared[t] if t in shared else fresh[t] for t in texts])
-                vec.write_block(chunk[0][0], emb.contiguous())                   # straight into the HBM slab
+            # Encode every DISTINCT text of the field once, shortest first (length-bucketed batches: no padding to the
+            # longest document of an arbitrary corpus slice), then gather the rows in corpus order.  A text that occurs more
+            # than once -- above all "": documents that lack the field, format.py:58-59 -- gets bit-identical rows, which
+            # lets the index treat them as one duplicate group (csrc/mfar_screen.h) instead of thousands of near-ties.
+            texts = [t for _, t in docs]
+            uniq = list(dict.fromkeys(texts))
+            slot = {t: i for i, t in enumerate(uniq)}
+            order = sorted(range(len(uniq)), key=lambda i: len(uniq[i]))
+            emb_u = torch.empty(len(uniq), self.slab.dim, device=self.device)
+            for b in range(0, len(order), bs):
+                sel = order[b:b + bs]
+                enc = self.encoder.encode([uniq[i] for i in sel], batch_size=bs, convert_to_tensor=True).float()
+                emb_u[torch.tensor(sel, device=self.device)] = enc
+            rows = torch.tensor([slot[t] for t in texts], device=self.device)
+            step = max(bs, 65536)
+            for b in range(0, len(docs), step):
+                vec.write_block(docs[b][0], emb_u.index_select(0, rows[b:b + step]).contiguous())   # straight into the HBM slab
+            del emb_u
         torch.cuda.synchronize(self.device)
         _barrier()                                                               # :491 (no memmap reopen needed)
         self._corpus_encoded = True
