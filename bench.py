@@ -10,8 +10,8 @@ ranks exactly like the reference shards its corpus encode (reference mfar/modeli
 one pass of the hot path over one batch of 64 query embeddings (reference default dev_batch_size, train.py:45):
 per-field exhaustive top-100 -> candidate union -> re-score -> mask -> query-conditioned field-weight softmax ->
 top-100, i.e. RetrievalTrainingModule.trec_eval_step (contrastive.py:669-704) with the encoder forward excluded
-(query embeddings are inputs, already in HBM).  N > 1: per-shard payloads are exchanged with ONE RCCL all-gather and
-merged on every rank.  The corpus is fixed while N grows: strong scaling.
+(query embeddings are inputs, already in HBM).  N > 1: lists-first exchange (two small RCCL all-gathers per batch, every rank
+re-scores only the candidates it owns).  The corpus is fixed while N grows: strong scaling.
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel from its HIP-event duration measured on the
 launch stream.  Default (fp32 index, certified fp16 screen on): `mfar_stage1_f16_kernel`, HBM-bound, algorithmic bytes =
@@ -183,7 +183,8 @@ def main():
             "config": {"workload": f"synthetic STaRK-amazon-shaped corpus, {D} docs x {F} dense fields x {E}d {args.dtype}, "
                                    f"row-sharded over {N} GPU(s); two-stage scorer k1=k2=100, zero-sentinel mode",
                        "docs": D, "fields": F, "dim": E, "query_batch": Q, "k1": K1, "k2": K2,
-                       "parallelism": f"row-shard x{N} + RCCL all-gather merge" if N > 1 else "single shard",
+                       "parallelism": (f"row-shard x{N}, lists-first exchange over RCCL (per batch: all-gather of the stage-1 lists, "
+                                       f"all-gather of the local top-k, all-reduce of the certificate flag)") if N > 1 else "single shard",
                        "pipeline": "2 batches in flight (stage 1 of batch i+1 overlaps the tail of batch i)"},
             "stage1": ("certified fp16 screen of the fp32 slab (k+64 rows per list re-scored with the exact fp32 chain, top-k proven "
                        "or redone by the exact fp32 pass per field): outputs bit-identical to the plain fp32 pass" if screened else
