@@ -170,8 +170,9 @@ def main():
         s1_kernel = f"mfar_stage1_bf16{rr}_kernel" if args.dtype == "bf16" else (f"mfar_stage1_f16{rr}_kernel" if screened else "mfar_stage1_kernel")
         achieved_tf = flops_per_launch / (s1_avg_ms * 1e-3) / 1e12 if s1_avg_ms > 0 else 0.0
         traffic = None          # HBM bytes per stage-1 launch from the committed PMC pass of this same workload
-        tj = os.path.join(ROOT, "profiles", "r01_stage1_f16_traffic.json" if screened else "r01_stage1_traffic.json")
-        if N == 1 and args.dtype == "f32" and (D, F, E, Q) == (1_000_000, 8, 768, 64) and os.path.exists(tj):
+        tj = os.path.join(ROOT, "profiles", "r01_stage1_bf16_traffic.json" if args.dtype == "bf16" else
+                          ("r01_stage1_f16_traffic.json" if screened else "r01_stage1_traffic.json"))
+        if N == 1 and (D, F, E, Q) == (1_000_000, 8, 768, 64) and os.path.exists(tj):
             t_ = json.load(open(tj))
             if t_.get("kernel") == s1_kernel:
                 traffic = t_["hbm_read_bytes_per_launch"] + t_["hbm_write_bytes_per_launch"]

@@ -12,4 +12,8 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_G
 python $R/tools/prof_summary.py /tmp/kt /tmp/pf /tmp/pw /tmp/ps > $O/rocprofv3_summary.txt
 python $R/tools/prof_summary.py --traffic-json $O/stage1_f16_traffic.json /tmp/pf /tmp/pw mfar_stage1_f16r_kernel
 python $R/tools/trace_timeline.py /tmp/kt > $O/timeline.txt 2>/dev/null
+# the bf16 slab: traffic of its scan kernel
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/bf -o r1 --output-format csv -- python $R/bench.py --dtype bf16 --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/bw -o r1 --output-format csv -- python $R/bench.py --dtype bf16 --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python $R/tools/prof_summary.py --traffic-json $O/stage1_bf16_traffic.json /tmp/bf /tmp/bw mfar_stage1_bf16r_kernel
 tail -c 600 $O/bench.json
