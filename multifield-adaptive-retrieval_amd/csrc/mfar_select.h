@@ -417,6 +417,9 @@ struct ScoreParams {
 // fp32 slab: 64-byte segments (16 dims), 4 lanes per segment, ring slot = 1 k-step (4 KB per wave).
 // bf16 slab: 32-byte segments (16 dims), 2 lanes per segment, ring slot = 2 k-steps (4 KB per wave); the chain walks the
 //            dims in natural order and widens bf16 -> fp32 exactly, so scores equal the oracle's bits.
+#ifndef SC_AUX
+#define SC_AUX 0                             // cache policy of the row gathers (2 = non-temporal)
+#endif
 #define SC_SLOT_BYTES 4096
 #define SC_WAVE_BYTES (2 * SC_SLOT_BYTES)   // two-slot ring; 35 KB per workgroup with the query row: fits beside two
                                             // resident stage-1 workgroups when batches are pipelined
@@ -475,7 +478,7 @@ __global__ void __launch_bounds__(256) mfar_score_candidates_kernel(const ScoreP
     _Pragma("unroll") for (int s_ = 0; s_ < STEPS; ++s_) _Pragma("unroll") for (int i = 0; i < IPS; ++i)           \
         __builtin_amdgcn_global_load_lds(                                                                         \
             (const __attribute__((address_space(1))) void*)(src[i] + (size_t)((G) * STEPS + s_) * STEP_STRIDE),    \
-            (__attribute__((address_space(3))) void*)(ring + (SLOT) * SC_SLOT_BYTES + s_ * (64 * SEG) + i * 1024), 16, 0, 0)
+            (__attribute__((address_space(3))) void*)(ring + (SLOT) * SC_SLOT_BYTES + s_ * (64 * SEG) + i * 1024), 16, 0, SC_AUX)
     SC_ISSUE(0, 0);
     float acc = 0.0f;
     for (int g = 0; g < n_groups; ++g) {
