@@ -94,14 +94,24 @@ __device__ __forceinline__ float mfar_exp(float x) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Tiled slab layout ("LDS-image order").  One field of the index is stored as
-//     [n_blk 64-row blocks][n_steps = E/16][64 rows][16 floats]
-// so that the 4 KB a wave needs for one k-step of its 64 rows is ONE contiguous, already bank-swizzled piece:
-// a wave streams its block with four linear 1 KB global_load_lds_dwordx4 per step, and HBM sees purely sequential
-// reads.  Inside a 4 KB tile, the 16-byte granule at (row rr, position p) holds dims 16*step + 4*c .. +3 with
-// c = p ^ ((rr >> 2) & 3): ds_read_b128 of one k-chunk over 16 consecutive rows then touches all 64 banks once.
+// fp32 slab layout.  One field of the index is stored as
+//     [n_blk 64-row blocks][n_steps / 2 k-step PAIRS][64 rows][32 floats]
+// i.e. 8 KB tiles in which every row owns one full 128-byte line (dims 32*pair .. 32*pair + 31, natural order).
+//   * the exact fp32 pass streams a block tile by tile: per k-step each lane fetches one 16-byte granule (LDS-DMA), the
+//     bank swizzle of the LDS image is applied by the lane -> granule mapping, not by the memory layout; the two k-steps
+//     of a pair touch the same lines, the second time in L2;
+//   * the row gathers (exact re-scoring of the screened lists, stage 2) fetch whole lines: E/32 lines per (row, field),
+//     no half of a fetched line belongs to another row (the former [64][16] tiles wasted every second 64 bytes fetched:
+//     the gathers moved 2x the bytes they used).
+// The query tile of the exact pass keeps the 4 KB LDS-image layout ([n_steps][64 queries][16 floats], granule position
+// p = c ^ ((rr >> 2) & 3)): lds_image_offset().
 // ---------------------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ size_t tiled_offset(int64_t n_steps, int64_t row, int e) {
+    const int64_t blk = row >> 6;
+    const int rr = (int)(row & 63);
+    return (size_t)((blk * (n_steps >> 1) + (e >> 5)) * 2048 + rr * 32 + (e & 31));
+}
+__host__ __device__ __forceinline__ size_t lds_image_offset(int64_t n_steps, int64_t row, int e) {
     const int64_t blk = row >> 6;
     const int rr = (int)(row & 63);
     const int step = e >> 4;

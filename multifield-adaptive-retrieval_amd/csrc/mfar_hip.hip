@@ -115,7 +115,7 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_topk_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_shards_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_shards_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)mfar_score_candidates_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_score_rows_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_score_candidates_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1B_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1B_LDS_BYTES));
@@ -717,7 +717,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     sp.F = F;
     sp.C = kp;
     sp.per_field = 1;
-    mfar_score_candidates_kernel<0><<<dim3((unsigned)((kp * F + 255) / 256), qt_n), dim3(256), SCORE_LDS_BYTES(idx->E), st>>>(sp);
+    mfar_score_rows_f32_kernel<<<dim3((unsigned)((kp * F + SCF_THREADS - 1) / SCF_THREADS), qt_n), dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(sp);
     HIPCHK(hipGetLastError());
     // 3. exact top-k + certificate
     CertifyParams cp = {};
@@ -875,10 +875,10 @@ static int run_score(mfar_index* idx, const float* q, int Q, const long long* ca
     p.E = idx->E;
     p.F = idx->F;
     p.C = C;
-    const unsigned gx = (unsigned)(((size_t)C * idx->F + 255) / 256);
+    const unsigned gx = (unsigned)(((size_t)C * idx->F + 255) / 256), gf = (unsigned)(((size_t)C * idx->F + SCF_THREADS - 1) / SCF_THREADS);
     if (gx == 0 || Q == 0) return MFAR_OK;
     if (idx->dtype == MFAR_DTYPE_BF16) mfar_score_candidates_kernel<1><<<dim3(gx, Q), dim3(256), SCORE_LDS_BYTES(idx->E), st>>>(p);
-    else mfar_score_candidates_kernel<0><<<dim3(gx, Q), dim3(256), SCORE_LDS_BYTES(idx->E), st>>>(p);
+    else mfar_score_rows_f32_kernel<<<dim3(gf, Q), dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(p);
     HIPCHK(hipGetLastError());
     return MFAR_OK;
 }

@@ -82,21 +82,24 @@ __global__ void __launch_bounds__(256) mfar_screen_stats_kernel(const float* __r
                                                                 long long n_rows, const float* __restrict__ mean,
                                                                 u32* __restrict__ stats) {
     const int f = blockIdx.y;
-    const int rr = threadIdx.x >> 2, pp = threadIdx.x & 3;
+    const int rr = threadIdx.x >> 2, pp = threadIdx.x & 3;   // thread = quarter pp (8 floats) of row rr's 128-byte line per k-step pair
     const bool live = (long long)blockIdx.x * 64 + rr < n_rows;   // padding rows are not part of the field
-    const float* tile = slab + (size_t)f * field_stride + (size_t)blockIdx.x * n_steps * 1024 + threadIdx.x * 4;
-    const float* mrow = mean + (size_t)f * n_steps * 16 + ((pp ^ ((rr >> 2) & 3)) << 2);
+    const float* tile = slab + (size_t)f * field_stride + (size_t)blockIdx.x * n_steps * 1024 + rr * 32 + pp * 8;
+    const float* mrow = mean + (size_t)f * n_steps * 16 + pp * 8;
     float amax = 0.0f, ss = 0.0f;
     if (live)
-        for (int s = 0; s < n_steps; ++s) {
-            const f32x4 v = *(const f32x4*)(tile + (size_t)s * 1024) - *(const f32x4*)(mrow + s * 16);
+        for (int pr = 0; pr < (n_steps >> 1); ++pr) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                amax = fmaxf(amax, fabsf(v[i]));
-                ss = __builtin_fmaf(v[i], v[i], ss);
+            for (int hq = 0; hq < 2; ++hq) {
+                const f32x4 v = *(const f32x4*)(tile + (size_t)pr * 2048 + hq * 4) - *(const f32x4*)(mrow + pr * 32 + hq * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    amax = fmaxf(amax, fabsf(v[i]));
+                    ss = __builtin_fmaf(v[i], v[i], ss);
+                }
             }
         }
-    // threads 4r .. 4r+3 hold the four 16-byte pieces of row r
+    // threads 4r .. 4r+3 hold the four quarters of row r
     ss += __shfl_xor(ss, 1);
     ss += __shfl_xor(ss, 2);
     u32 a = __float_as_uint(amax), n = __float_as_uint(ss) & 0x7FFFFFFFu;
@@ -145,14 +148,15 @@ __global__ void __launch_bounds__(256) mfar_screen_build_kernel(const float* __r
     if (g >= n_granules) return;
     const int f = blockIdx.y;
     const float sc = sf[f].scale;
-    const long long tile = g >> 7;           // 128 granules per [64][16] tile
+    const long long tile = g >> 7;           // 128 granules per [64][16] fp16 tile = (block, k-step)
     const int rr = (int)(g >> 1) & 63, c8 = (int)g & 1;
-    const int sw = (rr >> 2) & 3;
     const int step = (int)(tile % n_steps);
-    const float* src = slab + (size_t)f * field_stride + (size_t)tile * 1024 + rr * 16;
+    const long long blk = tile / n_steps;
+    // source: row rr's 128-byte line of k-step pair step / 2, half step & 1, dims 8 c8 .. 8 c8 + 7 of the step
+    const float* src = slab + (size_t)f * field_stride + (size_t)(blk * (n_steps >> 1) + (step >> 1)) * 2048 + rr * 32 + (step & 1) * 16 + c8 * 8;
     const float* m = mean + (size_t)f * n_steps * 16 + step * 16 + c8 * 8;
-    const f32x4 a = *(const f32x4*)(src + (((2 * c8) ^ sw) << 2)) - *(const f32x4*)m;
-    const f32x4 b = *(const f32x4*)(src + (((2 * c8 + 1) ^ sw) << 2)) - *(const f32x4*)(m + 4);
+    const f32x4 a = *(const f32x4*)src - *(const f32x4*)m;
+    const f32x4 b = *(const f32x4*)(src + 4) - *(const f32x4*)(m + 4);
     f16x8 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -256,19 +260,22 @@ __global__ void __launch_bounds__(256) mfar_dup_compare_kernel(const float* __re
     const int f = blockIdx.y;
     const int cand = grp[f].cand;
     if (cand < 0) return;   // workgroup-uniform
-    const int rr = threadIdx.x >> 2, pp = threadIdx.x & 3;
+    const int rr = threadIdx.x >> 2, pp = threadIdx.x & 3;   // thread = quarter pp (8 floats) of row rr's line per k-step pair
     const long long row = (long long)blockIdx.x * 64 + rr;
-    const float* tile = slab + (size_t)f * field_stride + (size_t)blockIdx.x * n_steps * 1024 + threadIdx.x * 4;
-    const int e0 = (pp ^ ((rr >> 2) & 3)) << 2;   // this thread's dims inside a k-step
+    const float* tile = slab + (size_t)f * field_stride + (size_t)blockIdx.x * n_steps * 1024 + rr * 32 + pp * 8;
+    const float* cnd = slab + (size_t)f * field_stride + tiled_offset(n_steps, cand, pp * 8);
     bool same = row < n_rows;
-    for (int s = 0; s < n_steps; ++s) {
+    for (int pr = 0; pr < (n_steps >> 1); ++pr) {
         if (!__any(same)) break;   // wave-uniform
-        const f32x4 a = *(const f32x4*)(tile + (size_t)s * 1024);
-        const f32x4 b = *(const f32x4*)(slab + (size_t)f * field_stride + tiled_offset(n_steps, cand, s * 16 + e0));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) same = same && __float_as_uint(a[i]) == __float_as_uint(b[i]);
+        for (int hq = 0; hq < 2; ++hq) {
+            const f32x4 a = *(const f32x4*)(tile + (size_t)pr * 2048 + hq * 4);
+            const f32x4 b = *(const f32x4*)(cnd + (size_t)pr * 2048 + hq * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) same = same && __float_as_uint(a[i]) == __float_as_uint(b[i]);
+        }
     }
-    // threads 4r .. 4r+3 hold the four pieces of row r
+    // threads 4r .. 4r+3 hold the four quarters of row r
     same = (__shfl_xor((int)same, 1) & (int)same) != 0;
     same = (__shfl_xor((int)same, 2) & (int)same) != 0;
     const u64 m = __ballot(same && pp == 0);   // bit 4r set: row r of this wave's 16 rows equals the candidate

@@ -37,7 +37,7 @@ __global__ void mfar_tile_queries_kernel(const float* __restrict__ q, float* __r
     const int e = (gid - r * gpr) << 2;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (q0 + r < Q) v = *(const f32x4*)(q + (size_t)(q0 + r) * E + e);
-    *(f32x4*)(qt + tiled_offset(E >> 4, r, e)) = v;
+    *(f32x4*)(qt + lds_image_offset(E >> 4, r, e)) = v;
 }
 
 // bf16 slab variants: rows are rounded to bf16 (RNE) on the way in and widened exactly on the way out
@@ -526,6 +526,101 @@ __global__ void __launch_bounds__(256) mfar_score_candidates_kernel(const ScoreP
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 #undef SC_ISSUE
+    if (idx < p.C * p.F) p.out[(size_t)qi * p.C * p.F + idx] = valid ? acc : __builtin_nanf("");
+}
+
+// fp32 slab: every (row, k-step pair) is one full 128-byte line (mfar_device.h), so a wave gathers 64 rows x 128 B = 8 KB
+// per ring slot: 8 lanes per row, 8 rows per 1 KB LDS-DMA instruction, 8 instructions per slot; two slots per wave.  A
+// workgroup is 2 waves (32 KB + the query row: fits beside two resident stage-1 workgroups).  The 16-byte pieces of a row
+// are stored at position piece ^ (row & 7) inside its 128 bytes, which spreads the lanes' ds_read_b128 over the banks.
+// Chain order = the arithmetic contract (inside every aligned group of 8 dims: 0,4,1,5,2,6,3,7).
+#define SCF_THREADS 128
+#define SCF_SLOT_BYTES 8192
+#define SCF_WAVE_BYTES (2 * SCF_SLOT_BYTES)
+#define SCORE_F32_LDS_BYTES(E) ((size_t)(SCF_THREADS / 64) * SCF_WAVE_BYTES + (size_t)(E) * 4)
+__global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_f32_kernel(const ScoreParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qs = (float*)(smem + (SCF_THREADS / 64) * SCF_WAVE_BYTES);
+    const int qi = blockIdx.y;
+    const int nc = p.n_cand ? p.n_cand[qi] : p.C;
+    const int first = blockIdx.x * blockDim.x;
+    const int idx = first + threadIdx.x;
+    if (first >= nc * p.F) {
+        // slots past the candidate count: define the output (NaN) so downstream never reads garbage
+        if (idx < p.C * p.F) p.out[(size_t)qi * p.C * p.F + idx] = __builtin_nanf("");
+        return;
+    }
+    for (int e = threadIdx.x; e < p.E; e += blockDim.x) qs[e] = p.q[(size_t)qi * p.E + e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* ring = smem + w * SCF_WAVE_BYTES;
+    // this lane's row
+    bool valid = false;
+    int rr = 0;
+    const char* rowbase = (const char*)p.slab;  // harmless in-bounds address for invalid rows
+    if (idx < p.C * p.F) {
+        const int c = p.per_field ? idx % p.C : idx / p.F;
+        const int f = p.per_field ? idx / p.C : idx - c * p.F;
+        if (c < nc) {
+            const long long id = p.cand[p.per_field ? ((size_t)qi * p.F + f) * p.C + c : (size_t)qi * p.C + c] - p.row_offset;
+            if (id >= 0 && id < p.n_rows) {
+                valid = true;
+                rr = (int)(id & 63);
+                rowbase = (const char*)p.slab + ((size_t)f * p.field_stride + (size_t)(id >> 6) * p.n_steps * 1024) * 4 + rr * 128;
+            }
+        }
+    }
+    // lane l fetches, for the rows (l / 8) + 8 i, the piece that belongs at LDS position l % 8: piece (l % 8) ^ (row & 7)
+    const char* src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = (lane >> 3) + 8 * i;
+        const unsigned long long b = (unsigned long long)rowbase;
+        const u32 lo = __shfl((int)(u32)b, r), hi = __shfl((int)(u32)(b >> 32), r);
+        const int rr_r = __shfl(rr, r);
+        src[i] = (const char*)(((unsigned long long)hi << 32) | lo) + (((lane & 7) ^ (rr_r & 7)) << 4);
+    }
+    const int n_pairs = p.n_steps >> 1;
+#define SCF_ISSUE(G, SLOT)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) __builtin_amdgcn_global_load_lds(                                \
+        (const __attribute__((address_space(1))) void*)(src[i] + (size_t)(G) * 8192),                              \
+        (__attribute__((address_space(3))) void*)(ring + (SLOT) * SCF_SLOT_BYTES + i * 1024), 16, 0, SC_AUX)
+    SCF_ISSUE(0, 0);
+    float acc = 0.0f;
+    const int sw = rr & 7;
+    for (int g = 0; g < n_pairs; ++g) {
+        const int slot = g & 1;
+        if (g + 1 < n_pairs) {
+            SCF_ISSUE(g + 1, slot ^ 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 8 loads of the next slot may stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const float* t = (const float*)(ring + slot * SCF_SLOT_BYTES + lane * 128);
+        const float* qq = qs + g * 32;
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {   // the two k-steps of the pair: pieces 4 hs .. 4 hs + 3 = dims 16 hs .. 16 hs + 15
+            const f32x4 c0 = *(const f32x4*)(t + (((4 * hs + 0) ^ sw) << 2));
+            const f32x4 c1 = *(const f32x4*)(t + (((4 * hs + 1) ^ sw) << 2));
+            const f32x4 c2 = *(const f32x4*)(t + (((4 * hs + 2) ^ sw) << 2));
+            const f32x4 c3 = *(const f32x4*)(t + (((4 * hs + 3) ^ sw) << 2));
+            const float* qh = qq + 16 * hs;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                acc = __builtin_fmaf(qh[x], c0[x], acc);
+                acc = __builtin_fmaf(qh[4 + x], c1[x], acc);
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                acc = __builtin_fmaf(qh[8 + x], c2[x], acc);
+                acc = __builtin_fmaf(qh[12 + x], c3[x], acc);
+            }
+        }
+        // the LDS reads of this slot have been consumed before the slot is re-filled two iterations later
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#undef SCF_ISSUE
     if (idx < p.C * p.F) p.out[(size_t)qi * p.C * p.F + idx] = valid ? acc : __builtin_nanf("");
 }
 

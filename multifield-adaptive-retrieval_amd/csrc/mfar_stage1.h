@@ -411,24 +411,33 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
 
     char* const dring = smem + w * (S1_STAGES * 4096);
     const size_t step_bytes = 4096;
-    const size_t tile_jump = (size_t)3 * p.n_steps * step_bytes;  // from the end of block b to the start of block b+4
-    // load cursor (runs two k-steps ahead of the compute cursor)
-    const char* dnext = (const char*)p.slab + ((size_t)f * (size_t)p.field_stride) * 4 +
-                        ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes + lane * 16;
+    // The slab stores a block as k-step PAIRS of [64 rows][32 floats] (mfar_device.h).  This lane's granule of the four 1 KB
+    // DMA pieces of a k-step: piece pc covers rows 16 pc .. 16 pc + 15 of the wave's block, and LDS slot (row, position p)
+    // must receive dims chunk c = p ^ ((row >> 2) & 3) -- the bank swizzle lives in this mapping, not in memory.
+    int loff[4];
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) {
+        const int rr = 16 * pc + (lane >> 2), c = (lane & 3) ^ ((rr >> 2) & 3);
+        loff[pc] = rr * 128 + c * 16;
+    }
+    // load cursor (runs two k-steps ahead of the compute cursor): base of the wave's block of the current tile
+    const char* dblk = (const char*)p.slab + ((size_t)f * (size_t)p.field_stride) * 4 + ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes;
+    const size_t tile_jump = (size_t)4 * p.n_steps * step_bytes;  // to the wave's block of the next tile
     const char* const qbase = (const char*)p.qt + w * 1024 + lane * 16;
     int s_next = 0, st_next = 0;
     const int total = (t1 - t0) * p.n_steps;
     int issued = 0;
-    // one k-step of loads: the wave's own 4 KB doc tile (nt: read once per batch) + its quarter of the shared query tile
+    // one k-step of loads: the wave's own 4 KB of docs (cached: the other k-step of the pair reads the same lines) + its
+    // quarter of the shared query tile
 #define S1_ISSUE_NEXT()                                                                                   \
     do {                                                                                                  \
         char* db_ = dring + st_next * 4096;                                                               \
-        _Pragma("unroll") for (int pc = 0; pc < 4; ++pc) S1_GLDS(dnext + pc * 1024, db_ + pc * 1024, 2);   \
+        const char* src_ = dblk + (size_t)(s_next >> 1) * 8192 + (s_next & 1) * 64;                       \
+        _Pragma("unroll") for (int pc = 0; pc < 4; ++pc) S1_GLDS(src_ + loff[pc], db_ + pc * 1024, 0);     \
         S1_GLDS(qbase + (size_t)s_next * step_bytes, qring + st_next * 4096 + w * 1024, 0);               \
-        dnext += step_bytes;                                                                              \
         if (++s_next == p.n_steps) {                                                                      \
             s_next = 0;                                                                                   \
-            dnext += tile_jump;                                                                           \
+            dblk += tile_jump;                                                                            \
         }                                                                                                 \
         st_next = (st_next == S1_STAGES - 1) ? 0 : st_next + 1;                                           \
         ++issued;                                                                                         \
