@@ -410,13 +410,13 @@ struct ScoreParams {
     int n_rows, n_steps, E, F, C;
     int per_field;           // != 0: cand is [Q, F, C] (one list per field), out is [Q, F, C]: row (f, c) is scored for field f only
 };
-// Each wave owns 64 (candidate, field) rows, one per lane.  A row of the tiled slab is 64-byte segments 4 KB apart
-// (one per k-step), so the wave gathers them cooperatively -- 4 lanes per segment, 16 segments per 1 KB LDS-DMA
-// instruction -- into a private two-slot LDS ring (2 k-steps per slot), and every lane then walks ITS row's segment
-// from LDS in chain order.  No barriers: the ring is private to the wave, ordered by counted vmcnt waits.
-// fp32 slab: 64-byte segments (16 dims), 4 lanes per segment, ring slot = 1 k-step (4 KB per wave).
-// bf16 slab: 32-byte segments (16 dims), 2 lanes per segment, ring slot = 2 k-steps (4 KB per wave); the chain walks the
-//            dims in natural order and widens bf16 -> fp32 exactly, so scores equal the oracle's bits.
+// Each wave owns 64 (candidate, field) rows, one per lane, gathers their segments cooperatively by LDS-DMA into a private
+// two-slot LDS ring, and every lane then walks ITS row's segment from LDS in chain order.  No barriers: the ring is private
+// to the wave, ordered by counted vmcnt waits.
+// bf16 slab (this kernel, DT = 1): 32-byte segments (16 dims) 2 KB apart, 2 lanes per segment, ring slot = 2 k-steps (4 KB
+//            per wave); the chain walks the dims in natural order and widens bf16 -> fp32 exactly, so scores equal the
+//            oracle's bits.  (Each segment costs a whole 128-byte line: the bf16 slab is laid out for the scan.)
+// fp32 slab: mfar_score_rows_f32_kernel below (whole-line gathers).
 #ifndef SC_AUX
 #define SC_AUX 0                             // cache policy of the row gathers (2 = non-temporal)
 #endif
