@@ -85,7 +85,8 @@ def main():
 
     D, F, E, Q = args.docs, args.fields, args.dim, args.batch
     K1 = K2 = 100
-    n_q_total = max(4096, (args.steps + args.warmup) * Q)
+    # distinct synthetic queries (each plants up to 5 relevant documents); long runs cycle through them
+    n_q_total = max(Q, min(max(4096, (args.steps + args.warmup) * Q), 65536, D // 16))
     t_build = time.time()
     corpus = synth.SyntheticCorpus(D, F, E, n_queries=n_q_total, seed=0xDEADBEEF, device=str(dev))
     row0, row1 = D * rank // N, D * (rank + 1) // N          # contrastive.py:470
