@@ -693,10 +693,9 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     int* fflags = sl.fail.as<int>();
     // 1. screened pass on the fp16 slab: the k' best approximate scores per (query, field)
     if (phases & S1_PREPARE) {
-        HIPCHK(hipMemsetAsync(fflags, 0, (size_t)(F + 1) * 4, st));   // field flags + "any"; [F+1] accumulates statistics
         mfar_screen_queries_kernel<<<dim3(64), dim3(256), 0, st>>>(q, (_Float16*)sl.qt16.p, sl.qinfo.as<ScreenQuery>(),
                                                                    idx->s_field.as<ScreenField>(), sl.eps.as<float>(), sl.base.as<float>(),
-                                                                   q0, Q, idx->E, F, idx->screen_eps_mult);
+                                                                   fflags, q0, Q, idx->E, F, idx->screen_eps_mult);
         HIPCHK(hipGetLastError());
     }
     const S1Out so = {sl.sids.as<long long>(), sl.ssc.as<float>(), sl.scnt.as<int>(), 0, 0};

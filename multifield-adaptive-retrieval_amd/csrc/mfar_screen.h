@@ -339,10 +339,13 @@ __global__ void __launch_bounds__(64) mfar_dup_finish_kernel(DupGroup* __restric
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* __restrict__ q, _Float16* __restrict__ qt,
                                                                   ScreenQuery* __restrict__ qinfo, const ScreenField* __restrict__ sf,
-                                                                  float* __restrict__ eps, float* __restrict__ tau_base, int q0, int Q,
-                                                                  int E, int F, float eps_mult) {
+                                                                  float* __restrict__ eps, float* __restrict__ tau_base,
+                                                                  int* __restrict__ fail_flags, int q0, int Q, int E, int F,
+                                                                  float eps_mult) {
     __shared__ float red_a[4], red_s[4];
     const int r = blockIdx.x;
+    // a new batch: clear the certificate flags of the fields and the "any" flag ([F + 1] keeps accumulating statistics)
+    if (r == 0 && (int)threadIdx.x <= F) fail_flags[threadIdx.x] = 0;
     const bool live = q0 + r < Q;
     const float* row = q + (size_t)(q0 + (live ? r : 0)) * E;
     // ONE round of global loads (this kernel opens a batch on the critical path, usually while the previous batch's gathers
