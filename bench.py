@@ -10,17 +10,28 @@ ranks exactly like the reference shards its corpus encode (reference mfar/modeli
 one pass of the hot path over one batch of 64 query embeddings (reference default dev_batch_size, train.py:45):
 per-field exhaustive top-100 -> candidate union -> re-score -> mask -> query-conditioned field-weight softmax ->
 top-100, i.e. RetrievalTrainingModule.trec_eval_step (contrastive.py:669-704) with the encoder forward excluded
-(query embeddings are inputs, already in HBM).  N > 1: lists-first exchange (two small RCCL all-gathers per batch, every rank
-re-scores only the candidates it owns).  The corpus is fixed while N grows: strong scaling.
+(query embeddings are inputs, already in HBM).  N > 1: lists-first exchange (two small RCCL all-gathers per batch, every
+rank re-scores only the candidates it owns).  The corpus is fixed while N grows: strong scaling.
 
-Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel from its HIP-event duration measured on the
-launch stream.  Default (fp32 index, certified fp16 screen on): `mfar_stage1_f16_kernel`, HBM-bound, algorithmic bytes =
-D_local * F * E * 2 per launch (the fp16 screen slab is read once per batch).  `--screen off`: `mfar_stage1_kernel`,
-fp32-MFMA-bound, algorithmic flops = 2 * D_local * F * E * 64 per launch.  The results are bit-identical in both modes.
-`cpu_baseline` times the oracle's torch port of the reference algorithm (same torch ops as the reference's CPU path)
-on a bounded row sample of the same corpus, on this box's host cores (N = 1 only).
+Prints ONE JSON line on rank 0:
+  roofline             the dominant kernel of the timed region, priced from its HIP-event duration on its launch stream.
+                       Default: the certified fp16 SCREEN scan of the fp32 index (HBM-bound); its algorithmic bytes are
+                       the fp16 screen rows it has to read once per batch.  The line also carries SURVEY 8(d)'s fp32
+                       figure (D*F*E*4 per batch) so nobody reads the screen's rate as "fp32 slab at > HBM peak": the
+                       speed comes from a proven-exact byte cut (every list certified or redone), not from the kernel.
+  roofline_exact_fp32  a short second leg of the SAME run with the screen off: the exhaustive fp32 MFMA pass
+                       (`mfar_stage1_kernel`, 2*D*F*E*64 flops per launch against the 157.3 TFLOP/s fp32 MFMA peak).
+                       Same output bits as the default leg (asserted on the last batch).
+  cpu_baseline         the oracle's torch port of the reference algorithm (same torch ops as the reference's CPU path) on
+                       this box's host cores, on the FULL corpus when host RAM allows; every GPU-vs-port difference is
+                       classified (order swap inside a <= 1e-4 tie / cut-off near-tie in the final or the stage-1 list /
+                       other) and the run FAILS on "other".
+  structured_corpus    a short leg on a corpus with realistic duplicate structure (Zipf-distributed duplicates, a
+                       10-distinct-value field, a heavy-tailed-norm field): unique rows per field, lists certified vs. redone.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -32,12 +43,50 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
+K1 = K2 = 100
+
+
+def source_hash() -> str:
+    """Identity of the kernels: sha256 over the HIP sources.  Profile files under profiles/ carry the hash of the sources
+    they were measured with; bench.py only quotes counters (HBM traffic, MFMA utilisation) whose hash matches."""
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "multifield-adaptive-retrieval_amd", "csrc", "*.h")) +
+                     glob.glob(os.path.join(ROOT, "multifield-adaptive-retrieval_amd", "csrc", "*.hip")) +
+                     [os.path.join(ROOT, "include", "mfar_hip.h")]):
+        h.update(os.path.basename(fn).encode())
+        h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_counters(kernel: str, shape) -> dict:
+    """{traffic, mfma_util, source} for `kernel` from a committed rocprofv3 PMC summary of this exact workload AND these
+    exact sources (tools/prof_round.sh writes profiles/*_counters.json); empty when none matches."""
+    want = source_hash()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), reverse=True):
+        try:
+            d = json.load(open(fn))
+        except Exception:
+            continue
+        if d.get("source_hash") != want or tuple(d.get("shape", ())) != tuple(shape):
+            continue
+        k = d.get("kernels", {}).get(kernel)
+        if k:
+            return {"traffic": k.get("hbm_bytes_per_launch"), "mfma_util": k.get("mfma_util"),
+                    "counters_source": os.path.relpath(fn, ROOT) + " (rocprofv3 --pmc passes, same sources: " + want + ")"}
+    return {"traffic": None, "mfma_util": None, "counters_source": None}
+
+
+def s1_kernel_name(dtype, screened, E):
+    rr = "" if os.environ.get("MFAR_S1_REGRING", "1") == "0" else ("r" if (E // 16) % 6 == 0 else ("r4" if (E // 16) % 4 == 0 else ""))
+    if dtype == "bf16":
+        return f"mfar_stage1_bf16{rr}_kernel"
+    return f"mfar_stage1_f16{rr}_kernel" if screened else "mfar_stage1_kernel"
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--docs", type=int, default=1_000_000)
     ap.add_argument("--fields", type=int, default=8)
@@ -47,12 +96,21 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="slab storage (default: the exact fp32 path)")
     ap.add_argument("--screen", choices=["auto", "off"], default="auto",
                     help="f32 only: certified fp16 screening of stage 1 (bit-identical results; csrc/mfar_screen.h)")
+    ap.add_argument("--corpus", choices=["plain", "structured"], default="plain",
+                    help="structured: realistic duplicate / norm structure in three of the fields (mfar/synth.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-docs", type=int, default=100_000)
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the exact-fp32 leg and the structured-corpus leg")
+    ap.add_argument("--cpu-sample-docs", type=int, default=0, help="0 = the full corpus when host RAM allows, else 100000")
     args = ap.parse_args()
 
     import numpy as np
     import torch
+
+    # result-invalidating diagnostics must be off in a measured run
+    if os.environ.get("MFAR_S1_DEBUG", "0") not in ("", "0"):
+        raise SystemExit("MFAR_S1_DEBUG is set: the selection epilogue would be skipped and the results invalid")
+    if os.environ.get("MFAR_SCREEN_EPS_MULT", "1") not in ("", "1", "1.0"):
+        raise SystemExit("MFAR_SCREEN_EPS_MULT is set: the certificate would not be the rigorous one")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -82,71 +140,103 @@ def main():
 
     from mfar import synth
     from mfar.data import index as idxmod
+    from mfar.data.pipeline import PipelinedSearcher
 
     D, F, E, Q = args.docs, args.fields, args.dim, args.batch
-    K1 = K2 = 100
     # distinct synthetic queries (each plants up to 5 relevant documents); long runs cycle through them
     n_q_total = max(Q, min(max(4096, (args.steps + args.warmup) * Q), 65536, D // 16))
     t_build = time.time()
-    corpus = synth.SyntheticCorpus(D, F, E, n_queries=n_q_total, seed=0xDEADBEEF, device=str(dev))
+    corpus = synth.SyntheticCorpus(D, F, E, n_queries=n_q_total, seed=0xDEADBEEF, device=str(dev),
+                                   structured=(args.corpus == "structured"))
     row0, row1 = D * rank // N, D * (rank + 1) // N          # contrastive.py:470
     ix = corpus.build_index(idxmod, row0=row0, n=row1 - row0, dtype=args.dtype)
     if args.wgs_per_cu:
         ix.set_wgs_per_cu(args.wgs_per_cu)
     if args.screen == "off":
         ix.set_screen(0)
+    mode, eps_mult = ix.screen_setting
+    if eps_mult != 1.0:
+        raise SystemExit(f"screen eps_mult = {eps_mult}: the certificate would not be the rigorous one")
     t_build = time.time() - t_build
     W = corpus.W
     mask = torch.ones(F, device=dev)
 
-    from mfar.data.pipeline import PipelinedSearcher
     # Two-deep pipeline: stage 1 of batch i+1 (main stream) overlaps the tail of batch i (side stream).  Every batch is
     # still processed completely inside the timed region (the region ends with a full device synchronisation).
     ps = PipelinedSearcher(ix, W, mask, k1=K1, k2=K2, sentinel=True, query_cond=True, max_batch=Q)
 
-    def run(first, n, keep):
+    def run(searcher, cp, first, n, keep):
         prev = None
         for i in range(n):
-            t = ps.submit(corpus.queries((first + i) * Q, Q))
+            t = searcher.submit(cp.queries((first + i) * Q, Q))
             if prev is not None and keep is not None:
-                r = ps.result(prev)
-                keep.append((r["ids"].clone(), r["n_valid"].clone()))
+                r = searcher.result(prev)
+                keep.append((r["ids"].clone(), r["scores"].clone(), r["n_valid"].clone()))
             prev = t
-        if prev is not None and keep is not None:
-            r = ps.result(prev)
-            keep.append((r["ids"].clone(), r["n_valid"].clone()))
+        if prev is not None:
+            r = searcher.result(prev)
+            if keep is not None:
+                keep.append((r["ids"].clone(), r["scores"].clone(), r["n_valid"].clone()))
+
+    def timed(searcher, index, cp, first, steps, keep):
+        torch.cuda.synchronize()
+        if N > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        index.set_timing(True)
+        t0 = time.perf_counter()
+        run(searcher, cp, first, steps, keep)
+        torch.cuda.synchronize()
+        if N > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ms, n = index.stage1_timing()
+        index.set_timing(False)
+        if N > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, ms / max(1, n), n
 
     # Setup, not warm-up: the first two batches allocate the pipeline's scratch (both slots) and build the fp16 screen slab
     # of an fp32 index (one pass over the corpus, part of index construction).  --warmup steps follow as asked.
     t_prime = time.time()
-    run(0, 2, None)
+    run(ps, corpus, 0, 2, None)
     torch.cuda.synchronize()
     t_build += time.time() - t_prime
     results = []
-    run(0, args.warmup, None)
-    torch.cuda.synchronize()
-    if N > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ix.set_timing(True)
-    t0 = time.perf_counter()
-    run(args.warmup, args.steps, results)
-    torch.cuda.synchronize()
-    if N > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    s1_ms, s1_n = ix.stage1_timing()
-    ix.set_timing(False)
-    if N > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    run(ps, corpus, 0, args.warmup, None)
+    scr0 = ix.screen_stats()
+    dt, s1_avg_ms, s1_n = timed(ps, ix, corpus, args.warmup, args.steps, results)
+    scr = ix.screen_stats()
+    screened = args.dtype == "f32" and scr["built"]          # stage 1 ran on the fp16 screen slab of the fp32 index
+
+    # ---- second leg, same process, same index: the exhaustive fp32 MFMA pass (screen off), and its bits vs the default leg
+    exact_leg = None
+    if args.dtype == "f32" and screened and not args.no_extra_legs:
+        ix.set_screen(0)
+        run(ps, corpus, 0, 2, None)
+        ex_res = []
+        ex_steps = min(8, args.steps)
+        ex_dt, ex_ms, ex_n = timed(ps, ix, corpus, args.warmup + args.steps - ex_steps, ex_steps, ex_res)
+        ix.set_screen(1)
+        same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(results[-ex_steps:], ex_res))
+        if not same:
+            raise SystemExit("the certified screen and the exhaustive fp32 pass returned different bits")
+        fl = 2.0 * (row1 - row0) * F * E * 64
+        exact_leg = {"bound": "mfma", "kernel": "mfar_stage1_kernel", "achieved": fl / (ex_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": fl / (ex_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": ex_ms, "launches": ex_n,
+                     "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": float(row1 - row0) * F * E * 4,
+                     "hbm_GBps_algorithmic": float(row1 - row0) * F * E * 4 / (ex_ms * 1e-3) / 1e9,
+                     "queries_per_s": ex_steps * Q / ex_dt, "ms_per_step": ex_dt / ex_steps * 1e3,
+                     "ids_and_score_bits_identical_to_default_leg": True,
+                     **profile_counters("mfar_stage1_kernel", (D, F, E, Q, N))}
 
     if rank == 0:
         # Recall@20 against the synthetic qrels (quality gate named by the metric)
         rec = []
-        for i, (ids, nv) in enumerate(results):
+        for i, (ids, _, nv) in enumerate(results):
             ids = ids.cpu().numpy()
             rel = corpus.qrels((args.warmup + i) * Q, Q)
             for j in range(Q):
@@ -154,89 +244,141 @@ def main():
         recall20 = float(np.mean(rec))
         checksum = None
         if os.environ.get("MFAR_BENCH_DUMP_IDS") == "1":      # used by tests/test_gpu_multirank.py
-            import hashlib
             h = hashlib.sha256()
-            for ids, _ in results:
+            for ids, _, _ in results:
                 h.update(ids.cpu().numpy().tobytes())
             checksum = h.hexdigest()
         qps = args.steps * Q / dt
-        s1_avg_ms = s1_ms / max(1, s1_n)
         flops_per_launch = 2.0 * (row1 - row0) * F * E * 64      # algorithmic: 2*D*F*E per query x 64 queries
-        scr = ix.screen_stats()
-        screened = args.dtype == "f32" and scr["built"]          # stage 1 ran on the fp16 screen slab of the fp32 index
+        n_scan_rows = scr.get("scan_rows", (row1 - row0) * F) if screened else (row1 - row0) * F
         esize = 2 if (args.dtype == "bf16" or screened) else 4
-        bytes_per_launch = float(row1 - row0) * F * E * esize    # the scanned slab is read once per batch
-        # 16-bit passes: the register-ring kernels ("...r") run when dim / 16 divides into their 6 register slots
-        rr = "" if os.environ.get("MFAR_S1_REGRING", "1") == "0" else ("r" if (E // 16) % 6 == 0 else ("r4" if (E // 16) % 4 == 0 else ""))
-        s1_kernel = f"mfar_stage1_bf16{rr}_kernel" if args.dtype == "bf16" else (f"mfar_stage1_f16{rr}_kernel" if screened else "mfar_stage1_kernel")
+        bytes_per_launch = float(n_scan_rows) * E * esize        # the scanned rows are read once per batch
+        s1_kernel = s1_kernel_name(args.dtype, screened, E)
         achieved_tf = flops_per_launch / (s1_avg_ms * 1e-3) / 1e12 if s1_avg_ms > 0 else 0.0
-        traffic = None          # HBM bytes per stage-1 launch from the committed PMC pass of this same workload
-        tj = os.path.join(ROOT, "profiles", "r01_stage1_bf16_traffic.json" if args.dtype == "bf16" else
-                          ("r01_stage1_f16_traffic.json" if screened else "r01_stage1_traffic.json"))
-        if N == 1 and (D, F, E, Q) == (1_000_000, 8, 768, 64) and os.path.exists(tj):
-            t_ = json.load(open(tj))
-            if t_.get("kernel") == s1_kernel:
-                traffic = t_["hbm_read_bytes_per_launch"] + t_["hbm_write_bytes_per_launch"]
+        gbps = bytes_per_launch / (s1_avg_ms * 1e-3) / 1e9 if s1_avg_ms > 0 else 0.0
+        counters = profile_counters(s1_kernel, (D, F, E, Q, N))
+        roof = ({"bound": "mfma", "kernel": s1_kernel, "achieved": achieved_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                 "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS} if esize == 4 else
+                {"bound": "hbm", "kernel": s1_kernel, "achieved": gbps, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBS})
+        roof.update(counters)
+        roof.update({
+            "avg_launch_ms": s1_avg_ms, "launches": s1_n,
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "algorithmic_bytes_definition": (
+                f"{n_scan_rows} scanned rows x {E} dims x {esize} B: the " +
+                ("fp16 SCREEN rows of the fp32 index (unique rows per field), read once per 64-query batch" if screened else
+                 ("bf16 slab" if args.dtype == "bf16" else "fp32 slab") + ", read once per 64-query batch")),
+            "fp32_slab_bytes_per_batch_survey_8d": float(row1 - row0) * F * E * 4,
+            "note": ("SURVEY 8(d) prices a batch at D*F*E*4 bytes of fp32 rows; the default stage 1 does not read them -- it scans a "
+                     "half-size fp16 copy and PROVES per list (rigorous error bound; failed lists are redone by the exact fp32 pass) "
+                     "that the exact fp32 top-k is among the re-scored rows.  See roofline_exact_fp32 for the kernel that does read "
+                     "the fp32 slab.") if screened else None,
+            "algorithmic_flops_per_launch": flops_per_launch,
+        })
         line = {
             "metric": "queries/sec (whole node) at Recall@20 parity, 1M-doc x 8-field x 768d corpus",
             "value": qps, "unit": "queries/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16 docs x fp32 queries (3 exact bf16 terms), fp32 accumulate", "data": "synthetic",
-            "config": {"workload": f"synthetic STaRK-amazon-shaped corpus, {D} docs x {F} dense fields x {E}d {args.dtype}, "
+            "config": {"workload": f"synthetic STaRK-amazon-shaped corpus ({args.corpus}), {D} docs x {F} dense fields x {E}d {args.dtype}, "
                                    f"row-sharded over {N} GPU(s); two-stage scorer k1=k2=100, zero-sentinel mode",
-                       "docs": D, "fields": F, "dim": E, "query_batch": Q, "k1": K1, "k2": K2,
+                       "docs": D, "fields": F, "dim": E, "query_batch": Q, "k1": K1, "k2": K2, "timed_queries": args.steps * Q,
                        "parallelism": (f"row-shard x{N}, lists-first exchange over RCCL (per batch: all-gather of the stage-1 lists, "
-                                       f"all-gather of the local top-k, all-reduce of the certificate flag)") if N > 1 else "single shard",
+                                       f"all-gather of the local top-k + certificate flag)") if N > 1 else "single shard",
                        "pipeline": "2 batches in flight (stage 1 of batch i+1 overlaps the tail of batch i)"},
-            "stage1": ("certified fp16 screen of the fp32 slab (k+64 rows per list re-scored with the exact fp32 chain, top-k proven "
-                       "or redone by the exact fp32 pass per field): outputs bit-identical to the plain fp32 pass" if screened else
+            "stage1": ("certified fp16 screen of the fp32 slab (min(k+92,192) rows per list re-scored with the exact fp32 chain, top-k "
+                       "proven or redone by the exact fp32 pass per field): outputs bit-identical to the plain fp32 pass" if screened else
                        ("exact fp32 MFMA pass" if args.dtype == "f32" else "bf16 slab pass")),
-            "screen": ({"lists_certified": scr["n_checked"] - scr["n_failed"], "lists_redone_exactly": scr["n_failed"],
-                        "screen_slab_bytes": scr["screen_bytes"]} if screened else None),
-            "recall_at_20": recall20, "ids_checksum": checksum,
-            "index_build_s": t_build,
-            "roofline": ({"bound": "mfma", "kernel": s1_kernel, "achieved": achieved_tf,
-                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS}
-                         if esize == 4 else
-                         {"bound": "hbm", "kernel": s1_kernel, "achieved": bytes_per_launch / (s1_avg_ms * 1e-3) / 1e9,
-                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_per_launch / (s1_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}) | {
-                         "traffic": traffic, "traffic_source": os.path.relpath(tj, ROOT) + " (rocprofv3 PMC pass)" if traffic else None, "avg_launch_ms": s1_avg_ms, "launches": s1_n,
-                         "algorithmic_flops_per_launch": flops_per_launch,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "hbm_GBps_algorithmic": bytes_per_launch / (s1_avg_ms * 1e-3) / 1e9 if s1_avg_ms > 0 else 0.0,
-                         "hbm_frac_of_8TBps": bytes_per_launch / (s1_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if s1_avg_ms > 0 else 0.0},
+            "screen": ({"lists_certified": (scr["n_checked"] - scr0["n_checked"]) - (scr["n_failed"] - scr0["n_failed"]),
+                        "lists_redone_exactly": scr["n_failed"] - scr0["n_failed"], "batches_redone": ps.n_redone,
+                        "screen_slab_bytes": scr["screen_bytes"], "unique_rows_per_field": scr.get("unique_rows")} if screened else None),
+            "recall_at_20": recall20, "ids_checksum": checksum, "index_build_s": t_build, "source_hash": source_hash(),
+            "diagnostic_knobs": {"MFAR_S1_DEBUG": "unset", "screen_eps_mult": eps_mult},
+            "roofline": roof,
+            "roofline_exact_fp32": exact_leg,
         }
+        if N == 1 and args.dtype == "f32" and args.corpus == "plain" and not args.no_extra_legs:
+            line["structured_corpus"] = structured_leg(synth, idxmod, PipelinedSearcher, run, dev, E, Q, torch, np)
         if N == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(corpus, ix, idxmod, args, np, torch)
+            line["cpu_baseline"] = cpu_baseline(corpus, ix, args, np, torch)
         print(json.dumps(line), flush=True)
     if N > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(corpus, ix, idxmod, args, np, torch):
+def structured_leg(synth, idxmod, PipelinedSearcher, run, dev, E, Q, torch, np):
+    """250 k docs x 8 fields with realistic duplicate structure in three of them (mfar/synth.py `structured=True`): what
+    the certified screen does when lists are full of bit-identical rows / when row norms are heavy-tailed."""
+    D, F, steps = 250_000, 8, 16
+    cp = synth.SyntheticCorpus(D, F, E, n_queries=2048, seed=0xDEADBEEF, device=str(dev), structured=True)
+    ix = cp.build_index(idxmod)
+    ps = PipelinedSearcher(ix, cp.W, torch.ones(F, device=dev), k1=K1, k2=K2, max_batch=Q)
+    run(ps, cp, 0, 3, None)
+    torch.cuda.synchronize()
+    s0 = ix.screen_stats()
+    keep = []
+    t0 = time.perf_counter()
+    run(ps, cp, 3, steps, keep)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    s1 = ix.screen_stats()
+    # same bits with the screen off (two batches)
+    ix.set_screen(0)
+    ex = []
+    run(ps, cp, 3, 2, ex)
+    torch.cuda.synchronize()
+    same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(keep[:2], ex))
+    rec = []
+    for i, (ids, _, _) in enumerate(keep):
+        ids = ids.cpu().numpy()
+        rel = cp.qrels((3 + i) * Q, Q)
+        rec += [len(set(ids[j, :20].tolist()) & rel[j]) / len(rel[j]) for j in range(Q)]
+    out = {"docs": D, "fields": F, "field_kinds": cp.field_kinds, "steps": steps, "queries_per_s": steps * Q / dt,
+           "unique_rows_per_field": s1.get("unique_rows"),
+           "lists_certified": (s1["n_checked"] - s0["n_checked"]) - (s1["n_failed"] - s0["n_failed"]),
+           "lists_redone_exactly": s1["n_failed"] - s0["n_failed"], "batches_redone": ps.n_redone,
+           "bits_identical_with_screen_off": bool(same), "recall_at_20": float(np.mean(rec))}
+    ix.close()
+    if not same:
+        raise SystemExit(f"structured corpus: screen on / off differ: {out}")
+    return out
+
+
+def cpu_baseline(corpus, ix, args, np, torch):
     """The reference CPU path, restated (oracle torch port = same torch ops as index.py:181-232 + weighting.py:17-29 +
-    contrastive.py:669-704), on the first `cpu_sample_docs` rows of the same corpus, all host cores.  The oracle is
-    only the thing timed/checked here, never part of the GPU path."""
+    contrastive.py:669-704), on the rows of the same corpus, host cores only.  The oracle is only the thing timed and the
+    checker here, never part of the GPU path.  Parity gate: the SAME batches through the GPU index; every difference is
+    classified and anything that is not a <= 1e-4 near-tie fails the run."""
+    import psutil
     from oracle import mfar_oracle as O
-    Ds = min(args.cpu_sample_docs, ix.n_rows)
     F, E, Q = ix.n_fields, ix.dim, args.batch
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    n_logical = os.cpu_count() or 1
+    try:
+        n_avail = len(os.sched_getaffinity(0))
+    except Exception:
+        n_avail = n_logical
+    full_bytes = ix.n_rows * F * E * 4
+    avail = psutil.virtual_memory().available
+    Ds = args.cpu_sample_docs or (ix.n_rows if avail > full_bytes + (24 << 30) else 100_000)
+    Ds = min(Ds, ix.n_rows)
     slab = np.empty((F, Ds, E), dtype=np.float32)
     for f in range(F):
         ix.read_rows(f, 0, Ds, out=slab[f])
     W = corpus.W.cpu().numpy()
     mask = np.ones(F, dtype=np.float32)
-    # GPU result on the same sample, for the parity gate
-    sub = idxmod.MultiFieldIndex(Ds, F, E, device=ix.device)
-    for f in range(F):
-        sub.write_rows(f, 0, slab[f])
-    # the reference lets torch pick its thread count (= all cores); on many-core hosts the per-query python loop of
-    # small ops runs faster with fewer threads, so time one batch with 32 threads and one with all and keep the faster
+    if Ds == ix.n_rows:
+        sub = ix                       # the bench index itself: full-corpus parity gate
+    else:
+        from mfar.data import index as idxmod
+        sub = idxmod.MultiFieldIndex(Ds, F, E, device=ix.device)
+        for f in range(F):
+            sub.write_rows(f, 0, slab[f])
+    # the reference lets torch pick its thread count (= all cores); the per-query python loop of small ops can run faster with
+    # fewer threads on many-core hosts, so one batch is timed with 32 threads and one with all, the faster setting is kept
     q0 = corpus.queries(0, Q).cpu().numpy()
-    best_threads, best_t = cores, None
-    for th in sorted({min(32, cores), cores}):
+    best_threads, best_t = n_avail, None
+    for th in sorted({min(32, n_avail), n_avail}):
         torch.set_num_threads(th)
         t0 = time.perf_counter()
         O.ref_two_stage(slab, q0, W, mask)
@@ -244,31 +386,44 @@ def cpu_baseline(corpus, ix, idxmod, args, np, torch):
         if best_t is None or dt0 < best_t:
             best_threads, best_t = th, dt0
     torch.set_num_threads(best_threads)
-    cores = best_threads
-    n_batches, t_used, match, match_tol = 0, 0.0, [], []
-    while t_used < 12.0 and n_batches < 50:
+    n_batches, t_used = 0, 0.0
+    classes = {"identical": 0, "order_in_tie": 0, "final_cutoff_tie": 0, "stage1_cutoff_tie": 0, "other": 0}
+    top20_same, dmax, others = [], 0.0, []
+    budget_s, max_batches = 20.0, 50
+    while n_batches < 2 or (t_used < budget_s and n_batches < max_batches):
         q = corpus.queries(n_batches * Q, Q).cpu().numpy()
         t0 = time.perf_counter()
-        ci, cs = O.ref_two_stage(slab, q, W, mask)
+        ci, cs, cfi, cfs = O.ref_two_stage(slab, q, W, mask, return_fields=True)
         t_used += time.perf_counter() - t0
-        g = sub.search(q, W, mask)
-        match.append(float(np.mean([np.array_equal(g["ids"][i, :20], ci[i, :20]) for i in range(Q)])))
-        ok = 0
+        g = sub.search(q, W, mask, return_fields=True)
         for i in range(Q):
-            try:
-                O.assert_topk_equivalent(g["ids"][i], g["scores"][i], ci[i], cs[i], tol=1e-4)
-                ok += 1
-            except AssertionError:
-                pass
-        match_tol.append(ok / Q)
+            a = dict(ids=g["ids"][i], scores=g["scores"][i], field_ids=g["field_ids"][i], field_scores=g["field_scores"][i])
+            b = dict(ids=ci[i], scores=cs[i], field_ids=cfi[i], field_scores=cfs[i])
+            cls, d = O.classify_topk_mismatch(a, b, tol=1e-4)
+            classes[cls] += 1
+            dmax = max(dmax, d)
+            top20_same.append(bool(np.array_equal(g["ids"][i, :20], ci[i, :20])))
+            if cls == "other" and len(others) < 4:
+                others.append({"batch": n_batches, "query": i, "gpu_ids_head": g["ids"][i, :5].tolist(), "port_ids_head": ci[i, :5].tolist()})
         n_batches += 1
-    sub.close()
+    if sub is not ix:
+        sub.close()
     qps_sample = n_batches * Q / t_used
-    return {"value": qps_sample * Ds / corpus.D, "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"{n_batches} batches of {Q} queries over the first {Ds} docs x {F} fields x {E}d of the same corpus "
-                      f"({qps_sample:.1f} q/s on the sample, scaled by {Ds}/{corpus.D} to the full corpus; work is linear in docs)",
-            "top20_ids_identical_to_gpu": float(np.mean(match)),
-            "top100_equivalent_to_gpu_within_1e-4": float(np.mean(match_tol))}
+    out = {"value": qps_sample * Ds / corpus.D, "unit": "queries/s", "cores": best_threads, "kind": "port",
+           "host_logical_cpus": n_logical, "host_cpus_available_to_process": n_avail,
+           "sample": (f"{n_batches} batches of {Q} queries over " +
+                      (f"ALL {Ds} docs" if Ds == corpus.D else f"the first {Ds} docs") + f" x {F} fields x {E}d of the same corpus"
+                      + ("" if Ds == corpus.D else f" ({qps_sample:.1f} q/s on the sample, scaled by {Ds}/{corpus.D}: work is linear in docs)")),
+           "parity_vs_gpu": {"queries": n_batches * Q, "mismatch_classes": classes, "max_abs_score_diff_common_ids": dmax,
+                             "top20_ids_identical": float(np.mean(top20_same)), "tolerance": 1e-4,
+                             "classes": "identical | order_in_tie (same ids, swaps inside <=2e-4 score runs) | final_cutoff_tie (an id "
+                                        "ranked just below the other side's k2 cut-off) | stage1_cutoff_tie (an id that missed the other "
+                                        "side's per-field list by a near-tie with its last entry) | other (a real disagreement: fails)"}}
+    if classes["other"]:
+        out["parity_vs_gpu"]["other_examples"] = others
+        print(json.dumps({"cpu_baseline": out}), file=sys.stderr, flush=True)
+        raise SystemExit(f"GPU vs reference port: {classes['other']} unexplained mismatches")
+    return out
 
 
 if __name__ == "__main__":

@@ -54,24 +54,34 @@ class _Instances:
         self.corpus = corpus
         self.key_to_row = {k: i for i, (k, _) in enumerate(corpus)}
         self.qrels = [r for r in self.qrels if r.doc_id in self.key_to_row]
+        self.seed = seed
         self.rng = random.Random(seed)
 
-    def batches(self, batch_size, rank, world, shuffle):
+    def batches(self, batch_size, rank, world, shuffle, fixed_negatives=False):
         order = list(range(len(self.qrels)))
         if shuffle:
             self.rng.shuffle(order)                      # same seed on every rank -> same order
-        usable = (len(order) // (batch_size * world)) * batch_size * world or len(order)
-        order = order[:usable]
-        for b in range(rank * batch_size, len(order), batch_size * world):
-            rows = [self.qrels[i] for i in order[b:b + batch_size]]
-            if rows:
-                negs = []
-                for r in rows:
-                    n = self.rng.randrange(len(self.corpus))
-                    while self.corpus[n][0] == r.doc_id and len(self.corpus) > 1:
-                        n = self.rng.randrange(len(self.corpus))
-                    negs.append(n)
-                yield rows, negs
+        # every rank must run the SAME number of steps (the loss all-gathers and all-reduces): whole global batches
+        # only; with fewer instances than one global batch the per-rank batch shrinks to what divides evenly
+        if len(order) < world:
+            raise ValueError(f"{len(order)} training instances cannot be split over {world} ranks")
+        if len(order) < batch_size * world:
+            batch_size = len(order) // world
+        order = order[:(len(order) // (batch_size * world)) * batch_size * world]
+        # validation passes `fixed_negatives`: a generator re-seeded per pass draws the same negatives every epoch, so
+        # valid_loss values are comparable between epochs (early stopping and best-checkpoint selection rest on them)
+        neg_rng = random.Random(self.seed + 7919) if fixed_negatives else self.rng
+        for g in range(0, len(order), batch_size * world):
+            # negatives are drawn for the whole global batch on every rank (same stream everywhere), then sliced
+            grows = [self.qrels[i] for i in order[g:g + batch_size * world]]
+            gnegs = []
+            for r in grows:
+                n = neg_rng.randrange(len(self.corpus))
+                while self.corpus[n][0] == r.doc_id and len(self.corpus) > 1:
+                    n = neg_rng.randrange(len(self.corpus))
+                gnegs.append(n)
+            lo = rank * batch_size
+            yield grows[lo:lo + batch_size], gnegs[lo:lo + batch_size]
 
 
 def _encode_fields(module, tokenizer, docs, max_length, device):
@@ -100,13 +110,27 @@ def _loss_on_batch(module, loss_fn, tokenizer, inst, rows, negs, max_length, dev
 
 
 def _sync_grads(params, world):
+    """Average the gradients over the ranks.  Called on the still-SCALED gradients, before `scaler.unscale_`: the
+    GradScaler records inf/NaN per rank at unscale time, so reducing first makes every rank see the same overflow,
+    skip the same step and keep the same loss scale (weights stay bit-equal across ranks)."""
     if world == 1:
         return
     import torch.distributed as dist
     for p in params:
-        if p.grad is not None:
-            dist.all_reduce(p.grad)
-            p.grad /= world
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)      # a rank whose batch did not touch p must still join the collective
+        dist.all_reduce(p.grad)
+        p.grad /= world
+
+
+def _train_step_sync(scaler, opts, params, world):
+    """all-reduce (scaled) -> unscale -> step -> update, in that order on every rank."""
+    _sync_grads(params, world)
+    for o in opts:
+        scaler.unscale_(o)
+    for o in opts:
+        scaler.step(o)
+    scaler.update()
 
 
 def main(
@@ -165,12 +189,7 @@ def main(
                 o.zero_grad(set_to_none=True)
             loss = _loss_on_batch(module, loss_fn, tokenizer, train_inst, rows, negs, train_max_length, device, precision)
             scaler.scale(loss).backward()
-            for o in opts:
-                scaler.unscale_(o)
-            _sync_grads(enc_params + lin_params, world)
-            for o in opts:
-                scaler.step(o)
-            scaler.update()
+            _train_step_sync(scaler, opts, enc_params + lin_params, world)
             step += 1
             if rank == 0:
                 print(f"Training loss: {loss.item()}")
@@ -182,7 +201,8 @@ def main(
         loss_fn.eval()
         tot, cnt = 0.0, 0
         with torch.no_grad():
-            for rows, negs in val_inst.batches(dev_batch_size if dev_batch_size < 32 else 16, rank, world, shuffle=False):
+            for rows, negs in val_inst.batches(dev_batch_size if dev_batch_size < 32 else 16, rank, world, shuffle=False,
+                                                fixed_negatives=True):
                 tot += float(_loss_on_batch(module, loss_fn, tokenizer, val_inst, rows, negs, dev_max_length, device, precision))
                 cnt += 1
                 if run_one_iteration:
@@ -191,6 +211,7 @@ def main(
         if world > 1:
             torch.distributed.all_reduce(t)
         valid_loss = float(t[0] / max(1.0, float(t[1])))
+        module.bn_state = {k: v.detach().cpu() for k, v in loss_fn.bn.state_dict().items()}
         if rank == 0:
             print(f"Validation loss: {valid_loss}")
             ckpt = f"{out}/epoch={epoch}-valid_loss={valid_loss:.3f}.ckpt"
@@ -214,10 +235,7 @@ def main(
         torch.distributed.broadcast_object_list(holder, src=0)
         best_path = holder[0]
     if best_path:                                                                            # trainer.test(ckpt_path="best")
-        sd = torch.load(best_path, map_location="cpu", weights_only=False)["state_dict"]
-        module.encoder.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")})
-        module.mixture_of_fields_layer.weight.data.copy_(sd["mixture_of_fields_layer.weight"])
-        module.mark_encoder_updated()
+        module.load_reference_state_dict(torch.load(best_path, map_location="cpu", weights_only=False)["state_dict"])
     elif rank == 0:
         best_path = f"{out}/last.ckpt"
         module.save_checkpoint(best_path)

@@ -5,8 +5,8 @@ Rules of `format_documents` (format.py:26-61): a missing field gives "" (and is 
 lacking a field yields the same vector, which is where exact score ties come from); str as is; numbers via str();
 list of str joined by ", "; list of dicts -> per item "key: value" lines (minus a fixed set of bookkeeping keys),
 items joined by newlines; None -> ""; dict -> `format_dict`.
-The whole-document 'single' field (format.py:113-415) belongs to the single_dense baseline, not to the multi-field
-path, and is not restated."""
+The whole-document 'single' field of the single_dense baseline (format.py:20-22, 113-415) is rendered by
+`mfar.data.format_single` (pinned by tests/golden/format_single.json)."""
 from typing import Any, List, Tuple
 
 _DROP_KEYS = {"reviewerID", "style", "verified", "overall", "reviewTime", "vote", "questionType", "answerType", "answerTime"}
@@ -68,7 +68,8 @@ def _field_text(value: Any) -> str:
 def format_documents(documents, field_name: str, dataset_name: str) -> List[Tuple[str, str]]:
     """[(doc_id, doc_json)] -> [(doc_id, text of `field_name`)]."""
     if field_name == "single":
-        raise NotImplementedError("the whole-document 'single' field (single_dense baseline) is outside the multi-field path")
+        from mfar.data.format_single import format_single_documents
+        return format_single_documents(documents, dataset_name)
     out = []
     for doc_id, body in documents:
         out.append((doc_id, _field_text(body[field_name]) if field_name in body else ""))

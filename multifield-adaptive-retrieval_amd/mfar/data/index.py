@@ -469,16 +469,25 @@ class DenseFlatIndex(Index[str, str]):
         import torch
         qe = self._encode(queries)
         rows = np.asarray([self.key_to_numeric_ids[k] for k in keys], dtype=np.int64)   # KeyError like index.py:229
+        # a row-sharded slab holds only [row_offset, row_offset + n_rows): a valid key owned by another rank cannot be
+        # scored here (the reference keeps the full memmap on every rank).  Fail loudly instead of returning NaN.
+        lo, hi = self.slab.row_offset, self.slab.row_offset + self.slab.n_rows
+        off = rows[(rows < lo) | (rows >= hi)]
+        if off.size:
+            raise KeyError(f"{keys[int(np.nonzero((rows < lo) | (rows >= hi))[0][0])]!r} (row {int(off[0])}) is outside this "
+                           f"rank's row shard [{lo}, {hi})")
         cand = np.broadcast_to(rows, (qe.shape[0], rows.size)).copy()                 # global row numbers
         x = self.slab.score_candidates(qe, cand)
         return torch.from_numpy(np.ascontiguousarray(x[:, :, self.field_index]))
 
 
 def candidate_encoding_stream(encoder, corpus: Iterable[Tuple[str, str]], batch_size: int = 64, multiprocess: bool = True,
-                              show_progress: bool = True) -> Iterable[Tuple[str, np.ndarray]]:
-    """(id, text) pairs -> (id, embedding[E]) pairs in chunks of `batch_size` (reference index.py:234-258).
+                              show_progress: bool = True, as_tensor: bool = False) -> Iterable[Tuple[str, np.ndarray]]:
+    """(id, text) pairs -> (id, embedding[E]) pairs in chunks of `batch_size`, in input order (reference index.py:234-258).
     `multiprocess` is accepted for signature compatibility; one process drives one GPU here (the reference's eval
-    path always passes multiprocess=False, contrastive.py:487)."""
+    path always passes multiprocess=False, contrastive.py:487).  `as_tensor=True` (extension, used by `on_eval_start`)
+    yields the rows as tensors on the encoder's device instead of numpy arrays, so the corpus encode writes into the
+    HBM slab without a host round trip."""
     it = corpus
     if show_progress:
         try:
@@ -490,14 +499,17 @@ def candidate_encoding_stream(encoder, corpus: Iterable[Tuple[str, str]], batch_
     for item in it:
         batch.append(item)
         if len(batch) == batch_size:
-            yield from _encode_batch(encoder, batch, batch_size)
+            yield from _encode_batch(encoder, batch, batch_size, as_tensor)
             batch = []
     if batch:
-        yield from _encode_batch(encoder, batch, batch_size)
+        yield from _encode_batch(encoder, batch, batch_size, as_tensor)
 
 
-def _encode_batch(encoder, batch, batch_size):
+def _encode_batch(encoder, batch, batch_size, as_tensor=False):
     ids = [i for i, _ in batch]
     texts = [t for _, t in batch]
-    embs = encoder.encode(texts, batch_size=batch_size, convert_to_numpy=True)
+    if as_tensor:
+        embs = encoder.encode(texts, batch_size=batch_size, convert_to_tensor=True)
+    else:
+        embs = encoder.encode(texts, batch_size=batch_size, convert_to_numpy=True)
     return zip(ids, embs)

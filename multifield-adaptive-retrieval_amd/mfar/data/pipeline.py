@@ -27,6 +27,8 @@ from mfar.data import index as _index
 class PipelinedSearcher:
     def __init__(self, index, W, mask=None, k1: int = 100, k2: int = 100, sentinel: bool = True, query_cond: bool = True,
                  max_batch: int = 64, group=None):
+        # W / mask may be re-assigned between submissions (mask_fields sweeps): every submit copies them into buffers
+        # owned by the batch's slot, so a batch in flight never reads a tensor the caller has replaced or freed
         self.ix, self.W, self.mask = index, W, mask
         self.k1, self.k2, self.sentinel, self.query_cond = k1, k2, sentinel, query_cond
         self.group = group
@@ -48,6 +50,7 @@ class PipelinedSearcher:
                      ids=torch.empty(self.Qmax, k2, dtype=torch.int64, device=self.dev),
                      scores=torch.empty(self.Qmax, k2, device=self.dev),
                      n_valid=torch.empty(self.Qmax, dtype=torch.int32, device=self.dev),
+                     W=torch.empty_like(W, device=self.dev), mask=torch.ones(F, device=self.dev),
                      fail=torch.zeros(1, dtype=torch.int32, device=self.dev),
                      fail_host=torch.zeros(1, dtype=torch.int32).pin_memory(),
                      stage1=torch.cuda.Event(), done=torch.cuda.Event(), Q=0, checked=True)
@@ -79,11 +82,11 @@ class PipelinedSearcher:
         qk = s["q"][:Q]
         out = dict(ids=s["ids"][:Q], scores=s["scores"][:Q], n_valid=s["n_valid"][:Q])
         if self.world == 1:
-            self.ix.search_stage2(qk, self.W, s["fid"][:Q], self.mask, self.k1, self.k2, self.query_cond, slot=slot, out=out)
+            self.ix.search_stage2(qk, s["W"], s["fid"][:Q], s["mask"], self.k1, self.k2, self.query_cond, slot=slot, out=out)
         else:
             dist = torch.distributed
             dist.all_gather_into_tensor(s["lists_all"], s["lists"], group=self.group)
-            self.ix.search_owned(s["lists_all"], self.world, qk, self.W, s["topk"], self.mask, self.k1, self.k2, self.sentinel,
+            self.ix.search_owned(s["lists_all"], self.world, qk, s["W"], s["topk"], s["mask"], self.k1, self.k2, self.sentinel,
                                  self.query_cond, slot=slot)
             dist.all_gather_into_tensor(s["topk_all"], s["topk"], group=self.group)
             _index.merge_topk(s["topk_all"], self.world, Q, self.k2, device=self.ix.device, out=out)
@@ -107,6 +110,14 @@ class PipelinedSearcher:
         with torch.cuda.stream(self.main):
             qk = s["q"][:Q]
             qk.copy_(q)
+            s["W"].copy_(self.W)
+            if self.mask is None:
+                s["mask"].fill_(1.0)
+            else:
+                s["mask"].copy_(self.mask.reshape(-1))
+            for t_ in (q, self.W, self.mask):       # sources allocated on the caller's stream, read on this one
+                if t_ is not None and t_.is_cuda:
+                    t_.record_stream(self.main)
             fid, fsc = self._list_targets(s)
             self.ix.stage1_begin(qk, slot, fid, fsc, self.k1, self.sentinel)
             s["stage1"].record(self.main)

@@ -101,12 +101,25 @@ class HbmFieldVectors(MutableMapping):
 
     # raw float32 [D, E] files == the reference's {temp_dir}/{field}.npy layout (data/util.py:35)
     def export_memmap(self, path: str, n_total_rows: int = None):
+        """Write this shard's rows into the raw [n_total, E] float32 file.  With several ranks, rank 0 creates and sizes
+        the file, everybody waits at a barrier, then every rank opens it "r+" and writes only its own row range (a second
+        rank opening with "w+" would zero rows already written)."""
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         n_total = n_total_rows or (self.slab.row_offset + self.slab.n_rows)
         nbytes = n_total * self.slab.dim * 4
-        fresh = not (os.path.exists(path) and os.path.getsize(path) == nbytes)
-        mm = np.memmap(path, dtype=np.float32, mode="w+" if fresh else "r+", shape=(n_total, self.slab.dim))
+        if not multi or dist.get_rank() == 0:
+            with open(path, "ab"):
+                pass
+            os.truncate(path, nbytes)          # sparse resize; existing rows of a right-sized file are kept
+        if multi:
+            dist.barrier()
+        mm = np.memmap(path, dtype=np.float32, mode="r+", shape=(n_total, self.slab.dim))
         mm[self.slab.row_offset:self.slab.row_offset + self.slab.n_rows] = self.file
         mm.flush()
+        del mm
+        if multi:
+            dist.barrier()
 
     def import_memmap(self, path: str, n_total_rows: int):
         mm = np.memmap(path, dtype=np.float32, mode="r", shape=(n_total_rows, self.slab.dim))

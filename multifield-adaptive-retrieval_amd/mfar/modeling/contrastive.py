@@ -24,7 +24,8 @@ import torch
 from mfar.data import trec
 from mfar.data.dataset import QueryDataset
 from mfar.data.format import format_documents
-from mfar.data.sharded import HipShardBackend, ShardedSearcher, shard_bounds
+from mfar.data.index import candidate_encoding_stream
+from mfar.data.sharded import shard_bounds
 from mfar.data.typedef import Field, FieldType
 from mfar.modeling.weighting import LinearWeights
 
@@ -116,6 +117,9 @@ class RetrievalTrainingModule(torch.nn.Module):
         self.additional_qres_output: Optional[TextIO] = None
         self._corpus_encoded = False
         self._searcher = None
+        # `hybrid_contrastive_loss_fn.bn.*` of a use_batchnorm run: trained by commands/train.py's loss object, unused at
+        # evaluation (contrastive.py:685-694 applies no BatchNorm), carried through checkpoints under the reference's keys
+        self.bn_state: Dict[str, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -163,10 +167,17 @@ class RetrievalTrainingModule(torch.nn.Module):
             slot = {t: i for i, t in enumerate(uniq)}
             order = sorted(range(len(uniq)), key=lambda i: len(uniq[i]))
             emb_u = torch.empty(len(uniq), self.slab.dim, device=self.device)
-            for b in range(0, len(order), bs):
-                sel = order[b:b + bs]
-                enc = self.encoder.encode([uniq[i] for i in sel], batch_size=bs, convert_to_tensor=True).float()
-                emb_u[torch.tensor(sel, device=self.device)] = enc
+            stream = candidate_encoding_stream(self.encoder, ((i, uniq[i]) for i in order), batch_size=bs, multiprocess=False,
+                                               show_progress=False, as_tensor=True)             # contrastive.py:483-489
+            got, vecs = [], []
+            for i, v in stream:
+                got.append(i)
+                vecs.append(v)
+                if len(got) == bs:
+                    emb_u[torch.tensor(got, device=self.device)] = torch.stack(vecs).float()
+                    got, vecs = [], []
+            if got:
+                emb_u[torch.tensor(got, device=self.device)] = torch.stack(vecs).float()
             rows = torch.tensor([slot[t] for t in texts], device=self.device)
             step = max(bs, 65536)
             for b in range(0, len(docs), step):
@@ -178,33 +189,67 @@ class RetrievalTrainingModule(torch.nn.Module):
 
     # ------------------------------------------------------------------ scoring (contrastive.py:669-704)
     def _get_searcher(self):
-        if self._searcher is None:
-            self._searcher = ShardedSearcher(HipShardBackend(self.slab))
+        """The two-deep batch pipeline over this rank's slab (mfar/data/pipeline.py): stage 1 of batch i+1 runs beside the
+        tail of batch i; with several ranks it uses the lists-first exchange (two small RCCL all-gathers per batch)."""
+        from mfar.data.pipeline import PipelinedSearcher
+        qmax = min(64, max(1, int(self.dev_batch_size)))
+        if self._searcher is None or self._searcher.ix is not self.slab or self._searcher.Qmax != qmax:
+            self._searcher = PipelinedSearcher(self.slab, self._weights(), None, k1=TOP_K, k2=TOP_K, sentinel=True,
+                                               query_cond=self.query_cond, max_batch=qmax)
         return self._searcher
 
     @torch.no_grad()
-    def trec_eval_step(self, batch, batch_idx: int, qres_output) -> None:
-        data = batch.instances
+    def encode_query_batch(self, batch) -> torch.Tensor:
+        """[Q, E] fp32 embeddings of a collated query batch: ONE encoder forward over the batch-padded tokens sliced to the
+        encoder's max length (contrastive.py:688-693).  The reference additionally re-encodes every query 2F times
+        through `encoder.encode` (index.py:187,228); here this single embedding serves retrieval, re-scoring and gating."""
         toks = batch.query[FieldType.DENSE]
         L = self.encoder.get_max_seq_length()
         feats = {k: v[:, :L].to(self.device) for k, v in toks.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
-        x = self.encoder(feats)["sentence_embedding"].float().contiguous()       # ONE forward per batch
-        mask = self.mask[:, 0].float().contiguous().to(self.device)
-        if _dist()[1] == 1:
-            res = self.slab.search(x, self._weights(), mask, k1=TOP_K, k2=TOP_K, sentinel=True, query_cond=self.query_cond)
-        else:
-            res = self._get_searcher().search(x, self._weights(), mask, k1=TOP_K, k2=TOP_K, sentinel=True,
-                                              query_cond=self.query_cond)
-        n_valid = res["n_valid"].cpu().tolist()
-        if min(n_valid) < TOP_K:                                                 # what torch.topk raises at :696
-            raise RuntimeError(f"selected index k out of range: only {min(n_valid)} candidates for k={TOP_K}")
+        return self.encoder(feats)["sentence_embedding"].float().contiguous()
+
+    def _submit(self, batch, qres_output):
+        """Enqueue one query batch (asynchronous); returns what `_collect` needs.  Batches above the pipeline's width are
+        split; with several ranks a short (last) batch is padded with zero queries to the fixed exchange size."""
+        ps = self._get_searcher()
+        ps.W, ps.mask = self._weights(), self.mask[:, 0].float().contiguous().to(self.device)
+        x = self.encode_query_batch(batch)
+        parts = []
+        for b in range(0, x.shape[0], ps.Qmax):
+            xb = x[b:b + ps.Qmax]
+            n = xb.shape[0]
+            if ps.world > 1 and n < ps.Qmax:
+                xb = torch.cat([xb, xb.new_zeros(ps.Qmax - n, xb.shape[1])])
+            parts.append((ps.submit(xb.contiguous()), batch.instances[b:b + n]))
+        return parts, qres_output
+
+    def _collect(self, pending) -> None:
+        parts, qres_output = pending
+        ps = self._get_searcher()
         rank, _ = _dist()
-        if rank != 0 or qres_output is None:
+        for ticket, data in parts:
+            res = ps.result(ticket)
+            n = len(data)
+            n_valid = res["n_valid"][:n].cpu().tolist()
+            if min(n_valid) < TOP_K:                                             # what torch.topk raises at :696
+                raise RuntimeError(f"selected index k out of range: only {min(n_valid)} candidates for k={TOP_K}")
+            if rank != 0 or qres_output is None:
+                continue
+            ids, sims = res["ids"][:n].cpu().tolist(), res["scores"][:n].cpu().tolist()
+            for q, row_ids, row_sims in zip(data, ids, sims):
+                for d, s in zip(row_ids, row_sims):
+                    print(trec.QRes(query_id=q._id, doc_id=self.numeric_ids_to_keys[d], sim=s), file=qres_output)
+
+    @torch.no_grad()
+    def trec_eval_step(self, batch, batch_idx: int, qres_output) -> None:
+        """One batch, synchronously (the reference's hook signature).  `test()` overlaps consecutive batches instead."""
+        if len(batch.instances) > self._get_searcher().Qmax:
+            for b in range(0, len(batch.instances), self._searcher.Qmax):         # at most two tickets may be in flight
+                sub = SimpleNamespace(instances=batch.instances[b:b + self._searcher.Qmax],
+                                      query={k: {n: t[b:b + self._searcher.Qmax] for n, t in v.items()} for k, v in batch.query.items()})
+                self._collect(self._submit(sub, qres_output))
             return
-        ids, sims = res["ids"].cpu().tolist(), res["scores"].cpu().tolist()
-        for q, row_ids, row_sims in zip(data, ids, sims):
-            for d, s in zip(row_ids, row_sims):
-                print(trec.QRes(query_id=q._id, doc_id=self.numeric_ids_to_keys[d], sim=s), file=qres_output)
+        self._collect(self._submit(batch, qres_output))
 
     def mask_field(self, field_idx_list) -> None:                                # contrastive.py:706-714
         names = list(self.field_info.keys())
@@ -241,9 +286,23 @@ class RetrievalTrainingModule(torch.nn.Module):
         was_training = self.training
         self.eval()
         self.on_test_epoch_start()
-        for li, loader in enumerate(data_module.test_dataloader()):
-            for bi, batch in enumerate(loader):
-                self.test_step(batch, bi, dataloader_idx=li)
+        pending = None          # one batch stays in flight while the next one is tokenised, encoded and submitted
+        with torch.no_grad():
+            for li, loader in enumerate(data_module.test_dataloader()):
+                out = self.qres_output if li == 0 else self.additional_qres_output
+                for batch in loader:
+                    if len(batch.instances) > self._get_searcher().Qmax:
+                        if pending is not None:
+                            self._collect(pending)
+                            pending = None
+                        self.trec_eval_step(batch, 0, out)
+                        continue
+                    nxt = self._submit(batch, out)
+                    if pending is not None:
+                        self._collect(pending)
+                    pending = nxt
+            if pending is not None:
+                self._collect(pending)
         self.on_test_epoch_end()
         if was_training:
             self.train()
@@ -285,6 +344,8 @@ class RetrievalTrainingModule(torch.nn.Module):
         w = self.mixture_of_fields_layer.weight.detach()
         sd["mixture_of_fields_layer.weight"] = w
         sd["hybrid_contrastive_loss_fn.mixture_of_fields_layer.weight"] = w      # registered twice in the reference (:279-293)
+        for k, v in self.bn_state.items():
+            sd[f"hybrid_contrastive_loss_fn.bn.{k}"] = v
         hp = dict(model_id=self.model_id, dataset_name=self.dataset_name, corpus_path=self.corpus_path, query_cond=self.query_cond,
                   prefix=self.prefix, contrastive_temp=self.contrastive_temp, encoder_learning_rate=self.encoder_learning_rate,
                   weights_learning_rate=self.weights_learning_rate, weight_decay=self.weight_decay, dev_batch_size=self.dev_batch_size,
@@ -313,11 +374,39 @@ class RetrievalTrainingModule(torch.nn.Module):
         if args.get("weights_learning_rate") is None:
             args["weights_learning_rate"] = 0.0
         module = cls(**args)
-        sd = ckpt["state_dict"]
+        module.load_reference_state_dict(ckpt["state_dict"])
+        return module
+
+    # buffers some transformers versions persist and others do not: their absence is not a layout mismatch
+    _NON_PERSISTENT = ("embeddings.position_ids", "embeddings.token_type_ids")
+
+    def load_reference_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        """Load a Lightning `state_dict` with the reference module's key layout (contrastive.py:279-293):
+        `encoder.0.auto_model.*` (SentenceTransformer Sequential index 0), `mixture_of_fields_layer.weight` and its alias
+        `hybrid_contrastive_loss_fn.mixture_of_fields_layer.weight` (the same Parameter registered twice), optional
+        `hybrid_contrastive_loss_fn.bn.*`.  Anything that does not line up raises: a checkpoint that silently loads
+        nothing would make `mask_fields` evaluate the base encoder."""
         enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
-        missing, unexpected = module.encoder.load_state_dict(enc, strict=False)
+        if not enc:
+            raise RuntimeError("checkpoint has no `encoder.*` keys: not a RetrievalTrainingModule checkpoint")
+        missing, unexpected = self.encoder.load_state_dict(enc, strict=False)
         if unexpected:
             raise RuntimeError(f"unexpected encoder keys in checkpoint: {unexpected[:5]}")
-        module.mixture_of_fields_layer.weight.data = sd["mixture_of_fields_layer.weight"].clone().float()
-        module.mark_encoder_updated()
-        return module
+        missing = [k for k in missing if not k.endswith(self._NON_PERSISTENT)]
+        if missing:
+            raise RuntimeError(f"checkpoint lacks {len(missing)} encoder tensors (first: {missing[:5]}): the encoder key "
+                               f"layout does not match `encoder.0.auto_model.*`")
+        names = ("mixture_of_fields_layer.weight", "hybrid_contrastive_loss_fn.mixture_of_fields_layer.weight")
+        have = [n for n in names if n in sd]
+        if not have:
+            raise RuntimeError("checkpoint has no mixture_of_fields_layer.weight")
+        w = sd[have[0]]
+        if len(have) == 2 and not torch.equal(sd[names[0]], sd[names[1]]):
+            raise RuntimeError("the two aliases of mixture_of_fields_layer.weight differ in this checkpoint")
+        want = tuple(self.mixture_of_fields_layer.weight.shape)       # [E, F] query-conditioned, [F, 1] otherwise
+        if tuple(w.shape) != want:
+            raise RuntimeError(f"mixture_of_fields_layer.weight is {tuple(w.shape)}, the current field set needs {want}")
+        self.mixture_of_fields_layer.weight.data = w.clone().float().to(self.mixture_of_fields_layer.weight.device)
+        pre = "hybrid_contrastive_loss_fn.bn."
+        self.bn_state = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        self.mark_encoder_updated()

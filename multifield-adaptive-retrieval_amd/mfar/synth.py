@@ -11,6 +11,15 @@ of 64 (train.py:45), seed 0xdeadbeef (train.py:50) -- and its data quirks:
     pulled towards the query -> synthetic qrels, so Recall@20 is meaningful and the field weights matter;
   * W = 0.05 * N(0,1) [E, F]: a non-trivial query-conditioned gate (mfar/modeling/weighting.py:10-15 starts at ones).
 
+`structured=True` gives three of every eight fields the duplicate / norm structure real STaRK fields have (the reference's
+field presets, mfar/data/schema.py:11-53: `brand`, `type`, `source` ... are low-cardinality; a text that occurs more than once
+is encoded to bit-identical rows):
+  * "zipf"    every row draws one of D/4 distinct texts from a Zipf-like law (P(t) ~ 1/t): a few huge groups of identical
+              rows, a long tail of singletons;
+  * "lowcard" ten distinct texts in the whole field (STaRK-prime `type`);
+  * "heavy"   distinct rows whose spread around the mean is Pareto(3)-scaled: a heavy tail of row norms (what a per-field
+              error bound of the certified screen has to survive).
+
 Rows are generated on the GPU in aligned chunks whose random stream depends only on (seed, field, chunk id), so any
 row-sharding of the corpus produces bit-identical vectors.
 """
@@ -22,7 +31,8 @@ CHUNK = 32768  # rows per generation chunk (aligned to global row numbers)
 
 class SyntheticCorpus:
     def __init__(self, n_docs: int, n_fields: int, dim: int, n_queries: int = 4096, seed: int = 0xDEADBEEF,
-                 device: str = "cuda:0", empty_frac: float = 0.08, sigma: float = 0.04, pull: float = 0.8):
+                 device: str = "cuda:0", empty_frac: float = 0.08, sigma: float = 0.04, pull: float = 0.8,
+                 structured: bool = False):
         self.D, self.F, self.E, self.NQ = int(n_docs), int(n_fields), int(dim), int(n_queries)
         self.seed, self.device = int(seed), torch.device(device)
         self.empty_frac, self.sigma, self.pull = float(empty_frac), float(sigma), float(pull)
@@ -33,6 +43,13 @@ class SyntheticCorpus:
         self.q_all = (self.mu.cpu() + self.sigma * torch.randn(self.NQ, self.E, generator=g)).to(self.device).contiguous()
         self.W = (0.05 * torch.randn(self.E, self.F, generator=g)).to(self.device).contiguous()
         self.empty_vec = (self.mu.cpu() * 0.6 + 0.02 * torch.randn(self.F, self.E, generator=g)).to(self.device)
+        kinds = ["plain", "zipf", "plain", "lowcard", "plain", "heavy", "plain", "plain"]
+        self.field_kinds = [kinds[f % 8] if structured else "plain" for f in range(self.F)]
+        if structured:      # text tables: the vector of text t is mu + sigma * (A[t % 4096] + B[t // 4096]) / sqrt(2)
+            g2 = torch.Generator(device="cpu")
+            g2.manual_seed(self.seed ^ 0x5EED)
+            self._tab_a = torch.randn(4096, self.E, generator=g2).to(self.device)
+            self._tab_b = torch.randn(4096, self.E, generator=g2).to(self.device)
         # planted relevance: (query, doc, field-subset)
         rng = np.random.default_rng(self.seed & 0x7FFFFFFF)
         n_rel = rng.integers(1, 6, size=self.NQ)
@@ -73,7 +90,19 @@ class SyntheticCorpus:
         """All CHUNK rows of field f, chunk cid (global rows cid*CHUNK ...), fp32 [CHUNK, E] on the device."""
         g = torch.Generator(device=self.device)
         g.manual_seed((self.seed * 1000003 + f * 7919 + cid * 104729) & 0x7FFFFFFFFFFFFFFF)
-        x = torch.randn(CHUNK, self.E, generator=g, device=self.device) * self.sigma + self.mu
+        kind = self.field_kinds[f]
+        if kind == "plain":
+            x = torch.randn(CHUNK, self.E, generator=g, device=self.device) * self.sigma + self.mu
+        elif kind == "heavy":
+            u = torch.rand(CHUNK, 1, generator=g, device=self.device)
+            scale = (1.0 - u).clamp_min(1e-6).pow(-1.0 / 3.0).clamp_max(30.0)            # Pareto(3) >= 1
+            x = torch.randn(CHUNK, self.E, generator=g, device=self.device) * (self.sigma * scale) + self.mu
+        else:
+            n_texts = 10 if kind == "lowcard" else max(16, self.D // 4)
+            u = torch.rand(CHUNK, generator=g, device=self.device)
+            t = (torch.exp(u * float(np.log(n_texts))).long() - 1).clamp_(0, n_texts - 1)    # P(t) ~ 1 / (t + 1)
+            t = t + 7919 * (f + 1)                                                            # other fields, other texts
+            x = (self._tab_a[t % 4096] + self._tab_b[(t // 4096) % 4096]) * (self.sigma * 0.70710678) + self.mu
         if self.empty_frac > 0:
             m = torch.rand(CHUNK, generator=g, device=self.device) < self.empty_frac
             x[m] = self.empty_vec[f]

@@ -230,15 +230,17 @@ def ref_linear_weights(x, q, W, query_cond=True):
     return torch.sum(wd.unsqueeze(1) * x, dim=-1).numpy()
 
 
-def ref_two_stage(slab, q, W, mask=None, k1=100, k2=100, vector_batch_size=1048576):
+def ref_two_stage(slab, q, W, mask=None, k1=100, k2=100, vector_batch_size=1048576, return_fields=False):
     """Port of trec_eval_step (contrastive.py:669-704) for query embeddings q[Q,E] (one embedding per query).
-    Returns canonical (ids[Q,k2], scores[Q,k2]). Raises RuntimeError like torch.topk when C < k2."""
+    Returns canonical (ids[Q,k2], scores[Q,k2]) [+ (field_ids[Q,F,k1], field_scores[Q,F,k1]) as torch.topk left them].
+    Raises RuntimeError like torch.topk when C < k2."""
     import torch
     slab = np.asarray(slab, dtype=np.float32)
     F = slab.shape[0]
     q = _f32(q)
     Q = q.shape[0]
-    hits = [ref_retrieve_batch(slab[f], q, k1, vector_batch_size)[0] for f in range(F)]   # :672-674
+    stage1 = [ref_retrieve_batch(slab[f], q, k1, vector_batch_size) for f in range(F)]     # :672-674
+    hits = [h[0] for h in stage1]
     m = torch.ones(F, 1) if mask is None else torch.from_numpy(_f32(mask)).reshape(F, 1)
     out_ids = np.empty((Q, k2), dtype=np.int64)
     out_sc = np.empty((Q, k2), dtype=np.float32)
@@ -250,13 +252,18 @@ def ref_two_stage(slab, q, W, mask=None, k1=100, k2=100, vector_batch_size=10485
         values, indices = torch.topk(scores, k=k2, dim=1)                                   # :696
         ids = np.asarray(all_ids, dtype=np.int64)[indices.flatten().numpy()]
         out_ids[i], out_sc[i] = canon(ids, values.flatten().numpy())
+    if return_fields:
+        return out_ids, out_sc, np.stack(hits, axis=1), np.stack([h[1] for h in stage1], axis=1)
     return out_ids, out_sc
 
 
-def assert_topk_equivalent(ids_a, sc_a, ids_b, sc_b, tol=1e-4, what=""):
-    """Two canonical result lists computed with different fp32 summation orders: scores must agree within
-    `tol`, and ids must agree everywhere except inside runs of near-tied scores (gap <= 2*tol), where only the
-    id multiset restricted to the 'safe' part has to match."""
+def assert_topk_equivalent(ids_a, sc_a, ids_b, sc_b, tol=1e-4, what="", relative=False):
+    """Two canonical result lists computed with different fp32 summation orders: scores must agree within `tol`
+    (ABSOLUTE -- the north-star's "scores within 1e-4 fp32"; `relative=True` scales it by max(1, max|score|) for data
+    whose scores are far above 1), and ids must agree everywhere except inside runs of near-tied scores (gap <= 2*tol),
+    where positions may be permuted.  The last position gets no special treatment: an id that differs there must be
+    in a near-tie with its neighbour like anywhere else, or the id SETS must differ only by elements whose scores are
+    within 2*tol of the cut-off (checked by `classify_topk_mismatch`, not here)."""
     ids_a, ids_b = np.asarray(ids_a), np.asarray(ids_b)
     sc_a, sc_b = np.asarray(sc_a, dtype=np.float64), np.asarray(sc_b, dtype=np.float64)
     assert ids_a.shape == ids_b.shape, (what, ids_a.shape, ids_b.shape)
@@ -264,15 +271,62 @@ def assert_topk_equivalent(ids_a, sc_a, ids_b, sc_b, tol=1e-4, what=""):
     for r in range(ids_a.reshape(-1, k).shape[0]):
         ia, ib = ids_a.reshape(-1, k)[r], ids_b.reshape(-1, k)[r]
         sa, sb = sc_a.reshape(-1, k)[r], sc_b.reshape(-1, k)[r]
-        scale = max(1.0, float(np.max(np.abs(sa[np.isfinite(sa)]))) if np.isfinite(sa).any() else 1.0)
+        scale = 1.0
+        if relative and np.isfinite(sa).any():
+            scale = max(1.0, float(np.max(np.abs(sa[np.isfinite(sa)]))))
         np.testing.assert_allclose(sa, sb, rtol=0, atol=tol * scale, err_msg=f"{what} row {r} scores")
-        bad = np.nonzero(ia != ib)[0]
-        for j in bad:
-            # a mismatch is tolerated only if both ids sit in a near-tie with a neighbour (or with the cut-off)
-            near = False
-            for jj in (j - 1, j + 1):
-                if 0 <= jj < k and abs(sa[j] - sa[jj]) <= 2 * tol * scale:
-                    near = True
-            if j == k - 1:
-                near = near or True  # boundary element may swap with the first excluded one
+        for j in np.nonzero(ia != ib)[0]:
+            near = any(0 <= jj < k and abs(sa[j] - sa[jj]) <= 2 * tol * scale for jj in (j - 1, j + 1))
             assert near, f"{what} row {r} pos {j}: ids {ia[j]} vs {ib[j]} with scores {sa[j]} vs {sb[j]}"
+
+
+def classify_topk_mismatch(a, b, tol=1e-4):
+    """Explain every difference between two runs of the two-stage scorer on the same inputs (different fp32 summation
+    orders).  a, b: dicts with ids[k2], scores[k2] (canonical order), field_ids[F,k1], field_scores[F,k1] for ONE query.
+    Returns one of
+      "identical"        same ids in the same order
+      "order_in_tie"     same id set; every position that differs sits in a run of scores within 2*tol
+      "final_cutoff_tie" id sets differ only by ids whose mixed score is within 2*tol of the k2-th score on the side
+                         that has them, and which the other side had as a CANDIDATE (it ranked them just below the cut)
+      "stage1_cutoff_tie" ... or which the other side never saw as a candidate because, in every field whose list
+                         carries the id on this side, its per-field score is within 2*tol of the other side's k1-th
+                         (last) list score in that field (a rank-k1 near-tie in stage 1)
+      "other"            anything else: a real disagreement
+    plus the largest score difference over the ids both sides returned."""
+    ia, ib = np.asarray(a["ids"]), np.asarray(b["ids"])
+    sa, sb = np.asarray(a["scores"], dtype=np.float64), np.asarray(b["scores"], dtype=np.float64)
+    pos_b = {int(x): j for j, x in enumerate(ib)}
+    common = [(j, pos_b[int(x)]) for j, x in enumerate(ia) if int(x) in pos_b]
+    dmax = max((abs(sa[j] - sb[jb]) for j, jb in common), default=0.0)
+    if dmax > tol:
+        return "other", dmax
+    if np.array_equal(ia, ib):
+        return "identical", dmax
+    k = len(ia)
+    if set(ia.tolist()) == set(ib.tolist()):
+        for j in np.nonzero(ia != ib)[0]:
+            if not any(0 <= jj < k and abs(sa[j] - sa[jj]) <= 2 * tol for jj in (j - 1, j + 1)):
+                return "other", dmax
+        return "order_in_tie", dmax
+    cls = "final_cutoff_tie"
+    for x, y in ((a, b), (b, a)):
+        xi, xs = np.asarray(x["ids"]), np.asarray(x["scores"], dtype=np.float64)
+        y_set = set(np.asarray(y["ids"]).tolist())
+        y_cand = set(np.asarray(y["field_ids"]).reshape(-1).tolist())
+        for j, d in enumerate(xi.tolist()):
+            if d in y_set:
+                continue
+            if abs(xs[j] - xs[-1]) <= 2 * tol and d in y_cand:
+                continue                                   # y ranked it just below its cut-off
+            if d not in y_cand:
+                # stage-1 explanation: in every field where x lists d, x's score of d is a near-tie with y's last entry
+                fx, fsx = np.asarray(x["field_ids"]), np.asarray(x["field_scores"], dtype=np.float64)
+                fsy = np.asarray(y["field_scores"], dtype=np.float64)
+                fields = [f for f in range(fx.shape[0]) if d in fx[f].tolist()]
+                ok = bool(fields) and all(abs(fsx[f][fx[f].tolist().index(d)] - fsy[f][-1]) <= 2 * tol for f in fields)
+                if ok:
+                    cls = "stage1_cutoff_tie"
+                    continue
+            return "other", dmax
+    # the ids both sides kept may be permuted only inside near-ties
+    return cls, dmax

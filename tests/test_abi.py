@@ -68,5 +68,8 @@ def test_python_mirror_keeps_reference_signatures():
     assert inspect.signature(DenseFlatIndex.__init__).parameters["vector_batch_size"].default == 1048576
     assert list(inspect.signature(DenseFlatIndex.retrieve_batch).parameters) == ["self", "queries", "top_k"]
     assert list(inspect.signature(DenseFlatIndex.score_batch).parameters) == ["self", "queries", "keys"]
-    assert list(inspect.signature(candidate_encoding_stream).parameters) == ["encoder", "corpus", "batch_size", "multiprocess", "show_progress"]
+    # the reference's five parameters in the reference's order; `as_tensor` is a trailing keyword extension (default off)
+    ps = inspect.signature(candidate_encoding_stream).parameters
+    assert list(ps)[:5] == ["encoder", "corpus", "batch_size", "multiprocess", "show_progress"]
+    assert list(ps)[5:] == ["as_tensor"] and ps["as_tensor"].default is False
     assert inspect.isabstract(Index)

@@ -32,6 +32,52 @@ def _write_dataset(root, n_docs=300, n_q=24, seed=0):
     return docs
 
 
+def _data_module(module, data, tmp, dataset, dev_batch_size):
+    """The query side exactly as the CLIs build it (same tokenizer, same batching)."""
+    from mfar.modeling.contrastive import RetrievalDataModule
+    dm = RetrievalDataModule(tokenizer=module.encoder.tokenizer, queries_path=data, corpus=module.corpus, temp_path=tmp,
+                             dev_partition="val", additional_partition=None, lexical_index="unused",
+                             negative_sampling_params=(100, 50, 1), dataset_name=dataset, dev_batch_size=dev_batch_size,
+                             field_info=module.field_info, indices_dict=module.indices_dict)
+    dm.setup("test")
+    return dm
+
+
+def _oracle_eval(module, dm, mask=None):
+    """{query id: (ids[100], scores[100])} from the C oracle, fed the rows read back from the module's slab and the query
+    embeddings computed exactly as the evaluation computes them (same padded batches through the same encoder)."""
+    import torch
+    from oracle import mfar_oracle as O
+    F = module.slab.n_fields
+    slab = np.stack([module.slab.read_rows(f) for f in range(F)])
+    W = module.mixture_of_fields_layer.weight.detach().cpu().numpy()
+    want = {}
+    for batch in dm.test_dataloader()[0]:
+        with torch.no_grad():
+            qe = module.encode_query_batch(batch).cpu().numpy()
+        o = O.c_two_stage(slab, qe, W, mask)
+        for i, inst in enumerate(batch.instances):
+            want[inst._id] = (o["ids"][i], o["scores"][i])
+    return want
+
+
+def _read_qres(path):
+    got = {}
+    for l in open(path).read().strip().split("\n"):
+        p = l.split("\t")
+        got.setdefault(p[0], []).append((int(p[2]), np.float32(float(p[4]))))
+    return got
+
+
+def _assert_qres_equals_oracle(path, want, bits=True):
+    got = _read_qres(path)
+    assert set(got) == set(want)
+    for qid, rows in got.items():
+        assert [d for d, _ in rows] == want[qid][0].tolist(), qid                 # exact ids, all 100 ranks
+        if bits:
+            assert np.array_equal(np.array([s for _, s in rows], np.float32).view(np.uint32), want[qid][1].view(np.uint32)), qid
+
+
 def test_train_then_mask_fields(tmp_path):
     import torch
     from mfar.commands import mask_fields, train
@@ -54,26 +100,10 @@ def test_train_then_mask_fields(tmp_path):
     rows = [json.loads(l) for l in open(f"{out}/results_dicts-all-0.jsonl")]
     assert rows[-1]["additional"] == "test" and rows[-2]["additional"] == "val" and "recall_20" in rows[-1]
 
-    # the evaluation the CLI ran == the oracle on the very same embeddings
-    from oracle import mfar_oracle as O
-    slab = np.stack([module.slab.read_rows(f) for f in range(3)])
+    # the evaluation the CLI ran == the oracle on the very same slab rows and query embeddings: exact ids, exact score bits
+    dm = _data_module(module, data, tmp, "amazon", 16)
+    _assert_qres_equals_oracle(f"{out}/final-all-0.qres", _oracle_eval(module, dm))
     W = module.mixture_of_fields_layer.weight.detach().cpu().numpy()
-    qs = dict(__import__("mfar.data.trec", fromlist=["x"]).read_corpus(f"{data}/val.queries"))
-    qids = list(qs)[:5]
-    qe = module.encoder.encode([qs[i] for i in qids], convert_to_numpy=True)
-    o = O.c_two_stage(slab, qe, W, None)
-    got = {}
-    for l in lines:
-        p = l.split("\t")
-        got.setdefault(p[0], []).append((int(p[2]), float(p[4])))
-    for i, qid in enumerate(qids):
-        ids = [d for d, _ in got[qid]]
-        sims = np.array([s for _, s in got[qid]], dtype=np.float32)
-        # the CLI encodes the query inside a padded batch, the check encodes it alone: scores agree to fp32 noise
-        np.testing.assert_allclose(sims, o["scores"][i], rtol=1e-4, atol=1e-4)
-        # (documents that share a text now share one embedding bit for bit, so this tiny corpus has many exact score ties;
-        #  the two query embeddings differ in the last bits and resolve a few more boundary near-ties differently)
-        assert len(set(ids) & set(o["ids"][i].tolist())) >= 90
 
     out2 = str(tmp_path / "out2")
     m2 = mask_fields.main(dataset_name="amazon", lexical_index="unused", out=out2, temp_dir=tmp, data=data,
@@ -87,3 +117,81 @@ def test_train_then_mask_fields(tmp_path):
     np.testing.assert_allclose(m2.mixture_of_fields_layer.weight.detach().cpu().numpy(), W)
     # masking every field zeroes all mixed scores
     assert rows[8]["recall_20"] <= rows[0]["recall_20"]
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE.json configs[0]
+_PRIME_REL = ["associated with", "carrier", "contraindication", "enzyme", "expression absent", "expression present", "indication",
+              "interacts with", "linked to", "off-label use", "parent-child", "phenotype absent", "phenotype present", "ppi",
+              "side effect", "synergistic interaction", "target", "transporter"]
+
+
+def _write_prime_dataset(root, n_docs=2000, n_q=40, seed=1):
+    """STaRK-prime shaped records (22 fields: name / type / source / details + 18 relation dicts, schema.py:19-42): a
+    handful of distinct `type` / `source` values, most relation fields missing from most records (-> "" -> big groups of
+    identical rows per field), nested dict values formatted by format_dict (format.py:64-110)."""
+    rng = np.random.default_rng(seed)
+    vocab = [f"w{i}" for i in range(300)]
+    types = ["gene/protein", "drug", "disease", "effect/phenotype", "anatomy", "pathway", "exposure", "molecular_function",
+             "biological_process", "cellular_component"]
+    sources = ["NCBI", "DrugBank", "MONDO", "HPO", "UBERON", "REACTOME"]
+    os.makedirs(root, exist_ok=True)
+    docs = []
+    with open(f"{root}/corpus", "w") as f:
+        for i in range(n_docs):
+            t = types[int(rng.zipf(1.6)) % len(types)]
+            body = {"name": " ".join(rng.choice(vocab, 2)), "type": t, "source": sources[int(rng.integers(0, len(sources)))],
+                    "details": {"description": " ".join(rng.choice(vocab, 6)), "half_life": int(rng.integers(1, 9))}}
+            for rel in _PRIME_REL:
+                if rng.random() < 0.25:
+                    body[rel] = {str(rng.choice(types)): [str(w) for w in rng.choice(vocab, int(rng.integers(1, 4)))]}
+            docs.append(body)
+            f.write(f"{i}\t{json.dumps(body)}\n")
+    for part in ("train", "val", "test"):
+        with open(f"{root}/{part}.queries", "w") as fq, open(f"{root}/{part}.qrels", "w") as fr:
+            for j in range(n_q):
+                d = int(rng.integers(0, n_docs))
+                fq.write(f"{part[0]}{j}\t{docs[d]['name']} {docs[d]['details']['description']}\n")
+                fr.write(f"{part[0]}{j}\t0\t{d}\t1\n")
+    return docs
+
+
+def test_prime_2000_all_dense_end_to_end(tmp_path, monkeypatch):
+    """BASELINE.json configs[0]: STaRK-prime shaped corpus, --max_docs 2000 sized, field_names=all_dense (F = 22), through the
+    CLIs (one training iteration, then the evaluation; then the mask sweep).  The .qres the CLI wrote must hold EXACTLY the
+    ids the C oracle computes from the same slab rows and the same query embeddings, and the same score bits."""
+    from mfar.commands import mask_fields, train
+    monkeypatch.setenv("MFAR_SCREEN", "2")      # 2000 rows are below the automatic threshold: force the certified screen on
+    data = str(tmp_path / "prime")
+    _write_prime_dataset(data)
+    out, tmp = str(tmp_path / "out"), str(tmp_path / "tmp")
+    module = train.main(dataset_name="prime", lexical_index="unused", out=out, temp_dir=tmp, data=data,
+                        model_name="random-init:256x1", field_names="all_dense", weights_lr=5e-2, encoder_lr=1e-4,
+                        train_batch_size=4, dev_batch_size=16, max_epochs=1, run_one_iteration=True, precision="32")
+    F = len(module.field_info)
+    assert F == 22 and module.slab.n_fields == 22 and module.slab.n_rows == 2000
+    assert list(module.field_info) == sorted(module.field_info)                   # schema.py:131-134 order == slab field order
+    # every field is full of bit-identical rows (missing relation -> ""; 10 types, 6 sources): the screen scans unique rows
+    slab = np.stack([module.slab.read_rows(f) for f in range(F)])
+    n_unique = [len(np.unique(slab[f], axis=0)) for f in range(F)]
+    assert n_unique[list(module.field_info).index("type_dense")] <= 10 and max(n_unique) > 1900
+    W = module.mixture_of_fields_layer.weight.detach().cpu().numpy()
+    assert not np.allclose(W, 1.0)                                                # the training step moved the gate
+
+    dm = _data_module(module, data, tmp, "prime", 16)
+    want = _oracle_eval(module, dm)
+    assert len(want) == 40
+    _assert_qres_equals_oracle(f"{out}/final-all-0.qres", want)
+    st = module.slab.screen_stats()
+    assert st["built"] and st["n_checked"] > 0 and st["n_failed"] == 0, st        # screened, and no list fell back to the exact pass
+
+    out2 = str(tmp_path / "out2")
+    m2 = mask_fields.main(dataset_name="prime", lexical_index="unused", out=out2, temp_dir=tmp, data=data, model_name="random-init:256x1",
+                          field_names="all_dense", checkpoint_dir=out, dev_batch_size=16)
+    rows = [json.loads(l) for l in open(f"{out2}/results_dicts-all-0.jsonl")]
+    assert len(rows) == 1 + 22 + 1 + 22                                          # baseline, per field, all-dense, per name (mask_fields.py:143-170)
+    # the last evaluation of the sweep masked the field named "type": its .qres equals the oracle with that mask
+    last = rows[-1]["masked_fields"]
+    assert last == "type_dense"
+    mask = np.ones(F, np.float32)
+    mask[list(m2.field_info).index("type_dense")] = 0
+    _assert_qres_equals_oracle(f"{out2}/final-all-0.qres", _oracle_eval(m2, _data_module(m2, data, tmp, "prime", 16), mask), bits=False)

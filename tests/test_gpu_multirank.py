@@ -12,9 +12,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(n, extra_env):
+def _bench(n, extra_env, dtype="f32"):
     env = dict(os.environ, **extra_env)
-    args = ["--docs", "70000", "--fields", "4", "--dim", "128", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    args = ["--docs", "70000", "--fields", "4", "--dim", "128", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extra-legs",
+            "--dtype", dtype]
     if n == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args
     else:
@@ -27,9 +28,12 @@ def _bench(n, extra_env):
     return json.loads(lines[0])
 
 
-def test_two_ranks_on_one_gpu_match_single_rank():
-    one = _bench(1, {"MFAR_BENCH_DUMP_IDS": "1"})
-    two = _bench(2, {"MFAR_BENCH_BACKEND": "gloo", "MFAR_BENCH_SHARE_GPU": "1", "MFAR_BENCH_DUMP_IDS": "1"})
-    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+@pytest.mark.parametrize("world,dtype", [(2, "f32"), (4, "f32"), (2, "bf16")])
+def test_ranks_on_one_gpu_match_single_rank(world, dtype):
+    """The PRODUCT multi-rank path (PipelinedSearcher, lists-first exchange: two all-gathers per batch, the certificate flag
+    travelling in the second) with `world` ranks, fp32 (screened) and bf16 slabs."""
+    one = _bench(1, {"MFAR_BENCH_DUMP_IDS": "1"}, dtype)
+    two = _bench(world, {"MFAR_BENCH_BACKEND": "gloo", "MFAR_BENCH_SHARE_GPU": "1", "MFAR_BENCH_DUMP_IDS": "1"}, dtype)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == world and two["scaling"] == "strong"
     assert one["recall_at_20"] > 0.3 and two["recall_at_20"] == one["recall_at_20"]   # (weak planted signal at dim 128)
     assert two["ids_checksum"] == one["ids_checksum"]          # same top-100 ids for every query of every step

@@ -41,6 +41,66 @@ def _load(idxmod, slab, row_offset=0):
     return ix
 
 
+def _gather_rows(ix, rows):
+    """Rows `rows` (global ids) of every field, row-major fp32 [F, len(rows), E], read back through the C ABI."""
+    import torch
+    out = np.empty((ix.n_fields, len(rows), ix.dim), np.float32)
+    buf = torch.empty(1, ix.dim, device=f"cuda:{ix.device}")
+    for f in range(ix.n_fields):
+        dev = torch.empty(len(rows), ix.dim, device=f"cuda:{ix.device}")
+        for j, x in enumerate(rows):
+            ix.read_rows(f, int(x) - ix.row_offset, 1, out=buf)
+            dev[j] = buf[0]
+        out[f] = dev.cpu().numpy()
+    return out
+
+
+def _exhaustive_stage1_check(ix, q, fid, fsc, queries, slack=2e-3):
+    """Independent, EXHAUSTIVE check of the stage-1 lists at any corpus size (plain torch fp32 matmul over every row read
+    back from the index): no row outside a list scores above the list's last entry, every row inside scores at least
+    that, and the listed scores agree with torch's.  `slack` covers the different fp32 summation orders."""
+    import torch
+    dev = f"cuda:{ix.device}"
+    qs = q[queries].to(dev)
+    step = 65536
+    for f in range(ix.n_fields):
+        S = torch.empty(len(queries), ix.n_rows, device=dev)
+        for r0 in range(0, ix.n_rows, step):
+            n = min(step, ix.n_rows - r0)
+            rows = torch.empty(n, ix.dim, device=dev)
+            ix.read_rows(f, r0, n, out=rows)
+            S[:, r0:r0 + n] = qs @ rows.t()
+        for j, qi in enumerate(queries):
+            ids = torch.as_tensor(fid[qi, f], device=dev) - ix.row_offset
+            sc = torch.as_tensor(fsc[qi, f], device=dev)
+            real = sc > 0                                   # zero-sentinel padding entries are (row 0, 0.0)
+            kth = float(sc[-1])
+            assert torch.allclose(S[j, ids[real]], sc[real], rtol=0, atol=slack), (f, qi)
+            inside = torch.zeros(ix.n_rows, dtype=torch.bool, device=dev)
+            inside[ids[real]] = True
+            above = (S[j] > max(kth, 0.0) + slack) & ~inside
+            assert not bool(above.any()), (f, qi, int(above.sum()))
+
+
+def _oracle_check_on_subset(ix, q, W, mask, r, queries, n_random=3000, seed=0):
+    """The FINAL mixed top-k (and the stage-1 lists) of `queries` against the C oracle, bit for bit, on a row subset that
+    contains every stage-1 list member of those queries plus random rows (the exhaustive check above proves the lists
+    complete, so the oracle's per-field top-k over the subset is the per-field top-k over the corpus)."""
+    fid, fsc = r["field_ids"].cpu().numpy(), r["field_scores"].cpu().numpy()
+    ids, sc = r["ids"].cpu().numpy(), r["scores"].cpu().numpy()
+    D = ix.row_offset + ix.n_rows
+    rng = np.random.default_rng(seed)
+    rows = np.unique(np.concatenate([fid[queries].ravel(), rng.integers(ix.row_offset, D, n_random), [ix.row_offset]]))
+    sub = _gather_rows(ix, rows)
+    qq = q[queries].cpu().numpy()
+    o = O.c_two_stage(sub, qq, W.cpu().numpy(), None if mask is None else mask.cpu().numpy())
+    for j, qi in enumerate(queries):
+        assert np.array_equal(rows[o["field_ids"][j]], fid[qi]), ("stage-1 ids", qi)
+        assert np.array_equal(o["field_scores"][j].view(np.uint32), fsc[qi].view(np.uint32)), ("stage-1 score bits", qi)
+        assert np.array_equal(rows[o["ids"][j]], ids[qi]), ("final ids", qi)
+        assert np.array_equal(o["scores"][j].view(np.uint32), sc[qi].view(np.uint32)), ("final score bits", qi)
+
+
 def test_rows_roundtrip_tiled_layout(idxmod):
     rng = np.random.default_rng(0)
     for D, E in [(1, 32), (63, 32), (64, 64), (65, 96), (257, 768), (1000, 32)]:
@@ -323,9 +383,16 @@ def test_full_size_properties(idxmod):
     rm = idxmod.merge_payloads(payloads, 2, q, W, None, n_fields=F)
     torch.cuda.synchronize()
     assert torch.equal(rm["ids"], r1["ids"]) and torch.equal(rm["scores"], r1["scores"])
-    # spot check against the oracle on a row subset that contains every returned doc for 2 queries
     for s in shards:
         s.close()
+    # oracle comparison AT the headline shape, 8 queries: (1) exhaustive torch check that the stage-1 lists are complete,
+    # (2) the C oracle on the union rows: stage-1 lists, final ids and final score BITS
+    ix = corpus.build_index(idxmod)
+    queries = [0, 7, 13, 21, 34, 42, 55, 63]
+    fid, fsc = r1["field_ids"].cpu().numpy(), r1["field_scores"].cpu().numpy()
+    _exhaustive_stage1_check(ix, q, fid, fsc, queries)
+    _oracle_check_on_subset(ix, q, W, None, r1, queries)
+    ix.close()
 
 
 def test_pipelined_searcher_equals_plain_search(idxmod):
@@ -384,22 +451,11 @@ def test_baseline_config_shapes(idxmod, name, D, F, n_shards):
     assert all(len(set(row.tolist())) == 100 for row in ids)
     rel = corpus.qrels(0, Q)
     assert np.mean([len(set(ids[i, :20].tolist()) & rel[i]) / len(rel[i]) for i in range(Q)]) > 0.9
-    # oracle spot check for 2 queries: rows = every stage-1 winner of those queries + random rows.  The per-field top-100 of
-    # the full corpus must be the per-field top-100 of that subset, with identical score bits.
-    for qi in (0, Q - 1):
-        rows = np.unique(np.concatenate([fid[qi].ravel(), np.random.default_rng(qi).integers(0, D, 5000)]))
-        # gather the subset rows from the index itself (read_rows is row-major == the reference memmap layout)
-        sub = np.empty((F, rows.size, E), np.float32)
-        for f in range(F):
-            for lo in range(0, rows.size, 512):
-                blk = rows[lo:lo + 512]
-                for j, x in enumerate(blk):
-                    sub[f, lo + j] = ix.read_rows(f, int(x), 1)[0]
-        qq = q[qi:qi + 1].cpu().numpy()
-        for f in range(F):
-            oi, osc = O.c_retrieve(sub[f], qq, 100, True)
-            assert np.array_equal(rows[oi[0]], fid[qi, f]), (name, qi, f)
-            assert np.array_equal(osc[0].view(np.uint32), fsc[qi, f].view(np.uint32)), (name, qi, f)
+    # oracle comparison at the full shape for 8 queries: the stage-1 lists are proven complete by an exhaustive torch scan,
+    # then the C oracle on the union rows must give the same stage-1 lists, final ids and final score BITS (mask included)
+    queries = [0, 9, 18, 27, 36, 45, 54, 63]
+    _exhaustive_stage1_check(ix, q, fid, fsc, queries)
+    _oracle_check_on_subset(ix, q, W, mask, r, queries)
     if n_shards > 1:
         ix.close()
         bounds = [D * g // n_shards for g in range(n_shards + 1)]
@@ -766,3 +822,98 @@ def test_screen_duplicate_group_is_masked_and_reinserted(idxmod):
     assert all(s_.screen_stats()["n_failed"] == 0 for s_ in shards)
     for s_ in shards:
         s_.close()
+
+
+# ------------------------------------------------------------------------------------------------ larger goldens (SURVEY 8(c) sizes)
+def test_stage1_large_and_tie_heavy_goldens(golden_dir, idxmod):
+    """G1 at D = 5000 x E = 768 (captured through the reference's 256-row chunk merge), and the tie-heavy grid case whose
+    scores must equal the reference's bit for bit -- on both stage-1 paths of an fp32 index."""
+    from test_oracle_golden import check_tie_grid_case
+    z = np.load(os.path.join(golden_dir, "retrieve_batch_large.npz"))
+    n = "g1_5000x768_chunk256"
+    V, q = z[n + "__V16"].astype(np.float32), z[n + "__q16"].astype(np.float32)
+    ix = _load(idxmod, V[None])
+    for screen in (0, 2):
+        ix.set_screen(screen)
+        ids, sc = ix.retrieve_fields(q, 100, True)
+        assert np.array_equal(ids[:, 0], z[n + "__ids"]), screen
+        np.testing.assert_allclose(sc[:, 0], z[n + "__scores"], rtol=0, atol=TOL)
+    ix.close()
+    V, q = z["g1_ties_grid__Vg"].astype(np.float32) / 8.0, z["g1_ties_grid__qg"].astype(np.float32) / 8.0
+    ix = _load(idxmod, V[None])
+    for screen in (0, 2):
+        ix.set_screen(screen)
+        ids, sc = ix.retrieve_fields(q, 100, True)
+        check_tie_grid_case(z, ids[:, 0], sc[:, 0])
+    ix.close()
+
+
+@pytest.mark.parametrize("name", ["L_f1_e768", "L_f4_e768", "L_f8_e768"])
+def test_two_stage_large_goldens(golden_dir, idxmod, name):
+    """G5 at E = 768, F in {1, 4, 8}: ids equal to the unmodified reference trec_eval_step, scores within 1e-4."""
+    z = np.load(os.path.join(golden_dir, f"trec_eval_step_{name}.npz"))
+    slab, q, W, mask = (z[k].astype(np.float32) for k in ("slab16", "q16", "W16", "mask"))
+    ix = _load(idxmod, slab)
+    for screen in (0, 2):
+        ix.set_screen(screen)
+        r = ix.search(q, W, mask)
+        assert np.array_equal(r["ids"], z["ids"]), (name, screen)
+        np.testing.assert_allclose(r["scores"], z["scores"], rtol=0, atol=TOL)
+    ix.close()
+
+
+# ------------------------------------------------------------------------------------------------ on-disk format of the vectors (SURVEY 8 f3)
+def test_memmap_export_import_roundtrip(idxmod, tmp_path):
+    """HbmFieldVectors.export_memmap writes the reference's raw {temp_dir}/{field}.npy layout (float32 [D, E], no header,
+    data/util.py:35): the reference's MemoryMapDict reads it, and import_memmap of a MemoryMapDict-written file restores
+    the slab bit for bit -- also when two row shards write the same file."""
+    from mfar.data.util import HbmFieldVectors, MemoryMapDict
+    rng = np.random.default_rng(40)
+    F, D, E = 2, 333, 64
+    slab, q, W = _mk(rng, F, D, E, 3)
+    keys = [f"doc{i}" for i in range(D)]
+    half = 150
+    shards = [_load(idxmod, slab[:, :half]), _load(idxmod, slab[:, half:], row_offset=half)]
+    for f in range(F):
+        path = str(tmp_path / f"field{f}.npy")
+        for sh in shards:
+            HbmFieldVectors(sh, f, keys).export_memmap(path, n_total_rows=D)
+        assert os.path.getsize(path) == D * E * 4
+        mm = MemoryMapDict(path, keys, (D, E))
+        assert np.array_equal(mm.file, slab[f]) and np.array_equal(mm["doc7"], slab[f, 7])
+        mm["doc7"] = np.arange(E, dtype=np.float32)                  # the reference's writer (data/util.py:40-41)
+        mm.close()
+    full = idxmod.MultiFieldIndex(D, F, E, device=0)
+    for f in range(F):
+        HbmFieldVectors(full, f, keys).import_memmap(str(tmp_path / f"field{f}.npy"), D)
+    want = slab.copy()
+    want[:, 7] = np.arange(E, dtype=np.float32)
+    for f in range(F):
+        assert np.array_equal(full.read_rows(f), want[f])
+    o = O.c_two_stage(want, q, W, None)
+    r = full.search(q, W, None)
+    assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32))
+    for ix in shards + [full]:
+        ix.close()
+
+
+def test_score_batch_refuses_rows_of_other_shards(idxmod):
+    """DenseFlatIndex.score_batch on a row shard: a valid key owned by another rank raises KeyError instead of scoring NaN."""
+    rng = np.random.default_rng(41)
+    slab, q, _ = _mk(rng, 1, 200, 32, 1)
+    keys = [str(i) for i in range(400)]
+    sh = _load(idxmod, slab, row_offset=200)
+    ix = idxmod.DenseFlatIndex(None, None, keys, {k: i for i, k in enumerate(keys)}, slab=sh, field_index=0)
+
+    class Enc:
+        def encode(self, texts, convert_to_tensor=False, **kw):
+            import torch
+            return torch.from_numpy(q[:len(texts)])
+    ix.model = Enc()
+    s = ix.score_batch(["q"], ["200", "399"])
+    assert tuple(s.shape) == (1, 2) and np.isfinite(s.numpy()).all()
+    with pytest.raises(KeyError):
+        ix.score_batch(["q"], ["200", "5"])        # row 5 lives on another rank
+    with pytest.raises(KeyError):
+        ix.score_batch(["q"], ["nope"])            # unknown key (index.py:229)
+    sh.close()

@@ -188,3 +188,131 @@ def test_sentence_encoder_structure():
     np.testing.assert_allclose(np.linalg.norm(encn.encode(texts[:2]), axis=1), 1.0, rtol=1e-5)
     with pytest.raises(ValueError):
         prepare_model("/definitely/not/a/model")
+
+
+def test_format_single_golden(golden_dir):
+    """The whole-document text of the single_dense field (format.py:20-22, 113-415), per dataset, incl. the records the
+    reference cannot format (it raises UnboundLocalError; so does the mirror)."""
+    from mfar.data.format import format_documents
+    d = json.load(open(os.path.join(golden_dir, "format_single.json")))
+    n = 0
+    for ds, rows in d["out"].items():
+        if ds == "bad_dataset":
+            continue
+        for doc, want in zip(d["docs"][ds], rows):
+            doc = (doc[0], doc[1])
+            if isinstance(want[1], dict):
+                with pytest.raises(Exception) as ei:
+                    format_documents([doc], "single", ds)
+                assert type(ei.value).__name__ == want[1]["raises"], (ds, doc[0])
+            else:
+                assert [list(x) for x in format_documents([doc], "single", ds)] == [want], (ds, doc[0])
+            n += 1
+    assert n == 14
+    with pytest.raises(ValueError):
+        format_documents([("x", {"title": "t"})], "single", "nosuch")
+    # resolve_fields("single_dense") names this field (schema.py:123-124)
+    from mfar.data.schema import resolve_fields
+    f = resolve_fields("single_dense", "amazon")["single_dense"]
+    assert f.name == "single" and f.max_seq_length == 512
+
+
+class _FakeEncoder:
+    """Records every encode() call; the embedding of a text is [len(text), #call, position in call]."""
+
+    def __init__(self):
+        self.calls = []
+
+    def encode(self, texts, batch_size=64, convert_to_numpy=False, convert_to_tensor=False, **kw):
+        self.calls.append((list(texts), batch_size, convert_to_numpy, convert_to_tensor))
+        arr = np.array([[len(t), len(self.calls) - 1, j] for j, t in enumerate(texts)], dtype=np.float32)
+        if convert_to_tensor:
+            import torch
+            return torch.from_numpy(arr)
+        return arr
+
+
+def test_candidate_encoding_stream_order_and_batches():
+    """index.py:234-258 (the non-multiprocess branch the eval path uses, contrastive.py:487): input order is kept, the
+    corpus is cut into chunks of batch_size with a short tail batch, and each chunk is one encoder.encode() call."""
+    from mfar.data.index import candidate_encoding_stream
+    corpus = [(f"d{i}", "x" * (i % 5)) for i in range(11)]
+    enc = _FakeEncoder()
+    out = list(candidate_encoding_stream(enc, iter(corpus), batch_size=4, multiprocess=False, show_progress=False))
+    assert [i for i, _ in out] == [i for i, _ in corpus]
+    assert [len(c[0]) for c in enc.calls] == [4, 4, 3]                       # tail batch
+    assert all(c[1] == 4 and c[2] is True for c in enc.calls)                # batch_size passed on, numpy rows (index.py:257)
+    for (i, v), (_, t) in zip(out, corpus):
+        assert isinstance(v, np.ndarray) and v.shape == (3,) and v[0] == len(t)
+    assert [int(v[1]) for _, v in out] == [0] * 4 + [1] * 4 + [2] * 3
+    assert list(candidate_encoding_stream(enc, [], batch_size=4, show_progress=False)) == []
+    # the device-resident variant used by on_eval_start yields tensors
+    import torch
+    out_t = list(candidate_encoding_stream(_FakeEncoder(), corpus[:5], batch_size=2, show_progress=False, as_tensor=True))
+    assert all(torch.is_tensor(v) for _, v in out_t) and [i for i, _ in out_t] == [f"d{i}" for i in range(5)]
+
+
+def _reference_layout_state_dict(encoder, E, F, with_bn=False):
+    """A state_dict with exactly the key set a checkpoint of the REFERENCE module holds (contrastive.py:279-293, 634-645):
+    `encoder.0.auto_model.*` (SentenceTransformer Sequential index 0), the field-weight matrix under both of its names
+    (the same Parameter is registered on the module and inside the loss), optional BatchNorm1d(F) of the loss."""
+    import torch
+    g = torch.Generator().manual_seed(5)
+    sd = {f"encoder.0.auto_model.{k}": torch.randn(v.shape, generator=g).to(v.dtype) if v.dtype.is_floating_point else v.clone()
+          for k, v in encoder.auto_model.state_dict().items()}
+    w = torch.randn(E, F, generator=g)
+    sd["mixture_of_fields_layer.weight"] = w
+    sd["hybrid_contrastive_loss_fn.mixture_of_fields_layer.weight"] = w.clone()
+    if with_bn:
+        sd.update({"hybrid_contrastive_loss_fn.bn.weight": torch.ones(F), "hybrid_contrastive_loss_fn.bn.bias": torch.zeros(F),
+                   "hybrid_contrastive_loss_fn.bn.running_mean": torch.zeros(F), "hybrid_contrastive_loss_fn.bn.running_var": torch.ones(F),
+                   "hybrid_contrastive_loss_fn.bn.num_batches_tracked": torch.tensor(3)})
+    return sd
+
+
+def test_load_checkpoint_with_reference_key_layout(tmp_path):
+    """mask_fields.py:110-121 -> load_from_checkpoint: a Lightning .ckpt with the reference's exact key set loads into the
+    mirror (encoder weights, W, BatchNorm state); layouts that do not line up raise instead of silently loading nothing."""
+    import torch
+    from mfar.data.schema import resolve_fields
+    from mfar.modeling.contrastive import RetrievalTrainingModule
+    from mfar.modeling.util import prepare_model
+    fields = resolve_fields("title_dense,brand_dense,feature_dense", "amazon")
+    _, enc, _ = prepare_model("random-init:64x2")
+    corpus = [("0", {"title": "a"}), ("1", {"title": "b"})]
+    sd = _reference_layout_state_dict(enc, 64, 3, with_bn=True)
+    hp = dict(model_id="random-init:64x2", dataset_name="amazon", corpus_path="/c", query_cond=True, weights_learning_rate=0.1,
+              field_info={k: f.serialize() for k, f in fields.items()}, indices_list=[], vectors_list=[], corpus=[],
+              precomputed_sparse_scores=[], some_future_hparam=1)
+    path = str(tmp_path / "ref.ckpt")
+    torch.save({"state_dict": sd, "hyper_parameters": hp, "pytorch-lightning_version": "2.0.0", "epoch": 3, "global_step": 7}, path)
+    kw = dict(corpus=corpus, indices_dict={}, vectors_dict={}, encoder=enc, dev_qrels_path="/q", field_info=fields, out_dir=str(tmp_path))
+    m = RetrievalTrainingModule.load_from_checkpoint(path, **kw)
+    assert torch.equal(m.mixture_of_fields_layer.weight.data, sd["mixture_of_fields_layer.weight"])
+    k0 = "embeddings.word_embeddings.weight"
+    assert torch.equal(m.encoder.auto_model.state_dict()[k0], sd["encoder.0.auto_model." + k0])
+    assert set(m.bn_state) == {"weight", "bias", "running_mean", "running_var", "num_batches_tracked"}
+    # what the mirror writes back carries the same keys the reference wrote
+    assert set(m.checkpoint_state()["state_dict"]) == set(sd)
+    # position_ids is persisted by some transformers versions only: its absence is fine
+    sd2 = {k: v for k, v in sd.items() if not k.endswith("position_ids")}
+    torch.save({"state_dict": sd2, "hyper_parameters": hp}, path)
+    RetrievalTrainingModule.load_from_checkpoint(path, **kw)
+    # a different encoder key layout (e.g. the gtr-t5 module stack): nothing would load -> must raise
+    bad = {k.replace("encoder.0.auto_model.", "encoder.0.model."): v for k, v in sd.items()}
+    torch.save({"state_dict": bad, "hyper_parameters": hp}, path)
+    with pytest.raises(RuntimeError):
+        RetrievalTrainingModule.load_from_checkpoint(path, **kw)
+    torch.save({"state_dict": {k: v for k, v in sd.items() if not k.startswith("encoder.")}, "hyper_parameters": hp}, path)
+    with pytest.raises(RuntimeError, match="encoder"):
+        RetrievalTrainingModule.load_from_checkpoint(path, **kw)
+    lost = {k: v for k, v in sd.items() if "layer.1.output.dense.weight" not in k}
+    torch.save({"state_dict": lost, "hyper_parameters": hp}, path)
+    with pytest.raises(RuntimeError, match="lacks"):
+        RetrievalTrainingModule.load_from_checkpoint(path, **kw)
+    # W trained for another field set
+    wrong = dict(sd)
+    wrong["mixture_of_fields_layer.weight"] = wrong["hybrid_contrastive_loss_fn.mixture_of_fields_layer.weight"] = torch.ones(64, 8)
+    torch.save({"state_dict": wrong, "hyper_parameters": hp}, path)
+    with pytest.raises(RuntimeError, match="field set"):
+        RetrievalTrainingModule.load_from_checkpoint(path, **kw)

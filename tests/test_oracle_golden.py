@@ -143,3 +143,105 @@ def test_sharded_merge_equals_unsharded():
 def test_schema_golden_shape(golden_dir):
     d = json.load(open(os.path.join(golden_dir, "schema.json")))
     assert [len(d[f"{ds}|all_dense"]) for ds in ("mag", "prime", "amazon")] == [5, 22, 8]
+
+
+# ------------------------------------------------------------------------------------------------ larger goldens (SURVEY 8(c) sizes)
+def test_retrieve_batch_large_golden(golden_dir):
+    """G1 at D = 5000 x E = 768 through the reference's chunk-merge path (vector_batch_size = 256)."""
+    z = np.load(os.path.join(golden_dir, "retrieve_batch_large.npz"))
+    n = "g1_5000x768_chunk256"
+    V, q = z[n + "__V16"].astype(np.float32), z[n + "__q16"].astype(np.float32)
+    gi, gs = z[n + "__ids"], z[n + "__scores"]
+    ri, rs = O.ref_retrieve_batch(V, q, 100, 256)
+    assert np.array_equal(ri, gi)
+    np.testing.assert_allclose(rs, gs, rtol=0, atol=1e-5)
+    ci, cs = O.c_retrieve(V, q, 100, sentinel=True)
+    assert np.array_equal(ci, gi)
+    np.testing.assert_allclose(cs, gs, rtol=0, atol=TOL)
+
+
+def check_tie_grid_case(z, ids, scores):
+    """The tie-heavy golden: scores must equal the reference's BIT FOR BIT (exact arithmetic on the value grid); ids must
+    be canonical, and equal the reference's wherever the reference had no choice (scores strictly above its k-th)."""
+    gi, gs = z["g1_ties_grid__ids"], z["g1_ties_grid__scores"]
+    V, q = z["g1_ties_grid__Vg"].astype(np.float32) / 8.0, z["g1_ties_grid__qg"].astype(np.float32) / 8.0
+    full = (q.astype(np.float64) @ V.astype(np.float64).T).astype(np.float32)     # exact: every partial sum is representable
+    assert np.array_equal(np.asarray(scores).view(np.uint32), gs.view(np.uint32))
+    for i in range(q.shape[0]):
+        above = gs[i] > gs[i, -1]
+        assert np.array_equal(np.asarray(ids)[i][above], gi[i][above]), i
+        # canonical order: (score desc, id asc) over ALL rows, zero sentinel (only positive scores enter)
+        order = np.lexsort((np.arange(V.shape[0]), -full[i].astype(np.float64)))
+        order = order[full[i][order] > 0][:100]
+        want = np.zeros(100, np.int64)
+        want[:order.size] = order
+        assert np.array_equal(np.asarray(ids)[i], want), i
+
+
+def test_retrieve_tie_heavy_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "retrieve_batch_large.npz"))
+    V, q = z["g1_ties_grid__Vg"].astype(np.float32) / 8.0, z["g1_ties_grid__qg"].astype(np.float32) / 8.0
+    gs = z["g1_ties_grid__scores"]
+    ri, rs = O.ref_retrieve_batch(V, q, 100, 1000)
+    assert np.array_equal(np.sort(rs, axis=1)[:, ::-1].view(np.uint32), gs.view(np.uint32))     # same score multiset
+    ci, cs = O.c_retrieve(V, q, 100, sentinel=True)
+    check_tie_grid_case(z, ci, cs)
+    assert (np.diff(gs[0]) == 0).sum() > 90            # query 0 hits the block of 500 identical rows: a list full of ties
+
+
+@pytest.mark.parametrize("name", ["L_f1_e768", "L_f4_e768", "L_f8_e768"])
+def test_trec_eval_step_large_golden(golden_dir, name):
+    """G5 at E = 768, F in {1, 4, 8}: the unmodified reference trec_eval_step vs the port and the C oracle."""
+    z = np.load(os.path.join(golden_dir, f"trec_eval_step_{name}.npz"))
+    slab, q, W, mask = (z[k].astype(np.float32) for k in ("slab16", "q16", "W16", "mask"))
+    gi, gs = z["ids"], z["scores"]
+    pi, ps = O.ref_two_stage(slab, q, W, mask)
+    assert np.array_equal(pi, gi)
+    np.testing.assert_allclose(ps, gs, rtol=2e-6, atol=1e-5)
+    r = O.c_two_stage(slab, q, W, mask)
+    O.assert_topk_equivalent(r["ids"], r["scores"], gi, gs, tol=TOL, what=name)
+    assert np.array_equal(r["ids"], gi)
+
+
+# ------------------------------------------------------------------------------------------------ the mismatch classifier (bench.py's gate)
+def _run(ids, scores, fid, fsc):
+    return dict(ids=np.asarray(ids), scores=np.asarray(scores, np.float32), field_ids=np.asarray(fid), field_scores=np.asarray(fsc, np.float32))
+
+
+def test_classify_topk_mismatch():
+    fid = np.array([[1, 2, 3, 4]])
+    fsc = np.array([[4.0, 3.0, 2.0, 1.0]])
+    a = _run([1, 2, 3], [3.0, 2.0, 1.0], fid, fsc)
+    assert O.classify_topk_mismatch(a, _run([1, 2, 3], [3.0, 2.0, 1.0], fid, fsc))[0] == "identical"
+    # order swap inside a 1e-5 tie
+    b = _run([2, 1, 3], [3.0, 3.0 - 1e-5, 1.0], fid, fsc)
+    a2 = _run([1, 2, 3], [3.0, 3.0 - 1e-5, 1.0], fid, fsc)
+    assert O.classify_topk_mismatch(a2, b)[0] == "order_in_tie"
+    # order swap with a real gap
+    assert O.classify_topk_mismatch(a, _run([2, 1, 3], [3.0, 2.0, 1.0], fid, fsc))[0] == "other"
+    # the last id differs, both were candidates and sit at the cut-off
+    c = _run([1, 2, 4], [3.0, 2.0, 1.0 + 1e-5], fid, fsc)
+    assert O.classify_topk_mismatch(a, c)[0] == "final_cutoff_tie"
+    # ... with a score far above the cut-off it is a real disagreement
+    assert O.classify_topk_mismatch(a, _run([1, 4, 2], [3.0, 2.5, 2.0], fid, fsc))[0] == "other"
+    # the other side never had the id as a candidate: explained only by a near-tie at the END of its stage-1 list
+    fid_b, fsc_b = np.array([[1, 2, 3, 9]]), np.array([[4.0, 3.0, 2.0, 1.0 + 2e-5]])
+    d = _run([1, 2, 9], [3.0, 2.0, 1.0], fid_b, fsc_b)
+    a3 = _run([1, 2, 4], [3.0, 2.0, 1.0], fid, fsc)
+    assert O.classify_topk_mismatch(a3, d)[0] == "stage1_cutoff_tie"
+    fsc_far = np.array([[4.0, 3.0, 2.0, 1.5]])
+    assert O.classify_topk_mismatch(a3, _run([1, 2, 9], [3.0, 2.0, 1.0], fid_b, fsc_far))[0] == "other"
+    # scores of common ids further apart than the tolerance
+    assert O.classify_topk_mismatch(a, _run([1, 2, 3], [3.0, 2.0, 1.001], fid, fsc))[0] == "other"
+
+
+def test_tolerant_checker_is_absolute():
+    ids = np.arange(5)[None]
+    sc = np.array([[50.0, 40.0, 30.0, 20.0, 10.0]], np.float32)
+    O.assert_topk_equivalent(ids, sc, ids, sc + 5e-5, tol=1e-4)
+    with pytest.raises(AssertionError):
+        O.assert_topk_equivalent(ids, sc, ids, sc + 2e-3, tol=1e-4)            # 1e-4 is absolute, not scaled by |score|
+    O.assert_topk_equivalent(ids, sc, ids, sc + 2e-3, tol=1e-4, relative=True)
+    swapped = np.array([[0, 1, 2, 4, 3]])
+    with pytest.raises(AssertionError):                                        # the last position gets no free pass
+        O.assert_topk_equivalent(ids, sc, swapped, sc, tol=1e-4)

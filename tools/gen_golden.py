@@ -178,6 +178,53 @@ def gen_retrieve(out, DenseFlatIndex):
     return list(cases)
 
 
+def f16_exact(a):
+    """Round to fp16-representable values: the fixture stores them as float16 (half the bytes), fp32 inputs are exact."""
+    return np.asarray(a, dtype=np.float32).astype(np.float16)
+
+
+def gen_retrieve_large(out, DenseFlatIndex):
+    """SURVEY 8(c) G1 at its full size: D = 5000 x E = 768 through the chunk-merge path (vector_batch_size = 256), plus a
+    TIE-HEAVY case on a coarse value grid (every product and every partial sum is exact in fp32, so ANY summation order
+    -- MKL's included -- gives the same bits: scores must match the reference bit for bit, ids up to the reference's
+    unspecified order inside runs of equal scores)."""
+    cases = {}
+    rng = np.random.default_rng(5000768)
+    D, E, Q, k = 5000, 768, 8, 100
+    mu = gauss(rng, (E,))
+    mu /= np.linalg.norm(mu)
+    V16 = f16_exact(gauss(rng, (D, E)) * 0.5 + 0.05 * mu * 4.0)
+    q16 = f16_exact(gauss(rng, (Q, E)) * 0.5 + mu * 2.0)
+    V, q = V16.astype(np.float32), q16.astype(np.float32)
+    keys = [str(i) for i in range(D)]
+    idx = DenseFlatIndex(None, V, keys, {k_: i for i, k_ in enumerate(keys)}, vector_batch_size=256)
+    res = idx.retrieve_batch(q, top_k=k)
+    cases["g1_5000x768_chunk256"] = dict(V16=V16, q16=q16, k=np.int64(k), chunk=np.int64(256),
+                                         ids=np.array([[int(key) for key, _ in r] for r in res], dtype=np.int64),
+                                         scores=np.array([[s_ for _, s_ in r] for r in res], dtype=np.float32))
+    # tie-heavy: values on the grid j/8, |j| <= 24, E = 64: products are multiples of 1/64 below 9, sums stay exact
+    rng = np.random.default_rng(777)
+    D, E, Q = 3000, 64, 6
+    Vg = rng.integers(-24, 25, size=(D, E)).astype(np.int8)
+    dup = rng.choice(D, size=900, replace=False)
+    Vg[dup[:500]] = Vg[dup[0]]                       # one block of 500 identical rows ("empty field", format.py:58-59)
+    Vg[dup[500:]] = Vg[dup[500 + (np.arange(400) % 7)]]   # seven smaller groups
+    qg = rng.integers(-24, 25, size=(Q, E)).astype(np.int8)
+    qg[0] = Vg[dup[0]]                               # query 0 scores the big group highest
+    V, q = Vg.astype(np.float32) / 8.0, qg.astype(np.float32) / 8.0
+    keys = [str(i) for i in range(D)]
+    idx = DenseFlatIndex(None, V, keys, {k_: i for i, k_ in enumerate(keys)}, vector_batch_size=1000)
+    res = idx.retrieve_batch(q, top_k=100)
+    ids = np.array([[int(key) for key, _ in r] for r in res], dtype=np.int64)
+    sc = np.array([[s_ for _, s_ in r] for r in res], dtype=np.float32)
+    for i in range(Q):
+        ids[i], sc[i] = canon(ids[i], sc[i])         # canonical inside the set the reference happened to return
+    cases["g1_ties_grid"] = dict(Vg=Vg, qg=qg, k=np.int64(100), chunk=np.int64(1000), ids=ids, scores=sc)
+    np.savez_compressed(os.path.join(out, "retrieve_batch_large.npz"),
+                        **{f"{n}__{k_}": v for n, c in cases.items() for k_, v in c.items()})
+    return list(cases)
+
+
 def gen_score_batch(out, DenseFlatIndex):
     rng = np.random.default_rng(1234)
     D, E, Q = 900, 64, 3
@@ -229,10 +276,18 @@ def gen_linear_weights(out, LinearWeights):
     np.savez_compressed(os.path.join(out, "linear_weights.npz"), W=W, x2=x2, q1=q1, x3=x3, q4=q4, w2=w2, **d)
 
 
+# SURVEY 8(c) G5 at E = 768, F in {1, 4, 8} (name, F, D, E, Q, mean, masked fields, std of W)
+LARGE_TREC_SPECS = [
+    ("L_f1_e768", 1, 2500, 768, 4, 0.05, [], 0.02),
+    ("L_f4_e768", 4, 1000, 768, 4, 0.05, [2], 0.02),
+    ("L_f8_e768", 8, 600, 768, 4, 0.05, [], 0.02),
+]
+
+
 def gen_trec_eval_step(out, DenseFlatIndex, LinearWeights, contrastive, FieldType, Query):
     """Drive the UNMODIFIED RetrievalTrainingModule.trec_eval_step (contrastive.py:669-704)."""
     torch.Tensor.cuda = lambda self, *a, **k: self  # reference hard-codes .cuda() (contrastive.py:685-686)
-    cases = {}
+    cases, large_cases = {}, {}
     specs = [
         # name, F, D, E, Q, mean, mask (list of masked field idx), std_W
         ("t_f1", 1, 900, 32, 4, 0.3, [], 0.05),
@@ -244,7 +299,8 @@ def gen_trec_eval_step(out, DenseFlatIndex, LinearWeights, contrastive, FieldTyp
         ("t_f3_e768", 3, 160, 768, 3, 0.05, [], 0.02),
         ("t_f22", 22, 260, 32, 3, 0.3, [5, 7], 0.05),
     ]
-    for name, F, D, E, Q, mean, masked, stdw in specs:
+    for name, F, D, E, Q, mean, masked, stdw in specs + LARGE_TREC_SPECS:
+        large = name.startswith("L_")
         rng = np.random.default_rng(sum(map(ord, name.split("_mask")[0])) + 1000)
         mu = gauss(rng, (E,))
         mu /= np.linalg.norm(mu)
@@ -257,6 +313,8 @@ def gen_trec_eval_step(out, DenseFlatIndex, LinearWeights, contrastive, FieldTyp
                 for f in rng.choice(F, size=max(1, F // 2), replace=False):
                     slab[f, d] = (0.6 * qtab[qi] + 0.3 * gauss(rng, (E,))).astype(np.float32)
         W = gauss(rng, (E, F), std=stdw)
+        if large:       # stored as float16 (exactly representable values): half the fixture bytes
+            slab, qtab, W = (f16_exact(x).astype(np.float32) for x in (slab, qtab, W))
         keys = [str(i) for i in range(D)]
         k2n = {k: i for i, k in enumerate(keys)}
         enc = LookupEncoder(qtab)
@@ -292,6 +350,11 @@ def gen_trec_eval_step(out, DenseFlatIndex, LinearWeights, contrastive, FieldTyp
         for qi in range(Q):
             ids[qi], sc[qi] = canon(ids[qi], sc[qi])
         cases[name] = dict(slab=slab, q=qtab, W=W, mask=mask.numpy()[:, 0].astype(np.float32), ids=ids, scores=sc)
+        if large:
+            c = cases.pop(name)
+            large_cases[name] = dict(slab16=c["slab"].astype(np.float16), q16=c["q"].astype(np.float16), W16=c["W"].astype(np.float16),
+                                     mask=c["mask"], ids=c["ids"], scores=c["scores"])
+            continue
         base = name.split("_mask")[0]
         if base != name:  # mask variants share the base case's inputs: store them once
             assert np.array_equal(cases[base]["slab"], slab) and np.array_equal(cases[base]["W"], W)
@@ -302,7 +365,9 @@ def gen_trec_eval_step(out, DenseFlatIndex, LinearWeights, contrastive, FieldTyp
             cases[name]["first_line"] = np.array(lines[0])
     np.savez_compressed(os.path.join(out, "trec_eval_step.npz"),
                         **{f"{n}__{k}": v for n, c in cases.items() for k, v in c.items()})
-    return list(cases)
+    for n, c in large_cases.items():      # one file per case: each stays well below 20 MB
+        np.savez_compressed(os.path.join(out, f"trec_eval_step_{n}.npz"), **c)
+    return list(cases) + list(large_cases)
 
 
 def gen_loss(out, LinearWeights):
@@ -435,6 +500,65 @@ def gen_format(out, format_documents):
         json.dump({"docs": docs, "out": res}, f, indent=1)      # key order of the documents matters: no sort_keys
 
 
+def gen_format_single(out, format_documents):
+    """The whole-document text of the `single_dense` / `single_sparse` field (format.py:20-22 -> format_stark,
+    format.py:113-415), per dataset, on hand-made documents that walk every branch; crashes of the reference on
+    documents it cannot format are recorded as such."""
+    docs = {
+        "amazon": [
+            ("a1", {"title": "Red shoe", "brand": "Acme", "description": [" comfy ", "shoe "], "feature": ["light", "", "ASIN: B01", "durable"],
+                    "review": [{"summary": "good", "reviewText": "I like it", "overall": 5}, {"summary": "meh", "reviewText": "ok"}],
+                    "qa": [{"question": "size?", "answer": "42"}], "also_buy": ["B2", "B3"], "also_view": ["B9"]}),
+            ("a2", {"title": "Blue hat", "also_buy": [], "also_view": []}),
+            ("a3", {"title": "Plain", "description": ["", " "], "also_buy": ["X"], "also_view": [], "feature": []}),
+            ("a4", {"title": "No relations at all"}),
+        ],
+        "mag": [
+            ("m1", {"type": "paper", "title": "A Paper", "abstract": "We study things.\r\n\n",
+                    "paper___cites___paper": ["P1", "P2"], "paper___has_topic___field_of_study": ["IR", "NLP"],
+                    "author___affiliated_with___institution": {"Ann": ["MIT", "CMU"], "Bob": []}}),
+            ("m2", {"type": "paper", "title": "Bare", "abstract": ""}),
+            ("m3", {"type": "author", "title": "Not a paper"}),
+        ],
+        "prime": [
+            ("p1", {"name": "aspirin", "type": "drug", "source": "DB",
+                    "details": {"description": "painkiller", "half_life": 3, "_private": "x", "drug_id": "D1", "empty": "", "nan": float("nan")},
+                    "interacts with": {"gene/protein": ["A", "B"], "drug": ["C"]}, "side effect": {"effect/phenotype": ["nausea"]}}),
+            ("p2", {"name": "TP53", "type": "gene/protein", "source": "NCBI",
+                    "details": {"name": "tumor protein", "alias": ["p53", "LFS1"], "interpro": {"desc": "P53 family", "id": "IPR1"},
+                                "generif": [{"text": "role in cancer", "pubmed": 1}, {"text": "binds DNA", "pubmed": 2}],
+                                "genomic_pos": [{"chr": "17", "start": 7}, {"chr": "X", "start": 1}], "summary": "guardian"},
+                    "ppi": {"gene/protein": ["MDM2"]}}),
+            ("p3", {"name": "x", "type": "disease", "source": "S"}),
+            ("p4", {"type": "disease", "source": "S"}),
+        ],
+        "whatsthatbook": [
+            ("b1", {"title": "Dune", "author": "F. Herbert", "author_url": "http://a", "description": "sand", "isbn": "123",
+                    "parsed_dates": ["1965", None, "1984"], "image_link": "http://i", "num_ratings": 10, "num_reviews": 2,
+                    "genres": ["sf", "classic"], "id": "77"}),
+            ("b2", {"title": "Bare", "parsed_dates": None, "genres": []}),
+            ("b3", {}),
+        ],
+    }
+    res = {}
+    for ds, corpus in docs.items():
+        rows = []
+        for doc in corpus:
+            try:
+                (i, text), = format_documents([doc], "single", ds)
+                rows.append([i, text])
+            except Exception as e:
+                rows.append([doc[0], {"raises": type(e).__name__}])
+        res[ds] = rows
+    try:
+        format_documents(docs["amazon"][:1], "single", "nosuch")
+        res["bad_dataset"] = None
+    except Exception as e:
+        res["bad_dataset"] = type(e).__name__
+    with open(os.path.join(out, "format_single.json"), "w") as f:
+        json.dump({"docs": docs, "out": res}, f, indent=1)
+
+
 def gen_memmap(out, MemoryMapDict):
     import tempfile
     with tempfile.TemporaryDirectory() as td:
@@ -491,12 +615,14 @@ def main():
     from mfar.modeling import contrastive
 
     print("retrieve_batch:", gen_retrieve(out, DenseFlatIndex))
+    print("retrieve_batch_large:", gen_retrieve_large(out, DenseFlatIndex))
     gen_score_batch(out, DenseFlatIndex)
     gen_linear_weights(out, LinearWeights)
     print("trec_eval_step:", gen_trec_eval_step(out, DenseFlatIndex, LinearWeights, contrastive, FieldType, Query))
     gen_schema(out, resolve_fields, FieldType)
     gen_trec(out, trec)
     gen_format(out, format_documents)
+    gen_format_single(out, format_documents)
     gen_memmap(out, MemoryMapDict)
     try:
         gen_loss(out, LinearWeights)
