@@ -85,6 +85,13 @@ int mfar_retrieve_fields(mfar_index* idx, const float* q, int Q, int k, int sent
                          float* field_scores, int on_device, void* stream);
 
 /*
+ * Stage 1 for ONE field == one DenseFlatIndex.retrieve_batch call of the reference's per-field loop
+ * (data/index.py:181-222 as driven by contrastive.py:672-674): scans only that field's rows.  ids/scores [Q, k].
+ */
+int mfar_retrieve_field(mfar_index* idx, int field, const float* q, int Q, int k, int sentinel, int64_t* ids, float* scores,
+                        int on_device, void* stream);
+
+/*
  * Stage 2 == DenseFlatIndex.score_batch (data/index.py:227-232) for all fields (contrastive.py:681-683):
  * out[Q, C, n_fields] = <q_i, slab[f, cand[i,c]]>.  cand [Q, C] int64 global ids; ids outside this shard
  * (or < 0) produce NaN (the reference raises KeyError for unknown keys -- the Python wrapper keeps that).
@@ -157,10 +164,14 @@ int mfar_merge_payloads(int device, const void* payloads, int n_shards, const fl
 int64_t mfar_lists_bytes(int Q, int n_fields, int k1);
 int64_t mfar_topk_bytes(int Q, int k2);
 int mfar_retrieve_lists(mfar_index* idx, const float* q, int Q, int k1, int sentinel, void* lists, void* stream);
+/* any_fail (device int32, may be NULL = 0): this rank's certificate flag of the batch as reported by mfar_stage1_finish; it
+ * travels inside the top-k payload, and mfar_merge_topk writes the OR over all ranks to *any_fail (device int32, may be
+ * NULL) -- every rank takes the same redo decision without a third collective. */
 int mfar_search_owned(mfar_index* idx, const void* gathered_lists, int n_shards, const float* q, int Q, const float* W,
-                      int query_cond, const float* mask, int k1, int k2, int sentinel, int slot, void* topk, void* stream);
+                      int query_cond, const float* mask, int k1, int k2, int sentinel, int slot, const int32_t* any_fail,
+                      void* topk, void* stream);
 int mfar_merge_topk(int device, const void* gathered_topk, int n_shards, int Q, int k2, int64_t* ids, float* scores,
-                    int32_t* n_valid, void* stream);
+                    int32_t* n_valid, int32_t* any_fail, void* stream);
 
 /* Stream choreography helper for pipelined batches: make `stream` wait until the most recently enqueued FULL stage-1
  * kernel of this handle is about to start (i.e. until everything enqueued before it, including the sample pass, has
@@ -200,10 +211,12 @@ int mfar_set_wgs_per_cu(mfar_index* idx, int wgs);
 /*
  * Certified fp16 screening of an fp32 index (no reference counterpart; the outputs of every entry point above are
  * bit-identical with and without it).  Stage 1 of an fp32 index is bound by the fp32 MFMA rate; with the screen it
- * scans a half-size fp16 copy of the rows for the min(k + 92, 192) best approximate scores per (query, field), re-scores those
- * rows exactly from the fp32 slab, and PROVES from a rigorous error bound that no other row can enter or tie into
- * the exact top-k; a field whose proof fails is re-done by the exact fp32 pass on the device (csrc/mfar_screen.h).
- * The screen slab (+50 % HBM) is built lazily by the first search after rows were written.
+ * scans an fp16 copy of each field's UNIQUE rows (bit-identical rows -- documents that share a text, above all "" for a
+ * missing field, format.py:58-59 -- are scanned once) for the min(k + 92, 192) best approximate scores per (query, field),
+ * re-scores those rows exactly from the fp32 slab, expands them to their documents, and PROVES from a rigorous error bound
+ * that no other row can enter or tie into the exact top-k; a field whose proof fails is re-done by the exact fp32 pass over
+ * the documents on the device (csrc/mfar_screen.h).  The screen slab (at most +50 % HBM) is built lazily by the first search
+ * after rows were written.
  *   mode      0 = off, 1 = auto (default; fp32 indexes with >= 16384 rows, k <= 128), 2 = whenever the shapes allow.
  *             Environment default: MFAR_SCREEN.
  *   eps_mult  multiplies the error bound of the proof; 1 = rigorous.  Test knob: a huge value makes every proof fail
@@ -214,11 +227,9 @@ int mfar_set_wgs_per_cu(mfar_index* idx, int wgs);
 int mfar_set_screen(mfar_index* idx, int mode, float eps_mult);
 int mfar_get_screen(const mfar_index* idx, int* mode, float* eps_mult);
 int mfar_screen_stats(mfar_index* idx, int* built, int64_t* screen_bytes, int64_t* n_checked, int64_t* n_failed);
-/* The duplicate group of a field found when the screen was built (synchronises the device): a field that a document lacks
- * is encoded from the empty string (format.py:58-59), so corpora hold one large group of bit-identical rows per field.  The
- * screened pass scans only the group's lowest row (rep_row, a global id; -1 = no group of >= 64 rows) and the certify step
- * re-inserts the n_masked others -- same score, ids ascending -- when that row is among the k best. */
-int mfar_screen_dup_group(mfar_index* idx, int field, int64_t* rep_row, int64_t* n_masked);
+/* After the screen was built: the number of distinct vectors of a field (what the screened pass scans) and the size of its
+ * largest group of bit-identical rows; -1 while no screen is current. */
+int mfar_screen_field_info(mfar_index* idx, int field, int64_t* n_unique_rows, int64_t* largest_group);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,9 @@
 // mfar_hip.hip -- host side of libmfar_hip.so: the C ABI declared in include/mfar_hip.h.
 // gfx950 only.  Every entry point returns an error code; nothing throws across the ABI.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>   // device radix sort + prefix sums of the unique-row build (index construction, not the hot path)
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -68,6 +70,29 @@ struct DevCtx {
 static DevCtx g_ctx[16];
 static bool g_attr_done[16] = {false};
 
+// Geometry of one scanned slab + its chunk tables (mfar_stage1.h: S1Chunk).  `all`: every field gets a share of the grid
+// proportional to its tiles (one launch scans all fields); `solo`: every field is cut as finely as the list merge allows
+// (a launch scans one field, mfar_retrieve_field).
+struct S1Table {
+    int k = -1, wgs = -1;             // built for this list depth / grid size
+    std::vector<S1Chunk> chunks;
+    std::vector<int> fchunk, samp_n;  // [F + 1], [F]
+    int n_chunks = 0, max_chunks = 0, samp_stride = 0, sample_tiles = 1;
+    long long total_tiles = 0;
+    DevBuf d_chunks, d_fchunk, d_samp_n;
+};
+struct S1Geom {
+    std::vector<long long> n_rows, base;   // per field: valid rows, element offset of the field inside the slab
+    std::vector<int> n_tiles;              // per field: 256-row tiles
+    S1Table all, solo;
+    void reset(int F) {
+        n_rows.assign(F, 0);
+        base.assign(F, 0);
+        n_tiles.assign(F, 0);
+        all.k = solo.k = -1;
+    }
+};
+
 struct mfar_index {
     int device = 0;
     int64_t n_rows = 0, row_offset = 0;
@@ -91,12 +116,18 @@ struct mfar_index {
     // certified fp16 screen of an fp32 index (mfar_screen.h)
     int screen_mode = 1;          // 0 off, 1 auto, 2 always (when the shapes allow)
     float screen_eps_mult = 1.0f; // test knob: scales the certificate's error bound
-    void* screen = nullptr;       // fp16 tiled slab, same element offsets as the fp32 slab
+    DevBuf screen;                // fp16 tiled slab of the fields' UNIQUE rows (per-field bases: geom_screen)
+    size_t screen_used = 0;       // bytes of it in use
     bool screen_dirty = true;     // rows were written since the screen was built
-    bool screen_nomem = false;
-    long long screen_checked = 0; // (query, field) lists certified so far    // the screen slab could not be allocated: stay on the exact pass
-    DevBuf s_stats, s_field, s_mean, s_dupmask, s_dupgrp;   // + duplicate groups: row bitmap [F][n_blk * 2], DupGroup [F]
-    bool screen_dedup = true;     // mask the field's big duplicate group out of the screened pass (MFAR_SCREEN_DEDUP=0: off)
+    bool screen_nomem = false;    // the screen slab could not be allocated: stay on the exact pass
+    long long screen_checked = 0; // (query, field) lists certified so far
+    DevBuf s_stats, s_field, s_mean;
+    // unique rows of every field (mfar_screen.h), each table [F][n_rows] (stride n_rows): representative document of a
+    // unique row, start / length of its member run in `members` (local rows grouped by unique row, ascending inside a group)
+    DevBuf u_rep, u_start, u_count, u_members, u_n;
+    std::vector<int> n_unique, largest_group;   // per field (host copies)
+    bool screen_dedup = true;     // MFAR_SCREEN_DEDUP=0: every document is its own unique row (diagnostic)
+    S1Geom geom_docs, geom_screen;
     hipEvent_t mid_ev = nullptr;  // recorded right before the full stage-1 kernel is launched
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -195,6 +226,14 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
         delete idx;
         return fail(MFAR_ERR_HIP, std::string("hipMemset(slab): ") + hipGetErrorString(e));
     }
+    idx->geom_docs.reset(n_fields);
+    for (int f = 0; f < n_fields; ++f) {
+        idx->geom_docs.n_rows[f] = n_rows_local;
+        idx->geom_docs.base[f] = (long long)f * idx->field_stride;
+        idx->geom_docs.n_tiles[f] = (int)(n_blk / 4);
+    }
+    idx->n_unique.assign(n_fields, 0);
+    idx->largest_group.assign(n_fields, 0);
     *out = idx;
     return MFAR_OK;
 }
@@ -206,8 +245,14 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
     DevBuf* bufs[] = {&idx->fid, &idx->fsc, &idx->cand[0], &idx->cand[1], &idx->ncand[0], &idx->ncand[1], &idx->x[0], &idx->x[1],
-                      &idx->own[0], &idx->own[1], &idx->s_stats, &idx->s_field, &idx->s_mean, &idx->s_dupmask,
-                      &idx->s_dupgrp};
+                      &idx->own[0], &idx->own[1], &idx->s_stats, &idx->s_field, &idx->s_mean, &idx->screen, &idx->u_rep, &idx->u_start,
+                      &idx->u_count, &idx->u_members, &idx->u_n};
+    for (S1Geom* g : {&idx->geom_docs, &idx->geom_screen})
+        for (S1Table* t : {&g->all, &g->solo}) {
+            t->d_chunks.release();
+            t->d_fchunk.release();
+            t->d_samp_n.release();
+        }
     for (DevBuf* b : bufs) b->release();
     for (auto& sl : idx->s1) {
         DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
@@ -217,7 +262,6 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     for (auto& b : idx->in) b.release();
     for (auto& b : idx->out) b.release();
     if (idx->slab) (void)hipFree(idx->slab);
-    if (idx->screen) (void)hipFree(idx->screen);
     delete idx;
 }
 
@@ -390,23 +434,76 @@ static int check_search_common(const mfar_index* idx, const float* q, int Q, int
 }
 
 // ------------------------------------------------------------------------------------------------ stage 1
-static int stage1_chunks(const mfar_index* idx, int k) {
-    const int n_tiles = (int)(idx->n_blk / 4);
-    long long target = ((long long)idx->wgs_per_cu * idx->n_cu + idx->F / 2) / idx->F;
-    if (target < 1) target = 1;
-    if (target > 128) target = 128;
-    if (target * k > 64 * 256) target = (64 * 256) / k;   // the list merge holds n_chunks * k keys in registers
-    if (target > n_tiles) target = n_tiles;
-    return (int)target;
+// Chunk table of a scanned slab for list depth k (mfar_stage1.h).  A field's share of the grid follows its tiles; the list
+// merge holds n_chunks * k keys of one field, which caps the chunks of a field.
+static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool solo, int sample_tiles_max, hipStream_t st) {
+    if (t.k == k && t.wgs == idx->wgs_per_cu) return MFAR_OK;
+    if (t.k >= 0) HIPCHK(hipDeviceSynchronize());   // a launch in flight may still read the old table
+    const int F = idx->F;
+    const long long want = (long long)idx->wgs_per_cu * idx->n_cu;
+    const int cap = std::max(1, std::min(128, (64 * 256) / k));
+    long long total_tiles = 0;
+    for (int f = 0; f < F; ++f) total_tiles += g.n_tiles[f];
+    t.chunks.clear();
+    t.fchunk.assign(F + 1, 0);
+    t.samp_n.assign(F, 0);
+    t.max_chunks = 0;
+    std::vector<int> cf(F);
+    for (int f = 0; f < F; ++f) {
+        long long c = solo ? want : (want * g.n_tiles[f] + total_tiles / 2) / std::max(1LL, total_tiles);
+        c = std::max(1LL, std::min<long long>(c, std::min(cap, std::max(1, g.n_tiles[f]))));
+        cf[f] = (int)c;
+        t.max_chunks = std::max(t.max_chunks, cf[f]);
+    }
+    long long n_chunks = 0;
+    for (int f = 0; f < F; ++f) n_chunks += cf[f];
+    // tiles per workgroup in the sample pass: more tiles = tighter starting thresholds = fewer appends in the full pass, at
+    // the price of reading those tiles twice; at most 1/12 of an average chunk and 2048 published values per (query, field)
+    // (measured: 2 tiles pay off for the HBM-bound 16-bit passes, 1 for the MFMA-bound fp32 pass)
+    static const int sample_div = getenv("MFAR_SAMPLE_DIV") ? atoi(getenv("MFAR_SAMPLE_DIV")) : 12;
+    int sample_tiles = (int)std::max(1LL, std::min<long long>(sample_tiles_max, total_tiles / std::max(1LL, n_chunks) / sample_div));
+    while (sample_tiles > 1 && 8 * t.max_chunks * sample_tiles > 2048) --sample_tiles;
+    t.sample_tiles = sample_tiles;
+    t.samp_stride = 0;
+    for (int f = 0; f < F; ++f) {
+        t.fchunk[f] = (int)t.chunks.size();
+        int tl = 0;
+        for (int c = 0; c < cf[f]; ++c) {
+            S1Chunk ck = {};
+            ck.f = f;
+            ck.t0 = (int)(((long long)c * g.n_tiles[f]) / cf[f]);
+            ck.t1 = (int)(((long long)(c + 1) * g.n_tiles[f]) / cf[f]);
+            ck.n_rows = (int)g.n_rows[f];
+            ck.base = g.base[f];
+            ck.tl0 = tl;
+            tl += std::min(sample_tiles, ck.t1 - ck.t0);
+            t.chunks.push_back(ck);
+        }
+        t.samp_n[f] = 4 * tl;
+        t.samp_stride = std::max(t.samp_stride, 4 * tl);
+    }
+    t.fchunk[F] = (int)t.chunks.size();
+    t.n_chunks = (int)t.chunks.size();
+    t.total_tiles = total_tiles;
+    RETCHK(t.d_chunks.ensure(t.chunks.size() * sizeof(S1Chunk)));
+    RETCHK(t.d_fchunk.ensure((F + 1) * sizeof(int)));
+    RETCHK(t.d_samp_n.ensure(F * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(t.d_chunks.p, t.chunks.data(), t.chunks.size() * sizeof(S1Chunk), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(t.d_fchunk.p, t.fchunk.data(), (F + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(t.d_samp_n.p, t.samp_n.data(), F * sizeof(int), hipMemcpyHostToDevice, st));
+    t.k = k;
+    t.wgs = idx->wgs_per_cu;
+    return MFAR_OK;
 }
 
 // One stage-1 pass over one slab for one block of <= 64 queries: [sample pass] -> full pass -> list merge.
 struct S1Out {
-    long long* ids;   // [., F, k]
+    long long* ids;   // [., nf, k]
     float* sc;
-    int* cnt;         // [qt_n * F] or nullptr
+    int* cnt;         // [qt_n * nf] or nullptr
     int q0;           // first output query row
     int sentinel;     // padding convention of the output lists
+    long long row_offset;   // added to the local rows of the lists (0: the lists hold unique-row numbers)
 };
 enum { S1_F32 = 0, S1_BF16 = 1, S1_F16 = 2 };
 static int launch_s1(int kind, bool sample, unsigned grid, hipStream_t st, const S1Params& p) {
@@ -438,6 +535,7 @@ static int launch_s1(int kind, bool sample, unsigned grid, hipStream_t st, const
     return MFAR_OK;
 }
 
+//   geom       geometry (rows / bases per field) of `slab`; f0, nf: the pass covers fields [f0, f0 + nf) (all, or one)
 //   tau0       strict starting threshold (0 = zero sentinel of index.py:192-193, -inf = none)
 //   tau_base   [F, 64] non-strict starting thresholds or nullptr (screened pass)
 //   only_failed  [F] device flags or nullptr: restrict the pass to flagged fields (screen fall-back)
@@ -445,35 +543,33 @@ static int launch_s1(int kind, bool sample, unsigned grid, hipStream_t st, const
 //   phases     S1_PREPARE (sample pass + thresholds) | S1_SCAN (the full pass) | S1_FINISH (list merge); the three may be
 //              issued by separate calls on different streams (ordered by the caller), all with the same arguments
 enum { S1_PREPARE = 1, S1_SCAN = 2, S1_FINISH = 4, S1_CERTIFY = 8, S1_ALL = 15 };   // S1_CERTIFY: stage1_block only
-static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, int phases, int kind, const void* slab, const void* qt, int qt_n,
-                       int k, float tau0, const float* tau_base, const int* only_failed, bool record, const S1Out& o,
-                       hipStream_t st) {
-    const int n_chunks = stage1_chunks(idx, k);
-    const int n_tiles = (int)(idx->n_blk / 4);
-    RETCHK(sl.lists.ensure((size_t)idx->F * n_chunks * 64 * S1_CAP * sizeof(uint2)));
-    RETCHK(sl.list_cnt.ensure((size_t)idx->F * n_chunks * 64 * sizeof(int)));
+static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, int f0, int nf, int phases, int kind, const void* slab,
+                       const void* qt, int qt_n, int k, float tau0, const float* tau_base, const int* only_failed, bool record,
+                       const S1Out& o, hipStream_t st) {
+    const bool solo = nf != idx->F;
+    S1Table& tb = solo ? geom.solo : geom.all;
+    static const int sample_tiles_env = getenv("MFAR_SAMPLE_TILES") ? atoi(getenv("MFAR_SAMPLE_TILES")) : 0;
+    RETCHK(build_table(idx, geom, tb, k, solo, sample_tiles_env > 0 ? sample_tiles_env : (kind == S1_F32 ? 1 : 2), st));
+    const int c_lo = tb.fchunk[f0], c_hi = tb.fchunk[f0 + nf];
+    RETCHK(sl.lists.ensure((size_t)tb.n_chunks * 64 * S1_CAP * sizeof(uint2)));
+    RETCHK(sl.list_cnt.ensure((size_t)tb.n_chunks * 64 * sizeof(int)));
     RETCHK(sl.gtau.ensure((size_t)idx->F * 64 * sizeof(float)));
     S1Params p = {};
     p.slab = slab;
     p.qt = qt;
     p.lists = sl.lists.as<uint2>();
     p.list_cnt = sl.list_cnt.as<int>();
-    p.field_stride = idx->field_stride;
-    p.n_rows = (int)idx->n_rows;
+    p.chunks = tb.d_chunks.as<S1Chunk>();
+    p.chunk0 = c_lo;
     p.n_steps = idx->n_steps;
-    p.n_tiles = n_tiles;
-    p.n_chunks = n_chunks;
     p.Q = qt_n;
     p.k = k;
     p.tau0 = tau0;
     p.gtau = tau_base;
     p.sample = 0;
     p.samp_out = nullptr;
+    p.samp_stride = tb.samp_stride;
     p.only_failed = only_failed;
-    if (kind == S1_F16) {   // the screened pass skips the masked members of the fields' duplicate groups
-        p.dup_mask = idx->s_dupmask.as<u32>();
-        p.dup_words = idx->n_blk * 2;
-    }
     {
         const char* dbg = getenv("MFAR_S1_DEBUG");
         p.dbg = dbg ? atoi(dbg) : 0;
@@ -481,18 +577,20 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, int phases, int 
     MergeParams m = {};
     m.lists = p.lists;
     m.list_cnt = p.list_cnt;
-    m.row_offset = idx->row_offset;
-    m.n_chunks = n_chunks;
-    m.F = idx->F;
+    m.fchunk = tb.d_fchunk.as<int>();
+    m.row_offset = o.row_offset;
+    m.f0 = f0;
+    m.nf = nf;
+    m.max_chunks = tb.max_chunks;
     m.k = k;
     m.q0 = o.q0;
     m.sentinel = o.sentinel;
     m.cnt_out = nullptr;
     m.only_failed = only_failed;
-    const int n_keys = n_chunks * k;
+    const int n_keys = tb.max_chunks * k;
     auto launch_merge = [&](const MergeParams& mp) -> int {
-        const dim3 grid(qt_n * idx->F), block(256);
-        if (k <= SEL_MAX_K && n_chunks <= 128 && n_keys <= 48 * 256) {   // keys stay in registers: no LDS staging
+        const dim3 grid(qt_n * nf), block(256);
+        if (k <= SEL_MAX_K && tb.max_chunks <= 128 && n_keys <= 48 * 256) {   // keys stay in registers: no LDS staging
             if (n_keys <= 8 * 256) mfar_merge_lists_regs_kernel<8><<<grid, block, 0, st>>>(mp);
             else if (n_keys <= 16 * 256) mfar_merge_lists_regs_kernel<16><<<grid, block, 0, st>>>(mp);
             else if (n_keys <= 32 * 256) mfar_merge_lists_regs_kernel<32><<<grid, block, 0, st>>>(mp);
@@ -507,35 +605,28 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, int phases, int 
         HIPCHK(hipGetLastError());
         return MFAR_OK;
     };
-    const unsigned grid = (unsigned)(idx->F * n_chunks);
-    // Sample pass: every workgroup scans only the first tile of its chunk; the k-th best score of that sample is
-    // a valid (non-strict) lower bound of the final k-th best, so the full pass starts with a tight threshold and
-    // appends / compacts almost nothing.  Worth it once a chunk is much longer than one tile.
+    const unsigned grid = (unsigned)(c_hi - c_lo);
+    if (grid == 0) return fail(MFAR_ERR_INVALID, "empty chunk range");
+    // Sample pass: every workgroup scans only the first tile(s) of its chunk; the k-th best score of that sample is a valid
+    // (non-strict) lower bound of the final k-th best, so the full pass starts with a tight threshold and appends /
+    // compacts almost nothing.  Worth it once the chunks are much longer than one tile.
     static const int sample_min_tiles = getenv("MFAR_SAMPLE_MIN_TILES") ? atoi(getenv("MFAR_SAMPLE_MIN_TILES")) : 3;
-    const bool use_sample = n_tiles >= sample_min_tiles * n_chunks && !(p.dbg & 2) && !only_failed;
-    // tiles per workgroup in the sample pass: more tiles = tighter starting thresholds = fewer appends in the full pass,
-    // at the price of reading those tiles twice; at most 1/12 of a chunk and 2048 published values per (query, field)
-    // (measured: 2 tiles pay off for the HBM-bound 16-bit passes, 1 for the MFMA-bound fp32 pass)
-    static const int sample_tiles_env = getenv("MFAR_SAMPLE_TILES") ? atoi(getenv("MFAR_SAMPLE_TILES")) : 0;
-    const int sample_tiles_max = sample_tiles_env > 0 ? sample_tiles_env : (kind == S1_F32 ? 1 : 2);
-    static const int sample_div = getenv("MFAR_SAMPLE_DIV") ? atoi(getenv("MFAR_SAMPLE_DIV")) : 12;
-    int sample_tiles = std::max(1, std::min(sample_tiles_max, n_tiles / n_chunks / sample_div));
-    while (sample_tiles > 1 && 8 * n_chunks * sample_tiles > 2048) --sample_tiles;
-    const int n_wave_blocks = 4 * n_chunks * sample_tiles;
-    const bool light_sample = use_sample && 2 * n_wave_blocks >= 2 * k && 2 * n_wave_blocks <= 2048;
-    p.sample_tiles = light_sample ? sample_tiles : 1;
+    const bool use_sample = tb.total_tiles >= (long long)sample_min_tiles * tb.n_chunks && !(p.dbg & 2) && !only_failed;
+    const bool light_sample = use_sample && 2 * tb.samp_stride <= 2048;
+    p.sample_tiles = light_sample ? tb.sample_tiles : 1;
     if (light_sample) {
         // every wave publishes the 2 best scores per query of its 64 sampled rows; tau = k-th largest of those
         if (phases & S1_PREPARE) {
             S1Params ps = p;
             ps.sample = 2;
-            RETCHK(sl.samp.ensure((size_t)idx->F * n_wave_blocks * 128 * sizeof(float)));
+            RETCHK(sl.samp.ensure((size_t)idx->F * tb.samp_stride * 128 * sizeof(float)));
             ps.samp_out = sl.samp.as<float>();
             RETCHK(launch_s1(kind, true, grid, st, ps));
-            const dim3 tg((64 * idx->F + 3) / 4), tb(256);
-            if (2 * n_wave_blocks <= 512) mfar_sample_tau_kernel<8><<<tg, tb, 0, st>>>(ps.samp_out, n_wave_blocks, idx->F, k, p.tau0, tau_base, sl.gtau.as<float>());
-            else if (2 * n_wave_blocks <= 1024) mfar_sample_tau_kernel<16><<<tg, tb, 0, st>>>(ps.samp_out, n_wave_blocks, idx->F, k, p.tau0, tau_base, sl.gtau.as<float>());
-            else mfar_sample_tau_kernel<32><<<tg, tb, 0, st>>>(ps.samp_out, n_wave_blocks, idx->F, k, p.tau0, tau_base, sl.gtau.as<float>());
+            const dim3 tg((64 * nf + 3) / 4), tb_(256);
+            const int* sn = tb.d_samp_n.as<int>();
+            if (2 * tb.samp_stride <= 512) mfar_sample_tau_kernel<8><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>());
+            else if (2 * tb.samp_stride <= 1024) mfar_sample_tau_kernel<16><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>());
+            else mfar_sample_tau_kernel<32><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>());
             HIPCHK(hipGetLastError());
         }
         p.gtau = sl.gtau.as<float>();
@@ -590,67 +681,159 @@ static bool screen_wanted(const mfar_index* idx, int k) {
     return idx->screen_mode >= 2 || idx->n_rows >= 16384;
 }
 
-// (re)build the screen slab from the fp32 slab when rows changed; false = not available (allocation failed)
+__global__ void mfar_iota_kernel(int* __restrict__ a, int* __restrict__ b, int* __restrict__ c, int* __restrict__ d, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        a[i] = (int)i;   // urep
+        b[i] = (int)i;   // ustart
+        c[i] = 1;        // ucount
+        d[i] = (int)i;   // members
+    }
+}
+
+// Unique rows of one field -> idx->u_* tables of that field; returns the number of unique rows and the largest group.
+static int build_unique_rows(mfar_index* idx, int f, DevBuf* tmp, hipStream_t st, int* n_unique_out, int* largest_out) {
+    const long long n = idx->n_rows;
+    const float* field = (const float*)idx->slab + (size_t)f * idx->field_stride;
+    int* urep = idx->u_rep.as<int>() + (size_t)f * n;
+    int* ustart = idx->u_start.as<int>() + (size_t)f * n;
+    int* ucount = idx->u_count.as<int>() + (size_t)f * n;
+    int* members = idx->u_members.as<int>() + (size_t)f * n;
+    if (!idx->screen_dedup || n < 2) {
+        if (n > 0) {
+            mfar_iota_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(urep, ustart, ucount, members, n);
+            HIPCHK(hipGetLastError());
+        }
+        *n_unique_out = (int)n;
+        *largest_out = n > 0 ? 1 : 0;
+        return MFAR_OK;
+    }
+    // tmp: 0 keys in, 1 keys out, 2 vals in, 3 head, 4 gid, 5 is_rep, 6 urank, 7 gstart, 8 cub scratch
+    RETCHK(tmp[0].ensure(n * 8));
+    RETCHK(tmp[1].ensure(n * 8));
+    for (int i = 2; i <= 7; ++i) RETCHK(tmp[i].ensure(n * 4));
+    u64* k_in = tmp[0].as<u64>();
+    u64* k_out = tmp[1].as<u64>();
+    u32* v_in = tmp[2].as<u32>();
+    u32* v_out = (u32*)members;      // the sorted row numbers ARE the member table
+    u32 *head = tmp[3].as<u32>(), *gid = tmp[4].as<u32>(), *is_rep = tmp[5].as<u32>(), *urank = tmp[6].as<u32>();
+    int* gstart = tmp[7].as<int>();
+    mfar_row_hash_kernel<<<dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st>>>(field, idx->n_steps, n, k_in, v_in);
+    HIPCHK(hipGetLastError());
+    size_t need = 0, need2 = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k_in, k_out, v_in, v_out, (int)n, 0, 64, st));
+    HIPCHK(hipcub::DeviceScan::InclusiveSum(nullptr, need2, head, gid, (int)n, st));
+    RETCHK(tmp[8].ensure(std::max(need, need2) + 256));
+    size_t cap = tmp[8].cap;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(tmp[8].p, cap, k_in, k_out, v_in, v_out, (int)n, 0, 64, st));   // stable: rows ascend inside a hash
+    mfar_group_heads_kernel<<<dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, st>>>(field, idx->n_steps, n, k_out, v_out, head);
+    HIPCHK(hipGetLastError());
+    cap = tmp[8].cap;
+    HIPCHK(hipcub::DeviceScan::InclusiveSum(tmp[8].p, cap, head, gid, (int)n, st));
+    HIPCHK(hipMemsetAsync(is_rep, 0, n * 4, st));
+    mfar_group_starts_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n, head, gid, v_out, gstart, is_rep);
+    HIPCHK(hipGetLastError());
+    cap = tmp[8].cap;
+    HIPCHK(hipcub::DeviceScan::InclusiveSum(tmp[8].p, cap, is_rep, urank, (int)n, st));
+    u32 n_groups = 0;
+    HIPCHK(hipMemcpyAsync(&n_groups, gid + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    mfar_unique_table_kernel<<<dim3((n_groups + 255) / 256), dim3(256), 0, st>>>(n, (int)n_groups, gstart, v_out, urank, urep, ustart, ucount);
+    HIPCHK(hipGetLastError());
+    // largest group (statistics only)
+    cap = tmp[8].cap;
+    int* d_max = (int*)tmp[3].p;
+    HIPCHK(hipcub::DeviceReduce::Max(nullptr, need, ucount, d_max, (int)n_groups, st));
+    RETCHK(tmp[8].ensure(need + 256));
+    cap = tmp[8].cap;
+    HIPCHK(hipcub::DeviceReduce::Max(tmp[8].p, cap, ucount, d_max, (int)n_groups, st));
+    int largest = 0;
+    HIPCHK(hipMemcpyAsync(&largest, d_max, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *n_unique_out = (int)n_groups;
+    *largest_out = largest;
+    return MFAR_OK;
+}
+
+// (re)build the screen from the fp32 slab when rows changed: per-field statistics, the unique rows of every field, the fp16
+// slab of those rows.  *ok = false: not available (allocation failed) -> the caller stays on the exact pass.
 static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
     *ok = false;
-    if (!idx->screen) {
-        hipError_t e = hipMalloc(&idx->screen, (size_t)idx->field_stride * 2 * idx->F);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            idx->screen = nullptr;
-            idx->screen_nomem = true;
-            return MFAR_OK;
-        }
-        idx->screen_dirty = true;
+    if (!idx->screen_dirty && idx->screen.p) {
+        *ok = true;
+        return MFAR_OK;
     }
-    if (idx->screen_dirty) {
-        RETCHK(idx->s_stats.ensure((size_t)idx->F * 2 * sizeof(u32)));
-        RETCHK(idx->s_field.ensure((size_t)idx->F * sizeof(ScreenField)));
-        RETCHK(idx->s_mean.ensure((size_t)idx->F * idx->E * sizeof(float)));
-        HIPCHK(hipMemsetAsync(idx->s_stats.p, 0, (size_t)idx->F * 2 * sizeof(u32), st));
-        HIPCHK(hipMemsetAsync(idx->s_mean.p, 0, (size_t)idx->F * idx->E * sizeof(float), st));
-        mfar_screen_mean_kernel<<<dim3((unsigned)((idx->n_blk + 7) / 8), idx->F), dim3(256), 0, st>>>(
-            (const float*)idx->slab, idx->field_stride, idx->n_steps, idx->n_blk, idx->n_rows, idx->s_mean.as<float>());
-        HIPCHK(hipGetLastError());
-        mfar_screen_mean_finish_kernel<<<dim3((idx->F * idx->E + 255) / 256), dim3(256), 0, st>>>(idx->s_mean.as<float>(), idx->F * idx->E,
-                                                                                                idx->n_rows);
-        HIPCHK(hipGetLastError());
-        mfar_screen_stats_kernel<<<dim3((unsigned)idx->n_blk, idx->F), dim3(256), 0, st>>>(
-            (const float*)idx->slab, idx->field_stride, idx->n_steps, idx->n_rows, idx->s_mean.as<float>(), idx->s_stats.as<u32>());
-        HIPCHK(hipGetLastError());
-        mfar_screen_scale_kernel<<<dim3(1), dim3(64), 0, st>>>(idx->s_stats.as<u32>(), idx->s_mean.as<float>(), idx->F, idx->E,
-                                                             idx->s_field.as<ScreenField>());
-        HIPCHK(hipGetLastError());
-        const long long n_gran = (long long)idx->n_blk * idx->n_steps * 128;
-        mfar_screen_build_kernel<<<dim3((unsigned)((n_gran + 255) / 256), idx->F), dim3(256), 0, st>>>(
-            (const float*)idx->slab, (_Float16*)idx->screen, idx->field_stride, n_gran, idx->n_steps, idx->s_mean.as<float>(),
-            idx->s_field.as<ScreenField>());
-        HIPCHK(hipGetLastError());
-        // duplicate groups (mfar_screen.h): always computed, so the bitmap and the group table are defined
-        const long long dw = idx->n_blk * 2;
-        RETCHK(idx->s_dupmask.ensure((size_t)idx->F * dw * sizeof(u32)));
-        RETCHK(idx->s_dupgrp.ensure((size_t)idx->F * sizeof(DupGroup)));
-        HIPCHK(hipMemsetAsync(idx->s_dupmask.p, 0, (size_t)idx->F * dw * sizeof(u32), st));
-        mfar_dup_sample_kernel<<<dim3(idx->F), dim3(256), DUP_SAMPLES * 8, st>>>((const float*)idx->slab, idx->field_stride, idx->n_steps,
-                                                                                   idx->screen_dedup ? idx->n_rows : 0,
-                                                                                   idx->s_dupgrp.as<DupGroup>());
-        HIPCHK(hipGetLastError());
-        mfar_dup_compare_kernel<<<dim3((unsigned)idx->n_blk, idx->F), dim3(256), 0, st>>>(
-            (const float*)idx->slab, idx->field_stride, idx->n_steps, idx->n_rows, idx->s_dupgrp.as<DupGroup>(), idx->s_dupmask.as<u32>(), dw);
-        HIPCHK(hipGetLastError());
-        mfar_dup_finish_kernel<<<dim3(idx->F), dim3(64), 0, st>>>(idx->s_dupgrp.as<DupGroup>(), idx->s_dupmask.as<u32>(), dw);
-        HIPCHK(hipGetLastError());
-        idx->screen_dirty = false;
+    HIPCHK(hipDeviceSynchronize());   // a rebuild replaces tables that launches in flight may still read
+    const int F = idx->F;
+    const long long n = idx->n_rows;
+    auto nomem = [&]() {
+        (void)hipGetLastError();
+        g_err.clear();
+        idx->screen_nomem = true;
+        return MFAR_OK;
+    };
+    if (idx->u_rep.ensure((size_t)F * n * 4) != MFAR_OK || idx->u_start.ensure((size_t)F * n * 4) != MFAR_OK ||
+        idx->u_count.ensure((size_t)F * n * 4) != MFAR_OK || idx->u_members.ensure((size_t)F * n * 4) != MFAR_OK ||
+        idx->u_n.ensure((size_t)F * 4) != MFAR_OK)
+        return nomem();
+    RETCHK(idx->s_stats.ensure((size_t)F * 2 * sizeof(u32)));
+    RETCHK(idx->s_field.ensure((size_t)F * sizeof(ScreenField)));
+    RETCHK(idx->s_mean.ensure((size_t)F * idx->E * sizeof(float)));
+    HIPCHK(hipMemsetAsync(idx->s_stats.p, 0, (size_t)F * 2 * sizeof(u32), st));
+    HIPCHK(hipMemsetAsync(idx->s_mean.p, 0, (size_t)F * idx->E * sizeof(float), st));
+    mfar_screen_mean_kernel<<<dim3((unsigned)((idx->n_blk + 7) / 8), F), dim3(256), 0, st>>>(
+        (const float*)idx->slab, idx->field_stride, idx->n_steps, idx->n_blk, idx->n_rows, idx->s_mean.as<float>());
+    HIPCHK(hipGetLastError());
+    mfar_screen_mean_finish_kernel<<<dim3((F * idx->E + 255) / 256), dim3(256), 0, st>>>(idx->s_mean.as<float>(), F * idx->E, idx->n_rows);
+    HIPCHK(hipGetLastError());
+    mfar_screen_stats_kernel<<<dim3((unsigned)idx->n_blk, F), dim3(256), 0, st>>>(
+        (const float*)idx->slab, idx->field_stride, idx->n_steps, idx->n_rows, idx->s_mean.as<float>(), idx->s_stats.as<u32>());
+    HIPCHK(hipGetLastError());
+    mfar_screen_scale_kernel<<<dim3(1), dim3(64), 0, st>>>(idx->s_stats.as<u32>(), idx->s_mean.as<float>(), F, idx->E,
+                                                         idx->s_field.as<ScreenField>());
+    HIPCHK(hipGetLastError());
+    // unique rows, field by field (scratch shared)
+    DevBuf tmp[9];
+    int rc = MFAR_OK;
+    for (int f = 0; f < F && rc == MFAR_OK; ++f) rc = build_unique_rows(idx, f, tmp, st, &idx->n_unique[f], &idx->largest_group[f]);
+    HIPCHK(hipStreamSynchronize(st));
+    for (auto& b : tmp) b.release();
+    if (rc == MFAR_ERR_NOMEM) return nomem();
+    RETCHK(rc);
+    HIPCHK(hipMemcpyAsync(idx->u_n.p, idx->n_unique.data(), (size_t)F * 4, hipMemcpyHostToDevice, st));
+    // geometry of the screen slab: every field holds its unique rows, padded to whole 256-row tiles
+    S1Geom& g = idx->geom_screen;
+    g.reset(F);
+    long long total = 0;
+    for (int f = 0; f < F; ++f) {
+        long long blk = ((long long)idx->n_unique[f] + 63) / 64;
+        blk = std::max(4LL, ((blk + 3) / 4) * 4);
+        g.n_rows[f] = idx->n_unique[f];
+        g.base[f] = total;
+        g.n_tiles[f] = (int)(blk / 4);
+        total += blk * 64 * idx->E;
     }
+    if (idx->screen.ensure((size_t)total * 2) != MFAR_OK) return nomem();
+    idx->screen_used = (size_t)total * 2;
+    for (int f = 0; f < F; ++f) {
+        const long long n_gran = (long long)g.n_tiles[f] * 4 * idx->n_steps * 128;
+        mfar_screen_build_kernel<<<dim3((unsigned)((n_gran + 255) / 256)), dim3(256), 0, st>>>(
+            (const float*)idx->slab + (size_t)f * idx->field_stride, (_Float16*)idx->screen.p + g.base[f], n_gran, idx->n_steps,
+            idx->n_unique[f], idx->u_rep.as<int>() + (size_t)f * n, idx->s_mean.as<float>() + (size_t)f * idx->E,
+            idx->s_field.as<ScreenField>() + f);
+        HIPCHK(hipGetLastError());
+    }
+    idx->screen_dirty = false;
     *ok = true;
     return MFAR_OK;
 }
 
-// One block of <= 64 queries (rows q0 .. of q) through stage 1.  all pointers are device pointers; fid/fsc are [Q, F, k].
+// One block of <= 64 queries (rows q0 .. of q) through stage 1 for fields [f0, f0 + nf).  all pointers are device pointers;
+// fid/fsc are [Q, nf, k].
 //   any_fail_out  nullptr: a failed certificate is repaired here by the exact pass (always launched, idle when nothing
 //                 failed); non-null (device int): only report -- the caller re-runs the batch exactly when it reads != 0
-static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, int Q, int q0, int k, int sentinel, long long* fid,
-                        float* fsc, int* any_fail_out, hipStream_t st) {
+static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, int Q, int q0, int k, int sentinel, int f0, int nf,
+                        long long* fid, float* fsc, int* any_fail_out, hipStream_t st) {
     mfar_index::S1Slot& sl = idx->s1[slot];
     const float tau0 = sentinel ? 0.0f : -INFINITY;
     const int F = idx->F, kp = std::min(k + SCREEN_EXTRA, SCREEN_MAX_KP);
@@ -673,8 +856,9 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
             }
             HIPCHK(hipGetLastError());
         }
-        const S1Out o = {fid, fsc, nullptr, q0, sentinel};
-        RETCHK(stage1_pass(idx, sl, phases, bf16 ? S1_BF16 : S1_F32, idx->slab, sl.qt.p, qt_n, k, tau0, nullptr, nullptr, true, o, st));
+        const S1Out o = {fid, fsc, nullptr, q0, sentinel, idx->row_offset};
+        RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, phases, bf16 ? S1_BF16 : S1_F32, idx->slab, sl.qt.p, qt_n, k, tau0, nullptr,
+                           nullptr, true, o, st));
         if ((phases & S1_CERTIFY) && any_fail_out) HIPCHK(hipMemsetAsync(any_fail_out, 0, 4, st));
         return MFAR_OK;
     }
@@ -691,17 +875,18 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     RETCHK(sl.sx.ensure((size_t)64 * F * kp * 4));
     RETCHK(sl.scnt.ensure((size_t)64 * F * 4));
     int* fflags = sl.fail.as<int>();
-    // 1. screened pass on the fp16 slab: the k' best approximate scores per (query, field)
+    // 1. screened pass on the fp16 slab of unique rows: the k' best approximate scores per (query, field)
     if (phases & S1_PREPARE) {
         mfar_screen_queries_kernel<<<dim3(64), dim3(256), 0, st>>>(q, (_Float16*)sl.qt16.p, sl.qinfo.as<ScreenQuery>(),
                                                                    idx->s_field.as<ScreenField>(), sl.eps.as<float>(), sl.base.as<float>(),
                                                                    fflags, q0, Q, idx->E, F, idx->screen_eps_mult);
         HIPCHK(hipGetLastError());
     }
-    const S1Out so = {sl.sids.as<long long>(), sl.ssc.as<float>(), sl.scnt.as<int>(), 0, 0};
-    RETCHK(stage1_pass(idx, sl, phases, S1_F16, idx->screen, sl.qt16.p, qt_n, kp, -INFINITY, sl.base.as<float>(), nullptr, true, so, st));
+    const S1Out so = {sl.sids.as<long long>(), sl.ssc.as<float>(), sl.scnt.as<int>(), 0, 0, 0};   // lists of unique-row numbers
+    RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, phases, S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY, sl.base.as<float>(),
+                       nullptr, true, so, st));
     if (!(phases & S1_CERTIFY)) return MFAR_OK;
-    // 2. exact scores of those rows (the contract's fma chain over the fp32 slab)
+    // 2. exact scores of those unique rows' representatives (the contract's fma chain over the fp32 slab)
     ScoreParams sp = {};
     sp.slab = idx->slab;
     sp.field_stride = idx->field_stride;
@@ -713,12 +898,16 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     sp.n_rows = (int)idx->n_rows;
     sp.n_steps = idx->n_steps;
     sp.E = idx->E;
-    sp.F = F;
+    sp.F = nf;
     sp.C = kp;
     sp.per_field = 1;
-    mfar_score_rows_f32_kernel<<<dim3((unsigned)((kp * F + SCF_THREADS - 1) / SCF_THREADS), qt_n), dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(sp);
+    sp.urep = idx->u_rep.as<int>();
+    sp.nuniq = idx->u_n.as<int>();
+    sp.ustride = idx->n_rows;
+    sp.f0 = f0;
+    mfar_score_rows_f32_kernel<<<dim3((unsigned)((kp * nf + SCF_THREADS - 1) / SCF_THREADS), qt_n), dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(sp);
     HIPCHK(hipGetLastError());
-    // 3. exact top-k + certificate
+    // 3. exact top-k documents + certificate
     CertifyParams cp = {};
     cp.sid = sl.sids.as<long long>();
     cp.ssc = sl.ssc.as<float>();
@@ -733,33 +922,54 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     cp.out_ids = fid;
     cp.out_scores = fsc;
     cp.fail = fflags;
-    cp.grp = idx->s_dupgrp.as<DupGroup>();
+    cp.ustart = idx->u_start.as<int>();
+    cp.ucount = idx->u_count.as<int>();
+    cp.members = idx->u_members.as<int>();
+    cp.ustride = idx->n_rows;
     cp.row_offset = idx->row_offset;
-    cp.F = F;
+    cp.f0 = f0;
+    cp.nf = nf;
     cp.k = k;
     cp.kp = kp;
     cp.q0 = q0;
     cp.sentinel = sentinel;
-    mfar_screen_certify_kernel<<<dim3(qt_n * F), dim3(256), 0, st>>>(cp);
+    static const bool cert_debug = getenv("MFAR_CERT_DEBUG") != nullptr;
+    DevBuf dbg;
+    if (cert_debug) {
+        RETCHK(dbg.ensure((size_t)qt_n * nf * 8 * 4));
+        cp.dbg = dbg.as<float>();
+    }
+    mfar_screen_certify_kernel<<<dim3(qt_n * nf), dim3(256), 0, st>>>(cp);
     HIPCHK(hipGetLastError());
-    idx->screen_checked += (long long)qt_n * F;
+    if (cert_debug) {   // diagnostics: failed certificates with their numbers (synchronises)
+        std::vector<float> h((size_t)qt_n * nf * 8);
+        HIPCHK(hipMemcpyAsync(h.data(), dbg.p, h.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int i = 0; i < qt_n * nf; ++i)
+            if (h[8 * i] == 0.0f)
+                fprintf(stderr, "[mfar cert] q=%d f=%d bound=%.7g T_k=%.7g a_real=%.7g eps=%.4g cnt=%g m_out=%g (ovf + 10 n + 1e4 total)=%g\n", q0 + i / nf,
+                        f0 + i % nf, h[8 * i + 1], h[8 * i + 2], h[8 * i + 3], h[8 * i + 4], h[8 * i + 5], h[8 * i + 6], h[8 * i + 7]);
+        dbg.release();
+    }
+    idx->screen_checked += (long long)qt_n * nf;
     if (any_fail_out) {   // report only: the caller repairs
-        HIPCHK(hipMemcpyAsync(any_fail_out, fflags + F, 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(any_fail_out, fflags + MFAR_MAX_FIELDS, 4, hipMemcpyDeviceToDevice, st));
         return MFAR_OK;
     }
-    // 4. fall-back: the exact fp32 pass for fields whose certificate failed (workgroups of other fields exit at once)
+    // 4. fall-back: the exact fp32 pass over the DOCUMENTS of the fields whose certificate failed (workgroups of other
+    //    fields exit at once)
     {
         const int total = 64 * (idx->E / 4);
         mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, sl.qt.as<float>(), q0, Q, idx->E);
         HIPCHK(hipGetLastError());
-        const S1Out o = {fid, fsc, nullptr, q0, sentinel};
-        RETCHK(stage1_pass(idx, sl, S1_ALL, S1_F32, idx->slab, sl.qt.p, qt_n, k, tau0, nullptr, fflags, false, o, st));
+        const S1Out o = {fid, fsc, nullptr, q0, sentinel, idx->row_offset};
+        RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, S1_ALL, S1_F32, idx->slab, sl.qt.p, qt_n, k, tau0, nullptr, fflags, false, o, st));
     }
     return MFAR_OK;
 }
 
 static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentinel, long long* fid, float* fsc, hipStream_t st) {
-    for (int q0 = 0; q0 < Q; q0 += 64) RETCHK(stage1_block(idx, 0, S1_ALL, q, Q, q0, k, sentinel, fid, fsc, nullptr, st));
+    for (int q0 = 0; q0 < Q; q0 += 64) RETCHK(stage1_block(idx, 0, S1_ALL, q, Q, q0, k, sentinel, 0, idx->F, fid, fsc, nullptr, st));
     return MFAR_OK;
 }
 
@@ -775,8 +985,8 @@ extern "C" int mfar_stage1_begin(mfar_index* idx, const float* q, int Q, int k, 
     if (Q == 0) return MFAR_OK;
     HIPCHK(hipSetDevice(idx->device));
     if (!field_ids || !field_scores) return fail(MFAR_ERR_INVALID, "output pointer is NULL");
-    return stage1_block(idx, slot, S1_PREPARE | S1_SCAN | S1_FINISH, q, Q, 0, k, sentinel, (long long*)field_ids, field_scores, nullptr,
-                        (hipStream_t)stream);
+    return stage1_block(idx, slot, S1_PREPARE | S1_SCAN | S1_FINISH, q, Q, 0, k, sentinel, 0, idx->F, (long long*)field_ids, field_scores,
+                        nullptr, (hipStream_t)stream);
 }
 extern "C" int mfar_stage1_finish(mfar_index* idx, const float* q, int Q, int k, int sentinel, int slot, int64_t* field_ids,
                                   float* field_scores, int32_t* any_fail, void* stream) {
@@ -784,7 +994,7 @@ extern "C" int mfar_stage1_finish(mfar_index* idx, const float* q, int Q, int k,
     if (Q == 0) return MFAR_OK;
     if (!field_ids || !field_scores) return fail(MFAR_ERR_INVALID, "output pointer is NULL");
     HIPCHK(hipSetDevice(idx->device));
-    return stage1_block(idx, slot, S1_CERTIFY, q, Q, 0, k, sentinel, (long long*)field_ids, field_scores, (int*)any_fail,
+    return stage1_block(idx, slot, S1_CERTIFY, q, Q, 0, k, sentinel, 0, idx->F, (long long*)field_ids, field_scores, (int*)any_fail,
                         (hipStream_t)stream);
 }
 
@@ -802,27 +1012,20 @@ extern "C" int mfar_get_screen(const mfar_index* idx, int* mode, float* eps_mult
     return MFAR_OK;
 }
 
-extern "C" int mfar_screen_dup_group(mfar_index* idx, int field, int64_t* rep_row, int64_t* n_masked) {
+extern "C" int mfar_screen_field_info(mfar_index* idx, int field, int64_t* n_unique_rows, int64_t* largest_group) {
     if (!idx || field < 0 || field >= idx->F) return fail(MFAR_ERR_INVALID, "bad idx / field");
-    HIPCHK(hipSetDevice(idx->device));
-    if (rep_row) *rep_row = -1;
-    if (n_masked) *n_masked = 0;
-    if (!idx->screen || idx->screen_dirty || !idx->s_dupgrp.p) return MFAR_OK;
-    HIPCHK(hipDeviceSynchronize());
-    DupGroup g;
-    HIPCHK(hipMemcpy(&g, idx->s_dupgrp.as<DupGroup>() + field, sizeof(DupGroup), hipMemcpyDeviceToHost));
-    if (g.rep >= 0) {
-        if (rep_row) *rep_row = idx->row_offset + g.rep;
-        if (n_masked) *n_masked = g.n_masked;
-    }
+    const bool built = idx->screen.p && !idx->screen_dirty;
+    if (n_unique_rows) *n_unique_rows = built ? idx->n_unique[field] : -1;
+    if (largest_group) *largest_group = built ? idx->largest_group[field] : -1;
     return MFAR_OK;
 }
 
 extern "C" int mfar_screen_stats(mfar_index* idx, int* built, int64_t* screen_bytes, int64_t* n_checked, int64_t* n_failed) {
     if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
     HIPCHK(hipSetDevice(idx->device));
-    if (built) *built = (idx->screen && !idx->screen_dirty) ? 1 : 0;
-    if (screen_bytes) *screen_bytes = idx->screen ? (int64_t)idx->field_stride * 2 * idx->F : 0;
+    const bool have = idx->screen.p && !idx->screen_dirty;
+    if (built) *built = have ? 1 : 0;
+    if (screen_bytes) *screen_bytes = have ? (int64_t)idx->screen_used : 0;
     if (n_checked) *n_checked = idx->screen_checked;
     if (n_failed) {
         *n_failed = 0;
@@ -830,7 +1033,7 @@ extern "C" int mfar_screen_stats(mfar_index* idx, int* built, int64_t* screen_by
             if (sl.fail.p) {
                 HIPCHK(hipDeviceSynchronize());
                 int v = 0;
-                HIPCHK(hipMemcpy(&v, sl.fail.as<int>() + idx->F + 1, 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(&v, sl.fail.as<int>() + MFAR_MAX_FIELDS + 1, 4, hipMemcpyDeviceToHost));
                 *n_failed += v;
             }
     }
@@ -854,6 +1057,28 @@ extern "C" int mfar_retrieve_fields(mfar_index* idx, const float* q, int Q, int 
     RETCHK(run_stage1(idx, qd, Q, k, sentinel, fid, fsc, st));
     RETCHK(copy_back((long long*)field_ids, fid, nl, on_device, st));
     RETCHK(copy_back(field_scores, fsc, nl, on_device, st));
+    if (!on_device) HIPCHK(hipStreamSynchronize(st));
+    return MFAR_OK;
+}
+
+extern "C" int mfar_retrieve_field(mfar_index* idx, int field, const float* q, int Q, int k, int sentinel, int64_t* ids, float* scores,
+                                   int on_device, void* stream) {
+    RETCHK(check_search_common(idx, q, Q, k));
+    if (field < 0 || field >= idx->F) return fail(MFAR_ERR_INVALID, "field out of range");
+    if (Q == 0) return MFAR_OK;
+    if (!ids || !scores) return fail(MFAR_ERR_INVALID, "output pointer is NULL");
+    HIPCHK(hipSetDevice(idx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nl = (size_t)Q * k;
+    const float* qd;
+    long long* fid;
+    float* fsc;
+    RETCHK(stage_in(idx->in[0], q, (size_t)Q * idx->E, on_device, st, &qd));
+    RETCHK(stage_out(idx->out[0], (long long*)ids, nl, on_device, &fid));
+    RETCHK(stage_out(idx->out[1], scores, nl, on_device, &fsc));
+    for (int q0 = 0; q0 < Q; q0 += 64) RETCHK(stage1_block(idx, 0, S1_ALL, qd, Q, q0, k, sentinel, field, 1, fid, fsc, nullptr, st));
+    RETCHK(copy_back((long long*)ids, fid, nl, on_device, st));
+    RETCHK(copy_back(scores, fsc, nl, on_device, st));
     if (!on_device) HIPCHK(hipStreamSynchronize(st));
     return MFAR_OK;
 }
@@ -1268,7 +1493,7 @@ static ListsLayout lists_layout(int Q, int F, int k1) {
     return L;
 }
 struct TopkLayout {
-    long long ids, scores, ncand, total;
+    long long ids, scores, ncand, flag, total;
 };
 static TopkLayout topk_layout(int Q, int k2) {
     auto up = [](long long v) { return (v + 255) & ~255LL; };
@@ -1276,7 +1501,8 @@ static TopkLayout topk_layout(int Q, int k2) {
     L.ids = 0;
     L.scores = up((long long)Q * k2 * 8);
     L.ncand = up(L.scores + (long long)Q * k2 * 4);
-    L.total = up(L.ncand + (long long)Q * 4);
+    L.flag = L.ncand + (long long)Q * 4;        // one int32: this rank's certificate flag of the batch (travels with the top-k)
+    L.total = up(L.flag + 4);
     return L;
 }
 extern "C" int64_t mfar_lists_bytes(int Q, int n_fields, int k1) {
@@ -1298,8 +1524,8 @@ extern "C" int mfar_retrieve_lists(mfar_index* idx, const float* q, int Q, int k
 }
 
 extern "C" int mfar_search_owned(mfar_index* idx, const void* gathered_lists, int n_shards, const float* q, int Q, const float* W,
-                                 int query_cond, const float* mask, int k1, int k2, int sentinel, int slot, void* topk,
-                                 void* stream) {
+                                 int query_cond, const float* mask, int k1, int k2, int sentinel, int slot, const int32_t* any_fail,
+                                 void* topk, void* stream) {
     RETCHK(check_search_common(idx, q, Q, k1));
     const int F = idx->F, E = idx->E, C = F * k1;
     RETCHK(check_mix(Q, C, F, E, k2, q, W, query_cond));
@@ -1348,11 +1574,13 @@ extern "C" int mfar_search_owned(mfar_index* idx, const void* gathered_lists, in
     RETCHK(run_mix(x, owned, nowned, q, W, query_cond, mask, Q, C, F, E, k2, (long long*)(tb + TL.ids), (float*)(tb + TL.scores),
                    nullptr, st));
     HIPCHK(hipMemcpyAsync(tb + TL.ncand, ncand, (size_t)Q * 4, hipMemcpyDeviceToDevice, st));
+    if (any_fail) HIPCHK(hipMemcpyAsync(tb + TL.flag, any_fail, 4, hipMemcpyDeviceToDevice, st));
+    else HIPCHK(hipMemsetAsync(tb + TL.flag, 0, 4, st));
     return MFAR_OK;
 }
 
 extern "C" int mfar_merge_topk(int device, const void* gathered_topk, int n_shards, int Q, int k2, int64_t* ids, float* scores,
-                               int32_t* n_valid, void* stream) {
+                               int32_t* n_valid, int32_t* any_fail, void* stream) {
     if (!gathered_topk || !ids || !scores || n_shards <= 0 || n_shards > 64) return fail(MFAR_ERR_INVALID, "bad arguments");
     if (k2 <= 0 || k2 > MFAR_MAX_K || Q < 0) return fail(MFAR_ERR_INVALID, "bad k2 / Q");
     if (Q == 0) return MFAR_OK;
@@ -1368,6 +1596,8 @@ extern "C" int mfar_merge_topk(int device, const void* gathered_topk, int n_shar
     p.ids_off = TL.ids;
     p.scores_off = TL.scores;
     p.ncand_off = TL.ncand;
+    p.flag_off = TL.flag;
+    p.any_fail = (int*)any_fail;
     p.ids = (long long*)ids;
     p.scores = scores;
     p.n_valid = (int*)n_valid;

@@ -139,57 +139,56 @@ __global__ void mfar_screen_scale_kernel(const u32* __restrict__ stats, const fl
     sf[f] = o;
 }
 
-// fp32 tiled slab -> fp16 tiled screen slab (centred, scaled).  One thread per 16-byte output granule (8 dims).
-// grid = (ceil(n_blk * n_steps * 128 / 256), F)
-__global__ void __launch_bounds__(256) mfar_screen_build_kernel(const float* __restrict__ slab, _Float16* __restrict__ screen,
-                                                                long long field_stride, long long n_granules, int n_steps,
-                                                                const float* __restrict__ mean, const ScreenField* __restrict__ sf) {
+// fp32 tiled slab -> fp16 tiled screen slab of ONE field (centred, scaled), unique rows only: output row u is the
+// document urep[u].  One thread per 16-byte output granule (8 dims).  grid = ceil(n_blk_u * n_steps * 128 / 256).
+__global__ void __launch_bounds__(256) mfar_screen_build_kernel(const float* __restrict__ field, _Float16* __restrict__ out,
+                                                                long long n_granules, int n_steps, int n_unique,
+                                                                const int* __restrict__ urep, const float* __restrict__ mean,
+                                                                const ScreenField* __restrict__ sf) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_granules) return;
-    const int f = blockIdx.y;
-    const float sc = sf[f].scale;
+    const float sc = sf->scale;
     const long long tile = g >> 7;           // 128 granules per [64][16] fp16 tile = (block, k-step)
     const int rr = (int)(g >> 1) & 63, c8 = (int)g & 1;
     const int step = (int)(tile % n_steps);
     const long long blk = tile / n_steps;
-    // source: row rr's 128-byte line of k-step pair step / 2, half step & 1, dims 8 c8 .. 8 c8 + 7 of the step
-    const float* src = slab + (size_t)f * field_stride + (size_t)(blk * (n_steps >> 1) + (step >> 1)) * 2048 + rr * 32 + (step & 1) * 16 + c8 * 8;
-    const float* m = mean + (size_t)f * n_steps * 16 + step * 16 + c8 * 8;
-    const f32x4 a = *(const f32x4*)src - *(const f32x4*)m;
-    const f32x4 b = *(const f32x4*)(src + 4) - *(const f32x4*)(m + 4);
+    const long long u = blk * 64 + rr;
     f16x8 o;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        o[i] = (_Float16)(a[i] * sc);
-        o[4 + i] = (_Float16)(b[i] * sc);
+    for (int i = 0; i < 8; ++i) o[i] = (_Float16)0.0f;
+    if (u < n_unique) {
+        const float* src = field + tiled_offset(n_steps, urep[u], step * 16 + c8 * 8);
+        const float* m = mean + step * 16 + c8 * 8;
+        const f32x4 a = *(const f32x4*)src - *(const f32x4*)m;
+        const f32x4 b = *(const f32x4*)(src + 4) - *(const f32x4*)(m + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i] = (_Float16)(a[i] * sc);
+            o[4 + i] = (_Float16)(b[i] * sc);
+        }
     }
-    *(f16x8*)(screen + (size_t)f * field_stride + (size_t)tile * 1024 + rr * 16 + ((c8 ^ ((rr >> 3) & 1)) << 3)) = o;
+    *(f16x8*)(out + (size_t)tile * 1024 + rr * 16 + ((c8 ^ ((rr >> 3) & 1)) << 3)) = o;
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Duplicate rows.  A field that a document lacks is encoded from the empty string (format.py:58-59), so real corpora hold
-// one huge group of IDENTICAL rows per field.  When that group reaches the top of a list, equal approximate scores cannot
-// separate the k-th from the k'-th entry and every certificate of the field would fail.  The screen therefore finds the
-// field's largest group of bit-identical rows at build time, scans only its lowest-id member (the others are masked out of
-// the screened pass by a row bitmap) and re-inserts the masked members -- same exact score, ids ascending -- when the
-// representative makes it into the exact top-k (mfar_screen_certify_kernel).  Masked rows can never be missed: they score
-// exactly what their representative scores and lose every tie against it.
-//   1. mfar_dup_sample_kernel   hashes DUP_SAMPLES pseudo-random rows of the field; the most frequent hash names a candidate row
-//   2. mfar_dup_compare_kernel  compares EVERY row with the candidate bit for bit -> bitmap of equal rows, their count, the lowest id
-//   3. mfar_dup_finish_kernel   drops groups below DUP_MIN_GROUP, clears the representative's bit, lists the DUP_MEMBERS lowest masked ids
+// Unique rows.  Real fields are full of bit-identical rows: a field a document lacks is encoded from the empty string
+// (format.py:58-59), low-cardinality fields (STaRK-prime `type` / `source`, amazon `brand`; schema.py:11-53) repeat a handful
+// of texts over the whole corpus, and the host encodes every distinct text once, so repeated texts ARE bit-identical rows.
+// Equal rows get equal approximate scores: a list full of them cannot separate its k-th from its k'-th entry, and every
+// certificate of such a field would fail.  The screen therefore scans each DISTINCT vector of a field once:
+//
+//   build   hash every row (mfar_row_hash_kernel) -> stable radix sort of (hash, row) -> a row starts a new group when its
+//           hash or -- compared bit for bit -- its vector differs from its predecessor's (mfar_group_heads_kernel; a hash
+//           collision merely splits a group, which costs a little bandwidth and never correctness) -> groups are numbered in
+//           the order of their lowest row ("unique row" u of the field; u ascending == representative ascending).
+//           Kept per field: urep[u] (lowest member = representative document), ustart[u] / ucount[u] into `members` (the
+//           rows sorted by group, ascending inside a group), and the fp16 screen slab built from the unique rows only.
+//   scan    the screened pass ranks unique rows; fields with few distinct vectors collapse to a few tiles.
+//   certify the exact top-k of the re-scored unique rows is EXPANDED to documents: a unique row with exact score s stands for
+//           ucount documents with score s; the k best (score desc, doc id asc) of the expanded entries are the list.  The
+//           certificate compares the bound on every unscanned unique row with the k-th best DOCUMENT.
 // ---------------------------------------------------------------------------------------------------------
-#define DUP_SAMPLES 4096
-#define DUP_MIN_GROUP 64
-#define DUP_MEMBERS 128        // >= MFAR_MAX_K: a list can never need more members than its depth
-struct DupGroup {              // per field
-    int rep;                   // local row of the lowest-id member, -1 = no group
-    int n_masked;              // masked members (all of them, not only the listed ones)
-    int cand;                  // scratch: the sampled candidate row
-    int count;                 // scratch: rows equal to the candidate
-    int members[DUP_MEMBERS];  // the lowest masked local rows, ascending; -1 padded
-};
-
-__device__ __forceinline__ u64 dup_mix(u64 x) {
+__device__ __forceinline__ u64 row_mix(u64 x) {
     x ^= x >> 30;
     x *= 0xBF58476D1CE4E5B9ull;
     x ^= x >> 27;
@@ -197,139 +196,82 @@ __device__ __forceinline__ u64 dup_mix(u64 x) {
     return x ^ (x >> 31);
 }
 
-// grid = F, block 256, dynamic LDS = DUP_SAMPLES * 8
-__global__ void __launch_bounds__(256) mfar_dup_sample_kernel(const float* __restrict__ slab, long long field_stride, int n_steps,
-                                                              long long n_rows, DupGroup* __restrict__ grp) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    u64* keys = (u64*)smem;   // (hash with the low 12 bits replaced by the sample index)
-    const int f = blockIdx.x, E = n_steps * 16;
-    for (int i = threadIdx.x; i < DUP_SAMPLES; i += blockDim.x) {
-        const long long row = n_rows > 0 ? (long long)(((u64)i * 0x9E3779B97F4A7C15ull) % (u64)n_rows) : 0;
-        u64 h = 0;
-        for (int e = 0; e < E; e += 4) {
-            const f32x4 v = *(const f32x4*)(slab + (size_t)f * field_stride + tiled_offset(n_steps, row, e));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) h += dup_mix((u64)__float_as_uint(v[j]) + (u64)(e + j + 1) * 0x9E3779B97F4A7C15ull);
-        }
-        keys[i] = (h & ~0xFFFull) | (u64)i;
-    }
-    __syncthreads();
-    for (int size = 2; size <= DUP_SAMPLES; size <<= 1)      // bitonic sort ascending
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = threadIdx.x; t < DUP_SAMPLES / 2; t += blockDim.x) {
-                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const u64 x = keys[lo], y = keys[hi];
-                if ((x > y) == up) {
-                    keys[lo] = y;
-                    keys[hi] = x;
-                }
-            }
-            __syncthreads();
-        }
-    // longest run of equal hashes (thread t looks at runs starting at positions t, t + 256, ...)
-    __shared__ unsigned long long best;   // (run length << 32) | start
-    if (threadIdx.x == 0) best = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < DUP_SAMPLES; i += blockDim.x) {
-        const u64 hk = keys[i] >> 12;
-        if (i > 0 && (keys[i - 1] >> 12) == hk) continue;   // not a run start
-        int j = i + 1;
-        while (j < DUP_SAMPLES && (keys[j] >> 12) == hk) ++j;
-        atomicMax(&best, ((unsigned long long)(j - i) << 32) | (unsigned)i);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int len = (int)(best >> 32), start = (int)(best & 0xFFFFFFFFu);
-        DupGroup* g = grp + f;
-        g->rep = 0x7FFFFFFF;
-        g->n_masked = 0;
-        g->count = 0;
-        g->cand = -1;
-        if (len >= 2 && n_rows >= DUP_MIN_GROUP) {
-            const int si = (int)(keys[start] & 0xFFFull);
-            g->cand = (int)(((u64)si * 0x9E3779B97F4A7C15ull) % (u64)n_rows);
-        }
-    }
-}
-
-// grid = (n_blk, F), block 256 (thread layout of mfar_screen_stats_kernel).  eq: [F][n_blk * 2] words, zeroed by the host.
-__global__ void __launch_bounds__(256) mfar_dup_compare_kernel(const float* __restrict__ slab, long long field_stride, int n_steps,
-                                                               long long n_rows, DupGroup* __restrict__ grp, u32* __restrict__ eq,
-                                                               long long words_per_field) {
-    const int f = blockIdx.y;
-    const int cand = grp[f].cand;
-    if (cand < 0) return;   // workgroup-uniform
-    const int rr = threadIdx.x >> 2, pp = threadIdx.x & 3;   // thread = quarter pp (8 floats) of row rr's line per k-step pair
+// grid = n_blk, block 256 (thread = quarter pp of row rr's 128-byte line per k-step pair); field = base of one field
+__global__ void __launch_bounds__(256) mfar_row_hash_kernel(const float* __restrict__ field, int n_steps, long long n_rows,
+                                                            u64* __restrict__ keys, u32* __restrict__ vals) {
+    const int rr = threadIdx.x >> 2, pp = threadIdx.x & 3;
     const long long row = (long long)blockIdx.x * 64 + rr;
-    const float* tile = slab + (size_t)f * field_stride + (size_t)blockIdx.x * n_steps * 1024 + rr * 32 + pp * 8;
-    const float* cnd = slab + (size_t)f * field_stride + tiled_offset(n_steps, cand, pp * 8);
-    bool same = row < n_rows;
-    for (int pr = 0; pr < (n_steps >> 1); ++pr) {
-        if (!__any(same)) break;   // wave-uniform
+    const float* tile = field + (size_t)blockIdx.x * n_steps * 1024 + rr * 32 + pp * 8;
+    u64 h = 0;
+    if (row < n_rows)
+        for (int pr = 0; pr < (n_steps >> 1); ++pr) {
 #pragma unroll
-        for (int hq = 0; hq < 2; ++hq) {
-            const f32x4 a = *(const f32x4*)(tile + (size_t)pr * 2048 + hq * 4);
-            const f32x4 b = *(const f32x4*)(cnd + (size_t)pr * 2048 + hq * 4);
+            for (int hq = 0; hq < 2; ++hq) {
+                const f32x4 v = *(const f32x4*)(tile + (size_t)pr * 2048 + hq * 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) same = same && __float_as_uint(a[i]) == __float_as_uint(b[i]);
+                for (int i = 0; i < 4; ++i)
+                    h += row_mix((u64)__float_as_uint(v[i]) + (u64)(pr * 32 + pp * 8 + hq * 4 + i + 1) * 0x9E3779B97F4A7C15ull);
+            }
         }
-    }
-    // threads 4r .. 4r+3 hold the four quarters of row r
-    same = (__shfl_xor((int)same, 1) & (int)same) != 0;
-    same = (__shfl_xor((int)same, 2) & (int)same) != 0;
-    const u64 m = __ballot(same && pp == 0);   // bit 4r set: row r of this wave's 16 rows equals the candidate
-    if ((threadIdx.x & 63) == 0 && m) {
-        u32 bits = 0;
-        for (int r = 0; r < 16; ++r) bits |= (u32)((m >> (4 * r)) & 1ull) << r;
-        const int wv = threadIdx.x >> 6;                                     // wave: rows 16 wv .. 16 wv + 15 of the block
-        atomicOr(&eq[(size_t)f * words_per_field + blockIdx.x * 2 + (wv >> 1)], bits << (16 * (wv & 1)));
-        atomicAdd(&grp[f].count, __popc(bits));
-        atomicMin(&grp[f].rep, (int)(blockIdx.x * 64 + wv * 16 + __builtin_ctz(bits)));
+    // threads 4r .. 4r+3 hold the four quarters of row r (the sum is order independent)
+    h += ((u64)(u32)__shfl_xor((int)(u32)h, 1)) | ((u64)(u32)__shfl_xor((int)(u32)(h >> 32), 1) << 32);
+    h += ((u64)(u32)__shfl_xor((int)(u32)h, 2)) | ((u64)(u32)__shfl_xor((int)(u32)(h >> 32), 2) << 32);
+    if (pp == 0 && row < n_rows) {
+        keys[row] = h;
+        vals[row] = (u32)row;
     }
 }
 
-// grid = F, block 64
-__global__ void __launch_bounds__(64) mfar_dup_finish_kernel(DupGroup* __restrict__ grp, u32* __restrict__ eq, long long words_per_field) {
-    const int f = blockIdx.x, lane = threadIdx.x;
-    DupGroup* g = grp + f;
-    u32* w = eq + (size_t)f * words_per_field;
-    const bool have = g->cand >= 0 && g->count >= DUP_MIN_GROUP;
-    if (!have) {
-        for (long long i = lane; i < words_per_field; i += 64) w[i] = 0u;
-        if (lane == 0) {
-            g->rep = -1;
-            g->n_masked = 0;
+// head[i] = 1 when sorted position i starts a new group.  8 threads per position.  grid = ceil(n * 8 / 256), block 256.
+__global__ void __launch_bounds__(256) mfar_group_heads_kernel(const float* __restrict__ field, int n_steps, long long n,
+                                                               const u64* __restrict__ keys, const u32* __restrict__ vals,
+                                                               u32* __restrict__ head) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = gid >> 3;
+    const int part = (int)gid & 7;
+    bool differ = false, live = i < n;
+    if (live) {
+        if (i == 0 || keys[i] != keys[i - 1]) differ = true;
+        else {
+            const long long a = vals[i], b = vals[i - 1];
+            const int E = n_steps * 16;
+            for (int e = part * 4; e < E && !differ; e += 32) {
+                const f32x4 x = *(const f32x4*)(field + tiled_offset(n_steps, a, e));
+                const f32x4 y = *(const f32x4*)(field + tiled_offset(n_steps, b, e));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) differ = differ || __float_as_uint(x[c]) != __float_as_uint(y[c]);
+            }
         }
-        for (int i = lane; i < DUP_MEMBERS; i += 64) g->members[i] = -1;
-        return;
     }
-    const int rep = g->rep;
-    if (lane == 0) {
-        w[rep >> 5] &= ~(1u << (rep & 31));   // the representative stays in the scan
-        g->n_masked = g->count - 1;
-    }
-    __syncthreads();
-    // the DUP_MEMBERS lowest masked rows, ascending: walk the bitmap 64 words at a time
-    int found = 0;
-    for (long long base = 0; base < words_per_field && found < DUP_MEMBERS; base += 64) {
-        const u32 word = base + lane < words_per_field ? w[base + lane] : 0u;
-        const int cnt = __popc(word);
-        int incl = cnt;
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
-        }
-        int pos = found + incl - cnt;
-        u32 bitsw = word;
-        while (bitsw && pos < DUP_MEMBERS) {
-            const int b = __builtin_ctz(bitsw);
-            bitsw &= bitsw - 1;
-            g->members[pos++] = (int)((base + lane) * 32 + b);
-        }
-        found += __shfl(incl, 63);
-    }
-    for (int i = (found < DUP_MEMBERS ? found : DUP_MEMBERS) + lane; i < DUP_MEMBERS; i += 64) g->members[i] = -1;
+    int d = differ ? 1 : 0;
+    d |= __shfl_xor(d, 1);
+    d |= __shfl_xor(d, 2);
+    d |= __shfl_xor(d, 4);
+    if (live && part == 0) head[i] = (u32)d;
+}
+
+// gid = inclusive scan of head (1-based group number per sorted position).  For every group: its start in the sorted order
+// and its lowest row (the sort is stable, rows ascend inside a group); the lowest row is flagged in is_rep[row].
+__global__ void __launch_bounds__(256) mfar_group_starts_kernel(long long n, const u32* __restrict__ head, const u32* __restrict__ gid,
+                                                                const u32* __restrict__ vals, int* __restrict__ gstart,
+                                                                u32* __restrict__ is_rep) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !head[i]) return;
+    gstart[gid[i] - 1] = (int)i;
+    is_rep[vals[i]] = 1u;
+}
+// urank = inclusive scan of is_rep over the rows: unique number (1-based) of a representative row.
+__global__ void __launch_bounds__(256) mfar_unique_table_kernel(long long n, int n_groups, const int* __restrict__ gstart,
+                                                                const u32* __restrict__ vals, const u32* __restrict__ urank,
+                                                                int* __restrict__ urep, int* __restrict__ ustart, int* __restrict__ ucount) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const int s = gstart[g], e = g + 1 < n_groups ? gstart[g + 1] : (int)n;
+    const int rep = (int)vals[s];
+    const int u = (int)urank[rep] - 1;
+    urep[u] = rep;
+    ustart[u] = s;
+    ucount[u] = e - s;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -344,8 +286,8 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
                                                                   float eps_mult) {
     __shared__ float red_a[4], red_s[4];
     const int r = blockIdx.x;
-    // a new batch: clear the certificate flags of the fields and the "any" flag ([F + 1] keeps accumulating statistics)
-    if (r == 0 && (int)threadIdx.x <= F) fail_flags[threadIdx.x] = 0;
+    // a new batch: clear the certificate flags of the fields and the "any" flag ([MFAR_MAX_FIELDS + 1] keeps accumulating statistics)
+    if (r == 0 && (int)threadIdx.x <= MFAR_MAX_FIELDS) fail_flags[threadIdx.x] = 0;
     const bool live = q0 + r < Q;
     const float* row = q + (size_t)(q0 + (live ? r : 0)) * E;
     // ONE round of global loads (this kernel opens a batch on the critical path, usually while the previous batch's gathers
@@ -434,87 +376,144 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Certify: exact top-k of the k' re-scored rows of one (query, field) + the certificate.  grid = Qt * F, block 256.
+// Certify: exact top-k DOCUMENTS of the k' re-scored unique rows of one (query, field) + the certificate.
+//   grid = Qt * nf, block 256.
 // ---------------------------------------------------------------------------------------------------------
+#define CERT_EXPAND_CAP 1024    // expanded (score, doc) entries a block can rank; more -> the exact pass decides
 struct CertifyParams {
-    const long long* sid;     // [64, F, kp] global ids of the screened lists (-1 = empty)
-    const float* ssc;         // [64, F, kp] approximate scores (scaled units), descending
-    const int* scnt;          // [64 * F] entries per screened list
-    const float* sx;          // [64, F, kp] exact scores of those rows (NaN = not scored)
-    const ScreenField* sf;
+    const long long* sid;     // [64, nf, kp] unique-row numbers of the screened lists (-1 = empty)
+    const float* ssc;         // [64, nf, kp] approximate scores (scaled units), descending
+    const int* scnt;          // [64 * nf] entries per screened list
+    const float* sx;          // [64, nf, kp] exact scores of those rows' representatives (NaN = not scored)
+    const ScreenField* sf;    // [F]
     const ScreenQuery* qinfo;
     const float* eps;         // [F, 64]
     const float* q;           // [Qt, E] the block's queries (row-major)
     const float* mean;        // [F, E] field means: q . mean is added back to the centred approximate scores
     int E;
-    long long* out_ids;       // [Q, F, k]
+    long long* out_ids;       // [Q, nf, k]
     float* out_scores;
-    int* fail;                // [F] field flags, [F] = any, [F+1] = failed (query, field) pairs (statistics)
-    const DupGroup* grp;      // [F] duplicate groups (local rows) or nullptr
+    int* fail;                // [F] field flags, [MFAR_MAX_FIELDS] = any, [MFAR_MAX_FIELDS + 1] = failed (query, field) pairs (statistics)
+    // unique-row tables (per field f at offset f * ustride): ustart / ucount index `members` (local rows, grouped, ascending)
+    const int* ustart;
+    const int* ucount;
+    const int* members;
+    long long ustride;
     long long row_offset;
-    int F, k, kp, q0, sentinel;
+    int f0, nf, k, kp, q0, sentinel;
+    float* dbg;               // diagnostics (MFAR_CERT_DEBUG) or nullptr: per list {ok, bound, T_k, a_real, eps, cnt, m_out, overflow}
 };
 __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyParams p) {
-    __shared__ u64 keys[256], sel[256], sorted[256];
-    __shared__ int red[36];
-    const int ql = blockIdx.x / p.F, f = blockIdx.x - ql * p.F;
-    const size_t lb = ((size_t)ql * p.F + f) * p.kp;
-    const int cnt = min(p.scnt[ql * p.F + f], p.kp);
+    __shared__ u64 keys[CERT_EXPAND_CAP], sel[256], sorted[256];
+    __shared__ int red[36], ucnt_s[256], upre_s[256];
+    __shared__ float qm_s[4];
+    __shared__ int total_s, overflow_s;
+    const int ql = blockIdx.x / p.nf, fo = blockIdx.x - ql * p.nf, f = p.f0 + fo;
+    const size_t lb = ((size_t)ql * p.nf + fo) * p.kp;
+    const int cnt = min(p.scnt[ql * p.nf + fo], p.kp);
     const float tau0 = p.sentinel ? 0.0f : -__builtin_inff();
-    if (threadIdx.x == 0) red[32] = 0;
+    const int* ustart = p.ustart + (size_t)f * p.ustride;
+    const int* ucount = p.ucount + (size_t)f * p.ustride;
+    const int* members = p.members + (size_t)f * p.ustride;
+    if (threadIdx.x == 0) {
+        red[32] = 0;
+        overflow_s = 0;
+    }
     __syncthreads();
+    // 1. the unique rows that pass the sentinel (every thread keeps its candidate), ranked by (exact score desc, unique number asc)
+    u32 my_u = 0, my_bits = 0;
+    bool mine = false;
     if ((int)threadIdx.x < cnt) {
-        const long long id = p.sid[lb + threadIdx.x];
+        const long long u = p.sid[lb + threadIdx.x];
         const float s = p.sx[lb + threadIdx.x];
-        if (id >= 0 && s > tau0) keys[lds_add_rtn(&red[32], 1)] = make_key(s, (u32)id);
+        if (u >= 0 && s > tau0) {
+            mine = true;
+            my_u = (u32)u;
+            my_bits = f2ord(s);
+            keys[lds_add_rtn(&red[32], 1)] = make_key(s, my_u);
+        }
     }
     __syncthreads();
     const int n = red[32];
-    const int m = block_topk_sorted<1>(keys, n, p.k, sel, sorted, red);
+    const int m = block_topk_sorted<1>(keys, n, p.k, sel, sorted, red);      // k unique rows always cover k documents
     // q . mean(field) (any summation order: part of the approximation, budgeted in eps)
     float pm = 0.0f;
     for (int e = threadIdx.x; e < p.E; e += blockDim.x) pm = __builtin_fmaf(p.q[(size_t)ql * p.E + e], p.mean[(size_t)f * p.E + e], pm);
     for (int off = 32; off > 0; off >>= 1) pm += __shfl_xor(pm, off);
-    __shared__ float qm_s[4];
     if ((threadIdx.x & 63) == 0) qm_s[threadIdx.x >> 6] = pm;
+    // 2. expansion.  A unique row with exact score s stands for min(ucount, k) documents with score s.  Walking the ranked
+    //    rows, the first prefix that covers k documents ends at row j*: the k best documents are among the documents of all
+    //    candidates that score AT LEAST what row j* scores (rows that TIE with j* included, wherever they rank: their
+    //    documents may have lower ids -- exact fp32 ties between distinct vectors at the cut are rare but real).
+    ucnt_s[threadIdx.x] = (int)threadIdx.x < m ? min(ucount[key_id(sorted[threadIdx.x])], p.k) : 0;
     __syncthreads();
-    // certificate
+    if (threadIdx.x == 0) {      // m <= 128: a serial prefix is a few hundred cycles
+        int run = 0, jstar = m - 1;
+        for (int i = 0; i < m; ++i) {
+            run += ucnt_s[i];
+            if (run >= p.k) {
+                jstar = i;
+                break;
+            }
+        }
+        total_s = m > 0 ? (int)(u32)(sorted[jstar] >> 32) : -1;     // orderable score bits of row j* (0 = no candidate)
+    }
+    __syncthreads();
+    const u32 tie_bits = (u32)total_s;
+    const bool in = mine && m > 0 && my_bits >= tie_bits;
+    const int c = in ? min(ucount[my_u], p.k) : 0;
+    // block-wide exclusive prefix of c (256 threads = 4 waves)
+    int incl = c;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if ((int)(threadIdx.x & 63) >= off) incl += v;
+    }
+    __syncthreads();                                  // total_s was read by everybody
+    if ((threadIdx.x & 63) == 63) upre_s[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wbase += upre_s[w];
+    const int total_all = upre_s[0] + upre_s[1] + upre_s[2] + upre_s[3];
+    const bool fits = total_all <= CERT_EXPAND_CAP;   // more tied groups than the block can rank: the exact pass decides
+    const int total = fits ? total_all : 0;
+    if (fits && c > 0) {
+        const int off0 = wbase + incl - c;
+        const float s = ord2f(my_bits);
+        const int* mem = members + ustart[my_u];
+        for (int e = 0; e < c; ++e) keys[off0 + e] = make_key(s, (u32)(p.row_offset + mem[e]));
+    }
+    if (threadIdx.x == 0 && !fits) overflow_s = 1;
+    __syncthreads();
+    const int m_out = block_topk_sorted<4>(keys, total, p.k, sel, sorted, red);
+    // 3. certificate
     if (threadIdx.x == 0) {
-        bool ok = true;
-        if (cnt == p.kp) {  // the list is full: rows outside it exist
+        bool ok = overflow_s == 0;
+        float a_real = 0.0f, bound = 0.0f;
+        if (ok && cnt == p.kp) {  // the list is full: unique rows outside it exist
             const float qm = (qm_s[0] + qm_s[1]) + (qm_s[2] + qm_s[3]);
-            const float a_real = (p.ssc[lb + p.kp - 1] * p.qinfo[ql].inv_scale) * p.sf[f].inv_scale + qm;
-            const float bound = a_real + p.eps[f * 64 + ql];       // every outside row scores <= bound (exactly)
-            if (m == p.k) ok = bound < key_score(sorted[p.k - 1]); // ... strictly below the exact k-th best
+            a_real = (p.ssc[lb + p.kp - 1] * p.qinfo[ql].inv_scale) * p.sf[f].inv_scale + qm;
+            bound = a_real + p.eps[f * 64 + ql];                   // every outside row scores <= bound (exactly)
+            if (m_out == p.k) ok = bound < key_score(sorted[p.k - 1]); // ... strictly below the exact k-th best DOCUMENT
             else ok = bound <= tau0;                               // ... or cannot pass the sentinel at all
+        }
+        if (p.dbg) {
+            float* d = p.dbg + (size_t)blockIdx.x * 8;
+            d[0] = ok ? 1.0f : 0.0f;
+            d[1] = bound;
+            d[2] = m_out > 0 ? key_score(sorted[m_out - 1]) : 0.0f;
+            d[3] = a_real;
+            d[4] = p.eps[f * 64 + ql];
+            d[5] = (float)cnt;
+            d[6] = (float)m_out;
+            d[7] = (float)overflow_s + 10.0f * (float)n + 10000.0f * (float)total;
         }
         if (!ok) {
             atomicOr(&p.fail[f], 1);
-            atomicOr(&p.fail[p.F], 1);
-            atomicAdd(&p.fail[p.F + 1], 1);
+            atomicOr(&p.fail[MFAR_MAX_FIELDS], 1);
+            atomicAdd(&p.fail[MFAR_MAX_FIELDS + 1], 1);
         }
     }
-    // duplicate group: when its representative is among the k best, the masked members (same exact score, higher ids) take
-    // their canonical places right behind it -- select the k best of (the k selected) + (the group's lowest masked members)
-    int m_out = m;
-    if (p.grp && p.grp[f].rep >= 0 && m > 0) {
-        const DupGroup* g = p.grp + f;
-        const u32 rep_id = (u32)(p.row_offset + g->rep);
-        __shared__ int hit;
-        if (threadIdx.x == 0) hit = -1;
-        __syncthreads();
-        if ((int)threadIdx.x < m && key_id(sorted[threadIdx.x]) == rep_id) hit = threadIdx.x;
-        __syncthreads();
-        if (hit >= 0) {   // workgroup-uniform
-            const float s_rep = key_score(sorted[hit]);
-            const int n_add = min(min(g->n_masked, DUP_MEMBERS), p.k);
-            if ((int)threadIdx.x < m) keys[threadIdx.x] = sorted[threadIdx.x];
-            if ((int)threadIdx.x < n_add) keys[m + threadIdx.x] = make_key(s_rep, (u32)(p.row_offset + g->members[threadIdx.x]));
-            __syncthreads();
-            m_out = block_topk_sorted<1>(keys, m + n_add, p.k, sel, sorted, red);
-        }
-    }
-    const size_t ob = ((size_t)(p.q0 + ql) * p.F + f) * p.k;
+    const size_t ob = ((size_t)(p.q0 + ql) * p.nf + fo) * p.k;
     for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
         if (r < m_out) {
             p.out_ids[ob + r] = (long long)key_id(sorted[r]);

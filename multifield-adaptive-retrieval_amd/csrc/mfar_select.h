@@ -103,15 +103,18 @@ __global__ void mfar_tile_queries_bf16_kernel(const float* __restrict__ q, unsig
 //   grid = Qt * F workgroups (Qt <= 64 queries of this pass), dynamic LDS = n_chunks * k * 8 bytes.
 // ---------------------------------------------------------------------------------------------------------
 struct MergeParams {
-    const uint2* lists;   // [F * n_chunks * 64][S1_CAP]
-    const int* list_cnt;  // [F * n_chunks * 64]
-    long long* out_ids;   // [Q, F, k] global ids (nullptr: threshold-only pass)
-    float* out_scores;    // [Q, F, k]
+    const uint2* lists;   // [n_chunks_total * 64][S1_CAP]
+    const int* list_cnt;  // [n_chunks_total * 64]
+    const int* fchunk;    // [F + 1] first chunk of every field in the pass's chunk table (chunks of a field are consecutive)
+    long long* out_ids;   // [Q, nf, k] global ids (nullptr: threshold-only pass)
+    float* out_scores;    // [Q, nf, k]
     float* tau_out;       // [F, 64] or nullptr: k-th best score of the merged list (-inf when fewer than k entries)
-    int* cnt_out;         // [Qt * F] or nullptr: entries of the merged list
+    int* cnt_out;         // [Qt * nf] or nullptr: entries of the merged list
     const int* only_failed;  // [F] or nullptr: only fields whose flag is set are merged (screen fall-back pass)
     long long row_offset;
-    int n_chunks, F, k, q0, sentinel;
+    int f0, nf;           // this launch merges fields [f0, f0 + nf): grid = Qt * nf, output rows are nf wide
+    int max_chunks;       // largest chunk count of a field (sizes the LDS staging of the non-register variant)
+    int k, q0, sentinel;
 };
 // LDS carve-up shared by the selection kernels (everything in the dynamic region: 16-byte aligned base)
 //   keys[n_keys] u64 | sel[SEL_MAX_K] u64 | sorted[SEL_MAX_K] u64 | red[32] int | misc[4] int
@@ -138,25 +141,26 @@ __device__ __forceinline__ SelLds sel_lds(char* smem, int n_keys) {
 template <int NPT>
 __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const SelLds L = sel_lds(smem, p.n_chunks * p.k);
-    const int ql = blockIdx.x / p.F, f = blockIdx.x - ql * p.F;
+    const SelLds L = sel_lds(smem, p.max_chunks * p.k);
+    const int ql = blockIdx.x / p.nf, fo = blockIdx.x - ql * p.nf, f = p.f0 + fo;
     if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
+    const int c_lo = p.fchunk[f], n_chunks = p.fchunk[f + 1] - c_lo;
     // chunk counts first (LDS), then the entries eight chunks at a time: the global loads of a round are independent,
     // so their latencies overlap instead of adding up
-    int* cnts = (int*)L.sel;   // the selection scratch is free until block_topk_sorted runs
-    for (int c = threadIdx.x; c < p.n_chunks; c += blockDim.x) cnts[c] = min(p.list_cnt[(size_t)(f * p.n_chunks + c) * 64 + ql], p.k);
+    int* cnts = (int*)L.sel;   // the selection scratch is free until block_topk_sorted runs (<= 128 chunks per field)
+    for (int c = threadIdx.x; c < n_chunks; c += blockDim.x) cnts[c] = min(p.list_cnt[(size_t)(c_lo + c) * 64 + ql], p.k);
     if (threadIdx.x == 0) L.misc[0] = 0;
     __syncthreads();
     for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
-        for (int c0 = 0; c0 < p.n_chunks; c0 += 8) {
+        for (int c0 = 0; c0 < n_chunks; c0 += 8) {
             uint2 e[8];
             bool ok[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = c0 + u;
-                ok[u] = c < p.n_chunks && r < cnts[c < p.n_chunks ? c : 0];
+                ok[u] = c < n_chunks && r < cnts[c < n_chunks ? c : 0];
                 e[u] = make_uint2(0u, 0u);
-                if (ok[u]) e[u] = p.lists[((size_t)(f * p.n_chunks + c) * 64 + ql) * S1_CAP + r];
+                if (ok[u]) e[u] = p.lists[((size_t)(c_lo + c) * 64 + ql) * S1_CAP + r];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -175,9 +179,9 @@ __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams
     else if (NPT > 32 && n <= 32 * 256) m = block_topk_sorted<32>(L.keys, n, p.k, L.sel, L.sorted, L.red);
     else m = block_topk_sorted<NPT>(L.keys, n, p.k, L.sel, L.sorted, L.red);
     if (p.tau_out && threadIdx.x == 0) p.tau_out[f * 64 + ql] = m == p.k ? key_score(L.sorted[p.k - 1]) : -__builtin_inff();
-    if (p.cnt_out && threadIdx.x == 0) p.cnt_out[ql * p.F + f] = m;
+    if (p.cnt_out && threadIdx.x == 0) p.cnt_out[ql * p.nf + fo] = m;
     if (!p.out_ids) return;
-    const size_t ob = ((size_t)(p.q0 + ql) * p.F + f) * p.k;
+    const size_t ob = ((size_t)(p.q0 + ql) * p.nf + fo) * p.k;
     for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
         if (r < m) {
             p.out_ids[ob + r] = p.row_offset + (long long)key_id(L.sorted[r]);
@@ -196,12 +200,13 @@ template <int NPT, int TPB>
 __device__ __forceinline__ void merge_lists_regs_body(const MergeParams& p) {
     __shared__ u64 sel[SEL_MAX_K], sorted[SEL_MAX_K];
     __shared__ int red[36], cnts[128];
-    const int ql = blockIdx.x / p.F, f = blockIdx.x - ql * p.F;
+    const int ql = blockIdx.x / p.nf, fo = blockIdx.x - ql * p.nf, f = p.f0 + fo;
     if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
+    const int c_lo = p.fchunk[f], n_chunks = p.fchunk[f + 1] - c_lo;
     if (threadIdx.x < 128)
-        cnts[threadIdx.x] = (int)threadIdx.x < p.n_chunks ? min(p.list_cnt[(size_t)(f * p.n_chunks + threadIdx.x) * 64 + ql], p.k) : 0;
+        cnts[threadIdx.x] = (int)threadIdx.x < n_chunks ? min(p.list_cnt[(size_t)(c_lo + threadIdx.x) * 64 + ql], p.k) : 0;
     __syncthreads();
-    const int total = p.n_chunks * p.k;
+    const int total = n_chunks * p.k;
     // unconditional loads (clamped slot: always inside the list buffer), so that all NPT of them are in flight together;
     // validity is applied afterwards
     uint2 e[NPT];
@@ -210,7 +215,7 @@ __device__ __forceinline__ void merge_lists_regs_body(const MergeParams& p) {
         const int s_ = (int)threadIdx.x + TPB * i;
         const int sl = s_ < total ? s_ : 0;
         const int c = sl / p.k;
-        e[i] = p.lists[((size_t)(f * p.n_chunks + c) * 64 + ql) * S1_CAP + (sl - c * p.k)];
+        e[i] = p.lists[((size_t)(c_lo + c) * 64 + ql) * S1_CAP + (sl - c * p.k)];
     }
     u32 hi[NPT], lo[NPT];
     int mine = 0;
@@ -229,9 +234,9 @@ __device__ __forceinline__ void merge_lists_regs_body(const MergeParams& p) {
     __syncthreads();   // red[] is reused by the selection
     const int m = block_topk_regs<NPT>(hi, lo, n, p.k, sel, sorted, red);
     if (p.tau_out && threadIdx.x == 0) p.tau_out[f * 64 + ql] = m == p.k ? key_score(sorted[p.k - 1]) : -__builtin_inff();
-    if (p.cnt_out && threadIdx.x == 0) p.cnt_out[ql * p.F + f] = m;
+    if (p.cnt_out && threadIdx.x == 0) p.cnt_out[ql * p.nf + fo] = m;
     if (!p.out_ids) return;
-    const size_t ob = ((size_t)(p.q0 + ql) * p.F + f) * p.k;
+    const size_t ob = ((size_t)(p.q0 + ql) * p.nf + fo) * p.k;
     for (int i = threadIdx.x; i < p.k; i += blockDim.x) {
         if (i < m) {
             p.out_ids[ob + i] = p.row_offset + (long long)key_id(sorted[i]);
@@ -249,20 +254,21 @@ __global__ void __launch_bounds__(256, 2) mfar_merge_lists_regs_kernel(const Mer
 // One WAVE per (query, field), NV values per lane (n_vals <= 64 * NV): the 32-step radix descent on the score bits is
 // NV ballots + scalar popcounts per step, no LDS and no barriers.  grid = ceil(64 * F / 4), block 256.
 template <int NV>
-__global__ void __launch_bounds__(256) mfar_sample_tau_kernel(const float* __restrict__ samp, int n_wave_blocks, int F, int k,
-                                                              float tau0, const float* __restrict__ base,
-                                                              float* __restrict__ tau_out) {
-    const int n_vals = n_wave_blocks * 2;
+__global__ void __launch_bounds__(256) mfar_sample_tau_kernel(const float* __restrict__ samp, const int* __restrict__ samp_n,
+                                                              int samp_stride, int f0, int nf, int k, float tau0,
+                                                              const float* __restrict__ base, float* __restrict__ tau_out) {
     const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (pair >= 64 * F) return;   // wave-uniform
-    const int q = pair / F, f = pair - q * F;
+    if (pair >= 64 * nf) return;   // wave-uniform
+    const int q = pair / nf, f = f0 + pair - q * nf;
+    const int n_wave_blocks = samp_n[f];      // wave blocks the sample pass published for this field
+    const int n_vals = n_wave_blocks * 2;
     u32 hi[NV];
     int n = 0;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int i = lane + j * 64;
         const int ii = i < n_vals ? i : 0;
-        const float v = samp[((size_t)f * n_wave_blocks + (ii >> 1)) * 128 + q * 2 + (ii & 1)];
+        const float v = samp[((size_t)f * samp_stride + (ii >> 1)) * 128 + q * 2 + (ii & 1)];
         const bool ok = i < n_vals && v > tau0;
         hi[j] = ok ? f2ord(v) : 0u;     // 0 = empty: below every real score's key
         n += __popcll(__ballot(ok));
@@ -409,6 +415,13 @@ struct ScoreParams {
     long long row_offset;
     int n_rows, n_steps, E, F, C;
     int per_field;           // != 0: cand is [Q, F, C] (one list per field), out is [Q, F, C]: row (f, c) is scored for field f only
+    // per_field mode of the certified screen: cand holds UNIQUE-row numbers of the field's screen slab; the row that is
+    // gathered from the fp32 slab is the unique row's representative document urep[f * ustride + u] (local row, u < nuniq[f]).
+    // nullptr: cand holds global doc ids.
+    const int* urep;
+    const int* nuniq;        // [F]
+    long long ustride;
+    int f0;                  // per_field mode: list (q, j) belongs to field f0 + j (F = number of fields in this launch)
 };
 // Each wave owns 64 (candidate, field) rows, one per lane, gathers their segments cooperatively by LDS-DMA into a private
 // two-slot LDS ring, and every lane then walks ITS row's segment from LDS in chain order.  No barriers: the ring is private
@@ -561,9 +574,12 @@ __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_f32_kernel(const 
     const char* rowbase = (const char*)p.slab;  // harmless in-bounds address for invalid rows
     if (idx < p.C * p.F) {
         const int c = p.per_field ? idx % p.C : idx / p.F;
-        const int f = p.per_field ? idx / p.C : idx - c * p.F;
+        const int fl = p.per_field ? idx / p.C : idx - c * p.F;     // list / field slot of this launch
+        const int f = p.per_field ? p.f0 + fl : fl;                 // field of the slab
         if (c < nc) {
-            const long long id = p.cand[p.per_field ? ((size_t)qi * p.F + f) * p.C + c : (size_t)qi * p.C + c] - p.row_offset;
+            long long id = p.cand[p.per_field ? ((size_t)qi * p.F + fl) * p.C + c : (size_t)qi * p.C + c];
+            if (p.urep) id = (id >= 0 && id < p.nuniq[f]) ? (long long)p.urep[(size_t)f * p.ustride + id] : -1;   // unique row -> its document
+            else id -= p.row_offset;
             if (id >= 0 && id < p.n_rows) {
                 valid = true;
                 rr = (int)(id & 63);
@@ -802,7 +818,8 @@ __global__ void __launch_bounds__(64) mfar_filter_owned_kernel(const long long* 
 // final merge of the per-rank local top-k lists: [S][Q][k] (ids, scores) -> top-k; n_valid = min(global candidates, k)
 struct TopkMergeParams {
     const char* payloads;        // S payloads, `stride` bytes apart: ids[Q,k] int64 | scores[Q,k] f32 | n_cand_global[Q] int32
-    long long stride, ids_off, scores_off, ncand_off;
+    long long stride, ids_off, scores_off, ncand_off, flag_off;
+    int* any_fail;               // or nullptr: OR of the S ranks' certificate flags (every rank derives the same value)
     long long* ids;
     float* scores;
     int* n_valid;
@@ -831,6 +848,11 @@ __global__ void __launch_bounds__(256) mfar_merge_topk_kernel(const TopkMergePar
     if (threadIdx.x == 0 && p.n_valid) {
         const int ng = ((const int*)(p.payloads + p.ncand_off))[q];      // every rank derived the same global union
         p.n_valid[q] = min(ng, p.k);
+    }
+    if (q == 0 && threadIdx.x == 0 && p.any_fail) {
+        int any = 0;
+        for (int s = 0; s < p.S; ++s) any |= *(const int*)(p.payloads + (size_t)s * p.stride + p.flag_off);
+        *p.any_fail = any;
     }
 }
 

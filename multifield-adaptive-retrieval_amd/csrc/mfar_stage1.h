@@ -55,16 +55,26 @@
 #endif
 #define S1H_LDS_BYTES (4 * S1H_STAGES * 2048 + S1H_STAGES * 4096 + S1_STATE_BYTES_(S1_SCAP_LDS))
 
+// One workgroup of a stage-1 pass scans one CHUNK: a contiguous run of 256-row tiles of one field.  The chunk table is built
+// on the host from the fields' row counts (fields differ when the scanned slab holds each field's UNIQUE rows,
+// mfar_screen.h): every field gets a share of the grid proportional to its tiles, chunks of a field are consecutive.
+struct S1Chunk {
+    int f;                  // field
+    int t0, t1;             // tiles [t0, t1) of the field
+    int n_rows;             // valid rows of the field (rows beyond are zero padding)
+    long long base;         // element offset of the field's first tile inside the slab
+    int tl0;                // index of this chunk's first tile among the SAMPLED tiles of its field (sample pass output slot)
+    int pad;
+};
+
 struct S1Params {
-    const void* slab;       // tiled slab (fp32 or bf16)
+    const void* slab;       // tiled slab (fp32, bf16, or the fp16 screen slab)
     const void* qt;         // tiled queries: fp32 [n_steps][64][16]; bf16 [n_steps][4][64][16] (terms hi, mid, lo, zero pad)
-    uint2* lists;           // [F * n_chunks * 64][S1_CAP]  (score bits, local row)
-    int* list_cnt;          // [F * n_chunks * 64]
-    long long field_stride; // elements between fields
-    int n_rows;             // valid rows of this shard
+    uint2* lists;           // [n_chunks * 64][S1_CAP]  (score bits, local row)
+    int* list_cnt;          // [n_chunks * 64]
+    const S1Chunk* chunks;  // [n_chunks] chunk table of the scanned slab
+    int chunk0;             // first chunk of this launch (grid = a contiguous chunk range: all fields, or one field)
     int n_steps;            // E / 16
-    int n_tiles;            // n_blk / 4
-    int n_chunks;           // workgroups per field
     int Q;                  // valid queries (<= 64)
     int k;                  // list depth (<= S1_MAX_DEPTH)
     float tau0;             // 0 (zero sentinel, index.py:192-193) or -inf
@@ -72,10 +82,9 @@ struct S1Params {
     int sample;             // 1/2: threshold-estimation pass, every workgroup scans only the first tile of its chunk;
                             //      2 = light form: no lists, every wave publishes the 2 best scores per query of its 64 rows
     int sample_tiles;       // tiles per workgroup scanned by the sample pass (>= 1, <= tiles of the shortest chunk)
-    float* samp_out;        // [F][n_chunks * sample_tiles * 4][64][2] (sample == 2)
+    float* samp_out;        // [F][samp_stride wave blocks][64][2] (sample == 2): wave block = (sampled tile of the field, wave)
+    int samp_stride;        // wave blocks reserved per field
     const int* only_failed; // [F] or nullptr: workgroups of fields whose flag is 0 exit at once (screen fall-back pass)
-    const u32* dup_mask;    // [F][dup_words] or nullptr: rows whose bit is set are skipped (masked duplicates, mfar_screen.h)
-    long long dup_words;    // words per field = n_blk * 2
     int dbg;                // profiling only (MFAR_S1_DEBUG): 1 = skip the selection epilogue (results invalid; note that
                             // the downstream kernels then have no candidates, so they no longer compete with stage 1)
 };
@@ -174,37 +183,16 @@ __device__ __forceinline__ void s1_state_init(const S1State& st, const S1Params&
     __syncthreads();
 }
 
-// Rows that must never qualify, for both epilogues: the padding rows behind the field's last row, and (screened pass) the
-// masked members of the field's duplicate group.  acc layout: see s1_epilogue.
-__device__ __forceinline__ void s1_mask_rows(const S1Params& p, int f, int t, int w, f32x16& acc00, f32x16& acc01, f32x16& acc10,
-                                             f32x16& acc11) {
+// Rows that must never qualify, for both epilogues: the padding rows behind the field's last row.  acc layout: see s1_epilogue.
+__device__ __forceinline__ void s1_mask_rows(int n_rows, int t, int w, f32x16& acc00, f32x16& acc01, f32x16& acc10, f32x16& acc11) {
     const int h = (threadIdx.x & 63) >> 5;
-    if (t * S1_TILE_ROWS + S1_TILE_ROWS > p.n_rows) {  // last tile of the field
+    if (t * S1_TILE_ROWS + S1_TILE_ROWS > n_rows) {  // last tile of the field
         const int row_w = t * S1_TILE_ROWS + w * 64 + 4 * h;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row_w + (r & 3) + 8 * (r >> 2);
-            if (row >= p.n_rows) acc00[r] = acc01[r] = -__builtin_inff();
-            if (row + 32 >= p.n_rows) acc10[r] = acc11[r] = -__builtin_inff();
-        }
-    }
-    if (p.dup_mask) {
-        // the wave's 64 rows are two words of the bitmap (wave-uniform loads)
-        // (a scalar load through inline asm: a vector load the compiler can see would make it drain the k-loop's prefetch
-        //  queue -- vmcnt(0) -- in front of the first use)
-        const unsigned long long ma = (unsigned long long)(p.dup_mask + (size_t)f * p.dup_words + (size_t)t * 8 + w * 2);
-        const unsigned long long ms = ((unsigned long long)(u32)__builtin_amdgcn_readfirstlane((int)(ma >> 32)) << 32) |
-                                      (u32)__builtin_amdgcn_readfirstlane((int)(u32)ma);
-        unsigned long long mm;
-        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mm) : "s"(ms) : "memory");
-        const u32 m0 = (u32)mm, m1 = (u32)(mm >> 32);
-        if (m0 | m1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rw = (r & 3) + 8 * (r >> 2) + 4 * h;
-                if ((m0 >> rw) & 1u) acc00[r] = acc01[r] = -__builtin_inff();
-                if ((m1 >> rw) & 1u) acc10[r] = acc11[r] = -__builtin_inff();
-            }
+            if (row >= n_rows) acc00[r] = acc01[r] = -__builtin_inff();
+            if (row + 32 >= n_rows) acc10[r] = acc11[r] = -__builtin_inff();
         }
     }
 }
@@ -250,10 +238,10 @@ __device__ __forceinline__ void s1_drain(const S1Params& p, const S1State& st, i
 // wave and tile of the direct path cost 14 % of the 16-bit pass); staging turns them into about one coalesced store per
 // wave and tile.  Entries that do not fit the staging area (a lane with many survivors in one tile) go straight to the list.
 template <int SCAP>
-__device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st, int f, int t, int w, size_t wgq0, f32x16& acc00,
+__device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st, int n_rows, int t, int w, size_t wgq0, f32x16& acc00,
                                             f32x16& acc01, f32x16& acc10, f32x16& acc11) {
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
-    s1_mask_rows(p, f, t, w, acc00, acc01, acc10, acc11);
+    s1_mask_rows(n_rows, t, w, acc00, acc01, acc10, acc11);
     // (barrier A -- the compactions of the previous tile are complete, every wave has finished the tile's last k-step --
     //  is executed by the caller, which uses it to refill the ring slot that just became free before this epilogue runs)
     const float th0 = fmaxf(s1_nextup(st.tau[j]), st.tg[j]);
@@ -328,10 +316,10 @@ __device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st
 // Light threshold-estimation epilogue (sample == 2): per (wave, query) the two best scores among the wave's 64 rows.
 // They are scores of distinct real rows, so the k-th largest of all published values is a valid (non-strict) lower
 // bound of the final k-th best (mfar_sample_tau_kernel).
-__device__ __forceinline__ void s1_sample_top2(const S1Params& p, int f, int chunk, int tl, int t, int w, f32x16& acc00, f32x16& acc01,
+__device__ __forceinline__ void s1_sample_top2(const S1Params& p, const S1Chunk& c, int tl, int t, int w, f32x16& acc00, f32x16& acc01,
                                                f32x16& acc10, f32x16& acc11) {
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    s1_mask_rows(p, f, t, w, acc00, acc01, acc10, acc11);
+    s1_mask_rows(c.n_rows, t, w, acc00, acc01, acc10, acc11);
     float a1 = -__builtin_inff(), a2 = a1, b1 = a1, b2 = a1;   // query j: (a1 >= a2), query 32 + j: (b1 >= b2)
 #define S1_TOP2(V, M1, M2)                    \
     {                                         \
@@ -353,7 +341,7 @@ __device__ __forceinline__ void s1_sample_top2(const S1Params& p, int f, int chu
     const float ra1 = fmaxf(a1, oa1), ra2 = fmaxf(fminf(a1, oa1), fmaxf(a2, oa2));
     const float rb1 = fmaxf(b1, ob1), rb2 = fmaxf(fminf(b1, ob1), fmaxf(b2, ob2));
     if (h == 0) {
-        float* o = p.samp_out + (((size_t)(f * p.n_chunks + chunk) * p.sample_tiles + tl) * 4 + w) * 128;
+        float* o = p.samp_out + (((size_t)c.f * p.samp_stride) + (size_t)(c.tl0 + tl) * 4 + w) * 128;
         store_untracked_b64(&o[j * 2], ((u64)__float_as_uint(ra2) << 32) | __float_as_uint(ra1));
         store_untracked_b64(&o[(32 + j) * 2], ((u64)__float_as_uint(rb2) << 32) | __float_as_uint(rb1));
     }
@@ -395,13 +383,14 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
 
-    const int f = blockIdx.x / p.n_chunks;
+    const int chunk_id = p.chunk0 + (int)blockIdx.x;
+    const S1Chunk ck = p.chunks[chunk_id];            // workgroup-uniform (scalar loads)
+    const int f = ck.f;
     if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
-    const int chunk = blockIdx.x - f * p.n_chunks;
-    const int t0 = (int)(((long long)chunk * p.n_tiles) / p.n_chunks);
-    int t1 = (int)(((long long)(chunk + 1) * p.n_tiles) / p.n_chunks);
+    const int t0 = ck.t0;
+    int t1 = ck.t1;
     if (p.sample) t1 = min(t1, t0 + p.sample_tiles);
-    const size_t wgq0 = (size_t)blockIdx.x * 64;
+    const size_t wgq0 = (size_t)chunk_id * 64;
     s1_state_init(st, p, f);
 
     // fragment read offsets inside a 4 KB tile: row (32*blk + j), dims 8g + 4h .. +3  (chunk c = 2g + h)
@@ -421,7 +410,7 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
         loff[pc] = rr * 128 + c * 16;
     }
     // load cursor (runs two k-steps ahead of the compute cursor): base of the wave's block of the current tile
-    const char* dblk = (const char*)p.slab + ((size_t)f * (size_t)p.field_stride) * 4 + ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes;
+    const char* dblk = (const char*)p.slab + (size_t)ck.base * 4 + ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes;
     const size_t tile_jump = (size_t)4 * p.n_steps * step_bytes;  // to the wave's block of the next tile
     const char* const qbase = (const char*)p.qt + w * 1024 + lane * 16;
     int s_next = 0, st_next = 0;
@@ -488,14 +477,14 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
             continue;
         }
         if (p.sample == 2) {
-            s1_sample_top2(p, f, chunk, t - t0, t, w, acc00, acc01, acc10, acc11);
+            s1_sample_top2(p, ck, t - t0, t, w, acc00, acc01, acc10, acc11);
             continue;
         }
         // barrier A.  Every wave is past the last k-step of the tile, so that step's ring slot is free: refill it NOW,
         // the HBM stream then keeps its depth through the epilogue instead of draining (the next step skips its issue).
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (issued < total) S1_ISSUE_NEXT();
-        s1_epilogue<S1_SCAP_F32>(p, st, f, t, w, wgq0, acc00, acc01, acc10, acc11);
+        s1_epilogue<S1_SCAP_F32>(p, st, ck.n_rows, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
 #undef S1_ISSUE_NEXT
     if (p.sample != 2) s1_flush<S1_SCAP_F32>(p, st, w, wgq0);
@@ -539,13 +528,14 @@ __device__ __forceinline__ void s1_body_x16(const S1Params& p) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
 
-    const int f = blockIdx.x / p.n_chunks;
+    const int chunk_id = p.chunk0 + (int)blockIdx.x;
+    const S1Chunk ck = p.chunks[chunk_id];            // workgroup-uniform (scalar loads)
+    const int f = ck.f;
     if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
-    const int chunk = blockIdx.x - f * p.n_chunks;
-    const int t0 = (int)(((long long)chunk * p.n_tiles) / p.n_chunks);
-    int t1 = (int)(((long long)(chunk + 1) * p.n_tiles) / p.n_chunks);
+    const int t0 = ck.t0;
+    int t1 = ck.t1;
     if (p.sample) t1 = min(t1, t0 + p.sample_tiles);
-    const size_t wgq0 = (size_t)blockIdx.x * 64;
+    const size_t wgq0 = (size_t)chunk_id * 64;
     s1_state_init(st, p, f);
 
     // granule of row (32*blk + j), k-half h inside a 2 KB tile (rows are 32 B)
@@ -554,8 +544,7 @@ __device__ __forceinline__ void s1_body_x16(const S1Params& p) {
     char* const dring = smem + w * (X::STAGES * 2048);
     const size_t step_bytes = 2048;
     const size_t tile_jump = (size_t)3 * p.n_steps * step_bytes;
-    const char* dnext = (const char*)p.slab + ((size_t)f * (size_t)p.field_stride) * 2 +
-                        ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes + lane * 16;
+    const char* dnext = (const char*)p.slab + (size_t)ck.base * 2 + ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes + lane * 16;
     // bf16: the 6 KB query tile is 6 pieces of 1 KB: waves 0-1 load pieces {2w, 2w+1}, waves 2-3 load piece 2+w (twice, so
     // that every wave issues the same number of loads per stage and the counted vmcnt waits stay uniform).
     // fp16: 4 pieces, wave w loads piece w.
@@ -641,12 +630,12 @@ __device__ __forceinline__ void s1_body_x16(const S1Params& p) {
             continue;
         }
         if (p.sample == 2) {
-            s1_sample_top2(p, f, chunk, t - t0, t, w, acc00, acc01, acc10, acc11);
+            s1_sample_top2(p, ck, t - t0, t, w, acc00, acc01, acc10, acc11);
             continue;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A + early refill (see the fp32 body)
         if (issued < total) S1X_ISSUE_NEXT();
-        s1_epilogue<S1_SCAP_LDS>(p, st, f, t, w, wgq0, acc00, acc01, acc10, acc11);
+        s1_epilogue<S1_SCAP_LDS>(p, st, ck.n_rows, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
 #undef S1X_ISSUE_NEXT
     if (p.sample != 2) s1_flush<S1_SCAP_LDS>(p, st, w, wgq0);
@@ -684,21 +673,21 @@ __device__ __forceinline__ void s1_body_x16r(const S1Params& p) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
 
-    const int f = blockIdx.x / p.n_chunks;
+    const int chunk_id = p.chunk0 + (int)blockIdx.x;
+    const S1Chunk ck = p.chunks[chunk_id];            // workgroup-uniform (scalar loads)
+    const int f = ck.f;
     if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
-    const int chunk = blockIdx.x - f * p.n_chunks;
-    const int t0 = (int)(((long long)chunk * p.n_tiles) / p.n_chunks);
-    int t1 = (int)(((long long)(chunk + 1) * p.n_tiles) / p.n_chunks);
+    const int t0 = ck.t0;
+    int t1 = ck.t1;
     if (p.sample) t1 = min(t1, t0 + p.sample_tiles);
-    const size_t wgq0 = (size_t)blockIdx.x * 64;
+    const size_t wgq0 = (size_t)chunk_id * 64;
     s1_state_init(st, p, f);
 
     // granule of row (32*blk + j), k-half h inside a 2 KB tile: the same offset in memory (docs) and in LDS (queries)
     const int off = j * 32 + ((h ^ ((j >> 3) & 1)) << 4);
     const size_t step_bytes = 2048;
     const size_t tile_jump = (size_t)3 * p.n_steps * step_bytes;
-    const char* dnext = (const char*)p.slab + ((size_t)f * (size_t)p.field_stride) * 2 +
-                        ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes + off;
+    const char* dnext = (const char*)p.slab + (size_t)ck.base * 2 + ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes + off;
     const int qp0 = MODE ? w : (w < 2 ? 2 * w : 2 + w), qp1 = w < 2 ? 2 * w + 1 : 2 + w;
     const char* const qbase = (const char*)p.qt + lane * 16;
     int s_next = 0;
@@ -706,7 +695,7 @@ __device__ __forceinline__ void s1_body_x16r(const S1Params& p) {
     // chunk's last stage (clamped address) and are never consumed.  A constant issue pattern keeps the compiler's own
     // waitcnt insertion for the doc registers precise (with conditional issues it has to assume the worst path and
     // drains the queue once per R steps).
-    const char* const dlast = (const char*)p.slab + ((size_t)f * (size_t)p.field_stride) * 2 +
+    const char* const dlast = (const char*)p.slab + (size_t)ck.base * 2 +
                               ((size_t)(4 * (t1 - 1) + w) * p.n_steps + (p.n_steps - 1)) * step_bytes + off;
     vec8 dr0[R], dr1[R];
     // the query-piece LDS-DMA goes through inline asm: hipcc treats a visible global_load_lds and plain global loads as
@@ -782,11 +771,11 @@ __device__ __forceinline__ void s1_body_x16r(const S1Params& p) {
             continue;
         }
         if (p.sample == 2) {
-            s1_sample_top2(p, f, chunk, t - t0, t, w, acc00, acc01, acc10, acc11);
+            s1_sample_top2(p, ck, t - t0, t, w, acc00, acc01, acc10, acc11);
             continue;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A (see the fp32 body)
-        s1_epilogue<X::SCAP>(p, st, f, t, w, wgq0, acc00, acc01, acc10, acc11);
+        s1_epilogue<X::SCAP>(p, st, ck.n_rows, t, w, wgq0, acc00, acc01, acc10, acc11);
     }
 #undef S1R_ISSUE
     // the stages issued past the end are still in flight: no LDS-DMA write may land after the workgroup has left

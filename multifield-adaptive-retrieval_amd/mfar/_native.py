@@ -46,6 +46,7 @@ SIGNATURES = {
     "mfar_index_write_rows": (_i, [_vp, _i, _i64, _i64, _vp, _i, _vp]),
     "mfar_index_read_rows": (_i, [_vp, _i, _i64, _i64, _vp, _i, _vp]),
     "mfar_retrieve_fields": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "mfar_retrieve_field": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "mfar_score_candidates": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "mfar_mix_topk": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "mfar_search_two_stage": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -57,8 +58,8 @@ SIGNATURES = {
     "mfar_lists_bytes": (_i64, [_i, _i, _i]),
     "mfar_topk_bytes": (_i64, [_i, _i]),
     "mfar_retrieve_lists": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
-    "mfar_search_owned": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "mfar_merge_topk": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mfar_search_owned": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mfar_merge_topk": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "mfar_stream_wait_stage1_start": (_i, [_vp, _vp]),
     "mfar_set_timing": (_i, [_vp, _i]),
     "mfar_stage1_timing": (_i, [_vp, _c.POINTER(_c.c_double), _c.POINTER(_i)]),
@@ -67,7 +68,7 @@ SIGNATURES = {
     "mfar_stage1_finish": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mfar_set_screen": (_i, [_vp, _i, _c.c_float]),
     "mfar_get_screen": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_float)]),
-    "mfar_screen_dup_group": (_i, [_vp, _i, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
+    "mfar_screen_field_info": (_i, [_vp, _i, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "mfar_screen_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
 }
 

@@ -159,6 +159,17 @@ class MultiFieldIndex:
                                                           int(qa.on_device), _current_stream(self.device, qa.on_device)))
         return ids, sc
 
+    def retrieve_field(self, field: int, q, top_k: int = 100, sentinel: bool = True):
+        """Stage 1 of ONE field (one `retrieve_batch` call of the reference's per-field loop): -> ids [Q, k], scores [Q, k]."""
+        qa = _Arg(q, np.float32, self.device)
+        Q = qa.keep.shape[0]
+        ids = _empty_like_side(qa.on_device, self.device, (Q, top_k), np.int64)
+        sc = _empty_like_side(qa.on_device, self.device, (Q, top_k), np.float32)
+        ia, sa = _Arg(ids, np.int64, self.device), _Arg(sc, np.float32, self.device)
+        _native.check(_native.lib().mfar_retrieve_field(self._h, int(field), qa.ptr, Q, int(top_k), int(bool(sentinel)), ia.ptr, sa.ptr,
+                                                         int(qa.on_device), _current_stream(self.device, qa.on_device)))
+        return ids, sc
+
     # ---- stage 2: DenseFlatIndex.score_batch for all fields (index.py:227-232) ----
     def score_candidates(self, q, cand):
         qa, ca = _Arg(q, np.float32, self.device), _Arg(cand, np.int64, self.device)
@@ -272,8 +283,9 @@ class MultiFieldIndex:
                                                         _current_stream(self.device, True)))
 
     def search_owned(self, gathered_lists, n_shards: int, q, W, topk, mask=None, k1: int = 100, k2: int = 100, sentinel: bool = True,
-                     query_cond: bool = True, slot: int = 0):
-        """Merge the gathered lists, score + mix the candidates this shard owns, write the local top-k2 payload."""
+                     query_cond: bool = True, slot: int = 0, any_fail=None):
+        """Merge the gathered lists, score + mix the candidates this shard owns, write the local top-k2 payload (which
+        also carries `any_fail`, this rank's certificate flag of the batch: a CUDA int32 tensor or None)."""
         qa, Wa = _Arg(q, np.float32, self.device), _Arg(W, np.float32, self.device)
         ma = _Arg(mask, np.float32, self.device, allow_none=True)
         ga, ta = _Arg(gathered_lists, np.uint8, self.device), _Arg(topk, np.uint8, self.device)
@@ -281,7 +293,8 @@ class MultiFieldIndex:
             raise ValueError("search_owned needs CUDA tensors")
         _native.check(_native.lib().mfar_search_owned(self._h, ga.ptr, int(n_shards), qa.ptr, qa.keep.shape[0], Wa.ptr,
                                                        int(bool(query_cond)), ma.ptr, int(k1), int(k2), int(bool(sentinel)), int(slot),
-                                                       ta.ptr, _current_stream(self.device, True)))
+                                                       None if any_fail is None else _dev_ptr(any_fail), ta.ptr,
+                                                       _current_stream(self.device, True)))
         return topk
 
     # instrumentation for bench.py
@@ -301,11 +314,12 @@ class MultiFieldIndex:
         Outputs are bit-identical in every mode; `eps_mult` is a test knob (1 = rigorous proof)."""
         _native.check(_native.lib().mfar_set_screen(self._h, int(mode), float(eps_mult)))
 
-    def screen_dup_group(self, field: int):
-        """(representative global row or -1, number of masked duplicates) of the field's duplicate group (include/mfar_hip.h)."""
-        rep, n = ctypes.c_int64(), ctypes.c_int64()
-        _native.check(_native.lib().mfar_screen_dup_group(self._h, int(field), ctypes.byref(rep), ctypes.byref(n)))
-        return rep.value, n.value
+    def screen_field_info(self, field: int):
+        """(distinct vectors of the field = rows the screened pass scans, size of its largest group of identical rows);
+        (-1, -1) while no screen is current (include/mfar_hip.h)."""
+        nu, big = ctypes.c_int64(), ctypes.c_int64()
+        _native.check(_native.lib().mfar_screen_field_info(self._h, int(field), ctypes.byref(nu), ctypes.byref(big)))
+        return nu.value, big.value
 
     @property
     def screen_setting(self):
@@ -318,7 +332,11 @@ class MultiFieldIndex:
         built, nbytes, chk, bad = ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         _native.check(_native.lib().mfar_screen_stats(self._h, ctypes.byref(built), ctypes.byref(nbytes), ctypes.byref(chk),
                                                       ctypes.byref(bad)))
-        return dict(built=bool(built.value), screen_bytes=nbytes.value, n_checked=chk.value, n_failed=bad.value)
+        st = dict(built=bool(built.value), screen_bytes=nbytes.value, n_checked=chk.value, n_failed=bad.value)
+        if st["built"]:
+            st["unique_rows"] = [self.screen_field_info(f)[0] for f in range(self.n_fields)]
+            st["scan_rows"] = sum(st["unique_rows"])
+        return st
 
 
 def merge_workspace_bytes(Q: int, n_fields: int, k1: int = 100) -> int:
@@ -349,8 +367,9 @@ def merge_payloads(payloads, n_shards: int, q, W, mask=None, n_fields: int = Non
     return dict(ids=ids, scores=sc, n_valid=nv)
 
 
-def merge_topk(gathered_topk, n_shards: int, Q: int, k2: int = 100, device: int = 0, out=None):
-    """Final merge of the all-gathered local top-k payloads (lists-first exchange)."""
+def merge_topk(gathered_topk, n_shards: int, Q: int, k2: int = 100, device: int = 0, out=None, any_fail=None):
+    """Final merge of the all-gathered local top-k payloads (lists-first exchange); `any_fail` (CUDA int32 tensor or None)
+    receives the OR of the ranks' certificate flags that travelled in the payloads."""
     ga = _Arg(gathered_topk, np.uint8, device)
     if not ga.on_device:
         raise ValueError("merge_topk needs CUDA tensors")
@@ -360,7 +379,7 @@ def merge_topk(gathered_topk, n_shards: int, Q: int, k2: int = 100, device: int 
     nv = out.get("n_valid") if out.get("n_valid") is not None else _empty_like_side(True, device, (Q,), np.int32)
     ia, sa, na = _Arg(ids, np.int64, device), _Arg(sc, np.float32, device), _Arg(nv, np.int32, device)
     _native.check(_native.lib().mfar_merge_topk(int(device), ga.ptr, int(n_shards), int(Q), int(k2), ia.ptr, sa.ptr, na.ptr,
-                                                _current_stream(device, True)))
+                                                None if any_fail is None else _dev_ptr(any_fail), _current_stream(device, True)))
     return dict(ids=ids, scores=sc, n_valid=nv)
 
 
@@ -452,12 +471,7 @@ class DenseFlatIndex(Index[str, str]):
 
     def retrieve_batch(self, queries: Union[np.ndarray, Sequence[str]], top_k: int):
         qe = self._encode(queries)
-        if self.slab.n_fields == 1:
-            ids, sc = self.slab.retrieve_fields(qe, top_k, sentinel=True)
-            ids, sc = ids[:, 0], sc[:, 0]
-        else:
-            ids, sc = self.slab.retrieve_fields(qe, top_k, sentinel=True)
-            ids, sc = ids[:, self.field_index], sc[:, self.field_index]
+        ids, sc = self.slab.retrieve_field(self.field_index, qe, top_k, sentinel=True)      # scans this field only
         ids_l, sc_l = ids.tolist(), sc.tolist()
         # ids are global row numbers == positions in numeric_ids_to_key (the corpus line order)
         return [list(zip([self.numeric_ids_to_key[j] for j in ids_l[i]], sc_l[i])) for i in range(len(queries))]

@@ -5,7 +5,8 @@ On the GPU the per-batch work is one long scan (stage 1: per-field exhaustive to
 gather-bound kernels around it.  `PipelinedSearcher` keeps the scans of consecutive batches back to back on a
 high-priority stream (`mfar_stage1_begin`: query prep, sample pass, scan, list merge) and runs everything that follows a
 scan -- exact re-scoring + certificate of the screened lists (`mfar_stage1_finish`), candidate union, stage 2, mixer;
-with several GPUs the two small all-gathers, `mfar_search_owned` and `mfar_merge_topk` -- on a side stream BESIDE the
+with several GPUs the two small all-gathers (the second also carries the certificate flag), `mfar_search_owned` and
+`mfar_merge_topk` -- on a side stream BESIDE the
 next batch's scan: the 16-bit scan kernels keep their doc tiles in registers, so those small kernels fit next to them
 on every CU.  Results are identical to `MultiFieldIndex.search` / `ShardedSearcher.search`.
 
@@ -86,10 +87,12 @@ class PipelinedSearcher:
         else:
             dist = torch.distributed
             dist.all_gather_into_tensor(s["lists_all"], s["lists"], group=self.group)
+            # the rank's certificate flag travels inside the top-k payload; merge_topk ORs the ranks' flags back into
+            # s["fail"], so every rank takes the same redo decision without a third collective
             self.ix.search_owned(s["lists_all"], self.world, qk, s["W"], s["topk"], s["mask"], self.k1, self.k2, self.sentinel,
-                                 self.query_cond, slot=slot)
+                                 self.query_cond, slot=slot, any_fail=s["fail"])
             dist.all_gather_into_tensor(s["topk_all"], s["topk"], group=self.group)
-            _index.merge_topk(s["topk_all"], self.world, Q, self.k2, device=self.ix.device, out=out)
+            _index.merge_topk(s["topk_all"], self.world, Q, self.k2, device=self.ix.device, out=out, any_fail=s["fail"])
 
     def submit(self, q) -> int:
         """q: [Q, E] float32 CUDA tensor (Q == max_batch for the sharded path: fixed payload size)."""
@@ -128,8 +131,6 @@ class PipelinedSearcher:
                 s["fail"].zero_()
             else:
                 self.ix.stage1_finish(qk, slot, fid, fsc, self.k1, self.sentinel, any_fail=s["fail"])
-                if self.world > 1:                    # every rank must take the same decision about a redo
-                    torch.distributed.all_reduce(s["fail"], op=torch.distributed.ReduceOp.MAX, group=self.group)
             self._tail(s, slot)
             s["fail_host"].copy_(s["fail"], non_blocking=True)
             s["done"].record(self.side)

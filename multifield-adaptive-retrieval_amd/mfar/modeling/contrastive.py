@@ -375,6 +375,7 @@ class RetrievalTrainingModule(torch.nn.Module):
             args["weights_learning_rate"] = 0.0
         module = cls(**args)
         module.load_reference_state_dict(ckpt["state_dict"])
+        module.eval()       # a module restored for evaluation: dropout off until the caller asks for .train()
         return module
 
     # buffers some transformers versions persist and others do not: their absence is not a layout mismatch

@@ -106,16 +106,20 @@ class SentenceEncoder(torch.nn.Sequential):
 def _tiny_random_model(spec: str):
     """'random-init:<hidden>x<layers>' -> a randomly initialised BERT + a character-level WordPiece tokenizer.
     For plumbing tests and smoke runs on boxes without checkpoints (there is no network)."""
-    import tempfile
-    from transformers import BertConfig, BertModel, BertTokenizerFast
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
+    from transformers import BertConfig, BertModel, PreTrainedTokenizerFast
     dims = spec.split(":", 1)[1] if ":" in spec else "64x2"
     hidden, layers = (int(x) for x in dims.split("x"))
-    chars = list("abcdefghijklmnopqrstuvwxyz0123456789.,:;!?-_'\"()/")
+    chars = list("abcdefghijklmnopqrstuvwxyz0123456789.,:;!?-_'\"()/{}[]")
     vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + chars + ["##" + c for c in chars]
-    d = tempfile.mkdtemp(prefix="mfar_tok_")
-    with open(os.path.join(d, "vocab.txt"), "w") as f:
-        f.write("\n".join(vocab) + "\n")
-    tok = BertTokenizerFast(vocab_file=os.path.join(d, "vocab.txt"), do_lower_case=True)
+    ids = {t: i for i, t in enumerate(vocab)}
+    tk = Tokenizer(models.WordPiece(vocab=ids, unk_token="[UNK]", max_input_chars_per_word=200))
+    tk.normalizer = normalizers.BertNormalizer(lowercase=True)
+    tk.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    tk.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", pair="[CLS] $A [SEP] $B:1 [SEP]:1",
+                                                      special_tokens=[("[CLS]", ids["[CLS]"]), ("[SEP]", ids["[SEP]"])])
+    tok = PreTrainedTokenizerFast(tokenizer_object=tk, unk_token="[UNK]", pad_token="[PAD]", cls_token="[CLS]", sep_token="[SEP]",
+                                  mask_token="[MASK]")
     cfg = BertConfig(vocab_size=len(vocab), hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=max(1, hidden // 32),
                      intermediate_size=hidden * 4, max_position_embeddings=512)
     torch.manual_seed(0)

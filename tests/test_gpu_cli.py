@@ -52,6 +52,7 @@ def _oracle_eval(module, dm, mask=None):
     slab = np.stack([module.slab.read_rows(f) for f in range(F)])
     W = module.mixture_of_fields_layer.weight.detach().cpu().numpy()
     want = {}
+    module.eval()
     for batch in dm.test_dataloader()[0]:
         with torch.no_grad():
             qe = module.encode_query_batch(batch).cpu().numpy()

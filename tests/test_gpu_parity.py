@@ -691,14 +691,16 @@ def test_screen_massive_ties_and_huge_values(idxmod):
     """Thousands of NEAR-identical rows at the top of every list (the same vector up to the last bits, as batched encoder
     forwards of one text produce) are no duplicate group, and their approximate scores cannot separate the k-th from the
     k'-th entry: the certificate must fail, the exact pass must take over, and the canonical tie-break must hold.
-    Bit-identical rows, in contrast, are masked and re-inserted (test_screen_duplicate_group_is_masked_and_reinserted).
+    Bit-identical rows, in contrast, are scanned once and expanded (test_screen_scans_unique_rows_and_expands_groups).
     A row with huge finite values overflows the norm statistics."""
     rng = np.random.default_rng(13)
     F, D, E, Q, k = 2, 20000, 64, 9, 100
     slab, q, _ = _mk(rng, F, D, E, Q)
     top = q.mean(0) * 3.0
     rows = rng.choice(D, size=3000, replace=False)
-    slab[0, rows] = top * (1.0 + rng.integers(-2, 3, size=(3000, 1)).astype(np.float32) * np.float32(2.0 ** -22))
+    # 3000 DISTINCT vectors (bit-identical rows would simply be scanned once), equal up to the last bits
+    slab[0, rows] = top * (1.0 + np.arange(3000, dtype=np.float32)[:, None] * np.float32(2.0 ** -22))
+    assert len(np.unique(slab[0, rows], axis=0)) == 3000
     ix = _load(idxmod, slab)
     ix.set_screen(2)
     _check_stage1(ix, slab, q, k, True, "near ties")
@@ -781,33 +783,62 @@ def test_screen_anisotropic_embeddings_are_certified(idxmod):
     ix.close()
 
 
-def test_screen_duplicate_group_is_masked_and_reinserted(idxmod):
-    """A field missing from a document is encoded from the empty string (format.py:58-59): one large group of IDENTICAL rows
-    per field.  Such a group defeats the certificate when it reaches the top of a list (equal approximate scores); the
-    screen scans only its lowest row and the certify step re-inserts the others (same score, ids ascending).  Here the
-    shared vector is every query's best match in field 0 and mediocre in field 1: no list may fall back, every bit must
-    match the oracle, also across shards (each shard handles its own part of the group)."""
+def test_screen_scans_unique_rows_and_expands_groups(idxmod):
+    """Real fields are full of bit-identical rows: "" for every document that lacks the field (format.py:58-59), a handful of
+    texts in low-cardinality fields (schema.py:11-53), every repeated text encoded once by on_eval_start.  The screen scans
+    each distinct vector once and the certify step expands a selected vector to its documents (same score, ids ascending).
+      field 0: FOUR large groups (9000 / 4000 / 2500 / 700 rows) that are every query's best matches, in that order
+      field 1: one ordinary group of 5000 rows + a Zipf-like tail of small groups
+      field 2: ten distinct vectors in the whole field
+      field 3: no duplicates
+    No list may fall back to the exact pass, every bit must match the oracle -- also across shards (each shard groups its own
+    rows) and through the single-field entry point."""
     rng = np.random.default_rng(17)
-    F, D, E, Q, k = 3, 24000, 96, 40, 100
+    F, D, E, Q, k = 4, 24000, 96, 40, 100
     slab, q, W = _mk(rng, F, D, E, Q)
-    top = (q.mean(0) * 3.0).astype(np.float32)
-    g0 = np.sort(rng.choice(D, size=9000, replace=False))
-    slab[0, g0] = top                                        # field 0: 9000 identical rows, best match of every query
+    top = (q.mean(0) * 8.0).astype(np.float32)               # far above every ordinary row, for every query
+    perm = rng.permutation(D)
+    sizes = [9000, 4000, 2500, 700]
+    lo = 0
+    for gi, n in enumerate(sizes):
+        slab[0, perm[lo:lo + n]] = top * np.float32(1.0 - 0.05 * gi)       # best, second best, ... of every query
+        lo += n
     g1 = np.sort(rng.choice(D, size=5000, replace=False))
-    slab[1, g1] = slab[1, g1[0]]                             # field 1: 5000 identical ordinary rows
+    slab[1, g1] = slab[1, g1[0]]
+    rest = np.setdiff1d(np.arange(D), g1)
+    for gsz in (300, 120, 64, 30, 30, 9, 2, 2):                             # a tail of smaller groups
+        pick = rng.choice(rest, size=gsz, replace=False)
+        slab[1, pick] = slab[1, pick[0]]
+    texts = rng.integers(0, 10, size=D)
+    slab[2] = slab[2, :10][texts]
     ix = _load(idxmod, slab)
     ix.set_screen(2)
     for sentinel in (True, False):
-        _check_stage1(ix, slab, q, k, sentinel, ("dup group", sentinel))
-    assert ix.screen_dup_group(0) == (int(g0[0]), 8999) and ix.screen_dup_group(1) == (int(g1[0]), 4999)
-    assert ix.screen_dup_group(2)[0] == -1
+        _check_stage1(ix, slab, q, k, sentinel, ("unique rows", sentinel))
+    nu = [ix.screen_field_info(f) for f in range(F)]
+    assert nu[0] == (D - sum(sizes) + 4, 9000), nu
+    assert nu[2] == (10, int(np.bincount(texts).max())) and nu[3] == (D, 1), nu
+    assert nu[1][1] == 5000 and nu[1][0] == len(np.unique(slab[1], axis=0)), nu
     st = ix.screen_stats()
-    assert st["n_failed"] == 0, st                           # no exact fall-back despite the 9000-way tie at the top
-    r = ix.search(q, W, None)
+    assert st["n_failed"] == 0 and st["unique_rows"] == [n for n, _ in nu], st      # no exact fall-back despite the ties
+    assert st["screen_bytes"] < D * F * E * 2                                       # the slab holds unique rows only
+    r = ix.search(q, W, None, return_fields=True)
     o = O.c_two_stage(slab, q, W, None)
     assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32))
+    # field 0's lists: the 100 lowest ids of the best group (one score), field 2's: the best text's documents
+    assert all(len(set(r["field_scores"][i, 0].tolist())) == 1 for i in range(Q))
+    assert np.array_equal(r["field_ids"][:, 0], np.broadcast_to(np.sort(perm[:9000])[:100], (Q, 100)))
+    # the single-field entry point (what DenseFlatIndex.retrieve_batch calls) gives the same lists
+    for f in range(F):
+        ids, sc = ix.retrieve_field(f, q, k, True)
+        assert np.array_equal(ids, o["field_ids"][:, f]) and np.array_equal(sc.view(np.uint32), o["field_scores"][:, f].view(np.uint32)), f
+    assert ix.screen_stats()["n_failed"] == 0
+    ix.set_screen(0)
+    for f in (0, 2):
+        ids, sc = ix.retrieve_field(f, q, k, True)
+        assert np.array_equal(ids, o["field_ids"][:, f]) and np.array_equal(sc.view(np.uint32), o["field_scores"][:, f].view(np.uint32)), f
     ix.close()
-    # sharded: the group is split over the shards, each shard masks / re-inserts its own members
+    # sharded: the groups are split over the shards, each shard finds and expands its own members
     bounds = [0, 7001, 15000, D]
     shards = [_load(idxmod, slab[:, bounds[i]:bounds[i + 1]], row_offset=bounds[i]) for i in range(3)]
     import torch
@@ -822,6 +853,30 @@ def test_screen_duplicate_group_is_masked_and_reinserted(idxmod):
     assert all(s_.screen_stats()["n_failed"] == 0 for s_ in shards)
     for s_ in shards:
         s_.close()
+
+
+def test_screen_tied_scores_of_distinct_vectors(idxmod):
+    """Distinct vectors with EXACTLY equal scores (values on a coarse grid: all arithmetic exact) around the k-th place:
+    the expansion must interleave their documents by id; when more tied vectors exist than the certify step looks at, the
+    exact pass decides.  Bits equal the oracle either way."""
+    rng = np.random.default_rng(18)
+    F, D, E, Q, k = 1, 20000, 32, 6, 100
+    slab = (rng.integers(-8, 9, size=(F, D, E)) / 8.0).astype(np.float32)
+    q = (rng.integers(-8, 9, size=(Q, E)) / 8.0).astype(np.float32)
+    # 40 distinct vectors that all score the same against query 0: swap two coordinates where q[0] has equal entries
+    base = slab[0, 0].copy()
+    eq = [(a, b) for a in range(E) for b in range(a + 1, E) if q[0, a] == q[0, b] and base[a] != base[b]]
+    rows = rng.choice(np.arange(1, D), size=1200, replace=False)
+    for j, r_ in enumerate(rows):
+        v = base.copy()
+        a, b = eq[j % min(len(eq), 40)]
+        v[a], v[b] = v[b], v[a]
+        slab[0, r_] = v * 4.0                                    # far above everything else for query 0
+    ix = _load(idxmod, slab)
+    ix.set_screen(2)
+    for sentinel in (True, False):
+        _check_stage1(ix, slab, q, k, sentinel, ("tied distinct vectors", sentinel))
+    ix.close()
 
 
 # ------------------------------------------------------------------------------------------------ larger goldens (SURVEY 8(c) sizes)
