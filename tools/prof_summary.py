@@ -54,3 +54,44 @@ if "--traffic-json" in sys.argv:
                "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; on gfx950 FETCH_SIZE reports half "
                        "the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM section): read bytes = 2 x FETCH_SIZE x 1024"},
               open(out, "w"), indent=1)
+
+
+# optional: --counters-json <out.json> <fetch_dir> <write_dir> <sq_dir> <source_hash> D F E Q N
+#   -> per mfar kernel: HBM bytes per launch (2 x FETCH_SIZE KB + WRITE_SIZE KB) and MFMA utilisation
+#      (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x shader cycles); GRBM_GUI_ACTIVE is summed over the 8 XCDs).
+#   bench.py quotes these counters only when source_hash and shape match the run (profile_counters()).
+if "--counters-json" in sys.argv:
+    import json
+    i = sys.argv.index("--counters-json")
+    out, fdir, wdir, sdir, shash = sys.argv[i + 1:i + 6]
+    shape = [int(x) for x in sys.argv[i + 6:i + 11]]
+    def table(d, off=False):
+        # <d>/off/ holds the --screen off pass of the same counter set: only its exact fp32 scan kernels are taken from there
+        acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(lambda: defaultdict(int))
+        for fn in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
+            in_off = (os.sep + "off" + os.sep) in fn
+            for r in csv.DictReader(open(fn)):
+                if in_off != short(r["Kernel_Name"]).startswith("mfar_stage1_kernel") and os.path.isdir(os.path.join(d, "off")): continue
+                k = short(r["Kernel_Name"])
+                if "mfar" not in k: continue
+                acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
+        return {k: {c: acc[k][c] / cnt[k][c] for c in acc[k]} for k in acc}, {k: max(cnt[k].values()) for k in cnt}
+    tf, nf = table(fdir); tw, _ = table(wdir); ts, _ = table(sdir)
+    kernels = {}
+    for k in sorted(set(tf) | set(ts)):
+        e = {"launches_in_fetch_pass": nf.get(k, 0)}
+        if k in tf and "FETCH_SIZE" in tf[k]:
+            rd = 2.0 * tf[k]["FETCH_SIZE"] * 1024
+            wr = tw.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
+            e.update(hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr)
+        s = ts.get(k, {})
+        if s.get("GRBM_GUI_ACTIVE"):
+            cyc = s["GRBM_GUI_ACTIVE"] / 8.0
+            e["mfma_util"] = s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4 * 256 * cyc)
+            e["lds_bank_conflict_cycles"] = s.get("SQ_LDS_BANK_CONFLICT")
+            e["sq_wave_cycles"] = s.get("SQ_WAVE_CYCLES")
+        kernels[k] = e
+    json.dump({"source_hash": shash, "shape": shape, "shape_is": "docs, fields, dim, query batch, gpus",
+               "method": "rocprofv3 --kernel-trace --pmc, one pass each for FETCH_SIZE, WRITE_SIZE and the SQ/GRBM set; HBM read bytes = "
+                         "2 x FETCH_SIZE x 1024 on gfx950 (MI355X_MICROARCH.md, HBM section); averages per launch",
+               "kernels": kernels}, open(out, "w"), indent=1)
