@@ -76,10 +76,12 @@ def profile_counters(kernel: str, shape) -> dict:
     return {"traffic": None, "mfma_util": None, "counters_source": None}
 
 
-def s1_kernel_name(dtype, screened, E):
+def s1_kernel_name(dtype, screened, E, wide=False):
     rr = "" if os.environ.get("MFAR_S1_REGRING", "1") == "0" else ("r" if (E // 16) % 6 == 0 else ("r4" if (E // 16) % 4 == 0 else ""))
     if dtype == "bf16":
         return f"mfar_stage1_bf16{rr}_kernel"
+    if screened and wide:
+        return "mfar_stage1_f16w_kernel" if (E // 16) % 6 == 0 else "mfar_stage1_f16w4_kernel"
     return f"mfar_stage1_f16{rr}_kernel" if screened else "mfar_stage1_kernel"
 
 
@@ -98,6 +100,7 @@ def main():
                     help="f32 only: certified fp16 screening of stage 1 (bit-identical results; csrc/mfar_screen.h)")
     ap.add_argument("--corpus", choices=["plain", "structured"], default="plain",
                     help="structured: realistic duplicate / norm structure in three of the fields (mfar/synth.py)")
+    ap.add_argument("--coalesce", type=int, default=0, help="batches scanned per launch (0 = auto: 2 when the wide screened pass is available)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the exact-fp32 leg and the structured-corpus leg")
     ap.add_argument("--cpu-sample-docs", type=int, default=0, help="0 = the full corpus when host RAM allows, else 100000")
@@ -163,20 +166,22 @@ def main():
 
     # Two-deep pipeline: stage 1 of batch i+1 (main stream) overlaps the tail of batch i (side stream).  Every batch is
     # still processed completely inside the timed region (the region ends with a full device synchronisation).
-    ps = PipelinedSearcher(ix, W, mask, k1=K1, k2=K2, sentinel=True, query_cond=True, max_batch=Q)
+    ps = PipelinedSearcher(ix, W, mask, k1=K1, k2=K2, sentinel=True, query_cond=True, max_batch=Q, coalesce=args.coalesce or None)
 
     def run(searcher, cp, first, n, keep):
-        prev = None
-        for i in range(n):
-            t = searcher.submit(cp.queries((first + i) * Q, Q))
-            if prev is not None and keep is not None:
-                r = searcher.result(prev)
-                keep.append((r["ids"].clone(), r["scores"].clone(), r["n_valid"].clone()))
-            prev = t
-        if prev is not None:
-            r = searcher.result(prev)
+        # results are taken `lag` submissions late, so that two launches of the pipeline stay in flight (a launch scans one
+        # batch, or two coalesced ones when the index offers the wide screened pass: mfar/data/pipeline.py)
+        tickets = []
+        def take(t):
+            r = searcher.result(t)
             if keep is not None:
                 keep.append((r["ids"].clone(), r["scores"].clone(), r["n_valid"].clone()))
+        for i in range(n):
+            tickets.append(searcher.submit(cp.queries((first + i) * Q, Q)))
+            if i >= searcher.lag:
+                take(tickets[i - searcher.lag])
+        for t in tickets[max(0, n - searcher.lag):]:
+            take(t)
 
     def timed(searcher, index, cp, first, steps, keep):
         torch.cuda.synchronize()
@@ -216,10 +221,12 @@ def main():
     exact_leg = None
     if args.dtype == "f32" and screened and not args.no_extra_legs:
         ix.set_screen(0)
-        run(ps, corpus, 0, 2, None)
+        ps_ex = PipelinedSearcher(ix, W, mask, k1=K1, k2=K2, sentinel=True, query_cond=True, max_batch=Q)   # 64 queries per exact pass
+        run(ps_ex, corpus, 0, 2, None)
         ex_res = []
         ex_steps = min(8, args.steps)
-        ex_dt, ex_ms, ex_n = timed(ps, ix, corpus, args.warmup + args.steps - ex_steps, ex_steps, ex_res)
+        ex_dt, ex_ms, ex_n = timed(ps_ex, ix, corpus, args.warmup + args.steps - ex_steps, ex_steps, ex_res)
+        del ps_ex
         ix.set_screen(1)
         same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(results[-ex_steps:], ex_res))
         if not same:
@@ -253,7 +260,7 @@ def main():
         n_scan_rows = scr.get("scan_rows", (row1 - row0) * F) if screened else (row1 - row0) * F
         esize = 2 if (args.dtype == "bf16" or screened) else 4
         bytes_per_launch = float(n_scan_rows) * E * esize        # the scanned rows are read once per batch
-        s1_kernel = s1_kernel_name(args.dtype, screened, E)
+        s1_kernel = s1_kernel_name(args.dtype, screened, E, wide=ps.Qmax > 64)
         achieved_tf = flops_per_launch / (s1_avg_ms * 1e-3) / 1e12 if s1_avg_ms > 0 else 0.0
         gbps = bytes_per_launch / (s1_avg_ms * 1e-3) / 1e9 if s1_avg_ms > 0 else 0.0
         counters = profile_counters(s1_kernel, (D, F, E, Q, N))
@@ -262,7 +269,7 @@ def main():
                 {"bound": "hbm", "kernel": s1_kernel, "achieved": gbps, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBS})
         roof.update(counters)
         roof.update({
-            "avg_launch_ms": s1_avg_ms, "launches": s1_n,
+            "avg_launch_ms": s1_avg_ms, "launches": s1_n, "queries_per_launch": ps.Qmax,
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "algorithmic_bytes_definition": (
                 f"{n_scan_rows} scanned rows x {E} dims x {esize} B: the " +
@@ -285,8 +292,11 @@ def main():
                        "docs": D, "fields": F, "dim": E, "query_batch": Q, "k1": K1, "k2": K2, "timed_queries": args.steps * Q,
                        "parallelism": (f"row-shard x{N}, lists-first exchange over RCCL (per batch: all-gather of the stage-1 lists, "
                                        f"all-gather of the local top-k + certificate flag)") if N > 1 else "single shard",
-                       "pipeline": "2 batches in flight (stage 1 of batch i+1 overlaps the tail of batch i)"},
-            "stage1": ("certified fp16 screen of the fp32 slab (min(k+92,192) rows per list re-scored with the exact fp32 chain, top-k "
+                       "pipeline": (f"2 launches in flight (stage 1 of launch i+1 overlaps the tail of launch i); a launch scans {ps.coalesce} "
+                                    f"coalesced batch(es) of {Q} queries" + (" with the wide 128-column screened pass (one fp16 query term)"
+                                                                             if ps.Qmax > 64 else "")),
+                       "queries_per_launch": ps.Qmax},
+            "stage1": ("certified fp16 screen of the fp32 slab (min(k+92,192) unique rows per list re-scored with the exact fp32 chain, top-k "
                        "proven or redone by the exact fp32 pass per field): outputs bit-identical to the plain fp32 pass" if screened else
                        ("exact fp32 MFMA pass" if args.dtype == "f32" else "bf16 slab pass")),
             "screen": ({"lists_certified": (scr["n_checked"] - scr0["n_checked"]) - (scr["n_failed"] - scr0["n_failed"]),
@@ -326,7 +336,7 @@ def structured_leg(synth, idxmod, PipelinedSearcher, run, dev, E, Q, torch, np):
     # same bits with the screen off (two batches)
     ix.set_screen(0)
     ex = []
-    run(ps, cp, 3, 2, ex)
+    run(PipelinedSearcher(ix, cp.W, torch.ones(F, device=dev), k1=K1, k2=K2, max_batch=Q), cp, 3, 2, ex)
     torch.cuda.synchronize()
     same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(keep[:2], ex))
     rec = []

@@ -180,7 +180,7 @@ int mfar_merge_topk(int device, const void* gathered_topk, int n_shards, int Q, 
 int mfar_stream_wait_stage1_start(mfar_index* idx, void* stream);
 
 /*
- * Split-phase stage 1 for pipelined callers (device pointers, Q <= 64, asynchronous on `stream`).
+ * Split-phase stage 1 for pipelined callers (device pointers, Q <= mfar_max_split_batch(), asynchronous on `stream`).
  *   mfar_stage1_begin   query preparation, sample pass, the long scan and the list merge of batch `slot` (two slots,
  *                       0 / 1).  Without the fp16 screen this already leaves the final lists in field_ids / field_scores.
  *   mfar_stage1_finish  with the screen: exact re-scoring of the min(k + 92, 192) screened rows per list and the certificate ->
@@ -197,6 +197,20 @@ int mfar_stream_wait_stage1_start(mfar_index* idx, void* stream);
  */
 int mfar_stage1_begin(mfar_index* idx, const float* q, int Q, int k, int sentinel, int slot, int64_t* field_ids,
                       float* field_scores, void* stream);
+/*
+ * The WIDE screened pass.  The screened scan is HBM-bound with the MFMA pipe at ~40 %: two fp16 query terms x 64 queries.
+ * A block of 65 .. 128 queries is scanned with ONE fp16 term per query instead (mfar_stage1_f16w_kernel): the same MFMA
+ * work per byte, the screen slab read once per 128 queries instead of once per 64.  The certificate's error bound includes
+ * the query rounding (about 2x the two-term bound); outputs stay bit-identical to the exhaustive fp32 pass, lists whose
+ * proof fails are redone exactly as before.  Every entry point that takes Q queries cuts them into blocks of 128 (wide)
+ * while more than 64 remain, so callers with larger batches (the reference's dev_batch_size is 64, train.py:45; pipelined
+ * callers may coalesce two batches: mfar.data.pipeline) halve the scan bytes per query.
+ *   mfar_max_split_batch  queries one mfar_stage1_begin / finish batch may hold: 128 when the wide pass is available for
+ *                         this index and depth k (builds the screen slab if it is not current), else 64.
+ *   mfar_set_wide         0: never use the wide pass (every block is 64 queries); default 1.  Environment: MFAR_WIDE.
+ */
+int mfar_max_split_batch(mfar_index* idx, int k);
+int mfar_set_wide(mfar_index* idx, int enable);
 int mfar_stage1_finish(mfar_index* idx, const float* q, int Q, int k, int sentinel, int slot, int64_t* field_ids,
                        float* field_scores, int32_t* any_fail, void* stream);
 

@@ -111,6 +111,7 @@ struct mfar_index {
         DevBuf qt, lists, list_cnt, gtau, samp;                          // any pass
         DevBuf qt16, qinfo, eps, base, fail, sids, ssc, scnt, sx;        // fp16 screen
         bool screened = false;                                          // decided by the begin phase of the batch
+        int qw = 64;                                                    // query columns of the batch's pass (128: wide screen pass)
     } s1[2];
     DevBuf fid, fsc, cand[2], ncand[2], x[2], own[2], in[8], out[8];
     // certified fp16 screen of an fp32 index (mfar_screen.h)
@@ -127,6 +128,7 @@ struct mfar_index {
     DevBuf u_rep, u_start, u_count, u_members, u_n;
     std::vector<int> n_unique, largest_group;   // per field (host copies)
     bool screen_dedup = true;     // MFAR_SCREEN_DEDUP=0: every document is its own unique row (diagnostic)
+    bool wide = true;             // blocks of 65 .. 128 queries go through the wide screened pass (MFAR_WIDE=0: always 64 per pass)
     S1Geom geom_docs, geom_screen;
     hipEvent_t mid_ev = nullptr;  // recorded right before the full stage-1 kernel is launched
     bool timing = false;
@@ -161,6 +163,10 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16r4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HR4_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16r4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BR4_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16r4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BR4_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW4_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW4_LDS_BYTES));
     g_attr_done[device] = true;
     return MFAR_OK;
 }
@@ -213,6 +219,7 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     if (const char* e = getenv("MFAR_SCREEN")) idx->screen_mode = atoi(e);
     if (const char* e = getenv("MFAR_SCREEN_EPS_MULT")) idx->screen_eps_mult = (float)atof(e);
     if (const char* e = getenv("MFAR_SCREEN_DEDUP")) idx->screen_dedup = atoi(e) != 0;
+    if (const char* e = getenv("MFAR_WIDE")) idx->wide = atoi(e) != 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) idx->n_cu = prop.multiProcessorCount;
     hipError_t e = hipMalloc(&idx->slab, idx->slab_bytes);
@@ -462,6 +469,19 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
     // (measured: 2 tiles pay off for the HBM-bound 16-bit passes, 1 for the MFMA-bound fp32 pass)
     static const int sample_div = getenv("MFAR_SAMPLE_DIV") ? atoi(getenv("MFAR_SAMPLE_DIV")) : 12;
     int sample_tiles = (int)std::max(1LL, std::min<long long>(sample_tiles_max, total_tiles / std::max(1LL, n_chunks) / sample_div));
+    // Short chunks (small shards, many fields): the sample yields a threshold only when it publishes at least k values per
+    // (query, field) -- 8 per sampled tile -- and a useful one from about 3 k.  Without a threshold every list compacts on
+    // nearly every tile.  Spend up to a sixth of a chunk on it.
+    {
+        int min_cf = 1 << 30;
+        long long min_tiles_per_chunk = 1LL << 40;
+        for (int f = 0; f < F; ++f) {
+            min_cf = std::min(min_cf, cf[f]);
+            min_tiles_per_chunk = std::min<long long>(min_tiles_per_chunk, g.n_tiles[f] / std::max(1, cf[f]));
+        }
+        const int st_cap = (int)std::max(1LL, min_tiles_per_chunk / 6);
+        while (sample_tiles < st_cap && 8LL * min_cf * sample_tiles < 3LL * k) ++sample_tiles;
+    }
     while (sample_tiles > 1 && 8 * t.max_chunks * sample_tiles > 2048) --sample_tiles;
     t.sample_tiles = sample_tiles;
     t.samp_stride = 0;
@@ -505,12 +525,20 @@ struct S1Out {
     int sentinel;     // padding convention of the output lists
     long long row_offset;   // added to the local rows of the lists (0: the lists hold unique-row numbers)
 };
-enum { S1_F32 = 0, S1_BF16 = 1, S1_F16 = 2 };
+enum { S1_F32 = 0, S1_BF16 = 1, S1_F16 = 2, S1_F16W = 3 };   // S1_F16W: the wide (128-query, one fp16 term) screen pass
 static int launch_s1(int kind, bool sample, unsigned grid, hipStream_t st, const S1Params& p) {
     const dim3 g(grid), b(S1_THREADS);
     if (kind == S1_F32) {
         if (sample) mfar_stage1_sample_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
         else mfar_stage1_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
+    } else if (kind == S1_F16W) {
+        if (p.n_steps % 6 == 0) {
+            if (sample) mfar_stage1_f16w_sample_kernel<<<g, b, S1HW_LDS_BYTES, st>>>(p);
+            else mfar_stage1_f16w_kernel<<<g, b, S1HW_LDS_BYTES, st>>>(p);
+        } else {
+            if (sample) mfar_stage1_f16w4_sample_kernel<<<g, b, S1HW4_LDS_BYTES, st>>>(p);
+            else mfar_stage1_f16w4_kernel<<<g, b, S1HW4_LDS_BYTES, st>>>(p);
+        }
     } else {
         // register-ring variants (docs straight into VGPRs, 25 / 37 KB of LDS) when the k-steps divide into the 6 register slots
         static const bool regring = !(getenv("MFAR_S1_REGRING") && atoi(getenv("MFAR_S1_REGRING")) == 0);
@@ -546,14 +574,15 @@ enum { S1_PREPARE = 1, S1_SCAN = 2, S1_FINISH = 4, S1_CERTIFY = 8, S1_ALL = 15 }
 static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, int f0, int nf, int phases, int kind, const void* slab,
                        const void* qt, int qt_n, int k, float tau0, const float* tau_base, const int* only_failed, bool record,
                        const S1Out& o, hipStream_t st) {
+    const int qw = kind == S1_F16W ? 128 : 64;   // query columns of the pass: stride of every per-query table below
     const bool solo = nf != idx->F;
     S1Table& tb = solo ? geom.solo : geom.all;
     static const int sample_tiles_env = getenv("MFAR_SAMPLE_TILES") ? atoi(getenv("MFAR_SAMPLE_TILES")) : 0;
     RETCHK(build_table(idx, geom, tb, k, solo, sample_tiles_env > 0 ? sample_tiles_env : (kind == S1_F32 ? 1 : 2), st));
     const int c_lo = tb.fchunk[f0], c_hi = tb.fchunk[f0 + nf];
-    RETCHK(sl.lists.ensure((size_t)tb.n_chunks * 64 * S1_CAP * sizeof(uint2)));
-    RETCHK(sl.list_cnt.ensure((size_t)tb.n_chunks * 64 * sizeof(int)));
-    RETCHK(sl.gtau.ensure((size_t)idx->F * 64 * sizeof(float)));
+    RETCHK(sl.lists.ensure((size_t)tb.n_chunks * qw * S1_CAP * sizeof(uint2)));
+    RETCHK(sl.list_cnt.ensure((size_t)tb.n_chunks * qw * sizeof(int)));
+    RETCHK(sl.gtau.ensure((size_t)idx->F * qw * sizeof(float)));
     S1Params p = {};
     p.slab = slab;
     p.qt = qt;
@@ -563,6 +592,7 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
     p.chunk0 = c_lo;
     p.n_steps = idx->n_steps;
     p.Q = qt_n;
+    p.qw = qw;
     p.k = k;
     p.tau0 = tau0;
     p.gtau = tau_base;
@@ -585,6 +615,7 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
     m.k = k;
     m.q0 = o.q0;
     m.sentinel = o.sentinel;
+    m.qw = qw;
     m.cnt_out = nullptr;
     m.only_failed = only_failed;
     const int n_keys = tb.max_chunks * k;
@@ -619,14 +650,14 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
         if (phases & S1_PREPARE) {
             S1Params ps = p;
             ps.sample = 2;
-            RETCHK(sl.samp.ensure((size_t)idx->F * tb.samp_stride * 128 * sizeof(float)));
+            RETCHK(sl.samp.ensure((size_t)idx->F * tb.samp_stride * 2 * qw * sizeof(float)));
             ps.samp_out = sl.samp.as<float>();
             RETCHK(launch_s1(kind, true, grid, st, ps));
-            const dim3 tg((64 * nf + 3) / 4), tb_(256);
+            const dim3 tg((qw * nf + 3) / 4), tb_(256);
             const int* sn = tb.d_samp_n.as<int>();
-            if (2 * tb.samp_stride <= 512) mfar_sample_tau_kernel<8><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>());
-            else if (2 * tb.samp_stride <= 1024) mfar_sample_tau_kernel<16><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>());
-            else mfar_sample_tau_kernel<32><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>());
+            if (2 * tb.samp_stride <= 512) mfar_sample_tau_kernel<8><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>(), qw);
+            else if (2 * tb.samp_stride <= 1024) mfar_sample_tau_kernel<16><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>(), qw);
+            else mfar_sample_tau_kernel<32><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>(), qw);
             HIPCHK(hipGetLastError());
         }
         p.gtau = sl.gtau.as<float>();
@@ -828,22 +859,29 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
     return MFAR_OK;
 }
 
-// One block of <= 64 queries (rows q0 .. of q) through stage 1 for fields [f0, f0 + nf).  all pointers are device pointers;
-// fid/fsc are [Q, nf, k].
+// the wide pass exists as 6-slot and 4-slot register-ring kernels: the k-steps must divide into one of them
+static bool wide_ok(const mfar_index* idx) { return idx->wide && (idx->n_steps % 6 == 0 || idx->n_steps % 4 == 0); }
+
+// One block of queries (rows q0 .. of q) through stage 1 for fields [f0, f0 + nf): 64 per block, or up to 128 when the
+// wide screened pass applies (more than 64 queries left, screen available).  all pointers are device pointers; fid/fsc are
+// [Q, nf, k].  *n_done (may be nullptr) = queries of this block.
 //   any_fail_out  nullptr: a failed certificate is repaired here by the exact pass (always launched, idle when nothing
 //                 failed); non-null (device int): only report -- the caller re-runs the batch exactly when it reads != 0
 static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, int Q, int q0, int k, int sentinel, int f0, int nf,
-                        long long* fid, float* fsc, int* any_fail_out, hipStream_t st) {
+                        long long* fid, float* fsc, int* any_fail_out, hipStream_t st, int* n_done = nullptr) {
     mfar_index::S1Slot& sl = idx->s1[slot];
     const float tau0 = sentinel ? 0.0f : -INFINITY;
     const int F = idx->F, kp = std::min(k + SCREEN_EXTRA, SCREEN_MAX_KP);
-    const int qt_n = std::min(64, Q - q0);
     const bool bf16 = idx->dtype == MFAR_DTYPE_BF16;
     if (phases & S1_PREPARE) {
         bool screened = false;
         if (screen_wanted(idx, k)) RETCHK(ensure_screen(idx, st, &screened));
         sl.screened = screened;
+        sl.qw = (screened && wide_ok(idx) && Q - q0 > 64) ? 128 : 64;
     }
+    const int qw = sl.qw;
+    const int qt_n = std::min(qw, Q - q0);
+    if (n_done) *n_done = qt_n;
     RETCHK(sl.qt.ensure((size_t)idx->n_steps * (bf16 ? 8192 : 4096)));
     if (!sl.screened) {
         if (phases & S1_PREPARE) {
@@ -863,28 +901,28 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         return MFAR_OK;
     }
     RETCHK(sl.qt16.ensure((size_t)idx->n_steps * 4096));
-    RETCHK(sl.qinfo.ensure(64 * sizeof(ScreenQuery)));
-    RETCHK(sl.eps.ensure((size_t)F * 64 * 4));
-    RETCHK(sl.base.ensure((size_t)F * 64 * 4));
+    RETCHK(sl.qinfo.ensure(128 * sizeof(ScreenQuery)));
+    RETCHK(sl.eps.ensure((size_t)F * 128 * 4));
+    RETCHK(sl.base.ensure((size_t)F * 128 * 4));
     if (!sl.fail.p) {
         RETCHK(sl.fail.ensure((size_t)(MFAR_MAX_FIELDS + 2) * 4));
         HIPCHK(hipMemsetAsync(sl.fail.p, 0, (size_t)(MFAR_MAX_FIELDS + 2) * 4, st));
     }
-    RETCHK(sl.sids.ensure((size_t)64 * F * kp * 8));
-    RETCHK(sl.ssc.ensure((size_t)64 * F * kp * 4));
-    RETCHK(sl.sx.ensure((size_t)64 * F * kp * 4));
-    RETCHK(sl.scnt.ensure((size_t)64 * F * 4));
+    RETCHK(sl.sids.ensure((size_t)128 * F * kp * 8));
+    RETCHK(sl.ssc.ensure((size_t)128 * F * kp * 4));
+    RETCHK(sl.sx.ensure((size_t)128 * F * kp * 4));
+    RETCHK(sl.scnt.ensure((size_t)128 * F * 4));
     int* fflags = sl.fail.as<int>();
     // 1. screened pass on the fp16 slab of unique rows: the k' best approximate scores per (query, field)
     if (phases & S1_PREPARE) {
-        mfar_screen_queries_kernel<<<dim3(64), dim3(256), 0, st>>>(q, (_Float16*)sl.qt16.p, sl.qinfo.as<ScreenQuery>(),
+        mfar_screen_queries_kernel<<<dim3(qw), dim3(256), 0, st>>>(q, (_Float16*)sl.qt16.p, sl.qinfo.as<ScreenQuery>(),
                                                                    idx->s_field.as<ScreenField>(), sl.eps.as<float>(), sl.base.as<float>(),
-                                                                   fflags, q0, Q, idx->E, F, idx->screen_eps_mult);
+                                                                   fflags, q0, Q, idx->E, F, idx->screen_eps_mult, qw);
         HIPCHK(hipGetLastError());
     }
     const S1Out so = {sl.sids.as<long long>(), sl.ssc.as<float>(), sl.scnt.as<int>(), 0, 0, 0};   // lists of unique-row numbers
-    RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, phases, S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY, sl.base.as<float>(),
-                       nullptr, true, so, st));
+    RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, phases, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
+                       sl.base.as<float>(), nullptr, true, so, st));
     if (!(phases & S1_CERTIFY)) return MFAR_OK;
     // 2. exact scores of those unique rows' representatives (the contract's fma chain over the fp32 slab)
     ScoreParams sp = {};
@@ -933,6 +971,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     cp.kp = kp;
     cp.q0 = q0;
     cp.sentinel = sentinel;
+    cp.qw = qw;
     static const bool cert_debug = getenv("MFAR_CERT_DEBUG") != nullptr;
     DevBuf dbg;
     if (cert_debug) {
@@ -958,24 +997,43 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     }
     // 4. fall-back: the exact fp32 pass over the DOCUMENTS of the fields whose certificate failed (workgroups of other
     //    fields exit at once)
-    {
+    for (int b0 = 0; b0 < qt_n; b0 += 64) {   // the exact pass takes 64 queries at a time
         const int total = 64 * (idx->E / 4);
-        mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, sl.qt.as<float>(), q0, Q, idx->E);
+        mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, sl.qt.as<float>(), q0 + b0, Q, idx->E);
         HIPCHK(hipGetLastError());
-        const S1Out o = {fid, fsc, nullptr, q0, sentinel, idx->row_offset};
-        RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, S1_ALL, S1_F32, idx->slab, sl.qt.p, qt_n, k, tau0, nullptr, fflags, false, o, st));
+        const S1Out o = {fid, fsc, nullptr, q0 + b0, sentinel, idx->row_offset};
+        RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, S1_ALL, S1_F32, idx->slab, sl.qt.p, std::min(64, qt_n - b0), k, tau0, nullptr, fflags,
+                           false, o, st));
     }
     return MFAR_OK;
 }
 
 static int run_stage1(mfar_index* idx, const float* q, int Q, int k, int sentinel, long long* fid, float* fsc, hipStream_t st) {
-    for (int q0 = 0; q0 < Q; q0 += 64) RETCHK(stage1_block(idx, 0, S1_ALL, q, Q, q0, k, sentinel, 0, idx->F, fid, fsc, nullptr, st));
+    for (int q0 = 0, n = 0; q0 < Q; q0 += n) RETCHK(stage1_block(idx, 0, S1_ALL, q, Q, q0, k, sentinel, 0, idx->F, fid, fsc, nullptr, st, &n));
     return MFAR_OK;
 }
 
+// queries one split-phase batch may hold: 128 when the wide screened pass serves blocks of more than 64 queries, else 64
+static int max_split_batch(const mfar_index* idx, int k) { return (screen_wanted(idx, k) && wide_ok(idx)) ? 128 : 64; }
+static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok);
+extern "C" int mfar_max_split_batch(mfar_index* idx, int k) {
+    if (!idx || k <= 0 || k > MFAR_MAX_K) return 0;
+    if (max_split_batch(idx, k) == 64) return 64;
+    // the wide pass needs the screen slab: build it now (synchronously), so that the answer holds for the batches to come
+    bool ok = false;
+    if (hipSetDevice(idx->device) != hipSuccess || ensure_screen(idx, nullptr, &ok) != MFAR_OK || !ok) return 64;
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return 64;
+    return 128;
+}
+extern "C" int mfar_set_wide(mfar_index* idx, int enable) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    idx->wide = enable != 0;
+    return MFAR_OK;
+}
 static int check_split(const mfar_index* idx, const float* q, int Q, int k, int slot) {
     RETCHK(check_search_common(idx, q, Q, k));
-    if (Q > 64) return fail(MFAR_ERR_INVALID, "the split-phase entry points take at most 64 queries");
+    if (Q > max_split_batch(idx, k))
+        return fail(MFAR_ERR_INVALID, "the split-phase entry points take at most mfar_max_split_batch() queries (64; 128 with the wide screened pass)");
     if (slot < 0 || slot > 1) return fail(MFAR_ERR_INVALID, "slot must be 0 or 1");
     return MFAR_OK;
 }
@@ -985,8 +1043,11 @@ extern "C" int mfar_stage1_begin(mfar_index* idx, const float* q, int Q, int k, 
     if (Q == 0) return MFAR_OK;
     HIPCHK(hipSetDevice(idx->device));
     if (!field_ids || !field_scores) return fail(MFAR_ERR_INVALID, "output pointer is NULL");
-    return stage1_block(idx, slot, S1_PREPARE | S1_SCAN | S1_FINISH, q, Q, 0, k, sentinel, 0, idx->F, (long long*)field_ids, field_scores,
-                        nullptr, (hipStream_t)stream);
+    RETCHK(stage1_block(idx, slot, S1_PREPARE | S1_SCAN | S1_FINISH, q, Q, 0, k, sentinel, 0, idx->F, (long long*)field_ids, field_scores,
+                        nullptr, (hipStream_t)stream));
+    if (Q > idx->s1[slot].qw)   // the screen slab became unavailable (rows rewritten, rebuild out of memory): only 64 queries were begun
+        return fail(MFAR_ERR_UNSUPPORTED, "a split-phase batch of more than 64 queries needs the screen slab, which could not be (re)built");
+    return MFAR_OK;
 }
 extern "C" int mfar_stage1_finish(mfar_index* idx, const float* q, int Q, int k, int sentinel, int slot, int64_t* field_ids,
                                   float* field_scores, int32_t* any_fail, void* stream) {
@@ -1076,7 +1137,7 @@ extern "C" int mfar_retrieve_field(mfar_index* idx, int field, const float* q, i
     RETCHK(stage_in(idx->in[0], q, (size_t)Q * idx->E, on_device, st, &qd));
     RETCHK(stage_out(idx->out[0], (long long*)ids, nl, on_device, &fid));
     RETCHK(stage_out(idx->out[1], scores, nl, on_device, &fsc));
-    for (int q0 = 0; q0 < Q; q0 += 64) RETCHK(stage1_block(idx, 0, S1_ALL, qd, Q, q0, k, sentinel, field, 1, fid, fsc, nullptr, st));
+    for (int q0 = 0, n = 0; q0 < Q; q0 += n) RETCHK(stage1_block(idx, 0, S1_ALL, qd, Q, q0, k, sentinel, field, 1, fid, fsc, nullptr, st, &n));
     RETCHK(copy_back((long long*)ids, fid, nl, on_device, st));
     RETCHK(copy_back(scores, fsc, nl, on_device, st));
     if (!on_device) HIPCHK(hipStreamSynchronize(st));

@@ -44,7 +44,7 @@ struct ScreenField {     // per field, written by mfar_screen_scale_kernel
     float dnorm_max;     // largest 2-norm of a centred row of the field (inf / NaN when the field holds non-finite values)
     float mnorm;         // 2-norm of the field's mean vector
 };
-struct ScreenQuery {     // per query of the current 64-query block
+struct ScreenQuery {     // per query of the current block of 64 / 128 queries
     float scale, inv_scale, norm, pad;
 };
 
@@ -275,15 +275,19 @@ __global__ void __launch_bounds__(256) mfar_unique_table_kernel(long long n, int
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Queries of one 64-query block: per-query scale + norm, two-term fp16 split tiles [n_steps][2][64][16], and per
-// (field, query): eps (real units) and the starting threshold of the screened pass (scaled units).
-//   grid = 64 (one workgroup per query row), block 256.
+// Queries of one block of qw = 64 or 128 queries: per-query scale + norm, the fp16 tiles, and per (field, query): eps (real
+// units) and the starting threshold of the screened pass (scaled units).
+//   qw == 64:  two-term split (hi + lo = 22 significant bits), tiles [n_steps][2 terms][64][16];
+//   qw == 128: ONE fp16 term per query (the wide pass, mfar_stage1.h), tiles [n_steps][2 query blocks][64][16]; the query
+//              rounding error |fp16(Qi) - Qi| <= u16 |Qi| + 2^-25 enters the bound at first order:
+//              |A D' - Qi Di| <= (2 u16 + u16^2) |Qi||Di| + 2^-25 (1 + u16) (|Qi| + |Di|).
+//   grid = qw (one workgroup per query row), block 256.
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* __restrict__ q, _Float16* __restrict__ qt,
                                                                   ScreenQuery* __restrict__ qinfo, const ScreenField* __restrict__ sf,
                                                                   float* __restrict__ eps, float* __restrict__ tau_base,
                                                                   int* __restrict__ fail_flags, int q0, int Q, int E, int F,
-                                                                  float eps_mult) {
+                                                                  float eps_mult, int qw) {
     __shared__ float red_a[4], red_s[4];
     const int r = blockIdx.x;
     // a new batch: clear the certificate flags of the fields and the "any" flag ([MFAR_MAX_FIELDS + 1] keeps accumulating statistics)
@@ -344,10 +348,13 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
             lo[j] = (_Float16)(x - (float)a);
         }
         const int step = e >> 4;
-        const size_t in_tile = tiled_offset_bf16(E >> 4, r, e) - (size_t)step * 1024;
+        const size_t in_tile = tiled_offset_bf16(E >> 4, r & 63, e) - (size_t)step * 1024;
         _Float16* base = qt + (size_t)step * 2048;   // 2 tiles of 1024 halves per k-step
-        *(f16x8*)(base + in_tile) = hi;
-        *(f16x8*)(base + 1024 + in_tile) = lo;
+        if (qw == 128) *(f16x8*)(base + (r >> 6) * 1024 + in_tile) = hi;      // tile = query block
+        else {
+            *(f16x8*)(base + in_tile) = hi;                                   // tile = term
+            *(f16x8*)(base + 1024 + in_tile) = lo;
+        }
     }
     if (threadIdx.x == 0) {
         ScreenQuery o;
@@ -361,17 +368,17 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
         const int f = threadIdx.x;
         const ScreenField s = fld;
         const float K = (float)E, u32f = 5.9604645e-8f;
-        const float c_rel = 1.02f * 4.8828125e-4f + (4.0f * K + 66.0f) * u32f;
+        const float c_rel = (qw == 128 ? 2.04f : 1.02f) * 4.8828125e-4f + (4.0f * K + 66.0f) * u32f;
         const float c_abs = u32f * sqrtf(K) * 1.0001f;
         float e_ = SCREEN_SLACK * (c_rel * qn * s.dnorm_max + K * u32f * qn * (s.dnorm_max + 2.0f * s.mnorm) +
                                    c_abs * (qn * s.inv_scale + s.dnorm_max / sq));
         e_ *= eps_mult;
         if (!live) e_ = 0.0f;
-        eps[f * 64 + r] = e_;
+        eps[f * qw + r] = e_;
         // starting threshold of the screened pass: none for live queries (the zero sentinel of index.py:192-193 is applied
         // to the EXACT scores by the certify kernel; deciding it here would need q.m on the critical path), +inf for the
         // padding queries of a short batch so that they append nothing
-        tau_base[f * 64 + r] = live ? -__builtin_inff() : __builtin_inff();
+        tau_base[f * qw + r] = live ? -__builtin_inff() : __builtin_inff();
     }
 }
 
@@ -387,7 +394,7 @@ struct CertifyParams {
     const float* sx;          // [64, nf, kp] exact scores of those rows' representatives (NaN = not scored)
     const ScreenField* sf;    // [F]
     const ScreenQuery* qinfo;
-    const float* eps;         // [F, 64]
+    const float* eps;         // [F, qw]
     const float* q;           // [Qt, E] the block's queries (row-major)
     const float* mean;        // [F, E] field means: q . mean is added back to the centred approximate scores
     int E;
@@ -401,6 +408,7 @@ struct CertifyParams {
     long long ustride;
     long long row_offset;
     int f0, nf, k, kp, q0, sentinel;
+    int qw;                   // query columns of the screened pass (64 / 128): stride of eps
     float* dbg;               // diagnostics (MFAR_CERT_DEBUG) or nullptr: per list {ok, bound, T_k, a_real, eps, cnt, m_out, overflow}
 };
 __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyParams p) {
@@ -492,7 +500,7 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
         if (ok && cnt == p.kp) {  // the list is full: unique rows outside it exist
             const float qm = (qm_s[0] + qm_s[1]) + (qm_s[2] + qm_s[3]);
             a_real = (p.ssc[lb + p.kp - 1] * p.qinfo[ql].inv_scale) * p.sf[f].inv_scale + qm;
-            bound = a_real + p.eps[f * 64 + ql];                   // every outside row scores <= bound (exactly)
+            bound = a_real + p.eps[f * p.qw + ql];                   // every outside row scores <= bound (exactly)
             if (m_out == p.k) ok = bound < key_score(sorted[p.k - 1]); // ... strictly below the exact k-th best DOCUMENT
             else ok = bound <= tau0;                               // ... or cannot pass the sentinel at all
         }
@@ -502,7 +510,7 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
             d[1] = bound;
             d[2] = m_out > 0 ? key_score(sorted[m_out - 1]) : 0.0f;
             d[3] = a_real;
-            d[4] = p.eps[f * 64 + ql];
+            d[4] = p.eps[f * p.qw + ql];
             d[5] = (float)cnt;
             d[6] = (float)m_out;
             d[7] = (float)overflow_s + 10.0f * (float)n + 10000.0f * (float)total;

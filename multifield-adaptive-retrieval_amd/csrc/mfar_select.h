@@ -103,18 +103,19 @@ __global__ void mfar_tile_queries_bf16_kernel(const float* __restrict__ q, unsig
 //   grid = Qt * F workgroups (Qt <= 64 queries of this pass), dynamic LDS = n_chunks * k * 8 bytes.
 // ---------------------------------------------------------------------------------------------------------
 struct MergeParams {
-    const uint2* lists;   // [n_chunks_total * 64][S1_CAP]
-    const int* list_cnt;  // [n_chunks_total * 64]
+    const uint2* lists;   // [n_chunks_total * qw][S1_CAP]
+    const int* list_cnt;  // [n_chunks_total * qw]
     const int* fchunk;    // [F + 1] first chunk of every field in the pass's chunk table (chunks of a field are consecutive)
     long long* out_ids;   // [Q, nf, k] global ids (nullptr: threshold-only pass)
     float* out_scores;    // [Q, nf, k]
-    float* tau_out;       // [F, 64] or nullptr: k-th best score of the merged list (-inf when fewer than k entries)
+    float* tau_out;       // [F, qw] or nullptr: k-th best score of the merged list (-inf when fewer than k entries)
     int* cnt_out;         // [Qt * nf] or nullptr: entries of the merged list
     const int* only_failed;  // [F] or nullptr: only fields whose flag is set are merged (screen fall-back pass)
     long long row_offset;
     int f0, nf;           // this launch merges fields [f0, f0 + nf): grid = Qt * nf, output rows are nf wide
     int max_chunks;       // largest chunk count of a field (sizes the LDS staging of the non-register variant)
     int k, q0, sentinel;
+    int qw;               // query columns of the stage-1 pass (64 / 128): stride of the per-chunk tables and of tau_out
 };
 // LDS carve-up shared by the selection kernels (everything in the dynamic region: 16-byte aligned base)
 //   keys[n_keys] u64 | sel[SEL_MAX_K] u64 | sorted[SEL_MAX_K] u64 | red[32] int | misc[4] int
@@ -148,7 +149,7 @@ __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams
     // chunk counts first (LDS), then the entries eight chunks at a time: the global loads of a round are independent,
     // so their latencies overlap instead of adding up
     int* cnts = (int*)L.sel;   // the selection scratch is free until block_topk_sorted runs (<= 128 chunks per field)
-    for (int c = threadIdx.x; c < n_chunks; c += blockDim.x) cnts[c] = min(p.list_cnt[(size_t)(c_lo + c) * 64 + ql], p.k);
+    for (int c = threadIdx.x; c < n_chunks; c += blockDim.x) cnts[c] = min(p.list_cnt[(size_t)(c_lo + c) * p.qw + ql], p.k);
     if (threadIdx.x == 0) L.misc[0] = 0;
     __syncthreads();
     for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
@@ -160,7 +161,7 @@ __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams
                 const int c = c0 + u;
                 ok[u] = c < n_chunks && r < cnts[c < n_chunks ? c : 0];
                 e[u] = make_uint2(0u, 0u);
-                if (ok[u]) e[u] = p.lists[((size_t)(c_lo + c) * 64 + ql) * S1_CAP + r];
+                if (ok[u]) e[u] = p.lists[((size_t)(c_lo + c) * p.qw + ql) * S1_CAP + r];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams
     else if (NPT > 16 && n <= 16 * 256) m = block_topk_sorted<16>(L.keys, n, p.k, L.sel, L.sorted, L.red);
     else if (NPT > 32 && n <= 32 * 256) m = block_topk_sorted<32>(L.keys, n, p.k, L.sel, L.sorted, L.red);
     else m = block_topk_sorted<NPT>(L.keys, n, p.k, L.sel, L.sorted, L.red);
-    if (p.tau_out && threadIdx.x == 0) p.tau_out[f * 64 + ql] = m == p.k ? key_score(L.sorted[p.k - 1]) : -__builtin_inff();
+    if (p.tau_out && threadIdx.x == 0) p.tau_out[f * p.qw + ql] = m == p.k ? key_score(L.sorted[p.k - 1]) : -__builtin_inff();
     if (p.cnt_out && threadIdx.x == 0) p.cnt_out[ql * p.nf + fo] = m;
     if (!p.out_ids) return;
     const size_t ob = ((size_t)(p.q0 + ql) * p.nf + fo) * p.k;
@@ -204,7 +205,7 @@ __device__ __forceinline__ void merge_lists_regs_body(const MergeParams& p) {
     if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
     const int c_lo = p.fchunk[f], n_chunks = p.fchunk[f + 1] - c_lo;
     if (threadIdx.x < 128)
-        cnts[threadIdx.x] = (int)threadIdx.x < n_chunks ? min(p.list_cnt[(size_t)(c_lo + threadIdx.x) * 64 + ql], p.k) : 0;
+        cnts[threadIdx.x] = (int)threadIdx.x < n_chunks ? min(p.list_cnt[(size_t)(c_lo + threadIdx.x) * p.qw + ql], p.k) : 0;
     __syncthreads();
     const int total = n_chunks * p.k;
     // unconditional loads (clamped slot: always inside the list buffer), so that all NPT of them are in flight together;
@@ -215,7 +216,7 @@ __device__ __forceinline__ void merge_lists_regs_body(const MergeParams& p) {
         const int s_ = (int)threadIdx.x + TPB * i;
         const int sl = s_ < total ? s_ : 0;
         const int c = sl / p.k;
-        e[i] = p.lists[((size_t)(c_lo + c) * 64 + ql) * S1_CAP + (sl - c * p.k)];
+        e[i] = p.lists[((size_t)(c_lo + c) * p.qw + ql) * S1_CAP + (sl - c * p.k)];
     }
     u32 hi[NPT], lo[NPT];
     int mine = 0;
@@ -233,7 +234,7 @@ __device__ __forceinline__ void merge_lists_regs_body(const MergeParams& p) {
     const int n = block_sum<NPT>(mine, red, 0);
     __syncthreads();   // red[] is reused by the selection
     const int m = block_topk_regs<NPT>(hi, lo, n, p.k, sel, sorted, red);
-    if (p.tau_out && threadIdx.x == 0) p.tau_out[f * 64 + ql] = m == p.k ? key_score(sorted[p.k - 1]) : -__builtin_inff();
+    if (p.tau_out && threadIdx.x == 0) p.tau_out[f * p.qw + ql] = m == p.k ? key_score(sorted[p.k - 1]) : -__builtin_inff();
     if (p.cnt_out && threadIdx.x == 0) p.cnt_out[ql * p.nf + fo] = m;
     if (!p.out_ids) return;
     const size_t ob = ((size_t)(p.q0 + ql) * p.nf + fo) * p.k;
@@ -252,13 +253,14 @@ __global__ void __launch_bounds__(256, 2) mfar_merge_lists_regs_kernel(const Mer
 // tau[f][q] = max(base[f][q], k-th largest of the n_vals scores published by the light sample pass for (q, f)); the k-th
 // largest counts only scores above tau0 and is -inf when there are fewer than k of them (then the sample gives no bound).
 // One WAVE per (query, field), NV values per lane (n_vals <= 64 * NV): the 32-step radix descent on the score bits is
-// NV ballots + scalar popcounts per step, no LDS and no barriers.  grid = ceil(64 * F / 4), block 256.
+// NV ballots + scalar popcounts per step, no LDS and no barriers.  grid = ceil(qw * F / 4), block 256 (qw = query columns
+// of the pass, 64 / 128).
 template <int NV>
 __global__ void __launch_bounds__(256) mfar_sample_tau_kernel(const float* __restrict__ samp, const int* __restrict__ samp_n,
                                                               int samp_stride, int f0, int nf, int k, float tau0,
-                                                              const float* __restrict__ base, float* __restrict__ tau_out) {
+                                                              const float* __restrict__ base, float* __restrict__ tau_out, int qw) {
     const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (pair >= 64 * nf) return;   // wave-uniform
+    if (pair >= qw * nf) return;   // wave-uniform
     const int q = pair / nf, f = f0 + pair - q * nf;
     const int n_wave_blocks = samp_n[f];      // wave blocks the sample pass published for this field
     const int n_vals = n_wave_blocks * 2;
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(256) mfar_sample_tau_kernel(const float* __res
     for (int j = 0; j < NV; ++j) {
         const int i = lane + j * 64;
         const int ii = i < n_vals ? i : 0;
-        const float v = samp[((size_t)f * samp_stride + (ii >> 1)) * 128 + q * 2 + (ii & 1)];
+        const float v = samp[((size_t)f * samp_stride + (ii >> 1)) * (size_t)(2 * qw) + q * 2 + (ii & 1)];
         const bool ok = i < n_vals && v > tau0;
         hi[j] = ok ? f2ord(v) : 0u;     // 0 = empty: below every real score's key
         n += __popcll(__ballot(ok));
@@ -286,8 +288,8 @@ __global__ void __launch_bounds__(256) mfar_sample_tau_kernel(const float* __res
         t = ord2f(T);
     }
     if (lane == 0) {
-        if (base) t = fmaxf(t, base[f * 64 + q]);
-        tau_out[f * 64 + q] = t;
+        if (base) t = fmaxf(t, base[f * qw + q]);
+        tau_out[f * qw + q] = t;
     }
 }
 

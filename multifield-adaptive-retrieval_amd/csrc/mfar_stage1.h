@@ -75,14 +75,16 @@ struct S1Params {
     const S1Chunk* chunks;  // [n_chunks] chunk table of the scanned slab
     int chunk0;             // first chunk of this launch (grid = a contiguous chunk range: all fields, or one field)
     int n_steps;            // E / 16
-    int Q;                  // valid queries (<= 64)
+    int Q;                  // valid queries (<= qw)
+    int qw;                 // query columns of the pass: 64, or 128 for the wide fp16 screen pass (mfar_stage1_f16w_kernel);
+                            // sizes every per-query table: lists [n_chunks * qw][S1_CAP], gtau [F, qw], samp_out [..][qw][2]
     int k;                  // list depth (<= S1_MAX_DEPTH)
     float tau0;             // 0 (zero sentinel, index.py:192-193) or -inf
-    const float* gtau;      // [F, 64] non-strict lower bounds from the sample pass, or nullptr
+    const float* gtau;      // [F, qw] non-strict lower bounds from the sample pass, or nullptr
     int sample;             // 1/2: threshold-estimation pass, every workgroup scans only the first tile of its chunk;
                             //      2 = light form: no lists, every wave publishes the 2 best scores per query of its 64 rows
     int sample_tiles;       // tiles per workgroup scanned by the sample pass (>= 1, <= tiles of the shortest chunk)
-    float* samp_out;        // [F][samp_stride wave blocks][64][2] (sample == 2): wave block = (sampled tile of the field, wave)
+    float* samp_out;        // [F][samp_stride wave blocks][qw][2] (sample == 2): wave block = (sampled tile of the field, wave)
     int samp_stride;        // wave blocks reserved per field
     const int* only_failed; // [F] or nullptr: workgroups of fields whose flag is 0 exit at once (screen fall-back pass)
     int dbg;                // profiling only (MFAR_S1_DEBUG): 1 = skip the selection epilogue (results invalid; note that
@@ -171,12 +173,13 @@ __device__ __forceinline__ S1State s1_state(char* base) {
     s.stage = (u32)(uintptr_t)(base + 1040);
     return s;
 }
-__device__ __forceinline__ void s1_state_init(const S1State& st, const S1Params& p, int f) {
+// qoff: first query column this state serves (0; the wide pass keeps a second state for columns 64 .. 127)
+__device__ __forceinline__ void s1_state_init(const S1State& st, const S1Params& p, int f, int qoff = 0) {
     const int tid = threadIdx.x;
     if (tid < 64) {
-        st.tau[tid] = tid < p.Q ? p.tau0 : __builtin_inff();
+        st.tau[tid] = qoff + tid < p.Q ? p.tau0 : __builtin_inff();
         st.cnt[tid] = 0;
-        st.tg[tid] = p.gtau ? p.gtau[f * 64 + tid] : -__builtin_inff();
+        st.tg[tid] = p.gtau ? p.gtau[f * p.qw + qoff + tid] : -__builtin_inff();
         st.scnt[tid] = 0;
     }
     if (tid == 0) *st.flag = 0;
@@ -237,9 +240,13 @@ __device__ __forceinline__ void s1_drain(const S1Params& p, const S1State& st, i
 // counted wait behind a pending store has to drain deeper than it needs (measured: the ~20 scattered 8-byte stores per
 // wave and tile of the direct path cost 14 % of the 16-bit pass); staging turns them into about one coalesced store per
 // wave and tile.  Entries that do not fit the staging area (a lane with many survivors in one tile) go straight to the list.
+// The epilogue has two halves, so that the wide pass can run the first half for BOTH of its query blocks before anything
+// heavy happens: s1_epilogue_append consumes the accumulators (compare, reserve, stage / store the survivors);
+// s1_epilogue_finish (behind barrier B) drains the staging area and compacts lists -- register-hungry radix selects that
+// must not run while another block's 64 accumulators are still live.
 template <int SCAP>
-__device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st, int n_rows, int t, int w, size_t wgq0, f32x16& acc00,
-                                            f32x16& acc01, f32x16& acc10, f32x16& acc11) {
+__device__ __forceinline__ void s1_epilogue_append(const S1Params& p, const S1State& st, int n_rows, int t, int w, size_t wgq0, f32x16& acc00,
+                                                   f32x16& acc01, f32x16& acc10, f32x16& acc11) {
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     s1_mask_rows(n_rows, t, w, acc00, acc01, acc10, acc11);
     // (barrier A -- the compactions of the previous tile are complete, every wave has finished the tile's last k-step --
@@ -285,8 +292,12 @@ __device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st
         S1_APPEND(acc11, 1, th1, l1, b1, s1, 32 + j)
 #undef S1_APPEND
     }
-    // barrier B: slot counters (and, on the direct path, the compaction flag) of this tile are final
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// second half; the caller has executed barrier B (slot counters and, on the direct path, the compaction flag of this tile
+// are final) after the appends
+template <int SCAP>
+__device__ __forceinline__ void s1_epilogue_finish(const S1Params& p, const S1State& st, int w, size_t wgq0) {
+    const int tid = threadIdx.x, lane = tid & 63;
     if (SCAP) {
         s1_drain<SCAP>(p, st, w, wgq0, SCAP * S1_DRAIN_NUM / 4);
         // barrier C: list counts and the compaction flag are final
@@ -312,12 +323,19 @@ __device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st
         }
     }
 }
+template <int SCAP>
+__device__ __forceinline__ void s1_epilogue(const S1Params& p, const S1State& st, int n_rows, int t, int w, size_t wgq0, f32x16& acc00,
+                                            f32x16& acc01, f32x16& acc10, f32x16& acc11) {
+    s1_epilogue_append<SCAP>(p, st, n_rows, t, w, wgq0, acc00, acc01, acc10, acc11);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier B
+    s1_epilogue_finish<SCAP>(p, st, w, wgq0);
+}
 
 // Light threshold-estimation epilogue (sample == 2): per (wave, query) the two best scores among the wave's 64 rows.
 // They are scores of distinct real rows, so the k-th largest of all published values is a valid (non-strict) lower
 // bound of the final k-th best (mfar_sample_tau_kernel).
 __device__ __forceinline__ void s1_sample_top2(const S1Params& p, const S1Chunk& c, int tl, int t, int w, f32x16& acc00, f32x16& acc01,
-                                               f32x16& acc10, f32x16& acc11) {
+                                               f32x16& acc10, f32x16& acc11, int qoff = 0) {
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     s1_mask_rows(c.n_rows, t, w, acc00, acc01, acc10, acc11);
     float a1 = -__builtin_inff(), a2 = a1, b1 = a1, b2 = a1;   // query j: (a1 >= a2), query 32 + j: (b1 >= b2)
@@ -341,7 +359,7 @@ __device__ __forceinline__ void s1_sample_top2(const S1Params& p, const S1Chunk&
     const float ra1 = fmaxf(a1, oa1), ra2 = fmaxf(fminf(a1, oa1), fmaxf(a2, oa2));
     const float rb1 = fmaxf(b1, ob1), rb2 = fmaxf(fminf(b1, ob1), fmaxf(b2, ob2));
     if (h == 0) {
-        float* o = p.samp_out + (((size_t)c.f * p.samp_stride) + (size_t)(c.tl0 + tl) * 4 + w) * 128;
+        float* o = p.samp_out + (((size_t)c.f * p.samp_stride) + (size_t)(c.tl0 + tl) * 4 + w) * (size_t)(2 * p.qw) + 2 * qoff;
         store_untracked_b64(&o[j * 2], ((u64)__float_as_uint(ra2) << 32) | __float_as_uint(ra1));
         store_untracked_b64(&o[(32 + j) * 2], ((u64)__float_as_uint(rb2) << 32) | __float_as_uint(rb1));
     }
@@ -390,7 +408,7 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
     const int t0 = ck.t0;
     int t1 = ck.t1;
     if (p.sample) t1 = min(t1, t0 + p.sample_tiles);
-    const size_t wgq0 = (size_t)chunk_id * 64;
+    const size_t wgq0 = (size_t)chunk_id * p.qw;
     s1_state_init(st, p, f);
 
     // fragment read offsets inside a 4 KB tile: row (32*blk + j), dims 8g + 4h .. +3  (chunk c = 2g + h)
@@ -535,7 +553,7 @@ __device__ __forceinline__ void s1_body_x16(const S1Params& p) {
     const int t0 = ck.t0;
     int t1 = ck.t1;
     if (p.sample) t1 = min(t1, t0 + p.sample_tiles);
-    const size_t wgq0 = (size_t)chunk_id * 64;
+    const size_t wgq0 = (size_t)chunk_id * p.qw;
     s1_state_init(st, p, f);
 
     // granule of row (32*blk + j), k-half h inside a 2 KB tile (rows are 32 B)
@@ -680,7 +698,7 @@ __device__ __forceinline__ void s1_body_x16r(const S1Params& p) {
     const int t0 = ck.t0;
     int t1 = ck.t1;
     if (p.sample) t1 = min(t1, t0 + p.sample_tiles);
-    const size_t wgq0 = (size_t)chunk_id * 64;
+    const size_t wgq0 = (size_t)chunk_id * p.qw;
     s1_state_init(st, p, f);
 
     // granule of row (32*blk + j), k-half h inside a 2 KB tile: the same offset in memory (docs) and in LDS (queries)
@@ -783,6 +801,122 @@ __device__ __forceinline__ void s1_body_x16r(const S1Params& p) {
     if (p.sample != 2) s1_flush<X::SCAP>(p, st, w, wgq0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// WIDE fp16 screen pass ("f16w"): 128 query columns per scan.  The screened pass is HBM-bound with the MFMA pipe at ~40 %
+// (two fp16 query terms x 64 queries = 8 MFMAs per 2 KB of docs per wave).  Spending the same 8 MFMAs on ONE fp16 term of
+// 128 queries reads the screen slab once per 128 queries instead of once per 64: half the scan bytes per query at the same
+// MFMA load.  The price is the query rounding error (u16 |q_i| per element instead of u16^2), which the certificate's
+// bound accounts for (mfar_screen.h: eps roughly doubles; the re-scored margin k' - k is as wide as before).
+// Same structure as s1_body_x16r<1, R>: docs in a register ring, the 4 KB query stage (two 64-query blocks x 2 KB) in an
+// LDS ring, 8 accumulators (128 VGPRs), one selection state per 64-query block and the epilogue run once per block.
+// ---------------------------------------------------------------------------------------------------------------------
+#define S1_SCAP_WIDE 32
+template <int R>
+struct S1W {
+    static constexpr int Q_STAGE = 4096;
+    static constexpr int LOADS = 3;
+    static constexpr int SCAP = S1_SCAP_WIDE;
+    static constexpr int LDS_BYTES = R * Q_STAGE + 2 * S1_STATE_BYTES_(SCAP);
+};
+
+template <int R>
+__device__ __forceinline__ void s1_body_f16w(const S1Params& p) {
+    typedef S1W<R> X;
+    typedef short vec8 __attribute__((ext_vector_type(8)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const qring = smem;
+    const S1State stA = s1_state(smem + R * X::Q_STAGE);
+    const S1State stB = s1_state(smem + R * X::Q_STAGE + S1_STATE_BYTES_(X::SCAP));
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    const int chunk_id = p.chunk0 + (int)blockIdx.x;
+    const S1Chunk ck = p.chunks[chunk_id];
+    const int f = ck.f;
+    if (p.only_failed && !p.only_failed[f]) return;
+    const int t0 = ck.t0;
+    int t1 = ck.t1;
+    if (p.sample) t1 = min(t1, t0 + p.sample_tiles);
+    const size_t wgq0 = (size_t)chunk_id * p.qw;      // qw == 128
+    s1_state_init(stA, p, f, 0);
+    s1_state_init(stB, p, f, 64);
+
+    const int off = j * 32 + ((h ^ ((j >> 3) & 1)) << 4);
+    const size_t step_bytes = 2048;
+    const size_t tile_jump = (size_t)3 * p.n_steps * step_bytes;
+    const char* dnext = (const char*)p.slab + (size_t)ck.base * 2 + ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes + off;
+    const char* const qbase = (const char*)p.qt + lane * 16 + w * 1024;   // wave w loads piece w of the 4 KB stage
+    int s_next = 0;
+    const char* const dlast = (const char*)p.slab + (size_t)ck.base * 2 +
+                              ((size_t)(4 * (t1 - 1) + w) * p.n_steps + (p.n_steps - 1)) * step_bytes + off;
+    vec8 dr0[R], dr1[R];
+#define S1W_QDMA(S, D)                                                                                           \
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(S), "s"(__builtin_amdgcn_readfirstlane((int)(u32)(uintptr_t)(D))) : "memory")
+#define S1W_ISSUE(SLOT)                                                                                   \
+    do {                                                                                                  \
+        asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(dr0[SLOT]) : "v"(dnext) : "memory");    \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024 nt" : "=&v"(dr1[SLOT]) : "v"(dnext) : "memory"); \
+        S1W_QDMA(qbase + (size_t)s_next * X::Q_STAGE, qring + (SLOT) * X::Q_STAGE + w * 1024);             \
+        const char* nx_ = dnext + step_bytes;                                                             \
+        if (++s_next == p.n_steps) {                                                                      \
+            s_next = 0;                                                                                   \
+            nx_ += tile_jump;                                                                             \
+        }                                                                                                 \
+        dnext = (unsigned long long)nx_ <= (unsigned long long)dlast ? nx_ : dlast;                       \
+    } while (0)
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) S1W_ISSUE(i);
+
+    for (int t = t0; t < t1; ++t) {
+        // [query block A/B][doc block][query half]
+        f32x16 a00 = {0}, a01 = {0}, a10 = {0}, a11 = {0}, b00 = {0}, b01 = {0}, b10 = {0}, b11 = {0};
+        for (int s0 = 0; s0 < p.n_steps; s0 += R) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                asm volatile("s_waitcnt vmcnt(%2)\n\ts_barrier" : "+v"(dr0[u]), "+v"(dr1[u]) : "n"((R - 2) * X::LOADS) : "memory");
+                const char* curq = qring + u * X::Q_STAGE;
+                const f16x8 e0 = __builtin_bit_cast(f16x8, dr0[u]), e1 = __builtin_bit_cast(f16x8, dr1[u]);
+                const f16x8 qa0 = *(const f16x8*)(curq + off), qa1 = *(const f16x8*)(curq + 1024 + off);
+                const f16x8 qb0 = *(const f16x8*)(curq + 2048 + off), qb1 = *(const f16x8*)(curq + 3072 + off);
+                S1W_ISSUE((u + R - 1) % R);
+                a00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qa0, a00, 0, 0, 0);
+                a01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qa1, a01, 0, 0, 0);
+                a10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, qa0, a10, 0, 0, 0);
+                a11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, qa1, a11, 0, 0, 0);
+                b00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qb0, b00, 0, 0, 0);
+                b01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qb1, b01, 0, 0, 0);
+                b10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, qb0, b10, 0, 0, 0);
+                b11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, qb1, b11, 0, 0, 0);
+            }
+        }
+        if (p.dbg & 1) {
+            asm volatile("" ::"v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(b00), "v"(b01), "v"(b10), "v"(b11));
+            continue;
+        }
+        if (p.sample == 2) {
+            s1_sample_top2(p, ck, t - t0, t, w, a00, a01, a10, a11, 0);
+            s1_sample_top2(p, ck, t - t0, t, w, b00, b01, b10, b11, 64);
+            continue;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A (see the fp32 body)
+        s1_epilogue_append<X::SCAP>(p, stA, ck.n_rows, t, w, wgq0, a00, a01, a10, a11);
+        s1_epilogue_append<X::SCAP>(p, stB, ck.n_rows, t, w, wgq0 + 64, b00, b01, b10, b11);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier B for both blocks; the accumulators are dead from here
+        s1_epilogue_finish<X::SCAP>(p, stA, w, wgq0);
+        s1_epilogue_finish<X::SCAP>(p, stB, w, wgq0 + 64);
+    }
+#undef S1W_ISSUE
+#undef S1W_QDMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.sample != 2) {
+        s1_flush<X::SCAP>(p, stA, w, wgq0);
+        s1_flush<X::SCAP>(p, stB, w, wgq0 + 64);
+    }
+}
+
 // The full pass and the threshold-estimation pass are the same code under two kernel names, so that profiles list them
 // separately (the sample pass scans 1 tile per workgroup and is ~30x shorter).
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_kernel(const S1Params p) { s1_body_f32(p); }
@@ -808,4 +942,10 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r4_kernel(const
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r4_sample_kernel(const S1Params p) { s1_body_x16r<0, 4>(p); }
 #define S1HR4_LDS_BYTES (4 * 4096 + S1_STATE_BYTES_(S1_SCAP_REG))
 #define S1BR4_LDS_BYTES (4 * 6144 + S1_STATE_BYTES_(S1_SCAP_REG / 2))
-
+// wide fp16 screen pass (128 queries, one fp16 term): 6-slot ring for k-steps divisible by 6, 4-slot twin otherwise
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_kernel(const S1Params p) { s1_body_f16w<6>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_sample_kernel(const S1Params p) { s1_body_f16w<6>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_kernel(const S1Params p) { s1_body_f16w<4>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_sample_kernel(const S1Params p) { s1_body_f16w<4>(p); }
+#define S1HW_LDS_BYTES (6 * 4096 + 2 * S1_STATE_BYTES_(S1_SCAP_WIDE))
+#define S1HW4_LDS_BYTES (4 * 4096 + 2 * S1_STATE_BYTES_(S1_SCAP_WIDE))

@@ -309,6 +309,15 @@ class MultiFieldIndex:
     def set_wgs_per_cu(self, n: int):
         _native.check(_native.lib().mfar_set_wgs_per_cu(self._h, int(n)))
 
+    def max_split_batch(self, k1: int = 100) -> int:
+        """Queries one stage1_begin / stage1_finish batch may hold: 128 when the wide screened pass is available for this index
+        (builds the screen slab if it is not current), else 64 (include/mfar_hip.h)."""
+        return int(_native.lib().mfar_max_split_batch(self._h, int(k1)))
+
+    def set_wide(self, enable: bool = True):
+        """Blocks of 65 .. 128 queries use the wide (one fp16 term, 128 columns) screened pass; False: always 64 per pass."""
+        _native.check(_native.lib().mfar_set_wide(self._h, int(bool(enable))))
+
     def set_screen(self, mode: int = 1, eps_mult: float = 1.0):
         """Certified fp16 screening of an fp32 index (include/mfar_hip.h): 0 off, 1 auto, 2 whenever possible.
         Outputs are bit-identical in every mode; `eps_mult` is a test knob (1 = rigorous proof)."""

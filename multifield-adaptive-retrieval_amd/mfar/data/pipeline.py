@@ -2,20 +2,29 @@
 
 The reference scores one batch at a time, synchronously (reference mfar/modeling/contrastive.py:559-563 -> 669-704).
 On the GPU the per-batch work is one long scan (stage 1: per-field exhaustive top-k) and a chain of short, latency- or
-gather-bound kernels around it.  `PipelinedSearcher` keeps the scans of consecutive batches back to back on a
+gather-bound kernels around it.  `PipelinedSearcher` keeps the scans of consecutive launches back to back on a
 high-priority stream (`mfar_stage1_begin`: query prep, sample pass, scan, list merge) and runs everything that follows a
 scan -- exact re-scoring + certificate of the screened lists (`mfar_stage1_finish`), candidate union, stage 2, mixer;
 with several GPUs the two small all-gathers (the second also carries the certificate flag), `mfar_search_owned` and
-`mfar_merge_topk` -- on a side stream BESIDE the
-next batch's scan: the 16-bit scan kernels keep their doc tiles in registers, so those small kernels fit next to them
-on every CU.  Results are identical to `MultiFieldIndex.search` / `ShardedSearcher.search`.
+`mfar_merge_topk` -- on a side stream BESIDE the next launch's scan: the 16-bit scan kernels keep their doc tiles in
+registers, so those small kernels fit next to them on every CU.  Results are identical to `MultiFieldIndex.search` /
+`ShardedSearcher.search`.
+
+COALESCING.  The screened scan is HBM-bound: it reads the screen slab once per launch whatever the number of query columns
+(up to 128, include/mfar_hip.h "the WIDE screened pass").  The reference's batch is 64 queries (dev_batch_size,
+train.py:45); when the index offers the wide pass the searcher therefore holds a submitted batch until the next one
+arrives and scans both with ONE launch -- half the scan bytes per query, same result bits per query (a query's lists do
+not depend on its neighbours).  `result()` of a batch that is still waiting launches it alone.
 
     ps = PipelinedSearcher(index, W, mask)
-    t0 = ps.submit(q0)            # returns immediately (everything is enqueued asynchronously)
+    t0 = ps.submit(q0)            # returns immediately (everything is enqueued asynchronously, or held for coalescing)
     t1 = ps.submit(q1)
-    r0 = ps.result(t0)            # dict(ids, scores, n_valid): valid until two more batches have been submitted
+    r0 = ps.result(t0)            # dict(ids, scores, n_valid): valid until 2 * ps.coalesce more batches were submitted
 
-A screened batch whose certificate failed (include/mfar_hip.h, `any_fail`) is detected in `result()` and redone there
+To keep two launches in flight, ask for results `ps.lag` (= 2 * coalesce - 1) submissions late: submit(i); result(i - lag).
+`W` / `mask` are read when a launch is issued: call `flush()` before replacing them (mask_fields sweeps).
+
+A screened launch whose certificate failed (include/mfar_hip.h, `any_fail`) is detected in `result()` and redone there
 through the non-split entry points (which repair the failed fields with the exact pass), so what `result()` returns is
 always the exact answer.
 """
@@ -27,9 +36,7 @@ from mfar.data import index as _index
 
 class PipelinedSearcher:
     def __init__(self, index, W, mask=None, k1: int = 100, k2: int = 100, sentinel: bool = True, query_cond: bool = True,
-                 max_batch: int = 64, group=None):
-        # W / mask may be re-assigned between submissions (mask_fields sweeps): every submit copies them into buffers
-        # owned by the batch's slot, so a batch in flight never reads a tensor the caller has replaced or freed
+                 max_batch: int = 64, group=None, coalesce=None):
         self.ix, self.W, self.mask = index, W, mask
         self.k1, self.k2, self.sentinel, self.query_cond = k1, k2, sentinel, query_cond
         self.group = group
@@ -38,27 +45,35 @@ class PipelinedSearcher:
         self.dev = torch.device(f"cuda:{index.device}")
         self.main = torch.cuda.Stream(device=self.dev, priority=-1)   # the scans: dispatched ahead of the small kernels
         self.side = torch.cuda.Stream(device=self.dev)
-        self.Qmax = int(max_batch)
-        if self.Qmax > 64:
-            raise ValueError("the split-phase stage 1 takes at most 64 queries per batch")
+        self.Qb = int(max_batch)      # queries per submitted batch (at most)
+        cap = index.max_split_batch(k1)                       # 128 with the wide screened pass, else 64
+        if self.Qb > cap:
+            raise ValueError(f"the split-phase stage 1 takes at most {cap} queries per batch on this index")
+        if coalesce is None:
+            coalesce = max(1, min(2, cap // self.Qb))
+        if coalesce < 1 or coalesce * self.Qb > cap:
+            raise ValueError(f"coalesce x max_batch must not exceed {cap} on this index")
+        self.coalesce = int(coalesce)
+        self.lag = 2 * self.coalesce - 1
+        self.Qmax = self.Qb * self.coalesce                   # queries per launch
         F, E = index.n_fields, index.dim
-        self.n_redone = 0             # batches whose screen certificate failed and that were redone exactly
-        self._recent = []             # 1 = redone, over the last 16 checked batches
+        self.n_redone = 0             # launches whose screen certificate failed and that were redone exactly
+        self._recent = []             # 1 = redone, over the last 16 checked launches
         self.inline_repair = False    # many failures: let finish() repair on the device instead of reporting (see _check)
         self.slots = []
         for _ in range(2):
-            s = dict(q=torch.empty(self.Qmax, E, device=self.dev),
+            s = dict(q=torch.zeros(self.Qmax, E, device=self.dev),
                      ids=torch.empty(self.Qmax, k2, dtype=torch.int64, device=self.dev),
                      scores=torch.empty(self.Qmax, k2, device=self.dev),
                      n_valid=torch.empty(self.Qmax, dtype=torch.int32, device=self.dev),
                      W=torch.empty_like(W, device=self.dev), mask=torch.ones(F, device=self.dev),
                      fail=torch.zeros(1, dtype=torch.int32, device=self.dev),
                      fail_host=torch.zeros(1, dtype=torch.int32).pin_memory(),
-                     stage1=torch.cuda.Event(), done=torch.cuda.Event(), Q=0, checked=True)
+                     stage1=torch.cuda.Event(), done=torch.cuda.Event(), Q=0, checked=True, launch=-1)
             if self.world == 1:
                 s["fid"] = torch.empty(self.Qmax, F, k1, dtype=torch.int64, device=self.dev)
                 s["fsc"] = torch.empty(self.Qmax, F, k1, device=self.dev)
-            else:       # lists-first exchange: two small all-gathers per batch (include/mfar_hip.h)
+            else:       # lists-first exchange: two small all-gathers per launch (include/mfar_hip.h)
                 nl, nt = index.lists_bytes(self.Qmax, k1), index.topk_bytes(self.Qmax, k2)
                 s["lists"] = torch.empty(nl, dtype=torch.uint8, device=self.dev)
                 s["lists_all"] = torch.empty(nl * self.world, dtype=torch.uint8, device=self.dev)
@@ -66,7 +81,10 @@ class PipelinedSearcher:
                 s["topk_all"] = torch.empty(nt * self.world, dtype=torch.uint8, device=self.dev)
             s["done"].record(torch.cuda.current_stream(self.dev))
             self.slots.append(s)
-        self.n_submitted = 0
+        self.n_submitted = 0          # batches (tickets)
+        self.n_launched = 0           # launches issued
+        self._pending = []            # batches copied into the next launch's slot, not launched yet: (ticket, row offset, Q)
+        self._where = {}              # ticket -> (launch, row offset, Q) for the pending batches and the last two launches
 
     # where stage 1 leaves the per-field lists of a slot: (ids, scores) as tensors or raw device addresses
     def _list_targets(self, s):
@@ -77,7 +95,7 @@ class PipelinedSearcher:
         ids_bytes = self.Qmax * self.ix.n_fields * self.k1 * 8
         return base, base + ((ids_bytes + 255) & ~255)
 
-    # everything after the lists of a batch are final, on the current stream
+    # everything after the lists of a launch are final, on the current stream
     def _tail(self, s, slot: int):
         Q = s["Q"]
         qk = s["q"][:Q]
@@ -95,30 +113,59 @@ class PipelinedSearcher:
             _index.merge_topk(s["topk_all"], self.world, Q, self.k2, device=self.ix.device, out=out, any_fail=s["fail"])
 
     def submit(self, q) -> int:
-        """q: [Q, E] float32 CUDA tensor (Q == max_batch for the sharded path: fixed payload size)."""
+        """q: [Q, E] float32 CUDA tensor, Q <= max_batch (Q == max_batch for the sharded path: fixed payload size)."""
         t = self.n_submitted
-        slot = t & 1
-        s = self.slots[slot]
         Q = q.shape[0]
-        if Q > self.Qmax or (self.world > 1 and Q != self.Qmax):
+        if Q > self.Qb or (self.world > 1 and Q != self.Qb):
             raise ValueError("batch size does not fit the pipeline's buffers")
-        if not s["checked"]:
-            self._check(t - 2)                        # the slot's previous batch must be verified before its buffers go
-        self.n_submitted += 1
+        slot = self.n_launched & 1
+        s = self.slots[slot]
         cur = torch.cuda.current_stream(self.dev)
+        if not self._pending:
+            if not s["checked"]:
+                self._check(self.n_launched - 2)      # the slot's previous launch must be verified before its buffers go
+            self.main.wait_event(s["done"])           # the slot's previous tail has finished with these buffers
         self.main.wait_stream(cur)                    # q may have been produced on the caller's stream
-        self.main.wait_event(s["done"])               # the slot's previous tail has finished with these buffers
-        s["Q"] = Q
-        s["checked"] = False
+        off = sum(p[2] for p in self._pending)
+        with torch.cuda.stream(self.main):
+            s["q"][off:off + Q].copy_(q)
+            if q.is_cuda:
+                q.record_stream(self.main)
+        self._pending.append((t, off, Q))
+        self._where[t] = (self.n_launched, off, Q)
+        self.n_submitted += 1
+        if len(self._pending) == self.coalesce:
+            self._launch()
+        return t
+
+    def flush(self):
+        """Issue the launch of a batch that is being held for coalescing (no-op when nothing is held)."""
+        if self._pending:
+            self._launch()
+
+    def _launch(self):
+        slot = self.n_launched & 1
+        s = self.slots[slot]
+        Q = sum(p[2] for p in self._pending)
+        if self.world > 1 and Q != self.Qmax:         # fixed payload size: the missing batch is scanned as zero queries
+            with torch.cuda.stream(self.main):
+                s["q"][Q:].zero_()
+            Q = self.Qmax
+        self._pending = []
+        for tk in [tk for tk, (L, _, _) in self._where.items() if L <= self.n_launched - 2]:
+            del self._where[tk]                       # this launch overwrites the results of the slot's previous launch
+        s["Q"], s["checked"], s["launch"] = Q, False, self.n_launched
+        self.n_launched += 1
+        cur = torch.cuda.current_stream(self.dev)
+        self.main.wait_stream(cur)                    # W / mask may have been produced on the caller's stream
         with torch.cuda.stream(self.main):
             qk = s["q"][:Q]
-            qk.copy_(q)
             s["W"].copy_(self.W)
             if self.mask is None:
                 s["mask"].fill_(1.0)
             else:
                 s["mask"].copy_(self.mask.reshape(-1))
-            for t_ in (q, self.W, self.mask):       # sources allocated on the caller's stream, read on this one
+            for t_ in (self.W, self.mask):            # sources allocated on the caller's stream, read on this one
                 if t_ is not None and t_.is_cuda:
                     t_.record_stream(self.main)
             fid, fsc = self._list_targets(s)
@@ -134,19 +181,20 @@ class PipelinedSearcher:
             self._tail(s, slot)
             s["fail_host"].copy_(s["fail"], non_blocking=True)
             s["done"].record(self.side)
-        return t
 
-    # host side of the certificate: wait for the batch, redo it exactly if its screen could not be proven
-    def _check(self, ticket: int):
-        slot = ticket & 1
+    # host side of the certificate: wait for the launch, redo it exactly if its screen could not be proven
+    def _check(self, launch: int):
+        if launch < 0:
+            return
+        slot = launch & 1
         s = self.slots[slot]
-        if s["checked"]:
+        if s["checked"] or s["launch"] != launch:
             return
         s["done"].synchronize()
         s["checked"] = True
         failed = int(s["fail_host"][0]) != 0
         # A redo costs a pipeline drain plus a second pass.  When certificates fail often on this data (a quarter of the last
-        # 16 batches), stop reporting and let finish() repair on the device: the exact kernel then stalls the side stream
+        # 16 launches), stop reporting and let finish() repair on the device: the exact kernel then stalls the side stream
         # until the next scan is through, but nothing is done twice.  (Same decision on every rank: the flags are all-reduced.)
         self._recent = (self._recent + [1 if failed else 0])[-16:]
         if sum(self._recent) >= 4:
@@ -156,7 +204,7 @@ class PipelinedSearcher:
         self.n_redone += 1
         torch.cuda.synchronize(self.dev)              # the redo uses the index's slot-0 scratch: nothing else may be in flight
         # the non-split entry points repair a failed certificate themselves: screened pass again, then the exact fp32 pass
-        # for the failed fields only (cheaper than switching the screen off for the whole batch)
+        # for the failed fields only (cheaper than switching the screen off for the whole launch)
         Q = s["Q"]
         qk = s["q"][:Q]
         if self.world == 1:
@@ -169,9 +217,14 @@ class PipelinedSearcher:
         torch.cuda.current_stream(self.dev).synchronize()
 
     def result(self, ticket: int):
-        if ticket < self.n_submitted - 2 or ticket >= self.n_submitted:
+        w = self._where.get(ticket)
+        if w is None or ticket >= self.n_submitted:
             raise ValueError("ticket is no longer (or not yet) in flight")
-        self._check(ticket)
-        s = self.slots[ticket & 1]
-        Q = s["Q"]
-        return dict(ids=s["ids"][:Q], scores=s["scores"][:Q], n_valid=s["n_valid"][:Q])
+        launch, off, Q = w
+        if launch == self.n_launched:                 # still held for coalescing: launch it alone
+            self._launch()
+        if launch < self.n_launched - 2:
+            raise ValueError("ticket is no longer in flight")
+        self._check(launch)
+        s = self.slots[launch & 1]
+        return dict(ids=s["ids"][off:off + Q], scores=s["scores"][off:off + Q], n_valid=s["n_valid"][off:off + Q])

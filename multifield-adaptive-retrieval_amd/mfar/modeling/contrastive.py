@@ -16,6 +16,7 @@
 """
 import json
 import os
+from collections import deque
 from types import SimpleNamespace
 from typing import Dict, List, Optional, TextIO, Tuple
 
@@ -193,7 +194,7 @@ class RetrievalTrainingModule(torch.nn.Module):
         tail of batch i; with several ranks it uses the lists-first exchange (two small RCCL all-gathers per batch)."""
         from mfar.data.pipeline import PipelinedSearcher
         qmax = min(64, max(1, int(self.dev_batch_size)))
-        if self._searcher is None or self._searcher.ix is not self.slab or self._searcher.Qmax != qmax:
+        if self._searcher is None or self._searcher.ix is not self.slab or self._searcher.Qb != qmax:
             self._searcher = PipelinedSearcher(self.slab, self._weights(), None, k1=TOP_K, k2=TOP_K, sentinel=True,
                                                query_cond=self.query_cond, max_batch=qmax)
         return self._searcher
@@ -215,11 +216,11 @@ class RetrievalTrainingModule(torch.nn.Module):
         ps.W, ps.mask = self._weights(), self.mask[:, 0].float().contiguous().to(self.device)
         x = self.encode_query_batch(batch)
         parts = []
-        for b in range(0, x.shape[0], ps.Qmax):
-            xb = x[b:b + ps.Qmax]
+        for b in range(0, x.shape[0], ps.Qb):
+            xb = x[b:b + ps.Qb]
             n = xb.shape[0]
-            if ps.world > 1 and n < ps.Qmax:
-                xb = torch.cat([xb, xb.new_zeros(ps.Qmax - n, xb.shape[1])])
+            if ps.world > 1 and n < ps.Qb:
+                xb = torch.cat([xb, xb.new_zeros(ps.Qb - n, xb.shape[1])])
             parts.append((ps.submit(xb.contiguous()), batch.instances[b:b + n]))
         return parts, qres_output
 
@@ -243,10 +244,10 @@ class RetrievalTrainingModule(torch.nn.Module):
     @torch.no_grad()
     def trec_eval_step(self, batch, batch_idx: int, qres_output) -> None:
         """One batch, synchronously (the reference's hook signature).  `test()` overlaps consecutive batches instead."""
-        if len(batch.instances) > self._get_searcher().Qmax:
-            for b in range(0, len(batch.instances), self._searcher.Qmax):         # at most two tickets may be in flight
-                sub = SimpleNamespace(instances=batch.instances[b:b + self._searcher.Qmax],
-                                      query={k: {n: t[b:b + self._searcher.Qmax] for n, t in v.items()} for k, v in batch.query.items()})
+        if len(batch.instances) > self._get_searcher().Qb:
+            for b in range(0, len(batch.instances), self._searcher.Qb):           # one ticket at a time
+                sub = SimpleNamespace(instances=batch.instances[b:b + self._searcher.Qb],
+                                      query={k: {n: t[b:b + self._searcher.Qb] for n, t in v.items()} for k, v in batch.query.items()})
                 self._collect(self._submit(sub, qres_output))
             return
         self._collect(self._submit(batch, qres_output))
@@ -286,23 +287,23 @@ class RetrievalTrainingModule(torch.nn.Module):
         was_training = self.training
         self.eval()
         self.on_test_epoch_start()
-        pending = None          # one batch stays in flight while the next one is tokenised, encoded and submitted
+        # `lag` batches stay in flight while the next one is tokenised, encoded and submitted (two launches of the pipeline;
+        # with the wide screened pass a launch scans two coalesced batches, mfar/data/pipeline.py)
+        pending = deque()
         with torch.no_grad():
             for li, loader in enumerate(data_module.test_dataloader()):
                 out = self.qres_output if li == 0 else self.additional_qres_output
                 for batch in loader:
-                    if len(batch.instances) > self._get_searcher().Qmax:
-                        if pending is not None:
-                            self._collect(pending)
-                            pending = None
+                    if len(batch.instances) > self._get_searcher().Qb:
+                        while pending:
+                            self._collect(pending.popleft())
                         self.trec_eval_step(batch, 0, out)
                         continue
-                    nxt = self._submit(batch, out)
-                    if pending is not None:
-                        self._collect(pending)
-                    pending = nxt
-            if pending is not None:
-                self._collect(pending)
+                    pending.append(self._submit(batch, out))
+                    while len(pending) > self._searcher.lag:
+                        self._collect(pending.popleft())
+            while pending:
+                self._collect(pending.popleft())
         self.on_test_epoch_end()
         if was_training:
             self.train()

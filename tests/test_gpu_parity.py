@@ -972,3 +972,52 @@ def test_score_batch_refuses_rows_of_other_shards(idxmod):
     with pytest.raises(KeyError):
         ix.score_batch(["q"], ["nope"])            # unknown key (index.py:229)
     sh.close()
+
+
+def test_wide_screen_pass_and_coalescing(idxmod):
+    """Blocks of 65 .. 128 queries take the WIDE screened pass (one fp16 query term, 128 columns per scan; mfar_stage1_f16w_kernel,
+    6-slot and 4-slot twins): same bits as the oracle, as the 64-column pass (set_wide(False)) and as the forced exact
+    fall-back; random data is certified without a single redo; the pipeline coalesces two 64-query batches into one launch
+    and hands out exactly what the plain search returns."""
+    import torch
+    from mfar.data.pipeline import PipelinedSearcher
+    rng = np.random.default_rng(41)
+    dev = torch.device("cuda:0")
+    for F, D, E, Q in ((3, 40000, 768, 128), (2, 30000, 128, 100), (4, 20000, 96, 192), (1, 17000, 64, 65)):
+        slab, q, W = _mk(rng, F, D, E, Q)
+        ix = _load(idxmod, slab)
+        ix.set_screen(2)
+        assert ix.max_split_batch(100) == 128
+        o = O.c_two_stage(slab, q, W, None)
+        r = ix.search(q, W, None, return_fields=True)
+        assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32)), (F, D, E, Q)
+        st = ix.screen_stats()
+        assert st["n_checked"] == Q * F and st["n_failed"] == 0, st
+        ix.set_wide(False)
+        assert ix.max_split_batch(100) == 64
+        r64 = ix.search(q, W, None, return_fields=True)
+        ix.set_wide(True)
+        ix.set_screen(2, 1e9)                      # every certificate fails: the exact pass repairs both 64-query halves
+        rx = ix.search(q, W, None, return_fields=True)
+        ix.set_screen(2, 1.0)
+        for key in ("ids", "scores", "field_ids", "field_scores", "n_cand"):
+            assert np.array_equal(np.asarray(r[key]).view(np.uint8), np.asarray(r64[key]).view(np.uint8)), (key, "wide vs 64")
+            assert np.array_equal(np.asarray(r[key]).view(np.uint8), np.asarray(rx[key]).view(np.uint8)), (key, "wide vs fall-back")
+        # the pipeline: batches of <= 64 queries, two per launch
+        Wd = torch.from_numpy(W).to(dev)
+        ps = PipelinedSearcher(ix, Wd, None, max_batch=64)
+        assert ps.coalesce == 2 and ps.lag == 3
+        cuts = list(range(0, Q, 64)) * 3            # several launches, the last one possibly a single (flushed) batch
+        tickets, got = [], []
+        for i, c in enumerate(cuts):
+            tickets.append(ps.submit(torch.from_numpy(q[c:c + 64]).to(dev)))
+            if i >= ps.lag:
+                got.append({k: v.cpu().numpy().copy() for k, v in ps.result(tickets[i - ps.lag]).items()})
+        for t in tickets[max(0, len(cuts) - ps.lag):]:
+            got.append({k: v.cpu().numpy().copy() for k, v in ps.result(t).items()})
+        assert len(got) == len(cuts) and ps.n_redone == 0
+        for c, g in zip(cuts, got):
+            assert np.array_equal(g["ids"], o["ids"][c:c + 64]) and np.array_equal(g["scores"].view(np.uint32), o["scores"][c:c + 64].view(np.uint32))
+        with pytest.raises(ValueError):
+            ps.result(tickets[0])
+        ix.close()
