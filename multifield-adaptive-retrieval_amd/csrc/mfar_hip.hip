@@ -85,11 +85,12 @@ struct S1Geom {
     std::vector<long long> n_rows, base;   // per field: valid rows, element offset of the field inside the slab
     std::vector<int> n_tiles;              // per field: 256-row tiles
     S1Table all, solo;
+    S1Table all_w, solo_w;   // the wide pass keeps its own tables (same rule today; its list depth k' may differ from a 64-column pass in flight)
     void reset(int F) {
         n_rows.assign(F, 0);
         base.assign(F, 0);
         n_tiles.assign(F, 0);
-        all.k = solo.k = -1;
+        all.k = solo.k = all_w.k = solo_w.k = -1;
     }
 };
 
@@ -255,7 +256,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
                       &idx->own[0], &idx->own[1], &idx->s_stats, &idx->s_field, &idx->s_mean, &idx->screen, &idx->u_rep, &idx->u_start,
                       &idx->u_count, &idx->u_members, &idx->u_n};
     for (S1Geom* g : {&idx->geom_docs, &idx->geom_screen})
-        for (S1Table* t : {&g->all, &g->solo}) {
+        for (S1Table* t : {&g->all, &g->solo, &g->all_w, &g->solo_w}) {
             t->d_chunks.release();
             t->d_fchunk.release();
             t->d_samp_n.release();
@@ -443,11 +444,13 @@ static int check_search_common(const mfar_index* idx, const float* q, int Q, int
 // ------------------------------------------------------------------------------------------------ stage 1
 // Chunk table of a scanned slab for list depth k (mfar_stage1.h).  A field's share of the grid follows its tiles; the list
 // merge holds n_chunks * k keys of one field, which caps the chunks of a field.
-static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool solo, int sample_tiles_max, hipStream_t st) {
-    if (t.k == k && t.wgs == idx->wgs_per_cu) return MFAR_OK;
+//   waves   waves per workgroup of the pass (4; 8 for the wide pass): wave blocks published per sampled tile
+//   wgs     workgroups per CU the grid is sized for
+static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool solo, int sample_tiles_max, int waves, int wgs, hipStream_t st) {
+    if (t.k == k && t.wgs == wgs) return MFAR_OK;
     if (t.k >= 0) HIPCHK(hipDeviceSynchronize());   // a launch in flight may still read the old table
     const int F = idx->F;
-    const long long want = (long long)idx->wgs_per_cu * idx->n_cu;
+    const long long want = (long long)wgs * idx->n_cu;
     const int cap = std::max(1, std::min(128, (64 * 256) / k));
     long long total_tiles = 0;
     for (int f = 0; f < F; ++f) total_tiles += g.n_tiles[f];
@@ -480,9 +483,9 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
             min_tiles_per_chunk = std::min<long long>(min_tiles_per_chunk, g.n_tiles[f] / std::max(1, cf[f]));
         }
         const int st_cap = (int)std::max(1LL, min_tiles_per_chunk / 6);
-        while (sample_tiles < st_cap && 8LL * min_cf * sample_tiles < 3LL * k) ++sample_tiles;
+        while (sample_tiles < st_cap && 2LL * waves * min_cf * sample_tiles < 3LL * k) ++sample_tiles;
     }
-    while (sample_tiles > 1 && 8 * t.max_chunks * sample_tiles > 2048) --sample_tiles;
+    while (sample_tiles > 1 && 2 * waves * t.max_chunks * sample_tiles > 2048) --sample_tiles;
     t.sample_tiles = sample_tiles;
     t.samp_stride = 0;
     for (int f = 0; f < F; ++f) {
@@ -499,8 +502,8 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
             tl += std::min(sample_tiles, ck.t1 - ck.t0);
             t.chunks.push_back(ck);
         }
-        t.samp_n[f] = 4 * tl;
-        t.samp_stride = std::max(t.samp_stride, 4 * tl);
+        t.samp_n[f] = waves * tl;
+        t.samp_stride = std::max(t.samp_stride, waves * tl);
     }
     t.fchunk[F] = (int)t.chunks.size();
     t.n_chunks = (int)t.chunks.size();
@@ -512,7 +515,7 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
     HIPCHK(hipMemcpyAsync(t.d_fchunk.p, t.fchunk.data(), (F + 1) * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(t.d_samp_n.p, t.samp_n.data(), F * sizeof(int), hipMemcpyHostToDevice, st));
     t.k = k;
-    t.wgs = idx->wgs_per_cu;
+    t.wgs = wgs;
     return MFAR_OK;
 }
 
@@ -532,7 +535,8 @@ static int launch_s1(int kind, bool sample, unsigned grid, hipStream_t st, const
         if (sample) mfar_stage1_sample_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
         else mfar_stage1_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
     } else if (kind == S1_F16W) {
-        if (p.n_steps % 6 == 0) {
+        static const int w_ring = getenv("MFAR_WIDE_RING") ? atoi(getenv("MFAR_WIDE_RING")) : 0;   // diagnostic: 4 forces the 4-slot twin
+        if (p.n_steps % 6 == 0 && !(w_ring == 4 && p.n_steps % 4 == 0)) {
             if (sample) mfar_stage1_f16w_sample_kernel<<<g, b, S1HW_LDS_BYTES, st>>>(p);
             else mfar_stage1_f16w_kernel<<<g, b, S1HW_LDS_BYTES, st>>>(p);
         } else {
@@ -575,10 +579,10 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
                        const void* qt, int qt_n, int k, float tau0, const float* tau_base, const int* only_failed, bool record,
                        const S1Out& o, hipStream_t st) {
     const int qw = kind == S1_F16W ? 128 : 64;   // query columns of the pass: stride of every per-query table below
-    const bool solo = nf != idx->F;
-    S1Table& tb = solo ? geom.solo : geom.all;
+    const bool solo = nf != idx->F, wide = kind == S1_F16W;
+    S1Table& tb = wide ? (solo ? geom.solo_w : geom.all_w) : (solo ? geom.solo : geom.all);
     static const int sample_tiles_env = getenv("MFAR_SAMPLE_TILES") ? atoi(getenv("MFAR_SAMPLE_TILES")) : 0;
-    RETCHK(build_table(idx, geom, tb, k, solo, sample_tiles_env > 0 ? sample_tiles_env : (kind == S1_F32 ? 1 : 2), st));
+    RETCHK(build_table(idx, geom, tb, k, solo, sample_tiles_env > 0 ? sample_tiles_env : (kind == S1_F32 ? 1 : 2), 4, idx->wgs_per_cu, st));
     const int c_lo = tb.fchunk[f0], c_hi = tb.fchunk[f0 + nf];
     RETCHK(sl.lists.ensure((size_t)tb.n_chunks * qw * S1_CAP * sizeof(uint2)));
     RETCHK(sl.list_cnt.ensure((size_t)tb.n_chunks * qw * sizeof(int)));

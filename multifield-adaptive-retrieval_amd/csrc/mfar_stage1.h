@@ -807,8 +807,14 @@ __device__ __forceinline__ void s1_body_x16r(const S1Params& p) {
 // 128 queries reads the screen slab once per 128 queries instead of once per 64: half the scan bytes per query at the same
 // MFMA load.  The price is the query rounding error (u16 |q_i| per element instead of u16^2), which the certificate's
 // bound accounts for (mfar_screen.h: eps roughly doubles; the re-scored margin k' - k is as wide as before).
-// Same structure as s1_body_x16r<1, R>: docs in a register ring, the 4 KB query stage (two 64-query blocks x 2 KB) in an
-// LDS ring, 8 accumulators (128 VGPRs), one selection state per 64-query block and the epilogue run once per block.
+// Same structure as s1_body_x16r<1, R>: 4 waves, two workgroups per CU, docs in a register ring, the 4 KB query stage (two
+// 64-query blocks x 2 KB) in an LDS ring, 8 accumulators (128 VGPRs), one selection state per 64-query block; the append
+// half of the epilogue runs for both blocks before anything register-hungry (drain, compaction) does.
+// Shapes that were measured and dropped (1 M x 8 x 768, 2.0-2.3 ms per launch for this one): ONE workgroup per CU -- 8 waves
+// of 32 rows x 128 queries (184 VGPRs, no spills: 3.2 ms) or these 4 waves with a 12-slot ring and 512 VGPRs (3.6 ms): with a
+// single barrier domain per CU every late load stalls the whole CU.  The price of this shape is its register file: 256 VGPRs
+// x 2 waves per SIMD leave no room for the small kernels of the neighbouring launches, which therefore run between the
+// scans, not beside them (the 64-column pass, 221 VGPRs, does leave room).
 // ---------------------------------------------------------------------------------------------------------------------
 #define S1_SCAP_WIDE 32
 template <int R>
