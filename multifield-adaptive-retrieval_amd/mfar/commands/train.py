@@ -8,9 +8,11 @@ training is the accelerated path: corpus encode into the HBM slab + `mfar_search
 
 Training itself is stock PyTorch-ROCm (out of scope for kernels): one process per GPU, two AdamW optimisers
 (encoder / field weights, contrastive.py:305-374), `HybridContrastiveLoss` with in-batch negatives and the autograd-aware
-all-gather, early stopping on the proxy validation loss (train.py:225-240).  Two documented differences: the hard
-negative of an instance is a random corpus document instead of a BM25-mined one (`bm25s` is not installed and sparse
-indices are out of scope), and `--lexical_index` / `--sparse_scores_path` are accepted but unused.
+all-gather, early stopping on the proxy validation loss (train.py:225-240).  Hard negatives are mined like the reference
+does (contrastive.py:71-77: `IndexNegativeSampler` over the BM25 index `{lexical_index}/single_sparse_sparse_index`, built by
+`python -m mfar.commands.create_bm25s_index`) when that index exists; without it the negative of an instance is a random
+corpus document.  Sparse fields contribute BM25 score columns to the loss (`--sparse_scores_path`: precomputed scores in
+the reference's `{field}_keys_bm25.npy / {field}_vals_bm25.npy` layout, else computed on the fly).
 """
 import json
 import os
@@ -24,7 +26,7 @@ from mfar.commands import _setup
 from mfar.commands._cli import run
 from mfar.data import trec
 from mfar.data.format import format_documents
-from mfar.data.typedef import FieldType
+from mfar.data.typedef import FieldType, Query
 from mfar.modeling.contrastive import RetrievalTrainingModule
 from mfar.modeling.losses import HybridContrastiveLoss
 
@@ -47,7 +49,7 @@ def _autocast(precision: str, device):
 class _Instances:
     """(query, positive doc, one negative doc) triples from `<partition>.queries` / `<partition>.qrels`."""
 
-    def __init__(self, queries_path, partition, corpus, seed):
+    def __init__(self, queries_path, partition, corpus, seed, sampler=None):
         self.queries = dict(trec.read_corpus(f"{queries_path}/{partition}.queries"))
         with open(f"{queries_path}/{partition}.qrels") as f:
             self.qrels = [r for r in trec.QRels.from_text_io(f) if r.relevance > 0 and r.query_id in self.queries]
@@ -56,6 +58,11 @@ class _Instances:
         self.qrels = [r for r in self.qrels if r.doc_id in self.key_to_row]
         self.seed = seed
         self.rng = random.Random(seed)
+        # BM25-mined hard negatives (negative_sampler.py:40-60); positives of a query = all its relevant documents
+        self.sampler = sampler
+        self.pos_for_each_qid = {}
+        for r in self.qrels:
+            self.pos_for_each_qid.setdefault(r.query_id, set()).add(r.doc_id)
 
     def batches(self, batch_size, rank, world, shuffle, fixed_negatives=False):
         order = list(range(len(self.qrels)))
@@ -76,6 +83,11 @@ class _Instances:
             grows = [self.qrels[i] for i in order[g:g + batch_size * world]]
             gnegs = []
             for r in grows:
+                if getattr(self, "sampler", None) is not None:
+                    self.sampler.rng = neg_rng
+                    doc = self.sampler.sample(Query(r.query_id, self.queries[r.query_id]), self.pos_for_each_qid)[0]
+                    gnegs.append(self.key_to_row[doc._id])
+                    continue
                 n = neg_rng.randrange(len(self.corpus))
                 while self.corpus[n][0] == r.doc_id and len(self.corpus) > 1:
                     n = neg_rng.randrange(len(self.corpus))
@@ -96,17 +108,78 @@ def _encode_fields(module, tokenizer, docs, max_length, device):
         toks = tokenizer(texts, padding=True, truncation=True, max_length=min(max_length, field.max_seq_length, module.encoder.get_max_seq_length()),
                          return_tensors="pt")
         outs.append(module.encoder({k: v.to(device) for k, v in toks.items()})["sentence_embedding"])
+    if not outs:                                   # an all-sparse field set: no dense columns
+        return torch.zeros(len(docs), 0, module.encoder.get_sentence_embedding_dimension(), device=device)
     return torch.stack(outs, dim=1)
 
 
-def _loss_on_batch(module, loss_fn, tokenizer, inst, rows, negs, max_length, device, precision):
+def _sparse_columns(module, inst, rows, negs, device, sparse_scores):
+    """BM25 score columns of the loss for this rank's batch (losses.py:303-324): (pos [B, ws*B, Fs], neg [B, ws*B, Fs],
+    rev [ws*B, B, Fs]) or (None, None, None) without sparse fields.  Texts / keys of the other ranks come through
+    `all_gather_object` like in the reference (losses.py:262-273)."""
+    sparse = [(k, module.indices_dict[k]) for k, f in module.field_info.items() if f.field_type == FieldType.SPARSE]
+    if not sparse:
+        return None, None, None
+    import torch.distributed as dist
+    queries = [inst.queries[r.query_id] for r in rows]
+    qids = [r.query_id for r in rows]
+    pos_keys = [r.doc_id for r in rows]
+    neg_keys = [inst.corpus[n][0] for n in negs]
+    all_q, all_qids, all_pos, all_neg = queries, qids, pos_keys, neg_keys
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        def gather(x):
+            out = [None] * dist.get_world_size()
+            dist.all_gather_object(out, x)
+            return [y for part in out for y in part]
+        all_q, all_qids, all_pos, all_neg = gather(queries), gather(qids), gather(pos_keys), gather(neg_keys)
+
+    def cols(qs, ids, keys):
+        per_field = []
+        for key, si in sparse:
+            cache = (sparse_scores or {}).get(key)
+            if cache and all(_qkey(i) in cache for i in ids):
+                per_field.append(si.score_batch_with_cache([_qkey(i) for i in ids], keys, cache).float())
+            else:
+                per_field.append(si.score_batch(qs, keys).float())
+        return torch.stack(per_field, dim=-1).to(device)
+    return cols(queries, qids, all_pos), cols(queries, qids, all_neg), cols(all_q, all_qids, pos_keys)
+
+
+def _qkey(qid):
+    """Precomputed sparse scores are keyed by the integer query id (precompute_bm25s_scores.py:56)."""
+    try:
+        return int(qid)
+    except (TypeError, ValueError):
+        return qid
+
+
+def read_sparse_scores(scores_path, field_info):
+    """{field_key: {query id: {doc number: score}}} from `{scores_path}/{field_key}_keys_bm25.npy` ([n, 2] int: query id,
+    doc number) and `{field_key}_vals_bm25.npy` ([n] float16) -- reference modeling/util.py:151-173."""
+    import numpy as np
+    out = {}
+    for key, f in field_info.items():
+        if f.field_type != FieldType.SPARSE:
+            continue
+        keys = np.load(f"{scores_path}/{key}_keys_bm25.npy")
+        vals = np.load(f"{scores_path}/{key}_vals_bm25.npy")
+        assert len(keys) == len(vals)
+        d = {}
+        for (qid, doc), v in zip(keys.tolist(), vals.tolist()):
+            d.setdefault(qid, {})[doc] = v
+        out[key] = d
+    return out
+
+
+def _loss_on_batch(module, loss_fn, tokenizer, inst, rows, negs, max_length, device, precision, sparse_scores=None):
     qt = tokenizer([inst.queries[r.query_id] for r in rows], padding=True, truncation=True,
                    max_length=module.encoder.get_max_seq_length(), return_tensors="pt")
     with _autocast(precision, device):
         q = module.encoder({k: v.to(device) for k, v in qt.items()})["sentence_embedding"]
         d_pos = _encode_fields(module, tokenizer, [inst.corpus[inst.key_to_row[r.doc_id]] for r in rows], max_length, device)
         d_neg = _encode_fields(module, tokenizer, [inst.corpus[n] for n in negs], max_length, device).unsqueeze(2)
-    return loss_fn(q.float(), d_pos.float(), d_neg.float())
+    sp_pos, sp_neg, sp_rev = _sparse_columns(module, inst, rows, negs, device, sparse_scores)
+    return loss_fn(q.float(), d_pos.float(), d_neg.float(), sp_pos, sp_neg, sp_rev)
 
 
 def _sync_grads(params, world):
@@ -166,8 +239,22 @@ def main(
         indices_dict=st.indices_dict, vectors_dict=st.vectors_dict, trec_val_freq=trec_val_freq, freeze_encoder=freeze_encoder,
         query_cond=query_cond, prefix=prefix, use_batchnorm=use_batchnorm)
     module.to(device)
+    sparse_indices = {k: st.indices_dict[k] for k, f in field_info.items() if f.field_type == FieldType.SPARSE}
     loss_fn = HybridContrastiveLoss(temperature=temperature, mixture_of_fields_layer=module.mixture_of_fields_layer,
-                                    sparse_indices_dict={}, num_fields=len(field_info), use_batchnorm=use_batchnorm).to(device)
+                                    sparse_indices_dict=sparse_indices, num_fields=len(field_info), use_batchnorm=use_batchnorm).to(device)
+    sparse_scores = read_sparse_scores(sparse_scores_path, field_info) if (sparse_scores_path and sparse_indices) else None
+    # hard negatives: BM25 over the whole-document text, as the reference's data module sets up (contrastive.py:71-77)
+    sampler = None
+    neg_index = f"{lexical_index}/single_sparse_sparse_index"
+    if max_epochs > 0 and os.path.exists(f"{neg_index}/keys.json"):
+        from mfar.data.index import BM25sSparseIndex
+        from mfar.data.negative_sampler import IndexNegativeSampler
+        if int(negative_sampling_params[2]) != 1:
+            raise NotImplementedError("one negative per instance (n_sample = 1, the reference default)")
+        sampler = IndexNegativeSampler(BM25sSparseIndex.load(neg_index), dict(corpus_contents), n_retrieve=int(negative_sampling_params[0]),
+                                       n_bottom=int(negative_sampling_params[1]), n_sample=1)
+    elif max_epochs > 0 and rank == 0:
+        print(f"No BM25 index at {neg_index}: training negatives are random corpus documents")
 
     enc_params = [p for p in module.encoder.parameters() if p.requires_grad]
     lin_params = [p for p in list(module.mixture_of_fields_layer.parameters()) + list(loss_fn.bn.parameters()) if p.requires_grad]
@@ -178,8 +265,8 @@ def main(
     scaler = torch.amp.GradScaler("cuda", enabled=precision.startswith("16"))
 
     best_path, best_loss, bad_epochs, step = "", float("inf"), 0, 0
-    train_inst = _Instances(queries, "train", corpus_contents, seed) if max_epochs > 0 else None
-    val_inst = _Instances(queries, "val", corpus_contents, seed + 1) if max_epochs > 0 else None
+    train_inst = _Instances(queries, "train", corpus_contents, seed, sampler) if max_epochs > 0 else None
+    val_inst = _Instances(queries, "val", corpus_contents, seed + 1, sampler) if max_epochs > 0 else None
     print(f"Starting training: {time.strftime('%Y-%m-%d %H:%M:%S')}")
     for epoch in range(max_epochs):
         module.train()
@@ -187,7 +274,7 @@ def main(
         for rows, negs in train_inst.batches(train_batch_size, rank, world, shuffle=True):
             for o in opts:
                 o.zero_grad(set_to_none=True)
-            loss = _loss_on_batch(module, loss_fn, tokenizer, train_inst, rows, negs, train_max_length, device, precision)
+            loss = _loss_on_batch(module, loss_fn, tokenizer, train_inst, rows, negs, train_max_length, device, precision, sparse_scores)
             scaler.scale(loss).backward()
             _train_step_sync(scaler, opts, enc_params + lin_params, world)
             step += 1
@@ -203,7 +290,7 @@ def main(
         with torch.no_grad():
             for rows, negs in val_inst.batches(dev_batch_size if dev_batch_size < 32 else 16, rank, world, shuffle=False,
                                                 fixed_negatives=True):
-                tot += float(_loss_on_batch(module, loss_fn, tokenizer, val_inst, rows, negs, dev_max_length, device, precision))
+                tot += float(_loss_on_batch(module, loss_fn, tokenizer, val_inst, rows, negs, dev_max_length, device, precision, sparse_scores))
                 cnt += 1
                 if run_one_iteration:
                     break

@@ -5,6 +5,7 @@ Mirrors the reference's `mfar.data.index` surface (reference mfar/data/index.py)
   * `DenseFlatIndex`            index.py:160-232 (same constructor, `.vectors` re-assignable, `retrieve_batch`,
                                                   `score_batch`, KeyError on unknown keys)
   * `candidate_encoding_stream` index.py:234-258
+  * `BM25sSparseIndex`          index.py:39-157  (sparse fields and hard-negative mining; host CPU, mfar/data/bm25.py)
 and adds `MultiFieldIndex`, the on-HBM row shard of ALL fields that replaces the per-field np.memmap files
 (data/util.py:28-59) and runs the whole of `trec_eval_step` (modeling/contrastive.py:669-704) on the GPU through
 the C ABI of libmfar_hip.so (include/mfar_hip.h).  There is no CPU fallback: without the HIP library these
@@ -12,7 +13,7 @@ classes raise.
 """
 import ctypes
 from abc import ABC, abstractmethod
-from typing import Dict, Generic, Iterable, Optional, Sequence, Tuple, TypeVar, Union
+from typing import Dict, Generic, Iterable, List, Optional, Sequence, Tuple, TypeVar, Union
 
 import numpy as np
 
@@ -410,6 +411,98 @@ def mix_topk(cand_scores, cand_ids, q, W, mask=None, n_cand=None, k: int = 100, 
                                               Q, C, F, E, int(k), ia.ptr, sa.ptr, nva.ptr, int(on_dev),
                                               _current_stream(device, on_dev)))
     return dict(ids=ids, scores=sc, n_valid=nv)
+
+
+class BM25sSparseIndex(Index[str, str]):
+    """A sparse field index (reference index.py:39-157): same constructor, methods and return shapes.  The reference
+    wraps the third-party `bm25s` package; here the BM25 arithmetic is the restatement in mfar/data/bm25.py (host CPU,
+    parity unpinned -- see that module).  Ties follow the canonical order (score desc, doc number asc)."""
+
+    def __init__(self, keys: List[str], index, stemmer=None, index_limit: int = 5000, safe_docs=None):
+        self.keys = keys
+        self.key_to_id = {key: i for i, key in enumerate(keys)}
+        self.index = index
+        self.stemmer = stemmer
+        self.index_limit = index_limit
+        self.safe_docs = safe_docs if safe_docs is not None else {}
+        self.name = None
+        self._score_memo: Dict[str, np.ndarray] = {}      # the reference memoises get_scores per query (lru_cache 2**15)
+
+    def set_safe_docs(self, safe_docs):
+        self.safe_docs = safe_docs
+
+    @staticmethod
+    def tokenize_single(query: str, stopwords: str, stemmer=None, return_ids: bool = False):
+        if return_ids:
+            raise NotImplementedError("token-id output (bm25s `Tokenized`) is not part of the restated surface")
+        from mfar.data import bm25
+        return bm25.tokenize(query, stopwords=stopwords, stemmer=stemmer)[0]
+
+    def tokenize(self, queries, stopwords, stemmer, return_ids=False):
+        if isinstance(queries, str):
+            return BM25sSparseIndex.tokenize_single(queries, stopwords, stemmer, return_ids)
+        return [BM25sSparseIndex.tokenize_single(q, stopwords, stemmer, return_ids) for q in queries]
+
+    def get_scores(self, query: str) -> np.ndarray:        # [D]
+        s = self._score_memo.get(query)
+        if s is None:
+            s = self.index.get_scores(self.tokenize(query, stopwords="en", stemmer=self.stemmer))
+            if len(self._score_memo) >= 2 ** 15:
+                self._score_memo.clear()
+            self._score_memo[query] = s
+        return s
+
+    def get_scores_sparse(self, query: str) -> Dict[int, float]:
+        dense = self.index.get_scores(self.tokenize(query, stopwords="en", stemmer=self.stemmer))
+        return {int(i): dense[i] for i in np.nonzero(dense)[0] if int(i) in self.safe_docs}
+
+    def retrieve(self, query: str, top_k: int) -> Sequence[Tuple[str, float]]:
+        return self.retrieve_batch([query], top_k)[0]
+
+    def retrieve_batch(self, queries: Sequence[str], top_k: int) -> Sequence[Sequence[Tuple[str, float]]]:
+        toks = self.tokenize(list(queries), stopwords="en", stemmer=self.stemmer)
+        ids, scores = self.index.retrieve(toks, k=top_k)
+        return [[(self.keys[ids[i, j]], scores[i, j]) for j in range(ids.shape[1])] for i in range(ids.shape[0])]
+
+    def score(self, query: str, keys: Sequence[str]) -> np.ndarray:       # [Cand]; KeyError on unknown keys like the reference
+        doc_ids = np.array([self.key_to_id[key] for key in keys], dtype=np.int64)
+        return self.get_scores(query)[doc_ids]
+
+    def score_batch(self, queries: Sequence[str], keys: Sequence[str]):   # -> tensor [Query, Cand]; unknown keys score 0
+        import torch
+        doc_ids = np.array([self.key_to_id.get(key, -1) for key in keys], dtype=np.int64)
+        all_scores = np.stack([self.get_scores(q) for q in queries], axis=0) if len(queries) else np.zeros((0, len(self.keys)), np.float32)
+        out = all_scores[:, np.maximum(doc_ids, 0)] if doc_ids.size else np.zeros((len(queries), 0), np.float32)
+        out[:, doc_ids < 0] = 0
+        return torch.tensor(out)
+
+    def score_batch_with_cache(self, query_ids, keys: Sequence[str], sparse_scores: Dict):
+        import torch
+        doc_ids = [self.key_to_id[key] for key in keys]
+        rows = [sparse_scores.get(qid, {}) for qid in query_ids]
+        return torch.tensor([[row.get(d, 0) for d in doc_ids] for row in rows])
+
+    @classmethod
+    def create(cls, corpus, stemmer=None, dataset_name: Optional[str] = ""):
+        from mfar.data import bm25
+        keys = list(corpus.keys())
+        texts = [d.text for d in corpus.docs]
+        index = bm25.BM25(method="lucene", k1=1.2, b=0.75).index(bm25.tokenize(texts, stopwords="en", stemmer=stemmer))
+        return cls(keys, index, stemmer, 5000 if dataset_name == "amazon" else 12000)
+
+    def save(self, path: str):
+        import json
+        self.index.save(f"{path}/index")
+        with open(f"{path}/keys.json", "w") as f:
+            json.dump(self.keys, f)
+
+    @classmethod
+    def load(cls, path: str, stemmer=None):
+        import json
+        from mfar.data import bm25
+        with open(f"{path}/keys.json", "r") as f:
+            keys = json.load(f)
+        return cls(keys, bm25.BM25.load(f"{path}/index", mmap=True), stemmer)
 
 
 class DenseFlatIndex(Index[str, str]):

@@ -1,10 +1,10 @@
-"""Small data types of the path (reference mfar/data/typedef.py): `FieldType`, `Field`, `Query`, `Document`.
-Only the shapes the dense scoring path needs are kept; the gzip/JSON-mixin loaders of the reference are training-data
+"""Small data types of the path (reference mfar/data/typedef.py): `FieldType`, `Field`, `Query`, `Document`, `Corpus`.
+Only the shapes the scoring path needs are kept; the gzip/JSON-mixin loaders of the reference are training-data
 plumbing and out of scope."""
 import json
 from dataclasses import dataclass
 from enum import Enum
-from typing import Any, Optional
+from typing import Any, Dict, Iterator, List, Optional
 
 
 class FieldType(Enum):
@@ -57,3 +57,41 @@ class Document:
     text: Any
     title: Optional[str] = None
     metadata: Any = None
+
+
+@dataclass
+class Corpus:
+    """Ordered documents with key -> position lookup (typedef.py:125-171); what `BM25sSparseIndex.create` consumes."""
+    docs: List[Document]
+    dataset_name: Optional[str] = None
+
+    def __post_init__(self):
+        self.key_to_id = {doc._id: i for i, doc in enumerate(self.docs)}
+
+    def keys(self) -> Iterator[str]:
+        return (doc._id for doc in self.docs)
+
+    def __len__(self):
+        return len(self.docs)
+
+    def get_text_by_id(self, doc_id: int) -> str:
+        return self.docs[doc_id].text
+
+    def get_text_by_key(self, key: str) -> str:
+        return self.docs[self.key_to_id[key]].text
+
+    def get_doc_by_id(self, doc_id: int) -> Document:
+        return self.docs[doc_id]
+
+    def get_doc_by_key(self, key: str) -> Document:
+        try:
+            return self.docs[self.key_to_id[key]]
+        except KeyError:
+            raise KeyError(f"Key {key} not found in corpus.")
+
+    def pairs(self):
+        return ((doc._id, doc.text) for doc in self.docs)
+
+    @classmethod
+    def from_docs_dict(cls, docs_dict: Dict[Any, str], dataset_name: str = None) -> "Corpus":
+        return cls([Document(key, text) for key, text in docs_dict.items()], dataset_name)

@@ -129,7 +129,15 @@ class RetrievalTrainingModule(torch.nn.Module):
 
     @property
     def slab(self):
-        return next(iter(self.indices_dict.values())).slab
+        """The HBM row shard shared by the dense fields (None for an all-sparse field set)."""
+        for ix in self.indices_dict.values():
+            if getattr(ix, "slab", None) is not None:
+                return ix.slab
+        return None
+
+    @property
+    def has_sparse(self) -> bool:
+        return any(f.field_type == FieldType.SPARSE for f in self.field_info.values())
 
     def mark_encoder_updated(self):
         """Call after the encoder weights changed (a training epoch, a checkpoint load): the next evaluation re-encodes."""
@@ -154,7 +162,7 @@ class RetrievalTrainingModule(torch.nn.Module):
         bs = self.dev_batch_size
         for key, field in self.field_info.items():
             if field.field_type != FieldType.DENSE:
-                continue
+                continue                                                         # sparse fields were indexed at start-up (BM25)
             docs = format_documents(segment, field.name, field.dataset)          # contrastive.py:473-475
             if self.prefix:
                 docs = [(i, field.name + ": " + t) for i, t in docs]            # :476-481
@@ -184,7 +192,8 @@ class RetrievalTrainingModule(torch.nn.Module):
             for b in range(0, len(docs), step):
                 vec.write_block(docs[b][0], emb_u.index_select(0, rows[b:b + step]).contiguous())   # straight into the HBM slab
             del emb_u
-        torch.cuda.synchronize(self.device)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
         _barrier()                                                               # :491 (no memmap reopen needed)
         self._corpus_encoded = True
 
@@ -242,8 +251,61 @@ class RetrievalTrainingModule(torch.nn.Module):
                     print(trec.QRes(query_id=q._id, doc_id=self.numeric_ids_to_keys[d], sim=s), file=qres_output)
 
     @torch.no_grad()
+    def _hybrid_step(self, batch, qres_output) -> None:
+        """trec_eval_step (contrastive.py:669-704) for a field set WITH sparse fields, one batch, synchronously: the dense
+        per-field lists and candidate scores come from the HBM slab through the C ABI (`mfar_retrieve_fields`,
+        `mfar_score_candidates`), the sparse lists and score columns from the host BM25 indices (index.py:97-124), and the
+        mask + field-weight softmax + top-k runs in `mfar_mix_topk` over all F columns in `field_info` order."""
+        import numpy as np
+        from mfar.data import index as idxmod
+        rank, world = _dist()
+        if world > 1:
+            raise NotImplementedError("sparse fields are evaluated on one rank (the dense row shards have no sparse counterpart)")
+        x = self.encode_query_batch(batch)
+        Q = x.shape[0]
+        texts = [q.text for q in batch.instances]
+        fields = list(self.field_info.items())
+        dense_cols = [i for i, (_, f) in enumerate(fields) if f.field_type == FieldType.DENSE]
+        lists = [[] for _ in range(Q)]                                           # per query: arrays of numeric doc ids
+        if dense_cols:
+            fid, _ = self.slab.retrieve_fields(x, TOP_K, True)                   # zero-sentinel lists incl. their (0, 0.0) padding
+            fid = fid.cpu().numpy()
+            for i in range(Q):
+                lists[i].append(fid[i].reshape(-1))
+        for key, f in fields:
+            if f.field_type == FieldType.SPARSE:
+                for i, row in enumerate(self.indices_dict[key].retrieve_batch(texts, TOP_K)):          # :672-674
+                    lists[i].append(np.array([self.keys_to_numeric_ids[k] for k, _ in row], dtype=np.int64))
+        cands = [np.unique(np.concatenate(l)) for l in lists]                    # :678-679 (set union)
+        cands = [c[c >= 0] for c in cands]
+        C = max(len(c) for c in cands)
+        cand = np.full((Q, C), -1, np.int64)
+        n_cand = np.zeros(Q, np.int32)
+        for i, c in enumerate(cands):
+            cand[i, :len(c)], n_cand[i] = c, len(c)
+        xs = np.zeros((Q, C, len(fields)), np.float32)
+        if dense_cols:
+            cd = torch.from_numpy(cand).to(self.device)
+            xs[:, :, dense_cols] = self.slab.score_candidates(x, cd).cpu().numpy()                     # :681-683, dense
+        for col, (key, f) in enumerate(fields):
+            if f.field_type == FieldType.SPARSE:
+                for i in range(Q):
+                    keys = [self.numeric_ids_to_keys[d] for d in cands[i]]
+                    xs[i, :len(keys), col] = self.indices_dict[key].score_batch([texts[i]], keys)[0].numpy()
+        res = idxmod.mix_topk(xs, cand, x.cpu().numpy(), self._weights().cpu().numpy(), self.mask[:, 0].float().numpy(),
+                              n_cand=n_cand, k=TOP_K, query_cond=self.query_cond, device=self.device.index or 0)   # :685-696
+        if int(res["n_valid"].min()) < TOP_K:
+            raise RuntimeError(f"selected index k out of range: only {int(res['n_valid'].min())} candidates for k={TOP_K}")
+        if rank == 0 and qres_output is not None:
+            for q, row_ids, row_sims in zip(batch.instances, res["ids"].tolist(), res["scores"].tolist()):
+                for d, sim in zip(row_ids, row_sims):
+                    print(trec.QRes(query_id=q._id, doc_id=self.numeric_ids_to_keys[d], sim=sim), file=qres_output)
+
+    @torch.no_grad()
     def trec_eval_step(self, batch, batch_idx: int, qres_output) -> None:
         """One batch, synchronously (the reference's hook signature).  `test()` overlaps consecutive batches instead."""
+        if self.has_sparse:
+            return self._hybrid_step(batch, qres_output)
         if len(batch.instances) > self._get_searcher().Qb:
             for b in range(0, len(batch.instances), self._searcher.Qb):           # one ticket at a time
                 sub = SimpleNamespace(instances=batch.instances[b:b + self._searcher.Qb],
@@ -294,6 +356,9 @@ class RetrievalTrainingModule(torch.nn.Module):
             for li, loader in enumerate(data_module.test_dataloader()):
                 out = self.qres_output if li == 0 else self.additional_qres_output
                 for batch in loader:
+                    if self.has_sparse:
+                        self.trec_eval_step(batch, 0, out)
+                        continue
                     if len(batch.instances) > self._get_searcher().Qb:
                         while pending:
                             self._collect(pending.popleft())

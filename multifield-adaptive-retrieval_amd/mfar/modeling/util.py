@@ -18,9 +18,10 @@ import numpy as np
 import torch
 
 from mfar.data import trec
-from mfar.data.index import DenseFlatIndex, MultiFieldIndex
+from mfar.data.format import format_documents
+from mfar.data.index import BM25sSparseIndex, DenseFlatIndex, MultiFieldIndex
 from mfar.data.sharded import shard_bounds
-from mfar.data.typedef import FieldType
+from mfar.data.typedef import Corpus, FieldType
 from mfar.data.util import HbmFieldVectors
 
 
@@ -158,23 +159,29 @@ def _dist_info() -> Tuple[int, int, int]:
 
 
 def read_and_create_indices(corpus_path, dataset_name, field_info, temp_dir, encoder):
-    """-> (corpus [(id, json)], vectors_dict {field_key: HbmFieldVectors}, indices_dict {field_key: DenseFlatIndex}).
+    """-> (corpus [(id, json)], vectors_dict {field_key: HbmFieldVectors}, indices_dict {field_key: DenseFlatIndex | BM25sSparseIndex}).
     All dense fields share one `MultiFieldIndex` holding this rank's row shard (contrastive.py:470); the field order
-    inside the slab is the order of `field_info` (schema.py:131-134)."""
+    inside the slab is the order of the dense keys in `field_info` (schema.py:131-134: dense keys first, then sparse).
+    Sparse fields get a host-side BM25 index over the field's formatted text (modeling/util.py:102-106)."""
     corpus = list(trec.read_corpus(corpus_path))
     dense = [k for k, f in field_info.items() if f.field_type == FieldType.DENSE]
-    if any(f.field_type == FieldType.SPARSE for f in field_info.values()):
-        raise NotImplementedError("BM25 sparse fields are outside the dense scoring path (SURVEY.md section 2)")
     keys = [x[0] for x in corpus]
     key_to_id = {k: i for i, k in enumerate(keys)}
     Path(temp_dir).mkdir(parents=True, exist_ok=True)
     rank, world, local_rank = _dist_info()
     r0, r1 = shard_bounds(len(corpus), rank, world)
-    slab = MultiFieldIndex(r1 - r0, len(dense), encoder.get_sentence_embedding_dimension(), device=local_rank, row_offset=r0)
     vectors_dict, indices_dict = {}, {}
-    for fi, key in enumerate(dense):
-        field = field_info[key]
-        vectors_dict[key] = HbmFieldVectors(slab, fi, keys, path=f"{temp_dir}/{field.name}.npy")
-        indices_dict[key] = DenseFlatIndex(encoder, None, numeric_ids_to_keys=keys, keys_to_numeric_ids=key_to_id, slab=slab,
-                                           field_index=fi)
+    if dense:
+        slab = MultiFieldIndex(r1 - r0, len(dense), encoder.get_sentence_embedding_dimension(), device=local_rank, row_offset=r0)
+        for fi, key in enumerate(dense):
+            field = field_info[key]
+            vectors_dict[key] = HbmFieldVectors(slab, fi, keys, path=f"{temp_dir}/{field.name}.npy")
+            indices_dict[key] = DenseFlatIndex(encoder, None, numeric_ids_to_keys=keys, keys_to_numeric_ids=key_to_id, slab=slab,
+                                               field_index=fi)
+    for key, field in field_info.items():
+        if field.field_type == FieldType.SPARSE:
+            formatted = format_documents(corpus, field.name, field.dataset)
+            docs = Corpus.from_docs_dict({item[0]: item[1] for item in formatted})
+            indices_dict[key] = BM25sSparseIndex.create(docs, dataset_name=dataset_name)
+            indices_dict[key].name = field.name
     return corpus, vectors_dict, indices_dict

@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _write_dataset(root, n_docs=300, n_q=24, seed=0):
+def _write_dataset(root, n_docs=300, n_q=24, seed=0, relations=False):
     rng = np.random.default_rng(seed)
     words = ["red", "blue", "shoe", "hat", "acme", "zen", "light", "heavy", "wool", "cotton", "alpha", "beta", "gamma", "delta"]
     os.makedirs(root, exist_ok=True)
@@ -18,6 +18,9 @@ def _write_dataset(root, n_docs=300, n_q=24, seed=0):
         for i in range(n_docs):
             body = {"title": " ".join(rng.choice(words, 3)), "brand": str(rng.choice(words)),
                     "feature": [str(w) for w in rng.choice(words, 2)]}
+            if relations:                    # the whole-document ("single") rendering reads both lists (format.py:196-207)
+                body["also_buy"] = [str(w) for w in rng.choice(words, 2)]
+                body["also_view"] = []
             if i % 7 == 0:
                 del body["brand"]            # missing field -> "" -> identical vectors -> ties
             docs.append(body)
@@ -196,3 +199,62 @@ def test_prime_2000_all_dense_end_to_end(tmp_path, monkeypatch):
     mask = np.ones(F, np.float32)
     mask[list(m2.field_info).index("type_dense")] = 0
     _assert_qres_equals_oracle(f"{out2}/final-all-0.qres", _oracle_eval(m2, _data_module(m2, data, tmp, "prime", 16), mask), bits=False)
+
+
+def test_sparse_fields_and_bm25_negatives(tmp_path):
+    """a field set with sparse (BM25) fields through the CLIs.  `create_bm25s_index` builds the whole-document
+    index that hard-negative mining reads; `train` mines its negatives from it, feeds the BM25 score columns to the loss and
+    evaluates with the hybrid step (dense lists / scores from the HBM slab, sparse lists / scores from the host index, one
+    mixer over all columns).  The .qres must equal the same algorithm restated on the host from the oracle's pieces."""
+    import torch
+    from mfar.commands import create_bm25s_index, mask_fields, train
+    from mfar.data.typedef import FieldType
+    from oracle import mfar_oracle as O
+    data, lex = str(tmp_path / "data"), str(tmp_path / "lex")
+    _write_dataset(data, relations=True)
+    create_bm25s_index.main(data_path=data, dataset_name="amazon", output_path=lex, fields_str="single_sparse")
+    assert os.path.exists(f"{lex}/single_sparse_sparse_index/keys.json")
+    out, tmp = str(tmp_path / "out"), str(tmp_path / "tmp")
+    module = train.main(dataset_name="amazon", lexical_index=lex, out=out, temp_dir=tmp, data=data, model_name="random-init:64x2",
+                        field_names="title_dense,brand_dense,title_sparse,feature_sparse", weights_lr=1e-2, encoder_lr=1e-4,
+                        train_batch_size=8, dev_batch_size=16, max_epochs=1, precision="32", negative_sampling_params=(20, 5, 1))
+    fields = list(module.field_info.items())
+    assert [k for k, _ in fields] == ["brand_dense", "title_dense", "feature_sparse", "title_sparse"]      # schema.py:131-134
+    assert module.slab.n_fields == 2 and module.has_sparse
+    W = module.mixture_of_fields_layer.weight.detach().cpu().numpy()
+    assert W.shape == (64, 4) and not np.allclose(W, 1.0)
+
+    # the same algorithm from the oracle's pieces (contrastive.py:669-704 with sparse indices in indices_dict)
+    slab = np.stack([module.slab.read_rows(f) for f in range(2)])
+    dm = _data_module(module, data, tmp, "amazon", 16)
+    keys = module.numeric_ids_to_keys
+    want = {}
+    module.eval()
+    for batch in dm.test_dataloader()[0]:
+        with torch.no_grad():
+            qe = module.encode_query_batch(batch).cpu().numpy()
+        for i, inst in enumerate(batch.instances):
+            lists = [O.c_retrieve(slab[f], qe[i:i + 1], 100, True)[0][0] for f in range(2)]
+            for key, f in fields:
+                if f.field_type == FieldType.SPARSE:
+                    lists.append(np.array([module.keys_to_numeric_ids[k] for k, _ in module.indices_dict[key].retrieve(inst.text, 100)]))
+            cand = np.unique(np.concatenate(lists))
+            xs = np.zeros((len(cand), 4), np.float32)
+            xs[:, :2] = O.c_score_candidates(slab, qe[i:i + 1], cand[None])[0]
+            for col, (key, f) in enumerate(fields):
+                if f.field_type == FieldType.SPARSE:
+                    xs[:, col] = module.indices_dict[key].score(inst.text, [keys[d] for d in cand])
+            ids, sc = O.canon(cand, O.c_mix(xs, O.c_gate(qe[i], W, True), None))
+            want[inst._id] = (ids[:100], sc[:100])
+    _assert_qres_equals_oracle(f"{out}/final-all-0.qres", want)
+    # sparse scores matter: the ranking differs from the dense-only ranking for at least one query
+    dense_only = O.c_two_stage(slab, qe, W[:, :2].copy(), None)
+    assert any(not np.array_equal(want[inst._id][0], dense_only["ids"][i]) for i, inst in enumerate(batch.instances))
+
+    # mask_fields: baseline, 4 single fields, all-sparse, all-dense, then per field NAME (brand, feature, title)
+    out2 = str(tmp_path / "out2")
+    mask_fields.main(dataset_name="amazon", lexical_index=lex, out=out2, temp_dir=tmp, data=data, model_name="random-init:64x2",
+                     field_names="title_dense,brand_dense,title_sparse,feature_sparse", checkpoint_dir=out, dev_batch_size=16)
+    rows = [json.loads(l) for l in open(f"{out2}/results_dicts-all-0.jsonl")]
+    assert [r["masked_fields"] for r in rows][:7] == ["", "brand_dense", "title_dense", "feature_sparse", "title_sparse",
+                                                      "feature_sparse,title_sparse", "brand_dense,title_dense"]
