@@ -121,6 +121,21 @@ int mfar_search_two_stage(mfar_index* idx, const float* q, int Q, const float* W
                           int64_t* field_ids, float* field_scores, int32_t* n_cand, int on_device, void* stream);
 
 /*
+ * Fused mode (no reference counterpart): the EXHAUSTIVE mix instead of the two-stage one.  The reference scores a
+ * document as sum_f softmax_f(q W) mask_f <q, d_f> (weighting.py:25-29, contrastive.py:685-694) but only over the union of the
+ * per-field top-100 lists; folding the gate into the query, that sum is one inner product in n_fields * dim dimensions, and
+ * this entry point returns its top-k over ALL rows of the shard: ids / scores [Q, k] (padding (-1, -inf)), canonical order.
+ * It is a different result set than mfar_search_two_stage (a document strong in the mix but outside every per-field list is
+ * found here and not there): it claims Recall@k parity, not id parity, and bench.py reports it separately.  The score of a
+ * pair is the contract's fma chain over the n_fields * dim folded products.  The first call builds a companion slab of rows of
+ * dim n_fields * dim over the same documents (+100 % HBM for the fp32 copy); fp32 indexes only, k < 128.  It is scanned by
+ * the exact fp32 MFMA pass: 2 * D * F * E flops per query at the fp32 MFMA rate, i.e. SLOWER than the certified two-stage path
+ * on this hardware (the certificate's norm bound does not shrink with averaged scores, so screening does not pay for it).
+ */
+int mfar_search_fused(mfar_index* idx, const float* q, int Q, const float* W, int query_cond, const float* mask, int k,
+                      int64_t* ids, float* scores, int on_device, void* stream);
+
+/*
  * Second half of mfar_search_two_stage on its own: union (contrastive.py:678-679) -> stage 2 (:681-683) -> mask, field
  * weights, top-k2 (:685-696), given the stage-1 lists produced by mfar_retrieve_fields.  Device pointers only, nothing
  * synchronises.  `slot` (0/1) selects one of two internal workspaces: with mfar_retrieve_fields(batch i+1) on one stream

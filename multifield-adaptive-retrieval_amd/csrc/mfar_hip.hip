@@ -131,6 +131,10 @@ struct mfar_index {
     bool screen_dedup = true;     // MFAR_SCREEN_DEDUP=0: every document is its own unique row (diagnostic)
     bool wide = true;             // blocks of 65 .. 128 queries go through the wide screened pass (MFAR_WIDE=0: always 64 per pass)
     S1Geom geom_docs, geom_screen;
+    // fused mode (mfar_search_fused): a one-field companion index of dim F * E over the same rows, built on first use
+    mfar_index* fused = nullptr;
+    bool fused_dirty = true;      // rows were written since the companion was filled
+    DevBuf fused_q;               // folded queries [Q, F * E]
     hipEvent_t mid_ev = nullptr;  // recorded right before the full stage-1 kernel is launched
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -154,6 +158,7 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1B_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1B_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_mix_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_fold_queries_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1H_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1H_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16r_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HR_LDS_BYTES));
@@ -250,6 +255,8 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
     (void)hipDeviceSynchronize();
+    if (idx->fused) mfar_index_destroy(idx->fused);
+    idx->fused_q.release();
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
     DevBuf* bufs[] = {&idx->fid, &idx->fsc, &idx->cand[0], &idx->cand[1], &idx->ncand[0], &idx->ncand[1], &idx->x[0], &idx->x[1],
@@ -337,6 +344,7 @@ extern "C" int mfar_index_write_rows(mfar_index* idx, int field, int64_t local_r
     if (n == 0) return MFAR_OK;
     HIPCHK(hipSetDevice(idx->device));
     idx->screen_dirty = true;
+    idx->fused_dirty = true;
     hipStream_t st = (hipStream_t)stream;
     char* fbase = (char*)idx->slab + (size_t)field * idx->field_stride * idx->esize;
     const int64_t chunk = on_device ? n : std::min<int64_t>(n, (int64_t)(256u << 20) / (idx->E * 4));
@@ -1355,6 +1363,90 @@ extern "C" int mfar_search_stage2(mfar_index* idx, const float* q, int Q, const 
     HIPCHK(hipSetDevice(idx->device));
     return run_stage2_mix(idx, q, Q, W, query_cond, mask, k1, k2, (const long long*)field_ids, slot, (long long*)ids, scores,
                           (int*)n_valid, (int*)n_cand, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ fused mode
+// The companion: rows of dim F * E -- for every document the concatenation of its F field vectors -- spread over
+// FUSED_GROUPS interleaved row groups that are stored as the "fields" of an ordinary index (document r = group r % G, local
+// row r / G).  Everything stage 1 offers (certified fp16 screen over unique rows, wide pass, sample pass, a full grid) then
+// applies to the fused search unchanged; mfar_merge_groups_kernel takes the final top-k of the G group lists.
+#define FUSED_GROUPS 8
+static int ensure_fused(mfar_index* idx, hipStream_t st) {
+    if (idx->dtype != MFAR_DTYPE_F32) return fail(MFAR_ERR_UNSUPPORTED, "the fused mode is built for fp32 indexes");
+    const long long FE = (long long)idx->F * idx->E;
+    const int G = FUSED_GROUPS;
+    if (!idx->fused) {
+        RETCHK(mfar_index_create(&idx->fused, idx->device, (idx->n_rows + G - 1) / G, idx->row_offset, G, (int)FE, MFAR_DTYPE_F32));
+        idx->fused_dirty = true;
+    }
+    if (idx->fused_dirty) {
+        HIPCHK(hipDeviceSynchronize());   // a fused search in flight may still read the companion
+        const long long total = idx->n_rows * (idx->E / 4);
+        for (int f = 0; f < idx->F && total > 0; ++f) {
+            mfar_concat_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(
+                (const float*)idx->slab + (size_t)f * idx->field_stride, (float*)idx->fused->slab, idx->fused->field_stride, idx->n_rows, idx->E,
+                (int)FE, f * idx->E, G);
+            HIPCHK(hipGetLastError());
+        }
+        idx->fused->screen_dirty = true;
+        idx->fused_dirty = false;
+    }
+    // The companion is scanned by the exact fp32 pass.  The certified screen does not pay here (measured at 1 M x 8 x 768: every
+    // certificate fails and the exact pass runs anyway): its error bound follows |q|_2 |c|_2 of the 6144-dim vectors, which
+    // does not shrink when F per-field scores are averaged, while the gap between the k-th and the k'-th mixed score does
+    // (by sqrt(F)); MFAR_FUSED_SCREEN=1 turns it on for experiments.
+    static const bool fused_screen = getenv("MFAR_FUSED_SCREEN") && atoi(getenv("MFAR_FUSED_SCREEN")) != 0;
+    idx->fused->screen_mode = fused_screen ? 2 : 0;
+    idx->fused->screen_eps_mult = idx->screen_eps_mult;
+    idx->fused->wide = idx->wide;
+    return MFAR_OK;
+}
+
+extern "C" int mfar_search_fused(mfar_index* idx, const float* q, int Q, const float* W, int query_cond, const float* mask, int k,
+                                 int64_t* ids, float* scores, int on_device, void* stream) {
+    RETCHK(check_search_common(idx, q, Q, k));
+    if (k >= MFAR_MAX_K) return fail(MFAR_ERR_INVALID, "the fused mode takes k < 128 (its group lists are one entry deeper)");
+    if (!W) return fail(MFAR_ERR_INVALID, "W is NULL");
+    if (Q == 0) return MFAR_OK;
+    if (!ids || !scores) return fail(MFAR_ERR_INVALID, "output pointer is NULL");
+    const int F = idx->F, E = idx->E, G = FUSED_GROUPS, kg = k + 1;
+    if (FOLD_LDS_BYTES(E, query_cond ? F : 0) > 160 * 1024) return fail(MFAR_ERR_UNSUPPORTED, "dim * n_fields too large for the gate kernel's LDS staging");
+    HIPCHK(hipSetDevice(idx->device));
+    hipStream_t st = (hipStream_t)stream;
+    RETCHK(ensure_fused(idx, st));
+    const float *qd, *Wd, *md;
+    long long* idd;
+    float* scd;
+    RETCHK(stage_in(idx->in[0], q, (size_t)Q * E, on_device, st, &qd));
+    RETCHK(stage_in(idx->in[1], W, query_cond ? (size_t)E * F : (size_t)F, on_device, st, &Wd));
+    RETCHK(stage_in(idx->in[2], mask, (size_t)F, on_device, st, &md));
+    RETCHK(stage_out(idx->out[0], (long long*)ids, (size_t)Q * k, on_device, &idd));
+    RETCHK(stage_out(idx->out[1], scores, (size_t)Q * k, on_device, &scd));
+    RETCHK(idx->fused_q.ensure((size_t)Q * F * E * 4));
+    RETCHK(idx->fid.ensure((size_t)Q * G * kg * 8));
+    RETCHK(idx->fsc.ensure((size_t)Q * G * kg * 4));
+    mfar_fold_queries_kernel<<<dim3(Q), dim3(256), FOLD_LDS_BYTES(E, query_cond ? F : 0), st>>>(qd, Wd, md, query_cond, F, E,
+                                                                                               idx->fused_q.as<float>());
+    HIPCHK(hipGetLastError());
+    // exhaustive top-(k + 1) of the folded inner product per row group: no zero sentinel (the reference's mixed scores have
+    // none, contrastive.py:696)
+    RETCHK(run_stage1(idx->fused, idx->fused_q.as<float>(), Q, kg, 0, idx->fid.as<long long>(), idx->fsc.as<float>(), st));
+    GroupMergeParams gp = {};
+    gp.gids = idx->fid.as<long long>();
+    gp.gsc = idx->fsc.as<float>();
+    gp.ids = idd;
+    gp.scores = scd;
+    gp.row_offset = idx->row_offset;
+    gp.n_rows = idx->n_rows;
+    gp.G = G;
+    gp.kg = kg;
+    gp.k = k;
+    mfar_merge_groups_kernel<<<dim3(Q), dim3(256), SEL_LDS_BYTES(G * kg), st>>>(gp);
+    HIPCHK(hipGetLastError());
+    RETCHK(copy_back((long long*)ids, idd, (size_t)Q * k, on_device, st));
+    RETCHK(copy_back(scores, scd, (size_t)Q * k, on_device, st));
+    if (!on_device) HIPCHK(hipStreamSynchronize(st));
+    return MFAR_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ multi-GPU

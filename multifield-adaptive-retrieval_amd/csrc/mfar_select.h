@@ -858,3 +858,100 @@ __global__ void __launch_bounds__(256) mfar_merge_topk_kernel(const TopkMergePar
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused mode (mfar_search_fused): sum_f g_f(q) mask_f <q, d_f> = <[g_1 m_1 q; ...; g_F m_F q], [d_1; ...; d_F]>, i.e. plain
+// inner-product search in F * E dims with the gate folded into the query (weighting.py:25-29).
+//   mfar_concat_rows_kernel  field f of the multi-field slab -> columns [f E, (f + 1) E) of the one-field companion slab
+//                            (both tiled; one thread per 16-byte granule);
+//   mfar_fold_queries_kernel gate logits (natural-order fma chain), deterministic softmax (same code as the mixer),
+//                            folded query qf[q, f E + e] = (g_f * mask_f) * q[e].   grid = Q, block 256.
+// ---------------------------------------------------------------------------------------------------------
+// companion layout: G interleaved row groups stored as G "fields" of ceil(n_rows / G) rows -- row r lives in group r % G at
+// local row r / G -- so that the stage-1 grid is cut into G x (chunks per field) workgroups (one field alone is limited to
+// the chunks one list merge can hold)
+__global__ void mfar_concat_rows_kernel(const float* __restrict__ src_field, float* __restrict__ dst, long long dst_field_stride,
+                                        long long n_rows, int E, int FE, int col0, int G) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gpr = E >> 2;
+    if (gid >= n_rows * gpr) return;
+    const long long r = gid / gpr;
+    const int e = (int)(gid - r * gpr) << 2;
+    *(f32x4*)(dst + (size_t)(r % G) * dst_field_stride + tiled_offset(FE >> 4, r / G, col0 + e)) =
+        *(const f32x4*)(src_field + tiled_offset(E >> 4, r, e));
+}
+
+// final top-k of the G group lists of one query: ids arrive as row_offset + local row, the document is
+// row_offset + local * G + g; the one padding row a group may hold (documents beyond n_rows) is dropped here, which is why
+// the group lists are one entry deeper than k.   grid = Q, block 256, dynamic LDS = SEL_LDS_BYTES(G * kg).
+struct GroupMergeParams {
+    const long long* gids;   // [Q, G, kg]
+    const float* gsc;        // [Q, G, kg]
+    long long* ids;          // [Q, k]
+    float* scores;           // [Q, k]
+    long long row_offset, n_rows;
+    int G, kg, k;
+};
+__global__ void __launch_bounds__(256) mfar_merge_groups_kernel(const GroupMergeParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SelLds L = sel_lds(smem, p.G * p.kg);
+    const int q = blockIdx.x;
+    if (threadIdx.x == 0) L.misc[0] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.G * p.kg; i += blockDim.x) {
+        const int g = i / p.kg;
+        const long long id = p.gids[(size_t)q * p.G * p.kg + i];
+        if (id < 0) continue;
+        const long long doc = (id - p.row_offset) * p.G + g;
+        if (doc >= p.n_rows) continue;
+        L.keys[lds_add_rtn(&L.misc[0], 1)] = make_key(p.gsc[(size_t)q * p.G * p.kg + i], (u32)(p.row_offset + doc));
+    }
+    __syncthreads();
+    const int n = L.misc[0];
+    const int m = block_topk_sorted<8>(L.keys, n, p.k, L.sel, L.sorted, L.red);
+    for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
+        p.ids[(size_t)q * p.k + r] = r < m ? (long long)key_id(L.sorted[r]) : -1;
+        p.scores[(size_t)q * p.k + r] = r < m ? key_score(L.sorted[r]) : -__builtin_inff();
+    }
+}
+
+__global__ void __launch_bounds__(256) mfar_fold_queries_kernel(const float* __restrict__ q, const float* __restrict__ W,
+                                                                const float* __restrict__ mask, int query_cond, int F, int E,
+                                                                float* __restrict__ qf) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* z = (float*)smem;                 // z | g : 2 * MFAR_MAX_FIELDS floats, then q [E], W [E * F]
+    float* g = z + MFAR_MAX_FIELDS;
+    float* qs = g + MFAR_MAX_FIELDS;
+    float* Ws = qs + E;
+    const int qi = blockIdx.x;
+    const float* qr = q + (size_t)qi * E;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) qs[e] = qr[e];
+    if (query_cond)
+        for (int i = threadIdx.x; i < E * F; i += blockDim.x) Ws[i] = W[i];
+    __syncthreads();
+    if ((int)threadIdx.x < F) {
+        const int f = threadIdx.x;
+        float acc;
+        if (query_cond) {
+            acc = 0.0f;
+            for (int e = 0; e < E; ++e) acc = __builtin_fmaf(qs[e], Ws[e * F + f], acc);
+        } else acc = W[f];
+        z[f] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = -__builtin_inff();
+        for (int f = 0; f < F; ++f) m = z[f] > m ? z[f] : m;
+        float sum = 0.0f;
+        for (int f = 0; f < F; ++f) {
+            g[f] = mfar_exp(z[f] - m);
+            sum = sum + g[f];
+        }
+        for (int f = 0; f < F; ++f) g[f] = (g[f] / sum) * (mask ? mask[f] : 1.0f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < F * E; i += blockDim.x) {
+        const int f = i / E;
+        qf[(size_t)qi * F * E + i] = g[f] * qs[i - f * E];
+    }
+}
+#define FOLD_LDS_BYTES(E, F) ((size_t)2 * MFAR_MAX_FIELDS * 4 + (size_t)(E) * 4 + (size_t)(E) * (F) * 4)

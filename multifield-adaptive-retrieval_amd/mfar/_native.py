@@ -50,6 +50,7 @@ SIGNATURES = {
     "mfar_score_candidates": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "mfar_mix_topk": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "mfar_search_two_stage": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mfar_search_fused": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "mfar_payload_bytes": (_i64, [_i, _i, _i]),
     "mfar_search_stage2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "mfar_search_local": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),

@@ -211,6 +211,21 @@ class MultiFieldIndex:
             res.update(field_ids=fid, field_scores=fsc, n_cand=nc)
         return res
 
+    # ---- fused mode: exhaustive top-k of the gate-folded inner product (include/mfar_hip.h) ----
+    def search_fused(self, q, W, mask=None, k: int = 100, query_cond: bool = True):
+        """-> dict(ids [Q,k] int64, scores [Q,k] f32): top-k over ALL rows of sum_f softmax_f(q W) mask_f <q, d_f> (the
+        reference mixes only the union of the per-field lists: Recall parity, not id parity)."""
+        qa, Wa = _Arg(q, np.float32, self.device), _Arg(W, np.float32, self.device)
+        ma = _Arg(mask, np.float32, self.device, allow_none=True)
+        on_dev = _same_side([qa, Wa, ma])
+        Q = qa.keep.shape[0]
+        ids = _empty_like_side(on_dev, self.device, (Q, k), np.int64)
+        sc = _empty_like_side(on_dev, self.device, (Q, k), np.float32)
+        ia, sa = _Arg(ids, np.int64, self.device), _Arg(sc, np.float32, self.device)
+        _native.check(_native.lib().mfar_search_fused(self._h, qa.ptr, Q, Wa.ptr, int(bool(query_cond)), ma.ptr, int(k), ia.ptr, sa.ptr,
+                                                      int(on_dev), _current_stream(self.device, on_dev)))
+        return dict(ids=ids, scores=sc)
+
     # ---- multi-GPU: local half + merge of all-gathered payloads ----
     def payload_bytes(self, Q: int, k1: int = 100) -> int:
         return int(_native.lib().mfar_payload_bytes(int(Q), self.n_fields, int(k1)))

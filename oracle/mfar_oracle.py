@@ -171,6 +171,21 @@ def c_two_stage(slab, q, W, mask=None, k1=100, k2=100, sentinel=True, query_cond
     return dict(ids=ids, scores=sc, n_valid=nv, n_cand=nc, field_ids=fid, field_scores=fsc)
 
 
+def c_search_fused(slab, q, W, mask=None, k=100, query_cond=True):
+    """Fused mode (include/mfar_hip.h mfar_search_fused): per query the gate (contract softmax), the folded query
+    [g_f * mask_f * q]_f, and the exhaustive top-k of its inner product with the concatenated field vectors -- the contract's
+    fma chain over F * E dims, no zero sentinel."""
+    slab, q, W = _f32(slab), _f32(q), _f32(W)
+    F, D, E = slab.shape
+    cat = np.ascontiguousarray(slab.transpose(1, 0, 2).reshape(D, F * E))
+    m = _f32(mask).reshape(-1) if mask is not None else np.ones(F, np.float32)
+    qf = np.empty((q.shape[0], F * E), np.float32)
+    for i in range(q.shape[0]):
+        g = c_gate(q[i], W, query_cond) * m                       # fp32 products, same operation order as the kernel
+        qf[i] = (g[:, None] * q[i][None, :]).reshape(-1)
+    return c_retrieve(cat, qf, k, sentinel=False)
+
+
 def c_merge_lists(ids, scores, sentinel=True):
     ids = np.ascontiguousarray(ids, dtype=np.int64)
     scores = _f32(scores)
