@@ -43,12 +43,17 @@ class SentenceEncoder(torch.nn.Sequential):
     `__call__(features)["sentence_embedding"]` (contrastive.py:693), `.get_sentence_embedding_dimension()`,
     `.get_max_seq_length()`, `.tokenizer`."""
 
-    def __init__(self, auto_model, tokenizer, normalize: bool = False, max_seq_length: Optional[int] = None):
+    def __init__(self, auto_model, tokenizer, normalize: bool = False, max_seq_length: Optional[int] = None,
+                 dense: Optional[torch.nn.Module] = None):
         super().__init__(_Transformer(auto_model))
+        if dense is not None:
+            # sentence-transformers numbers its modules: 0 Transformer, 1 Pooling (no parameters), 2 Dense -> the projection's
+            # checkpoint key is `2.linear.weight` (gtr-t5: Dense(768 -> 768, bias=False, identity activation))
+            self.add_module("2", dense)
         self.tokenizer = tokenizer
         self.normalize = normalize
         cfg = auto_model.config
-        limit = getattr(cfg, "max_position_embeddings", 512)
+        limit = getattr(cfg, "max_position_embeddings", None) or getattr(cfg, "n_positions", None) or 512
         self.max_seq_length = min(max_seq_length or limit, limit)
         self.train(auto_model.training)      # the wrapper starts in the wrapped model's mode (from_pretrained: eval)
 
@@ -60,7 +65,13 @@ class SentenceEncoder(torch.nn.Sequential):
     def device(self):
         return next(self.parameters()).device
 
+    @property
+    def dense(self):
+        return self._modules.get("2")
+
     def get_sentence_embedding_dimension(self) -> int:
+        if self.dense is not None:
+            return int(self.dense.linear.out_features)
         return int(self.auto_model.config.hidden_size)
 
     def get_max_seq_length(self) -> int:
@@ -70,6 +81,8 @@ class SentenceEncoder(torch.nn.Sequential):
         tok = self[0](features)
         m = features["attention_mask"].unsqueeze(-1).to(tok.dtype)
         emb = (tok * m).sum(1) / m.sum(1).clamp(min=1e-9)      # Pooling(mean): sum of unmasked tokens / their count
+        if self.dense is not None:
+            emb = self.dense(emb)
         if self.normalize:
             emb = torch.nn.functional.normalize(emb, p=2, dim=1)
         return {"token_embeddings": tok, "sentence_embedding": emb, **features}
@@ -127,14 +140,85 @@ def _tiny_random_model(spec: str):
     return tok, BertModel(cfg).eval()       # from_pretrained() also hands models out in eval mode
 
 
+class _Dense(torch.nn.Module):
+    """sentence-transformers `models.Dense` with its defaults for gtr-t5: `linear` without bias, identity activation."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = False):
+        super().__init__()
+        self.linear = torch.nn.Linear(in_features, out_features, bias=bias)
+
+    def forward(self, x):
+        return self.linear(x)
+
+
+def _is_gtr_t5(model_id: str) -> bool:
+    return model_id.startswith("sentence-transformers/gtr-t5") or model_id.startswith("random-init-t5") or \
+        (os.path.isdir(model_id) and os.path.isdir(os.path.join(model_id, "2_Dense")))
+
+
+def _prepare_gtr_t5(model_id: str, with_decoder: bool, normalize: bool):
+    """The gtr-t5 branch (modeling/util.py:22-36): `SentenceTransformer(model_id)` = T5 encoder -> mean pooling -> Dense(d -> d,
+    no bias) -> Normalize, the Normalize dropped unless --normalize; with_decoder: a `T5ForConditionalGeneration` whose
+    encoder IS the sentence encoder's (shared parameters).  Weights come from a local directory in the sentence-transformers
+    layout (`config.json` + T5 encoder weights at the root, `2_Dense/{model.safetensors|pytorch_model.bin}`): there is no
+    network here, so a hub id resolves only through the local HF cache.  `random-init-t5:<d>x<layers>` builds the same
+    structure with random weights (plumbing tests)."""
+    from transformers import T5Config, T5EncoderModel, T5ForConditionalGeneration
+    if model_id.startswith("random-init-t5"):
+        dims = model_id.split(":", 1)[1] if ":" in model_id else "64x2"
+        d, layers = (int(x) for x in dims.split("x"))
+        tokenizer, _ = _tiny_random_model(f"random-init:{d}x1")
+        cfg = T5Config(vocab_size=len(tokenizer), d_model=d, d_kv=max(8, d // 4), d_ff=2 * d, num_layers=layers, num_decoder_layers=layers,
+                       num_heads=4, decoder_start_token_id=0, pad_token_id=tokenizer.pad_token_id)
+        torch.manual_seed(0)
+        t5 = T5EncoderModel(cfg).eval()
+        dense = _Dense(d, d)
+        full = T5ForConditionalGeneration(cfg).eval() if with_decoder else None
+    else:
+        from transformers import AutoTokenizer
+        try:
+            tokenizer = AutoTokenizer.from_pretrained(model_id)
+            t5 = T5EncoderModel.from_pretrained(model_id)
+        except Exception as e:
+            raise ValueError(f"Unsupported model_id or unable to find: {model_id}") from e
+        d = int(t5.config.d_model)
+        dense = _Dense(d, d)
+        root = model_id if os.path.isdir(model_id) else None
+        if root is None:
+            try:
+                from huggingface_hub import snapshot_download
+                root = snapshot_download(model_id, local_files_only=True)
+            except Exception as e:
+                raise ValueError(f"unable to find the Dense module of {model_id} locally") from e
+        st_path, bin_path = os.path.join(root, "2_Dense", "model.safetensors"), os.path.join(root, "2_Dense", "pytorch_model.bin")
+        if os.path.exists(st_path):
+            from safetensors.torch import load_file
+            dense.load_state_dict(load_file(st_path))
+        elif os.path.exists(bin_path):
+            dense.load_state_dict(torch.load(bin_path, map_location="cpu"))
+        else:
+            raise ValueError(f"{root}/2_Dense holds no weights")
+        full = None
+        if with_decoder:
+            size = model_id.rstrip("/").split("-")[-1]                       # util.py:33-34
+            try:
+                full = T5ForConditionalGeneration.from_pretrained(f"google-t5/t5-{size}")
+            except Exception as e:
+                raise ValueError(f"unable to find google-t5/t5-{size} locally") from e
+    encoder = SentenceEncoder(t5, tokenizer, normalize=normalize, dense=dense, max_seq_length=512)
+    if full is not None:
+        full.encoder = t5.encoder                                            # util.py:35: the decoder model reads THE encoder
+    return tokenizer, encoder, full
+
+
 def prepare_model(model_id: str, with_decoder: bool = False, normalize: bool = False, freeze_encoder: bool = False):
     """(tokenizer, encoder, decoder|None) -- reference modeling/util.py:16-71.  The contriever branch and the
-    local-directory branch are the same thing here (HF AutoModel + mean pooling); the gtr-t5 branch needs the
-    sentence-transformers model zoo and is not available."""
-    if model_id.startswith("sentence-transformers/gtr-t5"):
-        raise NotImplementedError("the gtr-t5 branch needs sentence-transformers pretrained modules (not installed)")
+    local-directory branch are the same thing here (HF AutoModel + mean pooling); the gtr-t5 branch (`_prepare_gtr_t5`) adds
+    the Dense projection and, with_decoder, the T5 decoder over the shared encoder."""
+    if _is_gtr_t5(model_id):
+        return _prepare_gtr_t5(model_id, with_decoder, normalize)
     if with_decoder:
-        raise NotImplementedError("with_decoder is only defined for the gtr-t5 branch")
+        raise UnboundLocalError("with_decoder is only defined for the gtr-t5 branch (the reference's other branches return no decoder)")
     if model_id.startswith("random-init"):
         tokenizer, model = _tiny_random_model(model_id)
     else:

@@ -316,3 +316,45 @@ def test_load_checkpoint_with_reference_key_layout(tmp_path):
     torch.save({"state_dict": wrong, "hyper_parameters": hp}, path)
     with pytest.raises(RuntimeError, match="field set"):
         RetrievalTrainingModule.load_from_checkpoint(path, **kw)
+
+
+def test_gtr_t5_branch_and_decoder(tmp_path):
+    """prepare_model's gtr-t5 branch (modeling/util.py:22-36): T5 encoder -> mean pooling -> bias-free Dense [-> Normalize],
+    sentence-transformers checkpoint keys (`0.auto_model.*`, `2.linear.weight`), with_decoder = a T5ForConditionalGeneration
+    that shares the encoder's parameters; loading from a local directory in the sentence-transformers layout."""
+    import torch
+    from mfar.modeling.util import prepare_model
+    tok, enc, dec = prepare_model("random-init-t5:64x2", with_decoder=True)
+    assert enc.get_sentence_embedding_dimension() == 64 and enc.get_max_seq_length() == 512
+    keys = list(enc.state_dict())
+    assert "2.linear.weight" in keys and "2.linear.bias" not in keys and any(k.startswith("0.auto_model.encoder.") for k in keys)
+    texts = ["a red shoe", "blue", "the quick brown fox"]
+    feats = enc.tokenize(texts)
+    with torch.no_grad():
+        hid = enc.auto_model(input_ids=feats["input_ids"], attention_mask=feats["attention_mask"]).last_hidden_state
+        m = feats["attention_mask"].unsqueeze(-1).float()
+        want = ((hid * m).sum(1) / m.sum(1).clamp(min=1e-9)) @ enc.dense.linear.weight.t()
+        got = enc(feats)["sentence_embedding"]
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+    assert not np.allclose(np.linalg.norm(got.numpy(), axis=1), 1.0)                 # Normalize is dropped without --normalize
+    _, encn, _ = prepare_model("random-init-t5:64x2", normalize=True)
+    np.testing.assert_allclose(np.linalg.norm(encn.encode(texts), axis=1), 1.0, rtol=1e-5)
+    # the decoder model runs over the SAME encoder parameters
+    assert dec is not None and dec.encoder is enc.auto_model.encoder
+    p0 = next(enc.auto_model.encoder.parameters())
+    assert any(p is p0 for p in dec.encoder.parameters())
+    with torch.no_grad():
+        out = dec(input_ids=feats["input_ids"], attention_mask=feats["attention_mask"], decoder_input_ids=feats["input_ids"][:, :2])
+    assert out.logits.shape[:2] == (3, 2)
+    with pytest.raises(UnboundLocalError):
+        prepare_model("random-init:64x2", with_decoder=True)
+    # a local sentence-transformers directory: config + encoder weights at the root, 2_Dense/model.safetensors
+    from safetensors.torch import save_file
+    root = tmp_path / "gtr-t5-tiny"
+    enc.auto_model.save_pretrained(root)
+    tok.save_pretrained(root)
+    os.makedirs(root / "2_Dense")
+    save_file({"linear.weight": enc.dense.linear.weight.detach().clone()}, str(root / "2_Dense" / "model.safetensors"))
+    _, enc2, dec2 = prepare_model(str(root))
+    assert dec2 is None and enc2.dense is not None
+    np.testing.assert_allclose(enc2.encode(texts), enc.encode(texts), rtol=1e-5, atol=1e-6)
