@@ -217,6 +217,19 @@ def main():
     scr = ix.screen_stats()
     screened = args.dtype == "f32" and scr["built"]          # stage 1 ran on the fp16 screen slab of the fp32 index
 
+    # ---- the dominant kernel with nothing beside it: the same scans issued serially on one stream (the split-phase tail of the
+    #      previous launch is what stretches a scan inside the pipeline; it moves ~3 GB of row gathers through the same HBM)
+    alone_ms = None
+    if screened and N == 1 and not args.no_extra_legs:
+        nq = ps.Qmax // Q
+        ix.set_timing(True)
+        for i in range(6):
+            ix.retrieve_fields(torch.cat([corpus.queries((args.warmup + i * nq + j) * Q, Q) for j in range(nq)]), K1, True)
+        torch.cuda.synchronize()
+        ms, n = ix.stage1_timing()
+        ix.set_timing(False)
+        alone_ms = ms / max(1, n)
+
     # ---- second leg, same process, same index: the exhaustive fp32 MFMA pass (screen off), and its bits vs the default leg
     exact_leg = None
     if args.dtype == "f32" and screened and not args.no_extra_legs:
@@ -276,10 +289,19 @@ def main():
                 ("fp16 SCREEN rows of the fp32 index (unique rows per field), read once per 64-query batch" if screened else
                  ("bf16 slab" if args.dtype == "bf16" else "fp32 slab") + ", read once per 64-query batch")),
             "fp32_slab_bytes_per_batch_survey_8d": float(row1 - row0) * F * E * 4,
+            "alone": ({"avg_launch_ms": alone_ms, "achieved": bytes_per_launch / (alone_ms * 1e-3) / 1e9,
+                       "frac": bytes_per_launch / (alone_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                       "what": "the same kernel with no other kernel beside it (scans issued serially on one stream)"}
+                      if alone_ms else None),
+            "algorithmic_bytes_per_query": bytes_per_launch / ps.Qmax,
             "note": ("SURVEY 8(d) prices a batch at D*F*E*4 bytes of fp32 rows; the default stage 1 does not read them -- it scans a "
                      "half-size fp16 copy and PROVES per list (rigorous error bound; failed lists are redone by the exact fp32 pass) "
                      "that the exact fp32 top-k is among the re-scored rows.  See roofline_exact_fp32 for the kernel that does read "
-                     "the fp32 slab.") if screened else None,
+                     "the fp32 slab.  One launch serves queries_per_launch queries: the wide pass (one fp16 query term, 128 "
+                     "columns) reads the screen rows once per 128 queries, round 1's pass (two terms, 64 columns) once per 64 -- "
+                     "bytes per QUERY halved, which is where the throughput comes from; `frac` is per launch and lower than "
+                     "round 1's 0.73 because the tail of the previous launch (exact re-scoring + stage 2: ~3 GB of row gathers "
+                     "for 128 queries) shares HBM with the scan for most of its duration (`alone` = the same kernel by itself).") if screened else None,
             "algorithmic_flops_per_launch": flops_per_launch,
         })
         line = {
@@ -302,6 +324,7 @@ def main():
             "screen": ({"lists_certified": (scr["n_checked"] - scr0["n_checked"]) - (scr["n_failed"] - scr0["n_failed"]),
                         "lists_redone_exactly": scr["n_failed"] - scr0["n_failed"], "batches_redone": ps.n_redone,
                         "screen_slab_bytes": scr["screen_bytes"], "unique_rows_per_field": scr.get("unique_rows")} if screened else None),
+            "ms_per_launch": dt / args.steps * 1e3 * ps.coalesce,
             "recall_at_20": recall20, "ids_checksum": checksum, "index_build_s": t_build, "source_hash": source_hash(),
             "diagnostic_knobs": {"MFAR_S1_DEBUG": "unset", "screen_eps_mult": eps_mult},
             "roofline": roof,

@@ -246,9 +246,11 @@ class RetrievalTrainingModule(torch.nn.Module):
             if rank != 0 or qres_output is None:
                 continue
             ids, sims = res["ids"][:n].cpu().tolist(), res["scores"][:n].cpu().tolist()
-            for q, row_ids, row_sims in zip(data, ids, sims):
-                for d, s in zip(row_ids, row_sims):
-                    print(trec.QRes(query_id=q._id, doc_id=self.numeric_ids_to_keys[d], sim=s), file=qres_output)
+            keys = self.numeric_ids_to_keys
+            # the lines `print(QRes(...), file=...)` writes (trec.py:49-50: "{qid}\t0\t{doc}\t0\t{sim}\t0"), formatted in one
+            # pass: 6400 dataclass constructions + prints per batch were the slowest step of an evaluation
+            qres_output.write("".join(f"{q._id}\t0\t{keys[d]}\t0\t{s}\t0\n" for q, row_ids, row_sims in zip(data, ids, sims)
+                                      for d, s in zip(row_ids, row_sims)))
 
     @torch.no_grad()
     def _hybrid_step(self, batch, qres_output) -> None:
