@@ -80,6 +80,12 @@ struct S1Table {
     int n_chunks = 0, max_chunks = 0, samp_stride = 0, sample_tiles = 1;
     long long total_tiles = 0;
     DevBuf d_chunks, d_fchunk, d_samp_n;
+    // two-level merge: a field cut into more chunks than one merge workgroup can hold (few fields, or a single-field pass)
+    // is merged in GROUPS of consecutive chunks first (mfar_select.h MergeParams)
+    bool two_level = false;
+    std::vector<int> gchunk, fgroup, gfield;   // [n_groups + 1] chunk boundaries, [F + 1] groups of a field, [n_groups] field of a group
+    int n_groups = 0, max_group_chunks = 0, max_groups = 0;
+    DevBuf d_gchunk, d_fgroup, d_gfield;
 };
 struct S1Geom {
     std::vector<long long> n_rows, base;   // per field: valid rows, element offset of the field inside the slab
@@ -109,7 +115,7 @@ struct mfar_index {
     // stage-1 scratch, two slots: the pipelined caller finishes batch i (merge, re-score, certify) on one stream while
     // batch i+1 scans on another (mfar_stage1_begin / mfar_stage1_finish)
     struct S1Slot {
-        DevBuf qt, lists, list_cnt, gtau, samp;                          // any pass
+        DevBuf qt, lists, list_cnt, gtau, samp, lists2, list_cnt2;      // any pass (lists2: group lists of a two-level merge)
         DevBuf qt16, qinfo, eps, base, fail, sids, ssc, scnt, sx;        // fp16 screen
         bool screened = false;                                          // decided by the begin phase of the batch
         int qw = 64;                                                    // query columns of the batch's pass (128: wide screen pass)
@@ -267,10 +273,13 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
             t->d_chunks.release();
             t->d_fchunk.release();
             t->d_samp_n.release();
+            t->d_gchunk.release();
+            t->d_fgroup.release();
+            t->d_gfield.release();
         }
     for (DevBuf* b : bufs) b->release();
     for (auto& sl : idx->s1) {
-        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
+        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.lists2, &sl.list_cnt2, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
                         &sl.ssc, &sl.scnt, &sl.sx};
         for (DevBuf* b : sb) b->release();
     }
@@ -467,10 +476,13 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
     t.samp_n.assign(F, 0);
     t.max_chunks = 0;
     std::vector<int> cf(F);
+    const int l2cap = std::max(1, std::min(cap, 8192 / k));   // lists the second level merges per field (register-resident keys)
+    t.two_level = false;
     for (int f = 0; f < F; ++f) {
         long long c = solo ? want : (want * g.n_tiles[f] + total_tiles / 2) / std::max(1LL, total_tiles);
-        c = std::max(1LL, std::min<long long>(c, std::min(cap, std::max(1, g.n_tiles[f]))));
+        c = std::max(1LL, std::min<long long>(c, std::min<long long>((long long)cap * l2cap, std::max(1, g.n_tiles[f]))));
         cf[f] = (int)c;
+        if (cf[f] > cap) t.two_level = true;
         t.max_chunks = std::max(t.max_chunks, cf[f]);
     }
     long long n_chunks = 0;
@@ -493,7 +505,7 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
         const int st_cap = (int)std::max(1LL, min_tiles_per_chunk / 6);
         while (sample_tiles < st_cap && 2LL * waves * min_cf * sample_tiles < 3LL * k) ++sample_tiles;
     }
-    while (sample_tiles > 1 && 2 * waves * t.max_chunks * sample_tiles > 2048) --sample_tiles;
+    while (sample_tiles > 1 && 2 * waves * t.max_chunks * sample_tiles > 4096) --sample_tiles;
     t.sample_tiles = sample_tiles;
     t.samp_stride = 0;
     for (int f = 0; f < F; ++f) {
@@ -516,6 +528,31 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
     t.fchunk[F] = (int)t.chunks.size();
     t.n_chunks = (int)t.chunks.size();
     t.total_tiles = total_tiles;
+    t.gchunk.clear();
+    t.gfield.clear();
+    t.fgroup.assign(F + 1, 0);
+    t.max_group_chunks = t.max_groups = 0;
+    if (t.two_level) {
+        for (int f = 0; f < F; ++f) {
+            t.fgroup[f] = (int)t.gfield.size();
+            const int gs = (cf[f] + l2cap - 1) / l2cap;                  // chunks per group (<= cap by construction)
+            for (int c0 = 0; c0 < cf[f]; c0 += gs) {
+                t.gchunk.push_back(t.fchunk[f] + c0);
+                t.gfield.push_back(f);
+                t.max_group_chunks = std::max(t.max_group_chunks, std::min(gs, cf[f] - c0));
+            }
+            t.max_groups = std::max(t.max_groups, (int)t.gfield.size() - t.fgroup[f]);
+        }
+        t.fgroup[F] = (int)t.gfield.size();
+        t.gchunk.push_back(t.n_chunks);
+        t.n_groups = (int)t.gfield.size();
+        RETCHK(t.d_gchunk.ensure(t.gchunk.size() * sizeof(int)));
+        RETCHK(t.d_fgroup.ensure((F + 1) * sizeof(int)));
+        RETCHK(t.d_gfield.ensure(t.gfield.size() * sizeof(int)));
+        HIPCHK(hipMemcpyAsync(t.d_gchunk.p, t.gchunk.data(), t.gchunk.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(t.d_fgroup.p, t.fgroup.data(), (F + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(t.d_gfield.p, t.gfield.data(), t.gfield.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    }
     RETCHK(t.d_chunks.ensure(t.chunks.size() * sizeof(S1Chunk)));
     RETCHK(t.d_fchunk.ensure((F + 1) * sizeof(int)));
     RETCHK(t.d_samp_n.ensure(F * sizeof(int)));
@@ -630,10 +667,11 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
     m.qw = qw;
     m.cnt_out = nullptr;
     m.only_failed = only_failed;
-    const int n_keys = tb.max_chunks * k;
-    auto launch_merge = [&](const MergeParams& mp) -> int {
-        const dim3 grid(qt_n * nf), block(256);
-        if (k <= SEL_MAX_K && tb.max_chunks <= 128 && n_keys <= 48 * 256) {   // keys stay in registers: no LDS staging
+    // one merge launch: `n_lists` = most lists a workgroup of it merges, grid = (query, list owner) pairs
+    auto launch_merge = [&](const MergeParams& mp, int n_lists, int owners) -> int {
+        const int n_keys = n_lists * k;
+        const dim3 grid(qt_n * owners), block(256);
+        if (k <= SEL_MAX_K && n_lists <= 128 && n_keys <= 48 * 256) {   // keys stay in registers: no LDS staging
             if (n_keys <= 8 * 256) mfar_merge_lists_regs_kernel<8><<<grid, block, 0, st>>>(mp);
             else if (n_keys <= 16 * 256) mfar_merge_lists_regs_kernel<16><<<grid, block, 0, st>>>(mp);
             else if (n_keys <= 32 * 256) mfar_merge_lists_regs_kernel<32><<<grid, block, 0, st>>>(mp);
@@ -655,7 +693,7 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
     // compacts almost nothing.  Worth it once the chunks are much longer than one tile.
     static const int sample_min_tiles = getenv("MFAR_SAMPLE_MIN_TILES") ? atoi(getenv("MFAR_SAMPLE_MIN_TILES")) : 3;
     const bool use_sample = tb.total_tiles >= (long long)sample_min_tiles * tb.n_chunks && !(p.dbg & 2) && !only_failed;
-    const bool light_sample = use_sample && 2 * tb.samp_stride <= 2048;
+    const bool light_sample = use_sample && 2 * tb.samp_stride <= 4096;
     p.sample_tiles = light_sample ? tb.sample_tiles : 1;
     if (light_sample) {
         // every wave publishes the 2 best scores per query of its 64 sampled rows; tau = k-th largest of those
@@ -669,11 +707,12 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
             const int* sn = tb.d_samp_n.as<int>();
             if (2 * tb.samp_stride <= 512) mfar_sample_tau_kernel<8><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>(), qw);
             else if (2 * tb.samp_stride <= 1024) mfar_sample_tau_kernel<16><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>(), qw);
-            else mfar_sample_tau_kernel<32><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>(), qw);
+            else if (2 * tb.samp_stride <= 2048) mfar_sample_tau_kernel<32><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>(), qw);
+            else mfar_sample_tau_kernel<64><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>(), qw);
             HIPCHK(hipGetLastError());
         }
         p.gtau = sl.gtau.as<float>();
-    } else if (use_sample && !tau_base) {
+    } else if (use_sample && !tau_base && !tb.two_level) {
         if (phases & S1_PREPARE) {
             S1Params ps = p;
             ps.sample = 1;
@@ -682,7 +721,7 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
             ms.out_ids = nullptr;
             ms.out_scores = nullptr;
             ms.tau_out = sl.gtau.as<float>();
-            RETCHK(launch_merge(ms));
+            RETCHK(launch_merge(ms, tb.max_chunks, nf));
         }
         p.gtau = sl.gtau.as<float>();
     }
@@ -711,7 +750,31 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
         m.out_scores = o.sc;
         m.tau_out = nullptr;
         m.cnt_out = o.cnt;
-        RETCHK(launch_merge(m));
+        if (tb.two_level) {
+            // level 1: every group of chunks -> one list in chunk format; level 2: the groups of a field -> the final list
+            RETCHK(sl.lists2.ensure((size_t)tb.n_groups * qw * S1_CAP * sizeof(uint2)));
+            RETCHK(sl.list_cnt2.ensure((size_t)tb.n_groups * qw * sizeof(int)));
+            MergeParams m1 = m;
+            m1.fchunk = tb.d_gchunk.as<int>();
+            m1.gfield = tb.d_gfield.as<int>();
+            m1.f0 = tb.fgroup[f0];
+            m1.nf = tb.fgroup[f0 + nf] - tb.fgroup[f0];
+            m1.out_ids = nullptr;
+            m1.out_scores = nullptr;
+            m1.cnt_out = nullptr;
+            m1.out_lists = sl.lists2.as<uint2>();
+            m1.out_cnt = sl.list_cnt2.as<int>();
+            m1.max_chunks = tb.max_group_chunks;
+            RETCHK(launch_merge(m1, tb.max_group_chunks, m1.nf));
+            MergeParams m2 = m;
+            m2.lists = sl.lists2.as<uint2>();
+            m2.list_cnt = sl.list_cnt2.as<int>();
+            m2.fchunk = tb.d_fgroup.as<int>();
+            m2.max_chunks = tb.max_groups;
+            RETCHK(launch_merge(m2, tb.max_groups, nf));
+        } else {
+            RETCHK(launch_merge(m, tb.max_chunks, nf));
+        }
     }
     return MFAR_OK;
 }

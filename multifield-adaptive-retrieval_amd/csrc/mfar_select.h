@@ -116,6 +116,12 @@ struct MergeParams {
     int max_chunks;       // largest chunk count of a field (sizes the LDS staging of the non-register variant)
     int k, q0, sentinel;
     int qw;               // query columns of the stage-1 pass (64 / 128): stride of the per-chunk tables and of tau_out
+    // two-level merge (fields cut into more chunks than one merge can hold): level 1 merges GROUPS of chunks -- "field" f is
+    // then a group, fchunk the group boundaries, gfield[f] the real field (for only_failed) -- and writes its result in the
+    // chunk-list format (out_lists / out_cnt, list (f, query)), which level 2 merges like chunk lists
+    const int* gfield;    // [n_groups] or nullptr
+    uint2* out_lists;     // [n_groups * qw][S1_CAP] or nullptr
+    int* out_cnt;         // [n_groups * qw]
 };
 // LDS carve-up shared by the selection kernels (everything in the dynamic region: 16-byte aligned base)
 //   keys[n_keys] u64 | sel[SEL_MAX_K] u64 | sorted[SEL_MAX_K] u64 | red[32] int | misc[4] int
@@ -144,7 +150,7 @@ __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SelLds L = sel_lds(smem, p.max_chunks * p.k);
     const int ql = blockIdx.x / p.nf, fo = blockIdx.x - ql * p.nf, f = p.f0 + fo;
-    if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
+    if (p.only_failed && !p.only_failed[p.gfield ? p.gfield[f] : f]) return;   // workgroup-uniform
     const int c_lo = p.fchunk[f], n_chunks = p.fchunk[f + 1] - c_lo;
     // chunk counts first (LDS), then the entries eight chunks at a time: the global loads of a round are independent,
     // so their latencies overlap instead of adding up
@@ -181,6 +187,12 @@ __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams
     else m = block_topk_sorted<NPT>(L.keys, n, p.k, L.sel, L.sorted, L.red);
     if (p.tau_out && threadIdx.x == 0) p.tau_out[f * p.qw + ql] = m == p.k ? key_score(L.sorted[p.k - 1]) : -__builtin_inff();
     if (p.cnt_out && threadIdx.x == 0) p.cnt_out[ql * p.nf + fo] = m;
+    if (p.out_lists) {   // level 1 of a two-level merge: the group's list, in chunk-list format
+        uint2* ol = p.out_lists + ((size_t)f * p.qw + ql) * S1_CAP;
+        for (int r = threadIdx.x; r < m; r += blockDim.x) ol[r] = make_uint2(__float_as_uint(key_score(L.sorted[r])), key_id(L.sorted[r]));
+        if (threadIdx.x == 0) p.out_cnt[(size_t)f * p.qw + ql] = m;
+        return;
+    }
     if (!p.out_ids) return;
     const size_t ob = ((size_t)(p.q0 + ql) * p.nf + fo) * p.k;
     for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
@@ -202,7 +214,7 @@ __device__ __forceinline__ void merge_lists_regs_body(const MergeParams& p) {
     __shared__ u64 sel[SEL_MAX_K], sorted[SEL_MAX_K];
     __shared__ int red[36], cnts[128];
     const int ql = blockIdx.x / p.nf, fo = blockIdx.x - ql * p.nf, f = p.f0 + fo;
-    if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
+    if (p.only_failed && !p.only_failed[p.gfield ? p.gfield[f] : f]) return;   // workgroup-uniform
     const int c_lo = p.fchunk[f], n_chunks = p.fchunk[f + 1] - c_lo;
     if (threadIdx.x < 128)
         cnts[threadIdx.x] = (int)threadIdx.x < n_chunks ? min(p.list_cnt[(size_t)(c_lo + threadIdx.x) * p.qw + ql], p.k) : 0;
@@ -236,6 +248,12 @@ __device__ __forceinline__ void merge_lists_regs_body(const MergeParams& p) {
     const int m = block_topk_regs<NPT>(hi, lo, n, p.k, sel, sorted, red);
     if (p.tau_out && threadIdx.x == 0) p.tau_out[f * p.qw + ql] = m == p.k ? key_score(sorted[p.k - 1]) : -__builtin_inff();
     if (p.cnt_out && threadIdx.x == 0) p.cnt_out[ql * p.nf + fo] = m;
+    if (p.out_lists) {   // level 1 of a two-level merge
+        uint2* ol = p.out_lists + ((size_t)f * p.qw + ql) * S1_CAP;
+        for (int r = threadIdx.x; r < m; r += blockDim.x) ol[r] = make_uint2(__float_as_uint(key_score(sorted[r])), key_id(sorted[r]));
+        if (threadIdx.x == 0) p.out_cnt[(size_t)f * p.qw + ql] = m;
+        return;
+    }
     if (!p.out_ids) return;
     const size_t ob = ((size_t)(p.q0 + ql) * p.nf + fo) * p.k;
     for (int i = threadIdx.x; i < p.k; i += blockDim.x) {
