@@ -47,6 +47,15 @@ class PipelinedSearcher:
         self.side = torch.cuda.Stream(device=self.dev)
         self.Qb = int(max_batch)      # queries per submitted batch (at most)
         cap = index.max_split_batch(k1)                       # 128 with the wide screened pass, else 64
+        if self.world > 1:
+            # every rank must cut the query stream into the same launches (fixed-size payloads are all-gathered): shards
+            # whose sizes straddle the screen's row threshold, or a rank that could not allocate its screen slab, would
+            # otherwise disagree -- take the smallest answer
+            t = torch.tensor([cap], dtype=torch.int32, device=torch.device(f"cuda:{index.device}"))
+            if dist.get_backend(group) == "gloo":
+                t = t.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            cap = int(t.item())
         if self.Qb > cap:
             raise ValueError(f"the split-phase stage 1 takes at most {cap} queries per batch on this index")
         if coalesce is None:

@@ -28,7 +28,7 @@ def main():
             E = int(rng.choice([32, 96, 96, 192]))
             F = int(rng.integers(1, 4))
         D = min(D, int(3e7 // (F * E)))
-        Q = int(rng.choice([rng.integers(1, 9), 64, rng.integers(9, 131)]))
+        Q = int(rng.choice([rng.integers(1, 9), 64, rng.integers(9, 131), 128, rng.integers(129, 261)]))   # > 64: wide blocks of 128 + a rest
         k = int(rng.choice([1, 10, 100, 100, 128, rng.integers(1, 129)]))
         sentinel = bool(rng.integers(0, 2))
         mean = float(rng.choice([0.3, -0.4, 0.0, 2.0]))
