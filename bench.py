@@ -78,7 +78,7 @@ def profile_counters(kernel: str, shape) -> dict:
 
 def s1_kernel_name(dtype, screened, E, wide=False):
     rr = "" if os.environ.get("MFAR_S1_REGRING", "1") == "0" else ("r" if (E // 16) % 6 == 0 else ("r4" if (E // 16) % 4 == 0 else ""))
-    if dtype == "bf16":
+    if dtype == "bf16" and not screened:
         return f"mfar_stage1_bf16{rr}_kernel"
     if screened and wide:
         return "mfar_stage1_f16w_kernel" if (E // 16) % 6 == 0 else "mfar_stage1_f16w4_kernel"
@@ -96,8 +96,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--wgs-per-cu", type=int, default=0)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="slab storage (default: the exact fp32 path)")
-    ap.add_argument("--screen", choices=["auto", "off"], default="auto",
-                    help="f32 only: certified fp16 screening of stage 1 (bit-identical results; csrc/mfar_screen.h)")
+    ap.add_argument("--screen", choices=["auto", "off", "on"], default="auto",
+                    help="certified fp16 screening of stage 1 (bit-identical results; csrc/mfar_screen.h): auto = fp32 indexes; "
+                         "on = also a bf16 index (doubles its footprint)")
     ap.add_argument("--corpus", choices=["plain", "structured"], default="plain",
                     help="structured: realistic duplicate / norm structure in three of the fields (mfar/synth.py)")
     ap.add_argument("--coalesce", type=int, default=0, help="batches scanned per launch (0 = auto: 2 when the wide screened pass is available)")
@@ -157,6 +158,8 @@ def main():
         ix.set_wgs_per_cu(args.wgs_per_cu)
     if args.screen == "off":
         ix.set_screen(0)
+    elif args.screen == "on":
+        ix.set_screen(2)
     mode, eps_mult = ix.screen_setting
     if eps_mult != 1.0:
         raise SystemExit(f"screen eps_mult = {eps_mult}: the certificate would not be the rigorous one")
@@ -215,7 +218,7 @@ def main():
     scr0 = ix.screen_stats()
     dt, s1_avg_ms, s1_n = timed(ps, ix, corpus, args.warmup, args.steps, results)
     scr = ix.screen_stats()
-    screened = args.dtype == "f32" and scr["built"]          # stage 1 ran on the fp16 screen slab of the fp32 index
+    screened = bool(scr["built"])                            # stage 1 ran on the fp16 screen slab of the index
 
     # ---- the dominant kernel with nothing beside it: the same scans issued serially on one stream (the split-phase tail of the
     #      previous launch is what stretches a scan inside the pipeline; it moves ~3 GB of row gathers through the same HBM)
@@ -286,7 +289,7 @@ def main():
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "algorithmic_bytes_definition": (
                 f"{n_scan_rows} scanned rows x {E} dims x {esize} B: the " +
-                ("fp16 SCREEN rows of the fp32 index (unique rows per field), read once per 64-query batch" if screened else
+                (f"fp16 SCREEN rows of the {args.dtype} index (unique rows per field), read once per launch" if screened else
                  ("bf16 slab" if args.dtype == "bf16" else "fp32 slab") + ", read once per 64-query batch")),
             "fp32_slab_bytes_per_batch_survey_8d": float(row1 - row0) * F * E * 4,
             "alone": ({"avg_launch_ms": alone_ms, "achieved": bytes_per_launch / (alone_ms * 1e-3) / 1e9,
@@ -308,7 +311,9 @@ def main():
             "metric": "queries/sec (whole node) at Recall@20 parity, 1M-doc x 8-field x 768d corpus",
             "value": qps, "unit": "queries/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "f32" else "bf16 docs x fp32 queries (3 exact bf16 terms), fp32 accumulate", "data": "synthetic",
+            "dtype": ("f32" if args.dtype == "f32" else
+                      ("bf16 docs, fp32 queries; lists and scores = the exact fp32 chain over the bf16 docs (certified fp16 screen)" if screened
+                       else "bf16 docs x fp32 queries (3 exact bf16 terms), fp32 accumulate")), "data": "synthetic",
             "config": {"workload": f"synthetic STaRK-amazon-shaped corpus ({args.corpus}), {D} docs x {F} dense fields x {E}d {args.dtype}, "
                                    f"row-sharded over {N} GPU(s); two-stage scorer k1=k2=100, zero-sentinel mode",
                        "docs": D, "fields": F, "dim": E, "query_batch": Q, "k1": K1, "k2": K2, "timed_queries": args.steps * Q,
@@ -318,8 +323,9 @@ def main():
                                     f"coalesced batch(es) of {Q} queries" + (" with the wide 128-column screened pass (one fp16 query term)"
                                                                              if ps.Qmax > 64 else "")),
                        "queries_per_launch": ps.Qmax},
-            "stage1": ("certified fp16 screen of the fp32 slab (min(k+92,192) unique rows per list re-scored with the exact fp32 chain, top-k "
-                       "proven or redone by the exact fp32 pass per field): outputs bit-identical to the plain fp32 pass" if screened else
+            "stage1": (f"certified fp16 screen of the {args.dtype} slab (min(k+92,192) unique rows per list re-scored with the exact fp32 chain, "
+                       "top-k proven or redone by the exact pass per field)" +
+                       (": outputs bit-identical to the plain fp32 pass" if args.dtype == "f32" else "") if screened else
                        ("exact fp32 MFMA pass" if args.dtype == "f32" else "bf16 slab pass")),
             "screen": ({"lists_certified": (scr["n_checked"] - scr0["n_checked"]) - (scr["n_failed"] - scr0["n_failed"]),
                         "lists_redone_exactly": scr["n_failed"] - scr0["n_failed"], "batches_redone": ps.n_redone,

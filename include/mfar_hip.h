@@ -247,7 +247,9 @@ int mfar_set_wgs_per_cu(mfar_index* idx, int wgs);
  * the documents on the device (csrc/mfar_screen.h).  The screen slab (at most +50 % HBM) is built lazily by the first search
  * after rows were written.
  *   mode      0 = off, 1 = auto (default; fp32 indexes with >= 16384 rows, k <= 128), 2 = whenever the shapes allow.
- *             Environment default: MFAR_SCREEN.
+ *             Environment default: MFAR_SCREEN.  A bf16 index is screened only in mode 2 (opt-in: the fp16 copy doubles its
+ *             footprint): its lists then equal the exact natural-order fp32 chain over the bf16 rows bit for bit (the plain
+ *             bf16 MFMA pass agrees with that chain to 1e-4), and the wide pass applies (1.75x the plain pass's throughput).
  *   eps_mult  multiplies the error bound of the proof; 1 = rigorous.  Test knob: a huge value makes every proof fail
  *             (exercises the exact fall-back), 0 disables the proof (NOT exact any more).
  * mfar_screen_stats synchronises the device: built = the screen slab is current, screen_bytes = its size,

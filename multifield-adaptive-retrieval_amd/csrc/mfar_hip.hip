@@ -781,7 +781,8 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
 
 // ------------------------------------------------------------------------------------------------ fp16 screen
 static bool screen_wanted(const mfar_index* idx, int k) {
-    if (idx->dtype != MFAR_DTYPE_F32 || idx->screen_mode == 0 || idx->screen_nomem) return false;
+    if (idx->screen_mode == 0 || idx->screen_nomem) return false;
+    if (idx->dtype == MFAR_DTYPE_BF16 && idx->screen_mode < 2) return false;   // bf16 indexes: opt-in (the screen doubles their footprint)
     if (k + SCREEN_EXTRA_MIN > SCREEN_MAX_KP) return false;
     if (idx->E * 4 > 60 * 1024) return false;   // the re-scoring kernel stages a query row in LDS
     return idx->screen_mode >= 2 || idx->n_rows >= 16384;
@@ -798,9 +799,8 @@ __global__ void mfar_iota_kernel(int* __restrict__ a, int* __restrict__ b, int* 
 }
 
 // Unique rows of one field -> idx->u_* tables of that field; returns the number of unique rows and the largest group.
-static int build_unique_rows(mfar_index* idx, int f, DevBuf* tmp, hipStream_t st, int* n_unique_out, int* largest_out) {
+static int build_unique_rows(mfar_index* idx, int f, const float* field, DevBuf* tmp, hipStream_t st, int* n_unique_out, int* largest_out) {
     const long long n = idx->n_rows;
-    const float* field = (const float*)idx->slab + (size_t)f * idx->field_stride;
     int* urep = idx->u_rep.as<int>() + (size_t)f * n;
     int* ustart = idx->u_start.as<int>() + (size_t)f * n;
     int* ucount = idx->u_count.as<int>() + (size_t)f * n;
@@ -887,24 +887,65 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
     RETCHK(idx->s_mean.ensure((size_t)F * idx->E * sizeof(float)));
     HIPCHK(hipMemsetAsync(idx->s_stats.p, 0, (size_t)F * 2 * sizeof(u32), st));
     HIPCHK(hipMemsetAsync(idx->s_mean.p, 0, (size_t)F * idx->E * sizeof(float), st));
-    mfar_screen_mean_kernel<<<dim3((unsigned)((idx->n_blk + 7) / 8), F), dim3(256), 0, st>>>(
-        (const float*)idx->slab, idx->field_stride, idx->n_steps, idx->n_blk, idx->n_rows, idx->s_mean.as<float>());
-    HIPCHK(hipGetLastError());
-    mfar_screen_mean_finish_kernel<<<dim3((F * idx->E + 255) / 256), dim3(256), 0, st>>>(idx->s_mean.as<float>(), F * idx->E, idx->n_rows);
-    HIPCHK(hipGetLastError());
-    mfar_screen_stats_kernel<<<dim3((unsigned)idx->n_blk, F), dim3(256), 0, st>>>(
-        (const float*)idx->slab, idx->field_stride, idx->n_steps, idx->n_rows, idx->s_mean.as<float>(), idx->s_stats.as<u32>());
-    HIPCHK(hipGetLastError());
+    // A bf16 index is screened through an fp32 staging copy of one field at a time (the rows widened exactly, in the fp32
+    // slab's tiled layout), so that every build kernel below exists once.  field_src(f) = the fp32 tiled rows of field f.
+    const bool bf16 = idx->dtype == MFAR_DTYPE_BF16;
+    DevBuf stage_rows, stage_field;
+    if (bf16 && (stage_rows.ensure((size_t)std::max<long long>(n, 1) * idx->E * 4) != MFAR_OK ||
+                 stage_field.ensure((size_t)idx->field_stride * 4) != MFAR_OK)) {
+        stage_rows.release();
+        stage_field.release();
+        return nomem();
+    }
+    auto field_src = [&](int f, const float** out) -> int {
+        if (!bf16) {
+            *out = (const float*)idx->slab + (size_t)f * idx->field_stride;
+            return MFAR_OK;
+        }
+        HIPCHK(hipMemsetAsync(stage_field.p, 0, (size_t)idx->field_stride * 4, st));
+        if (n > 0) {
+            const long long t8 = n * (idx->E / 8), t4 = n * (idx->E / 4);
+            mfar_untile_rows_bf16_kernel<<<dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, st>>>(
+                (const unsigned short*)idx->slab + (size_t)f * idx->field_stride, stage_rows.as<float>(), 0, n, idx->E);
+            mfar_tile_rows_kernel<<<dim3((unsigned)((t4 + 255) / 256)), dim3(256), 0, st>>>(stage_rows.as<float>(), stage_field.as<float>(), 0, n, idx->E);
+            HIPCHK(hipGetLastError());
+        }
+        *out = stage_field.as<float>();
+        return MFAR_OK;
+    };
+    // pass 1: per-field mean vector and statistics of the centred rows
+    for (int f = 0; f < F; ++f) {
+        const float* src;
+        RETCHK(field_src(f, &src));
+        float* mean_f = idx->s_mean.as<float>() + (size_t)f * idx->E;
+        mfar_screen_mean_kernel<<<dim3((unsigned)((idx->n_blk + 7) / 8), 1), dim3(256), 0, st>>>(src, idx->field_stride, idx->n_steps, idx->n_blk,
+                                                                                                idx->n_rows, mean_f);
+        HIPCHK(hipGetLastError());
+        mfar_screen_mean_finish_kernel<<<dim3((idx->E + 255) / 256), dim3(256), 0, st>>>(mean_f, idx->E, idx->n_rows);
+        HIPCHK(hipGetLastError());
+        mfar_screen_stats_kernel<<<dim3((unsigned)idx->n_blk, 1), dim3(256), 0, st>>>(src, idx->field_stride, idx->n_steps, idx->n_rows, mean_f,
+                                                                                     idx->s_stats.as<u32>() + 2 * f);
+        HIPCHK(hipGetLastError());
+    }
     mfar_screen_scale_kernel<<<dim3(1), dim3(64), 0, st>>>(idx->s_stats.as<u32>(), idx->s_mean.as<float>(), F, idx->E,
                                                          idx->s_field.as<ScreenField>());
     HIPCHK(hipGetLastError());
-    // unique rows, field by field (scratch shared)
+    // pass 2: unique rows, field by field (scratch shared); an fp32 index reads its slab in place
     DevBuf tmp[9];
     int rc = MFAR_OK;
-    for (int f = 0; f < F && rc == MFAR_OK; ++f) rc = build_unique_rows(idx, f, tmp, st, &idx->n_unique[f], &idx->largest_group[f]);
+    std::vector<const float*> srcs(F, nullptr);
+    for (int f = 0; f < F && rc == MFAR_OK; ++f) {
+        rc = field_src(f, &srcs[f]);
+        if (rc == MFAR_OK) rc = build_unique_rows(idx, f, srcs[f], tmp, st, &idx->n_unique[f], &idx->largest_group[f]);
+        if (bf16) HIPCHK(hipStreamSynchronize(st));   // the staging copy is reused by the next field
+    }
     HIPCHK(hipStreamSynchronize(st));
     for (auto& b : tmp) b.release();
-    if (rc == MFAR_ERR_NOMEM) return nomem();
+    if (rc == MFAR_ERR_NOMEM) {
+        stage_rows.release();
+        stage_field.release();
+        return nomem();
+    }
     RETCHK(rc);
     HIPCHK(hipMemcpyAsync(idx->u_n.p, idx->n_unique.data(), (size_t)F * 4, hipMemcpyHostToDevice, st));
     // geometry of the screen slab: every field holds its unique rows, padded to whole 256-row tiles
@@ -919,15 +960,27 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
         g.n_tiles[f] = (int)(blk / 4);
         total += blk * 64 * idx->E;
     }
-    if (idx->screen.ensure((size_t)total * 2) != MFAR_OK) return nomem();
+    if (idx->screen.ensure((size_t)total * 2) != MFAR_OK) {
+        stage_rows.release();
+        stage_field.release();
+        return nomem();
+    }
     idx->screen_used = (size_t)total * 2;
+    // pass 3: the fp16 rows
     for (int f = 0; f < F; ++f) {
+        const float* src;
+        RETCHK(field_src(f, &src));
         const long long n_gran = (long long)g.n_tiles[f] * 4 * idx->n_steps * 128;
         mfar_screen_build_kernel<<<dim3((unsigned)((n_gran + 255) / 256)), dim3(256), 0, st>>>(
-            (const float*)idx->slab + (size_t)f * idx->field_stride, (_Float16*)idx->screen.p + g.base[f], n_gran, idx->n_steps,
-            idx->n_unique[f], idx->u_rep.as<int>() + (size_t)f * n, idx->s_mean.as<float>() + (size_t)f * idx->E,
-            idx->s_field.as<ScreenField>() + f);
+            src, (_Float16*)idx->screen.p + g.base[f], n_gran, idx->n_steps, idx->n_unique[f], idx->u_rep.as<int>() + (size_t)f * n,
+            idx->s_mean.as<float>() + (size_t)f * idx->E, idx->s_field.as<ScreenField>() + f);
         HIPCHK(hipGetLastError());
+        if (bf16) HIPCHK(hipStreamSynchronize(st));
+    }
+    if (bf16) {
+        HIPCHK(hipStreamSynchronize(st));
+        stage_rows.release();
+        stage_field.release();
     }
     idx->screen_dirty = false;
     *ok = true;
@@ -1018,7 +1071,8 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     sp.nuniq = idx->u_n.as<int>();
     sp.ustride = idx->n_rows;
     sp.f0 = f0;
-    mfar_score_rows_f32_kernel<<<dim3((unsigned)((kp * nf + SCF_THREADS - 1) / SCF_THREADS), qt_n), dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(sp);
+    if (bf16) mfar_score_candidates_kernel<1><<<dim3((unsigned)((kp * nf + 255) / 256), qt_n), dim3(256), SCORE_LDS_BYTES(idx->E), st>>>(sp);
+    else mfar_score_rows_f32_kernel<<<dim3((unsigned)((kp * nf + SCF_THREADS - 1) / SCF_THREADS), qt_n), dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(sp);
     HIPCHK(hipGetLastError());
     // 3. exact top-k documents + certificate
     CertifyParams cp = {};
@@ -1073,12 +1127,17 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     // 4. fall-back: the exact fp32 pass over the DOCUMENTS of the fields whose certificate failed (workgroups of other
     //    fields exit at once)
     for (int b0 = 0; b0 < qt_n; b0 += 64) {   // the exact pass takes 64 queries at a time
-        const int total = 64 * (idx->E / 4);
-        mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, sl.qt.as<float>(), q0 + b0, Q, idx->E);
+        if (bf16) {
+            const int total = 64 * (idx->E / 8);
+            mfar_tile_queries_bf16_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, sl.qt.as<unsigned short>(), q0 + b0, Q, idx->E);
+        } else {
+            const int total = 64 * (idx->E / 4);
+            mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, sl.qt.as<float>(), q0 + b0, Q, idx->E);
+        }
         HIPCHK(hipGetLastError());
         const S1Out o = {fid, fsc, nullptr, q0 + b0, sentinel, idx->row_offset};
-        RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, S1_ALL, S1_F32, idx->slab, sl.qt.p, std::min(64, qt_n - b0), k, tau0, nullptr, fflags,
-                           false, o, st));
+        RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, S1_ALL, bf16 ? S1_BF16 : S1_F32, idx->slab, sl.qt.p, std::min(64, qt_n - b0), k, tau0,
+                           nullptr, fflags, false, o, st));
     }
     return MFAR_OK;
 }

@@ -487,9 +487,12 @@ __global__ void __launch_bounds__(256) mfar_score_candidates_kernel(const ScoreP
     const char* rowbase = (const char*)p.slab;  // harmless in-bounds address for invalid rows
     if (idx < p.C * p.F) {
         const int c = p.per_field ? idx % p.C : idx / p.F;
-        const int f = p.per_field ? idx / p.C : idx - c * p.F;
+        const int fl = p.per_field ? idx / p.C : idx - c * p.F;     // list / field slot of this launch
+        const int f = p.per_field ? p.f0 + fl : fl;                 // field of the slab
         if (c < nc) {
-            const long long id = p.cand[p.per_field ? ((size_t)qi * p.F + f) * p.C + c : (size_t)qi * p.C + c] - p.row_offset;
+            long long id = p.cand[p.per_field ? ((size_t)qi * p.F + fl) * p.C + c : (size_t)qi * p.C + c];
+            if (p.urep) id = (id >= 0 && id < p.nuniq[f]) ? (long long)p.urep[(size_t)f * p.ustride + id] : -1;   // unique row -> its document
+            else id -= p.row_offset;
             if (id >= 0 && id < p.n_rows) {
                 valid = true;
                 rr = (int)(id & 63);

@@ -1065,3 +1065,35 @@ def test_fused_mode_bit_exact_and_recall(idxmod):
     rec = lambda ids: float(np.mean([len(set(ids[j, :20].tolist()) & rel[j]) / len(rel[j]) for j in range(256)]))
     assert rec(fu) >= rec(two) - 0.001, (rec(fu), rec(two))
     ix.close()
+
+
+def test_bf16_index_with_certified_screen(idxmod):
+    """A bf16 index with the screen switched on (opt-in: it doubles the index's footprint): stage 1 scans an fp16 copy of each
+    field's unique rows (wide pass for more than 64 queries), re-scores with the bf16 contract's exact natural-order chain and
+    proves the lists -- which makes them BIT-identical to the oracle (the plain bf16 MFMA pass is only within 1e-4), duplicate
+    groups included; a forced fall-back stays within the plain pass's tolerance."""
+    rng = np.random.default_rng(61)
+    for F, D, E, Q, dup in ((3, 30000, 96, 70, 0), (2, 40000, 768, 128, 3000), (1, 20000, 64, 9, 0)):
+        slab, q, W = _mk(rng, F, D, E, Q, dup=dup)
+        rs = O.bf16_round(slab)
+        ix = _load_bf16(idxmod, slab)
+        assert ix.max_split_batch(100) == 64           # off by default for bf16 indexes
+        ix.set_screen(2)
+        assert ix.max_split_batch(100) == 128
+        r = ix.search(q, W, None, return_fields=True)
+        with O.chain("natural"):
+            o = O.c_two_stage(rs, q, W, None)
+        for key in ("field_ids", "ids"):
+            assert np.array_equal(r[key], o[key]), (key, F, D, E, Q)
+        for key in ("field_scores", "scores"):
+            assert np.array_equal(r[key].view(np.uint32), o[key].view(np.uint32)), (key, F, D, E, Q)
+        st = ix.screen_stats()
+        assert st["built"] and st["n_checked"] == Q * F and st["n_failed"] == 0, st
+        if dup:
+            assert min(st["unique_rows"]) <= D - dup + 1
+        ix.set_screen(2, 1e9)                          # every certificate fails: the plain bf16 pass repairs
+        rx = ix.search(q, W, None, return_fields=True)
+        for f in range(F):
+            O.assert_topk_equivalent(rx["field_ids"][:, f], rx["field_scores"][:, f], o["field_ids"][:, f], o["field_scores"][:, f],
+                                     tol=TOL, what=f"bf16 forced fall-back f{f}")
+        ix.close()
