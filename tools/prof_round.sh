@@ -5,6 +5,14 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_round; mkdir -p $O
 B="--no-cpu-baseline --no-extra-legs"
 python $R/bench.py > $O/bench.json 2> $O/bench.err
 python $R/bench.py --dtype bf16 --no-cpu-baseline > $O/bench_bf16.json 2>> $O/bench.err
+python $R/bench.py --dtype bf16 --screen on --no-cpu-baseline --no-extra-legs > $O/bench_bf16_screened.json 2>> $O/bench.err
+python $R/bench.py --coalesce 1 $B > $O/bench_coalesce1.json 2>> $O/bench.err
+# BASELINE.json's config shapes and other embedding widths (one line each)
+: > $O/shapes.txt
+for cfg in "129375 22 768" "700244 5 768" "957192 8 768" "125000 8 768" "2000000 8 384" "1500000 8 512" "750000 8 1024" "500000 8 1536"; do
+  set -- $cfg
+  python $R/bench.py $B --docs $1 --fields $2 --dim $3 2>> $O/bench.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['config']['docs'], d['config']['fields'], d['config']['dim'], 'q/s=%.0f' % d['value'], 'ms/step=%.3f' % d['ms_per_step'], r['kernel'], 'launch_ms=%.3f' % r['avg_launch_ms'], 'hbm_frac=%.3f' % r['frac'], 'redone=%d' % d['screen']['lists_redone_exactly'], 'recall20=%.3f' % d['recall_at_20'])" >> $O/shapes.txt
+done
 # kernel trace + stats of the default leg alone (the extra legs launch the same kernels on other shapes and would skew the averages)
 rocprofv3 --kernel-trace --stats -d /tmp/kt -o r1 --output-format csv -- python $R/bench.py --steps 16 --warmup 2 $B > $O/bench_under_rocprof.json 2>/dev/null
 # counters: one pass each; default leg, then the exact fp32 pass (--screen off) into a sub-directory of the same pass
