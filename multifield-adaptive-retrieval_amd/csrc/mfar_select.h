@@ -568,7 +568,7 @@ __global__ void __launch_bounds__(256) mfar_score_candidates_kernel(const ScoreP
 // fp32 slab: every (row, k-step pair) is one full 128-byte line (mfar_device.h), so a wave gathers 64 rows x 128 B = 8 KB
 // per ring slot: 8 lanes per row, 8 rows per 1 KB LDS-DMA instruction, 8 instructions per slot; two slots per wave.  A
 // workgroup is 2 waves (32 KB + the query row: fits beside two resident stage-1 workgroups).  The 16-byte pieces of a row
-// are stored at position piece ^ (row & 7) inside its 128 bytes, which spreads the lanes' ds_read_b128 over the banks.
+// are stored at position piece ^ ((owner lane >> 1) & 7) inside its 128 bytes: conflict-free ds_read_b128 for any rows.
 // Chain order = the arithmetic contract (inside every aligned group of 8 dims: 0,4,1,5,2,6,3,7).
 #define SCF_THREADS 128
 #define SCF_SLOT_BYTES 8192
@@ -610,15 +610,17 @@ __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_f32_kernel(const 
             }
         }
     }
-    // lane l fetches, for the rows (l / 8) + 8 i, the piece that belongs at LDS position l % 8: piece (l % 8) ^ (row & 7)
+    // lane l fetches, for the rows owned by lanes r = (l / 8) + 8 i, the piece that belongs at LDS position l % 8:
+    // piece (l % 8) ^ key(r), key(r) = (r >> 1) & 7.  The key follows the OWNER LANE, not the row number: the 16 lanes a
+    // ds_read_b128 serves per pass (two lanes per 64-bank row pair) then always hit 16 distinct bank groups, whatever rows
+    // the candidates are (keyed by the row number, random candidates collided: SQ_LDS_BANK_CONFLICT was 9 % of the wave cycles)
     const char* src[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = (lane >> 3) + 8 * i;
         const unsigned long long b = (unsigned long long)rowbase;
         const u32 lo = __shfl((int)(u32)b, r), hi = __shfl((int)(u32)(b >> 32), r);
-        const int rr_r = __shfl(rr, r);
-        src[i] = (const char*)(((unsigned long long)hi << 32) | lo) + (((lane & 7) ^ (rr_r & 7)) << 4);
+        src[i] = (const char*)(((unsigned long long)hi << 32) | lo) + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
     }
     const int n_pairs = p.n_steps >> 1;
 #define SCF_ISSUE(G, SLOT)                                                                                         \
@@ -627,7 +629,7 @@ __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_f32_kernel(const 
         (__attribute__((address_space(3))) void*)(ring + (SLOT) * SCF_SLOT_BYTES + i * 1024), 16, 0, SC_AUX)
     SCF_ISSUE(0, 0);
     float acc = 0.0f;
-    const int sw = rr & 7;
+    const int sw = (lane >> 1) & 7;
     for (int g = 0; g < n_pairs; ++g) {
         const int slot = g & 1;
         if (g + 1 < n_pairs) {
