@@ -767,20 +767,21 @@ def test_screen_anisotropic_embeddings_are_certified(idxmod):
     The screen slab is centred on the field mean, so its error bound scales with the spread of the rows, not with their
     norm: even with the common part 10x the spread every list is certified (no exact fall-back), bit-exact as always."""
     rng = np.random.default_rng(16)
-    F, D, E, Q, k = 2, 30000, 96, 33, 100
-    common = rng.standard_normal(E).astype(np.float32)
-    common *= np.float32(10.0 * np.sqrt(E) * 0.05 / np.linalg.norm(common))          # |common| = 10 x the noise norm
-    slab = (rng.standard_normal((F, D, E)) * 0.05 + common).astype(np.float32)
-    q = (rng.standard_normal((Q, E)) * 0.05 + common * 0.5).astype(np.float32)
-    ix = _load(idxmod, slab)
-    ix.set_screen(2)
-    for sentinel in (True, False):
-        _check_stage1(ix, slab, q, k, sentinel, ("anisotropic", sentinel))
-    st = ix.screen_stats()
-    assert st["n_checked"] == 2 * Q * F and st["n_failed"] == 0, st
-    # negative common component: every score is far below zero, the zero sentinel empties the lists
-    _check_stage1(ix, slab, -q, k, True, "all negative")
-    ix.close()
+    for Q in (33, 128):                     # the 64-column pass (two query terms) and the wide pass (one term: eps about doubles)
+        F, D, E, k = 2, 30000, 96, 100
+        common = rng.standard_normal(E).astype(np.float32)
+        common *= np.float32(10.0 * np.sqrt(E) * 0.05 / np.linalg.norm(common))          # |common| = 10 x the noise norm
+        slab = (rng.standard_normal((F, D, E)) * 0.05 + common).astype(np.float32)
+        q = (rng.standard_normal((Q, E)) * 0.05 + common * 0.5).astype(np.float32)
+        ix = _load(idxmod, slab)
+        ix.set_screen(2)
+        for sentinel in (True, False):
+            _check_stage1(ix, slab, q, k, sentinel, ("anisotropic", sentinel, Q))
+        st = ix.screen_stats()
+        assert st["n_checked"] == 2 * Q * F and st["n_failed"] == 0, st
+        # negative common component: every score is far below zero, the zero sentinel empties the lists
+        _check_stage1(ix, slab, -q, k, True, "all negative")
+        ix.close()
 
 
 def test_screen_scans_unique_rows_and_expands_groups(idxmod):

@@ -358,3 +358,19 @@ def test_gtr_t5_branch_and_decoder(tmp_path):
     _, enc2, dec2 = prepare_model(str(root))
     assert dec2 is None and enc2.dense is not None
     np.testing.assert_allclose(enc2.encode(texts), enc.encode(texts), rtol=1e-5, atol=1e-6)
+
+
+def test_prepare_model_from_local_directory(tmp_path):
+    """The local-directory branch of prepare_model (modeling/util.py:54-71): a HF model directory (what a fine-tuned contriever
+    is on disk) -> AutoModel + mean pooling [+ Normalize]; unknown paths raise ValueError like the reference."""
+    import torch
+    from mfar.modeling.util import prepare_model
+    tok, enc, _ = prepare_model("random-init:64x2")
+    root = tmp_path / "bert-tiny"
+    enc.auto_model.save_pretrained(root)
+    tok.save_pretrained(root)
+    tok2, enc2, dec2 = prepare_model(str(root), freeze_encoder=True)
+    assert dec2 is None and not any(p.requires_grad for p in enc2.parameters())
+    texts = ["a red shoe", "the quick brown fox jumps", ""]
+    np.testing.assert_allclose(enc2.encode(texts), enc.encode(texts), rtol=1e-5, atol=1e-6)
+    assert set(enc2.state_dict()) == set(enc.state_dict())
