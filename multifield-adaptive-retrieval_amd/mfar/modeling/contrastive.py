@@ -179,12 +179,17 @@ class RetrievalTrainingModule(torch.nn.Module):
             stream = candidate_encoding_stream(self.encoder, ((i, uniq[i]) for i in order), batch_size=bs, multiprocess=False,
                                                show_progress=False, as_tensor=True)             # contrastive.py:483-489
             got, vecs = [], []
-            for i, v in stream:
-                got.append(i)
-                vecs.append(v)
-                if len(got) == bs:
-                    emb_u[torch.tensor(got, device=self.device)] = torch.stack(vecs).float()
-                    got, vecs = [], []
+            # MFAR_ENCODE_AUTOCAST=bf16|fp16: run the corpus-encode forwards under autocast ("bf16 encoder").  Off by
+            # default: the reference encodes the corpus in fp32 (its precision plugin wraps the steps, not on_test_epoch_start);
+            # the rows written to the slab are fp32 either way.
+            ac = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(os.environ.get("MFAR_ENCODE_AUTOCAST", "").lower())
+            with torch.autocast(device_type=self.device.type, dtype=ac, enabled=ac is not None):
+                for i, v in stream:
+                    got.append(i)
+                    vecs.append(v)
+                    if len(got) == bs:
+                        emb_u[torch.tensor(got, device=self.device)] = torch.stack(vecs).float()
+                        got, vecs = [], []
             if got:
                 emb_u[torch.tensor(got, device=self.device)] = torch.stack(vecs).float()
             rows = torch.tensor([slot[t] for t in texts], device=self.device)

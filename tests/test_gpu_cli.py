@@ -258,3 +258,22 @@ def test_sparse_fields_and_bm25_negatives(tmp_path):
     rows = [json.loads(l) for l in open(f"{out2}/results_dicts-all-0.jsonl")]
     assert [r["masked_fields"] for r in rows][:7] == ["", "brand_dense", "title_dense", "feature_sparse", "title_sparse",
                                                       "feature_sparse,title_sparse", "brand_dense,title_dense"]
+
+
+def test_corpus_encode_under_autocast(tmp_path, monkeypatch):
+    """MFAR_ENCODE_AUTOCAST=bf16: the corpus encode runs under bf16 autocast, the slab still holds fp32 rows, and
+    they stay close to the fp32 encode's (same texts -> bit-identical duplicate rows either way)."""
+    from mfar.commands import train
+    data = str(tmp_path / "data")
+    _write_dataset(data, n_docs=120, n_q=101)      # >= 100 candidates per query are needed by the top-100
+    rows = {}
+    for mode in ("", "bf16"):
+        monkeypatch.setenv("MFAR_ENCODE_AUTOCAST", mode)
+        m = train.main(dataset_name="amazon", lexical_index="unused", out=str(tmp_path / f"out{mode}"), temp_dir=str(tmp_path / f"tmp{mode}"),
+                       data=data, model_name="random-init:64x2", field_names="title_dense,brand_dense", weights_lr=1e-2, max_epochs=0,
+                       dev_batch_size=16, precision="32")
+        rows[mode] = np.stack([m.slab.read_rows(f) for f in range(2)])
+    a, b = rows[""], rows["bf16"]
+    cos = (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+    assert cos.min() > 0.995 and not np.array_equal(a, b)
+    assert len(np.unique(b[1], axis=0)) == len(np.unique(a[1], axis=0))       # brand: the same duplicate structure
