@@ -36,18 +36,23 @@ from mfar.data import index as _index
 
 class PipelinedSearcher:
     def __init__(self, index, W, mask=None, k1: int = 100, k2: int = 100, sentinel: bool = True, query_cond: bool = True,
-                 max_batch: int = 64, group=None, coalesce=None):
+                 max_batch: int = 64, group=None, coalesce=None, exchange=None):
         self.ix, self.W, self.mask = index, W, mask
         self.k1, self.k2, self.sentinel, self.query_cond = k1, k2, sentinel, query_cond
         self.group = group
         dist = torch.distributed
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        # exchange=True runs the lists-first exchange (the two all-gathers + owned scoring + merge) even with ONE rank: the
+        # RCCL code path of the multi-GPU pipeline can then be exercised on a one-GPU box (tests/test_gpu_multirank.py)
+        self.sharded = self.world > 1 if exchange is None else bool(exchange)
+        if self.sharded and not (dist.is_available() and dist.is_initialized()):
+            raise ValueError("the exchange path needs an initialised torch.distributed process group")
         self.dev = torch.device(f"cuda:{index.device}")
         self.main = torch.cuda.Stream(device=self.dev, priority=-1)   # the scans: dispatched ahead of the small kernels
         self.side = torch.cuda.Stream(device=self.dev)
         self.Qb = int(max_batch)      # queries per submitted batch (at most)
         cap = index.max_split_batch(k1)                       # 128 with the wide screened pass, else 64
-        if self.world > 1:
+        if self.sharded:
             # every rank must cut the query stream into the same launches (fixed-size payloads are all-gathered): shards
             # whose sizes straddle the screen's row threshold, or a rank that could not allocate its screen slab, would
             # otherwise disagree -- take the smallest answer
@@ -79,7 +84,7 @@ class PipelinedSearcher:
                      fail=torch.zeros(1, dtype=torch.int32, device=self.dev),
                      fail_host=torch.zeros(1, dtype=torch.int32).pin_memory(),
                      stage1=torch.cuda.Event(), done=torch.cuda.Event(), Q=0, checked=True, launch=-1)
-            if self.world == 1:
+            if not self.sharded:
                 s["fid"] = torch.empty(self.Qmax, F, k1, dtype=torch.int64, device=self.dev)
                 s["fsc"] = torch.empty(self.Qmax, F, k1, device=self.dev)
             else:       # lists-first exchange: two small all-gathers per launch (include/mfar_hip.h)
@@ -97,7 +102,7 @@ class PipelinedSearcher:
 
     # where stage 1 leaves the per-field lists of a slot: (ids, scores) as tensors or raw device addresses
     def _list_targets(self, s):
-        if self.world == 1:
+        if not self.sharded:
             Q = s["Q"]
             return s["fid"][:Q], s["fsc"][:Q]
         base = s["lists"].data_ptr()                     # lists layout: ids | scores (256-byte aligned), include/mfar_hip.h
@@ -109,7 +114,7 @@ class PipelinedSearcher:
         Q = s["Q"]
         qk = s["q"][:Q]
         out = dict(ids=s["ids"][:Q], scores=s["scores"][:Q], n_valid=s["n_valid"][:Q])
-        if self.world == 1:
+        if not self.sharded:
             self.ix.search_stage2(qk, s["W"], s["fid"][:Q], s["mask"], self.k1, self.k2, self.query_cond, slot=slot, out=out)
         else:
             dist = torch.distributed
@@ -125,7 +130,7 @@ class PipelinedSearcher:
         """q: [Q, E] float32 CUDA tensor, Q <= max_batch (Q == max_batch for the sharded path: fixed payload size)."""
         t = self.n_submitted
         Q = q.shape[0]
-        if Q > self.Qb or (self.world > 1 and Q != self.Qb):
+        if Q > self.Qb or (self.sharded and Q != self.Qb):
             raise ValueError("batch size does not fit the pipeline's buffers")
         slot = self.n_launched & 1
         s = self.slots[slot]
@@ -156,9 +161,9 @@ class PipelinedSearcher:
         slot = self.n_launched & 1
         s = self.slots[slot]
         Q = sum(p[2] for p in self._pending)
-        if self.world > 1 and Q != self.Qmax:         # fixed payload size: the missing batch is scanned as zero queries
-            with torch.cuda.stream(self.main):
-                s["q"][Q:].zero_()
+        if self.sharded and Q != self.Qmax:         # fixed payload size: the missing batch repeats the last real query
+            with torch.cuda.stream(self.main):       # (an all-zero query cannot be certified -- every row ties at 0 -- and
+                s["q"][Q:].copy_(s["q"][Q - 1:Q].expand(self.Qmax - Q, -1))   # would send the launch through the exact redo)
             Q = self.Qmax
         self._pending = []
         for tk in [tk for tk, (L, _, _) in self._where.items() if L <= self.n_launched - 2]:
@@ -216,7 +221,7 @@ class PipelinedSearcher:
         # for the failed fields only (cheaper than switching the screen off for the whole launch)
         Q = s["Q"]
         qk = s["q"][:Q]
-        if self.world == 1:
+        if not self.sharded:
             _native.check(_native.lib().mfar_retrieve_fields(
                 self.ix._h, qk.data_ptr(), Q, int(self.k1), int(bool(self.sentinel)), s["fid"].data_ptr(), s["fsc"].data_ptr(), 1,
                 torch.cuda.current_stream(self.dev).cuda_stream))

@@ -225,7 +225,7 @@ class RetrievalTrainingModule(torch.nn.Module):
 
     def _submit(self, batch, qres_output):
         """Enqueue one query batch (asynchronous); returns what `_collect` needs.  Batches above the pipeline's width are
-        split; with several ranks a short (last) batch is padded with zero queries to the fixed exchange size."""
+        split; with several ranks a short (last) batch is padded to the fixed exchange size."""
         ps = self._get_searcher()
         ps.W, ps.mask = self._weights(), self.mask[:, 0].float().contiguous().to(self.device)
         x = self.encode_query_batch(batch)
@@ -233,8 +233,8 @@ class RetrievalTrainingModule(torch.nn.Module):
         for b in range(0, x.shape[0], ps.Qb):
             xb = x[b:b + ps.Qb]
             n = xb.shape[0]
-            if ps.world > 1 and n < ps.Qb:
-                xb = torch.cat([xb, xb.new_zeros(ps.Qb - n, xb.shape[1])])
+            if ps.sharded and n < ps.Qb:       # fixed exchange size: pad with copies of the last query (results are dropped)
+                xb = torch.cat([xb, xb[-1:].expand(ps.Qb - n, -1)])
             parts.append((ps.submit(xb.contiguous()), batch.instances[b:b + n]))
         return parts, qres_output
 

@@ -37,3 +37,14 @@ def test_ranks_on_one_gpu_match_single_rank(world, dtype):
     assert one["n_gpus"] == 1 and two["n_gpus"] == world and two["scaling"] == "strong"
     assert one["recall_at_20"] > 0.3 and two["recall_at_20"] == one["recall_at_20"]   # (weak planted signal at dim 128)
     assert two["ids_checksum"] == one["ids_checksum"]          # same top-100 ids for every query of every step
+
+
+def test_exchange_path_over_rccl_with_one_rank():
+    """RCCL itself: a one-rank nccl process group on cuda:0 carries the two all-gathers of every launch of the pipelined
+    searcher's exchange path (fp32 index with the wide screened pass, bf16 index); results equal the plain search bit for bit."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_one_rank.py"), "29577"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["f32"]["same"] and res["bf16"]["same"], res
+    assert res["f32"]["coalesce"] == 2 and res["f32"]["n"] == 7 and res["f32"]["redone"] == 0, res
