@@ -107,6 +107,12 @@ def main():
     ap.add_argument("--cpu-sample-docs", type=int, default=0, help="0 = the full corpus when host RAM allows, else 100000")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result of rank 0: libraries that write to the process's stdout on their own (RCCL
+    # prints a version banner from C when the first communicator is created) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -140,6 +146,14 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=N)
     else:
         torch.cuda.set_device(local_rank)
+        if os.environ.get("MFAR_BENCH_FORCE_EXCHANGE") == "1":
+            # diagnostic: N = 1 through the multi-GPU exchange path (one-rank RCCL group: both all-gathers per launch, owned
+            # scoring, top-k merge) -- what the exchange costs per launch on top of the single-shard tail
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29512")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{local_rank}"))
     dev = torch.device(f"cuda:{local_rank}")
 
     from mfar import synth
@@ -169,7 +183,9 @@ def main():
 
     # Two-deep pipeline: stage 1 of batch i+1 (main stream) overlaps the tail of batch i (side stream).  Every batch is
     # still processed completely inside the timed region (the region ends with a full device synchronisation).
-    ps = PipelinedSearcher(ix, W, mask, k1=K1, k2=K2, sentinel=True, query_cond=True, max_batch=Q, coalesce=args.coalesce or None)
+    force_exchange = N == 1 and os.environ.get("MFAR_BENCH_FORCE_EXCHANGE") == "1"
+    ps = PipelinedSearcher(ix, W, mask, k1=K1, k2=K2, sentinel=True, query_cond=True, max_batch=Q, coalesce=args.coalesce or None,
+                           exchange=True if force_exchange else None)
 
     def run(searcher, cp, first, n, keep):
         # results are taken `lag` submissions late, so that two launches of the pipeline stay in flight (a launch scans one
@@ -318,7 +334,8 @@ def main():
                                    f"row-sharded over {N} GPU(s); two-stage scorer k1=k2=100, zero-sentinel mode",
                        "docs": D, "fields": F, "dim": E, "query_batch": Q, "k1": K1, "k2": K2, "timed_queries": args.steps * Q,
                        "parallelism": (f"row-shard x{N}, lists-first exchange over RCCL (per batch: all-gather of the stage-1 lists, "
-                                       f"all-gather of the local top-k + certificate flag)") if N > 1 else "single shard",
+                                       f"all-gather of the local top-k + certificate flag)") if N > 1 else
+                                      ("single shard through the exchange path (one-rank RCCL group, diagnostic)" if force_exchange else "single shard"),
                        "pipeline": (f"2 launches in flight (stage 1 of launch i+1 overlaps the tail of launch i); a launch scans {ps.coalesce} "
                                     f"coalesced batch(es) of {Q} queries" + (" with the wide 128-column screened pass (one fp16 query term)"
                                                                              if ps.Qmax > 64 else "")),
@@ -342,8 +359,10 @@ def main():
             line["fused_mode"] = fused_leg(corpus, ix, results, args, Q, recall20, torch, np)
         if N == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(corpus, ix, args, np, torch)
-        print(json.dumps(line), flush=True)
-    if N > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if N > 1 or force_exchange:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 
