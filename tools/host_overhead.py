@@ -14,10 +14,16 @@ from mfar.data import index as idxmod
 from mfar.data.pipeline import PipelinedSearcher
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 125000
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+EXCHANGE = os.environ.get("MFAR_BENCH_FORCE_EXCHANGE") == "1"       # the multi-GPU exchange path over a one-rank RCCL group
+if EXCHANGE:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29513")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
 corpus = synth.SyntheticCorpus(D, F, 768, n_queries=4096, seed=1, device="cuda:0")
 ix = corpus.build_index(idxmod)
 for coalesce in (None, 1):
-    ps = PipelinedSearcher(ix, corpus.W, torch.ones(F, device="cuda:0"), max_batch=64, coalesce=coalesce)
+    ps = PipelinedSearcher(ix, corpus.W, torch.ones(F, device="cuda:0"), max_batch=64, coalesce=coalesce, exchange=True if EXCHANGE else None)
     qs = [corpus.queries((i % 60) * 64, 64) for i in range(260)]
     tk = []
     for i in range(20):                       # warm-up: scratch allocation, screen build
@@ -34,6 +40,6 @@ for coalesce in (None, 1):
     for t in tk[-ps.lag:]: ps.result(t)
     torch.cuda.synchronize()
     tot = time.perf_counter() - t0
-    print(json.dumps({"docs": D, "fields": F, "coalesce": ps.coalesce, "batches": n, "wall_ms_per_batch": tot / n * 1e3,
+    print(json.dumps({"docs": D, "fields": F, "exchange_path": EXCHANGE, "coalesce": ps.coalesce, "batches": n, "wall_ms_per_batch": tot / n * 1e3,
                       "host_in_submit_ms_per_batch": tsub / n * 1e3, "host_waiting_in_result_ms_per_batch": tres / n * 1e3,
                       "queries_per_s": n * 64 / tot}))
