@@ -40,6 +40,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "multifield-adaptive-retrieval_amd"))
 sys.path.insert(0, ROOT)
+# one hardware queue per HIP stream (scans, tail kernels, RCCL): see mfar/_native.py; before anything initialises the GPU
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
