@@ -52,9 +52,8 @@ def main():
             ix.write_rows(f, 0, slab[f])
         ref = O.bf16_round(slab) if dtype == "bf16" else slab
         ok = True
-        for screen in ((0,) if dtype == "bf16" else (0, 2)):
-            if dtype == "f32":
-                ix.set_screen(screen)
+        for screen in (0, 2):
+            ix.set_screen(screen)        # bf16: 2 = the opt-in certified screen (lists then equal the natural-order chain bit for bit)
             ix.set_wgs_per_cu(int(rng.choice([1, 2, 4])))
             ids, sc = ix.retrieve_fields(q, k, sentinel)
             for f in range(F):
@@ -62,6 +61,8 @@ def main():
                     with O.chain("natural"):
                         oi, osc = O.c_retrieve(ref[f], q, k, sentinel)
                     good = np.allclose(sc[:, f], osc, rtol=0, atol=1e-4 * max(1.0, float(np.abs(osc).max())))
+                    if screen == 2 and k + 64 <= 192 and ix.screen_stats()["n_failed"] == 0:      # certified: exact ids and bits
+                        good = good and np.array_equal(ids[:, f], oi) and np.array_equal(sc[:, f].view(np.uint32), osc.view(np.uint32))
                 else:
                     oi, osc = O.c_retrieve(ref[f], q, k, sentinel)
                     good = np.array_equal(ids[:, f], oi) and np.array_equal(sc[:, f].view(np.uint32), osc.view(np.uint32))
@@ -84,7 +85,14 @@ def main():
                     ok = False
                     print("MISMATCH two-stage", dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, kind=int(kind), screen=screen,
                                                      seed=seed, n=n), flush=True)
-        st = ix.screen_stats() if dtype == "f32" else {}
+        if ok and dtype == "f32" and k < 128 and D * F * E * Q < 2e9 and rng.random() < 0.3:      # fused mode against its contract
+            Wf = (rng.standard_normal((E, F)) * 0.05).astype(np.float32)
+            oi, osc = O.c_search_fused(slab, q, Wf, None, k)
+            r = ix.search_fused(q, Wf, None, k)
+            if not (np.array_equal(r["ids"], oi) and np.array_equal(r["scores"].view(np.uint32), osc.view(np.uint32))):
+                ok = False
+                print("MISMATCH fused", dict(F=F, D=D, E=E, Q=Q, k=k, seed=seed, n=n), flush=True)
+        st = ix.screen_stats()
         ix.close()
         n += 1
         print(f"{n:4d} ok={ok} F={F} D={D} E={E} Q={Q} k={k} sent={int(sentinel)} mean={mean} {dtype} kind={int(kind)} "
