@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--screen", type=int, default=1)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--queries", type=int, default=64, help="queries per call (more than 64: the wide pass)")
     a = ap.parse_args()
     import torch
     from mfar import synth
@@ -26,16 +27,16 @@ def main():
     ix = corpus.build_index(idxmod, dtype=a.dtype)
     ix.set_screen(a.screen)
     for i in range(3):
-        ix.retrieve_fields(corpus.queries(i * 64, 64), a.k, True)
+        ix.retrieve_fields(corpus.queries(i * a.queries, a.queries), a.k, True)
     torch.cuda.synchronize()
     ix.set_timing(True)
     t0 = time.perf_counter()
     for i in range(a.iters):
-        ix.retrieve_fields(corpus.queries((3 + i) * 64, 64), a.k, True)
+        ix.retrieve_fields(corpus.queries(((3 + i) % 8) * a.queries, a.queries), a.k, True)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters * 1e3
     ms, n = ix.stage1_timing()
-    print(f"dtype={a.dtype} screen={a.screen} dbg={os.environ.get('MFAR_S1_DEBUG', '0')} stage1_total_ms={dt:.3f} main_kernel_ms={ms / max(n, 1):.3f} "
+    print(f"queries={a.queries} dtype={a.dtype} screen={a.screen} dbg={os.environ.get('MFAR_S1_DEBUG', '0')} stage1_total_ms={dt:.3f} main_kernel_ms={ms / max(n, 1):.3f} "
           f"stats={ix.screen_stats()}")
 
 
