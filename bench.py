@@ -78,6 +78,29 @@ def profile_counters(kernel: str, shape) -> dict:
     return {"traffic": None, "mfma_util": None, "counters_source": None}
 
 
+def pipeline_traffic(shape, s1_kernel, sample_kernel) -> dict:
+    """Measured HBM bytes one launch of the screened pipeline moves, summed over its kernels (same committed PMC summary as
+    `profile_counters`, same source-hash rule): the scan, its sample pass, the two row-gather launches (exact re-scoring of
+    the screened rows + stage 2) and the small kernels.  None when no matching summary exists."""
+    want = source_hash()
+    per_launch = {s1_kernel: 1, sample_kernel: 1, "mfar_score_rows_f32_kernel": 2, "void mfar_merge_lists_regs_kernel<48>": 1,
+                  "mfar_screen_certify_kernel": 1, "mfar_union_kernel": 1, "mfar_mix_topk_kernel": 1, "void mfar_sample_tau_kernel<16>": 1}
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), reverse=True):
+        try:
+            d = json.load(open(fn))
+        except Exception:
+            continue
+        if d.get("source_hash") != want or tuple(d.get("shape", ())) != tuple(shape):
+            continue
+        ks = d.get("kernels", {})
+        if s1_kernel not in ks:
+            continue
+        parts = {k: m * ks[k]["hbm_bytes_per_launch"] for k, m in per_launch.items() if k in ks and "hbm_bytes_per_launch" in ks[k]}
+        return {"bytes_per_launch": sum(parts.values()), "by_kernel_GB": {k: round(v / 1e9, 3) for k, v in parts.items()},
+                "source": os.path.relpath(fn, ROOT)}
+    return None
+
+
 def s1_kernel_name(dtype, screened, E, wide=False):
     rr = "" if os.environ.get("MFAR_S1_REGRING", "1") == "0" else ("r" if (E // 16) % 6 == 0 else ("r4" if (E // 16) % 4 == 0 else ""))
     if dtype == "bf16" and not screened:
@@ -325,6 +348,13 @@ def main():
                      "for 128 queries) shares HBM with the scan for most of its duration (`alone` = the same kernel by itself).") if screened else None,
             "algorithmic_flops_per_launch": flops_per_launch,
         })
+        pipe = pipeline_traffic((D, F, E, Q, N), s1_kernel, s1_kernel.replace("_kernel", "_sample_kernel")) if (screened and N == 1) else None
+        if pipe:
+            ms_launch = dt / args.steps * 1e3 * ps.coalesce
+            pipe.update({"ms_per_launch": ms_launch, "achieved": pipe["bytes_per_launch"] / (ms_launch * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                         "unit": "GB/s", "frac": pipe["bytes_per_launch"] / (ms_launch * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                         "what": "all kernels of one launch (scan + sample pass + row gathers + selection kernels): measured HBM bytes "
+                                 "from the PMC summary / wall time per launch -- the rate the two streams sustain together"})
         line = {
             "metric": "queries/sec (whole node) at Recall@20 parity, 1M-doc x 8-field x 768d corpus",
             "value": qps, "unit": "queries/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
@@ -353,6 +383,7 @@ def main():
             "recall_at_20": recall20, "ids_checksum": checksum, "index_build_s": t_build, "source_hash": source_hash(),
             "diagnostic_knobs": {"MFAR_S1_DEBUG": "unset", "screen_eps_mult": eps_mult},
             "roofline": roof,
+            "pipeline_hbm": pipe,
             "roofline_exact_fp32": exact_leg,
         }
         if N == 1 and args.dtype == "f32" and args.corpus == "plain" and not args.no_extra_legs:
