@@ -403,29 +403,29 @@ def main():
 def structured_leg(synth, idxmod, PipelinedSearcher, run, dev, E, Q, torch, np):
     """250 k docs x 8 fields with realistic duplicate structure in three of them (mfar/synth.py `structured=True`): what
     the certified screen does when lists are full of bit-identical rows / when row norms are heavy-tailed."""
-    D, F, steps = 250_000, 8, 16
+    D, F, steps = 250_000, 8, 32
     cp = synth.SyntheticCorpus(D, F, E, n_queries=2048, seed=0xDEADBEEF, device=str(dev), structured=True)
     ix = cp.build_index(idxmod)
     ps = PipelinedSearcher(ix, cp.W, torch.ones(F, device=dev), k1=K1, k2=K2, max_batch=Q)
-    run(ps, cp, 0, 3, None)
+    run(ps, cp, 0, 6, None)          # both slots and a coalesced launch each: scratch allocated, screen built
     torch.cuda.synchronize()
     s0 = ix.screen_stats()
     keep = []
     t0 = time.perf_counter()
-    run(ps, cp, 3, steps, keep)
+    run(ps, cp, 6, steps, keep)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     s1 = ix.screen_stats()
     # same bits with the screen off (two batches)
     ix.set_screen(0)
     ex = []
-    run(PipelinedSearcher(ix, cp.W, torch.ones(F, device=dev), k1=K1, k2=K2, max_batch=Q), cp, 3, 2, ex)
+    run(PipelinedSearcher(ix, cp.W, torch.ones(F, device=dev), k1=K1, k2=K2, max_batch=Q), cp, 6, 2, ex)
     torch.cuda.synchronize()
     same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(keep[:2], ex))
     rec = []
     for i, (ids, _, _) in enumerate(keep):
         ids = ids.cpu().numpy()
-        rel = cp.qrels((3 + i) * Q, Q)
+        rel = cp.qrels((6 + i) * Q, Q)
         rec += [len(set(ids[j, :20].tolist()) & rel[j]) / len(rel[j]) for j in range(Q)]
     out = {"docs": D, "fields": F, "field_kinds": cp.field_kinds, "steps": steps, "queries_per_s": steps * Q / dt,
            "unique_rows_per_field": s1.get("unique_rows"),
