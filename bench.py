@@ -404,7 +404,7 @@ def structured_leg(synth, idxmod, PipelinedSearcher, run, dev, E, Q, torch, np):
     """250 k docs x 8 fields with realistic duplicate structure in three of them (mfar/synth.py `structured=True`): what
     the certified screen does when lists are full of bit-identical rows / when row norms are heavy-tailed."""
     D, F, steps = 250_000, 8, 32
-    cp = synth.SyntheticCorpus(D, F, E, n_queries=2048, seed=0xDEADBEEF, device=str(dev), structured=True)
+    cp = synth.SyntheticCorpus(D, F, E, n_queries=4096, seed=0xDEADBEEF, device=str(dev), structured=True)
     ix = cp.build_index(idxmod)
     ps = PipelinedSearcher(ix, cp.W, torch.ones(F, device=dev), k1=K1, k2=K2, max_batch=Q)
     run(ps, cp, 0, 6, None)          # both slots and a coalesced launch each: scratch allocated, screen built
