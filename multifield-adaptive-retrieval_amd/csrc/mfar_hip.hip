@@ -463,7 +463,7 @@ static int check_search_common(const mfar_index* idx, const float* q, int Q, int
 // merge holds n_chunks * k keys of one field, which caps the chunks of a field.
 //   waves   waves per workgroup of the pass (4; 8 for the wide pass): wave blocks published per sampled tile
 //   wgs     workgroups per CU the grid is sized for
-static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool solo, int sample_tiles_max, int waves, int wgs, hipStream_t st) {
+static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool solo, int sample_tiles_max, bool sample_forced, int waves, int wgs, hipStream_t st) {
     if (t.k == k && t.wgs == wgs) return MFAR_OK;
     if (t.k >= 0) HIPCHK(hipDeviceSynchronize());   // a launch in flight may still read the old table
     const int F = idx->F;
@@ -488,10 +488,23 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
     long long n_chunks = 0;
     for (int f = 0; f < F; ++f) n_chunks += cf[f];
     // tiles per workgroup in the sample pass: more tiles = tighter starting thresholds = fewer appends in the full pass, at
-    // the price of reading those tiles twice; at most 1/12 of an average chunk and 2048 published values per (query, field)
-    // (measured: 2 tiles pay off for the HBM-bound 16-bit passes, 1 for the MFMA-bound fp32 pass)
+    // the price of reading those tiles twice; at most 1/12 of an average chunk and 4096 published values per (query, field)
+    // (measured at 1 M x 8: 2 tiles pay off for the HBM-bound 16-bit passes, 1 for the MFMA-bound fp32 pass).
+    // The threshold is the k-th best of the field's sampled rows, so a chunk expects k * (its rows) / (sampled rows of the field)
+    // appends per query: about 85 at 1 M x 8.  Long chunks of many-field shards (1.25 M x 16: 140 tiles per chunk, 32 chunks
+    // per field) would see ~280 with that fixed size -- past the compaction trigger, and every compaction drains the whole
+    // workgroup's prefetch ring (measured there: selection epilogue 1.85 of 6.2 ms) -- so the sample grows until a chunk
+    // expects no more than ~130 appends (MFAR_APPEND_TARGET; measured there: 75 .. 130 within 3 %, stage 1 6.8 -> 5.6 ms).
     static const int sample_div = getenv("MFAR_SAMPLE_DIV") ? atoi(getenv("MFAR_SAMPLE_DIV")) : 12;
-    int sample_tiles = (int)std::max(1LL, std::min<long long>(sample_tiles_max, total_tiles / std::max(1LL, n_chunks) / sample_div));
+    static const int append_target = getenv("MFAR_APPEND_TARGET") ? std::max(1, atoi(getenv("MFAR_APPEND_TARGET"))) : 130;
+    const long long tiles_per_chunk = total_tiles / std::max(1LL, n_chunks);
+    int sample_tiles = (int)std::max(1LL, std::min<long long>(sample_tiles_max, tiles_per_chunk / sample_div));
+    if (!sample_forced) {
+        int min_cf = 1 << 30;
+        for (int f = 0; f < F; ++f) min_cf = std::min(min_cf, cf[f]);
+        const long long want_tiles = ((long long)k * tiles_per_chunk + (long long)append_target * min_cf / 2) / ((long long)append_target * min_cf);
+        sample_tiles = (int)std::max<long long>(sample_tiles, std::min<long long>(want_tiles, std::max(1LL, tiles_per_chunk / sample_div)));
+    }
     // Short chunks (small shards, many fields): the sample yields a threshold only when it publishes at least k values per
     // (query, field) -- 8 per sampled tile -- and a useful one from about 3 k.  Without a threshold every list compacts on
     // nearly every tile.  Spend up to a sixth of a chunk on it.
@@ -627,7 +640,7 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
     const bool solo = nf != idx->F, wide = kind == S1_F16W;
     S1Table& tb = wide ? (solo ? geom.solo_w : geom.all_w) : (solo ? geom.solo : geom.all);
     static const int sample_tiles_env = getenv("MFAR_SAMPLE_TILES") ? atoi(getenv("MFAR_SAMPLE_TILES")) : 0;
-    RETCHK(build_table(idx, geom, tb, k, solo, sample_tiles_env > 0 ? sample_tiles_env : (kind == S1_F32 ? 1 : 2), 4, idx->wgs_per_cu, st));
+    RETCHK(build_table(idx, geom, tb, k, solo, sample_tiles_env > 0 ? sample_tiles_env : (kind == S1_F32 ? 1 : 2), sample_tiles_env > 0, 4, idx->wgs_per_cu, st));
     const int c_lo = tb.fchunk[f0], c_hi = tb.fchunk[f0 + nf];
     RETCHK(sl.lists.ensure((size_t)tb.n_chunks * qw * S1_CAP * sizeof(uint2)));
     RETCHK(sl.list_cnt.ensure((size_t)tb.n_chunks * qw * sizeof(int)));

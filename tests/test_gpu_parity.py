@@ -1024,6 +1024,32 @@ def test_wide_screen_pass_and_coalescing(idxmod):
         ix.close()
 
 
+def test_long_chunks_grow_the_sample(idxmod):
+    """Many fields x long chunks (32 fields share the grid: 16 chunks of ~38 tiles per field): the sample pass grows beyond its
+    2 tiles per chunk so that a chunk expects ~130 appends per query (build_table in csrc/mfar_hip.hip; here 3 tiles, the
+    1.25 M x 16 stress shape takes 6).  Thresholds only prune: wide screened pass == 64-column screened pass == exact fp32 pass."""
+    import torch
+    from mfar import synth
+    D, F, E, Q = 170_000, 32, 64, 128
+    corpus = synth.SyntheticCorpus(D, F, E, n_queries=Q, seed=77, device="cuda:0")
+    ix = corpus.build_index(idxmod)
+    q, W = corpus.queries(0, Q), corpus.W
+    ix.set_screen(2)
+    r = ix.search(q, W, None, return_fields=True)
+    st = ix.screen_stats()
+    assert st["built"] and st["n_checked"] == Q * F and st["n_failed"] == 0, st
+    ix.set_wide(False)
+    r64 = ix.search(q, W, None, return_fields=True)
+    ix.set_wide(True)
+    ix.set_screen(0)
+    r0 = ix.search(q, W, None, return_fields=True)
+    torch.cuda.synchronize()
+    for key in ("ids", "scores", "field_ids", "field_scores", "n_cand"):
+        assert torch.equal(r[key], r64[key]), (key, "wide vs 64")
+        assert torch.equal(r[key], r0[key]), (key, "screened vs exact")
+    ix.close()
+
+
 def test_fused_mode_bit_exact_and_recall(idxmod):
     """mfar_search_fused: the exhaustive top-k of the gate-folded inner product equals the oracle bit for bit (companion of 8
     interleaved row groups, incl. the padding row of an uneven split), follows row updates, and -- the claim it makes against
