@@ -246,7 +246,7 @@ int mfar_set_wgs_per_cu(mfar_index* idx, int wgs);
  * that no other row can enter or tie into the exact top-k; a field whose proof fails is re-done by the exact fp32 pass over
  * the documents on the device (csrc/mfar_screen.h).  The screen slab (at most +50 % HBM) is built lazily by the first search
  * after rows were written.
- *   mode      0 = off, 1 = auto (default; fp32 indexes with >= 16384 rows, k <= 128), 2 = whenever the shapes allow.
+ *   mode      0 = off, 1 = auto (default; fp32 indexes with >= 16384 rows, dim <= 2560, k <= 128), 2 = whenever the shapes allow.
  *             Environment default: MFAR_SCREEN.  A bf16 index is screened only in mode 2 (opt-in: the fp16 copy doubles its
  *             footprint): its lists then equal the exact natural-order fp32 chain over the bf16 rows bit for bit (the plain
  *             bf16 MFMA pass agrees with that chain to 1e-4), and the wide pass applies (1.75x the plain pass's throughput).

@@ -798,6 +798,11 @@ static bool screen_wanted(const mfar_index* idx, int k) {
     if (idx->dtype == MFAR_DTYPE_BF16 && idx->screen_mode < 2) return false;   // bf16 indexes: opt-in (the screen doubles their footprint)
     if (k + SCREEN_EXTRA_MIN > SCREEN_MAX_KP) return false;
     if (idx->E * 4 > 60 * 1024) return false;   // the re-scoring kernel stages a query row in LDS
+    // auto mode stays off for very wide rows: the certificate's fp32-accumulation term (4 E + 66) u32 grows with E while the
+    // relative gap between the k-th and the k'-th score shrinks like 1 / sqrt(E).  Isotropic 300 k x 8 rows: no failed list up
+    // to E = 2048, 2 of 11 264 at 2560, 380 at 3072 -- and ONE failed list sends its whole field through the exact pass, so at
+    // 3072 every launch pays the screen AND the exact pass.  mfar_set_screen(2) still forces the screen.
+    if (idx->screen_mode < 2 && idx->E > 2560) return false;
     return idx->screen_mode >= 2 || idx->n_rows >= 16384;
 }
 

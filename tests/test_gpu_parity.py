@@ -1024,6 +1024,23 @@ def test_wide_screen_pass_and_coalescing(idxmod):
         ix.close()
 
 
+def test_auto_screen_stays_off_for_very_wide_rows(idxmod):
+    """Auto mode (the default) does not screen rows wider than 2560 dims (csrc/mfar_hip.hip screen_wanted: the certificate's
+    accumulation term eats the k..k' margin there and every failure costs an exact pass); mode 2 still does, same bits."""
+    rng = np.random.default_rng(61)
+    F, D, E, Q = 1, 16500, 2592, 70
+    slab, q, W = _mk(rng, F, D, E, Q)
+    ix = _load(idxmod, slab)
+    r = ix.search(q, W, None, return_fields=True)
+    assert not ix.screen_stats()["built"] and ix.max_split_batch(100) == 64
+    ix.set_screen(2)
+    r2 = ix.search(q, W, None, return_fields=True)
+    assert ix.screen_stats()["built"] and ix.max_split_batch(100) == 128
+    for key in ("ids", "scores", "field_ids", "field_scores", "n_cand"):
+        assert np.array_equal(np.asarray(r[key]).view(np.uint8), np.asarray(r2[key]).view(np.uint8)), key
+    ix.close()
+
+
 def test_long_chunks_grow_the_sample(idxmod):
     """Many fields x long chunks (32 fields share the grid: 16 chunks of ~38 tiles per field): the sample pass grows beyond its
     2 tiles per chunk so that a chunk expects ~130 appends per query (build_table in csrc/mfar_hip.hip; here 3 tiles, the
