@@ -133,6 +133,7 @@ struct mfar_index {
     // unique rows of every field (mfar_screen.h), each table [F][n_rows] (stride n_rows): representative document of a
     // unique row, start / length of its member run in `members` (local rows grouped by unique row, ascending inside a group)
     DevBuf u_rep, u_start, u_count, u_members, u_n;
+    DevBuf u_repof;               // [F][n_rows] representative of every row's group (stage 2 gathers it in the row's place); optional
     std::vector<int> n_unique, largest_group;   // per field (host copies)
     bool screen_dedup = true;     // MFAR_SCREEN_DEDUP=0: every document is its own unique row (diagnostic)
     bool wide = true;             // blocks of 65 .. 128 queries go through the wide screened pass (MFAR_WIDE=0: always 64 per pass)
@@ -267,7 +268,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
     DevBuf* bufs[] = {&idx->fid, &idx->fsc, &idx->cand[0], &idx->cand[1], &idx->ncand[0], &idx->ncand[1], &idx->x[0], &idx->x[1],
                       &idx->own[0], &idx->own[1], &idx->s_stats, &idx->s_field, &idx->s_mean, &idx->screen, &idx->u_rep, &idx->u_start,
-                      &idx->u_count, &idx->u_members, &idx->u_n};
+                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof};
     for (S1Geom* g : {&idx->geom_docs, &idx->geom_screen})
         for (S1Table* t : {&g->all, &g->solo, &g->all_w, &g->solo_w}) {
             t->d_chunks.release();
@@ -478,48 +479,78 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
     std::vector<int> cf(F);
     const int l2cap = std::max(1, std::min(cap, 8192 / k));   // lists the second level merges per field (register-resident keys)
     t.two_level = false;
+    // SMALL FIELDS (low-cardinality fields collapse to a few unique rows: STaRK-prime `type` has ten texts).  The threshold of a
+    // field is the k-th best of the values its sample publishes, 8 per sampled tile; a field that cannot publish k values even
+    // when sampled whole has NO threshold, and then every row of a tile survives into the lists (measured: 0.235 ms per tile and
+    // workgroup in the wide pass against ~0.03 ms with a threshold).  One workgroup walking such a field tile after tile held
+    // up the whole launch (structured 1 M x 8 corpus, 6 tiles of a ten-text field in one chunk: scan 4.3 ms instead of 1.7).
+    //   * a field without a possible threshold is cut into one-tile chunks (its cost is then bounded by one tile);
+    //   * any field gets enough chunks to sample min(its tiles, tiles that publish 3 k values) at <= 4 tiles per chunk, so its
+    //     sample workgroups stay as short as everybody's; the whole of such a field may be sampled (its bytes do not matter).
+    // The chunks these rules add are taken from the largest fields, so the grid stays one wave of workgroups.
+    const long long need_tiles = (3LL * k + 7) / 8;            // sampled tiles that publish 3 k values
+    std::vector<int> floor_cf(F, 0);                           // > 0: the field was cut by one of the two rules
+    {
+        std::vector<long long> want_cf(F);
+        long long extra = 0, spare = 0;
+        for (int f = 0; f < F; ++f) {
+            const long long tiles = std::max(1, g.n_tiles[f]);
+            const long long lim = std::min<long long>((long long)cap * l2cap, tiles);
+            long long c = solo ? want : (want * g.n_tiles[f] + total_tiles / 2) / std::max(1LL, total_tiles);
+            c = std::max(1LL, std::min(c, lim));
+            const long long fl = std::max(1LL, std::min(8 * tiles < k ? tiles : (std::min(tiles, need_tiles) + 3) / 4, lim));
+            cf[f] = (int)c;
+            want_cf[f] = fl;
+            if (fl > c) extra += fl - c;
+            else spare += c - fl;
+        }
+        // the extra chunks come out of the fields that have more than their own floor; when nobody has (many equal fields),
+        // only the fields without a possible threshold are cut (they must be) and the grid grows by those few workgroups
+        for (int f = 0; f < F; ++f) {
+            const bool hard = 8LL * std::max(1, g.n_tiles[f]) < k;
+            if (want_cf[f] > cf[f] && (hard || solo || spare >= extra)) {
+                cf[f] = (int)want_cf[f];
+                floor_cf[f] = cf[f];
+            }
+        }
+        if (!solo && extra > 0 && spare >= extra)
+            for (int f = 0; f < F; ++f)
+                if (!floor_cf[f] && cf[f] > want_cf[f]) cf[f] -= (int)(((cf[f] - want_cf[f]) * extra + spare - 1) / spare);
+    }
+    long long n_chunks = 0;
     for (int f = 0; f < F; ++f) {
-        long long c = solo ? want : (want * g.n_tiles[f] + total_tiles / 2) / std::max(1LL, total_tiles);
-        c = std::max(1LL, std::min<long long>(c, std::min<long long>((long long)cap * l2cap, std::max(1, g.n_tiles[f]))));
-        cf[f] = (int)c;
+        n_chunks += cf[f];
         if (cf[f] > cap) t.two_level = true;
         t.max_chunks = std::max(t.max_chunks, cf[f]);
     }
-    long long n_chunks = 0;
-    for (int f = 0; f < F; ++f) n_chunks += cf[f];
-    // tiles per workgroup in the sample pass: more tiles = tighter starting thresholds = fewer appends in the full pass, at
-    // the price of reading those tiles twice; at most 1/12 of an average chunk and 4096 published values per (query, field)
+    // tiles per workgroup in the sample pass, per field: more tiles = tighter starting thresholds = fewer appends in the full
+    // pass, at the price of reading those tiles twice; at most 1/12 of a chunk and 4096 published values per (query, field)
     // (measured at 1 M x 8: 2 tiles pay off for the HBM-bound 16-bit passes, 1 for the MFMA-bound fp32 pass).
     // The threshold is the k-th best of the field's sampled rows, so a chunk expects k * (its rows) / (sampled rows of the field)
     // appends per query: about 85 at 1 M x 8.  Long chunks of many-field shards (1.25 M x 16: 140 tiles per chunk, 32 chunks
     // per field) would see ~280 with that fixed size -- past the compaction trigger, and every compaction drains the whole
     // workgroup's prefetch ring (measured there: selection epilogue 1.85 of 6.2 ms) -- so the sample grows until a chunk
     // expects no more than ~130 appends (MFAR_APPEND_TARGET; measured there: 75 .. 130 within 3 %, stage 1 6.8 -> 5.6 ms).
+    // Short chunks (small shards, many fields) and the small fields above: the sample yields a threshold only when it
+    // publishes at least k values per (query, field) and a useful one from about 3 k; without a threshold every list compacts
+    // on nearly every tile.  Spend up to a sixth of a chunk on it -- the whole chunk in a field that was cut for this.
     static const int sample_div = getenv("MFAR_SAMPLE_DIV") ? atoi(getenv("MFAR_SAMPLE_DIV")) : 12;
     static const int append_target = getenv("MFAR_APPEND_TARGET") ? std::max(1, atoi(getenv("MFAR_APPEND_TARGET"))) : 130;
-    const long long tiles_per_chunk = total_tiles / std::max(1LL, n_chunks);
-    int sample_tiles = (int)std::max(1LL, std::min<long long>(sample_tiles_max, tiles_per_chunk / sample_div));
-    if (!sample_forced) {
-        int min_cf = 1 << 30;
-        for (int f = 0; f < F; ++f) min_cf = std::min(min_cf, cf[f]);
-        const long long want_tiles = ((long long)k * tiles_per_chunk + (long long)append_target * min_cf / 2) / ((long long)append_target * min_cf);
-        sample_tiles = (int)std::max<long long>(sample_tiles, std::min<long long>(want_tiles, std::max(1LL, tiles_per_chunk / sample_div)));
-    }
-    // Short chunks (small shards, many fields): the sample yields a threshold only when it publishes at least k values per
-    // (query, field) -- 8 per sampled tile -- and a useful one from about 3 k.  Without a threshold every list compacts on
-    // nearly every tile.  Spend up to a sixth of a chunk on it.
-    {
-        int min_cf = 1 << 30;
-        long long min_tiles_per_chunk = 1LL << 40;
-        for (int f = 0; f < F; ++f) {
-            min_cf = std::min(min_cf, cf[f]);
-            min_tiles_per_chunk = std::min<long long>(min_tiles_per_chunk, g.n_tiles[f] / std::max(1, cf[f]));
+    std::vector<int> ns(F, 1);
+    t.sample_tiles = 1;
+    for (int f = 0; f < F; ++f) {
+        const long long tpc = std::max(1LL, (long long)g.n_tiles[f] / cf[f]);      // tiles of the field's shortest chunk
+        long long v = std::max(1LL, std::min<long long>(sample_tiles_max, tpc / sample_div));
+        if (!sample_forced) {
+            const long long want_tiles = ((long long)k * tpc + (long long)append_target * cf[f] / 2) / ((long long)append_target * cf[f]);
+            v = std::max(v, std::min(want_tiles, std::max(1LL, tpc / sample_div)));
+            const long long st_cap = cf[f] == floor_cf[f] ? tpc : std::max(1LL, tpc / 6);
+            while (v < st_cap && 2LL * waves * cf[f] * v < 3LL * k) ++v;
         }
-        const int st_cap = (int)std::max(1LL, min_tiles_per_chunk / 6);
-        while (sample_tiles < st_cap && 2LL * waves * min_cf * sample_tiles < 3LL * k) ++sample_tiles;
+        while (v > 1 && 2LL * waves * cf[f] * v > 4096) --v;
+        ns[f] = (int)v;
+        t.sample_tiles = std::max(t.sample_tiles, ns[f]);
     }
-    while (sample_tiles > 1 && 2 * waves * t.max_chunks * sample_tiles > 4096) --sample_tiles;
-    t.sample_tiles = sample_tiles;
     t.samp_stride = 0;
     for (int f = 0; f < F; ++f) {
         t.fchunk[f] = (int)t.chunks.size();
@@ -532,7 +563,8 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
             ck.n_rows = (int)g.n_rows[f];
             ck.base = g.base[f];
             ck.tl0 = tl;
-            tl += std::min(sample_tiles, ck.t1 - ck.t0);
+            ck.ns = std::max(1, std::min(ns[f], ck.t1 - ck.t0));
+            tl += std::min(ck.ns, ck.t1 - ck.t0);
             t.chunks.push_back(ck);
         }
         t.samp_n[f] = waves * tl;
@@ -806,13 +838,14 @@ static bool screen_wanted(const mfar_index* idx, int k) {
     return idx->screen_mode >= 2 || idx->n_rows >= 16384;
 }
 
-__global__ void mfar_iota_kernel(int* __restrict__ a, int* __restrict__ b, int* __restrict__ c, int* __restrict__ d, long long n) {
+__global__ void mfar_iota_kernel(int* __restrict__ a, int* __restrict__ b, int* __restrict__ c, int* __restrict__ d, int* __restrict__ e, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         a[i] = (int)i;   // urep
         b[i] = (int)i;   // ustart
         c[i] = 1;        // ucount
         d[i] = (int)i;   // members
+        if (e) e[i] = (int)i;   // repof
     }
 }
 
@@ -823,9 +856,10 @@ static int build_unique_rows(mfar_index* idx, int f, const float* field, DevBuf*
     int* ustart = idx->u_start.as<int>() + (size_t)f * n;
     int* ucount = idx->u_count.as<int>() + (size_t)f * n;
     int* members = idx->u_members.as<int>() + (size_t)f * n;
+    int* repof = idx->u_repof.p ? idx->u_repof.as<int>() + (size_t)f * n : nullptr;
     if (!idx->screen_dedup || n < 2) {
         if (n > 0) {
-            mfar_iota_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(urep, ustart, ucount, members, n);
+            mfar_iota_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(urep, ustart, ucount, members, repof, n);
             HIPCHK(hipGetLastError());
         }
         *n_unique_out = (int)n;
@@ -864,6 +898,10 @@ static int build_unique_rows(mfar_index* idx, int f, const float* field, DevBuf*
     HIPCHK(hipStreamSynchronize(st));
     mfar_unique_table_kernel<<<dim3((n_groups + 255) / 256), dim3(256), 0, st>>>(n, (int)n_groups, gstart, v_out, urank, urep, ustart, ucount);
     HIPCHK(hipGetLastError());
+    if (repof) {
+        mfar_rep_of_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n, gid, gstart, v_out, repof);
+        HIPCHK(hipGetLastError());
+    }
     // largest group (statistics only)
     cap = tmp[8].cap;
     int* d_max = (int*)tmp[3].p;
@@ -900,6 +938,11 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
         idx->u_count.ensure((size_t)F * n * 4) != MFAR_OK || idx->u_members.ensure((size_t)F * n * 4) != MFAR_OK ||
         idx->u_n.ensure((size_t)F * 4) != MFAR_OK)
         return nomem();
+    if (idx->u_repof.ensure((size_t)F * n * 4) != MFAR_OK) {   // optional: without it stage 2 gathers every row itself
+        (void)hipGetLastError();
+        g_err.clear();
+        idx->u_repof.release();
+    }
     RETCHK(idx->s_stats.ensure((size_t)F * 2 * sizeof(u32)));
     RETCHK(idx->s_field.ensure((size_t)F * sizeof(ScreenField)));
     RETCHK(idx->s_mean.ensure((size_t)F * idx->E * sizeof(float)));
@@ -1312,6 +1355,11 @@ static int run_score(mfar_index* idx, const float* q, int Q, const long long* ca
     p.E = idx->E;
     p.F = idx->F;
     p.C = C;
+    static const bool use_rep = !(getenv("MFAR_STAGE2_REP") && atoi(getenv("MFAR_STAGE2_REP")) == 0);   // diagnostic: 0 = gather every row itself
+    if (use_rep && idx->screen.p && !idx->screen_dirty && idx->u_repof.p) {   // the unique-row tables describe the rows as they are now
+        p.repof = idx->u_repof.as<int>();
+        p.ustride = idx->n_rows;
+    }
     const unsigned gx = (unsigned)(((size_t)C * idx->F + 255) / 256), gf = (unsigned)(((size_t)C * idx->F + SCF_THREADS - 1) / SCF_THREADS);
     if (gx == 0 || Q == 0) return MFAR_OK;
     if (idx->dtype == MFAR_DTYPE_BF16) mfar_score_candidates_kernel<1><<<dim3(gx, Q), dim3(256), SCORE_LDS_BYTES(idx->E), st>>>(p);

@@ -274,6 +274,16 @@ __global__ void __launch_bounds__(256) mfar_unique_table_kernel(long long n, int
     ucount[u] = e - s;
 }
 
+// repof[row] = the representative (lowest row) of row's group of bit-identical rows.  Stage 2 gathers the representative
+// instead of the row itself (same bits): the rows a low-cardinality field repeats over the corpus -- the empty-string vector
+// of a field most documents lack -- then come from the caches instead of HBM.  grid = ceil(n / 256), block 256.
+__global__ void __launch_bounds__(256) mfar_rep_of_kernel(long long n, const u32* __restrict__ gid, const int* __restrict__ gstart,
+                                                          const u32* __restrict__ vals, int* __restrict__ repof) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    repof[vals[i]] = (int)vals[gstart[gid[i] - 1]];
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Queries of one block of qw = 64 or 128 queries: per-query scale + norm, the fp16 tiles, and per (field, query): eps (real
 // units) and the starting threshold of the screened pass (scaled units).

@@ -442,6 +442,9 @@ struct ScoreParams {
     const int* nuniq;        // [F]
     long long ustride;
     int f0;                  // per_field mode: list (q, j) belongs to field f0 + j (F = number of fields in this launch)
+    // all-fields mode: repof[f * ustride + local row] = representative of the row's group of bit-identical rows (mfar_screen.h),
+    // gathered in its place; nullptr: every row is gathered itself
+    const int* repof;
 };
 // Each wave owns 64 (candidate, field) rows, one per lane, gathers their segments cooperatively by LDS-DMA into a private
 // two-slot LDS ring, and every lane then walks ITS row's segment from LDS in chain order.  No barriers: the ring is private
@@ -495,6 +498,7 @@ __global__ void __launch_bounds__(256) mfar_score_candidates_kernel(const ScoreP
             else id -= p.row_offset;
             if (id >= 0 && id < p.n_rows) {
                 valid = true;
+                if (p.repof && !p.per_field) id = p.repof[(size_t)f * p.ustride + id];
                 rr = (int)(id & 63);
                 rowbase = (const char*)p.slab + ((size_t)f * p.field_stride + (size_t)(id >> 6) * p.n_steps * 1024) * (DT ? 2 : 4) + rr * SEG;
             }
@@ -605,6 +609,7 @@ __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_f32_kernel(const 
             else id -= p.row_offset;
             if (id >= 0 && id < p.n_rows) {
                 valid = true;
+                if (p.repof && !p.per_field) id = p.repof[(size_t)f * p.ustride + id];
                 rr = (int)(id & 63);
                 rowbase = (const char*)p.slab + ((size_t)f * p.field_stride + (size_t)(id >> 6) * p.n_steps * 1024) * 4 + rr * 128;
             }

@@ -64,7 +64,7 @@ struct S1Chunk {
     int n_rows;             // valid rows of the field (rows beyond are zero padding)
     long long base;         // element offset of the field's first tile inside the slab
     int tl0;                // index of this chunk's first tile among the SAMPLED tiles of its field (sample pass output slot)
-    int pad;
+    int ns;                 // tiles of this chunk the light sample pass scans (>= 1; per field: small fields are sampled deeper)
 };
 
 struct S1Params {
@@ -83,7 +83,7 @@ struct S1Params {
     const float* gtau;      // [F, qw] non-strict lower bounds from the sample pass, or nullptr
     int sample;             // 1/2: threshold-estimation pass, every workgroup scans only the first tile of its chunk;
                             //      2 = light form: no lists, every wave publishes the 2 best scores per query of its 64 rows
-    int sample_tiles;       // tiles per workgroup scanned by the sample pass (>= 1, <= tiles of the shortest chunk)
+    int sample_tiles;       // tiles per workgroup scanned by the list-building sample pass (sample == 1); the light pass uses S1Chunk::ns
     float* samp_out;        // [F][samp_stride wave blocks][qw][2] (sample == 2): wave block = (sampled tile of the field, wave)
     int samp_stride;        // wave blocks reserved per field
     const int* only_failed; // [F] or nullptr: workgroups of fields whose flag is 0 exit at once (screen fall-back pass)
@@ -407,7 +407,7 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
     if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
     const int t0 = ck.t0;
     int t1 = ck.t1;
-    if (p.sample) t1 = min(t1, t0 + p.sample_tiles);
+    if (p.sample) t1 = min(t1, t0 + (p.sample == 2 ? ck.ns : p.sample_tiles));
     const size_t wgq0 = (size_t)chunk_id * p.qw;
     s1_state_init(st, p, f);
 
@@ -552,7 +552,7 @@ __device__ __forceinline__ void s1_body_x16(const S1Params& p) {
     if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
     const int t0 = ck.t0;
     int t1 = ck.t1;
-    if (p.sample) t1 = min(t1, t0 + p.sample_tiles);
+    if (p.sample) t1 = min(t1, t0 + (p.sample == 2 ? ck.ns : p.sample_tiles));
     const size_t wgq0 = (size_t)chunk_id * p.qw;
     s1_state_init(st, p, f);
 
@@ -697,7 +697,7 @@ __device__ __forceinline__ void s1_body_x16r(const S1Params& p) {
     if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
     const int t0 = ck.t0;
     int t1 = ck.t1;
-    if (p.sample) t1 = min(t1, t0 + p.sample_tiles);
+    if (p.sample) t1 = min(t1, t0 + (p.sample == 2 ? ck.ns : p.sample_tiles));
     const size_t wgq0 = (size_t)chunk_id * p.qw;
     s1_state_init(st, p, f);
 
@@ -845,7 +845,7 @@ __device__ __forceinline__ void s1_body_f16w(const S1Params& p) {
     if (p.only_failed && !p.only_failed[f]) return;
     const int t0 = ck.t0;
     int t1 = ck.t1;
-    if (p.sample) t1 = min(t1, t0 + p.sample_tiles);
+    if (p.sample) t1 = min(t1, t0 + (p.sample == 2 ? ck.ns : p.sample_tiles));
     const size_t wgq0 = (size_t)chunk_id * p.qw;      // qw == 128
     s1_state_init(stA, p, f, 0);
     s1_state_init(stB, p, f, 64);

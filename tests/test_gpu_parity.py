@@ -728,6 +728,37 @@ def test_screen_follows_row_updates(idxmod):
     ix.close()
 
 
+def test_stage2_gathers_group_representatives(idxmod):
+    """Stage 2 reads a row's group representative instead of the row (bit-identical by construction, csrc/mfar_screen.h
+    mfar_rep_of_kernel): same bits as the oracle on a corpus full of duplicate groups; the map is ignored as soon as a row
+    is rewritten (a former duplicate that now differs must be scored from its own bytes) and rebuilt by the next search."""
+    rng = np.random.default_rng(16)
+    F, D, E, Q = 3, 20000, 96, 40
+    slab, q, W = _mk(rng, F, D, E, Q)
+    slab[0, 1000:] = slab[0, rng.integers(0, 1000, D - 1000)]          # field 0: 1000 distinct vectors over 20000 rows
+    slab[1, ::2] = slab[1, 0]                                          # field 1: every other row is one vector
+    ix = _load(idxmod, slab)
+    o = O.c_two_stage(slab, q, W, None)
+    r = ix.search(q, W, None, return_fields=True)
+    assert ix.screen_stats()["built"]
+    assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32))
+    cand = np.tile(np.arange(0, 64, dtype=np.int64), (Q, 1))           # rows 0, 2, 4 .. of field 1 are duplicates of row 0
+    x0 = np.asarray(ix.score_candidates(q, cand))
+    ref = O.c_score_candidates(slab, q, cand)
+    assert np.array_equal(x0.view(np.uint32), ref.view(np.uint32))
+    slab[1, 4] = q[0] * 3.0                                            # a former duplicate changes
+    ix.write_rows(1, 4, slab[1, 4:5])
+    x1 = np.asarray(ix.score_candidates(q, cand))                      # tables are stale now: every row from its own bytes
+    ref = O.c_score_candidates(slab, q, cand)
+    assert np.array_equal(x1.view(np.uint32), ref.view(np.uint32)) and not np.array_equal(x1, x0)
+    o = O.c_two_stage(slab, q, W, None)
+    r = ix.search(q, W, None)                                          # rebuilds the tables
+    assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32))
+    x2 = np.asarray(ix.score_candidates(q, cand))
+    assert np.array_equal(x2.view(np.uint32), ref.view(np.uint32))
+    ix.close()
+
+
 def test_pipelined_searcher_with_screen_and_redo(idxmod):
     """The split-phase pipeline over a screened index: certified batches flow through; with an impossible proof
     (eps_mult = 1e9) every batch reports a failed certificate and result() redoes it exactly -- same bits either way."""
