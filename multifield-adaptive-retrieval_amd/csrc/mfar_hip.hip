@@ -516,6 +516,29 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
         if (!solo && extra > 0 && spare >= extra)
             for (int f = 0; f < F; ++f)
                 if (!floor_cf[f] && cf[f] > want_cf[f]) cf[f] -= (int)(((cf[f] - want_cf[f]) * extra + spare - 1) / spare);
+        // exactly one wave of workgroups where the rules allow it: a grid of a few workgroups more leaves them waiting for the
+        // first to finish (a mid-size field's short chunks finish early: 515 workgroups, scan 2.36 ms instead of 1.85), a few
+        // less idles CUs.  The field with the longest chunks gives / the one with the shortest... takes: by tiles per chunk.
+        if (!solo) {
+            long long sum = 0;
+            for (int f = 0; f < F; ++f) sum += cf[f];
+            for (; sum != want; sum += sum < want ? 1 : -1) {
+                int best = -1;
+                double key = 0.0;
+                for (int f = 0; f < F; ++f) {
+                    const long long tiles = std::max(1, g.n_tiles[f]);
+                    const long long lim = std::min<long long>((long long)cap * l2cap, tiles);
+                    const double tpc = (double)tiles / cf[f];
+                    if (sum < want ? (cf[f] < lim && !floor_cf[f] && (best < 0 || tpc > key))
+                                   : (cf[f] > std::max<long long>(1, want_cf[f]) && !floor_cf[f] && (best < 0 || tpc < key))) {
+                        best = f;
+                        key = tpc;
+                    }
+                }
+                if (best < 0) break;
+                cf[best] += sum < want ? 1 : -1;
+            }
+        }
     }
     long long n_chunks = 0;
     for (int f = 0; f < F; ++f) {
