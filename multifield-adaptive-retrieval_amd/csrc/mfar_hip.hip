@@ -79,6 +79,7 @@ struct S1Table {
     std::vector<int> fchunk, samp_n;  // [F + 1], [F]
     int n_chunks = 0, max_chunks = 0, samp_stride = 0, sample_tiles = 1;
     long long total_tiles = 0;
+    long long thresholded_tiles = 0;  // tiles of the fields whose sample publishes at least k values (= yields a threshold)
     DevBuf d_chunks, d_fchunk, d_samp_n;
     // two-level merge: a field cut into more chunks than one merge workgroup can hold (few fields, or a single-field pass)
     // is merged in GROUPS of consecutive chunks first (mfar_select.h MergeParams)
@@ -518,7 +519,7 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
                 if (!floor_cf[f] && cf[f] > want_cf[f]) cf[f] -= (int)(((cf[f] - want_cf[f]) * extra + spare - 1) / spare);
         // exactly one wave of workgroups where the rules allow it: a grid of a few workgroups more leaves them waiting for the
         // first to finish (a mid-size field's short chunks finish early: 515 workgroups, scan 2.36 ms instead of 1.85), a few
-        // less idles CUs.  The field with the longest chunks gives / the one with the shortest... takes: by tiles per chunk.
+        // less idles CUs.  Short of a wave: the field with the longest chunks gets one more; over: the field with the shortest gives one up.
         if (!solo) {
             long long sum = 0;
             for (int f = 0; f < F; ++f) sum += cf[f];
@@ -563,18 +564,23 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
     t.sample_tiles = 1;
     for (int f = 0; f < F; ++f) {
         const long long tpc = std::max(1LL, (long long)g.n_tiles[f] / cf[f]);      // tiles of the field's shortest chunk
+        const long long tpc_hi = std::max(1LL, ((long long)g.n_tiles[f] + cf[f] - 1) / cf[f]);   // ... of its longest
         long long v = std::max(1LL, std::min<long long>(sample_tiles_max, tpc / sample_div));
         if (!sample_forced) {
             const long long want_tiles = ((long long)k * tpc + (long long)append_target * cf[f] / 2) / ((long long)append_target * cf[f]);
             v = std::max(v, std::min(want_tiles, std::max(1LL, tpc / sample_div)));
             const long long st_cap = cf[f] == floor_cf[f] ? tpc : std::max(1LL, tpc / 6);
             while (v < st_cap && 2LL * waves * cf[f] * v < 3LL * k) ++v;
+            // no threshold at all (fewer than k values) costs 8 x a normal tile in the full pass: rather sample short chunks whole
+            // (90 % empty 129 k x 22: 56 tiles per field in 23 chunks, 184 values from one tile each -- stage 1 1.34 ms)
+            while (v < tpc_hi && 2LL * waves * std::min<long long>(g.n_tiles[f], cf[f] * v) < (long long)k) ++v;
         }
         while (v > 1 && 2LL * waves * cf[f] * v > 4096) --v;
         ns[f] = (int)v;
         t.sample_tiles = std::max(t.sample_tiles, ns[f]);
     }
     t.samp_stride = 0;
+    t.thresholded_tiles = 0;
     for (int f = 0; f < F; ++f) {
         t.fchunk[f] = (int)t.chunks.size();
         int tl = 0;
@@ -591,6 +597,7 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
             t.chunks.push_back(ck);
         }
         t.samp_n[f] = waves * tl;
+        if (2LL * waves * tl >= k) t.thresholded_tiles += g.n_tiles[f];
         t.samp_stride = std::max(t.samp_stride, waves * tl);
     }
     t.fchunk[F] = (int)t.chunks.size();
@@ -760,7 +767,10 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
     // (non-strict) lower bound of the final k-th best, so the full pass starts with a tight threshold and appends /
     // compacts almost nothing.  Worth it once the chunks are much longer than one tile.
     static const int sample_min_tiles = getenv("MFAR_SAMPLE_MIN_TILES") ? atoi(getenv("MFAR_SAMPLE_MIN_TILES")) : 3;
-    const bool use_sample = tb.total_tiles >= (long long)sample_min_tiles * tb.n_chunks && !(p.dbg & 2) && !only_failed;
+    // ... or, with short chunks, whenever it yields thresholds for most of the rows: a tile without one costs 8 x a normal tile in
+    // the full pass (90 % empty 129 k x 22: 2.4 tiles per chunk, scan 0.85 ms without the sample pass)
+    const bool use_sample = (tb.total_tiles >= (long long)sample_min_tiles * tb.n_chunks || 2 * tb.thresholded_tiles >= tb.total_tiles) &&
+                            !(p.dbg & 2) && !only_failed;
     const bool light_sample = use_sample && 2 * tb.samp_stride <= 4096;
     p.sample_tiles = light_sample ? tb.sample_tiles : 1;
     if (light_sample) {
