@@ -126,6 +126,9 @@ def main():
                          "on = also a bf16 index (doubles its footprint)")
     ap.add_argument("--corpus", choices=["plain", "structured"], default="plain",
                     help="structured: realistic duplicate / norm structure in three of the fields (mfar/synth.py)")
+    ap.add_argument("--empty-frac", type=float, default=0.08,
+                    help="share of (document, field) pairs that hold the field's empty-text vector (real STaRK fields are sparse; "
+                         "0.08 = the headline corpus)")
     ap.add_argument("--coalesce", type=int, default=0, help="batches scanned per launch (0 = auto: 2 when the wide screened pass is available)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the exact-fp32 leg and the structured-corpus leg")
@@ -190,7 +193,7 @@ def main():
     n_q_total = max(Q, min(max(4096, (args.steps + args.warmup) * Q), 65536, D // 16))
     t_build = time.time()
     corpus = synth.SyntheticCorpus(D, F, E, n_queries=n_q_total, seed=0xDEADBEEF, device=str(dev),
-                                   structured=(args.corpus == "structured"))
+                                   structured=(args.corpus == "structured"), empty_frac=args.empty_frac)
     row0, row1 = D * rank // N, D * (rank + 1) // N          # contrastive.py:470
     ix = corpus.build_index(idxmod, row0=row0, n=row1 - row0, dtype=args.dtype)
     if args.wgs_per_cu:
@@ -362,7 +365,7 @@ def main():
             "dtype": ("f32" if args.dtype == "f32" else
                       ("bf16 docs, fp32 queries; lists and scores = the exact fp32 chain over the bf16 docs (certified fp16 screen)" if screened
                        else "bf16 docs x fp32 queries (3 exact bf16 terms), fp32 accumulate")), "data": "synthetic",
-            "config": {"workload": f"synthetic STaRK-amazon-shaped corpus ({args.corpus}), {D} docs x {F} dense fields x {E}d {args.dtype}, "
+            "config": {"workload": f"synthetic STaRK-amazon-shaped corpus ({args.corpus}" + (f", {args.empty_frac:g} of the field vectors empty" if args.empty_frac != 0.08 else "") + f"), {D} docs x {F} dense fields x {E}d {args.dtype}, "
                                    f"row-sharded over {N} GPU(s); two-stage scorer k1=k2=100, zero-sentinel mode",
                        "docs": D, "fields": F, "dim": E, "query_batch": Q, "k1": K1, "k2": K2, "timed_queries": args.steps * Q,
                        "parallelism": (f"row-shard x{N}, lists-first exchange over RCCL (per batch: all-gather of the stage-1 lists, "

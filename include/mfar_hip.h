@@ -226,6 +226,17 @@ int mfar_stage1_begin(mfar_index* idx, const float* q, int Q, int k, int sentine
  */
 int mfar_max_split_batch(mfar_index* idx, int k);
 int mfar_set_wide(mfar_index* idx, int enable);
+/*
+ * How the exact pass REPAIRS fields whose certificate failed (the entry points that repair on the device launch it behind
+ * every screened block; it is idle when nothing failed).
+ *   fine = 0 (default)  the fields keep their share of one wave of workgroups: an idle repair costs two short launches, but a
+ *                       single failed field is scanned by its share of the GPU only (1 M x 8: several ms);
+ *   fine = 1            every field is cut into up to a whole wave of chunks, walked by one wave of workgroups, with its own
+ *                       sample pass: a failed field is scanned by the whole GPU (under 1 ms there), an idle repair costs five
+ *                       launches (+0.15 ms per 64 queries).  For callers that only ask for repairs after a failure was
+ *                       reported (mfar.data.pipeline.PipelinedSearcher sets it).
+ */
+int mfar_set_repair_mode(mfar_index* idx, int fine);
 int mfar_stage1_finish(mfar_index* idx, const float* q, int Q, int k, int sentinel, int slot, int64_t* field_ids,
                        float* field_scores, int32_t* any_fail, void* stream);
 

@@ -74,6 +74,8 @@ struct S1Params {
     int* list_cnt;          // [n_chunks * 64]
     const S1Chunk* chunks;  // [n_chunks] chunk table of the scanned slab
     int chunk0;             // first chunk of this launch (grid = a contiguous chunk range: all fields, or one field)
+    int n_launch;           // chunks of this launch: workgroup b scans chunks chunk0 + b, chunk0 + b + gridDim.x, ... (grid == n_launch
+                            // except for a repair pass, whose finely cut table is walked by one wave of workgroups)
     int n_steps;            // E / 16
     int Q;                  // valid queries (<= qw)
     int qw;                 // query columns of the pass: 64, or 128 for the wide fp16 screen pass (mfar_stage1_f16w_kernel);
@@ -141,6 +143,22 @@ __device__ __forceinline__ float s1_compact(uint2* list, int n, int k) {
         base += __popcll(m);
     }
     return ord2f(T);
+}
+
+// The chunk descriptor of a workgroup, in scalar registers (inside the chunk loop of a repair pass hipcc fetches it with vector
+// loads; the tile loop bounds and the slab base must not end up in VGPRs)
+__device__ __forceinline__ S1Chunk s1_load_chunk(const S1Params& p, int chunk_id) {
+    S1Chunk c = p.chunks[chunk_id];
+    c.f = __builtin_amdgcn_readfirstlane(c.f);
+    c.t0 = __builtin_amdgcn_readfirstlane(c.t0);
+    c.t1 = __builtin_amdgcn_readfirstlane(c.t1);
+    c.n_rows = __builtin_amdgcn_readfirstlane(c.n_rows);
+    c.tl0 = __builtin_amdgcn_readfirstlane(c.tl0);
+    c.ns = __builtin_amdgcn_readfirstlane(c.ns);
+    const unsigned long long b = (unsigned long long)c.base;
+    c.base = (long long)(((unsigned long long)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(b >> 32)) << 32) |
+                         (u32)__builtin_amdgcn_readfirstlane((int)(u32)b));
+    return c;
 }
 
 // A score survives when it beats the workgroup's own running k-th best (strict: later rows lose ties to earlier
@@ -391,7 +409,7 @@ __device__ __forceinline__ void s1_flush(const S1Params& p, const S1State& st, i
 // ---------------------------------------------------------------------------------------------------------------------
 // fp32 slab
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void s1_body_f32(const S1Params& p) {
+__device__ __forceinline__ void s1_body_f32(const S1Params& p, const int chunk_id) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const qring = smem + S1_D_BYTES;
     const S1State st = s1_state(smem + S1_D_BYTES + S1_Q_BYTES);
@@ -401,8 +419,7 @@ __device__ __forceinline__ void s1_body_f32(const S1Params& p) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
 
-    const int chunk_id = p.chunk0 + (int)blockIdx.x;
-    const S1Chunk ck = p.chunks[chunk_id];            // workgroup-uniform (scalar loads)
+    const S1Chunk ck = s1_load_chunk(p, chunk_id);    // workgroup-uniform
     const int f = ck.f;
     if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
     const int t0 = ck.t0;
@@ -535,7 +552,7 @@ __device__ __forceinline__ void s1_wait_barrier() {
 }
 
 template <int MODE>
-__device__ __forceinline__ void s1_body_x16(const S1Params& p) {
+__device__ __forceinline__ void s1_body_x16(const S1Params& p, const int chunk_id) {
     typedef S1X<MODE> X;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const qring = smem + X::D_BYTES;
@@ -546,8 +563,7 @@ __device__ __forceinline__ void s1_body_x16(const S1Params& p) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
 
-    const int chunk_id = p.chunk0 + (int)blockIdx.x;
-    const S1Chunk ck = p.chunks[chunk_id];            // workgroup-uniform (scalar loads)
+    const S1Chunk ck = s1_load_chunk(p, chunk_id);    // workgroup-uniform
     const int f = ck.f;
     if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
     const int t0 = ck.t0;
@@ -679,7 +695,7 @@ struct S1XR {
 };
 
 template <int MODE, int R>
-__device__ __forceinline__ void s1_body_x16r(const S1Params& p) {
+__device__ __forceinline__ void s1_body_x16r(const S1Params& p, const int chunk_id) {
     typedef S1XR<MODE, R> X;
     typedef short vec8 __attribute__((ext_vector_type(8)));   // 16 bytes of bf16 / fp16 bits
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -691,8 +707,7 @@ __device__ __forceinline__ void s1_body_x16r(const S1Params& p) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
 
-    const int chunk_id = p.chunk0 + (int)blockIdx.x;
-    const S1Chunk ck = p.chunks[chunk_id];            // workgroup-uniform (scalar loads)
+    const S1Chunk ck = s1_load_chunk(p, chunk_id);    // workgroup-uniform
     const int f = ck.f;
     if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
     const int t0 = ck.t0;
@@ -826,7 +841,7 @@ struct S1W {
 };
 
 template <int R>
-__device__ __forceinline__ void s1_body_f16w(const S1Params& p) {
+__device__ __forceinline__ void s1_body_f16w(const S1Params& p, const int chunk_id) {
     typedef S1W<R> X;
     typedef short vec8 __attribute__((ext_vector_type(8)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -839,8 +854,7 @@ __device__ __forceinline__ void s1_body_f16w(const S1Params& p) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
 
-    const int chunk_id = p.chunk0 + (int)blockIdx.x;
-    const S1Chunk ck = p.chunks[chunk_id];
+    const S1Chunk ck = s1_load_chunk(p, chunk_id);    // workgroup-uniform
     const int f = ck.f;
     if (p.only_failed && !p.only_failed[f]) return;
     const int t0 = ck.t0;
@@ -923,35 +937,45 @@ __device__ __forceinline__ void s1_body_f16w(const S1Params& p) {
     }
 }
 
+// The exact passes (fp32, bf16) double as REPAIR passes of the certified screen (only_failed): their table is then cut finely
+// (every field into up to a whole wave of chunks, so that a single failed field is scanned by the whole GPU), but launched as
+// ONE wave of workgroups that walk it -- the workgroups of fields that did not fail would otherwise cost more to dispatch
+// than the repair itself (idle repair launches follow every screened batch of the non-pipelined entry points).
+#define S1_COMMA ,
+#define S1_CHUNK_LOOP(BODY)                                                                   \
+    for (int c_ = (int)blockIdx.x; c_ < p.n_launch; c_ += (int)gridDim.x) {                   \
+        BODY(p, __builtin_amdgcn_readfirstlane(p.chunk0 + c_));                               \
+        __syncthreads();                                                                      \
+    }
 // The full pass and the threshold-estimation pass are the same code under two kernel names, so that profiles list them
 // separately (the sample pass scans 1 tile per workgroup and is ~30x shorter).
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_kernel(const S1Params p) { s1_body_f32(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_sample_kernel(const S1Params p) { s1_body_f32(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16_kernel(const S1Params p) { s1_body_x16<0>(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16_sample_kernel(const S1Params p) { s1_body_x16<0>(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16_kernel(const S1Params p) { s1_body_x16<1>(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16_sample_kernel(const S1Params p) { s1_body_x16<1>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_f32) }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_sample_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_f32) }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_x16<0>) }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16_sample_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_x16<0>) }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16_kernel(const S1Params p) { s1_body_x16<1>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16_sample_kernel(const S1Params p) { s1_body_x16<1>(p, p.chunk0 + (int)blockIdx.x); }
 #ifndef S1HR_R
 #define S1HR_R 6
 #endif
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r_kernel(const S1Params p) { s1_body_x16r<1, S1HR_R>(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r_sample_kernel(const S1Params p) { s1_body_x16r<1, S1HR_R>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r_kernel(const S1Params p) { s1_body_x16r<1, S1HR_R>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r_sample_kernel(const S1Params p) { s1_body_x16r<1, S1HR_R>(p, p.chunk0 + (int)blockIdx.x); }
 #define S1HR_LDS_BYTES (S1HR_R * 4096 + S1_STATE_BYTES_(S1_SCAP_REG))
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r_kernel(const S1Params p) { s1_body_x16r<0, 6>(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r_sample_kernel(const S1Params p) { s1_body_x16r<0, 6>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_x16r<0 S1_COMMA  6>) }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r_sample_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_x16r<0 S1_COMMA  6>) }
 #define S1BR_LDS_BYTES (6 * 6144 + S1_STATE_BYTES_(S1_SCAP_REG / 2))
 // 4-slot twins for dims whose k-steps divide by 4 but not by 6 (64, 128, 256, 512, 1024, ...): measured equal to the 6-slot
 // ring; without them those dims would fall to the LDS ring, beside which nothing else fits on a CU
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r4_kernel(const S1Params p) { s1_body_x16r<1, 4>(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r4_sample_kernel(const S1Params p) { s1_body_x16r<1, 4>(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r4_kernel(const S1Params p) { s1_body_x16r<0, 4>(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r4_sample_kernel(const S1Params p) { s1_body_x16r<0, 4>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r4_kernel(const S1Params p) { s1_body_x16r<1, 4>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16r4_sample_kernel(const S1Params p) { s1_body_x16r<1, 4>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r4_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_x16r<0 S1_COMMA  4>) }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r4_sample_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_x16r<0 S1_COMMA  4>) }
 #define S1HR4_LDS_BYTES (4 * 4096 + S1_STATE_BYTES_(S1_SCAP_REG))
 #define S1BR4_LDS_BYTES (4 * 6144 + S1_STATE_BYTES_(S1_SCAP_REG / 2))
 // wide fp16 screen pass (128 queries, one fp16 term): 6-slot ring for k-steps divisible by 6, 4-slot twin otherwise
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_kernel(const S1Params p) { s1_body_f16w<6>(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_sample_kernel(const S1Params p) { s1_body_f16w<6>(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_kernel(const S1Params p) { s1_body_f16w<4>(p); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_sample_kernel(const S1Params p) { s1_body_f16w<4>(p); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_kernel(const S1Params p) { s1_body_f16w<6>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_sample_kernel(const S1Params p) { s1_body_f16w<6>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_kernel(const S1Params p) { s1_body_f16w<4>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_sample_kernel(const S1Params p) { s1_body_f16w<4>(p, p.chunk0 + (int)blockIdx.x); }
 #define S1HW_LDS_BYTES (6 * 4096 + 2 * S1_STATE_BYTES_(S1_SCAP_WIDE))
 #define S1HW4_LDS_BYTES (4 * 4096 + 2 * S1_STATE_BYTES_(S1_SCAP_WIDE))

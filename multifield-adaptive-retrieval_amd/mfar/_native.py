@@ -76,6 +76,7 @@ SIGNATURES = {
     "mfar_stage1_finish": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mfar_max_split_batch": (_i, [_vp, _i]),
     "mfar_set_wide": (_i, [_vp, _i]),
+    "mfar_set_repair_mode": (_i, [_vp, _i]),
     "mfar_set_screen": (_i, [_vp, _i, _c.c_float]),
     "mfar_get_screen": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_float)]),
     "mfar_screen_field_info": (_i, [_vp, _i, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),

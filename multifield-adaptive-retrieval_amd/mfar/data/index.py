@@ -334,6 +334,12 @@ class MultiFieldIndex:
         """Blocks of 65 .. 128 queries use the wide (one fp16 term, 128 columns) screened pass; False: always 64 per pass."""
         _native.check(_native.lib().mfar_set_wide(self._h, int(bool(enable))))
 
+    def set_repair_mode(self, fine: bool = True):
+        """How failed certificates are repaired on the device: fine = every field cut into a whole wave of chunks (a failed
+        field is scanned by the whole GPU; idle repairs cost more launches) -- for callers that repair only after a reported
+        failure (include/mfar_hip.h)."""
+        _native.check(_native.lib().mfar_set_repair_mode(self._h, int(bool(fine))))
+
     def set_screen(self, mode: int = 1, eps_mult: float = 1.0):
         """Certified fp16 screening of an fp32 index (include/mfar_hip.h): 0 off, 1 auto, 2 whenever possible.
         Outputs are bit-identical in every mode; `eps_mult` is a test knob (1 = rigorous proof)."""

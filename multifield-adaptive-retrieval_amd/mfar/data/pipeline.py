@@ -50,6 +50,7 @@ class PipelinedSearcher:
         self.dev = torch.device(f"cuda:{index.device}")
         self.main = torch.cuda.Stream(device=self.dev, priority=-1)   # the scans: dispatched ahead of the small kernels
         self.side = torch.cuda.Stream(device=self.dev)
+        index.set_repair_mode(True)   # repairs are launched here only after a failure was reported (or when they are frequent)
         self.Qb = int(max_batch)      # queries per submitted batch (at most)
         cap = index.max_split_batch(k1)                       # 128 with the wide screened pass, else 64
         if self.sharded:

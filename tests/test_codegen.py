@@ -37,7 +37,7 @@ def test_ring_registers_are_never_copied_before_their_wait(asm):
     for name, body in _kernels(asm):
         ring = set()
         for line in body:
-            m = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\]", line)
+            m = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\], v\[\d+:\d+\], off", line)   # the inline-asm ring loads (flat address, no SGPR base)
             if m:
                 ring.update(range(int(m.group(1)), int(m.group(2)) + 1))
         if not ring:

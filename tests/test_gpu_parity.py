@@ -759,6 +759,38 @@ def test_stage2_gathers_group_representatives(idxmod):
     ix.close()
 
 
+def test_fine_repair_mode(idxmod):
+    """mfar_set_repair_mode(1): failed certificates are repaired over the finely cut table (every field a whole wave of chunks,
+    walked by one wave of workgroups: S1_CHUNK_LOOP in csrc/mfar_stage1.h, with its own sample pass) -- same bits as the oracle
+    when every list fails, when one field fails (near-ties in field 0 only) and when nothing fails; a bf16 index repairs to
+    the same lists in both modes."""
+    rng = np.random.default_rng(18)
+    for F, D, E, Q in ((3, 40000, 96, 70), (5, 20000, 64, 33), (2, 70000, 768, 128)):
+        slab, q, W = _mk(rng, F, D, E, Q)
+        rows = rng.choice(D, size=1500, replace=False)         # field 0: 1500 distinct vectors, equal up to the last bits
+        slab[0, rows] = (q[0] * 4.0) * (1.0 + np.arange(1500, dtype=np.float32)[:, None] * np.float32(2.0 ** -22))
+        ix = _load(idxmod, slab)
+        ix.set_repair_mode(True)
+        o = O.c_two_stage(slab, q, W, None)
+        for eps_mult in (1.0, 1e9):
+            ix.set_screen(2, eps_mult)
+            r = ix.search(q, W, None, return_fields=True)
+            assert np.array_equal(r["field_ids"], o["field_ids"]), (F, D, E, Q, eps_mult)
+            assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32))
+        st = ix.screen_stats()
+        assert st["n_failed"] >= Q * F, st
+        ix.close()
+    slab, q, W = _mk(rng, 3, 30000, 128, 100)
+    ix = _load_bf16(idxmod, slab)
+    ix.set_screen(2, 1e9)
+    r0 = ix.search(q, W, None, return_fields=True)
+    ix.set_repair_mode(True)
+    r1 = ix.search(q, W, None, return_fields=True)
+    for key in ("ids", "scores", "field_ids", "field_scores"):
+        assert np.array_equal(np.asarray(r0[key]).view(np.uint8), np.asarray(r1[key]).view(np.uint8)), key
+    ix.close()
+
+
 def test_pipelined_searcher_with_screen_and_redo(idxmod):
     """The split-phase pipeline over a screened index: certified batches flow through; with an impossible proof
     (eps_mult = 1e9) every batch reports a failed certificate and result() redoes it exactly -- same bits either way."""

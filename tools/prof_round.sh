@@ -17,6 +17,10 @@ done
 for scr in auto on; do
   python $R/bench.py $B --docs 1250000 --fields 16 --dtype bf16 --screen $scr 2>> $O/bench.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['config']['docs'], d['config']['fields'], d['config']['dim'], 'bf16 screen=$scr', 'q/s=%.0f' % d['value'], 'ms/step=%.3f' % d['ms_per_step'], r['kernel'], 'launch_ms=%.3f' % r['avg_launch_ms'], 'hbm_frac=%.3f' % r['frac'], 'recall20=%.3f' % d['recall_at_20'])" >> $O/shapes.txt
 done
+# the STaRK-prime shape with sparse fields (most documents lack most of its 22 fields) and with the structured field kinds
+for extra in "--empty-frac 0.7" "--empty-frac 0.9" "--corpus structured"; do
+  python $R/bench.py $B --docs 129375 --fields 22 $extra 2>> $O/bench.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['config']['docs'], d['config']['fields'], d['config']['dim'], '$extra', 'q/s=%.0f' % d['value'], 'ms/step=%.3f' % d['ms_per_step'], r['kernel'], 'launch_ms=%.3f' % r['avg_launch_ms'], 'redone=%d' % d['screen']['lists_redone_exactly'], 'recall20=%.3f' % d['recall_at_20'])" >> $O/shapes.txt
+done
 # kernel trace + stats of the default leg alone (the extra legs launch the same kernels on other shapes and would skew the averages)
 rocprofv3 --kernel-trace --stats -d /tmp/kt -o r1 --output-format csv -- python $R/bench.py --steps 16 --warmup 2 $B > $O/bench_under_rocprof.json 2>/dev/null
 # counters: one pass each; default leg, then the exact fp32 pass (--screen off) into a sub-directory of the same pass
