@@ -228,15 +228,15 @@ int mfar_max_split_batch(mfar_index* idx, int k);
 int mfar_set_wide(mfar_index* idx, int enable);
 /*
  * How the exact pass REPAIRS fields whose certificate failed (the entry points that repair on the device launch it behind
- * every screened block; it is idle when nothing failed).
- *   fine = 0 (default)  the fields keep their share of one wave of workgroups: an idle repair costs two short launches, but a
- *                       single failed field is scanned by its share of the GPU only (1 M x 8: several ms);
- *   fine = 1            every field is cut into up to a whole wave of chunks, walked by one wave of workgroups, with its own
- *                       sample pass: a failed field is scanned by the whole GPU (under 1 ms there), an idle repair costs five
- *                       launches (+0.15 ms per 64 queries).  For callers that only ask for repairs after a failure was
- *                       reported (mfar.data.pipeline.PipelinedSearcher sets it).
+ * every screened block; it is idle when nothing failed).  A repair walks a finely cut table -- every field up to a whole
+ * wave of chunks, scanned by ONE wave of workgroups -- so that a single failed field is scanned by the whole GPU (1 M x 8:
+ * under 1 ms instead of the several ms its share of the grid would take) while an idle repair stays three short launches.
+ *   thorough = 0 (default)  no sample pass: right when failures are rare;
+ *   thorough = 1            the repair runs its own sample pass (thresholds for the failed fields: 20 % faster when most
+ *                           fields fail, two more launches when none does).  For callers that only ask for repairs after a
+ *                           failure was reported (mfar.data.pipeline.PipelinedSearcher sets it).
  */
-int mfar_set_repair_mode(mfar_index* idx, int fine);
+int mfar_set_repair_mode(mfar_index* idx, int thorough);
 int mfar_stage1_finish(mfar_index* idx, const float* q, int Q, int k, int sentinel, int slot, int64_t* field_ids,
                        float* field_scores, int32_t* any_fail, void* stream);
 

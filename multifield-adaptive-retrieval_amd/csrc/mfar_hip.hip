@@ -138,7 +138,7 @@ struct mfar_index {
     std::vector<int> n_unique, largest_group;   // per field (host copies)
     bool screen_dedup = true;     // MFAR_SCREEN_DEDUP=0: every document is its own unique row (diagnostic)
     bool wide = true;             // blocks of 65 .. 128 queries go through the wide screened pass (MFAR_WIDE=0: always 64 per pass)
-    bool repair_fine = false;     // mfar_set_repair_mode: repairs walk the finely cut table (see stage1_pass)
+    bool repair_sample = false;   // mfar_set_repair_mode: repairs run their own sample pass (see stage1_pass)
     S1Geom geom_docs, geom_screen;
     // fused mode (mfar_search_fused): a one-field companion index of dim F * E over the same rows, built on first use
     mfar_index* fused = nullptr;
@@ -705,11 +705,11 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
                        const void* qt, int qt_n, int k, float tau0, const float* tau_base, const int* only_failed, bool record,
                        const S1Out& o, hipStream_t st) {
     const int qw = kind == S1_F16W ? 128 : 64;   // query columns of the pass: stride of every per-query table below
-    // a repair pass (only_failed) in the fine mode (mfar_set_repair_mode) uses the finely cut table as well: the workgroups of the fields that did not fail exit at once,
+    // a repair pass (only_failed) uses the finely cut table as well: the workgroups of the fields that did not fail exit at once,
     // and a failed field is then scanned by the whole GPU instead of by its share of one wave (one failed field of eight at 1 M
     // rows: 64 workgroups x 61 tiles at the MFMA-bound rate = several ms; cut into 512 chunks: under 1 ms)
-    const bool fine_repair = only_failed != nullptr && idx->repair_fine;
-    const bool solo = nf != idx->F || fine_repair, wide = kind == S1_F16W;
+    const bool repair = only_failed != nullptr;
+    const bool solo = nf != idx->F || repair, wide = kind == S1_F16W;
     S1Table& tb = wide ? (solo ? geom.solo_w : geom.all_w) : (solo ? geom.solo : geom.all);
     static const int sample_tiles_env = getenv("MFAR_SAMPLE_TILES") ? atoi(getenv("MFAR_SAMPLE_TILES")) : 0;
     RETCHK(build_table(idx, geom, tb, k, solo, sample_tiles_env > 0 ? sample_tiles_env : (kind == S1_F32 ? 1 : 2), sample_tiles_env > 0, 4, idx->wgs_per_cu, st));
@@ -780,7 +780,7 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
     // ... or, with short chunks, whenever it yields thresholds for most of the rows: a tile without one costs 8 x a normal tile in
     // the full pass (90 % empty 129 k x 22: 2.4 tiles per chunk, scan 0.85 ms without the sample pass)
     const bool use_sample = (tb.total_tiles >= (long long)sample_min_tiles * tb.n_chunks || 2 * tb.thresholded_tiles >= tb.total_tiles) &&
-                            !(p.dbg & 2) && (!only_failed || fine_repair);
+                            !(p.dbg & 2) && (!repair || idx->repair_sample);
     const bool light_sample = use_sample && 2 * tb.samp_stride <= 4096;
     p.sample_tiles = light_sample ? tb.sample_tiles : 1;
     if (light_sample) {
@@ -1263,9 +1263,9 @@ extern "C" int mfar_max_split_batch(mfar_index* idx, int k) {
     if (hipStreamSynchronize(nullptr) != hipSuccess) return 64;
     return 128;
 }
-extern "C" int mfar_set_repair_mode(mfar_index* idx, int fine) {
+extern "C" int mfar_set_repair_mode(mfar_index* idx, int thorough) {
     if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
-    idx->repair_fine = fine != 0;
+    idx->repair_sample = thorough != 0;
     return MFAR_OK;
 }
 extern "C" int mfar_set_wide(mfar_index* idx, int enable) {
@@ -1635,7 +1635,7 @@ static int ensure_fused(mfar_index* idx, hipStream_t st) {
     idx->fused->screen_mode = fused_screen ? 2 : 0;
     idx->fused->screen_eps_mult = idx->screen_eps_mult;
     idx->fused->wide = idx->wide;
-    idx->fused->repair_fine = idx->repair_fine;
+    idx->fused->repair_sample = idx->repair_sample;
     return MFAR_OK;
 }
 

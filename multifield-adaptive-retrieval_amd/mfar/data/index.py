@@ -334,11 +334,10 @@ class MultiFieldIndex:
         """Blocks of 65 .. 128 queries use the wide (one fp16 term, 128 columns) screened pass; False: always 64 per pass."""
         _native.check(_native.lib().mfar_set_wide(self._h, int(bool(enable))))
 
-    def set_repair_mode(self, fine: bool = True):
-        """How failed certificates are repaired on the device: fine = every field cut into a whole wave of chunks (a failed
-        field is scanned by the whole GPU; idle repairs cost more launches) -- for callers that repair only after a reported
-        failure (include/mfar_hip.h)."""
-        _native.check(_native.lib().mfar_set_repair_mode(self._h, int(bool(fine))))
+    def set_repair_mode(self, thorough: bool = True):
+        """Repairs of failed certificates on the device: thorough = with their own sample pass (faster when many fields fail,
+        two more launches when none does) -- for callers that repair only after a reported failure (include/mfar_hip.h)."""
+        _native.check(_native.lib().mfar_set_repair_mode(self._h, int(bool(thorough))))
 
     def set_screen(self, mode: int = 1, eps_mult: float = 1.0):
         """Certified fp16 screening of an fp32 index (include/mfar_hip.h): 0 off, 1 auto, 2 whenever possible.

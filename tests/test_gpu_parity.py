@@ -760,22 +760,22 @@ def test_stage2_gathers_group_representatives(idxmod):
 
 
 def test_fine_repair_mode(idxmod):
-    """mfar_set_repair_mode(1): failed certificates are repaired over the finely cut table (every field a whole wave of chunks,
-    walked by one wave of workgroups: S1_CHUNK_LOOP in csrc/mfar_stage1.h, with its own sample pass) -- same bits as the oracle
-    when every list fails, when one field fails (near-ties in field 0 only) and when nothing fails; a bf16 index repairs to
-    the same lists in both modes."""
+    """Failed certificates are repaired over the finely cut table (every field a whole wave of chunks, walked by one wave of
+    workgroups: S1_CHUNK_LOOP in csrc/mfar_stage1.h); mfar_set_repair_mode(1) adds the repair's own sample pass -- same bits
+    as the oracle when every list fails, when one field fails (near-ties in field 0 only) and when nothing fails, in both
+    modes; a bf16 index repairs to the same lists in both modes."""
     rng = np.random.default_rng(18)
     for F, D, E, Q in ((3, 40000, 96, 70), (5, 20000, 64, 33), (2, 70000, 768, 128)):
         slab, q, W = _mk(rng, F, D, E, Q)
         rows = rng.choice(D, size=1500, replace=False)         # field 0: 1500 distinct vectors, equal up to the last bits
         slab[0, rows] = (q[0] * 4.0) * (1.0 + np.arange(1500, dtype=np.float32)[:, None] * np.float32(2.0 ** -22))
         ix = _load(idxmod, slab)
-        ix.set_repair_mode(True)
         o = O.c_two_stage(slab, q, W, None)
-        for eps_mult in (1.0, 1e9):
+        for thorough, eps_mult in ((False, 1.0), (False, 1e9), (True, 1.0), (True, 1e9)):
+            ix.set_repair_mode(thorough)
             ix.set_screen(2, eps_mult)
             r = ix.search(q, W, None, return_fields=True)
-            assert np.array_equal(r["field_ids"], o["field_ids"]), (F, D, E, Q, eps_mult)
+            assert np.array_equal(r["field_ids"], o["field_ids"]), (F, D, E, Q, thorough, eps_mult)
             assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32))
         st = ix.screen_stats()
         assert st["n_failed"] >= Q * F, st
