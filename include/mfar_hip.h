@@ -144,6 +144,14 @@ int mfar_search_fused(mfar_index* idx, const float* q, int Q, const float* W, in
 int mfar_search_stage2(mfar_index* idx, const float* q, int Q, const float* W, int query_cond, const float* mask, int k1,
                        int k2, const int64_t* field_ids, int slot, int64_t* ids, float* scores, int32_t* n_valid,
                        int32_t* n_cand, void* stream);
+/*
+ * The same for a SWEEP of field masks (mask_fields.py:143-170 evaluates baseline + one masked run per field / field type /
+ * field name: 2 F + 2 runs that differ in the mask only): masks [n_masks, F]; the candidate union and stage 2 run once, the
+ * mixer once per mask.  ids / scores [n_masks, Q, k2], n_valid [n_masks, Q] (may be NULL); device pointers.
+ */
+int mfar_search_stage2_masks(mfar_index* idx, const float* q, int Q, const float* W, int query_cond, const float* masks,
+                             int n_masks, int k1, int k2, const int64_t* field_ids, int slot, int64_t* ids, float* scores,
+                             int32_t* n_valid, int32_t* n_cand, void* stream);
 
 /*
  * Multi-GPU (row shards + one exchange, replaces the file-based exchange of contrastive.py:491-494,519-536):

@@ -1601,6 +1601,28 @@ extern "C" int mfar_search_stage2(mfar_index* idx, const float* q, int Q, const 
                           (int*)n_valid, (int*)n_cand, (hipStream_t)stream);
 }
 
+extern "C" int mfar_search_stage2_masks(mfar_index* idx, const float* q, int Q, const float* W, int query_cond, const float* masks,
+                                        int n_masks, int k1, int k2, const int64_t* field_ids, int slot, int64_t* ids, float* scores,
+                                        int32_t* n_valid, int32_t* n_cand, void* stream) {
+    RETCHK(check_search_common(idx, q, Q, k1));
+    const int F = idx->F, E = idx->E, C = F * k1;
+    RETCHK(check_mix(Q, C, F, E, k2, q, W, query_cond));
+    if (n_masks <= 0 || !masks) return fail(MFAR_ERR_INVALID, "n_masks must be positive and masks non-NULL");
+    if (Q == 0) return MFAR_OK;
+    if (!ids || !scores || !field_ids) return fail(MFAR_ERR_INVALID, "NULL pointer");
+    if (slot < 0 || slot > 1) return fail(MFAR_ERR_INVALID, "slot must be 0 or 1");
+    HIPCHK(hipSetDevice(idx->device));
+    hipStream_t st = (hipStream_t)stream;
+    // candidate union and stage 2 once (the first mix included), then one mixer launch per further mask over the same scores
+    RETCHK(run_stage2_mix(idx, q, Q, W, query_cond, masks, k1, k2, (const long long*)field_ids, slot, (long long*)ids, scores, (int*)n_valid,
+                          (int*)n_cand, st));
+    const int* ncd = n_cand ? (const int*)n_cand : idx->ncand[slot].as<int>();
+    for (int m = 1; m < n_masks; ++m)
+        RETCHK(run_mix(idx->x[slot].as<float>(), idx->cand[slot].as<long long>(), ncd, q, W, query_cond, masks + (size_t)m * F, Q, C, F, E, k2,
+                       (long long*)ids + (size_t)m * Q * k2, scores + (size_t)m * Q * k2, n_valid ? (int*)n_valid + (size_t)m * Q : nullptr, st));
+    return MFAR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ fused mode
 // The companion: rows of dim F * E -- for every document the concatenation of its F field vectors -- spread over
 // FUSED_GROUPS interleaved row groups that are stored as the "fields" of an ordinary index (document r = group r % G, local

@@ -60,6 +60,7 @@ SIGNATURES = {
     "mfar_search_fused": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "mfar_payload_bytes": (_i64, [_i, _i, _i]),
     "mfar_search_stage2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mfar_search_stage2_masks": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "mfar_search_local": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "mfar_merge_workspace_bytes": (_i64, [_i, _i, _i]),
     "mfar_merge_payloads": (_i, [_i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp]),

@@ -4,9 +4,11 @@ Same keyword-only flags as the reference `main` (pinned by tests/golden/cli_sign
 (baseline, one run per field, all-sparse, all-dense, one run per field NAME; mask_fields.py:143-170) and the same output
 files ({out}/{rank}.qres, additional_{rank}.qres, final-*all-0.qres, results_dicts-all-0.jsonl).  The corpus is encoded
 into HBM once and reused by every masked run -- only the mixer changes with the mask -- instead of being re-encoded by
-each of the 1+F+1+F `trainer.test` calls (contrastive.py:553-554).  Launch one process per GPU with torch.distributed.run
+each of the 1+F+1+F `trainer.test` calls (contrastive.py:553-554); on one rank with dense fields the whole sweep is ONE
+pass over the queries (queries encoded once, stages 1 and 2 once per batch, the mixer once per mask).  Launch one process per GPU with torch.distributed.run
 for row-sharded multi-GPU evaluation; a single process uses GPU 0.
 """
+import os
 import time
 from typing import *  # noqa: F401,F403
 
@@ -43,20 +45,35 @@ def main(
     module.encoder.to(st.device)
     print(f"Starting re-testing of {checkpoint_path}: {time.strftime('%Y-%m-%d %H:%M:%S')}")
 
+    # the evaluation sequence of mask_fields.py:143-170: baseline, every field, all sparse, all dense, every field NAME
+    fields = list(field_info.values())
+    sparse_idx = [i for i, f in enumerate(fields) if f.field_type == FieldType.SPARSE]
+    dense_idx = [i for i, f in enumerate(fields) if f.field_type == FieldType.DENSE]
+    runs = [[]]
+    if not debug:
+        runs += [[idx] for idx in range(len(fields))]
+        runs += [sparse_idx] if sparse_idx else []
+        runs += [dense_idx] if dense_idx else []
+        runs += [[i for i, f in enumerate(fields) if f.name == name] for name in sorted({f.name for f in fields})]
     print("Baseline Evaluation")
+    # one rank, dense fields: the whole sweep in ONE pass over the queries (the mask only enters the mixer; contrastive.py
+    # test_sweep; MFAR_MASK_SWEEP=0 switches it off); otherwise one `test()` per run as the reference does
+    if os.environ.get("MFAR_MASK_SWEEP", "1") != "0" and module.test_sweep(data_module, runs):
+        if not debug and not sparse_idx:
+            print("No sparse fields")
+        if not debug and not dense_idx:
+            print("No dense fields")
+        return module
     module.test(data_module)
     if not debug:
-        fields = list(field_info.values())
         for idx in range(len(fields)):
             module.mask_field([idx])
             module.test(data_module)
-        sparse_idx = [i for i, f in enumerate(fields) if f.field_type == FieldType.SPARSE]
         if sparse_idx:
             module.mask_field(sparse_idx)
             module.test(data_module)
         else:
             print("No sparse fields")
-        dense_idx = [i for i, f in enumerate(fields) if f.field_type == FieldType.DENSE]
         if dense_idx:
             module.mask_field(dense_idx)
             module.test(data_module)

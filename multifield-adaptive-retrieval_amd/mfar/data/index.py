@@ -249,6 +249,27 @@ class MultiFieldIndex:
             ia.ptr, sa.ptr, na.ptr, None, _current_stream(self.device, True)))
         return dict(ids=ids, scores=sc, n_valid=nv)
 
+    def search_stage2_masks(self, q, W, field_ids, masks, k1: int = 100, k2: int = 100, query_cond: bool = True, slot: int = 0,
+                            out=None):
+        """`search_stage2` for a sweep of field masks [M, F]: candidate union and stage 2 once, the mixer once per mask
+        (include/mfar_hip.h mfar_search_stage2_masks).  -> ids / scores [M, Q, k2], n_valid [M, Q]."""
+        qa, Wa = _Arg(q, np.float32, self.device), _Arg(W, np.float32, self.device)
+        ma, fa = _Arg(masks, np.float32, self.device), _Arg(field_ids, np.int64, self.device)
+        if not _same_side([qa, Wa, ma, fa]):
+            raise ValueError("search_stage2_masks needs CUDA tensors")
+        Q, M = qa.keep.shape[0], ma.keep.shape[0]
+        if ma.keep.dim() != 2 or ma.keep.shape[1] != self.n_fields:
+            raise ValueError("masks must be [M, n_fields]")
+        out = dict(out) if out else {}
+        ids = out.get("ids") if out.get("ids") is not None else _empty_like_side(True, self.device, (M, Q, k2), np.int64)
+        sc = out.get("scores") if out.get("scores") is not None else _empty_like_side(True, self.device, (M, Q, k2), np.float32)
+        nv = out.get("n_valid") if out.get("n_valid") is not None else _empty_like_side(True, self.device, (M, Q), np.int32)
+        ia, sa, na = _Arg(ids, np.int64, self.device), _Arg(sc, np.float32, self.device), _Arg(nv, np.int32, self.device)
+        _native.check(_native.lib().mfar_search_stage2_masks(
+            self._h, qa.ptr, Q, Wa.ptr, int(bool(query_cond)), ma.ptr, int(M), int(k1), int(k2), fa.ptr, int(slot),
+            ia.ptr, sa.ptr, na.ptr, None, _current_stream(self.device, True)))
+        return dict(ids=ids, scores=sc, n_valid=nv)
+
     def search_local(self, q, k1: int = 100, sentinel: bool = True, payload=None, phases: int = 3):
         qa = _Arg(q, np.float32, self.device)
         Q = qa.keep.shape[0]

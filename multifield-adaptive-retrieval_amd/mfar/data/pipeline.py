@@ -36,8 +36,12 @@ from mfar.data import index as _index
 
 class PipelinedSearcher:
     def __init__(self, index, W, mask=None, k1: int = 100, k2: int = 100, sentinel: bool = True, query_cond: bool = True,
-                 max_batch: int = 64, group=None, coalesce=None, exchange=None):
+                 max_batch: int = 64, group=None, coalesce=None, exchange=None, masks=None):
         self.ix, self.W, self.mask = index, W, mask
+        # masks [M, F]: a SWEEP of field masks (mask_fields.py:143-170) -- stage 1, the candidate union and stage 2 run once per
+        # launch, the mixer once per mask; results then carry a leading mask dimension.  One shard only.
+        self.masks = None if masks is None else masks.float().contiguous()
+        self.M = 0 if masks is None else int(self.masks.shape[0])
         self.k1, self.k2, self.sentinel, self.query_cond = k1, k2, sentinel, query_cond
         self.group = group
         dist = torch.distributed
@@ -45,6 +49,8 @@ class PipelinedSearcher:
         # exchange=True runs the lists-first exchange (the two all-gathers + owned scoring + merge) even with ONE rank: the
         # RCCL code path of the multi-GPU pipeline can then be exercised on a one-GPU box (tests/test_gpu_multirank.py)
         self.sharded = self.world > 1 if exchange is None else bool(exchange)
+        if self.sharded and self.M:
+            raise ValueError("a mask sweep runs on one shard (run the masks one after the other across ranks)")
         if self.sharded and not (dist.is_available() and dist.is_initialized()):
             raise ValueError("the exchange path needs an initialised torch.distributed process group")
         self.dev = torch.device(f"cuda:{index.device}")
@@ -77,10 +83,11 @@ class PipelinedSearcher:
         self.inline_repair = False    # many failures: let finish() repair on the device instead of reporting (see _check)
         self.slots = []
         for _ in range(2):
+            lead = (self.M,) if self.M else ()
             s = dict(q=torch.zeros(self.Qmax, E, device=self.dev),
-                     ids=torch.empty(self.Qmax, k2, dtype=torch.int64, device=self.dev),
-                     scores=torch.empty(self.Qmax, k2, device=self.dev),
-                     n_valid=torch.empty(self.Qmax, dtype=torch.int32, device=self.dev),
+                     ids=torch.empty(*lead, self.Qmax, k2, dtype=torch.int64, device=self.dev),
+                     scores=torch.empty(*lead, self.Qmax, k2, device=self.dev),
+                     n_valid=torch.empty(*lead, self.Qmax, dtype=torch.int32, device=self.dev),
                      W=torch.empty_like(W, device=self.dev), mask=torch.ones(F, device=self.dev),
                      fail=torch.zeros(1, dtype=torch.int32, device=self.dev),
                      fail_host=torch.zeros(1, dtype=torch.int32).pin_memory(),
@@ -115,7 +122,17 @@ class PipelinedSearcher:
         Q = s["Q"]
         qk = s["q"][:Q]
         out = dict(ids=s["ids"][:Q], scores=s["scores"][:Q], n_valid=s["n_valid"][:Q])
-        if not self.sharded:
+        if self.M:
+            # (the kernels write [M, Q, k2] densely: hand them a dense scratch view when the launch is short)
+            if Q == self.Qmax:
+                dense = dict(ids=s["ids"], scores=s["scores"], n_valid=s["n_valid"])
+            else:
+                dense = dict(ids=s["ids"].view(-1)[:self.M * Q * self.k2].view(self.M, Q, self.k2),
+                             scores=s["scores"].view(-1)[:self.M * Q * self.k2].view(self.M, Q, self.k2),
+                             n_valid=s["n_valid"].view(-1)[:self.M * Q].view(self.M, Q))
+            self.ix.search_stage2_masks(qk, s["W"], s["fid"][:Q], self.masks, self.k1, self.k2, self.query_cond, slot=slot, out=dense)
+            s["dense_Q"] = Q
+        elif not self.sharded:
             self.ix.search_stage2(qk, s["W"], s["fid"][:Q], s["mask"], self.k1, self.k2, self.query_cond, slot=slot, out=out)
         else:
             dist = torch.distributed
@@ -242,4 +259,10 @@ class PipelinedSearcher:
             raise ValueError("ticket is no longer in flight")
         self._check(launch)
         s = self.slots[launch & 1]
+        if self.M:      # [M, Q, k2]: the launch's results are laid out densely over its own query count
+            QL = s["dense_Q"]
+            ids = s["ids"].view(-1)[:self.M * QL * self.k2].view(self.M, QL, self.k2)
+            sc = s["scores"].view(-1)[:self.M * QL * self.k2].view(self.M, QL, self.k2)
+            nv = s["n_valid"].view(-1)[:self.M * QL].view(self.M, QL)
+            return dict(ids=ids[:, off:off + Q], scores=sc[:, off:off + Q], n_valid=nv[:, off:off + Q])
         return dict(ids=s["ids"][off:off + Q], scores=s["scores"][off:off + Q], n_valid=s["n_valid"][off:off + Q])

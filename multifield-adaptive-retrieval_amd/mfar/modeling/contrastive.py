@@ -380,6 +380,73 @@ class RetrievalTrainingModule(torch.nn.Module):
         if was_training:
             self.train()
 
+    def test_sweep(self, data_module: RetrievalDataModule, field_idx_lists) -> bool:
+        """Every evaluation of a field-masking sweep (mask_fields.py:143-170: baseline, one run per field, per field type, per
+        field name) in ONE pass over the queries.  The runs differ in the mask only, and the mask only enters the mixer
+        (contrastive.py:685-686): queries are encoded once, stage 1, the candidate union and stage 2 run once per batch, the
+        mixer once per mask (`mfar_search_stage2_masks`).  Afterwards the runs are replayed in order -- `mask_field`, the
+        rank's .qres files, `merge_qres_and_score` -- so the output files, the printed metrics and results_dicts-*.jsonl
+        are what the 2 F + 2 separate `test()` calls leave behind.  `field_idx_lists`: one list of masked field indices per
+        run (empty = baseline).  Returns False without doing anything when the sweep path does not apply (several ranks:
+        the exchange is per mask; sparse fields: scored on the host) -- the caller then runs the masks one by one."""
+        from mfar.data.pipeline import PipelinedSearcher
+        rank, world = _dist()
+        if world > 1 or self.has_sparse or not field_idx_lists:
+            return False
+        data_module.setup("test")
+        was_training = self.training
+        self.eval()
+        self.on_eval_start()
+        self.qres_output.close()
+        F, M = len(self.field_info), len(field_idx_lists)
+        masks = torch.ones(M, F)
+        for m, idx in enumerate(field_idx_lists):
+            masks[m, list(idx)] = 0
+        qmax = min(64, max(1, int(self.dev_batch_size)))
+        ps = PipelinedSearcher(self.slab, self._weights(), None, k1=TOP_K, k2=TOP_K, sentinel=True, query_cond=self.query_cond,
+                               max_batch=qmax, masks=masks.to(self.device))
+        tmp = [[f"{self.out_dir}/.sweep_{m}_{li}_{rank}.qres" for li in range(2)] for m in range(M)]
+        files = [[open(fn, "w") for fn in pair] for pair in tmp]
+        keys = self.numeric_ids_to_keys
+
+        def collect(item):
+            ticket, data, li = item
+            res = ps.result(ticket)
+            n = len(data)
+            if int(res["n_valid"][:, :n].min()) < TOP_K:                         # what torch.topk raises at :696
+                raise RuntimeError(f"selected index k out of range: fewer than k={TOP_K} candidates")
+            ids, sims = res["ids"][:, :n].cpu().tolist(), res["scores"][:, :n].cpu().tolist()
+            for m in range(M):
+                files[m][li].write("".join(f"{q._id}\t0\t{keys[d]}\t0\t{s}\t0\n" for q, row_ids, row_sims in zip(data, ids[m], sims[m])
+                                           for d, s in zip(row_ids, row_sims)))
+
+        pending = deque()
+        with torch.no_grad():
+            for li, loader in enumerate(data_module.test_dataloader()):
+                for batch in loader:
+                    x = self.encode_query_batch(batch)
+                    for b in range(0, x.shape[0], ps.Qb):
+                        pending.append((ps.submit(x[b:b + ps.Qb].contiguous()), batch.instances[b:b + ps.Qb], min(li, 1)))
+                        while len(pending) > ps.lag:
+                            collect(pending.popleft())
+            while pending:
+                collect(pending.popleft())
+        for pair in files:
+            for f in pair:
+                f.close()
+        for m, idx in enumerate(field_idx_lists):                                # replay the runs in order
+            if idx:
+                self.mask_field(list(idx))
+            os.replace(tmp[m][0], f"{self.out_dir}/{rank}.qres")
+            os.replace(tmp[m][1], f"{self.out_dir}/additional_{rank}.qres")
+            has_additional = os.path.getsize(f"{self.out_dir}/additional_{rank}.qres") > 0
+            self.merge_qres_and_score([f"{self.out_dir}/{rank}.qres"], self.dev_qrels_path)
+            if has_additional:
+                self.merge_qres_and_score([f"{self.out_dir}/additional_{rank}.qres"], self.additional_qrels_path, additional="additional-")
+        if was_training:
+            self.train()
+        return True
+
     def merge_qres_and_score(self, qres_files, qrels_path, additional=""):       # contrastive.py:566-613
         rank, _ = _dist()
         if rank != 0:

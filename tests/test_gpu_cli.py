@@ -121,6 +121,19 @@ def test_train_then_mask_fields(tmp_path):
     np.testing.assert_allclose(m2.mixture_of_fields_layer.weight.detach().cpu().numpy(), W)
     # masking every field zeroes all mixed scores
     assert rows[8]["recall_20"] <= rows[0]["recall_20"]
+    # that ran as ONE pass over the queries (test_sweep: the mixer once per mask); one test() per mask, as the reference does,
+    # leaves the same files behind, byte for byte
+    out3 = str(tmp_path / "out3")
+    os.environ["MFAR_MASK_SWEEP"] = "0"
+    try:
+        mask_fields.main(dataset_name="amazon", lexical_index="unused", out=out3, temp_dir=tmp, data=data,
+                         model_name="random-init:64x2", field_names="title_dense,brand_dense,feature_dense",
+                         checkpoint_dir=out, dev_batch_size=16, additional_partition="test")
+    finally:
+        del os.environ["MFAR_MASK_SWEEP"]
+    for fn in ("results_dicts-all-0.jsonl", "0.qres", "additional_0.qres", "final-all-0.qres", "final-additional-all-0.qres"):
+        assert open(f"{out2}/{fn}").read() == open(f"{out3}/{fn}").read(), fn
+    assert not [fn for fn in os.listdir(out2) if fn.startswith(".sweep_")]
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE.json configs[0]

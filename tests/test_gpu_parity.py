@@ -759,6 +759,39 @@ def test_stage2_gathers_group_representatives(idxmod):
     ix.close()
 
 
+def test_mask_sweep_through_the_pipeline(idxmod):
+    """PipelinedSearcher(masks=[M, F]) / mfar_search_stage2_masks: stage 1, the candidate union and stage 2 once per launch, the
+    mixer once per mask -- every mask's results equal a separate search with that mask, bit for bit (full and short launches,
+    coalesced and single batches)."""
+    import torch
+    from mfar.data.pipeline import PipelinedSearcher
+    rng = np.random.default_rng(19)
+    dev = torch.device("cuda:0")
+    for F, D, E, Q, qb in ((4, 30000, 96, 150, 64), (3, 5000, 64, 70, 16), (6, 20000, 128, 64, 64)):
+        slab, q, W = _mk(rng, F, D, E, Q)
+        ix = _load(idxmod, slab)
+        masks = (rng.random((5, F)) < 0.6).astype(np.float32)
+        masks[0] = 1.0
+        masks[1] = 0.0
+        want = [ix.search(q, W, masks[m]) for m in range(len(masks))]
+        ps = PipelinedSearcher(ix, torch.from_numpy(W).to(dev), None, max_batch=qb, masks=torch.from_numpy(masks).to(dev))
+        tickets = [(c, ps.submit(torch.from_numpy(q[c:c + qb]).to(dev))) for c in range(0, Q, qb)]
+        got = {}
+        for i, (c, t) in enumerate(tickets):
+            if i >= ps.lag:
+                c0, t0 = tickets[i - ps.lag]
+                got[c0] = {k: v.cpu().numpy().copy() for k, v in ps.result(t0).items()}
+        for c, t in tickets[max(0, len(tickets) - ps.lag):]:
+            got[c] = {k: v.cpu().numpy().copy() for k, v in ps.result(t).items()}
+        for c, g in got.items():
+            n = min(qb, Q - c)
+            assert g["ids"].shape == (len(masks), n, 100)
+            for m in range(len(masks)):
+                assert np.array_equal(g["ids"][m], np.asarray(want[m]["ids"])[c:c + n]), (F, D, E, Q, qb, c, m)
+                assert np.array_equal(g["scores"][m].view(np.uint32), np.asarray(want[m]["scores"])[c:c + n].view(np.uint32)), (c, m)
+        ix.close()
+
+
 def test_fine_repair_mode(idxmod):
     """Failed certificates are repaired over the finely cut table (every field a whole wave of chunks, walked by one wave of
     workgroups: S1_CHUNK_LOOP in csrc/mfar_stage1.h); mfar_set_repair_mode(1) adds the repair's own sample pass -- same bits
