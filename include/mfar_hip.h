@@ -193,6 +193,11 @@ int mfar_retrieve_lists(mfar_index* idx, const float* q, int Q, int k1, int sent
 int mfar_search_owned(mfar_index* idx, const void* gathered_lists, int n_shards, const float* q, int Q, const float* W,
                       int query_cond, const float* mask, int k1, int k2, int sentinel, int slot, const int32_t* any_fail,
                       void* topk, void* stream);
+/* The same for a sweep of field masks [n_masks, F] (see mfar_search_stage2_masks): everything up to the owned candidates' score
+ * vectors once, then one local top-k payload per mask: topk holds n_masks payloads of mfar_topk_bytes() each, back to back. */
+int mfar_search_owned_masks(mfar_index* idx, const void* gathered_lists, int n_shards, const float* q, int Q, const float* W,
+                            int query_cond, const float* masks, int n_masks, int k1, int k2, int sentinel, int slot,
+                            const int32_t* any_fail, void* topk, void* stream);
 int mfar_merge_topk(int device, const void* gathered_topk, int n_shards, int Q, int k2, int64_t* ids, float* scores,
                     int32_t* n_valid, int32_t* any_fail, void* stream);
 

@@ -1939,9 +1939,9 @@ extern "C" int mfar_retrieve_lists(mfar_index* idx, const float* q, int Q, int k
     return run_stage1(idx, q, Q, k1, sentinel, (long long*)((char*)lists + L.ids), (float*)((char*)lists + L.scores), (hipStream_t)stream);
 }
 
-extern "C" int mfar_search_owned(mfar_index* idx, const void* gathered_lists, int n_shards, const float* q, int Q, const float* W,
-                                 int query_cond, const float* mask, int k1, int k2, int sentinel, int slot, const int32_t* any_fail,
-                                 void* topk, void* stream) {
+static int search_owned(mfar_index* idx, const void* gathered_lists, int n_shards, const float* q, int Q, const float* W,
+                        int query_cond, const float* mask, int n_masks, int k1, int k2, int sentinel, int slot, const int32_t* any_fail,
+                        void* topk, void* stream) {
     RETCHK(check_search_common(idx, q, Q, k1));
     const int F = idx->F, E = idx->E, C = F * k1;
     RETCHK(check_mix(Q, C, F, E, k2, q, W, query_cond));
@@ -1986,13 +1986,29 @@ extern "C" int mfar_search_owned(mfar_index* idx, const void* gathered_lists, in
     mfar_filter_owned_kernel<<<dim3(Q), dim3(64), 0, st>>>(cand, ncand, C, idx->row_offset, idx->row_offset + idx->n_rows, owned, nowned);
     HIPCHK(hipGetLastError());
     RETCHK(run_score(idx, q, Q, owned, nowned, C, x, st));
-    char* tb = (char*)topk;
-    RETCHK(run_mix(x, owned, nowned, q, W, query_cond, mask, Q, C, F, E, k2, (long long*)(tb + TL.ids), (float*)(tb + TL.scores),
-                   nullptr, st));
-    HIPCHK(hipMemcpyAsync(tb + TL.ncand, ncand, (size_t)Q * 4, hipMemcpyDeviceToDevice, st));
-    if (any_fail) HIPCHK(hipMemcpyAsync(tb + TL.flag, any_fail, 4, hipMemcpyDeviceToDevice, st));
-    else HIPCHK(hipMemsetAsync(tb + TL.flag, 0, 4, st));
+    // one top-k payload per mask (a sweep of field masks shares everything up to here: mfar_search_owned_masks)
+    for (int m = 0; m < n_masks; ++m) {
+        char* tb = (char*)topk + (size_t)m * TL.total;
+        RETCHK(run_mix(x, owned, nowned, q, W, query_cond, mask ? mask + (size_t)m * F : nullptr, Q, C, F, E, k2, (long long*)(tb + TL.ids),
+                       (float*)(tb + TL.scores), nullptr, st));
+        HIPCHK(hipMemcpyAsync(tb + TL.ncand, ncand, (size_t)Q * 4, hipMemcpyDeviceToDevice, st));
+        if (any_fail) HIPCHK(hipMemcpyAsync(tb + TL.flag, any_fail, 4, hipMemcpyDeviceToDevice, st));
+        else HIPCHK(hipMemsetAsync(tb + TL.flag, 0, 4, st));
+    }
     return MFAR_OK;
+}
+
+extern "C" int mfar_search_owned(mfar_index* idx, const void* gathered_lists, int n_shards, const float* q, int Q, const float* W,
+                                 int query_cond, const float* mask, int k1, int k2, int sentinel, int slot, const int32_t* any_fail,
+                                 void* topk, void* stream) {
+    return search_owned(idx, gathered_lists, n_shards, q, Q, W, query_cond, mask, 1, k1, k2, sentinel, slot, any_fail, topk, stream);
+}
+
+extern "C" int mfar_search_owned_masks(mfar_index* idx, const void* gathered_lists, int n_shards, const float* q, int Q, const float* W,
+                                       int query_cond, const float* masks, int n_masks, int k1, int k2, int sentinel, int slot,
+                                       const int32_t* any_fail, void* topk, void* stream) {
+    if (n_masks <= 0 || !masks) return fail(MFAR_ERR_INVALID, "n_masks must be positive and masks non-NULL");
+    return search_owned(idx, gathered_lists, n_shards, q, Q, W, query_cond, masks, n_masks, k1, k2, sentinel, slot, any_fail, topk, stream);
 }
 
 extern "C" int mfar_merge_topk(int device, const void* gathered_topk, int n_shards, int Q, int k2, int64_t* ids, float* scores,

@@ -68,6 +68,7 @@ SIGNATURES = {
     "mfar_topk_bytes": (_i64, [_i, _i]),
     "mfar_retrieve_lists": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "mfar_search_owned": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mfar_search_owned_masks": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mfar_merge_topk": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "mfar_stream_wait_stage1_start": (_i, [_vp, _vp]),
     "mfar_set_timing": (_i, [_vp, _i]),

@@ -4,7 +4,7 @@ Same keyword-only flags as the reference `main` (pinned by tests/golden/cli_sign
 (baseline, one run per field, all-sparse, all-dense, one run per field NAME; mask_fields.py:143-170) and the same output
 files ({out}/{rank}.qres, additional_{rank}.qres, final-*all-0.qres, results_dicts-all-0.jsonl).  The corpus is encoded
 into HBM once and reused by every masked run -- only the mixer changes with the mask -- instead of being re-encoded by
-each of the 1+F+1+F `trainer.test` calls (contrastive.py:553-554); on one rank with dense fields the whole sweep is ONE
+each of the 1+F+1+F `trainer.test` calls (contrastive.py:553-554); with dense fields the whole sweep is ONE
 pass over the queries (queries encoded once, stages 1 and 2 once per batch, the mixer once per mask).  Launch one process per GPU with torch.distributed.run
 for row-sharded multi-GPU evaluation; a single process uses GPU 0.
 """
@@ -56,7 +56,7 @@ def main(
         runs += [dense_idx] if dense_idx else []
         runs += [[i for i, f in enumerate(fields) if f.name == name] for name in sorted({f.name for f in fields})]
     print("Baseline Evaluation")
-    # one rank, dense fields: the whole sweep in ONE pass over the queries (the mask only enters the mixer; contrastive.py
+    # dense fields: the whole sweep in ONE pass over the queries (the mask only enters the mixer; contrastive.py
     # test_sweep; MFAR_MASK_SWEEP=0 switches it off); otherwise one `test()` per run as the reference does
     if os.environ.get("MFAR_MASK_SWEEP", "1") != "0" and module.test_sweep(data_module, runs):
         if not debug and not sparse_idx:

@@ -334,6 +334,21 @@ class MultiFieldIndex:
                                                        _current_stream(self.device, True)))
         return topk
 
+    def search_owned_masks(self, gathered_lists, n_shards: int, q, W, topk, masks, k1: int = 100, k2: int = 100, sentinel: bool = True,
+                           query_cond: bool = True, slot: int = 0, any_fail=None):
+        """`search_owned` for a sweep of field masks [M, F]: `topk` receives M payloads of topk_bytes() each, back to back."""
+        qa, Wa = _Arg(q, np.float32, self.device), _Arg(W, np.float32, self.device)
+        ma = _Arg(masks, np.float32, self.device)
+        ga, ta = _Arg(gathered_lists, np.uint8, self.device), _Arg(topk, np.uint8, self.device)
+        if not _same_side([qa, Wa, ma, ga, ta]):
+            raise ValueError("search_owned_masks needs CUDA tensors")
+        _native.check(_native.lib().mfar_search_owned_masks(self._h, ga.ptr, int(n_shards), qa.ptr, qa.keep.shape[0], Wa.ptr,
+                                                             int(bool(query_cond)), ma.ptr, int(ma.keep.shape[0]), int(k1), int(k2),
+                                                             int(bool(sentinel)), int(slot),
+                                                             None if any_fail is None else _dev_ptr(any_fail), ta.ptr,
+                                                             _current_stream(self.device, True)))
+        return topk
+
     # instrumentation for bench.py
     def set_timing(self, enable: bool):
         _native.check(_native.lib().mfar_set_timing(self._h, int(bool(enable))))

@@ -39,7 +39,8 @@ class PipelinedSearcher:
                  max_batch: int = 64, group=None, coalesce=None, exchange=None, masks=None):
         self.ix, self.W, self.mask = index, W, mask
         # masks [M, F]: a SWEEP of field masks (mask_fields.py:143-170) -- stage 1, the candidate union and stage 2 run once per
-        # launch, the mixer once per mask; results then carry a leading mask dimension.  One shard only.
+        # launch, the mixer once per mask; results then carry a leading mask dimension.  With several ranks the second all-gather
+        # carries one local top-k payload per mask.
         self.masks = None if masks is None else masks.float().contiguous()
         self.M = 0 if masks is None else int(self.masks.shape[0])
         self.k1, self.k2, self.sentinel, self.query_cond = k1, k2, sentinel, query_cond
@@ -49,8 +50,6 @@ class PipelinedSearcher:
         # exchange=True runs the lists-first exchange (the two all-gathers + owned scoring + merge) even with ONE rank: the
         # RCCL code path of the multi-GPU pipeline can then be exercised on a one-GPU box (tests/test_gpu_multirank.py)
         self.sharded = self.world > 1 if exchange is None else bool(exchange)
-        if self.sharded and self.M:
-            raise ValueError("a mask sweep runs on one shard (run the masks one after the other across ranks)")
         if self.sharded and not (dist.is_available() and dist.is_initialized()):
             raise ValueError("the exchange path needs an initialised torch.distributed process group")
         self.dev = torch.device(f"cuda:{index.device}")
@@ -99,8 +98,9 @@ class PipelinedSearcher:
                 nl, nt = index.lists_bytes(self.Qmax, k1), index.topk_bytes(self.Qmax, k2)
                 s["lists"] = torch.empty(nl, dtype=torch.uint8, device=self.dev)
                 s["lists_all"] = torch.empty(nl * self.world, dtype=torch.uint8, device=self.dev)
-                s["topk"] = torch.empty(nt, dtype=torch.uint8, device=self.dev)
-                s["topk_all"] = torch.empty(nt * self.world, dtype=torch.uint8, device=self.dev)
+                s["topk"] = torch.empty(nt * max(1, self.M), dtype=torch.uint8, device=self.dev)
+                s["topk_all"] = torch.empty(nt * max(1, self.M) * self.world, dtype=torch.uint8, device=self.dev)
+                self._nt = nt
             s["done"].record(torch.cuda.current_stream(self.dev))
             self.slots.append(s)
         self.n_submitted = 0          # batches (tickets)
@@ -130,8 +130,20 @@ class PipelinedSearcher:
                 dense = dict(ids=s["ids"].view(-1)[:self.M * Q * self.k2].view(self.M, Q, self.k2),
                              scores=s["scores"].view(-1)[:self.M * Q * self.k2].view(self.M, Q, self.k2),
                              n_valid=s["n_valid"].view(-1)[:self.M * Q].view(self.M, Q))
-            self.ix.search_stage2_masks(qk, s["W"], s["fid"][:Q], self.masks, self.k1, self.k2, self.query_cond, slot=slot, out=dense)
             s["dense_Q"] = Q
+            if not self.sharded:
+                self.ix.search_stage2_masks(qk, s["W"], s["fid"][:Q], self.masks, self.k1, self.k2, self.query_cond, slot=slot, out=dense)
+            else:       # (sharded launches always hold Qmax queries)
+                dist = torch.distributed
+                dist.all_gather_into_tensor(s["lists_all"], s["lists"], group=self.group)
+                self.ix.search_owned_masks(s["lists_all"], self.world, qk, s["W"], s["topk"], self.masks, self.k1, self.k2, self.sentinel,
+                                           self.query_cond, slot=slot, any_fail=s["fail"])
+                dist.all_gather_into_tensor(s["topk_all"], s["topk"], group=self.group)
+                per_rank = s["topk_all"].view(self.world, self.M, self._nt)
+                for m in range(self.M):     # the payloads of mask m from every rank, back to back, as merge_topk reads them
+                    _index.merge_topk(per_rank[:, m].contiguous().view(-1), self.world, Q, self.k2, device=self.ix.device,
+                                      out=dict(ids=dense["ids"][m], scores=dense["scores"][m], n_valid=dense["n_valid"][m]),
+                                      any_fail=s["fail"])
         elif not self.sharded:
             self.ix.search_stage2(qk, s["W"], s["fid"][:Q], s["mask"], self.k1, self.k2, self.query_cond, slot=slot, out=out)
         else:

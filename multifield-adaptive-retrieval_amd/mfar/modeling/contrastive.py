@@ -387,11 +387,12 @@ class RetrievalTrainingModule(torch.nn.Module):
         mixer once per mask (`mfar_search_stage2_masks`).  Afterwards the runs are replayed in order -- `mask_field`, the
         rank's .qres files, `merge_qres_and_score` -- so the output files, the printed metrics and results_dicts-*.jsonl
         are what the 2 F + 2 separate `test()` calls leave behind.  `field_idx_lists`: one list of masked field indices per
-        run (empty = baseline).  Returns False without doing anything when the sweep path does not apply (several ranks:
-        the exchange is per mask; sparse fields: scored on the host) -- the caller then runs the masks one by one."""
+        run (empty = baseline).  With several ranks the rows stay sharded and the second all-gather of the exchange carries one
+        local top-k payload per mask.  Returns False without doing anything when the sweep path does not apply (sparse
+        fields: scored on the host) -- the caller then runs the masks one by one."""
         from mfar.data.pipeline import PipelinedSearcher
         rank, world = _dist()
-        if world > 1 or self.has_sparse or not field_idx_lists:
+        if self.has_sparse or not field_idx_lists:
             return False
         data_module.setup("test")
         was_training = self.training
@@ -406,7 +407,7 @@ class RetrievalTrainingModule(torch.nn.Module):
         ps = PipelinedSearcher(self.slab, self._weights(), None, k1=TOP_K, k2=TOP_K, sentinel=True, query_cond=self.query_cond,
                                max_batch=qmax, masks=masks.to(self.device))
         tmp = [[f"{self.out_dir}/.sweep_{m}_{li}_{rank}.qres" for li in range(2)] for m in range(M)]
-        files = [[open(fn, "w") for fn in pair] for pair in tmp]
+        files = [[open(fn, "w") for fn in pair] for pair in tmp] if rank == 0 else None
         keys = self.numeric_ids_to_keys
 
         def collect(item):
@@ -415,6 +416,8 @@ class RetrievalTrainingModule(torch.nn.Module):
             n = len(data)
             if int(res["n_valid"][:, :n].min()) < TOP_K:                         # what torch.topk raises at :696
                 raise RuntimeError(f"selected index k out of range: fewer than k={TOP_K} candidates")
+            if rank != 0:
+                return
             ids, sims = res["ids"][:, :n].cpu().tolist(), res["scores"][:, :n].cpu().tolist()
             for m in range(M):
                 files[m][li].write("".join(f"{q._id}\t0\t{keys[d]}\t0\t{s}\t0\n" for q, row_ids, row_sims in zip(data, ids[m], sims[m])
@@ -426,23 +429,30 @@ class RetrievalTrainingModule(torch.nn.Module):
                 for batch in loader:
                     x = self.encode_query_batch(batch)
                     for b in range(0, x.shape[0], ps.Qb):
-                        pending.append((ps.submit(x[b:b + ps.Qb].contiguous()), batch.instances[b:b + ps.Qb], min(li, 1)))
+                        xb = x[b:b + ps.Qb]
+                        n = xb.shape[0]
+                        if ps.sharded and n < ps.Qb:       # fixed exchange size: pad with copies of the last query (results are dropped)
+                            xb = torch.cat([xb, xb[-1:].expand(ps.Qb - n, -1)])
+                        pending.append((ps.submit(xb.contiguous()), batch.instances[b:b + n], min(li, 1)))
                         while len(pending) > ps.lag:
                             collect(pending.popleft())
             while pending:
                 collect(pending.popleft())
-        for pair in files:
+        for pair in files or []:
             for f in pair:
                 f.close()
         for m, idx in enumerate(field_idx_lists):                                # replay the runs in order
             if idx:
                 self.mask_field(list(idx))
+            if rank != 0:
+                continue                                                         # rank 0 holds every query's results
             os.replace(tmp[m][0], f"{self.out_dir}/{rank}.qres")
             os.replace(tmp[m][1], f"{self.out_dir}/additional_{rank}.qres")
             has_additional = os.path.getsize(f"{self.out_dir}/additional_{rank}.qres") > 0
             self.merge_qres_and_score([f"{self.out_dir}/{rank}.qres"], self.dev_qrels_path)
             if has_additional:
                 self.merge_qres_and_score([f"{self.out_dir}/additional_{rank}.qres"], self.additional_qrels_path, additional="additional-")
+        _barrier()
         if was_training:
             self.train()
         return True

@@ -42,7 +42,22 @@ for dtype, (F, D, E) in (("f32", (4, 40000, 128)), ("bf16", (3, 20000, 64))):
         got.append({k: v.clone() for k, v in ps.result(t).items()})
     same = all(torch.equal(g["ids"], p["ids"]) and torch.equal(g["scores"], p["scores"]) and torch.equal(g["n_valid"], p["n_valid"])
                for g, p in zip(got, plain))
-    out[dtype] = dict(same=bool(same), coalesce=ps.coalesce, n=len(got), redone=ps.n_redone)
+    # a sweep of field masks through the same exchange: one local top-k payload per mask in the second all-gather
+    masks = torch.ones(3, F, device="cuda")
+    masks[1, 0] = 0
+    masks[2, 1:] = 0
+    want = [[ix.search(q, W, masks[m].contiguous()) for q in qs] for m in range(3)]
+    pm = PipelinedSearcher(ix, W, None, max_batch=64, exchange=True, masks=masks)
+    tickets, gm = [], []
+    for i, q in enumerate(qs):
+        tickets.append(pm.submit(q))
+        if i >= pm.lag:
+            gm.append({k: v.clone() for k, v in pm.result(tickets[i - pm.lag]).items()})
+    for t in tickets[max(0, len(qs) - pm.lag):]:
+        gm.append({k: v.clone() for k, v in pm.result(t).items()})
+    sweep_same = all(torch.equal(g["ids"][m], want[m][i]["ids"]) and torch.equal(g["scores"][m], want[m][i]["scores"])
+                     for i, g in enumerate(gm) for m in range(3))
+    out[dtype] = dict(same=bool(same), coalesce=ps.coalesce, n=len(got), redone=ps.n_redone, sweep_same=bool(sweep_same))
     ix.close()
 dist.barrier()
 dist.destroy_process_group()

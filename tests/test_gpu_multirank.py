@@ -47,4 +47,15 @@ def test_exchange_path_over_rccl_with_one_rank():
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["f32"]["same"] and res["bf16"]["same"], res
+    assert res["f32"]["sweep_same"] and res["bf16"]["sweep_same"], res      # PipelinedSearcher(masks=...) over the exchange
     assert res["f32"]["coalesce"] == 2 and res["f32"]["n"] == 7 and res["f32"]["redone"] == 0, res
+
+
+def test_mask_sweep_over_two_row_shards():
+    """PipelinedSearcher(masks=...) with two ranks (gloo, sharing cuda:0): per mask the sharded sweep equals the unsharded search."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "tests", "helpers", "two_rank_sweep.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["same"] and res["n"] == 5 and res["world"] == 2, res
