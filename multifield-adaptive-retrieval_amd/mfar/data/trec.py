@@ -79,17 +79,44 @@ def _dcg(gains) -> float:
     return sum(g / math.log2(i + 2) for i, g in enumerate(gains))
 
 
-def compute_metrics(qrels: Iterable[QRels], qres: Iterable[QRes]) -> Dict[str, float]:
+_CUTS = (5, 10, 15, 20, 30, 100, 200, 500, 1000)
+_DISCOUNT = [math.log2(i + 2) for i in range(1024)]
+
+
+def _dcg_prefix(gains) -> List[float]:
+    """out[k] = _dcg(gains[:k]) with the additions in the same left-to-right order."""
+    out, tot = [0.0], 0
+    disc = _DISCOUNT
+    for i, g in enumerate(gains):
+        tot = tot + g / (disc[i] if i < 1024 else math.log2(i + 2))
+        out.append(tot)
+    return out
+
+
+def read_qres_tuples(f: TextIO) -> List[Tuple[str, str, float]]:
+    """(query_id, doc_id, sim) of every line of a .qres file: what `QRes.from_text_io` parses, without the dataclasses (an
+    evaluation reads 100 lines per query; a mask sweep reads them 2 F + 2 times)."""
+    out = []
+    for line in f:
+        q, _, d, _, sim, _ = line.split()
+        out.append((q, d, float(sim)))
+    return out
+
+
+def compute_metrics(qrels: Iterable[QRels], qres) -> Dict[str, float]:
     """map, recip_rank, Rprec, ndcg, ndcg_cut_k, recall_k, success_k, P_k averaged over the queries that appear in the
     run and have at least one relevant document (trec_eval's default averaging).  Ranking: sim descending, ties by
-    doc id descending (trec_eval's tie rule); the rank column is ignored like trec_eval does."""
+    doc id descending (trec_eval's tie rule); the rank column is ignored like trec_eval does.
+    `qres`: QRes records or (query_id, doc_id, sim) tuples."""
     rel = defaultdict(dict)
     for r in qrels:
         rel[r.query_id][r.doc_id] = r.relevance
     runs = defaultdict(list)
     for r in qres:
-        runs[r.query_id].append((r.sim, r.doc_id))
-    cuts = (5, 10, 15, 20, 30, 100, 200, 500, 1000)
+        if isinstance(r, tuple):
+            runs[r[0]].append((r[2], r[1]))
+        else:
+            runs[r.query_id].append((r.sim, r.doc_id))
     sums = defaultdict(float)
     nq = 0
     for qid, docs in runs.items():
@@ -100,28 +127,35 @@ def compute_metrics(qrels: Iterable[QRels], qres: Iterable[QRes]) -> Dict[str, f
         docs = sorted(docs, key=lambda t: t[1], reverse=True)
         docs.sort(key=lambda t: t[0], reverse=True)
         ranked = [d for _, d in docs]
-        hits = [1 if d in pos else 0 for d in ranked]
+        n = len(ranked)
         R = len(pos)
         cum, ap, rr = 0, 0.0, 0.0
-        for i, h in enumerate(hits):
-            if h:
+        hits_prefix = [0]                                  # hits_prefix[k] = relevant documents among the first k
+        gains = []
+        for i, d in enumerate(ranked):
+            g = pos.get(d)
+            if g is not None:
                 cum += 1
                 ap += cum / (i + 1)
                 if rr == 0.0:
                     rr = 1.0 / (i + 1)
+                gains.append(g)
+            else:
+                gains.append(0.0)
+            hits_prefix.append(cum)
         sums["map"] += ap / R
         sums["recip_rank"] += rr
-        sums["Rprec"] += sum(hits[:R]) / R
+        sums["Rprec"] += hits_prefix[min(R, n)] / R
         ideal = sorted(pos.values(), reverse=True)
-        gains = [pos.get(d, 0.0) for d in ranked]
-        sums["ndcg"] += _dcg(gains) / _dcg(ideal)
-        for k in cuts:
-            top = sum(hits[:k])
+        dcg, idcg = _dcg_prefix(gains), _dcg_prefix(ideal)
+        sums["ndcg"] += dcg[n] / idcg[R]
+        for k in _CUTS:
+            top = hits_prefix[min(k, n)]
             sums[f"recall_{k}"] += top / R
             sums[f"P_{k}"] += top / k
-            sums[f"ndcg_cut_{k}"] += _dcg(gains[:k]) / _dcg(ideal[:k])
+            sums[f"ndcg_cut_{k}"] += dcg[min(k, n)] / idcg[min(k, R)]
         for k in (1, 5, 10):
-            sums[f"success_{k}"] += 1.0 if sum(hits[:k]) > 0 else 0.0
+            sums[f"success_{k}"] += 1.0 if hits_prefix[min(k, n)] > 0 else 0.0
     return {k: (v / nq if nq else 0.0) for k, v in sums.items()}
 
 
@@ -131,7 +165,7 @@ def call_trec_eval_and_get_metrics(qrels: str, qres: str) -> Dict[str, float]:
         proc = subprocess.run(["trec_eval", "-m", "all_trec", qrels, qres], stdout=subprocess.PIPE, check=True)
         return parse_trec_eval_output(proc.stdout.decode("utf-8"))
     with open(qrels) as f1, open(qres) as f2:
-        return compute_metrics(QRels.from_text_io(f1), QRes.from_text_io(f2))
+        return compute_metrics(QRels.from_text_io(f1), read_qres_tuples(f2))
 
 
 def read_corpus(path: str) -> Iterable[Tuple[str, object]]:
