@@ -178,8 +178,29 @@ class RetrievalTrainingModule(torch.nn.Module):
             slot = {t: i for i, t in enumerate(uniq)}
             order = sorted(range(len(uniq)), key=lambda i: len(uniq[i]))
             emb_u = torch.empty(len(uniq), self.slab.dim, device=self.device)
-            stream = candidate_encoding_stream(self.encoder, ((i, uniq[i]) for i in order), batch_size=bs, multiprocess=False,
-                                               show_progress=False, as_tensor=True)             # contrastive.py:483-489
+            # Batches by TOKEN budget, not by count: `dev_batch_size` texts of `max_seq_length` tokens is the largest forward the
+            # caller sized memory for; short texts (names, types, the relation fields of STaRK-prime) are launch-bound at 64 per
+            # forward, so a batch takes as many of them as fit that budget (at least dev_batch_size; MFAR_ENCODE_TOKEN_BUDGET=0:
+            # always dev_batch_size).  Lengths ascend, so the last text of a batch is its longest.
+            max_len = int(self.encoder.get_max_seq_length())
+            budget = bs * max_len if os.environ.get("MFAR_ENCODE_TOKEN_BUDGET", "1") != "0" else 0
+
+            def batches():
+                pos = 0
+                while pos < len(order):
+                    n = min(bs, len(order) - pos)
+                    if budget:
+                        n = min(4096, len(order) - pos)
+                        while n > bs and n * min(max_len, len(uniq[order[pos + n - 1]]) // 3 + 8) > budget:
+                            n = max(bs, (n * 3) // 4)
+                    yield [(i, uniq[i]) for i in order[pos:pos + n]]
+                    pos += n
+
+            def stream_all():
+                for group in batches():                                          # one forward per group (contrastive.py:483-489)
+                    yield from candidate_encoding_stream(self.encoder, group, batch_size=len(group), multiprocess=False,
+                                                         show_progress=False, as_tensor=True)
+            stream = stream_all()
             got, vecs = [], []
             # MFAR_ENCODE_AUTOCAST=bf16|fp16: run the corpus-encode forwards under autocast ("bf16 encoder").  Off by
             # default: the reference encodes the corpus in fp32 (its precision plugin wraps the steps, not on_test_epoch_start);
@@ -189,7 +210,7 @@ class RetrievalTrainingModule(torch.nn.Module):
                 for i, v in stream:
                     got.append(i)
                     vecs.append(v)
-                    if len(got) == bs:
+                    if len(got) == 4096:
                         emb_u[torch.tensor(got, device=self.device)] = torch.stack(vecs).float()
                         got, vecs = [], []
             if got:
