@@ -16,9 +16,19 @@ def init_distributed_from_env() -> None:
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        local = _local_device()
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        # MFAR_DIST_BACKEND=gloo + MFAR_SHARE_GPU=1: several ranks on ONE GPU (RCCL refuses two ranks on a device) -- how the
+        # row-sharded CLIs are rehearsed on a one-GPU box (tests/test_gpu_multirank.py)
+        backend = os.environ.get("MFAR_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
+
+
+def _local_device() -> int:
+    return 0 if os.environ.get("MFAR_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
 
 
 def build(flags: dict, freeze_encoder: bool = False) -> SimpleNamespace:
@@ -29,7 +39,7 @@ def build(flags: dict, freeze_encoder: bool = False) -> SimpleNamespace:
     init_distributed_from_env()
     if f.get("data"):
         f["queries"] = f["corpus"] = f["data"]
-    device = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
+    device = torch.device(f"cuda:{_local_device()}")
     field_info = resolve_fields(f["field_names"], f["dataset_name"])
     model_id = f.get("model_path") or f["model_name"]
     tokenizer, encoder, _ = prepare_model(model_id, normalize=f["normalize"], with_decoder=False, freeze_encoder=freeze_encoder)

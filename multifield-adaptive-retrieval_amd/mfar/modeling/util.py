@@ -237,9 +237,10 @@ def prepare_model(model_id: str, with_decoder: bool = False, normalize: bool = F
 
 def _dist_info() -> Tuple[int, int, int]:
     import torch.distributed as dist
+    share = os.environ.get("MFAR_SHARE_GPU") == "1"        # several ranks rehearsed on ONE GPU (mfar/commands/_setup.py)
     if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size(), int(os.environ.get("LOCAL_RANK", dist.get_rank()))
-    return 0, 1, int(os.environ.get("LOCAL_RANK", "0"))
+        return dist.get_rank(), dist.get_world_size(), 0 if share else int(os.environ.get("LOCAL_RANK", dist.get_rank()))
+    return 0, 1, 0 if share else int(os.environ.get("LOCAL_RANK", "0"))
 
 
 def read_and_create_indices(corpus_path, dataset_name, field_info, temp_dir, encoder):

@@ -59,3 +59,30 @@ def test_mask_sweep_over_two_row_shards():
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["same"] and res["n"] == 5 and res["world"] == 2, res
+
+
+def test_mask_fields_cli_over_two_row_shards(tmp_path, monkeypatch):
+    """The product CLI with two ranks (gloo, sharing cuda:0): each rank encodes and holds half of the corpus, `test_sweep` runs
+    the whole mask sweep through the lists-first exchange; the files equal a single process's, byte for byte."""
+    sys.path.insert(0, os.path.join(ROOT, "multifield-adaptive-retrieval_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_cli as T
+    from mfar.commands import mask_fields, train
+    data = str(tmp_path / "data")
+    T._write_dataset(data)
+    out, tmp = str(tmp_path / "out"), str(tmp_path / "tmp")
+    train.main(dataset_name="amazon", lexical_index="unused", out=out, temp_dir=tmp, data=data, model_name="random-init:64x2",
+               field_names="title_dense,brand_dense,feature_dense", weights_lr=1e-2, encoder_lr=1e-4, train_batch_size=8,
+               dev_batch_size=16, max_epochs=1, precision="32", additional_partition="test")
+    monkeypatch.setenv("MFAR_ENCODE_TOKEN_BUDGET", "0")      # with dev_batch_size = 1: every text is encoded alone, in both runs
+    one = str(tmp_path / "one")
+    mask_fields.main(dataset_name="amazon", lexical_index="unused", out=one, temp_dir=tmp, data=data, model_name="random-init:64x2",
+                     field_names="title_dense,brand_dense,feature_dense", checkpoint_dir=out, dev_batch_size=1, additional_partition="test")
+    two = str(tmp_path / "two")
+    env = dict(os.environ, MFAR_DIST_BACKEND="gloo", MFAR_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "tests", "helpers", "two_rank_mask_fields.py"), data, str(tmp_path / "tmp2"), out, two]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    for fn in ("results_dicts-all-0.jsonl", "final-all-0.qres", "final-additional-all-0.qres"):
+        assert open(f"{one}/{fn}").read() == open(f"{two}/{fn}").read(), fn
