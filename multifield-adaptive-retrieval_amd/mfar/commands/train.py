@@ -97,20 +97,47 @@ class _Instances:
 
 
 def _encode_fields(module, tokenizer, docs, max_length, device):
-    """[(id, json)] -> [B, F, E] (one encoder forward per dense field, contrastive.py:412-414)."""
-    outs = []
-    for field in module.field_info.values():
-        if field.field_type != FieldType.DENSE:
-            continue
+    """[(id, json)] -> [B, F, E] (contrastive.py:412-414 runs one encoder forward per dense field).  Here the F x B texts are
+    tokenised per field (each field keeps its own truncation length), sorted by length and encoded in as few forwards as a
+    token budget allows: the fields of STaRK records are mostly short texts, and 2 F forwards of B short texts per training
+    step are launch-bound (22 fields: 44 forwards + 44 small backward graphs per step).  A text's embedding does not depend
+    on what it is batched with (padding is masked), so the loss is the reference's; MFAR_TRAIN_FUSED_ENCODE=0 restores one
+    forward per field."""
+    fields = [f for f in module.field_info.values() if f.field_type == FieldType.DENSE]
+    if not fields:                                 # an all-sparse field set: no dense columns
+        return torch.zeros(len(docs), 0, module.encoder.get_sentence_embedding_dimension(), device=device)
+    B, F = len(docs), len(fields)
+    enc_max = module.encoder.get_max_seq_length()
+    per_field = []
+    for field in fields:
         texts = [t for _, t in format_documents(docs, field.name, field.dataset)]
         if module.prefix:
             texts = [field.name + ": " + t for t in texts]
-        toks = tokenizer(texts, padding=True, truncation=True, max_length=min(max_length, field.max_seq_length, module.encoder.get_max_seq_length()),
-                         return_tensors="pt")
-        outs.append(module.encoder({k: v.to(device) for k, v in toks.items()})["sentence_embedding"])
-    if not outs:                                   # an all-sparse field set: no dense columns
-        return torch.zeros(len(docs), 0, module.encoder.get_sentence_embedding_dimension(), device=device)
-    return torch.stack(outs, dim=1)
+        per_field.append((texts, min(max_length, field.max_seq_length, enc_max)))
+    if os.environ.get("MFAR_TRAIN_FUSED_ENCODE", "1") == "0":
+        outs = []
+        for texts, L in per_field:
+            toks = tokenizer(texts, padding=True, truncation=True, max_length=L, return_tensors="pt")
+            outs.append(module.encoder({k: v.to(device) for k, v in toks.items()})["sentence_embedding"])
+        return torch.stack(outs, dim=1)
+    seqs = []                                      # token ids of text (field f, document b) at index f * B + b
+    for texts, L in per_field:
+        seqs += tokenizer(texts, padding=False, truncation=True, max_length=L)["input_ids"]
+    order = sorted(range(len(seqs)), key=lambda i: len(seqs[i]))
+    budget = max(B * enc_max, 8192)                # padded tokens per forward: what ONE per-field forward may already take
+    out = [None] * len(seqs)
+    pos = 0
+    while pos < len(order):
+        n = 1
+        while pos + n < len(order) and (n + 1) * len(seqs[order[pos + n]]) <= budget:
+            n += 1
+        idx = order[pos:pos + n]
+        toks = tokenizer.pad({"input_ids": [seqs[i] for i in idx]}, padding=True, return_tensors="pt")
+        emb = module.encoder({k: v.to(device) for k, v in toks.items() if k in ("input_ids", "attention_mask", "token_type_ids")})["sentence_embedding"]
+        for j, i in enumerate(idx):
+            out[i] = emb[j]
+        pos += n
+    return torch.stack(out).view(F, B, -1).transpose(0, 1)
 
 
 def _sparse_columns(module, inst, rows, negs, device, sparse_scores):

@@ -190,6 +190,47 @@ def test_sentence_encoder_structure():
         prepare_model("/definitely/not/a/model")
 
 
+def test_training_step_encodes_all_fields_in_few_forwards(monkeypatch):
+    """train._encode_fields: the F x B field texts of a training batch go through the encoder in as few forwards as a token
+    budget allows (per-field truncation lengths kept) -- same [B, F, E] embeddings as one forward per field
+    (contrastive.py:412-414), gradients reach the encoder, and the number of forwards drops."""
+    import json
+    from types import SimpleNamespace
+    import torch
+    from mfar.commands import train
+    from mfar.data.schema import resolve_fields
+    from mfar.modeling.util import prepare_model
+    tok, enc, _ = prepare_model("random-init:64x2")
+    enc.eval()
+    rng = np.random.default_rng(3)
+    words = ["red", "blue", "shoe", "hat", "acme", "zen", "light", "heavy", "wool", "cotton"]
+    docs = [(str(i), {"title": " ".join(rng.choice(words, int(rng.integers(1, 9)))), "brand": str(rng.choice(words)),
+                      "feature": [str(w) for w in rng.choice(words, int(rng.integers(0, 5)))]}) for i in range(7)]
+    docs[3] = ("3", {"title": "only a title"})                                    # missing fields -> ""
+    module = SimpleNamespace(field_info=resolve_fields("title_dense,brand_dense,feature_dense", "amazon"), prefix=True, encoder=enc)
+    calls = []
+    orig = enc.forward
+    monkeypatch.setattr(enc, "forward", lambda feats: (calls.append(feats["input_ids"].shape), orig(feats))[1])
+    fused = train._encode_fields(module, tok, docs, 512, torch.device("cpu"))
+    n_fused = len(calls)
+    monkeypatch.setenv("MFAR_TRAIN_FUSED_ENCODE", "0")
+    calls.clear()
+    per_field = train._encode_fields(module, tok, docs, 512, torch.device("cpu"))
+    assert fused.shape == per_field.shape == (7, 3, 64) and len(calls) == 3 and n_fused == 1
+    np.testing.assert_allclose(fused.detach().numpy(), per_field.detach().numpy(), rtol=1e-4, atol=1e-5)
+    fused.sum().backward()
+    assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in enc.parameters())
+    # a field's own truncation length is kept (brand: 16 tokens, schema.py) when texts of all fields share a forward
+    long_brand = [("0", {"title": "t", "brand": "x " * 200, "feature": []})]
+    monkeypatch.setenv("MFAR_TRAIN_FUSED_ENCODE", "1")
+    calls.clear()
+    a = train._encode_fields(module, tok, long_brand, 512, torch.device("cpu"))
+    assert sorted(s[1] for s in calls)[-1] <= 16                                   # nothing longer than brand's 16 tokens was fed
+    monkeypatch.setenv("MFAR_TRAIN_FUSED_ENCODE", "0")
+    b = train._encode_fields(module, tok, long_brand, 512, torch.device("cpu"))
+    np.testing.assert_allclose(a.detach().numpy(), b.detach().numpy(), rtol=1e-4, atol=1e-5)
+
+
 def test_format_single_golden(golden_dir):
     """The whole-document text of the single_dense field (format.py:20-22, 113-415), per dataset, incl. the records the
     reference cannot format (it raises UnboundLocalError; so does the mirror)."""
