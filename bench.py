@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--empty-frac", type=float, default=0.08,
                     help="share of (document, field) pairs that hold the field's empty-text vector (real STaRK fields are sparse; "
                          "0.08 = the headline corpus)")
+    ap.add_argument("--stage2", choices=["auto", "full"], default="auto",
+                    help="auto: certified two-level stage 2 (fp16 gather slab -> bounds -> fp32 rows of the survivors; bit-identical); "
+                         "full: gather every (candidate, field) row from the fp32 slab")
     ap.add_argument("--coalesce", type=int, default=0, help="batches scanned per launch (0 = auto: 2 when the wide screened pass is available)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the exact-fp32 leg and the structured-corpus leg")
@@ -202,6 +205,8 @@ def main():
         ix.set_screen(0)
     elif args.screen == "on":
         ix.set_screen(2)
+    if args.stage2 == "full":
+        ix.set_stage2_mode(0)
     mode, eps_mult = ix.screen_setting
     if eps_mult != 1.0:
         raise SystemExit(f"screen eps_mult = {eps_mult}: the certificate would not be the rigorous one")
@@ -259,9 +264,9 @@ def main():
     t_build += time.time() - t_prime
     results = []
     run(ps, corpus, 0, args.warmup, None)
-    scr0 = ix.screen_stats()
+    scr0, st2_0 = ix.screen_stats(), ix.stage2_stats()
     dt, s1_avg_ms, s1_n = timed(ps, ix, corpus, args.warmup, args.steps, results)
-    scr = ix.screen_stats()
+    scr, st2 = ix.screen_stats(), ix.stage2_stats()
     screened = bool(scr["built"])                            # stage 1 ran on the fp16 screen slab of the index
 
     # ---- the dominant kernel with nothing beside it: the same scans issued serially on one stream (the split-phase tail of the
@@ -382,6 +387,13 @@ def main():
             "screen": ({"lists_certified": (scr["n_checked"] - scr0["n_checked"]) - (scr["n_failed"] - scr0["n_failed"]),
                         "lists_redone_exactly": scr["n_failed"] - scr0["n_failed"], "batches_redone": ps.n_redone,
                         "screen_slab_bytes": scr["screen_bytes"], "unique_rows_per_field": scr.get("unique_rows")} if screened else None),
+            "stage2": ({"mode": "certified two-level (fp16 gather slab -> interval bounds through the mixer's chain -> fp32 rows of the survivors)",
+                        "gather_slab_bytes": st2["gather_slab_bytes"],
+                        "candidates_per_query": (st2["n_candidates"] - st2_0["n_candidates"]) / max(1, args.steps * Q),
+                        "survivors_per_query": (st2["n_survivors"] - st2_0["n_survivors"]) / max(1, args.steps * Q)}
+                       if st2["two_level"] and st2["n_candidates"] > st2_0["n_candidates"] else
+                       {"mode": "every (candidate, field) row gathered" + (" from the row-major bf16 companion" if st2["gather_slab_bytes"] else ""),
+                        "gather_slab_bytes": st2["gather_slab_bytes"]}),
             "ms_per_launch": dt / args.steps * 1e3 * ps.coalesce,
             "recall_at_20": recall20, "ids_checksum": checksum, "index_build_s": t_build, "source_hash": source_hash(),
             "diagnostic_knobs": {"MFAR_S1_DEBUG": "unset", "screen_eps_mult": eps_mult},

@@ -43,7 +43,9 @@ extern "C" {
 
 typedef struct mfar_index mfar_index;
 
-/* library / device probes (no reference counterpart) */
+/* library / device probes (no reference counterpart).  mfar_version() == MFAR_ABI_VERSION of the header the caller was built
+ * against, or the caller must refuse the library: the value changes with every signature change. */
+#define MFAR_ABI_VERSION 101
 int mfar_version(void);
 const char* mfar_last_error(void);
 int mfar_device_count(int* n_out);
@@ -285,6 +287,25 @@ int mfar_screen_stats(mfar_index* idx, int* built, int64_t* screen_bytes, int64_
 /* After the screen was built: the number of distinct vectors of a field (what the screened pass scans) and the size of its
  * largest group of bit-identical rows; -1 while no screen is current. */
 int mfar_screen_field_info(mfar_index* idx, int field, int64_t* n_unique_rows, int64_t* largest_group);
+
+/*
+ * Certified two-level stage 2 (no reference counterpart; the outputs of every entry point above are bit-identical with and
+ * without it).  Stage 2 == DenseFlatIndex.score_batch x F (data/index.py:227-232, contrastive.py:681-683) gathers one row per
+ * (candidate, field) pair, and the candidate union grows with the number of fields: F^2 * k1 rows per query.  With the gather
+ * slab -- a row-major 16-bit copy of every row, built with the screen: fp16 of the centred + scaled values for an fp32 index
+ * (+50 % HBM), the bf16 values themselves for a bf16 index (+100 %, whole-line gathers instead of 32-byte segments) -- an fp32
+ * index scores every pair APPROXIMATELY at half the bytes, bounds every candidate's mixed score (contrastive.py:685-694) from both
+ * sides with a rigorous error bound evaluated through the mixer's own fma chain, and gathers fp32 rows only for the candidates
+ * whose upper bound reaches the k2-th largest lower bound (csrc/mfar_select.h: mfar_s2_prune_kernel); those are mixed exactly as
+ * before, so ids and score bits of the top-k2 do not change.
+ *   mode   0 = gather every (candidate, field) row from the fp32 slab, 1 = two-level when available (default; fp32 index whose
+ *          screen and gather slab are current, more candidates than k2).  Environment default: MFAR_STAGE2_PRUNE;
+ *          MFAR_GATHER_SLAB=0 never allocates a gather slab.  The error bound is scaled by mfar_set_screen's eps_mult (test knob).
+ * mfar_stage2_stats synchronises the device: candidates the prune kernel has seen / survivors it kept since the handle was created.
+ */
+int mfar_set_stage2_mode(mfar_index* idx, int mode);
+int mfar_stage2_stats(mfar_index* idx, int* two_level_available, int64_t* gather_slab_bytes, int64_t* n_candidates,
+                      int64_t* n_survivors);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,15 @@ typedef unsigned int u32;
 
 #define MFAR_INVALID_ID 0xFFFFFFFFu
 
+// Per-field constants of the 16-bit copies of an fp32 index (the fp16 screen slab, mfar_screen.h; the fp16 gather slab of
+// the two-level stage 2, mfar_select.h); written by mfar_screen_scale_kernel.
+struct ScreenField {
+    float scale;         // sf = 2^e: fp16 value = (fp32 value - mean) * sf
+    float inv_scale;
+    float dnorm_max;     // largest 2-norm of a centred row of the field (inf / NaN when the field holds non-finite values)
+    float mnorm;         // 2-norm of the field's mean vector
+};
+
 // monotone float -> uint map (-0.0 folded onto +0.0 so that float '==' and key '==' agree)
 __device__ __forceinline__ u32 f2ord(float s) {
     u32 u = __float_as_uint(s);

@@ -16,7 +16,7 @@
 #include "mfar_select.h"
 #include "mfar_screen.h"
 
-#define MFAR_VERSION 100
+#define MFAR_VERSION MFAR_ABI_VERSION   /* include/mfar_hip.h: bumped on EVERY signature change; mfar/_native.py refuses any other value */
 #define PAYLOAD_MAGIC 0x6d464152 /* "mFAR" */
 
 static thread_local std::string g_err;
@@ -122,6 +122,16 @@ struct mfar_index {
         int qw = 64;                                                    // query columns of the batch's pass (128: wide screen pass)
     } s1[2];
     DevBuf fid, fsc, cand[2], ncand[2], x[2], own[2], in[8], out[8];
+    // 16-bit GATHER slab (mfar_select.h mfar_score_rows_kernel): row-major [F][n_rows] rows of g_row_bytes.
+    //   fp32 index: fp16 of the centred + scaled rows (built with the screen: same mean / scale) -> the approximate level of the
+    //               certified two-level stage 2;   bf16 index: the slab's values bit for bit -> every row gather reads whole lines
+    DevBuf gslab;
+    size_t g_row_bytes = 0;
+    bool gslab_ok = false;        // the gather slab describes the rows as they are now
+    bool gslab_nomem = false;     // it could not be allocated: gathers stay on the scan-ordered slab
+    bool rows16_dirty = true;     // bf16 index: rows were written since the companion was filled
+    int stage2_mode = 1;          // 0 = gather every (candidate, field) row from the fp32 slab; 1 = certified two-level stage 2 when available
+    DevBuf xa[2], cand2[2], ncand2[2], s2qm[2], s2eps[2], s2stats;   // two-level stage 2 scratch (per pipeline slot) + counters
     // certified fp16 screen of an fp32 index (mfar_screen.h)
     int screen_mode = 1;          // 0 off, 1 auto, 2 always (when the shapes allow)
     float screen_eps_mult = 1.0f; // test knob: scales the certificate's error bound
@@ -162,7 +172,10 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_topk_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_shards_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_shards_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)mfar_score_rows_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_score_rows_kernel<SRC_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_score_rows_kernel<SRC_F16G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_score_rows_kernel<SRC_BF16G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_s2_prune_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_score_candidates_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1B_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1B_LDS_BYTES));
@@ -235,6 +248,7 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     if (const char* e = getenv("MFAR_SCREEN_EPS_MULT")) idx->screen_eps_mult = (float)atof(e);
     if (const char* e = getenv("MFAR_SCREEN_DEDUP")) idx->screen_dedup = atoi(e) != 0;
     if (const char* e = getenv("MFAR_WIDE")) idx->wide = atoi(e) != 0;
+    if (const char* e = getenv("MFAR_STAGE2_PRUNE")) idx->stage2_mode = atoi(e) != 0 ? 1 : 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) idx->n_cu = prop.multiProcessorCount;
     hipError_t e = hipMalloc(&idx->slab, idx->slab_bytes);
@@ -270,7 +284,9 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
     DevBuf* bufs[] = {&idx->fid, &idx->fsc, &idx->cand[0], &idx->cand[1], &idx->ncand[0], &idx->ncand[1], &idx->x[0], &idx->x[1],
                       &idx->own[0], &idx->own[1], &idx->s_stats, &idx->s_field, &idx->s_mean, &idx->screen, &idx->u_rep, &idx->u_start,
-                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof};
+                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->xa[0], &idx->xa[1], &idx->cand2[0],
+                      &idx->cand2[1], &idx->ncand2[0], &idx->ncand2[1], &idx->s2qm[0], &idx->s2qm[1], &idx->s2eps[0], &idx->s2eps[1],
+                      &idx->s2stats};
     for (S1Geom* g : {&idx->geom_docs, &idx->geom_screen})
         for (S1Table* t : {&g->all, &g->solo, &g->all_w, &g->solo_w}) {
             t->d_chunks.release();
@@ -357,6 +373,8 @@ extern "C" int mfar_index_write_rows(mfar_index* idx, int field, int64_t local_r
     HIPCHK(hipSetDevice(idx->device));
     idx->screen_dirty = true;
     idx->fused_dirty = true;
+    idx->rows16_dirty = true;
+    idx->gslab_ok = false;
     hipStream_t st = (hipStream_t)stream;
     char* fbase = (char*)idx->slab + (size_t)field * idx->field_stride * idx->esize;
     const int64_t chunk = on_device ? n : std::min<int64_t>(n, (int64_t)(256u << 20) / (idx->E * 4));
@@ -960,6 +978,46 @@ static int build_unique_rows(mfar_index* idx, int f, const float* field, DevBuf*
     return MFAR_OK;
 }
 
+// 16-bit gather slab (mfar_select.h).  Allocation failure is not an error: gathers stay on the scan-ordered slab.
+static bool gslab_alloc(mfar_index* idx) {
+    if (idx->gslab_nomem) return false;
+    idx->g_row_bytes = GSLAB_ROW_BYTES(idx->E);
+    const size_t need = (size_t)idx->F * (size_t)std::max<int64_t>(idx->n_rows, 1) * idx->g_row_bytes;
+    if (idx->gslab.ensure(need) != MFAR_OK) {
+        (void)hipGetLastError();
+        g_err.clear();
+        idx->gslab.release();
+        idx->gslab_nomem = true;
+        return false;
+    }
+    return true;
+}
+// bf16 index: the row-major companion (the slab's values bit for bit), filled lazily by the first gather after rows were written
+static int ensure_rows16(mfar_index* idx, hipStream_t st, bool* ok) {
+    *ok = false;
+    if (idx->dtype != MFAR_DTYPE_BF16 || idx->n_rows == 0) return MFAR_OK;
+    static const bool enabled = !(getenv("MFAR_GATHER_SLAB") && atoi(getenv("MFAR_GATHER_SLAB")) == 0);   // diagnostic: 0 = gather from the scan-ordered slab
+    if (!enabled) return MFAR_OK;
+    if (idx->gslab_ok && !idx->rows16_dirty) {
+        *ok = true;
+        return MFAR_OK;
+    }
+    HIPCHK(hipDeviceSynchronize());   // a gather in flight on another stream may still read the companion
+    if (!gslab_alloc(idx)) return MFAR_OK;
+    const long long total = idx->n_rows * (long long)(idx->g_row_bytes / 16);
+    for (int f = 0; f < idx->F; ++f) {
+        mfar_gslab_build_bf16_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(
+            (const unsigned short*)idx->slab + (size_t)f * idx->field_stride, idx->gslab.as<char>() + (size_t)f * idx->n_rows * idx->g_row_bytes,
+            idx->n_rows, idx->n_steps, (int)idx->g_row_bytes);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    idx->rows16_dirty = false;
+    idx->gslab_ok = true;
+    *ok = true;
+    return MFAR_OK;
+}
+
 // (re)build the screen from the fp32 slab when rows changed: per-field statistics, the unique rows of every field, the fp16
 // slab of those rows.  *ok = false: not available (allocation failed) -> the caller stays on the exact pass.
 static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
@@ -1086,6 +1144,20 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
         stage_rows.release();
         stage_field.release();
     }
+    // the fp16 gather slab of an fp32 index: the same centred + scaled values, every document's row, row-major (the approximate
+    // level of the certified two-level stage 2; +50 % of the fp32 slab, optional)
+    if (!bf16) idx->gslab_ok = false;
+    static const bool gs_enabled = !(getenv("MFAR_GATHER_SLAB") && atoi(getenv("MFAR_GATHER_SLAB")) == 0);
+    if (!bf16 && gs_enabled && n > 0 && gslab_alloc(idx)) {
+        const long long total = n * (long long)(idx->g_row_bytes / 16);
+        for (int f = 0; f < F; ++f) {
+            mfar_gslab_build_f16_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(
+                (const float*)idx->slab + (size_t)f * idx->field_stride, idx->gslab.as<char>() + (size_t)f * n * idx->g_row_bytes, n, idx->n_steps,
+                (int)idx->g_row_bytes, idx->s_mean.as<float>() + (size_t)f * idx->E, idx->s_field.as<ScreenField>() + f);
+            HIPCHK(hipGetLastError());
+        }
+        idx->gslab_ok = true;
+    }
     idx->screen_dirty = false;
     *ok = true;
     return MFAR_OK;
@@ -1175,8 +1247,14 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     sp.nuniq = idx->u_n.as<int>();
     sp.ustride = idx->n_rows;
     sp.f0 = f0;
-    if (bf16) mfar_score_candidates_kernel<1><<<dim3((unsigned)((kp * nf + 255) / 256), qt_n), dim3(256), SCORE_LDS_BYTES(idx->E), st>>>(sp);
-    else mfar_score_rows_f32_kernel<<<dim3((unsigned)((kp * nf + SCF_THREADS - 1) / SCF_THREADS), qt_n), dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(sp);
+    bool rows16 = false;
+    if (bf16) RETCHK(ensure_rows16(idx, st, &rows16));
+    sp.gslab = idx->gslab.p;
+    sp.g_row_bytes = (long long)idx->g_row_bytes;
+    const dim3 sgrid((unsigned)((kp * nf + SCF_THREADS - 1) / SCF_THREADS), qt_n);
+    if (bf16 && rows16) mfar_score_rows_kernel<SRC_BF16G><<<sgrid, dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(sp);
+    else if (bf16) mfar_score_candidates_kernel<1><<<dim3((unsigned)((kp * nf + 255) / 256), qt_n), dim3(256), SCORE_LDS_BYTES(idx->E), st>>>(sp);
+    else mfar_score_rows_kernel<SRC_F32><<<sgrid, dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(sp);
     HIPCHK(hipGetLastError());
     // 3. exact top-k documents + certificate
     CertifyParams cp = {};
@@ -1302,6 +1380,29 @@ extern "C" int mfar_stage1_finish(mfar_index* idx, const float* q, int Q, int k,
                         (hipStream_t)stream);
 }
 
+static bool two_level_ok(const mfar_index* idx, int C, int k2, int query_cond);
+extern "C" int mfar_set_stage2_mode(mfar_index* idx, int mode) {
+    if (!idx || mode < 0 || mode > 1) return fail(MFAR_ERR_INVALID, "mode must be 0 (gather every row) or 1 (certified two-level stage 2)");
+    idx->stage2_mode = mode;
+    return MFAR_OK;
+}
+
+extern "C" int mfar_stage2_stats(mfar_index* idx, int* two_level_available, int64_t* gather_slab_bytes, int64_t* n_candidates,
+                                 int64_t* n_survivors) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    HIPCHK(hipSetDevice(idx->device));
+    if (two_level_available) *two_level_available = two_level_ok(idx, MFAR_MAX_K + 1, 1, 0) ? 1 : 0;
+    if (gather_slab_bytes) *gather_slab_bytes = idx->gslab_ok ? (int64_t)((size_t)idx->F * idx->n_rows * idx->g_row_bytes) : 0;
+    unsigned long long h[2] = {0, 0};
+    if (idx->s2stats.p) {
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(h, idx->s2stats.p, sizeof(h), hipMemcpyDeviceToHost));
+    }
+    if (n_candidates) *n_candidates = (int64_t)h[0];
+    if (n_survivors) *n_survivors = (int64_t)h[1];
+    return MFAR_OK;
+}
+
 extern "C" int mfar_set_screen(mfar_index* idx, int mode, float eps_mult) {
     if (!idx || mode < 0 || mode > 2 || !(eps_mult >= 0.0f)) return fail(MFAR_ERR_INVALID, "mode must be 0, 1 or 2 and eps_mult >= 0");
     idx->screen_mode = mode;
@@ -1388,8 +1489,13 @@ extern "C" int mfar_retrieve_field(mfar_index* idx, int field, const float* q, i
 }
 
 // ------------------------------------------------------------------------------------------------ stage 2
+// approx != nullptr: the APPROXIMATE level of the two-level stage 2 (fp16 gather slab of an fp32 index; the caller checked
+// two_level_ok): approx->qm / the field scales are applied by the kernel
+struct ApproxArgs {
+    const float* qm;   // [Q, MFAR_MAX_FIELDS]
+};
 static int run_score(mfar_index* idx, const float* q, int Q, const long long* cand, const int* ncand, int C, float* x,
-                     hipStream_t st) {
+                     hipStream_t st, const ApproxArgs* approx = nullptr) {
     ScoreParams p = {};
     p.slab = idx->slab;
     p.field_stride = idx->field_stride;
@@ -1410,8 +1516,23 @@ static int run_score(mfar_index* idx, const float* q, int Q, const long long* ca
     }
     const unsigned gx = (unsigned)(((size_t)C * idx->F + 255) / 256), gf = (unsigned)(((size_t)C * idx->F + SCF_THREADS - 1) / SCF_THREADS);
     if (gx == 0 || Q == 0) return MFAR_OK;
-    if (idx->dtype == MFAR_DTYPE_BF16) mfar_score_candidates_kernel<1><<<dim3(gx, Q), dim3(256), SCORE_LDS_BYTES(idx->E), st>>>(p);
-    else mfar_score_rows_f32_kernel<<<dim3(gf, Q), dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(p);
+    p.gslab = idx->gslab.p;
+    p.g_row_bytes = (long long)idx->g_row_bytes;
+    if (approx) {
+        p.sfld = idx->s_field.as<ScreenField>();
+        p.qm = approx->qm;
+        p.qm_stride = MFAR_MAX_FIELDS;
+        mfar_score_rows_kernel<SRC_F16G><<<dim3(gf, Q), dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(p);
+    } else if (idx->dtype == MFAR_DTYPE_BF16) {
+        bool rows16 = false;
+        RETCHK(ensure_rows16(idx, st, &rows16));
+        p.gslab = idx->gslab.p;
+        p.g_row_bytes = (long long)idx->g_row_bytes;
+        if (rows16) mfar_score_rows_kernel<SRC_BF16G><<<dim3(gf, Q), dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(p);
+        else mfar_score_candidates_kernel<1><<<dim3(gx, Q), dim3(256), SCORE_LDS_BYTES(idx->E), st>>>(p);
+    } else {
+        mfar_score_rows_kernel<SRC_F32><<<dim3(gf, Q), dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(p);
+    }
     HIPCHK(hipGetLastError());
     return MFAR_OK;
 }
@@ -1513,9 +1634,70 @@ extern "C" int mfar_mix_topk(int device, const float* cand_scores, const int64_t
 }
 
 // ------------------------------------------------------------------------------------------------ full scorer
-// union -> stage 2 -> mixer, all pointers on the device; `slot` selects one of two internal workspaces so that two
-// batches can be in flight on different streams
-static int run_stage2_mix(mfar_index* idx, const float* qd, int Q, const float* Wd, int query_cond, const float* md, int k1,
+// The certified two-level stage 2 (mfar_select.h): approximate scores of every (candidate, field) pair from the fp16 gather slab ->
+// interval bounds on the mixed score -> the survivors' rows from the fp32 slab.  Available for fp32 indexes whose screen (mean,
+// scale, norms) and gather slab are current; otherwise every row is gathered from the fp32 / bf16 slab as before.
+static bool two_level_ok(const mfar_index* idx, int C, int k2, int query_cond) {
+    return idx->stage2_mode == 1 && idx->dtype == MFAR_DTYPE_F32 && idx->gslab_ok && idx->screen.p && !idx->screen_dirty && C > k2 &&
+           k2 <= SEL_MAX_K && PRUNE_LDS_BYTES(C, query_cond ? idx->E : 0, idx->F) <= 160 * 1024;
+}
+//   cand / ncand [Q, C] / [Q]: the candidates to score (sorted unique ids);  masks [n_masks, F] or nullptr (ones, n_masks = 1)
+//   x [Q, C, F]: exact score vectors of the SURVIVORS, row c of x belongs to (*cand_out)[q, c]
+static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* Wd, int query_cond, const float* masks, int n_masks, int k2,
+                         const long long* cand, const int* ncand, int C, int slot, float* x, const long long** cand_out,
+                         const int** ncand_out, hipStream_t st) {
+    const int F = idx->F, E = idx->E;
+    RETCHK(idx->xa[slot].ensure((size_t)Q * C * F * 4));
+    RETCHK(idx->cand2[slot].ensure((size_t)Q * C * 8));
+    RETCHK(idx->ncand2[slot].ensure((size_t)Q * 4));
+    RETCHK(idx->s2qm[slot].ensure((size_t)Q * MFAR_MAX_FIELDS * 4));
+    RETCHK(idx->s2eps[slot].ensure((size_t)Q * MFAR_MAX_FIELDS * 4));
+    if (!idx->s2stats.p) {
+        RETCHK(idx->s2stats.ensure(2 * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(idx->s2stats.p, 0, 2 * sizeof(unsigned long long), st));
+    }
+    S2PrepParams pp = {};
+    pp.q = qd;
+    pp.mean = idx->s_mean.as<float>();
+    pp.sf = idx->s_field.as<ScreenField>();
+    pp.qm = idx->s2qm[slot].as<float>();
+    pp.eps = idx->s2eps[slot].as<float>();
+    pp.E = E;
+    pp.F = F;
+    pp.eps_mult = idx->screen_eps_mult;
+    mfar_s2_prep_kernel<<<dim3(Q), dim3(256), 0, st>>>(pp);
+    HIPCHK(hipGetLastError());
+    const ApproxArgs ap = {pp.qm};
+    RETCHK(run_score(idx, qd, Q, cand, ncand, C, idx->xa[slot].as<float>(), st, &ap));
+    PruneParams pr = {};
+    pr.xa = idx->xa[slot].as<float>();
+    pr.cand = cand;
+    pr.n_cand = ncand;
+    pr.eps = pp.eps;
+    pr.q = qd;
+    pr.W = Wd;
+    pr.masks = masks;
+    pr.cand2 = idx->cand2[slot].as<long long>();
+    pr.n_cand2 = idx->ncand2[slot].as<int>();
+    pr.stats = idx->s2stats.as<unsigned long long>();
+    pr.C = C;
+    pr.F = F;
+    pr.E = E;
+    pr.k = k2;
+    pr.query_cond = query_cond;
+    pr.n_masks = masks ? n_masks : 1;
+    mfar_s2_prune_kernel<<<dim3(Q), dim3(256), PRUNE_LDS_BYTES(C, query_cond ? E : 0, F), st>>>(pr);
+    HIPCHK(hipGetLastError());
+    RETCHK(run_score(idx, qd, Q, pr.cand2, pr.n_cand2, C, x, st));
+    *cand_out = pr.cand2;
+    *ncand_out = pr.n_cand2;
+    return MFAR_OK;
+}
+
+// union -> stage 2 -> mixer (one launch per mask), all pointers on the device; `slot` selects one of two internal workspaces so
+// that two batches can be in flight on different streams.  masks [n_masks, F] (nullptr = no mask, n_masks = 1); ids / scores
+// [n_masks, Q, k2], nvd [n_masks, Q] or nullptr.
+static int run_stage2_mix(mfar_index* idx, const float* qd, int Q, const float* Wd, int query_cond, const float* masks, int n_masks, int k1,
                           int k2, const long long* fid, int slot, long long* idd, float* scd, int* nvd, int* ncd_out,
                           hipStream_t st) {
     const int F = idx->F, E = idx->E, C = F * k1;
@@ -1528,9 +1710,15 @@ static int run_stage2_mix(mfar_index* idx, const float* qd, int Q, const float* 
     RETCHK(idx->x[slot].ensure((size_t)Q * C * F * 4));
     mfar_union_kernel<<<dim3(Q), dim3(256), 0, st>>>(fid, F, k1, idx->cand[slot].as<long long>(), ncd);
     HIPCHK(hipGetLastError());
-    RETCHK(run_score(idx, qd, Q, idx->cand[slot].as<long long>(), ncd, C, idx->x[slot].as<float>(), st));
-    RETCHK(run_mix(idx->x[slot].as<float>(), idx->cand[slot].as<long long>(), ncd, qd, Wd, query_cond, md, Q, C, F, E, k2, idd,
-                   scd, nvd, st));
+    const long long* cm = idx->cand[slot].as<long long>();
+    const int* nm = ncd;
+    if (two_level_ok(idx, C, k2, query_cond))
+        RETCHK(run_two_level(idx, qd, Q, Wd, query_cond, masks, n_masks, k2, cm, nm, C, slot, idx->x[slot].as<float>(), &cm, &nm, st));
+    else
+        RETCHK(run_score(idx, qd, Q, cm, nm, C, idx->x[slot].as<float>(), st));
+    for (int m = 0; m < n_masks; ++m)
+        RETCHK(run_mix(idx->x[slot].as<float>(), cm, nm, qd, Wd, query_cond, masks ? masks + (size_t)m * F : nullptr, Q, C, F, E, k2,
+                       idd + (size_t)m * Q * k2, scd + (size_t)m * Q * k2, nvd ? nvd + (size_t)m * Q : nullptr, st));
     return MFAR_OK;
 }
 
@@ -1574,7 +1762,7 @@ extern "C" int mfar_search_two_stage(mfar_index* idx, const float* q, int Q, con
         ncd = idx->ncand[0].as<int>();
     }
     RETCHK(run_stage1(idx, qd, Q, k1, sentinel, fid, fsc, st));
-    RETCHK(run_stage2_mix(idx, qd, Q, Wd, query_cond, md, k1, k2, fid, 0, idd, scd, nvd, ncd, st));
+    RETCHK(run_stage2_mix(idx, qd, Q, Wd, query_cond, md, 1, k1, k2, fid, 0, idd, scd, nvd, ncd, st));
     RETCHK(copy_back((long long*)ids, idd, (size_t)Q * k2, on_device, st));
     RETCHK(copy_back(scores, scd, (size_t)Q * k2, on_device, st));
     RETCHK(copy_back((int*)n_valid, nvd, (size_t)Q, on_device, st));
@@ -1597,7 +1785,7 @@ extern "C" int mfar_search_stage2(mfar_index* idx, const float* q, int Q, const 
     if (!ids || !scores || !field_ids) return fail(MFAR_ERR_INVALID, "NULL pointer");
     if (slot < 0 || slot > 1) return fail(MFAR_ERR_INVALID, "slot must be 0 or 1");
     HIPCHK(hipSetDevice(idx->device));
-    return run_stage2_mix(idx, q, Q, W, query_cond, mask, k1, k2, (const long long*)field_ids, slot, (long long*)ids, scores,
+    return run_stage2_mix(idx, q, Q, W, query_cond, mask, 1, k1, k2, (const long long*)field_ids, slot, (long long*)ids, scores,
                           (int*)n_valid, (int*)n_cand, (hipStream_t)stream);
 }
 
@@ -1612,15 +1800,9 @@ extern "C" int mfar_search_stage2_masks(mfar_index* idx, const float* q, int Q, 
     if (!ids || !scores || !field_ids) return fail(MFAR_ERR_INVALID, "NULL pointer");
     if (slot < 0 || slot > 1) return fail(MFAR_ERR_INVALID, "slot must be 0 or 1");
     HIPCHK(hipSetDevice(idx->device));
-    hipStream_t st = (hipStream_t)stream;
-    // candidate union and stage 2 once (the first mix included), then one mixer launch per further mask over the same scores
-    RETCHK(run_stage2_mix(idx, q, Q, W, query_cond, masks, k1, k2, (const long long*)field_ids, slot, (long long*)ids, scores, (int*)n_valid,
-                          (int*)n_cand, st));
-    const int* ncd = n_cand ? (const int*)n_cand : idx->ncand[slot].as<int>();
-    for (int m = 1; m < n_masks; ++m)
-        RETCHK(run_mix(idx->x[slot].as<float>(), idx->cand[slot].as<long long>(), ncd, q, W, query_cond, masks + (size_t)m * F, Q, C, F, E, k2,
-                       (long long*)ids + (size_t)m * Q * k2, scores + (size_t)m * Q * k2, n_valid ? (int*)n_valid + (size_t)m * Q : nullptr, st));
-    return MFAR_OK;
+    // candidate union and stage 2 once, then one mixer launch per mask over the same scores
+    return run_stage2_mix(idx, q, Q, W, query_cond, masks, n_masks, k1, k2, (const long long*)field_ids, slot, (long long*)ids, scores,
+                          (int*)n_valid, (int*)n_cand, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------ fused mode
@@ -1985,11 +2167,15 @@ static int search_owned(mfar_index* idx, const void* gathered_lists, int n_shard
     HIPCHK(hipGetLastError());
     mfar_filter_owned_kernel<<<dim3(Q), dim3(64), 0, st>>>(cand, ncand, C, idx->row_offset, idx->row_offset + idx->n_rows, owned, nowned);
     HIPCHK(hipGetLastError());
-    RETCHK(run_score(idx, q, Q, owned, nowned, C, x, st));
+    // the local top-k2 of the OWNED candidates: the two-level stage 2 prunes against the owned set's own k2-th lower bound
+    const long long* cm = owned;
+    const int* nm = nowned;
+    if (two_level_ok(idx, C, k2, query_cond)) RETCHK(run_two_level(idx, q, Q, W, query_cond, mask, n_masks, k2, owned, nowned, C, slot, x, &cm, &nm, st));
+    else RETCHK(run_score(idx, q, Q, owned, nowned, C, x, st));
     // one top-k payload per mask (a sweep of field masks shares everything up to here: mfar_search_owned_masks)
     for (int m = 0; m < n_masks; ++m) {
         char* tb = (char*)topk + (size_t)m * TL.total;
-        RETCHK(run_mix(x, owned, nowned, q, W, query_cond, mask ? mask + (size_t)m * F : nullptr, Q, C, F, E, k2, (long long*)(tb + TL.ids),
+        RETCHK(run_mix(x, cm, nm, q, W, query_cond, mask ? mask + (size_t)m * F : nullptr, Q, C, F, E, k2, (long long*)(tb + TL.ids),
                        (float*)(tb + TL.scores), nullptr, st));
         HIPCHK(hipMemcpyAsync(tb + TL.ncand, ncand, (size_t)Q * 4, hipMemcpyDeviceToDevice, st));
         if (any_fail) HIPCHK(hipMemcpyAsync(tb + TL.flag, any_fail, 4, hipMemcpyDeviceToDevice, st));

@@ -38,12 +38,7 @@
 #define SCREEN_MAX_KP S1_MAX_DEPTH   // the stage-1 lists compact to k', which must leave room for one tile of appends
 #define SCREEN_SLACK 1.25f
 
-struct ScreenField {     // per field, written by mfar_screen_scale_kernel
-    float scale;         // sf = 2^e: fp16 value = (fp32 value - mean) * sf
-    float inv_scale;
-    float dnorm_max;     // largest 2-norm of a centred row of the field (inf / NaN when the field holds non-finite values)
-    float mnorm;         // 2-norm of the field's mean vector
-};
+// struct ScreenField: mfar_device.h (shared with the gather-slab kernels of mfar_select.h)
 struct ScreenQuery {     // per query of the current block of 64 / 128 queries
     float scale, inv_scale, norm, pad;
 };

@@ -445,6 +445,12 @@ struct ScoreParams {
     // all-fields mode: repof[f * ustride + local row] = representative of the row's group of bit-identical rows (mfar_screen.h),
     // gathered in its place; nullptr: every row is gathered itself
     const int* repof;
+    // 16-bit gather slab (mfar_score_rows_kernel<SRC_F16G / SRC_BF16G>): row-major [F][n_rows] rows of g_row_bytes
+    const void* gslab;
+    long long g_row_bytes;
+    const ScreenField* sfld;         // [F] SRC_F16G: the field's power-of-two scale
+    const float* qm;         // [Q, qm_stride] SRC_F16G: q . mean(field)
+    int qm_stride;
 };
 // Each wave owns 64 (candidate, field) rows, one per lane, gathers their segments cooperatively by LDS-DMA into a private
 // two-slot LDS ring, and every lane then walks ITS row's segment from LDS in chain order.  No barriers: the ring is private
@@ -569,16 +575,26 @@ __global__ void __launch_bounds__(256) mfar_score_candidates_kernel(const ScoreP
     if (idx < p.C * p.F) p.out[(size_t)qi * p.C * p.F + idx] = valid ? acc : __builtin_nanf("");
 }
 
-// fp32 slab: every (row, k-step pair) is one full 128-byte line (mfar_device.h), so a wave gathers 64 rows x 128 B = 8 KB
-// per ring slot: 8 lanes per row, 8 rows per 1 KB LDS-DMA instruction, 8 instructions per slot; two slots per wave.  A
-// workgroup is 2 waves (32 KB + the query row: fits beside two resident stage-1 workgroups).  The 16-byte pieces of a row
-// are stored at position piece ^ ((owner lane >> 1) & 7) inside its 128 bytes: conflict-free ds_read_b128 for any rows.
-// Chain order = the arithmetic contract (inside every aligned group of 8 dims: 0,4,1,5,2,6,3,7).
+// Row gathers in whole 128-byte lines.  A wave gathers 64 rows x 128 B = 8 KB per ring slot: 8 lanes per row, 8 rows per 1 KB
+// LDS-DMA instruction, 8 instructions per slot; two slots per wave.  A workgroup is 2 waves (32 KB + the query row: fits
+// beside two resident stage-1 workgroups).  The 16-byte pieces of a row are stored at position piece ^ ((owner lane >> 1) & 7)
+// inside its 128 bytes: conflict-free ds_read_b128 for any rows.  Three sources (template SRC):
+//   SRC_F32   the fp32 tiled slab: every (row, k-step pair) is one full line (mfar_device.h), lines of a row 8 KB apart.  Chain
+//             order = the arithmetic contract (inside every aligned group of 8 dims: 0,4,1,5,2,6,3,7): stage-1 bits.
+//   SRC_F16G  the fp16 GATHER slab of an fp32 index (row-major [F][rows][row_bytes], the screen's centred + scaled values, see
+//             mfar_gslab_build_kernel): a row is E * 2 contiguous bytes, HALF the bytes of the fp32 row.  out = the APPROXIMATE
+//             score acc / sf + q.m of the certified two-level stage 2 (mfar_s2_prune_kernel owns the error bound).
+//   SRC_BF16G the row-major bf16 companion of a bf16 index (exact copies of the slab's values): the scan-ordered bf16 slab keeps
+//             32-byte row segments 2 KB apart, every one a whole 128-byte line for a gather (4x the useful bytes); here a row is
+//             contiguous.  Natural-order chain, bf16 widened exactly: the bf16 contract's bits (same as DT = 1 above).
+enum { SRC_F32 = 0, SRC_F16G = 1, SRC_BF16G = 2 };
 #define SCF_THREADS 128
 #define SCF_SLOT_BYTES 8192
 #define SCF_WAVE_BYTES (2 * SCF_SLOT_BYTES)
 #define SCORE_F32_LDS_BYTES(E) ((size_t)(SCF_THREADS / 64) * SCF_WAVE_BYTES + (size_t)(E) * 4)
-__global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_f32_kernel(const ScoreParams p) {
+#define GSLAB_ROW_BYTES(E) ((size_t)(((E) + 63) / 64) * 128)   // 16-bit row-major rows padded to whole lines
+template <int SRC>
+__global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_kernel(const ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qs = (float*)(smem + (SCF_THREADS / 64) * SCF_WAVE_BYTES);
     const int qi = blockIdx.y;
@@ -597,12 +613,13 @@ __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_f32_kernel(const 
     char* ring = smem + w * SCF_WAVE_BYTES;
     // this lane's row
     bool valid = false;
-    int rr = 0;
-    const char* rowbase = (const char*)p.slab;  // harmless in-bounds address for invalid rows
+    int rr = 0, fld = 0;
+    const char* rowbase = (const char*)(SRC == SRC_F32 ? p.slab : p.gslab);  // harmless in-bounds address for invalid rows
     if (idx < p.C * p.F) {
         const int c = p.per_field ? idx % p.C : idx / p.F;
         const int fl = p.per_field ? idx / p.C : idx - c * p.F;     // list / field slot of this launch
         const int f = p.per_field ? p.f0 + fl : fl;                 // field of the slab
+        fld = f;
         if (c < nc) {
             long long id = p.cand[p.per_field ? ((size_t)qi * p.F + fl) * p.C + c : (size_t)qi * p.C + c];
             if (p.urep) id = (id >= 0 && id < p.nuniq[f]) ? (long long)p.urep[(size_t)f * p.ustride + id] : -1;   // unique row -> its document
@@ -611,7 +628,8 @@ __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_f32_kernel(const 
                 valid = true;
                 if (p.repof && !p.per_field) id = p.repof[(size_t)f * p.ustride + id];
                 rr = (int)(id & 63);
-                rowbase = (const char*)p.slab + ((size_t)f * p.field_stride + (size_t)(id >> 6) * p.n_steps * 1024) * 4 + rr * 128;
+                if (SRC == SRC_F32) rowbase = (const char*)p.slab + ((size_t)f * p.field_stride + (size_t)(id >> 6) * p.n_steps * 1024) * 4 + rr * 128;
+                else rowbase = (const char*)p.gslab + ((size_t)f * p.n_rows + (size_t)id) * p.g_row_bytes;
             }
         }
     }
@@ -627,47 +645,118 @@ __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_f32_kernel(const 
         const u32 lo = __shfl((int)(u32)b, r), hi = __shfl((int)(u32)(b >> 32), r);
         src[i] = (const char*)(((unsigned long long)hi << 32) | lo) + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
     }
-    const int n_pairs = p.n_steps >> 1;
+    // ring slots: fp32 = k-step pairs (32 dims, lines 8 KB apart); 16-bit row-major = 64 dims, consecutive lines
+    constexpr size_t SLOT_STRIDE = SRC == SRC_F32 ? 8192 : 128;
+    const int n_slots = SRC == SRC_F32 ? (p.n_steps >> 1) : (p.E + 63) >> 6;
 #define SCF_ISSUE(G, SLOT)                                                                                         \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) __builtin_amdgcn_global_load_lds(                                \
-        (const __attribute__((address_space(1))) void*)(src[i] + (size_t)(G) * 8192),                              \
+        (const __attribute__((address_space(1))) void*)(src[i] + (size_t)(G) * SLOT_STRIDE),                       \
         (__attribute__((address_space(3))) void*)(ring + (SLOT) * SCF_SLOT_BYTES + i * 1024), 16, 0, SC_AUX)
     SCF_ISSUE(0, 0);
     float acc = 0.0f;
     const int sw = (lane >> 1) & 7;
-    for (int g = 0; g < n_pairs; ++g) {
+    for (int g = 0; g < n_slots; ++g) {
         const int slot = g & 1;
-        if (g + 1 < n_pairs) {
+        if (g + 1 < n_slots) {
             SCF_ISSUE(g + 1, slot ^ 1);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 8 loads of the next slot may stay in flight
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        const float* t = (const float*)(ring + slot * SCF_SLOT_BYTES + lane * 128);
-        const float* qq = qs + g * 32;
+        if (SRC == SRC_F32) {
+            const float* t = (const float*)(ring + slot * SCF_SLOT_BYTES + lane * 128);
+            const float* qq = qs + g * 32;
 #pragma unroll
-        for (int hs = 0; hs < 2; ++hs) {   // the two k-steps of the pair: pieces 4 hs .. 4 hs + 3 = dims 16 hs .. 16 hs + 15
-            const f32x4 c0 = *(const f32x4*)(t + (((4 * hs + 0) ^ sw) << 2));
-            const f32x4 c1 = *(const f32x4*)(t + (((4 * hs + 1) ^ sw) << 2));
-            const f32x4 c2 = *(const f32x4*)(t + (((4 * hs + 2) ^ sw) << 2));
-            const f32x4 c3 = *(const f32x4*)(t + (((4 * hs + 3) ^ sw) << 2));
-            const float* qh = qq + 16 * hs;
+            for (int hs = 0; hs < 2; ++hs) {   // the two k-steps of the pair: pieces 4 hs .. 4 hs + 3 = dims 16 hs .. 16 hs + 15
+                const f32x4 c0 = *(const f32x4*)(t + (((4 * hs + 0) ^ sw) << 2));
+                const f32x4 c1 = *(const f32x4*)(t + (((4 * hs + 1) ^ sw) << 2));
+                const f32x4 c2 = *(const f32x4*)(t + (((4 * hs + 2) ^ sw) << 2));
+                const f32x4 c3 = *(const f32x4*)(t + (((4 * hs + 3) ^ sw) << 2));
+                const float* qh = qq + 16 * hs;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                acc = __builtin_fmaf(qh[x], c0[x], acc);
-                acc = __builtin_fmaf(qh[4 + x], c1[x], acc);
+                for (int x = 0; x < 4; ++x) {
+                    acc = __builtin_fmaf(qh[x], c0[x], acc);
+                    acc = __builtin_fmaf(qh[4 + x], c1[x], acc);
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    acc = __builtin_fmaf(qh[8 + x], c2[x], acc);
+                    acc = __builtin_fmaf(qh[12 + x], c3[x], acc);
+                }
             }
+        } else {
+            // 64 dims of the row (the last slot of a row whose dim is not a multiple of 64 holds 32: rows are padded to whole lines)
+            const char* t = ring + slot * SCF_SLOT_BYTES + lane * 128;
+            const float* qq = qs + g * 64;
+            const int np = (p.E - g * 64) >= 64 ? 8 : 4;      // 16-byte pieces (8 dims each) that hold real dims: wave-uniform
+            for (int pc = 0; pc < np; pc += 4) {
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                acc = __builtin_fmaf(qh[8 + x], c2[x], acc);
-                acc = __builtin_fmaf(qh[12 + x], c3[x], acc);
+                for (int u = 0; u < 4; ++u) {
+                    const int piece = pc + u;
+                    if (SRC == SRC_F16G) {
+                        const f16x8 c = *(const f16x8*)(t + ((piece ^ sw) << 4));
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) acc = __builtin_fmaf(qq[piece * 8 + x], (float)c[x], acc);
+                    } else {
+                        const bf16x8 c = *(const bf16x8*)(t + ((piece ^ sw) << 4));
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) acc = __builtin_fmaf(qq[piece * 8 + x], bf2f((unsigned short)c[x]), acc);
+                    }
+                }
             }
         }
         // the LDS reads of this slot have been consumed before the slot is re-filled two iterations later
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 #undef SCF_ISSUE
-    if (idx < p.C * p.F) p.out[(size_t)qi * p.C * p.F + idx] = valid ? acc : __builtin_nanf("");
+    if (idx < p.C * p.F) {
+        float o = acc;
+        if (SRC == SRC_F16G && valid) o = acc * p.sfld[fld].inv_scale + p.qm[(size_t)qi * p.qm_stride + fld];   // un-scale (power of two), add q . mean
+        p.out[(size_t)qi * p.C * p.F + idx] = valid ? o : __builtin_nanf("");
+    }
+}
+
+// Gather slabs: row-major 16-bit copies of a field's rows, rows padded to whole 128-byte lines (GSLAB_ROW_BYTES).
+//   fp32 index -> fp16 of (value - mean[f]) * scale[f], the screen's centring and power-of-two scale (mfar_screen.h);
+//   bf16 index -> the slab's bf16 values, bit for bit.
+// One thread per 16-byte output granule (8 dims).  grid = ceil(n_rows * (row_bytes / 16) / 256).
+__global__ void __launch_bounds__(256) mfar_gslab_build_f16_kernel(const float* __restrict__ field, char* __restrict__ out, long long n_rows,
+                                                                   int n_steps, int row_bytes, const float* __restrict__ mean,
+                                                                   const ScreenField* __restrict__ sf) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gpr = row_bytes >> 4;
+    if (g >= n_rows * gpr) return;
+    const long long r = g / gpr;
+    const int e = (int)(g - r * gpr) << 3;
+    const int E = n_steps * 16;
+    const float sc = sf->scale;
+    f16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (_Float16)0.0f;
+    if (e < E) {
+        const float* src = field + tiled_offset(n_steps, r, e);
+        const f32x4 a = *(const f32x4*)src - *(const f32x4*)(mean + e);
+        const f32x4 b = *(const f32x4*)(src + 4) - *(const f32x4*)(mean + e + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i] = (_Float16)(a[i] * sc);
+            o[4 + i] = (_Float16)(b[i] * sc);
+        }
+    }
+    *(f16x8*)(out + (size_t)r * row_bytes + (size_t)e * 2) = o;
+}
+__global__ void __launch_bounds__(256) mfar_gslab_build_bf16_kernel(const unsigned short* __restrict__ field, char* __restrict__ out,
+                                                                    long long n_rows, int n_steps, int row_bytes) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gpr = row_bytes >> 4;
+    if (g >= n_rows * gpr) return;
+    const long long r = g / gpr;
+    const int e = (int)(g - r * gpr) << 3;
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = 0;
+    if (e < n_steps * 16) o = *(const bf16x8*)(field + tiled_offset_bf16(n_steps, r, e));
+    *(bf16x8*)(out + (size_t)r * row_bytes + (size_t)e * 2) = o;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -740,6 +829,54 @@ struct MixParams {
     int* n_valid;           // [Q] or nullptr
     int C, F, E, k, query_cond;
 };
+// Field weights of one query, shared by the mixer and the prune kernel (the SAME instruction sequence => the same weight bits):
+// gate logits = natural-order fma chain per field (q and W staged in LDS by all threads first, so the F serial chains read LDS,
+// unrolled by 16, instead of paying a global-memory round trip per element), softmax over <= 32 fields in fixed order.
+// LDS: z | wgt | msk (3 * MFAR_MAX_FIELDS floats), qs [E], Ws [E * F].  Ends with a barrier; msk = mask or ones.
+__device__ __forceinline__ void mix_gate_weights(const float* __restrict__ q_row, const float* __restrict__ W, const float* __restrict__ mask,
+                                                 int query_cond, int E, int F, float* z, float* wgt, float* msk, float* qs, float* Ws) {
+    if (query_cond) {
+        for (int e = threadIdx.x; e < E; e += blockDim.x) qs[e] = q_row[e];
+        for (int i = threadIdx.x; i < E * F; i += blockDim.x) Ws[i] = W[i];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < F) {
+        const int f = threadIdx.x;
+        float acc;
+        if (query_cond) {
+            acc = 0.0f;
+            int e = 0;
+            for (; e + 16 <= E; e += 16) {
+                float qv[16], wv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    qv[i] = qs[e + i];
+                    wv[i] = Ws[(e + i) * F + f];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc = __builtin_fmaf(qv[i], wv[i], acc);
+            }
+            for (; e < E; ++e) acc = __builtin_fmaf(qs[e], Ws[e * F + f], acc);
+        } else {
+            acc = W[f];
+        }
+        z[f] = acc;
+        msk[f] = mask ? mask[f] : 1.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // softmax over <= 32 fields, fixed order
+        float m = -__builtin_inff();
+        for (int f = 0; f < F; ++f) m = z[f] > m ? z[f] : m;
+        float sum = 0.0f;
+        for (int f = 0; f < F; ++f) {
+            wgt[f] = mfar_exp(z[f] - m);
+            sum = sum + wgt[f];
+        }
+        for (int f = 0; f < F; ++f) wgt[f] = wgt[f] / sum;
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(256) mfar_mix_topk_kernel(const MixParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SelLds L = sel_lds(smem, p.C);
@@ -752,52 +889,10 @@ __global__ void __launch_bounds__(256) mfar_mix_topk_kernel(const MixParams p) {
     float* msk = wgt + MFAR_MAX_FIELDS;
     const int qi = blockIdx.x;
     const int nc = min(p.n_cand ? p.n_cand[qi] : p.C, p.C);
-    // gate logits: natural-order fma chain per field.  q and W are staged in LDS by all threads first, so the F
-    // serial chains read LDS (unrolled by 16) instead of paying a global-memory round trip per element.
     float* qs = msk + MFAR_MAX_FIELDS;   // [E]
     float* Ws = qs + p.E;                // [E * F]
-    if (p.query_cond) {
-        const float* qr = p.q + (size_t)qi * p.E;
-        for (int e = threadIdx.x; e < p.E; e += blockDim.x) qs[e] = qr[e];
-        for (int i = threadIdx.x; i < p.E * p.F; i += blockDim.x) Ws[i] = p.W[i];
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < p.F) {
-        const int f = threadIdx.x;
-        float acc;
-        if (p.query_cond) {
-            acc = 0.0f;
-            int e = 0;
-            for (; e + 16 <= p.E; e += 16) {
-                float qv[16], wv[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    qv[i] = qs[e + i];
-                    wv[i] = Ws[(e + i) * p.F + f];
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc = __builtin_fmaf(qv[i], wv[i], acc);
-            }
-            for (; e < p.E; ++e) acc = __builtin_fmaf(qs[e], Ws[e * p.F + f], acc);
-        } else {
-            acc = p.W[f];
-        }
-        z[f] = acc;
-        msk[f] = p.mask ? p.mask[f] : 1.0f;
-    }
     if (threadIdx.x == 0) n_s = 0;
-    __syncthreads();
-    if (threadIdx.x == 0) {  // softmax over <= 32 fields, fixed order
-        float m = -__builtin_inff();
-        for (int f = 0; f < p.F; ++f) m = z[f] > m ? z[f] : m;
-        float sum = 0.0f;
-        for (int f = 0; f < p.F; ++f) {
-            wgt[f] = mfar_exp(z[f] - m);
-            sum = sum + wgt[f];
-        }
-        for (int f = 0; f < p.F; ++f) wgt[f] = wgt[f] / sum;
-    }
-    __syncthreads();
+    mix_gate_weights(p.q + (size_t)qi * p.E, p.W, p.mask, p.query_cond, p.E, p.F, z, wgt, msk, qs, Ws);
     for (int c = threadIdx.x; c < nc; c += blockDim.x) {
         const long long id = p.cand[(size_t)qi * p.C + c];
         if (id < 0) continue;
@@ -815,6 +910,167 @@ __global__ void __launch_bounds__(256) mfar_mix_topk_kernel(const MixParams p) {
         p.scores[(size_t)qi * p.k + r] = r < m ? key_score(sorted[r]) : -__builtin_inff();
     }
     if (threadIdx.x == 0 && p.n_valid) p.n_valid[qi] = m;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Certified two-level stage 2 of an fp32 index (no reference counterpart; same output bits as gathering every row).
+//
+// Stage 2 needs C * F (candidate, field) scores per query and C grows with F: F^2 * k row gathers of E * 4 bytes (22 fields:
+// 148 MB per query against 34 MB scanned).  The bound the threshold algorithm would use -- an unknown s_cf is at most the field's
+// k-th list score -- prunes NOTHING on independent fields (profiles/r03_stage2_bound_survival.txt), so the bytes are cut instead:
+//   A. every (candidate, field) pair is scored APPROXIMATELY from the fp16 gather slab (mfar_score_rows_kernel<SRC_F16G>: half
+//      the bytes of the fp32 row) with a rigorous error bound eps(q, f) (mfar_s2_prep_kernel);
+//   B. mfar_s2_prune_kernel evaluates the mixer's own fma chain on the interval ends: the chain acc = fma(w_f, x_f * m_f, acc)
+//      is monotone in every x_f (w_f >= 0; a negative mask entry swaps the ends), and fp32 rounding is monotone, so
+//      LB_c <= mixed_c <= UB_c holds in the COMPUTED arithmetic with no further slack.  T = the k2-th largest LB; a candidate with
+//      UB_c < T is strictly below k2 candidates and can neither enter nor tie into the top-k2.  NaN bounds survive;
+//   C. the survivors (~1.3 k2 on the bench corpora) are gathered from the fp32 slab exactly as before and mixed: ids and score
+//      bits of the top-k2 are those of the full gather.  A sweep of masks keeps the union of the masks' survivors.
+//
+// eps (K = dim, u16 = 2^-11, u32 = 2^-24; c = fl(d - m) the centred row, h = fp16(c * sf), approx = fl(A / sf + fl(q.m)),
+// A = the fp32 fma chain of q_i * h_i in any order):
+//   |approx - exact chain| <= [u16 + 1.01 (K + 2) u32] sum|q_i||c_i| + 1.01 (K + 1) u32 sum|q_i||d_i| + 1.01 K u32 sum|q_i||m_i|
+//                             + 2^-24 |q|_1 / sf
+//   (fp16 rounding of the row; the centring; the fp32 chain over exactly representable products; the final add; the exact chain's
+//   own K u32; q.m in fp32; subnormal fp16 values), with sum|q||x| <= |q|_2 |x|_2, |c|_2 <= the field's largest centred row norm,
+//   |d| <= |c| + |m|, |q|_1 <= sqrt(K) |q|_2, times SCREEN_SLACK.  Non-finite data makes eps inf / NaN: everything survives.
+// ---------------------------------------------------------------------------------------------------------
+#define S2_SLACK 1.25f
+struct S2PrepParams {
+    const float* q;          // [Q, E]
+    const float* mean;       // [F, E] field means
+    const ScreenField* sf;   // [F]
+    float* qm;               // [Q, MFAR_MAX_FIELDS] q . mean(field), fp32, any order (budgeted in eps)
+    float* eps;              // [Q, MFAR_MAX_FIELDS]
+    int E, F;
+    float eps_mult;          // test knob (mfar_set_screen): scales the bound; 1 = rigorous
+};
+__global__ void __launch_bounds__(256) mfar_s2_prep_kernel(const S2PrepParams p) {
+    __shared__ float part[MFAR_MAX_FIELDS + 1][4];
+    const int qi = blockIdx.x;
+    const float* qr = p.q + (size_t)qi * p.E;
+    float ss = 0.0f;
+    for (int e = threadIdx.x; e < p.E; e += blockDim.x) ss = __builtin_fmaf(qr[e], qr[e], ss);
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((threadIdx.x & 63) == 0) part[MFAR_MAX_FIELDS][threadIdx.x >> 6] = ss;
+    for (int f = 0; f < p.F; ++f) {
+        float pm = 0.0f;
+        for (int e = threadIdx.x; e < p.E; e += blockDim.x) pm = __builtin_fmaf(qr[e], p.mean[(size_t)f * p.E + e], pm);
+        for (int off = 32; off > 0; off >>= 1) pm += __shfl_xor(pm, off);
+        if ((threadIdx.x & 63) == 0) part[f][threadIdx.x >> 6] = pm;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < p.F) {
+        const int f = threadIdx.x;
+        const ScreenField s = p.sf[f];
+        const float qn = sqrtf((part[MFAR_MAX_FIELDS][0] + part[MFAR_MAX_FIELDS][1]) + (part[MFAR_MAX_FIELDS][2] + part[MFAR_MAX_FIELDS][3])) * 1.0001f;
+        const float K = (float)p.E, u16f = 4.8828125e-4f, u32f = 5.9604645e-8f;
+        const float c_rel = u16f + 1.01f * (K + 2.0f) * u32f;
+        float e_ = S2_SLACK * (c_rel * qn * s.dnorm_max + 1.01f * (K + 1.0f) * u32f * qn * (s.dnorm_max + s.mnorm) + 1.01f * K * u32f * qn * s.mnorm +
+                               u32f * sqrtf(K) * 1.0001f * qn * s.inv_scale);
+        e_ *= p.eps_mult;
+        p.eps[(size_t)qi * MFAR_MAX_FIELDS + f] = e_;
+        p.qm[(size_t)qi * MFAR_MAX_FIELDS + f] = (part[f][0] + part[f][1]) + (part[f][2] + part[f][3]);
+    }
+}
+
+struct PruneParams {
+    const float* xa;         // [Q, C, F] approximate scores (NaN = not scored)
+    const long long* cand;   // [Q, C] sorted unique candidate ids (< 0 = empty)
+    const int* n_cand;       // [Q]
+    const float* eps;        // [Q, MFAR_MAX_FIELDS]
+    const float* q;          // [Q, E]
+    const float* W;          // [E, F] or [F]
+    const float* masks;      // [n_masks, F] or nullptr (ones)
+    long long* cand2;        // [Q, C] the survivors in ascending id order, padded with -1
+    int* n_cand2;            // [Q]
+    unsigned long long* stats;   // [2] or nullptr: candidates seen / survivors kept (mfar_stage2_stats)
+    int C, F, E, k, query_cond, n_masks;
+};
+#define PRUNE_LDS_BYTES(C, E, F) (MIX_LDS_BYTES(C, E, F) + (((size_t)(C) + 15) & ~(size_t)15))
+__device__ __forceinline__ float s2_nextdown(float x) { return -s1_nextup(-x); }
+__global__ void __launch_bounds__(256) mfar_s2_prune_kernel(const PruneParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SelLds L = sel_lds(smem, p.C);
+    u64* keys = L.keys;
+    int& n_s = L.misc[0];
+    float* z = (float*)(L.misc + 4);
+    float* wgt = z + MFAR_MAX_FIELDS;
+    float* msk = wgt + MFAR_MAX_FIELDS;
+    float* qs = msk + MFAR_MAX_FIELDS;
+    float* Ws = qs + (p.query_cond ? p.E : 0);
+    unsigned char* surv = (unsigned char*)(Ws + (p.query_cond ? (size_t)p.E * p.F : 0));
+    __shared__ float eps_s[MFAR_MAX_FIELDS];
+    __shared__ int wsum[4];
+    const int qi = blockIdx.x;
+    const int nc = min(p.n_cand[qi], p.C);
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) surv[c] = 0;
+    if ((int)threadIdx.x < p.F) eps_s[threadIdx.x] = p.eps[(size_t)qi * MFAR_MAX_FIELDS + threadIdx.x];
+    mix_gate_weights(p.q + (size_t)qi * p.E, p.W, nullptr, p.query_cond, p.E, p.F, z, wgt, msk, qs, Ws);
+    const float* xq = p.xa + (size_t)qi * p.C * p.F;
+    const long long* cq = p.cand + (size_t)qi * p.C;
+    for (int m = 0; m < p.n_masks; ++m) {
+        if ((int)threadIdx.x < p.F) msk[threadIdx.x] = p.masks ? p.masks[(size_t)m * p.F + threadIdx.x] : 1.0f;
+        if (threadIdx.x == 0) n_s = 0;
+        __syncthreads();
+        // lower ends: the mixer's chain on x - eps (x + eps under a negative mask entry), rounded outwards
+        for (int c = threadIdx.x; c < nc; c += blockDim.x) {
+            const long long id = cq[c];
+            if (id < 0) continue;
+            const float* xr = xq + (size_t)c * p.F;
+            float acc = 0.0f;
+            for (int f = 0; f < p.F; ++f) {
+                const float v = xr[f], e = eps_s[f], mf = msk[f];
+                const float end = mf >= 0.0f ? s2_nextdown(v - e) : s1_nextup(v + e);
+                acc = __builtin_fmaf(wgt[f], end * mf, acc);
+            }
+            if (acc != acc) continue;       // NaN: no lower bound (the candidate survives below)
+            keys[atomicAdd(&n_s, 1)] = make_key(acc, (u32)id);
+        }
+        __syncthreads();
+        const int n = n_s;
+        const int mm = block_topk_sorted<16>(keys, n, p.k, L.sel, L.sorted, L.red);
+        const float T = mm == p.k ? key_score(L.sorted[p.k - 1]) : -__builtin_inff();
+        for (int c = threadIdx.x; c < nc; c += blockDim.x) {
+            if (cq[c] < 0 || surv[c]) continue;
+            const float* xr = xq + (size_t)c * p.F;
+            float acc = 0.0f;
+            for (int f = 0; f < p.F; ++f) {
+                const float v = xr[f], e = eps_s[f], mf = msk[f];
+                const float end = mf >= 0.0f ? s1_nextup(v + e) : s2_nextdown(v - e);
+                acc = __builtin_fmaf(wgt[f], end * mf, acc);
+            }
+            if (!(acc < T)) surv[c] = 1;    // NaN upper ends survive
+        }
+        __syncthreads();                    // T (L.sorted), keys and n_s are reused by the next mask
+    }
+    // compaction in candidate order (every thread owns a contiguous run)
+    const int per = (p.C + 255) / 256;
+    const int b = threadIdx.x * per, e_ = min(b + per, nc);
+    int mine = 0;
+    for (int i = b; i < e_; ++i) mine += surv[i] ? 1 : 0;
+    int incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane_id() >= off) incl += v;
+    }
+    if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int ww = 0; ww < (int)(threadIdx.x >> 6); ++ww) wbase += wsum[ww];
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int pos = wbase + incl - mine;
+    long long* out = p.cand2 + (size_t)qi * p.C;
+    for (int i = b; i < e_; ++i)
+        if (surv[i]) out[pos++] = cq[i];
+    for (int i = total + threadIdx.x; i < p.C; i += blockDim.x) out[i] = -1;
+    if (threadIdx.x == 0) {
+        p.n_cand2[qi] = total;
+        if (p.stats) {
+            atomicAdd(&p.stats[0], (unsigned long long)nc);
+            atomicAdd(&p.stats[1], (unsigned long long)total);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

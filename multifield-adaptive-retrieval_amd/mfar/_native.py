@@ -83,7 +83,13 @@ SIGNATURES = {
     "mfar_get_screen": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_float)]),
     "mfar_screen_field_info": (_i, [_vp, _i, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "mfar_screen_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
+    "mfar_set_stage2_mode": (_i, [_vp, _i]),
+    "mfar_stage2_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
 }
+
+# MFAR_ABI_VERSION of include/mfar_hip.h these signatures were written against.  A library that reports another value has
+# different argument lists behind the same names (pointers would land in the wrong slots): lib() refuses it.
+ABI_VERSION = 101
 
 
 def lib():
@@ -104,6 +110,10 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        got = L.mfar_version()
+        if got != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} reports ABI version {got}, this package binds version {ABI_VERSION}: "
+                              f"rebuild the library (make -C {CSRC})")
         _lib = L
     return _lib
 

@@ -380,6 +380,16 @@ class MultiFieldIndex:
         Outputs are bit-identical in every mode; `eps_mult` is a test knob (1 = rigorous proof)."""
         _native.check(_native.lib().mfar_set_screen(self._h, int(mode), float(eps_mult)))
 
+    def set_stage2_mode(self, mode: int = 1):
+        """Stage 2 of an fp32 index (include/mfar_hip.h): 0 = gather every (candidate, field) row from the fp32 slab, 1 = the
+        certified two-level stage 2 whenever its gather slab is current.  Outputs are bit-identical in both modes."""
+        _native.check(_native.lib().mfar_set_stage2_mode(self._h, int(mode)))
+
+    def stage2_stats(self) -> dict:
+        ok, nbytes, nc, ns = ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _native.check(_native.lib().mfar_stage2_stats(self._h, ctypes.byref(ok), ctypes.byref(nbytes), ctypes.byref(nc), ctypes.byref(ns)))
+        return dict(two_level=bool(ok.value), gather_slab_bytes=nbytes.value, n_candidates=nc.value, n_survivors=ns.value)
+
     def screen_field_info(self, field: int):
         """(distinct vectors of the field = rows the screened pass scans, size of its largest group of identical rows);
         (-1, -1) while no screen is current (include/mfar_hip.h)."""

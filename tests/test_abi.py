@@ -26,7 +26,20 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"libmfar_hip.so does not export {name}"
     assert sorted(_native.SIGNATURES) == declared, "python binding table and header disagree"
-    assert L.mfar_version() >= 100
+    # the version is pinned exactly: header, library and binding table must move together on every signature change
+    hdr = open(os.path.join(ROOT, "include", "mfar_hip.h")).read()
+    want = int(re.search(r"#define\s+MFAR_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert L.mfar_version() == want == _native.ABI_VERSION == 101
+
+
+def test_stale_library_is_refused(tmp_path, monkeypatch):
+    """A library that reports another ABI version has other argument lists behind the same names: lib() must refuse it."""
+    from mfar import _native
+    _native.lib()
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "ABI_VERSION", _native.ABI_VERSION + 1)
+    with pytest.raises(ImportError, match="ABI version"):
+        _native.lib()
 
 
 def test_no_device_fails_loudly_not_silently():
@@ -59,6 +72,8 @@ def test_argument_validation_without_device():
     assert L.mfar_merge_workspace_bytes(64, 8, 100) > 64 * 800 * 8 * 4
     assert L.mfar_retrieve_fields(None, None, 1, 100, 1, None, None, 0, None) == -1
     assert L.mfar_set_wgs_per_cu(None, 2) == -1
+    assert L.mfar_set_stage2_mode(None, 1) == -1
+    assert L.mfar_stage2_stats(None, None, None, None, None) == -1
 
 
 def test_python_mirror_keeps_reference_signatures():

@@ -59,3 +59,32 @@ def test_screen_error_bound_holds(E, scale, seed, shift):
             assert err <= eps, (i, terms, err, eps)
             worst = max(worst, err / eps)
     assert worst < 0.5            # the rigorous bound is comfortably loose on real numbers
+
+
+def test_stage2_approximate_scores_stay_inside_the_rigorous_bound():
+    """The two-level stage 2's bound (csrc/mfar_select.h: mfar_s2_prep_kernel), measured: |approximate - exact| of every (query,
+    row) pair against eps, the approximate score re-derived in numpy from the same centring / scale rule (fp16 of
+    (d - mean) * 2^e, fp32 query) -- an independent restatement of the SRC_F16G arithmetic."""
+    rng = np.random.default_rng(304)
+    F, D, E, Q = 3, 5000, 768, 8
+    mu = rng.standard_normal(E).astype(np.float32)
+    mu /= np.linalg.norm(mu)
+    slab = (rng.standard_normal((F, D, E)) * 0.04 + mu).astype(np.float32)
+    q = (rng.standard_normal((Q, E)) * 0.04 + mu).astype(np.float32)
+    worst = 0.0
+    for f in range(F):
+        mean = slab[f].mean(0, dtype=np.float64).astype(np.float32)
+        c = slab[f] - mean
+        amax = np.abs(c).max()
+        sf = np.float32(2.0 ** (13 - int(np.floor(np.log2(amax)))))
+        h = (c * sf).astype(np.float16).astype(np.float64)
+        approx = (q.astype(np.float64) @ h.T) / float(sf) + (q.astype(np.float64) @ mean.astype(np.float64))[:, None]
+        exact = q.astype(np.float64) @ slab[f].astype(np.float64).T
+        qn = np.linalg.norm(q, axis=1)
+        dmax, mn = np.linalg.norm(c, axis=1).max(), np.linalg.norm(mean)
+        K, u16, u32 = float(E), 2.0 ** -11, 2.0 ** -24
+        eps = 1.25 * ((u16 + 1.01 * (K + 2) * u32) * qn * dmax + 1.01 * (K + 1) * u32 * qn * (dmax + mn) + 1.01 * K * u32 * qn * mn +
+                      u32 * np.sqrt(K) * qn / float(sf))
+        ratio = np.abs(approx - exact).max(1) / eps
+        worst = max(worst, float(ratio.max()))
+    assert worst < 0.5, worst       # typical errors sit far inside the worst-case bound
