@@ -392,7 +392,8 @@ def main():
                         "candidates_per_query": (st2["n_candidates"] - st2_0["n_candidates"]) / max(1, args.steps * Q),
                         "survivors_per_query": (st2["n_survivors"] - st2_0["n_survivors"]) / max(1, args.steps * Q)}
                        if st2["two_level"] and st2["n_candidates"] > st2_0["n_candidates"] else
-                       {"mode": "every (candidate, field) row gathered" + (" from the row-major bf16 companion" if st2["gather_slab_bytes"] else ""),
+                       {"mode": "every (candidate, field) row gathered from the " +
+                                ("row-major bf16 companion (whole-line gathers)" if args.dtype == "bf16" and st2["gather_slab_bytes"] else f"{args.dtype} slab"),
                         "gather_slab_bytes": st2["gather_slab_bytes"]}),
             "ms_per_launch": dt / args.steps * 1e3 * ps.coalesce,
             "recall_at_20": recall20, "ids_checksum": checksum, "index_build_s": t_build, "source_hash": source_hash(),

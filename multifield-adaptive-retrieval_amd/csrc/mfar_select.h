@@ -1000,13 +1000,15 @@ __global__ void __launch_bounds__(256) mfar_s2_prune_kernel(const PruneParams p)
     float* qs = msk + MFAR_MAX_FIELDS;
     float* Ws = qs + (p.query_cond ? p.E : 0);
     unsigned char* surv = (unsigned char*)(Ws + (p.query_cond ? (size_t)p.E * p.F : 0));
-    __shared__ float eps_s[MFAR_MAX_FIELDS];
-    __shared__ int wsum[4];
+    // no static LDS: the dynamic region may be the whole 160 KB.  eps lives in z[] (the gate logits are dead once the weights
+    // exist), the compaction's wave sums in the selection's reduction scratch
+    float* eps_s = z;
+    int* wsum = L.red;
     const int qi = blockIdx.x;
     const int nc = min(p.n_cand[qi], p.C);
     for (int c = threadIdx.x; c < p.C; c += blockDim.x) surv[c] = 0;
-    if ((int)threadIdx.x < p.F) eps_s[threadIdx.x] = p.eps[(size_t)qi * MFAR_MAX_FIELDS + threadIdx.x];
     mix_gate_weights(p.q + (size_t)qi * p.E, p.W, nullptr, p.query_cond, p.E, p.F, z, wgt, msk, qs, Ws);
+    if ((int)threadIdx.x < p.F) eps_s[threadIdx.x] = p.eps[(size_t)qi * MFAR_MAX_FIELDS + threadIdx.x];
     const float* xq = p.xa + (size_t)qi * p.C * p.F;
     const long long* cq = p.cand + (size_t)qi * p.C;
     for (int m = 0; m < p.n_masks; ++m) {
