@@ -2,7 +2,8 @@
 """bench.py -- queries/sec of the mFAR dense multi-field scorer on MI355X (BASELINE.json's metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W)
+    (N > 1: either under a launcher -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ... -- or
+     plainly: without WORLD_SIZE in the environment the script starts its own N ranks as child processes and relays rank 0's line)
 
 Workload (config.workload): the corpus BASELINE.json's metric is quoted on -- 1,000,000 docs x 8 dense fields x 768-d
 fp32, synthetic and STaRK-amazon shaped (mfar/synth.py) -- resident in HBM as the tiled slab, row-sharded over the N
@@ -80,11 +81,13 @@ def profile_counters(kernel: str, shape) -> dict:
 
 def pipeline_traffic(shape, s1_kernel, sample_kernel) -> dict:
     """Measured HBM bytes one launch of the screened pipeline moves, summed over its kernels (same committed PMC summary as
-    `profile_counters`, same source-hash rule): the scan, its sample pass, the two row-gather launches (exact re-scoring of
-    the screened rows + stage 2) and the small kernels.  None when no matching summary exists."""
+    `profile_counters`, same source-hash rule): the scan, its sample pass, the row-gather launches (exact re-scoring of the
+    screened rows; stage 2: approximate level from the fp16 gather slab + the survivors' fp32 rows) and the small kernels.
+    None when no matching summary exists."""
     want = source_hash()
-    per_launch = {s1_kernel: 1, sample_kernel: 1, "mfar_score_rows_f32_kernel": 2, "void mfar_merge_lists_regs_kernel<48>": 1,
-                  "mfar_screen_certify_kernel": 1, "mfar_union_kernel": 1, "mfar_mix_topk_kernel": 1, "void mfar_sample_tau_kernel<16>": 1}
+    per_launch = {s1_kernel: 1, sample_kernel: 1, "void mfar_score_rows_kernel<0>": 2, "void mfar_score_rows_kernel<1>": 1,
+                  "void mfar_merge_lists_regs_kernel<48>": 1, "mfar_screen_certify_kernel": 1, "mfar_union_kernel": 1, "mfar_mix_topk_kernel": 1,
+                  "void mfar_sample_tau_kernel<16>": 1, "mfar_s2_prune_kernel": 1, "mfar_s2_prep_kernel": 1}
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), reverse=True):
         try:
             d = json.load(open(fn))
@@ -95,7 +98,11 @@ def pipeline_traffic(shape, s1_kernel, sample_kernel) -> dict:
         ks = d.get("kernels", {})
         if s1_kernel not in ks:
             continue
-        parts = {k: m * ks[k]["hbm_bytes_per_launch"] for k, m in per_launch.items() if k in ks and "hbm_bytes_per_launch" in ks[k]}
+        parts = {}
+        for k, m in per_launch.items():
+            hit = [n for n in ks if n == k or n.startswith(k + "(")]
+            if hit and "hbm_bytes_per_launch" in ks[hit[0]]:
+                parts[k] = m * ks[hit[0]]["hbm_bytes_per_launch"]
         return {"bytes_per_launch": sum(parts.values()), "by_kernel_GB": {k: round(v / 1e9, 3) for k, v in parts.items()},
                 "source": os.path.relpath(fn, ROOT)}
     return None
@@ -108,6 +115,48 @@ def s1_kernel_name(dtype, screened, E, wide=False):
     if screened and wide:
         return "mfar_stage1_f16w_kernel" if (E // 16) % 6 == 0 else "mfar_stage1_f16w4_kernel"
     return f"mfar_stage1_f16{rr}_kernel" if screened else "mfar_stage1_kernel"
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher: start N ranks of this script as CHILD processes (one per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) before anything in this process has touched the GPU, relay rank 0's
+    JSON line, and fail when any rank fails.  The parent never imports torch and never re-execs."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    import threading
+    procs = []
+    out0 = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)   # drain rank 0's pipe while it runs
+    reader.start()
+    rc, line = 0, None
+    live = list(range(n))
+    while live:
+        for r in list(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.remove(r)
+            if r == 0:
+                reader.join(timeout=30)
+                line = out0[0] if out0 else None
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for o in live:                       # exactly the processes started above
+                    procs[o].terminate()
+        time.sleep(0.05)
+    if rc == 0 and line:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return rc or (0 if line else 1)
 
 
 def main():
@@ -130,13 +179,23 @@ def main():
                     help="share of (document, field) pairs that hold the field's empty-text vector (real STaRK fields are sparse; "
                          "0.08 = the headline corpus)")
     ap.add_argument("--stage2", choices=["auto", "full"], default="auto",
-                    help="auto: certified two-level stage 2 (fp16 gather slab -> bounds -> fp32 rows of the survivors; bit-identical); "
-                         "full: gather every (candidate, field) row from the fp32 slab")
+                    help="auto: certified two-level stage 2 (fp16 gather slab -> interval bounds -> fp32 rows of the survivors; "
+                         "bit-identical); full: gather every (candidate, field) row from the fp32 slab")
+    ap.add_argument("--row-shards", default="0",
+                    help="R row shards per replica group (N = G groups x R shards, mfar/data/sharded.py ReplicaLayout): 0 = N (the "
+                         "north-star layout: one group, every batch crosses xGMI), 1 = N full replicas (the reference's "
+                         "query-sharded search), 'auto' = the smallest R whose share of the index fits the free HBM")
     ap.add_argument("--coalesce", type=int, default=0, help="batches scanned per launch (0 = auto: 2 when the wide screened pass is available)")
+    ap.add_argument("--sustain-s", type=float, default=1.0, help="length of the sustained leg (same pipeline, >= this many seconds; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the exact-fp32 leg and the structured-corpus leg")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the exact-fp32 leg, the structured-corpus leg, the fused leg, "
+                                                                  "the sustained leg and (N > 1) the replica-layout leg")
     ap.add_argument("--cpu-sample-docs", type=int, default=0, help="0 = the full corpus when host RAM allows, else 100000")
     args = ap.parse_args()
+
+    # `--gpus N` without a launcher: this process only spawns the ranks (before anything initialises the GPU)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     # stdout carries exactly ONE line, the JSON result of rank 0: libraries that write to the process's stdout on their own (RCCL
     # prints a version banner from C when the first communicator is created) are sent to stderr for the duration of the run
@@ -160,13 +219,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     N = world
     dist = None
-    if N > 1:
+    rccl = None
+    force_exchange = N == 1 and os.environ.get("MFAR_BENCH_FORCE_EXCHANGE") == "1"
+    if N > 1 or force_exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("MASTER_PORT", "29511" if N > 1 else "29512")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # MFAR_BENCH_BACKEND=gloo + MFAR_BENCH_SHARE_GPU=1: dry-run of the N > 1 control flow on a one-GPU box (all ranks
         # on cuda:0, host-staged collectives).  The driver's scaling runs use the default: nccl (= RCCL), one GPU per rank.
+        # (N == 1 with MFAR_BENCH_FORCE_EXCHANGE=1: the exchange path over a one-rank RCCL group, a diagnostic.)
         backend = os.environ.get("MFAR_BENCH_BACKEND", "nccl")
         if os.environ.get("MFAR_BENCH_SHARE_GPU") == "1":
             local_rank = 0
@@ -177,100 +239,135 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=N)
     else:
         torch.cuda.set_device(local_rank)
-        if os.environ.get("MFAR_BENCH_FORCE_EXCHANGE") == "1":
-            # diagnostic: N = 1 through the multi-GPU exchange path (one-rank RCCL group: both all-gathers per launch, owned
-            # scoring, top-k merge) -- what the exchange costs per launch on top of the single-shard tail
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29512")
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{local_rank}"))
     dev = torch.device(f"cuda:{local_rank}")
 
     from mfar import synth
     from mfar.data import index as idxmod
     from mfar.data.pipeline import PipelinedSearcher
+    from mfar.data.sharded import ReplicaLayout, choose_row_shards
 
     D, F, E, Q = args.docs, args.fields, args.dim, args.batch
+    # layout: N ranks = G replica groups x R row shards (R = N unless asked otherwise)
+    esz = 2 if args.dtype == "bf16" else 4
+    whole_index_bytes = int(D * F * E * (esz + (2 if (args.dtype == "f32" or args.screen == "on") else 0) + 2) + D * F * 20)
+    if args.row_shards == "auto":
+        R = choose_row_shards(N, whole_index_bytes, torch.cuda.mem_get_info(local_rank)[0])
+        if N > 1:       # every rank must take the same decision: the most conservative one
+            t = torch.tensor([R], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            R = int(t.item())
+            while N % R:
+                R += 1
+    else:
+        R = int(args.row_shards) or N
+
+    if dist is not None:
+        # proof that the collective backend carries all N ranks: an all-reduce of ones, and every rank's placement
+        t = torch.ones(1, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t)
+        lay0 = ReplicaLayout(N, rank, R)
+        info = [None] * N
+        dist.all_gather_object(info, {"rank": rank, "device": f"cuda:{local_rank}", "pid": os.getpid(), "replica_group": lay0.group_index,
+                                      "row_shard": lay0.shard_index, "rows": list(lay0.rows(D))})
+        rccl = {"world_size": dist.get_world_size(), "backend": dist.get_backend() + (" (= RCCL)" if dist.get_backend() == "nccl" else ""),
+                "allreduce_of_ones": float(t.item()), "ranks": info}
+        if rccl["allreduce_of_ones"] != N:
+            raise SystemExit(f"all-reduce of ones over {N} ranks returned {rccl['allreduce_of_ones']}")
+
     # distinct synthetic queries (each plants up to 5 relevant documents); long runs cycle through them
     n_q_total = max(Q, min(max(4096, (args.steps + args.warmup) * Q), 65536, D // 16))
-    t_build = time.time()
+    t_build0 = time.time()
     corpus = synth.SyntheticCorpus(D, F, E, n_queries=n_q_total, seed=0xDEADBEEF, device=str(dev),
                                    structured=(args.corpus == "structured"), empty_frac=args.empty_frac)
-    row0, row1 = D * rank // N, D * (rank + 1) // N          # contrastive.py:470
-    ix = corpus.build_index(idxmod, row0=row0, n=row1 - row0, dtype=args.dtype)
-    if args.wgs_per_cu:
-        ix.set_wgs_per_cu(args.wgs_per_cu)
-    if args.screen == "off":
-        ix.set_screen(0)
-    elif args.screen == "on":
-        ix.set_screen(2)
-    if args.stage2 == "full":
-        ix.set_stage2_mode(0)
-    mode, eps_mult = ix.screen_setting
-    if eps_mult != 1.0:
-        raise SystemExit(f"screen eps_mult = {eps_mult}: the certificate would not be the rigorous one")
-    t_build = time.time() - t_build
     W = corpus.W
     mask = torch.ones(F, device=dev)
 
-    # Two-deep pipeline: stage 1 of batch i+1 (main stream) overlaps the tail of batch i (side stream).  Every batch is
-    # still processed completely inside the timed region (the region ends with a full device synchronisation).
-    force_exchange = N == 1 and os.environ.get("MFAR_BENCH_FORCE_EXCHANGE") == "1"
-    ps = PipelinedSearcher(ix, W, mask, k1=K1, k2=K2, sentinel=True, query_cond=True, max_batch=Q, coalesce=args.coalesce or None,
-                           exchange=True if force_exchange else None)
+    def sync_all():
+        torch.cuda.synchronize()
+        if N > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    def run(searcher, cp, first, n, keep):
-        # results are taken `lag` submissions late, so that two launches of the pipeline stay in flight (a launch scans one
-        # batch, or two coalesced ones when the index offers the wide screened pass: mfar/data/pipeline.py)
+    def run(searcher, cp, batches, keep):
+        """`batches`: the global batch indices this rank's group serves.  Results are taken `lag` submissions late, so that two
+        launches of the pipeline stay in flight (a launch scans one batch, or two coalesced ones when the index offers the wide
+        screened pass: mfar/data/pipeline.py)."""
         tickets = []
         def take(t):
             r = searcher.result(t)
             if keep is not None:
                 keep.append((r["ids"].clone(), r["scores"].clone(), r["n_valid"].clone()))
-        for i in range(n):
-            tickets.append(searcher.submit(cp.queries((first + i) * Q, Q)))
-            if i >= searcher.lag:
-                take(tickets[i - searcher.lag])
-        for t in tickets[max(0, n - searcher.lag):]:
+        for j, i in enumerate(batches):
+            tickets.append(searcher.submit(cp.queries(i * Q, Q)))
+            if j >= searcher.lag:
+                take(tickets[j - searcher.lag])
+        for t in tickets[max(0, len(batches) - searcher.lag):]:
             take(t)
 
-    def timed(searcher, index, cp, first, steps, keep):
-        torch.cuda.synchronize()
-        if N > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def timed(searcher, index, cp, lay, first, steps, keep):
+        """EXACTLY `steps` batches, dealt round-robin to the replica groups, between two barriers; max over ranks."""
+        mine = lay.my_batches(first, steps)
+        sync_all()
         index.set_timing(True)
         t0 = time.perf_counter()
-        run(searcher, cp, first, steps, keep)
-        torch.cuda.synchronize()
-        if N > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        run(searcher, cp, mine, keep)
+        sync_all()
         dt = time.perf_counter() - t0
         ms, n = index.stage1_timing()
         index.set_timing(False)
         if N > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dt, ms / max(1, n), n
+        return dt, ms / max(1, n), n, mine
 
-    # Setup, not warm-up: the first two batches allocate the pipeline's scratch (both slots) and build the fp16 screen slab
-    # of an fp32 index (one pass over the corpus, part of index construction).  --warmup steps follow as asked.
-    t_prime = time.time()
-    run(ps, corpus, 0, 2, None)
+    def build(lay):
+        row0, row1 = lay.rows(D)                                   # contrastive.py:470 inside the replica group
+        ix = corpus.build_index(idxmod, row0=row0, n=row1 - row0, dtype=args.dtype)
+        if args.wgs_per_cu:
+            ix.set_wgs_per_cu(args.wgs_per_cu)
+        if args.screen == "off":
+            ix.set_screen(0)
+        elif args.screen == "on":
+            ix.set_screen(2)
+        if args.stage2 == "full":
+            ix.set_stage2_mode(0)
+        # Two-deep pipeline: stage 1 of launch i+1 (main stream) overlaps the tail of launch i (side stream).  Every batch is
+        # still processed completely inside the timed region (the region ends with a full device synchronisation).
+        ps = PipelinedSearcher(ix, W, mask, k1=K1, k2=K2, sentinel=True, query_cond=True, max_batch=Q, coalesce=args.coalesce or None,
+                               group=lay.group, exchange=True if force_exchange else (lay.exchanges if N > 1 else None))
+        return ix, ps, row0, row1
+
+    lay = ReplicaLayout(N, rank, R)
+    lay.make_groups()
+    ix, ps, row0, row1 = build(lay)
+    mode, eps_mult = ix.screen_setting
+    if eps_mult != 1.0:
+        raise SystemExit(f"screen eps_mult = {eps_mult}: the certificate would not be the rigorous one")
+
+    # Setup, not warm-up: the first batches allocate the pipeline's scratch (both slots) and build the fp16 screen slab and the
+    # gather slab of an fp32 index (one pass over the corpus each, part of index construction).  --warmup steps follow as asked.
+    run(ps, corpus, lay.my_batches(0, 2 * lay.G * ps.coalesce), None)
     torch.cuda.synchronize()
-    t_build += time.time() - t_prime
+    t_build = time.time() - t_build0
     results = []
-    run(ps, corpus, 0, args.warmup, None)
+    run(ps, corpus, lay.my_batches(0, args.warmup), None)
     scr0, st2_0 = ix.screen_stats(), ix.stage2_stats()
-    dt, s1_avg_ms, s1_n = timed(ps, ix, corpus, args.warmup, args.steps, results)
+    dt, s1_avg_ms, s1_n, my_steps = timed(ps, ix, corpus, lay, args.warmup, args.steps, results)
     scr, st2 = ix.screen_stats(), ix.stage2_stats()
     screened = bool(scr["built"])                            # stage 1 ran on the fp16 screen slab of the index
 
+    # ---- sustained leg: the same pipeline for >= --sustain-s seconds (the driver's --steps 20 is a 27 ms region)
+    sustained = None
+    if args.sustain_s > 0 and not args.no_extra_legs:
+        n_sus = max(args.steps, int(args.sustain_s / max(dt / args.steps, 1e-6) * 1.05) + 1)
+        n_sus = min(n_sus, 20000)
+        sdt, _, _, _ = timed(ps, ix, corpus, lay, args.warmup, n_sus, None)
+        sustained = {"steps": n_sus, "seconds": sdt, "queries_per_s": n_sus * Q / sdt, "ms_per_step": sdt / n_sus * 1e3,
+                     "what": "the same pipeline and layout run for at least --sustain-s seconds (queries cycle through the pool)"}
+
     # ---- the dominant kernel with nothing beside it: the same scans issued serially on one stream (the split-phase tail of the
-    #      previous launch is what stretches a scan inside the pipeline; it moves ~3 GB of row gathers through the same HBM)
+    #      previous launch is what stretches a scan inside the pipeline; it moves GBs of row gathers through the same HBM)
     alone_ms = None
     if screened and N == 1 and not args.no_extra_legs:
         nq = ps.Qmax // Q
@@ -284,13 +381,13 @@ def main():
 
     # ---- second leg, same process, same index: the exhaustive fp32 MFMA pass (screen off), and its bits vs the default leg
     exact_leg = None
-    if args.dtype == "f32" and screened and not args.no_extra_legs:
+    if args.dtype == "f32" and screened and N == 1 and not args.no_extra_legs:
         ix.set_screen(0)
         ps_ex = PipelinedSearcher(ix, W, mask, k1=K1, k2=K2, sentinel=True, query_cond=True, max_batch=Q)   # 64 queries per exact pass
-        run(ps_ex, corpus, 0, 2, None)
+        run(ps_ex, corpus, list(range(2)), None)
         ex_res = []
         ex_steps = min(8, args.steps)
-        ex_dt, ex_ms, ex_n = timed(ps_ex, ix, corpus, args.warmup + args.steps - ex_steps, ex_steps, ex_res)
+        ex_dt, ex_ms, ex_n, _ = timed(ps_ex, ix, corpus, lay, args.warmup + args.steps - ex_steps, ex_steps, ex_res)
         del ps_ex
         ix.set_screen(1)
         same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(results[-ex_steps:], ex_res))
@@ -305,11 +402,51 @@ def main():
                      "ids_and_score_bits_identical_to_default_leg": True,
                      **profile_counters("mfar_stage1_kernel", (D, F, E, Q, N))}
 
+    # ---- N > 1: the other corner of the layout in the same run -- N full replicas, batches dealt round-robin, no exchange (the
+    #      reference's query-sharded search) -- when the main leg row-sharded and the whole index fits one GPU
+    replica_leg = None
+    n_redone_main = ps.n_redone
+    if N > 1 and R > 1 and not args.no_extra_legs and whole_index_bytes < 0.6 * torch.cuda.mem_get_info(local_rank)[1]:
+        del ps
+        ix.close()
+        lay_r = ReplicaLayout(N, rank, 1)
+        ix_r, ps_r, _, _ = build(lay_r)
+        run(ps_r, corpus, lay_r.my_batches(0, 2 * N * ps_r.coalesce), None)
+        torch.cuda.synchronize()
+        r_res = []
+        r_dt, _, _, r_mine = timed(ps_r, ix_r, corpus, lay_r, args.warmup, args.steps, r_res)
+        h = hashlib.sha256()
+        for ids, _, _ in r_res:
+            h.update(ids.cpu().numpy().tobytes())
+        mine_sum = [None] * N
+        dist.all_gather_object(mine_sum, {"batches": r_mine, "sha": h.hexdigest()})
+        replica_leg = {"parallelism": lay_r.describe(), "row_shards": 1, "replica_groups": N, "queries_per_s": args.steps * Q / r_dt,
+                       "ms_per_step": r_dt / args.steps * 1e3, "steps": args.steps, "batches_per_rank": [len(m["batches"]) for m in mine_sum],
+                       "what": "same corpus, same K steps, every rank holds ALL rows and serves every N-th batch: whole-node "
+                               "throughput of the reference's own evaluation layout (contrastive.py:184,200,207)"}
+        ps, ix = ps_r, ix_r
+
+    # results of all replica groups -> rank 0 (each group's first shard reports the batches it served)
+    gathered = None
+    if N > 1:
+        mine = None
+        if lay.shard_index == 0:
+            mine = {"batches": my_steps, "ids": [r[0].cpu().numpy() for r in results]}
+        allr = [None] * N
+        dist.all_gather_object(allr, mine)
+        if rank == 0:
+            by_batch = {}
+            for m in allr:
+                if m:
+                    by_batch.update(dict(zip(m["batches"], m["ids"])))
+            gathered = [by_batch[i] for i in range(args.warmup, args.warmup + args.steps)]
+    else:
+        gathered = [r[0].cpu().numpy() for r in results]
+
     if rank == 0:
         # Recall@20 against the synthetic qrels (quality gate named by the metric)
         rec = []
-        for i, (ids, _, nv) in enumerate(results):
-            ids = ids.cpu().numpy()
+        for i, ids in enumerate(gathered):
             rel = corpus.qrels((args.warmup + i) * Q, Q)
             for j in range(Q):
                 rec.append(len(set(ids[j, :20].tolist()) & rel[j]) / len(rel[j]))
@@ -317,8 +454,8 @@ def main():
         checksum = None
         if os.environ.get("MFAR_BENCH_DUMP_IDS") == "1":      # used by tests/test_gpu_multirank.py
             h = hashlib.sha256()
-            for ids, _, _ in results:
-                h.update(ids.cpu().numpy().tobytes())
+            for ids in gathered:
+                h.update(ids.tobytes())
             checksum = h.hexdigest()
         qps = args.steps * Q / dt
         flops_per_launch = 2.0 * (row1 - row0) * F * E * 64      # algorithmic: 2*D*F*E per query x 64 queries
@@ -352,7 +489,7 @@ def main():
                      "the fp32 slab.  One launch serves queries_per_launch queries: the wide pass (one fp16 query term, 128 "
                      "columns) reads the screen rows once per 128 queries, round 1's pass (two terms, 64 columns) once per 64 -- "
                      "bytes per QUERY halved, which is where the throughput comes from; `frac` is per launch and lower than "
-                     "round 1's 0.73 because the tail of the previous launch (exact re-scoring + stage 2: ~3 GB of row gathers "
+                     "the `alone` figure because the tail of the previous launch (exact re-scoring + stage 2: GBs of row gathers "
                      "for 128 queries) shares HBM with the scan for most of its duration (`alone` = the same kernel by itself).") if screened else None,
             "algorithmic_flops_per_launch": flops_per_launch,
         })
@@ -371,47 +508,48 @@ def main():
                       ("bf16 docs, fp32 queries; lists and scores = the exact fp32 chain over the bf16 docs (certified fp16 screen)" if screened
                        else "bf16 docs x fp32 queries (3 exact bf16 terms), fp32 accumulate")), "data": "synthetic",
             "config": {"workload": f"synthetic STaRK-amazon-shaped corpus ({args.corpus}" + (f", {args.empty_frac:g} of the field vectors empty" if args.empty_frac != 0.08 else "") + f"), {D} docs x {F} dense fields x {E}d {args.dtype}, "
-                                   f"row-sharded over {N} GPU(s); two-stage scorer k1=k2=100, zero-sentinel mode",
+                                   f"{lay.G} replica group(s) x {lay.R} row shard(s) over {N} GPU(s); two-stage scorer k1=k2=100, zero-sentinel mode",
                        "docs": D, "fields": F, "dim": E, "query_batch": Q, "k1": K1, "k2": K2, "timed_queries": args.steps * Q,
-                       "parallelism": (f"row-shard x{N}, lists-first exchange over RCCL (per batch: all-gather of the stage-1 lists, "
-                                       f"all-gather of the local top-k + certificate flag)") if N > 1 else
-                                      ("single shard through the exchange path (one-rank RCCL group, diagnostic)" if force_exchange else "single shard"),
+                       "parallelism": ("single shard through the exchange path (one-rank RCCL group, diagnostic)" if force_exchange else lay.describe()),
+                       "row_shards": lay.R, "replica_groups": lay.G,
                        "pipeline": (f"2 launches in flight (stage 1 of launch i+1 overlaps the tail of launch i); a launch scans {ps.coalesce} "
                                     f"coalesced batch(es) of {Q} queries" + (" with the wide 128-column screened pass (one fp16 query term)"
                                                                              if ps.Qmax > 64 else "")),
                        "queries_per_launch": ps.Qmax},
+            "rccl": rccl,
             "stage1": (f"certified fp16 screen of the {args.dtype} slab (min(k+92,192) unique rows per list re-scored with the exact fp32 chain, "
                        "top-k proven or redone by the exact pass per field)" +
                        (": outputs bit-identical to the plain fp32 pass" if args.dtype == "f32" else "") if screened else
                        ("exact fp32 MFMA pass" if args.dtype == "f32" else "bf16 slab pass")),
             "screen": ({"lists_certified": (scr["n_checked"] - scr0["n_checked"]) - (scr["n_failed"] - scr0["n_failed"]),
-                        "lists_redone_exactly": scr["n_failed"] - scr0["n_failed"], "batches_redone": ps.n_redone,
+                        "lists_redone_exactly": scr["n_failed"] - scr0["n_failed"], "batches_redone": n_redone_main,
                         "screen_slab_bytes": scr["screen_bytes"], "unique_rows_per_field": scr.get("unique_rows")} if screened else None),
             "stage2": ({"mode": "certified two-level (fp16 gather slab -> interval bounds through the mixer's chain -> fp32 rows of the survivors)",
                         "gather_slab_bytes": st2["gather_slab_bytes"],
-                        "candidates_per_query": (st2["n_candidates"] - st2_0["n_candidates"]) / max(1, args.steps * Q),
-                        "survivors_per_query": (st2["n_survivors"] - st2_0["n_survivors"]) / max(1, args.steps * Q)}
+                        "candidates_per_query": (st2["n_candidates"] - st2_0["n_candidates"]) / max(1, len(my_steps) * Q),
+                        "survivors_per_query": (st2["n_survivors"] - st2_0["n_survivors"]) / max(1, len(my_steps) * Q)}
                        if st2["two_level"] and st2["n_candidates"] > st2_0["n_candidates"] else
                        {"mode": "every (candidate, field) row gathered from the " +
                                 ("row-major bf16 companion (whole-line gathers)" if args.dtype == "bf16" and st2["gather_slab_bytes"] else f"{args.dtype} slab"),
                         "gather_slab_bytes": st2["gather_slab_bytes"]}),
             "ms_per_launch": dt / args.steps * 1e3 * ps.coalesce,
+            "sustained": sustained,
             "recall_at_20": recall20, "ids_checksum": checksum, "index_build_s": t_build, "source_hash": source_hash(),
             "diagnostic_knobs": {"MFAR_S1_DEBUG": "unset", "screen_eps_mult": eps_mult},
             "roofline": roof,
             "pipeline_hbm": pipe,
             "roofline_exact_fp32": exact_leg,
+            "replica_layout": replica_leg,
         }
         if N == 1 and args.dtype == "f32" and args.corpus == "plain" and not args.no_extra_legs:
             line["structured_corpus"] = structured_leg(synth, idxmod, PipelinedSearcher, run, dev, E, Q, torch, np)
         if N == 1 and args.dtype == "f32" and args.corpus == "plain" and not args.no_extra_legs:
-            line["fused_mode"] = fused_leg(corpus, ix, results, args, Q, recall20, torch, np)
+            line["fused_mode"] = fused_leg(corpus, ix, [(torch.from_numpy(g),) for g in gathered], args, Q, recall20, torch, np)
         if N == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(corpus, ix, args, np, torch)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
-    if N > 1 or force_exchange:
-        import torch.distributed as dist
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -423,19 +561,19 @@ def structured_leg(synth, idxmod, PipelinedSearcher, run, dev, E, Q, torch, np):
     cp = synth.SyntheticCorpus(D, F, E, n_queries=4096, seed=0xDEADBEEF, device=str(dev), structured=True)
     ix = cp.build_index(idxmod)
     ps = PipelinedSearcher(ix, cp.W, torch.ones(F, device=dev), k1=K1, k2=K2, max_batch=Q)
-    run(ps, cp, 0, 6, None)          # both slots and a coalesced launch each: scratch allocated, screen built
+    run(ps, cp, list(range(6)), None)          # both slots and a coalesced launch each: scratch allocated, screen built
     torch.cuda.synchronize()
     s0 = ix.screen_stats()
     keep = []
     t0 = time.perf_counter()
-    run(ps, cp, 6, steps, keep)
+    run(ps, cp, list(range(6, 6 + steps)), keep)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     s1 = ix.screen_stats()
     # same bits with the screen off (two batches)
     ix.set_screen(0)
     ex = []
-    run(PipelinedSearcher(ix, cp.W, torch.ones(F, device=dev), k1=K1, k2=K2, max_batch=Q), cp, 6, 2, ex)
+    run(PipelinedSearcher(ix, cp.W, torch.ones(F, device=dev), k1=K1, k2=K2, max_batch=Q), cp, [6, 7], ex)
     torch.cuda.synchronize()
     same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(keep[:2], ex))
     rec = []
@@ -477,7 +615,7 @@ def fused_leg(corpus, ix, results, args, Q, recall_exact, torch, np):
         for half in range(2):
             step = first + 2 * bi + half
             rel = corpus.qrels(step * Q, Q)
-            two = results[step - args.warmup][0].cpu().numpy()
+            two = results[step - args.warmup][0].numpy()
             for j in range(Q):
                 mine = set(ids[half * Q + j, :20].tolist())
                 rec.append(len(mine & rel[j]) / len(rel[j]))

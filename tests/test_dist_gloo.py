@@ -131,6 +131,80 @@ def test_two_rank_gloo_sharded_search_equals_unsharded(tmp_path):
         assert np.array_equal(o["n_valid"], ref["n_valid"])
 
 
+# ------------------------------------------------------------------------------------------------ replica groups x row shards
+def _layout_worker(rank, world, port, tmp, R):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "multifield-adaptive-retrieval_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mfar.data.sharded import ReplicaLayout, ShardedSearcher
+    lay = ReplicaLayout(world, rank, R)
+    lay.make_groups()
+    rng = np.random.default_rng(321)
+    F, D, E, Q, NB = 3, 803, 32, 4, 6
+    slab = (rng.standard_normal((F, D, E)) * 0.5 + 0.1).astype(np.float32)
+    qs = rng.standard_normal((NB, Q, E)).astype(np.float32)
+    W = (rng.standard_normal((E, F)) * 0.1).astype(np.float32)
+    r0, r1 = lay.rows(D)
+    searcher = ShardedSearcher(OracleShardBackend(slab[:, r0:r1].copy(), r0), group=lay.group) if lay.exchanges else None
+    out = {}
+    for b in lay.my_batches(0, NB):            # this group's share of the query batches
+        if searcher is not None:
+            assert searcher.world_size == R and searcher.rank == lay.shard_index
+            out[b] = searcher.search(qs[b], W, None)
+        else:                                   # R = 1: a full replica answers alone, no collective at all
+            from oracle import mfar_oracle as O
+            out[b] = O.c_two_stage(slab, qs[b], W, None)
+    np.savez(os.path.join(tmp, f"lay{R}_rank{rank}.npz"), batches=np.array(sorted(out), np.int64), r0=r0, r1=r1,
+             ids=np.stack([out[b]["ids"] for b in sorted(out)]) if out else np.zeros((0, Q, 100), np.int64),
+             scores=np.stack([out[b]["scores"] for b in sorted(out)]) if out else np.zeros((0, Q, 100), np.float32))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("R", [1, 2, 4])
+def test_replica_groups_times_row_shards_over_gloo(tmp_path, R):
+    """mfar/data/sharded.py ReplicaLayout with 4 gloo ranks: N = G groups x R row shards for R in {1, 2, 4}.  Batches are dealt
+    round-robin to the groups (contrastive.py:200), a group's ranks hold the reference's row split of the corpus (:470) and
+    exchange only among themselves; whatever R, every batch gets the unsharded oracle's ids and score bits, exactly once per
+    group member."""
+    import hashlib
+    world, port = 4, 30300 + (os.getpid() % 300) + 7 * R
+    mp.spawn(_layout_worker, args=(world, port, str(tmp_path), R), nprocs=world, join=True)
+    from oracle import mfar_oracle as O
+    from mfar.data.sharded import ReplicaLayout, choose_row_shards
+    rng = np.random.default_rng(321)
+    F, D, E, Q, NB = 3, 803, 32, 4, 6
+    slab = (rng.standard_normal((F, D, E)) * 0.5 + 0.1).astype(np.float32)
+    qs = rng.standard_normal((NB, Q, E)).astype(np.float32)
+    W = (rng.standard_normal((E, F)) * 0.1).astype(np.float32)
+    ref = [O.c_two_stage(slab, qs[b], W, None) for b in range(NB)]
+    seen = {b: 0 for b in range(NB)}
+    for r in range(world):
+        lay = ReplicaLayout(world, r, R)
+        o = np.load(os.path.join(tmp_path, f"lay{R}_rank{r}.npz"))
+        assert (int(o["r0"]), int(o["r1"])) == (D * lay.shard_index // R, D * (lay.shard_index + 1) // R)
+        assert o["batches"].tolist() == [b for b in range(NB) if b % lay.G == lay.group_index]
+        for j, b in enumerate(o["batches"].tolist()):
+            assert np.array_equal(o["ids"][j], ref[b]["ids"]), (R, r, b)
+            assert np.array_equal(o["scores"][j].view(np.uint32), ref[b]["scores"].view(np.uint32)), (R, r, b)
+            seen[b] += 1
+    assert all(v == R for v in seen.values())          # each batch answered by exactly one group (= R ranks)
+    h = hashlib.sha256(b"".join(ref[b]["ids"].tobytes() for b in range(NB))).hexdigest()
+    got = {}
+    for r in range(0, world, R):                       # one rank per group: the checksum over all batches equals the unsharded one
+        o = np.load(os.path.join(tmp_path, f"lay{R}_rank{r}.npz"))
+        got.update(dict(zip(o["batches"].tolist(), o["ids"])))
+    assert hashlib.sha256(b"".join(got[b].tobytes() for b in range(NB))).hexdigest() == h
+    # sizing rule: the smallest R whose share fits
+    assert choose_row_shards(8, 50 << 30, 250 << 30) == 1 and choose_row_shards(8, 400 << 30, 250 << 30) == 2
+    assert choose_row_shards(8, 1500 << 30, 250 << 30) == 8 and choose_row_shards(8, 10 ** 15, 250 << 30) == 8
+    with pytest.raises(ValueError):
+        ReplicaLayout(8, 0, 3)
+
+
 # ------------------------------------------------------------------------------------------------ training: gradient sync under fp16 loss scaling
 def _grad_worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)

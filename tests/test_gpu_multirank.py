@@ -12,12 +12,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(n, extra_env, dtype="f32"):
+def _bench(n, extra_env, dtype="f32", launcher=True, extra_args=()):
     env = dict(os.environ, **extra_env)
+    env.pop("WORLD_SIZE", None)
     args = ["--docs", "70000", "--fields", "4", "--dim", "128", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extra-legs",
-            "--dtype", dtype]
-    if n == 1:
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args
+            "--dtype", dtype] + list(extra_args)
+    if n == 1 or not launcher:      # plain `python bench.py --gpus N`: the script starts its own ranks
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
                "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + args
@@ -37,6 +38,56 @@ def test_ranks_on_one_gpu_match_single_rank(world, dtype):
     assert one["n_gpus"] == 1 and two["n_gpus"] == world and two["scaling"] == "strong"
     assert one["recall_at_20"] > 0.3 and two["recall_at_20"] == one["recall_at_20"]   # (weak planted signal at dim 128)
     assert two["ids_checksum"] == one["ids_checksum"]          # same top-100 ids for every query of every step
+
+
+def test_bench_starts_its_own_ranks_and_proves_them():
+    """`python bench.py --gpus 2` with NO launcher (the driver's command shape): the script spawns its two ranks itself, rank 0's
+    line is relayed, it names both ranks (all-reduce of ones == 2, per-rank rows) and the ids equal the single-rank run's."""
+    one = _bench(1, {"MFAR_BENCH_DUMP_IDS": "1"})
+    two = _bench(2, {"MFAR_BENCH_BACKEND": "gloo", "MFAR_BENCH_SHARE_GPU": "1", "MFAR_BENCH_DUMP_IDS": "1"}, launcher=False)
+    assert one["n_gpus"] == 1 and one["rccl"] is None
+    assert two["n_gpus"] == 2 and two["rccl"]["world_size"] == 2 and two["rccl"]["allreduce_of_ones"] == 2.0
+    assert [r["rows"] for r in two["rccl"]["ranks"]] == [[0, 35000], [35000, 70000]] and two["config"]["row_shards"] == 2
+    assert len({r["pid"] for r in two["rccl"]["ranks"]}) == 2
+    assert two["ids_checksum"] == one["ids_checksum"] and two["value"] > 0
+
+
+def test_bench_extra_legs_with_two_ranks():
+    """The default N > 1 run also measures the sustained leg and the other corner of the layout (N full replicas, no exchange)."""
+    env = dict(os.environ, MFAR_BENCH_BACKEND="gloo", MFAR_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--docs", "70000", "--fields", "4", "--dim", "128",
+                          "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--sustain-s", "0.2"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["sustained"]["seconds"] >= 0.2 and d["sustained"]["queries_per_s"] > 0
+    rl = d["replica_layout"]
+    assert rl["row_shards"] == 1 and rl["replica_groups"] == 2 and rl["batches_per_rank"] == [2, 2] and rl["queries_per_s"] > 0
+    assert d["config"]["row_shards"] == 2 and d["roofline_exact_fp32"] is None
+
+
+def test_bench_fails_when_a_rank_fails():
+    """A rank that dies takes the whole run down with a non-zero exit code (no line is printed, nothing hangs)."""
+    env = dict(os.environ, MFAR_BENCH_BACKEND="gloo", MFAR_BENCH_SHARE_GPU="1", MFAR_SCREEN_EPS_MULT="7")   # refused by every rank
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--docs", "20000", "--fields", "2", "--dim", "64",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra-legs"], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("R", [1, 2])
+def test_replica_group_layouts_match_single_rank(R):
+    """4 ranks = G replica groups x R row shards (`--row-shards R`; all on cuda:0 over gloo): R = 1 is the reference's
+    query-sharded search over full replicas (no exchange), R = 2 two groups of two row shards (exchange inside a group only).
+    Batches are dealt round-robin to the groups; the ids of every step equal the single-rank run's."""
+    one = _bench(1, {"MFAR_BENCH_DUMP_IDS": "1"})
+    four = _bench(4, {"MFAR_BENCH_BACKEND": "gloo", "MFAR_BENCH_SHARE_GPU": "1", "MFAR_BENCH_DUMP_IDS": "1"}, launcher=False,
+                  extra_args=["--row-shards", str(R)])
+    assert four["config"]["row_shards"] == R and four["config"]["replica_groups"] == 4 // R
+    assert [r["replica_group"] for r in four["rccl"]["ranks"]] == [i // R for i in range(4)]
+    assert four["ids_checksum"] == one["ids_checksum"] and four["recall_at_20"] == one["recall_at_20"]
 
 
 def test_exchange_path_over_rccl_with_one_rank():

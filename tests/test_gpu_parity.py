@@ -544,12 +544,15 @@ def test_bf16_sharded_equals_unsharded(idxmod):
 
 def test_bf16_stress_shape_per_gpu(idxmod):
     """BASELINE.json configs[4] (10M docs x 16 fields x 768d bf16 over 8 GPUs) at its PER-GPU shape: 1.25M x 16 x 768 bf16
-    = 30.7 GB.  Size-independent properties + re-sharding invariance."""
+    = 30.7 GB (+ the row-major companion for gathers).  Plain bf16 pass: size-independent properties, an EXHAUSTIVE torch check
+    of the stage-1 lists of three queries, re-sharding invariance.  Certified screen (`set_screen(2)`, bench.py --screen on):
+    the same exhaustive check and the oracle (natural-order chain over the bf16 rows, the bf16 contract) bit for bit -- stage-1
+    lists and the final top-100 -- on a row subset that holds every list member; plain and screened agree to 1e-4."""
     import torch
     from mfar import synth
     D, F, E, Q = 1_250_000, 16, 768, 64
-    if torch.cuda.mem_get_info(0)[0] < 80 << 30:
-        pytest.skip("needs ~70 GB of free HBM")
+    if torch.cuda.mem_get_info(0)[0] < 130 << 30:
+        pytest.skip("needs ~110 GB of free HBM")
     corpus = synth.SyntheticCorpus(D, F, E, n_queries=Q, seed=0xdeadbeef, device="cuda:0")
     ix = corpus.build_index(idxmod, dtype="bf16")
     q, W = corpus.queries(0, Q), corpus.W
@@ -561,6 +564,19 @@ def test_bf16_stress_shape_per_gpu(idxmod):
     assert (np.diff(sc, axis=1) <= 0).all() and (r1["n_valid"].cpu().numpy() == 100).all()
     rel = corpus.qrels(0, Q)
     assert np.mean([len(set(r1["ids"][i, :20].tolist()) & rel[i]) / len(rel[i]) for i in range(Q)]) > 0.9
+    probe = [0, 17, 63]
+    _exhaustive_stage1_check(ix, q, r1["field_ids"].cpu().numpy(), r1["field_scores"].cpu().numpy(), probe)
+    # the certified screen over the bf16 rows: lists and final scores are the exact natural-order chain's, bit for bit
+    ix.set_screen(2)
+    r3 = ix.search(q, W, None, return_fields=True)
+    torch.cuda.synchronize()
+    st = ix.screen_stats()
+    assert st["built"] and st["n_checked"] >= Q * F, st
+    _exhaustive_stage1_check(ix, q, r3["field_ids"].cpu().numpy(), r3["field_scores"].cpu().numpy(), probe)
+    with O.chain("natural"):
+        _oracle_check_on_subset(ix, q, W, None, r3, probe)
+    O.assert_topk_equivalent(r1["ids"].cpu().numpy(), r1["scores"].cpu().numpy(), r3["ids"].cpu().numpy(), r3["scores"].cpu().numpy(),
+                             tol=TOL, what="bf16 plain pass vs certified screen at 1.25M x 16")
     ix.close()
     half = D // 2
     shards = [corpus.build_index(idxmod, row0=0, n=half, dtype="bf16"), corpus.build_index(idxmod, row0=half, n=D - half, dtype="bf16")]

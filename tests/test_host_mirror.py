@@ -125,27 +125,10 @@ def test_query_dataset_short_query_rule():
 
 def test_hybrid_contrastive_loss_golden(golden_dir):
     """Training-time scorer + loss (losses.py:176-188, 275-360) against loss value and gradients captured from the
-    reference's HybridContrastiveLoss (1-rank group), with and without BatchNorm over fields."""
-    import torch
-    from mfar.modeling.losses import HybridContrastiveLoss
-    from mfar.modeling.weighting import LinearWeights
-    z = np.load(os.path.join(golden_dir, "hybrid_loss.npz"))
-    for name, use_bn in (("plain", False), ("bn", True)):
-        q = torch.tensor(z[f"{name}__q"], requires_grad=True)
-        d_pos = torch.tensor(z[f"{name}__d_pos"], requires_grad=True)
-        d_neg = torch.tensor(z[f"{name}__d_neg"], requires_grad=True)
-        E, F = z[f"{name}__W"].shape
-        lw = LinearWeights(E, F, query_cond=True)
-        lw.weight.data = torch.from_numpy(z[f"{name}__W"].copy())
-        fn = HybridContrastiveLoss(temperature=float(z["temperature"]), mixture_of_fields_layer=lw, sparse_indices_dict={},
-                                   num_fields=F, use_batchnorm=use_bn)
-        fn.train()
-        loss = fn(q, d_pos, d_neg)
-        loss.backward()
-        assert float(loss) == pytest.approx(float(z[f"{name}__loss"]), rel=1e-5, abs=1e-5), name
-        np.testing.assert_allclose(lw.weight.grad.numpy(), z[f"{name}__grad_W"], rtol=1e-4, atol=1e-5, err_msg=name)
-        np.testing.assert_allclose(q.grad.numpy(), z[f"{name}__grad_q"], rtol=1e-4, atol=1e-5, err_msg=name)
-        np.testing.assert_allclose(d_pos.grad.numpy(), z[f"{name}__grad_d_pos"], rtol=1e-4, atol=1e-5, err_msg=name)
+    reference's HybridContrastiveLoss (1-rank group): plain, with BatchNorm over fields, and with sparse score columns behind
+    the dense ones (tests/helpers/loss_check.py; the `-m gpu` twin runs the same check on the device)."""
+    from tests.helpers.loss_check import check_hybrid_loss_golden
+    assert check_hybrid_loss_golden(golden_dir, "cpu") == ["plain", "bn", "sparse"]
 
 
 def test_fire_like_cli_parsing():

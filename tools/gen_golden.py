@@ -401,6 +401,42 @@ def gen_loss(out, LinearWeights):
         res.update({f"{name}__q": q.detach().numpy(), f"{name}__d_pos": d_pos.detach().numpy(), f"{name}__d_neg": d_neg.detach().numpy(),
                     f"{name}__W": W0, f"{name}__loss": np.float32(loss.item()), f"{name}__grad_W": lw.weight.grad.numpy(),
                     f"{name}__grad_q": q.grad.numpy(), f"{name}__grad_d_pos": d_pos.grad.numpy()})
+    # sparse score columns (losses.py:303-345): two fake sparse indices (only `score_batch(queries, doc_ids)` is called when the
+    # `sparse_scores` cache is empty, losses.py:318-321) behind three dense fields, BatchNorm over all five columns
+    class TableSparseIndex:
+        def __init__(self, seed):
+            self.seed = seed
+
+        def score_batch(self, queries, doc_ids):
+            # raw BM25-like non-negative scores, a pure function of (query text, doc id)
+            out = torch.empty(len(queries), len(doc_ids))
+            for i, qt in enumerate(queries):
+                for j, d in enumerate(doc_ids):
+                    h = np.random.default_rng([self.seed, sum(map(ord, qt)), sum(map(ord, d)) * 7 + len(d)]).random()
+                    out[i, j] = float(np.float32(12.0 * h * h))
+            return out
+
+    rng = np.random.default_rng(777)
+    B, Fd, Fs, E, N = 4, 3, 2, 16, 1
+    q = torch.tensor(gauss(rng, (B, E)), requires_grad=True)
+    d_pos = torch.tensor(gauss(rng, (B, Fd, E)), requires_grad=True)
+    d_neg = torch.tensor(gauss(rng, (B, Fd, N, E)), requires_grad=True)
+    W0 = gauss(rng, (E, Fd + Fs), std=0.3)
+    lw = LinearWeights(E, Fd + Fs, query_cond=True)
+    lw.weight.data = torch.from_numpy(W0.copy())
+    sidx = {"s_a": TableSparseIndex(11), "s_b": TableSparseIndex(23)}
+    loss_fn = HybridContrastiveLoss(temperature=0.05, mixture_of_fields_layer=lw, sparse_indices_dict=sidx, num_fields=Fd + Fs,
+                                    use_batchnorm=True)
+    loss_fn.train()
+    qs, ps, ns = [f"q{i}" for i in range(B)], [f"p{i}" for i in range(B)], [f"n{i}" for i in range(B)]
+    loss = loss_fn(q, pickle.dumps(qs), d_pos, pickle.dumps(ps), d_neg, pickle.dumps(ns), pickle.dumps(list(range(B))), {})
+    loss.backward()
+    sp = torch.stack([si.score_batch(qs, ps) for si in sidx.values()], dim=-1)        # the columns the loss saw (inputs of the fixture)
+    sn = torch.stack([si.score_batch(qs, ns) for si in sidx.values()], dim=-1)
+    res.update({"sparse__q": q.detach().numpy(), "sparse__d_pos": d_pos.detach().numpy(), "sparse__d_neg": d_neg.detach().numpy(),
+                "sparse__W": W0, "sparse__sparse_pos": sp.numpy(), "sparse__sparse_neg": sn.numpy(), "sparse__sparse_rev": sp.numpy(),
+                "sparse__loss": np.float32(loss.item()), "sparse__grad_W": lw.weight.grad.numpy(), "sparse__grad_q": q.grad.numpy(),
+                "sparse__grad_d_pos": d_pos.grad.numpy()})
     res["temperature"] = np.float32(0.05)
     np.savez_compressed(os.path.join(out, "hybrid_loss.npz"), **res)
     dist.destroy_process_group()
@@ -595,7 +631,9 @@ def gen_cli(out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default=None, choices=[None, "loss"], help="regenerate one fixture only")
     args = ap.parse_args()
+    only = args.only
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
     if not os.path.isdir(REF):
@@ -614,6 +652,9 @@ def main():
     from mfar.data.util import MemoryMapDict
     from mfar.modeling import contrastive
 
+    if only == "loss":          # one fixture only (the others stay byte for byte what they are)
+        gen_loss(out, LinearWeights)
+        return
     print("retrieve_batch:", gen_retrieve(out, DenseFlatIndex))
     print("retrieve_batch_large:", gen_retrieve_large(out, DenseFlatIndex))
     gen_score_batch(out, DenseFlatIndex)
