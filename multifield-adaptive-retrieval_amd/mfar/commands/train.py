@@ -65,35 +65,51 @@ class _Instances:
             self.pos_for_each_qid.setdefault(r.query_id, set()).add(r.doc_id)
 
     def batches(self, batch_size, rank, world, shuffle, fixed_negatives=False):
+        """This rank's share of every global batch: (qrels rows, negative corpus rows).
+
+        Every instance is covered: like Lightning's DistributedSampler (drop_last=False) the instance list is padded to a multiple
+        of the world size by repeating instances from its start, so all ranks run the SAME number of steps (the loss all-gathers
+        and all-reduces) and the last step is simply smaller; nothing of train.qrels / val.qrels is silently dropped.
+        Negatives are mined for THIS rank's slice only (the reference mines inside each rank's dataloader workers,
+        negative_sampler.py:40-60): the draw of an instance comes from its own generator seeded with (seed, pass, position in the
+        pass), so it does not depend on the number of ranks or on what other ranks drew; the BM25 candidate list of a query
+        (retrieve, drop positives, keep the n_bottom lowest) is a pure function of the query and is computed once."""
         order = list(range(len(self.qrels)))
+        if not order:
+            return
         if shuffle:
             self.rng.shuffle(order)                      # same seed on every rank -> same order
-        # every rank must run the SAME number of steps (the loss all-gathers and all-reduces): whole global batches
-        # only; with fewer instances than one global batch the per-rank batch shrinks to what divides evenly
-        if len(order) < world:
-            raise ValueError(f"{len(order)} training instances cannot be split over {world} ranks")
-        if len(order) < batch_size * world:
-            batch_size = len(order) // world
-        order = order[:(len(order) // (batch_size * world)) * batch_size * world]
-        # validation passes `fixed_negatives`: a generator re-seeded per pass draws the same negatives every epoch, so
-        # valid_loss values are comparable between epochs (early stopping and best-checkpoint selection rest on them)
-        neg_rng = random.Random(self.seed + 7919) if fixed_negatives else self.rng
-        for g in range(0, len(order), batch_size * world):
-            # negatives are drawn for the whole global batch on every rank (same stream everywhere), then sliced
-            grows = [self.qrels[i] for i in order[g:g + batch_size * world]]
-            gnegs = []
-            for r in grows:
-                if getattr(self, "sampler", None) is not None:
-                    self.sampler.rng = neg_rng
-                    doc = self.sampler.sample(Query(r.query_id, self.queries[r.query_id]), self.pos_for_each_qid)[0]
-                    gnegs.append(self.key_to_row[doc._id])
-                    continue
-                n = neg_rng.randrange(len(self.corpus))
-                while self.corpus[n][0] == r.doc_id and len(self.corpus) > 1:
-                    n = neg_rng.randrange(len(self.corpus))
-                gnegs.append(n)
-            lo = rank * batch_size
-            yield grows[lo:lo + batch_size], gnegs[lo:lo + batch_size]
+        n_pass = getattr(self, "_n_pass", 0)
+        if not fixed_negatives:
+            self._n_pass = n_pass + 1
+        pad = (-len(order)) % world
+        order = order + [order[i % len(order)] for i in range(pad)]
+        # validation passes `fixed_negatives`: the same draws every epoch, so valid_loss values are comparable between epochs
+        # (early stopping and best-checkpoint selection rest on them)
+        pass_key = -1 if fixed_negatives else n_pass
+        G = batch_size * world
+        for g in range(0, len(order), G):
+            cur = order[g:g + G]
+            per = len(cur) // world
+            lo = rank * per
+            rows = [self.qrels[i] for i in cur[lo:lo + per]]
+            negs = [self._negative(r, random.Random(((self.seed * 1000003 + pass_key) * 1000003 + g + lo + j) & 0xFFFFFFFFFFFF))
+                    for j, r in enumerate(rows)]
+            yield rows, negs
+
+    def _negative(self, r, rng) -> int:
+        """Corpus row of one negative for qrels row `r`, drawn from `rng`."""
+        sampler = getattr(self, "sampler", None)
+        if sampler is not None:
+            cache = self.__dict__.setdefault("_bottom_cache", {})
+            bottom = cache.get(r.query_id)
+            if bottom is None:
+                bottom = cache[r.query_id] = sampler.bottom_candidates(Query(r.query_id, self.queries[r.query_id]), self.pos_for_each_qid)
+            return self.key_to_row[sampler.pick(bottom, rng)[0]]
+        n = rng.randrange(len(self.corpus))
+        while self.corpus[n][0] == r.doc_id and len(self.corpus) > 1:
+            n = rng.randrange(len(self.corpus))
+        return n
 
 
 def _encode_fields(module, tokenizer, docs, max_length, device):

@@ -492,7 +492,12 @@ class BM25sSparseIndex(Index[str, str]):
         self.index_limit = index_limit
         self.safe_docs = safe_docs if safe_docs is not None else {}
         self.name = None
-        self._score_memo: Dict[str, np.ndarray] = {}      # the reference memoises get_scores per query (lru_cache 2**15)
+        # the reference memoises get_scores per query (lru_cache 2**15 entries, index.py:86); a dense [D] fp32 array per entry is
+        # 4 MB at 1 M documents, so the memo here is an LRU bounded by BYTES (MFAR_BM25_MEMO_MB, default 256 MB per index)
+        from collections import OrderedDict
+        self._score_memo: "OrderedDict[str, np.ndarray]" = OrderedDict()
+        self._memo_bytes = 0
+        self._memo_cap = int(float(__import__("os").environ.get("MFAR_BM25_MEMO_MB", "256")) * (1 << 20))
 
     def set_safe_docs(self, safe_docs):
         self.safe_docs = safe_docs
@@ -511,11 +516,16 @@ class BM25sSparseIndex(Index[str, str]):
 
     def get_scores(self, query: str) -> np.ndarray:        # [D]
         s = self._score_memo.get(query)
-        if s is None:
-            s = self.index.get_scores(self.tokenize(query, stopwords="en", stemmer=self.stemmer))
-            if len(self._score_memo) >= 2 ** 15:
-                self._score_memo.clear()
+        if s is not None:
+            self._score_memo.move_to_end(query)
+            return s
+        s = self.index.get_scores(self.tokenize(query, stopwords="en", stemmer=self.stemmer))
+        if s.nbytes <= self._memo_cap:
             self._score_memo[query] = s
+            self._memo_bytes += s.nbytes
+            while self._memo_bytes > self._memo_cap or len(self._score_memo) > 2 ** 15:      # evict the least recently used
+                _, old = self._score_memo.popitem(last=False)
+                self._memo_bytes -= old.nbytes
         return s
 
     def get_scores_sparse(self, query: str) -> Dict[int, float]:

@@ -36,14 +36,23 @@ class IndexNegativeSampler(NegativeSampler):
     def _negatives(self, query: Query, positives: AbstractSet[str], top_k: int) -> List[Tuple[str, float]]:
         return [(doc_id, score) for doc_id, score in self.index.retrieve(query.text, top_k=top_k) if doc_id not in positives]
 
-    def sample(self, query: Query, pos_for_each_qid: Mapping[str, AbstractSet[str]]) -> List[Document]:
+    def bottom_candidates(self, query: Query, pos_for_each_qid: Mapping[str, AbstractSet[str]]) -> List[str]:
+        """The deterministic half of `sample` (negative_sampler.py:40-56): retrieve, drop the positives, keep the `n_bottom`
+        lowest-scored ids.  A pure function of the query: callers that sample the same query every epoch cache it."""
         positives = pos_for_each_qid[query._id]
         cand = self._negatives(query, positives, self.n_retrieve)
         if not cand:                                        # every retrieved document was a positive: look deeper (:47-53)
             cand = self._negatives(query, positives, len(positives) + self.n_bottom)
         cand.sort(key=lambda x: x[1], reverse=True)         # stable: equal scores keep the index's order
-        bottom = [doc_id for doc_id, _ in cand[-self.n_bottom:]]
-        picked = [bottom[i] for i in self.rng.sample(range(len(bottom)), self.n_sample)]
+        return [doc_id for doc_id, _ in cand[-self.n_bottom:]]
+
+    def pick(self, bottom: List[str], rng=None) -> List[str]:
+        """The random half (:57): `n_sample` of the bottom candidates."""
+        rng = rng if rng is not None else self.rng
+        return [bottom[i] for i in rng.sample(range(len(bottom)), self.n_sample)]
+
+    def sample(self, query: Query, pos_for_each_qid: Mapping[str, AbstractSet[str]]) -> List[Document]:
+        picked = self.pick(self.bottom_candidates(query, pos_for_each_qid))
         return [Document(i, self.documents.get(i, "")) for i in picked]
 
     def sample_batch(self, queries: List[Query], pos_for_each_qid: Mapping[str, AbstractSet[str]]) -> List[List[Document]]:

@@ -193,6 +193,19 @@ class RetrievalTrainingModule(torch.nn.Module):
                         n = min(4096, len(order) - pos)
                         while n > bs and n * min(max_len, len(uniq[order[pos + n - 1]]) // 3 + 8) > budget:
                             n = max(bs, (n * 3) // 4)
+                        # len // 3 + 8 is an estimate for English prose; digit-heavy, CJK or byte-level texts run ~1 token per
+                        # character.  A group that could exceed the budget even then (every character a token) is measured with
+                        # the tokenizer and clamped to n * L_real <= budget -- short-text groups never pay this second tokenisation
+                        tok = getattr(self.encoder, "tokenizer", None)
+                        if n > bs and tok is not None and n * min(max_len, len(uniq[order[pos + n - 1]]) + 2) > budget:
+                            lens = [len(x) for x in tok([uniq[i] for i in order[pos:pos + n]], padding=False, truncation=True,
+                                                        max_length=max_len)["input_ids"]]
+                            longest = 0
+                            for j, L in enumerate(lens):                 # largest prefix whose padded size fits (at least bs texts)
+                                longest = max(longest, L)
+                                if j + 1 > bs and (j + 1) * longest > budget:
+                                    n = j
+                                    break
                     yield [(i, uniq[i]) for i in order[pos:pos + n]]
                     pos += n
 

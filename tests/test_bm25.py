@@ -110,3 +110,66 @@ def test_negative_sampler_rule():
     got = ns2.sample(q, {"q1": set(ranked[:2])})
     assert {d._id for d in got} == set(ranked[2:4])
     assert [len(x) for x in ns2.sample_batch([q, q], {"q1": set()})] == [2, 2]
+
+
+def test_training_negatives_are_mined_per_rank_and_do_not_depend_on_the_world_size():
+    """commands/train.py `_Instances.batches`: a rank mines negatives only for ITS slice of a global batch, the draw
+    of an instance depends on (seed, pass, position) and not on the number of ranks, the BM25 candidate list of a query is computed
+    once, and every instance is covered (padding to a multiple of the world size like DistributedSampler, drop_last=False)."""
+    import random
+    from mfar.commands.train import _Instances
+    from mfar.data.index import Index
+    from mfar.data.negative_sampler import IndexNegativeSampler
+
+    class CountingIndex(Index):
+        def __init__(self):
+            self.calls = 0
+
+        def retrieve(self, query, top_k):
+            self.calls += 1
+            r = random.Random(query)
+            docs = [f"d{i}" for i in range(30)]
+            r.shuffle(docs)
+            return [(d, float(top_k - j)) for j, d in enumerate(docs[:top_k])]
+
+    def make():
+        inst = _Instances.__new__(_Instances)
+        inst.queries = {f"q{i}": f"text of query {i}" for i in range(5)}
+        inst.qrels = [type("R", (), {"doc_id": f"d{2 * i + 1}", "query_id": f"q{i % 5}"})() for i in range(11)]
+        inst.corpus = [(f"d{i}", {}) for i in range(30)]
+        inst.key_to_row = {k: i for i, (k, _) in enumerate(inst.corpus)}
+        inst.pos_for_each_qid = {}
+        for r in inst.qrels:
+            inst.pos_for_each_qid.setdefault(r.query_id, set()).add(r.doc_id)
+        inst.seed, inst.rng = 5, random.Random(5)
+        ix = CountingIndex()
+        inst.sampler = IndexNegativeSampler(ix, {}, n_retrieve=12, n_bottom=4, n_sample=1)
+        return inst, ix
+
+    def collect(world, passes=2):
+        per_pass = []
+        insts = [make() for _ in range(world)]
+        for _ in range(passes):
+            seen = {}
+            steps = []
+            for rank, (inst, _) in enumerate(insts):
+                n = 0
+                for rows, negs in inst.batches(4, rank, world, shuffle=True):
+                    assert len(rows) == len(negs) <= 4
+                    for r, ng in zip(rows, negs):
+                        assert inst.corpus[ng][0] not in inst.pos_for_each_qid[r.query_id]
+                        seen.setdefault((r.query_id, r.doc_id), []).append(ng)
+                    n += 1
+                steps.append(n)
+            assert len(set(steps)) == 1                              # every rank runs the same number of steps
+            per_pass.append(seen)
+        return per_pass, [ix.calls for _, ix in insts]
+
+    one, calls1 = collect(1)
+    three, calls3 = collect(3)
+    assert len(one[0]) == 11 and set(three[0]) == set(one[0])        # every instance covered, with 1 rank and with 3
+    for p in range(2):                                               # same negative for the same instance whatever the world size
+        for key, negs in one[p].items():
+            assert three[p][key][0] == negs[0], (p, key)
+    assert one[0] != one[1]                                          # a new pass draws anew
+    assert calls1 == [5] and all(c <= 5 for c in calls3) and sum(calls3) < 11 * 2      # one retrieval per distinct query per rank, not per instance

@@ -258,7 +258,8 @@ def test_two_rank_grad_sync_survives_a_one_sided_overflow(tmp_path):
     assert torch.equal(a["snaps"][0][:15], a["snaps"][1][:15]) and not torch.equal(a["snaps"][0][15:], a["snaps"][1][15:])
     assert not torch.equal(a["snaps"][1], a["snaps"][2])      # the next one was taken
     assert a["scale"] == b["scale"] == 512.0                  # both halved their loss scale once
-    # 5 instances, batch 4, 2 ranks -> per-rank batch 2, ONE step on each rank, disjoint rows, same negatives every pass
-    assert len(a["b1"]) == len(b["b1"]) == 1 and len(a["b1"][0][0]) == len(b["b1"][0][0]) == 2
-    assert not set(a["b1"][0][0]) & set(b["b1"][0][0])
+    # 5 instances, batch 4, 2 ranks: padded to 6 like a DistributedSampler (drop_last=False) -> ONE step of 3 rows on each rank,
+    # EVERY instance covered (the sixth slot repeats the first instance), same negatives every validation pass
+    assert len(a["b1"]) == len(b["b1"]) == 1 and len(a["b1"][0][0]) == len(b["b1"][0][0]) == 3
+    assert set(a["b1"][0][0]) | set(b["b1"][0][0]) == {"0", "1", "2", "3", "4"}
     assert a["b1"] == a["b2"] and b["b1"] == b["b2"]

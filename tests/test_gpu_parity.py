@@ -547,7 +547,7 @@ def test_bf16_stress_shape_per_gpu(idxmod):
     = 30.7 GB (+ the row-major companion for gathers).  Plain bf16 pass: size-independent properties, an EXHAUSTIVE torch check
     of the stage-1 lists of three queries, re-sharding invariance.  Certified screen (`set_screen(2)`, bench.py --screen on):
     the same exhaustive check and the oracle (natural-order chain over the bf16 rows, the bf16 contract) bit for bit -- stage-1
-    lists and the final top-100 -- on a row subset that holds every list member; plain and screened agree to 1e-4."""
+    lists and the final top-100 -- on a row subset that holds every list member; documents returned by both runs carry equal bits."""
     import torch
     from mfar import synth
     D, F, E, Q = 1_250_000, 16, 768, 64
@@ -575,8 +575,13 @@ def test_bf16_stress_shape_per_gpu(idxmod):
     _exhaustive_stage1_check(ix, q, r3["field_ids"].cpu().numpy(), r3["field_scores"].cpu().numpy(), probe)
     with O.chain("natural"):
         _oracle_check_on_subset(ix, q, W, None, r3, probe)
-    O.assert_topk_equivalent(r1["ids"].cpu().numpy(), r1["scores"].cpu().numpy(), r3["ids"].cpu().numpy(), r3["scores"].cpu().numpy(),
-                             tol=TOL, what="bf16 plain pass vs certified screen at 1.25M x 16")
+    # plain pass vs certified screen: the plain MFMA pass's stage-1 scores agree with the chain to 1e-4, so a list may swap a member
+    # at a near-tied cut-off and with it one final candidate; every document BOTH runs return carries the same exact score bits
+    i1, s1, i3, s3 = (r[k].cpu().numpy() for r in (r1, r3) for k in ("ids", "scores"))
+    for qi in range(Q):
+        common, a, b = np.intersect1d(i1[qi], i3[qi], return_indices=True)
+        assert common.size >= 98, (qi, common.size)
+        assert np.array_equal(s1[qi][a].view(np.uint32), s3[qi][b].view(np.uint32)), qi
     ix.close()
     half = D // 2
     shards = [corpus.build_index(idxmod, row0=0, n=half, dtype="bf16"), corpus.build_index(idxmod, row0=half, n=D - half, dtype="bf16")]
