@@ -73,24 +73,11 @@ static bool g_attr_done[16] = {false};
 // Geometry of one scanned slab + its chunk tables (mfar_stage1.h: S1Chunk).  `all`: every field gets a share of the grid
 // proportional to its tiles (one launch scans all fields); `solo`: every field is cut as finely as the list merge allows
 // (a launch scans one field, mfar_retrieve_field).
-struct S1Table {
-    int k = -1, wgs = -1;             // built for this list depth / grid size
-    std::vector<S1Chunk> chunks;
-    std::vector<int> fchunk, samp_n;  // [F + 1], [F]
-    int n_chunks = 0, max_chunks = 0, samp_stride = 0, sample_tiles = 1;
-    long long total_tiles = 0;
-    long long thresholded_tiles = 0;  // tiles of the fields whose sample publishes at least k values (= yields a threshold)
+struct S1Table : S1TableHost {       // mfar_tables.h + the device copies
     DevBuf d_chunks, d_fchunk, d_samp_n;
-    // two-level merge: a field cut into more chunks than one merge workgroup can hold (few fields, or a single-field pass)
-    // is merged in GROUPS of consecutive chunks first (mfar_select.h MergeParams)
-    bool two_level = false;
-    std::vector<int> gchunk, fgroup, gfield;   // [n_groups + 1] chunk boundaries, [F + 1] groups of a field, [n_groups] field of a group
-    int n_groups = 0, max_group_chunks = 0, max_groups = 0;
     DevBuf d_gchunk, d_fgroup, d_gfield;
 };
-struct S1Geom {
-    std::vector<long long> n_rows, base;   // per field: valid rows, element offset of the field inside the slab
-    std::vector<int> n_tiles;              // per field: 256-row tiles
+struct S1Geom : S1GeomHost {
     S1Table all, solo;
     S1Table all_w, solo_w;   // the wide pass keeps its own tables (same rule today; its list depth k' may differ from a 64-column pass in flight)
     void reset(int F) {
@@ -488,158 +475,12 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
     if (t.k == k && t.wgs == wgs) return MFAR_OK;
     if (t.k >= 0) HIPCHK(hipDeviceSynchronize());   // a launch in flight may still read the old table
     const int F = idx->F;
-    const long long want = (long long)wgs * idx->n_cu;
-    const int cap = std::max(1, std::min(128, (64 * 256) / k));
-    long long total_tiles = 0;
-    for (int f = 0; f < F; ++f) total_tiles += g.n_tiles[f];
-    t.chunks.clear();
-    t.fchunk.assign(F + 1, 0);
-    t.samp_n.assign(F, 0);
-    t.max_chunks = 0;
-    std::vector<int> cf(F);
-    const int l2cap = std::max(1, std::min(cap, 8192 / k));   // lists the second level merges per field (register-resident keys)
-    t.two_level = false;
-    // SMALL FIELDS (low-cardinality fields collapse to a few unique rows: STaRK-prime `type` has ten texts).  The threshold of a
-    // field is the k-th best of the values its sample publishes, 8 per sampled tile; a field that cannot publish k values even
-    // when sampled whole has NO threshold, and then every row of a tile survives into the lists (measured: 0.235 ms per tile and
-    // workgroup in the wide pass against ~0.03 ms with a threshold).  One workgroup walking such a field tile after tile held
-    // up the whole launch (structured 1 M x 8 corpus, 6 tiles of a ten-text field in one chunk: scan 4.3 ms instead of 1.7).
-    //   * a field without a possible threshold is cut into one-tile chunks (its cost is then bounded by one tile);
-    //   * any field gets enough chunks to sample min(its tiles, tiles that publish 3 k values) at <= 4 tiles per chunk, so its
-    //     sample workgroups stay as short as everybody's; the whole of such a field may be sampled (its bytes do not matter).
-    // The chunks these rules add are taken from the largest fields, so the grid stays one wave of workgroups.
-    const long long need_tiles = (3LL * k + 7) / 8;            // sampled tiles that publish 3 k values
-    std::vector<int> floor_cf(F, 0);                           // > 0: the field was cut by one of the two rules
-    {
-        std::vector<long long> want_cf(F);
-        long long extra = 0, spare = 0;
-        for (int f = 0; f < F; ++f) {
-            const long long tiles = std::max(1, g.n_tiles[f]);
-            const long long lim = std::min<long long>((long long)cap * l2cap, tiles);
-            long long c = solo ? want : (want * g.n_tiles[f] + total_tiles / 2) / std::max(1LL, total_tiles);
-            c = std::max(1LL, std::min(c, lim));
-            const long long fl = std::max(1LL, std::min(8 * tiles < k ? tiles : (std::min(tiles, need_tiles) + 3) / 4, lim));
-            cf[f] = (int)c;
-            want_cf[f] = fl;
-            if (fl > c) extra += fl - c;
-            else spare += c - fl;
-        }
-        // the extra chunks come out of the fields that have more than their own floor; when nobody has (many equal fields),
-        // only the fields without a possible threshold are cut (they must be) and the grid grows by those few workgroups
-        for (int f = 0; f < F; ++f) {
-            const bool hard = 8LL * std::max(1, g.n_tiles[f]) < k;
-            if (want_cf[f] > cf[f] && (hard || solo || spare >= extra)) {
-                cf[f] = (int)want_cf[f];
-                floor_cf[f] = cf[f];
-            }
-        }
-        if (!solo && extra > 0 && spare >= extra)
-            for (int f = 0; f < F; ++f)
-                if (!floor_cf[f] && cf[f] > want_cf[f]) cf[f] -= (int)(((cf[f] - want_cf[f]) * extra + spare - 1) / spare);
-        // exactly one wave of workgroups where the rules allow it: a grid of a few workgroups more leaves them waiting for the
-        // first to finish (a mid-size field's short chunks finish early: 515 workgroups, scan 2.36 ms instead of 1.85), a few
-        // less idles CUs.  Short of a wave: the field with the longest chunks gets one more; over: the field with the shortest gives one up.
-        if (!solo) {
-            long long sum = 0;
-            for (int f = 0; f < F; ++f) sum += cf[f];
-            for (; sum != want; sum += sum < want ? 1 : -1) {
-                int best = -1;
-                double key = 0.0;
-                for (int f = 0; f < F; ++f) {
-                    const long long tiles = std::max(1, g.n_tiles[f]);
-                    const long long lim = std::min<long long>((long long)cap * l2cap, tiles);
-                    const double tpc = (double)tiles / cf[f];
-                    if (sum < want ? (cf[f] < lim && !floor_cf[f] && (best < 0 || tpc > key))
-                                   : (cf[f] > std::max<long long>(1, want_cf[f]) && !floor_cf[f] && (best < 0 || tpc < key))) {
-                        best = f;
-                        key = tpc;
-                    }
-                }
-                if (best < 0) break;
-                cf[best] += sum < want ? 1 : -1;
-            }
-        }
-    }
-    long long n_chunks = 0;
-    for (int f = 0; f < F; ++f) {
-        n_chunks += cf[f];
-        if (cf[f] > cap) t.two_level = true;
-        t.max_chunks = std::max(t.max_chunks, cf[f]);
-    }
-    // tiles per workgroup in the sample pass, per field: more tiles = tighter starting thresholds = fewer appends in the full
-    // pass, at the price of reading those tiles twice; at most 1/12 of a chunk and 4096 published values per (query, field)
-    // (measured at 1 M x 8: 2 tiles pay off for the HBM-bound 16-bit passes, 1 for the MFMA-bound fp32 pass).
-    // The threshold is the k-th best of the field's sampled rows, so a chunk expects k * (its rows) / (sampled rows of the field)
-    // appends per query: about 85 at 1 M x 8.  Long chunks of many-field shards (1.25 M x 16: 140 tiles per chunk, 32 chunks
-    // per field) would see ~280 with that fixed size -- past the compaction trigger, and every compaction drains the whole
-    // workgroup's prefetch ring (measured there: selection epilogue 1.85 of 6.2 ms) -- so the sample grows until a chunk
-    // expects no more than ~130 appends (MFAR_APPEND_TARGET; measured there: 75 .. 130 within 3 %, stage 1 6.8 -> 5.6 ms).
-    // Short chunks (small shards, many fields) and the small fields above: the sample yields a threshold only when it
-    // publishes at least k values per (query, field) and a useful one from about 3 k; without a threshold every list compacts
-    // on nearly every tile.  Spend up to a sixth of a chunk on it -- the whole chunk in a field that was cut for this.
-    static const int sample_div = getenv("MFAR_SAMPLE_DIV") ? atoi(getenv("MFAR_SAMPLE_DIV")) : 12;
+    static const int sample_div = getenv("MFAR_SAMPLE_DIV") ? std::max(1, atoi(getenv("MFAR_SAMPLE_DIV"))) : 12;
     static const int append_target = getenv("MFAR_APPEND_TARGET") ? std::max(1, atoi(getenv("MFAR_APPEND_TARGET"))) : 130;
-    std::vector<int> ns(F, 1);
-    t.sample_tiles = 1;
-    for (int f = 0; f < F; ++f) {
-        const long long tpc = std::max(1LL, (long long)g.n_tiles[f] / cf[f]);      // tiles of the field's shortest chunk
-        const long long tpc_hi = std::max(1LL, ((long long)g.n_tiles[f] + cf[f] - 1) / cf[f]);   // ... of its longest
-        long long v = std::max(1LL, std::min<long long>(sample_tiles_max, tpc / sample_div));
-        if (!sample_forced) {
-            const long long want_tiles = ((long long)k * tpc + (long long)append_target * cf[f] / 2) / ((long long)append_target * cf[f]);
-            v = std::max(v, std::min(want_tiles, std::max(1LL, tpc / sample_div)));
-            const long long st_cap = cf[f] == floor_cf[f] ? tpc : std::max(1LL, tpc / 6);
-            while (v < st_cap && 2LL * waves * cf[f] * v < 3LL * k) ++v;
-            // no threshold at all (fewer than k values) costs 8 x a normal tile in the full pass: rather sample short chunks whole
-            // (90 % empty 129 k x 22: 56 tiles per field in 23 chunks, 184 values from one tile each -- stage 1 1.34 ms)
-            while (v < tpc_hi && 2LL * waves * std::min<long long>(g.n_tiles[f], cf[f] * v) < (long long)k) ++v;
-        }
-        while (v > 1 && 2LL * waves * cf[f] * v > 4096) --v;
-        ns[f] = (int)v;
-        t.sample_tiles = std::max(t.sample_tiles, ns[f]);
-    }
-    t.samp_stride = 0;
-    t.thresholded_tiles = 0;
-    for (int f = 0; f < F; ++f) {
-        t.fchunk[f] = (int)t.chunks.size();
-        int tl = 0;
-        for (int c = 0; c < cf[f]; ++c) {
-            S1Chunk ck = {};
-            ck.f = f;
-            ck.t0 = (int)(((long long)c * g.n_tiles[f]) / cf[f]);
-            ck.t1 = (int)(((long long)(c + 1) * g.n_tiles[f]) / cf[f]);
-            ck.n_rows = (int)g.n_rows[f];
-            ck.base = g.base[f];
-            ck.tl0 = tl;
-            ck.ns = std::max(1, std::min(ns[f], ck.t1 - ck.t0));
-            tl += std::min(ck.ns, ck.t1 - ck.t0);
-            t.chunks.push_back(ck);
-        }
-        t.samp_n[f] = waves * tl;
-        if (2LL * waves * tl >= k) t.thresholded_tiles += g.n_tiles[f];
-        t.samp_stride = std::max(t.samp_stride, waves * tl);
-    }
-    t.fchunk[F] = (int)t.chunks.size();
-    t.n_chunks = (int)t.chunks.size();
-    t.total_tiles = total_tiles;
-    t.gchunk.clear();
-    t.gfield.clear();
-    t.fgroup.assign(F + 1, 0);
-    t.max_group_chunks = t.max_groups = 0;
+    t.k = -1;                                       // invalid until everything below succeeded
+    s1_build_table(g, F, idx->n_cu, k, solo, sample_tiles_max, sample_forced, waves, wgs, sample_div, append_target, t);   // mfar_tables.h
+    t.k = -1;
     if (t.two_level) {
-        for (int f = 0; f < F; ++f) {
-            t.fgroup[f] = (int)t.gfield.size();
-            const int gs = (cf[f] + l2cap - 1) / l2cap;                  // chunks per group (<= cap by construction)
-            for (int c0 = 0; c0 < cf[f]; c0 += gs) {
-                t.gchunk.push_back(t.fchunk[f] + c0);
-                t.gfield.push_back(f);
-                t.max_group_chunks = std::max(t.max_group_chunks, std::min(gs, cf[f] - c0));
-            }
-            t.max_groups = std::max(t.max_groups, (int)t.gfield.size() - t.fgroup[f]);
-        }
-        t.fgroup[F] = (int)t.gfield.size();
-        t.gchunk.push_back(t.n_chunks);
-        t.n_groups = (int)t.gfield.size();
         RETCHK(t.d_gchunk.ensure(t.gchunk.size() * sizeof(int)));
         RETCHK(t.d_fgroup.ensure((F + 1) * sizeof(int)));
         RETCHK(t.d_gfield.ensure(t.gfield.size() * sizeof(int)));
@@ -1891,37 +1732,6 @@ extern "C" int mfar_search_fused(mfar_index* idx, const float* q, int Q, const f
 }
 
 // ------------------------------------------------------------------------------------------------ multi-GPU
-struct PayloadLayout {
-    long long hdr, ids, scores, cand, ncand, x, total;
-};
-static PayloadLayout payload_layout(int Q, int F, int k1) {
-    auto up = [](long long v) { return (v + 255) & ~255LL; };
-    PayloadLayout L;
-    const long long C = (long long)F * k1;
-    L.hdr = 0;
-    L.ids = up(sizeof(PayloadHeader));
-    L.scores = up(L.ids + (long long)Q * F * k1 * 8);
-    L.cand = up(L.scores + (long long)Q * F * k1 * 4);
-    L.ncand = up(L.cand + (long long)Q * C * 8);
-    L.x = up(L.ncand + (long long)Q * 4);
-    L.total = up(L.x + (long long)Q * C * F * 4);
-    return L;
-}
-struct MergeWsLayout {
-    long long lids, lsc, cand, ncand, x, total;
-};
-static MergeWsLayout merge_ws_layout(int Q, int F, int k1) {
-    auto up = [](long long v) { return (v + 255) & ~255LL; };
-    MergeWsLayout L;
-    const long long C = (long long)F * k1;
-    L.lids = 0;
-    L.lsc = up(L.lids + (long long)Q * F * k1 * 8);
-    L.cand = up(L.lsc + (long long)Q * F * k1 * 4);
-    L.ncand = up(L.cand + (long long)Q * C * 8);
-    L.x = up(L.ncand + (long long)Q * 4);
-    L.total = up(L.x + (long long)Q * C * F * 4);
-    return L;
-}
 extern "C" int64_t mfar_merge_workspace_bytes(int Q, int n_fields, int k1) {
     if (Q < 0 || n_fields <= 0 || k1 <= 0) return 0;
     return merge_ws_layout(Q, n_fields, k1).total;
@@ -2079,30 +1889,6 @@ extern "C" int mfar_merge_payloads(int device, const void* payloads, int n_shard
 }
 
 // ------------------------------------------------------------------------------------------------ lists-first exchange
-struct ListsLayout {
-    long long ids, scores, total;
-};
-static ListsLayout lists_layout(int Q, int F, int k1) {
-    auto up = [](long long v) { return (v + 255) & ~255LL; };
-    ListsLayout L;
-    L.ids = 0;
-    L.scores = up((long long)Q * F * k1 * 8);
-    L.total = up(L.scores + (long long)Q * F * k1 * 4);
-    return L;
-}
-struct TopkLayout {
-    long long ids, scores, ncand, flag, total;
-};
-static TopkLayout topk_layout(int Q, int k2) {
-    auto up = [](long long v) { return (v + 255) & ~255LL; };
-    TopkLayout L;
-    L.ids = 0;
-    L.scores = up((long long)Q * k2 * 8);
-    L.ncand = up(L.scores + (long long)Q * k2 * 4);
-    L.flag = L.ncand + (long long)Q * 4;        // one int32: this rank's certificate flag of the batch (travels with the top-k)
-    L.total = up(L.flag + 4);
-    return L;
-}
 extern "C" int64_t mfar_lists_bytes(int Q, int n_fields, int k1) {
     if (Q < 0 || n_fields <= 0 || k1 <= 0) return 0;
     return lists_layout(Q, n_fields, k1).total;

@@ -20,6 +20,7 @@
 // ~4.9 TB/s at full MFMA rate, so both roofs are close).  bf16: bound by HBM (D*F*E*2 bytes per batch).
 #pragma once
 #include "mfar_device.h"
+#include "mfar_tables.h"
 
 #define S1_THREADS 256
 #define S1_TILE_ROWS 256                     // rows per workgroup tile (4 waves x 64)
@@ -58,14 +59,7 @@
 // One workgroup of a stage-1 pass scans one CHUNK: a contiguous run of 256-row tiles of one field.  The chunk table is built
 // on the host from the fields' row counts (fields differ when the scanned slab holds each field's UNIQUE rows,
 // mfar_screen.h): every field gets a share of the grid proportional to its tiles, chunks of a field are consecutive.
-struct S1Chunk {
-    int f;                  // field
-    int t0, t1;             // tiles [t0, t1) of the field
-    int n_rows;             // valid rows of the field (rows beyond are zero padding)
-    long long base;         // element offset of the field's first tile inside the slab
-    int tl0;                // index of this chunk's first tile among the SAMPLED tiles of its field (sample pass output slot)
-    int ns;                 // tiles of this chunk the light sample pass scans (>= 1; per field: small fields are sampled deeper)
-};
+// struct S1Chunk: mfar_tables.h (plain C++, shared with the host-side table builder and its CPU sanitizer build)
 
 struct S1Params {
     const void* slab;       // tiled slab (fp32, bf16, or the fp16 screen slab)

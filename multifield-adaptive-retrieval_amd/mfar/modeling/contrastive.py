@@ -83,6 +83,34 @@ class RetrievalDataModule:
         return [self.batches(ds, self.dev_batch_size) for ds in [self.dev_queries] + self.additional_queries]
 
 
+def _all_gather_cat(t: torch.Tensor) -> torch.Tensor:
+    """All ranks' tensors concatenated along dim 0 (rank-major).  gloo stages through the host."""
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    src = t.contiguous()
+    if dist.get_backend() == "gloo":
+        src = src.cpu()
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src)
+    return out.to(t.device)
+
+
+def _merge_shard_lists(fid: torch.Tensor, fsc: torch.Tensor, k: int, world: int):
+    """[world * Q, F, k] zero-sentinel lists of the row shards -> the global per-field top-k [Q, F, k] in canonical order (score
+    desc, doc id asc), padded with (0, 0.0) like index.py:192-193.  A global top-k member is in its shard's local top-k, so the
+    merge of the shard lists is the list of the unsharded corpus."""
+    Q = fid.shape[0] // world
+    ids = fid.view(world, Q, *fid.shape[1:]).permute(1, 2, 0, 3).reshape(Q, fid.shape[1], world * k)
+    sc = fsc.view(world, Q, *fsc.shape[1:]).permute(1, 2, 0, 3).reshape(Q, fsc.shape[1], world * k)
+    real = sc > 0                                                     # everything else is sentinel padding
+    key_s = torch.where(real, sc, torch.full_like(sc, -1.0))
+    order = torch.argsort(ids.masked_fill(~real, 2 ** 62), dim=-1, stable=True)           # id asc first ...
+    key_s, ids, real = (torch.gather(a, -1, order) for a in (key_s, ids, real))
+    order = torch.argsort(key_s, dim=-1, descending=True, stable=True)[..., :k]           # ... then score desc, stably
+    key_s, ids, real = (torch.gather(a, -1, order) for a in (key_s, ids, real))
+    return ids.masked_fill(~real, 0), key_s.masked_fill(~real, 0.0)
+
+
 class RetrievalTrainingModule(torch.nn.Module):
     def __init__(self, encoder, model_id: str, decoder, corpus_path: str, corpus: List[Tuple[str, str]], dataset_name: str,
                  dev_qrels_path: str, out_dir: str, sparse_scores: Optional[Dict] = None, contrastive_temp: float = 0.01,
@@ -302,8 +330,12 @@ class RetrievalTrainingModule(torch.nn.Module):
         import numpy as np
         from mfar.data import index as idxmod
         rank, world = _dist()
-        if world > 1:
-            raise NotImplementedError("sparse fields are evaluated on one rank (the dense row shards have no sparse counterpart)")
+        # Several ranks: the dense rows are sharded (contrastive.py:470), the BM25 indices are host objects every rank holds in full
+        # -- like the reference, which evaluates sparse fields on every rank (index.py:97-124, contrastive.py:672-683).  Every rank
+        # scores the SAME batch: the per-shard dense lists are all-gathered and merged to the global per-field top-k, the sparse
+        # lists are computed redundantly (deterministic), the candidate union is therefore identical everywhere; a rank scores the
+        # dense columns of the candidates whose rows it owns (`mfar_score_candidates` returns NaN for foreign rows) and one more
+        # all-gather hands every rank all columns.
         x = self.encode_query_batch(batch)
         Q = x.shape[0]
         texts = [q.text for q in batch.instances]
@@ -311,7 +343,9 @@ class RetrievalTrainingModule(torch.nn.Module):
         dense_cols = [i for i, (_, f) in enumerate(fields) if f.field_type == FieldType.DENSE]
         lists = [[] for _ in range(Q)]                                           # per query: arrays of numeric doc ids
         if dense_cols:
-            fid, _ = self.slab.retrieve_fields(x, TOP_K, True)                   # zero-sentinel lists incl. their (0, 0.0) padding
+            fid, fsc = self.slab.retrieve_fields(x, TOP_K, True)                 # zero-sentinel lists incl. their (0, 0.0) padding
+            if world > 1:
+                fid, fsc = _merge_shard_lists(_all_gather_cat(fid), _all_gather_cat(fsc), TOP_K, world)
             fid = fid.cpu().numpy()
             for i in range(Q):
                 lists[i].append(fid[i].reshape(-1))
@@ -329,12 +363,19 @@ class RetrievalTrainingModule(torch.nn.Module):
         xs = np.zeros((Q, C, len(fields)), np.float32)
         if dense_cols:
             cd = torch.from_numpy(cand).to(self.device)
-            xs[:, :, dense_cols] = self.slab.score_candidates(x, cd).cpu().numpy()                     # :681-683, dense
+            xd = self.slab.score_candidates(x, cd)                                                     # :681-683, dense; NaN = not my row
+            if world > 1:
+                parts = _all_gather_cat(xd.unsqueeze(0))                                               # [world, Q, C, Fd]
+                own = ~torch.isnan(parts)
+                xd = torch.where(own, parts, torch.zeros_like(parts)).sum(0)                           # exactly one owner per real candidate
+                xd[~own.any(0)] = float("nan")                                                         # padding slots stay NaN
+            xs[:, :, dense_cols] = xd.cpu().numpy()
         for col, (key, f) in enumerate(fields):
             if f.field_type == FieldType.SPARSE:
                 for i in range(Q):
                     keys = [self.numeric_ids_to_keys[d] for d in cands[i]]
                     xs[i, :len(keys), col] = self.indices_dict[key].score_batch([texts[i]], keys)[0].numpy()
+        xs[np.isnan(xs) & (np.arange(C)[None, :, None] >= n_cand[:, None, None])] = 0.0                # padding slots: never mixed
         res = idxmod.mix_topk(xs, cand, x.cpu().numpy(), self._weights().cpu().numpy(), self.mask[:, 0].float().numpy(),
                               n_cand=n_cand, k=TOP_K, query_cond=self.query_cond, device=self.device.index or 0)   # :685-696
         if int(res["n_valid"].min()) < TOP_K:

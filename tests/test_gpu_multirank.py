@@ -137,3 +137,35 @@ def test_mask_fields_cli_over_two_row_shards(tmp_path, monkeypatch):
     assert res.returncode == 0, res.stderr[-3000:]
     for fn in ("results_dicts-all-0.jsonl", "final-all-0.qres", "final-additional-all-0.qres"):
         assert open(f"{one}/{fn}").read() == open(f"{two}/{fn}").read(), fn
+
+
+def test_sparse_fields_over_two_row_shards(tmp_path, monkeypatch):
+    """Sparse (BM25) fields with two ranks (gloo, sharing cuda:0): the dense rows are sharded, the BM25 indices replicated (the
+    reference evaluates sparse fields on every rank, index.py:97-124); the hybrid step merges the shards' dense lists, forms the
+    same candidate union everywhere and gathers the dense score columns from their owners -- the files of the whole mask sweep
+    equal a single process's, byte for byte."""
+    sys.path.insert(0, os.path.join(ROOT, "multifield-adaptive-retrieval_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_cli as T
+    from mfar.commands import create_bm25s_index, mask_fields, train
+    data, lex = str(tmp_path / "data"), str(tmp_path / "lex")
+    T._write_dataset(data, relations=True)
+    create_bm25s_index.main(data_path=data, dataset_name="amazon", output_path=lex, fields_str="single_sparse")
+    fields = "title_dense,brand_dense,title_sparse,feature_sparse"
+    out, tmp = str(tmp_path / "out"), str(tmp_path / "tmp")
+    train.main(dataset_name="amazon", lexical_index=lex, out=out, temp_dir=tmp, data=data, model_name="random-init:64x2", field_names=fields,
+               weights_lr=1e-2, encoder_lr=1e-4, train_batch_size=8, dev_batch_size=16, max_epochs=1, precision="32",
+               negative_sampling_params=(20, 5, 1), additional_partition="test")
+    monkeypatch.setenv("MFAR_ENCODE_TOKEN_BUDGET", "0")      # with dev_batch_size = 1: every text is encoded alone, in both runs
+    one = str(tmp_path / "one")
+    mask_fields.main(dataset_name="amazon", lexical_index=lex, out=one, temp_dir=tmp, data=data, model_name="random-init:64x2",
+                     field_names=fields, checkpoint_dir=out, dev_batch_size=1, additional_partition="test")
+    two = str(tmp_path / "two")
+    env = dict(os.environ, MFAR_DIST_BACKEND="gloo", MFAR_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29549", os.path.join(ROOT, "tests", "helpers", "two_rank_mask_fields.py"), data, str(tmp_path / "tmp2"), out, two,
+           fields, lex]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    for fn in ("results_dicts-all-0.jsonl", "final-all-0.qres", "final-additional-all-0.qres"):
+        assert open(f"{one}/{fn}").read() == open(f"{two}/{fn}").read(), fn

@@ -398,3 +398,28 @@ def test_prepare_model_from_local_directory(tmp_path):
     texts = ["a red shoe", "the quick brown fox jumps", ""]
     np.testing.assert_allclose(enc2.encode(texts), enc.encode(texts), rtol=1e-5, atol=1e-6)
     assert set(enc2.state_dict()) == set(enc.state_dict())
+
+
+def test_merge_of_shard_lists_equals_the_oracle_merge():
+    """modeling/contrastive.py `_merge_shard_lists` (the hybrid step with several ranks: per-shard zero-sentinel lists ->
+    global per-field top-k) against the oracle's list merge, ties and padding included."""
+    import torch
+    from mfar.modeling.contrastive import _merge_shard_lists
+    from oracle import mfar_oracle as O
+    rng = np.random.default_rng(9)
+    world, Q, F, k = 3, 4, 2, 10
+    ids = np.zeros((world, Q, F, k), np.int64)
+    sc = np.zeros((world, Q, F, k), np.float32)
+    for w in range(world):
+        for q in range(Q):
+            for f in range(F):
+                n = int(rng.integers(0, k + 1))                       # short lists are padded with (0, 0.0)
+                s = np.sort(rng.choice(np.array([0.5, 1.0, 1.5, 2.0, 2.5, 3.0], np.float32), n))[::-1]      # many ties
+                ids[w, q, f, :n] = 100 * w + np.sort(rng.choice(90, n, replace=False)) + 1
+                order = np.lexsort((ids[w, q, f, :n], -s))
+                sc[w, q, f, :n], ids[w, q, f, :n] = s[order], ids[w, q, f, :n][order]
+    gi, gs = _merge_shard_lists(torch.from_numpy(ids.reshape(world * Q, F, k)), torch.from_numpy(sc.reshape(world * Q, F, k)), k, world)
+    for q in range(Q):
+        for f in range(F):
+            wi, ws = O.c_merge_lists(ids[:, q, f], sc[:, q, f], True)
+            assert np.array_equal(gi[q, f].numpy(), wi) and np.array_equal(gs[q, f].numpy(), ws), (q, f)
