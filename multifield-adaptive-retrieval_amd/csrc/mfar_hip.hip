@@ -1192,6 +1192,12 @@ extern "C" int mfar_set_wide(mfar_index* idx, int enable) {
     idx->wide = enable != 0;
     return MFAR_OK;
 }
+// Where the list merge of a split-phase batch runs: with the scan (begin, default) or with the tail (finish: the scan stream then
+// carries nothing but query prep, sample pass and scans).  MFAR_MERGE_IN_FINISH=1; measured, see DESIGN 4.1c.
+static bool merge_in_finish() {
+    static const bool v = getenv("MFAR_MERGE_IN_FINISH") && atoi(getenv("MFAR_MERGE_IN_FINISH")) != 0;
+    return v;
+}
 static int check_split(const mfar_index* idx, const float* q, int Q, int k, int slot) {
     RETCHK(check_search_common(idx, q, Q, k));
     if (Q > max_split_batch(idx, k))
@@ -1205,8 +1211,8 @@ extern "C" int mfar_stage1_begin(mfar_index* idx, const float* q, int Q, int k, 
     if (Q == 0) return MFAR_OK;
     HIPCHK(hipSetDevice(idx->device));
     if (!field_ids || !field_scores) return fail(MFAR_ERR_INVALID, "output pointer is NULL");
-    RETCHK(stage1_block(idx, slot, S1_PREPARE | S1_SCAN | S1_FINISH, q, Q, 0, k, sentinel, 0, idx->F, (long long*)field_ids, field_scores,
-                        nullptr, (hipStream_t)stream));
+    RETCHK(stage1_block(idx, slot, S1_PREPARE | S1_SCAN | (merge_in_finish() ? 0 : S1_FINISH), q, Q, 0, k, sentinel, 0, idx->F, (long long*)field_ids,
+                        field_scores, nullptr, (hipStream_t)stream));
     if (Q > idx->s1[slot].qw)   // the screen slab became unavailable (rows rewritten, rebuild out of memory): only 64 queries were begun
         return fail(MFAR_ERR_UNSUPPORTED, "a split-phase batch of more than 64 queries needs the screen slab, which could not be (re)built");
     return MFAR_OK;
@@ -1217,8 +1223,8 @@ extern "C" int mfar_stage1_finish(mfar_index* idx, const float* q, int Q, int k,
     if (Q == 0) return MFAR_OK;
     if (!field_ids || !field_scores) return fail(MFAR_ERR_INVALID, "output pointer is NULL");
     HIPCHK(hipSetDevice(idx->device));
-    return stage1_block(idx, slot, S1_CERTIFY, q, Q, 0, k, sentinel, 0, idx->F, (long long*)field_ids, field_scores, (int*)any_fail,
-                        (hipStream_t)stream);
+    return stage1_block(idx, slot, S1_CERTIFY | (merge_in_finish() ? S1_FINISH : 0), q, Q, 0, k, sentinel, 0, idx->F, (long long*)field_ids,
+                        field_scores, (int*)any_fail, (hipStream_t)stream);
 }
 
 static bool two_level_ok(const mfar_index* idx, int C, int k2, int query_cond);

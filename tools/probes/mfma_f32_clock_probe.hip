@@ -1,0 +1,121 @@
+// Probe for VERDICT r02 item 7: why does the exact fp32 stage-1 pass sit at ~107 TFLOP/s when the micro-architecture guide
+// measures 155 TFLOP/s for v_mfma_f32_32x32x2_f32 "on random data"?  Hypothesis: the 155 is the ISSUE rate (64 cycles per MFMA and
+// SIMD) at the clock the chip holds while the operand REGISTERS do not change; a GEMM-shaped loop feeds new operand values to
+// every MFMA, the multiplier inputs toggle, power goes up and the clock the chip holds goes down.  The probe runs the same
+// back-to-back MFMA stream (4 independent accumulators, no memory traffic in modes 0-2) with
+//   mode 0  constant random operands (registers never change)
+//   mode 1  operands re-derived by one v_fma per MFMA (fresh mantissas every instruction, still no memory)
+//   mode 2  operands read from a 48 KB random LDS image (ds_read_b128 per 4 MFMAs), rotating through it
+//   mode 3  mode 2 + a streaming global_load_lds per step (what the real kernel does, minus selection)
+// at 1 and 2 waves per SIMD, and reports TFLOP/s, cycles per MFMA and SIMD (s_memtime) and the clock = cycles / wall time.
+// build: hipcc -O3 --offload-arch=gfx950 mfma_f32_clock_probe.hip -o /tmp/mfma_f32_clock_probe ; run: /tmp/mfma_f32_clock_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) probe(const float* __restrict__ g, float* out, unsigned long long* cyc, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 12288; i += 256) ((float*)smem)[i] = g[i];
+    __syncthreads();
+    f32x16 a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+    f32x4 d0 = *(const f32x4*)(g + 4 * threadIdx.x), d1 = *(const f32x4*)(g + 1024 + 4 * threadIdx.x);
+    f32x4 q0 = *(const f32x4*)(g + 2048 + 4 * threadIdx.x), q1 = *(const f32x4*)(g + 3072 + 4 * threadIdx.x);
+    const char* buf = smem + w * 12288;
+    const char* src = (const char*)g + ((size_t)blockIdx.x * 4 + w) * 4096 * (size_t)iters % (size_t)(1u << 30) + lane * 16;
+    int st = 0;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+        if (MODE >= 2) {
+            const char* c = buf + st * 4096 + (lane & 31) * 64 + ((lane >> 5) << 4);
+            d0 = *(const f32x4*)(c);
+            d1 = *(const f32x4*)(c + 2048);
+            q0 = *(const f32x4*)(c + 32);
+            q1 = *(const f32x4*)(c + 2048 + 32);
+            if (MODE == 3) {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                char* dst = (char*)buf + ((st + 2) % 3) * 4096;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024),
+                                                     (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+                src += 4096;
+            }
+            st = st == 2 ? 0 : st + 1;
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            if (MODE == 1) {   // new operand values for every MFMA (two v_fma per MFMA: hidden in its 64-cycle slot)
+                d0[x] = __builtin_fmaf(d0[x], 1.0009765625f, q1[x]);
+                q0[x] = __builtin_fmaf(q0[x], 0.9990234375f, d1[x]);
+            }
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(d0[x], q0[x], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d0[x], q1[x], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[x], q0[x], a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[x], q1[x], a3, 0, 0, 0);
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0;
+    for (int i = 0; i < 16; ++i) s += a0[i] + a1[i] + a2[i] + a3[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int MODE>
+static int run(const char* name, int wgs_per_cu, const float* g, float* out, unsigned long long* cyc, int n_cu) {
+    const int grid = n_cu * wgs_per_cu, iters = 60000;
+    CHK(hipFuncSetAttribute((const void*)probe<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152));
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0));
+    CHK(hipEventCreate(&e1));
+    probe<MODE><<<grid, 256, 49152>>>(g, out, cyc, iters / 4);       // warm-up: let the clock settle
+    CHK(hipEventRecord(e0));
+    probe<MODE><<<grid, 256, 49152>>>(g, out, cyc, iters);
+    CHK(hipEventRecord(e1));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h(grid);
+    CHK(hipMemcpy(h.data(), cyc, grid * 8, hipMemcpyDeviceToHost));
+    double c = 0;
+    for (auto v : h) c += (double)v;
+    c /= grid;
+    const double flop = 2.0 * 32 * 32 * 2 * 16.0 * iters * 4.0 * grid;       // 16 MFMAs per iteration and wave, 4 waves per workgroup
+    const double mfma_per_simd = 16.0 * iters * wgs_per_cu;                  // one wave of each workgroup per SIMD
+    printf("%-52s waves/SIMD=%d  %7.1f TFLOP/s  %6.2f ms  %5.1f counter ticks per MFMA and SIMD (s_memtime: 100 MHz ref -> x clock/100MHz)\n", name,
+           wgs_per_cu, flop / (ms * 1e-3) / 1e12, ms, c / mfma_per_simd * wgs_per_cu);
+    printf("%-52s             issue-bound time at 64 cyc/MFMA/SIMD and 2.4 GHz: %.2f ms -> sustained clock if issue-bound: %.0f MHz\n", "", mfma_per_simd * 64 / 2.4e9 * 1e3,
+           mfma_per_simd * 64 / (ms * 1e-3) / 1e6);
+    return 0;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CHK(hipGetDeviceProperties(&prop, 0));
+    const int n_cu = prop.multiProcessorCount;
+    float *g, *out;
+    unsigned long long* cyc;
+    const size_t n = (size_t)(1u << 30) / 4 + (1u << 22);
+    CHK(hipMalloc(&g, n * 4));
+    CHK(hipMalloc(&out, (size_t)n_cu * 2 * 256 * 4));
+    CHK(hipMalloc(&cyc, (size_t)n_cu * 2 * 8));
+    std::vector<float> h(1 << 22);
+    srand(1);
+    for (auto& v : h) v = (float)rand() / RAND_MAX * 2.0f - 1.0f;
+    for (size_t o = 0; o < n; o += h.size()) CHK(hipMemcpy(g + o, h.data(), std::min(h.size(), n - o) * 4, hipMemcpyHostToDevice));
+    printf("device: %s, %d CUs, clock %d MHz (max)\n", prop.name, n_cu, prop.clockRate / 1000);
+    for (int wpc = 1; wpc <= 2; ++wpc) {
+        if (run<0>("mode 0: constant operand registers", wpc, g, out, cyc, n_cu)) return 1;
+        if (run<1>("mode 1: fresh operand values per MFMA (v_fma)", wpc, g, out, cyc, n_cu)) return 1;
+        if (run<2>("mode 2: operands from a random LDS image", wpc, g, out, cyc, n_cu)) return 1;
+        if (run<3>("mode 3: mode 2 + streaming LDS-DMA from HBM", wpc, g, out, cyc, n_cu)) return 1;
+    }
+    return 0;
+}

@@ -29,6 +29,12 @@ for c in "pf FETCH_SIZE" "pw WRITE_SIZE" "ps SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU
   rocprofv3 --kernel-trace --pmc $* -d /tmp/$d -o r1 --output-format csv -- python $R/bench.py --steps 4 --warmup 1 $B > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc $* -d /tmp/$d/off -o r1 --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --screen off $B > /dev/null 2>&1
 done
+# stage-2 bytes per launch at the 22-field shape, certified two-level stage 2 vs full gather (one FETCH_SIZE pass each), and its kernel trace
+for m in auto full; do
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/s2_$m -o r1 --output-format csv -- python $R/bench.py --steps 4 --warmup 1 $B --docs 129375 --fields 22 --stage2 $m > /dev/null 2>&1
+done
+rocprofv3 --kernel-trace --stats -d /tmp/ktp -o r1 --output-format csv -- python $R/bench.py --steps 16 --warmup 2 $B --docs 129375 --fields 22 > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/s2_auto /tmp/s2_full /tmp/ktp > $O/stage2_traffic_prime.txt
 python $R/tools/prof_summary.py /tmp/kt /tmp/pf /tmp/pw /tmp/ps > $O/rocprofv3_summary.txt
 python $R/tools/prof_summary.py --counters-json $O/counters.json /tmp/pf /tmp/pw /tmp/ps $(cd $R && python -c "import bench; print(bench.source_hash())") 1000000 8 768 64 1
 python $R/tools/trace_timeline.py /tmp/kt > $O/timeline.txt 2>/dev/null
