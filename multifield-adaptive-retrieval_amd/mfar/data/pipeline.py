@@ -53,8 +53,12 @@ class PipelinedSearcher:
         if self.sharded and not (dist.is_available() and dist.is_initialized()):
             raise ValueError("the exchange path needs an initialised torch.distributed process group")
         self.dev = torch.device(f"cuda:{index.device}")
-        self.main = torch.cuda.Stream(device=self.dev, priority=-1)   # the scans: dispatched ahead of the small kernels
-        self.side = torch.cuda.Stream(device=self.dev)
+        # stream priorities: by default the scans are dispatched ahead of the small kernels.  MFAR_TAIL_PRIORITY=1 flips it (the
+        # tail's workgroups then take the CU slots a finely cut scan grid frees while it runs; measured)
+        import os
+        flip = os.environ.get("MFAR_TAIL_PRIORITY", "0") == "1"
+        self.main = torch.cuda.Stream(device=self.dev, priority=0 if flip else -1)
+        self.side = torch.cuda.Stream(device=self.dev, priority=-1 if flip else 0)
         index.set_repair_mode(True)   # repairs are launched here only after a failure was reported (or when they are frequent)
         self.Qb = int(max_batch)      # queries per submitted batch (at most)
         cap = index.max_split_batch(k1)                       # 128 with the wide screened pass, else 64

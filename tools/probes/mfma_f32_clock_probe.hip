@@ -6,7 +6,9 @@
 //   mode 0  constant random operands (registers never change)
 //   mode 1  operands re-derived by one v_fma per MFMA (fresh mantissas every instruction, still no memory)
 //   mode 2  operands read from a 48 KB random LDS image (ds_read_b128 per 4 MFMAs), rotating through it
-//   mode 3  mode 2 + a streaming global_load_lds per step (what the real kernel does, minus selection)
+//   mode 3  mode 2 + streaming global_load_lds at the REAL kernel's ratio: 4 KB of docs per 32 MFMAs and wave (64 rows x 16 dims
+//           x 4 B against 2 x 2 blocks x 8 MFMAs) = 2 KB per 16-MFMA iteration here, i.e. 32 flop per HBM byte
+//   mode 4  mode 3 at twice the bytes per flop (HBM-bound on purpose: the ceiling when the stream, not the MFMA pipe, limits)
 // at 1 and 2 waves per SIMD, and reports TFLOP/s, cycles per MFMA and SIMD (s_memtime) and the clock = cycles / wall time.
 // build: hipcc -O3 --offload-arch=gfx950 mfma_f32_clock_probe.hip -o /tmp/mfma_f32_clock_probe ; run: /tmp/mfma_f32_clock_probe
 #include <hip/hip_runtime.h>
@@ -27,7 +29,9 @@ __global__ void __launch_bounds__(256, 2) probe(const float* __restrict__ g, flo
     f32x4 d0 = *(const f32x4*)(g + 4 * threadIdx.x), d1 = *(const f32x4*)(g + 1024 + 4 * threadIdx.x);
     f32x4 q0 = *(const f32x4*)(g + 2048 + 4 * threadIdx.x), q1 = *(const f32x4*)(g + 3072 + 4 * threadIdx.x);
     const char* buf = smem + w * 12288;
-    const char* src = (const char*)g + ((size_t)blockIdx.x * 4 + w) * 4096 * (size_t)iters % (size_t)(1u << 30) + lane * 16;
+    // streaming source: walks a 1 GiB window of the buffer and wraps (every address stays inside the allocation)
+    size_t soff = (((size_t)blockIdx.x * 4 + w) * 4096 * 977) & ((size_t)(1u << 30) - 1);
+    const char* const sbase = (const char*)g + lane * 16;
     int st = 0;
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
@@ -37,14 +41,15 @@ __global__ void __launch_bounds__(256, 2) probe(const float* __restrict__ g, flo
             d1 = *(const f32x4*)(c + 2048);
             q0 = *(const f32x4*)(c + 32);
             q1 = *(const f32x4*)(c + 2048 + 32);
-            if (MODE == 3) {
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (MODE >= 3) {
+                constexpr int NP = MODE == 3 ? 2 : 4;
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
                 char* dst = (char*)buf + ((st + 2) % 3) * 4096;
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024),
+                for (int p = 0; p < NP; ++p)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + soff + p * 1024),
                                                      (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
-                src += 4096;
+                soff = (soff + 4096) & ((size_t)(1u << 30) - 1);      // + 4096 + lane * 16 + 3 * 1024 + 16 <= 1 GiB + 8 KB < allocation
             }
             st = st == 2 ? 0 : st + 1;
         }
@@ -89,8 +94,9 @@ static int run(const char* name, int wgs_per_cu, const float* g, float* out, uns
     c /= grid;
     const double flop = 2.0 * 32 * 32 * 2 * 16.0 * iters * 4.0 * grid;       // 16 MFMAs per iteration and wave, 4 waves per workgroup
     const double mfma_per_simd = 16.0 * iters * wgs_per_cu;                  // one wave of each workgroup per SIMD
-    printf("%-52s waves/SIMD=%d  %7.1f TFLOP/s  %6.2f ms  %5.1f counter ticks per MFMA and SIMD (s_memtime: 100 MHz ref -> x clock/100MHz)\n", name,
-           wgs_per_cu, flop / (ms * 1e-3) / 1e12, ms, c / mfma_per_simd * wgs_per_cu);
+    const double gb = MODE >= 3 ? (double)iters * (MODE == 3 ? 2048.0 : 4096.0) * 4.0 * grid / 1e9 : 0.0;
+    printf("%-52s waves/SIMD=%d  %7.1f TFLOP/s  %6.2f ms  %6.2f TB/s streamed  %5.1f cycle-counter ticks per MFMA and SIMD\n", name,
+           wgs_per_cu, flop / (ms * 1e-3) / 1e12, ms, gb / ms, c / mfma_per_simd * wgs_per_cu);
     printf("%-52s             issue-bound time at 64 cyc/MFMA/SIMD and 2.4 GHz: %.2f ms -> sustained clock if issue-bound: %.0f MHz\n", "", mfma_per_simd * 64 / 2.4e9 * 1e3,
            mfma_per_simd * 64 / (ms * 1e-3) / 1e6);
     return 0;
@@ -115,7 +121,8 @@ int main() {
         if (run<0>("mode 0: constant operand registers", wpc, g, out, cyc, n_cu)) return 1;
         if (run<1>("mode 1: fresh operand values per MFMA (v_fma)", wpc, g, out, cyc, n_cu)) return 1;
         if (run<2>("mode 2: operands from a random LDS image", wpc, g, out, cyc, n_cu)) return 1;
-        if (run<3>("mode 3: mode 2 + streaming LDS-DMA from HBM", wpc, g, out, cyc, n_cu)) return 1;
+        if (run<3>("mode 3: mode 2 + LDS-DMA stream, 32 flop/B (real)", wpc, g, out, cyc, n_cu)) return 1;
+        if (run<4>("mode 4: mode 2 + LDS-DMA stream, 16 flop/B", wpc, g, out, cyc, n_cu)) return 1;
     }
     return 0;
 }

@@ -38,4 +38,7 @@ python $R/tools/prof_summary.py /tmp/s2_auto /tmp/s2_full /tmp/ktp > $O/stage2_t
 python $R/tools/prof_summary.py /tmp/kt /tmp/pf /tmp/pw /tmp/ps > $O/rocprofv3_summary.txt
 python $R/tools/prof_summary.py --counters-json $O/counters.json /tmp/pf /tmp/pw /tmp/ps $(cd $R && python -c "import bench; print(bench.source_hash())") 1000000 8 768 64 1
 python $R/tools/trace_timeline.py /tmp/kt > $O/timeline.txt 2>/dev/null
+python $R/tools/trace_timeline.py /tmp/ktp > $O/timeline_prime.txt 2>/dev/null
+# what v_mfma_f32_32x32x2_f32 sustains with constant / fresh / LDS / streamed operands
+hipcc -O3 --offload-arch=gfx950 $R/tools/probes/mfma_f32_clock_probe.hip -o /tmp/mp 2>/dev/null && timeout -k 10 240 /tmp/mp > $O/mfma_f32_clock_probe.txt 2>&1
 tail -c 600 $O/bench.json
