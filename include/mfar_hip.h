@@ -299,7 +299,9 @@ int mfar_screen_field_info(mfar_index* idx, int field, int64_t* n_unique_rows, i
  * whose upper bound reaches the k2-th largest lower bound (csrc/mfar_select.h: mfar_s2_prune_kernel); those are mixed exactly as
  * before, so ids and score bits of the top-k2 do not change.
  *   mode   0 = gather every (candidate, field) row from the fp32 slab, 1 = two-level when available (default; fp32 index whose
- *          screen and gather slab are current, more candidates than k2).  Environment default: MFAR_STAGE2_PRUNE;
+ *          screen and gather slab are current, more candidates than k2, at most two masks in the call: the bounds cost one
+ *          selection per mask, which a sweep of 2 F + 2 masks does not earn back), 2 = also for sweeps of any number of masks
+ *          (the survivors are the union over the masks).  Environment default: MFAR_STAGE2_PRUNE;
  *          MFAR_GATHER_SLAB=0 never allocates a gather slab.  The error bound is scaled by mfar_set_screen's eps_mult (test knob).
  * mfar_stage2_stats synchronises the device: candidates the prune kernel has seen / survivors it kept since the handle was created.
  */

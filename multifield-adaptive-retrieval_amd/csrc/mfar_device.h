@@ -27,6 +27,9 @@ struct ScreenField {
     float dnorm_max;     // largest 2-norm of a centred row of the field (inf / NaN when the field holds non-finite values)
     float mnorm;         // 2-norm of the field's mean vector
 };
+struct ScreenQuery {     // per query of the current block of 64 / 128 queries (mfar_screen_queries_kernel)
+    float scale, inv_scale, norm, pad;
+};
 
 // monotone float -> uint map (-0.0 folded onto +0.0 so that float '==' and key '==' agree)
 __device__ __forceinline__ u32 f2ord(float s) {

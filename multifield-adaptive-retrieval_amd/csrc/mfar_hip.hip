@@ -1090,6 +1090,15 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     sp.f0 = f0;
     bool rows16 = false;
     if (bf16) RETCHK(ensure_rows16(idx, st, &rows16));
+    static const bool prefix = !(getenv("MFAR_RESCORE_PREFIX") && atoi(getenv("MFAR_RESCORE_PREFIX")) == 0);   // diagnostic: 0 = re-score all k' rows
+    if (prefix) {      // rows that cannot reach the exact top-k of their list are not gathered (mfar_select.h ScoreParams::pre_sc)
+        sp.pre_sc = sl.ssc.as<float>();
+        sp.pre_eps = sl.eps.as<float>();
+        sp.pre_qinfo = sl.qinfo.as<ScreenQuery>();
+        sp.pre_k = k;
+        sp.pre_qw = qw;
+        sp.sfld = idx->s_field.as<ScreenField>();
+    }
     sp.gslab = idx->gslab.p;
     sp.g_row_bytes = (long long)idx->g_row_bytes;
     const dim3 sgrid((unsigned)((kp * nf + SCF_THREADS - 1) / SCF_THREADS), qt_n);
@@ -1227,9 +1236,10 @@ extern "C" int mfar_stage1_finish(mfar_index* idx, const float* q, int Q, int k,
                         field_scores, (int*)any_fail, (hipStream_t)stream);
 }
 
-static bool two_level_ok(const mfar_index* idx, int C, int k2, int query_cond);
+static bool two_level_ok(const mfar_index* idx, int C, int k2, int query_cond, int n_masks);
 extern "C" int mfar_set_stage2_mode(mfar_index* idx, int mode) {
-    if (!idx || mode < 0 || mode > 1) return fail(MFAR_ERR_INVALID, "mode must be 0 (gather every row) or 1 (certified two-level stage 2)");
+    if (!idx || mode < 0 || mode > 2)
+        return fail(MFAR_ERR_INVALID, "mode must be 0 (gather every row), 1 (certified two-level stage 2) or 2 (also for sweeps of many masks)");
     idx->stage2_mode = mode;
     return MFAR_OK;
 }
@@ -1238,7 +1248,7 @@ extern "C" int mfar_stage2_stats(mfar_index* idx, int* two_level_available, int6
                                  int64_t* n_survivors) {
     if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
     HIPCHK(hipSetDevice(idx->device));
-    if (two_level_available) *two_level_available = two_level_ok(idx, MFAR_MAX_K + 1, 1, 0) ? 1 : 0;
+    if (two_level_available) *two_level_available = two_level_ok(idx, MFAR_MAX_K + 1, 1, 0, 1) ? 1 : 0;
     if (gather_slab_bytes) *gather_slab_bytes = idx->gslab_ok ? (int64_t)((size_t)idx->F * idx->n_rows * idx->g_row_bytes) : 0;
     unsigned long long h[2] = {0, 0};
     if (idx->s2stats.p) {
@@ -1484,8 +1494,14 @@ extern "C" int mfar_mix_topk(int device, const float* cand_scores, const int64_t
 // The certified two-level stage 2 (mfar_select.h): approximate scores of every (candidate, field) pair from the fp16 gather slab ->
 // interval bounds on the mixed score -> the survivors' rows from the fp32 slab.  Available for fp32 indexes whose screen (mean,
 // scale, norms) and gather slab are current; otherwise every row is gathered from the fp32 / bf16 slab as before.
-static bool two_level_ok(const mfar_index* idx, int C, int k2, int query_cond) {
-    return idx->stage2_mode == 1 && idx->dtype == MFAR_DTYPE_F32 && idx->gslab_ok && idx->screen.p && !idx->screen_dirty && C > k2 &&
+//   n_masks   masks of the call.  The prune kernel runs one k2-th-lower-bound selection per mask (~0.08 ms per 128 queries), so a
+//             sweep of 2 F + 2 masks (mask_fields.py:143-170) would spend more there than the full gather costs (measured: the
+//             18-mask sweep at 1 M x 8 68.9 ms against 53.7 ms, 46 masks at 129 k x 22 193.9 against 113.4 ms,
+//             profiles/r03_b_mask_sweep_two_level_every_mask.txt): mode 1 prunes for at most S2_MAX_MASKS masks, mode 2 always (tests)
+#define S2_MAX_MASKS 2
+static bool two_level_ok(const mfar_index* idx, int C, int k2, int query_cond, int n_masks) {
+    if (idx->stage2_mode == 1 && n_masks > S2_MAX_MASKS) return false;
+    return idx->stage2_mode >= 1 && idx->dtype == MFAR_DTYPE_F32 && idx->gslab_ok && idx->screen.p && !idx->screen_dirty && C > k2 &&
            k2 <= SEL_MAX_K && PRUNE_LDS_BYTES(C, query_cond ? idx->E : 0, idx->F) <= 160 * 1024;
 }
 //   cand / ncand [Q, C] / [Q]: the candidates to score (sorted unique ids);  masks [n_masks, F] or nullptr (ones, n_masks = 1)
@@ -1559,7 +1575,7 @@ static int run_stage2_mix(mfar_index* idx, const float* qd, int Q, const float* 
     HIPCHK(hipGetLastError());
     const long long* cm = idx->cand[slot].as<long long>();
     const int* nm = ncd;
-    if (two_level_ok(idx, C, k2, query_cond))
+    if (two_level_ok(idx, C, k2, query_cond, n_masks))
         RETCHK(run_two_level(idx, qd, Q, Wd, query_cond, masks, n_masks, k2, cm, nm, C, slot, idx->x[slot].as<float>(), &cm, &nm, st));
     else
         RETCHK(run_score(idx, qd, Q, cm, nm, C, idx->x[slot].as<float>(), st));
@@ -1962,7 +1978,7 @@ static int search_owned(mfar_index* idx, const void* gathered_lists, int n_shard
     // the local top-k2 of the OWNED candidates: the two-level stage 2 prunes against the owned set's own k2-th lower bound
     const long long* cm = owned;
     const int* nm = nowned;
-    if (two_level_ok(idx, C, k2, query_cond)) RETCHK(run_two_level(idx, q, Q, W, query_cond, mask, n_masks, k2, owned, nowned, C, slot, x, &cm, &nm, st));
+    if (two_level_ok(idx, C, k2, query_cond, n_masks)) RETCHK(run_two_level(idx, q, Q, W, query_cond, mask, n_masks, k2, owned, nowned, C, slot, x, &cm, &nm, st));
     else RETCHK(run_score(idx, q, Q, owned, nowned, C, x, st));
     // one top-k payload per mask (a sweep of field masks shares everything up to here: mfar_search_owned_masks)
     for (int m = 0; m < n_masks; ++m) {

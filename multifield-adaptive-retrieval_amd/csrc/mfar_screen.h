@@ -39,9 +39,7 @@
 #define SCREEN_SLACK 1.25f
 
 // struct ScreenField: mfar_device.h (shared with the gather-slab kernels of mfar_select.h)
-struct ScreenQuery {     // per query of the current block of 64 / 128 queries
-    float scale, inv_scale, norm, pad;
-};
+// struct ScreenQuery: mfar_device.h
 
 // ---------------------------------------------------------------------------------------------------------
 // Build, step 1: the per-field mean vector (row-major [F][E]).  Its exact value is irrelevant for correctness -- ANY

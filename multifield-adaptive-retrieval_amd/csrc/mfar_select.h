@@ -451,6 +451,15 @@ struct ScoreParams {
     const ScreenField* sfld;         // [F] SRC_F16G: the field's power-of-two scale
     const float* qm;         // [Q, qm_stride] SRC_F16G: q . mean(field)
     int qm_stride;
+    // per_field mode of the certified screen (exact re-scoring of the k' screened rows of every list): a list is sorted by
+    // APPROXIMATE score a (scaled units), |a - exact| <= eps for every row.  The k rows with the largest a all have exact >= a_(k-1) - eps,
+    // so a row with a + eps < a_(k-1) - eps is strictly below k rows of its own list: it can neither enter nor tie into the exact
+    // top-k and is NOT gathered (output NaN = "not scored", which mfar_screen_certify_kernel skips).  ~125 of the 192 rows are
+    // gathered on the bench corpora.  nullptr: every row is gathered.
+    const float* pre_sc;     // [Q, F, C] approximate scores of the lists
+    const float* pre_eps;    // [n_fields, pre_qw] eps in real units (mfar_screen_queries_kernel)
+    const ScreenQuery* pre_qinfo;   // [pre_qw]
+    int pre_k, pre_qw;
 };
 // Each wave owns 64 (candidate, field) rows, one per lane, gathers their segments cooperatively by LDS-DMA into a private
 // two-slot LDS ring, and every lane then walks ITS row's segment from LDS in chain order.  No barriers: the ring is private
@@ -624,6 +633,11 @@ __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_kernel(const Scor
             long long id = p.cand[p.per_field ? ((size_t)qi * p.F + fl) * p.C + c : (size_t)qi * p.C + c];
             if (p.urep) id = (id >= 0 && id < p.nuniq[f]) ? (long long)p.urep[(size_t)f * p.ustride + id] : -1;   // unique row -> its document
             else id -= p.row_offset;
+            if (p.per_field && p.pre_sc && c >= p.pre_k) {      // provably outside the exact top-k of its list: skip the gather
+                const size_t lb = ((size_t)qi * p.F + fl) * p.C;
+                const float e_sc = p.pre_eps[f * p.pre_qw + qi] * (p.pre_qinfo[qi].scale * p.sfld[f].scale);
+                if (p.pre_sc[lb + c] < p.pre_sc[lb + p.pre_k - 1] - 2.01f * e_sc) id = -1;
+            }
             if (id >= 0 && id < p.n_rows) {
                 valid = true;
                 if (p.repof && !p.per_field) id = p.repof[(size_t)f * p.ustride + id];

@@ -382,7 +382,8 @@ class MultiFieldIndex:
 
     def set_stage2_mode(self, mode: int = 1):
         """Stage 2 of an fp32 index (include/mfar_hip.h): 0 = gather every (candidate, field) row from the fp32 slab, 1 = the
-        certified two-level stage 2 whenever its gather slab is current.  Outputs are bit-identical in both modes."""
+        certified two-level stage 2 whenever its gather slab is current (calls with at most two masks), 2 = also for mask sweeps
+        of any size.  Outputs are bit-identical in every mode."""
         _native.check(_native.lib().mfar_set_stage2_mode(self._h, int(mode)))
 
     def stage2_stats(self) -> dict:

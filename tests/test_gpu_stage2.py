@@ -97,12 +97,22 @@ def test_two_level_masks_of_any_sign_and_sweeps(idxmod):
     dev = torch.device("cuda:0")
     qd, Wd, md = torch.from_numpy(q).to(dev), torch.from_numpy(W).to(dev), torch.from_numpy(masks).to(dev)
     fid, _ = ix.retrieve_fields(qd, 100, True)
-    ix.set_stage2_mode(1)
+    ix.set_stage2_mode(1)                       # mode 1 leaves sweeps of more than two masks to the full gather ...
+    s0 = ix.stage2_stats()
+    sw1 = ix.search_stage2_masks(qd, Wd, fid, md)
+    torch.cuda.synchronize()
+    assert ix.stage2_stats()["n_candidates"] == s0["n_candidates"]
+    sw2 = ix.search_stage2_masks(qd, Wd, fid, md[:2].contiguous())
+    torch.cuda.synchronize()
+    assert ix.stage2_stats()["n_candidates"] > s0["n_candidates"]          # ... and prunes for two
+    ix.set_stage2_mode(2)                       # mode 2: any number of masks, survivors = union over the masks
     s0 = ix.stage2_stats()
     sw = ix.search_stage2_masks(qd, Wd, fid, md)
     s1 = ix.stage2_stats()
     assert s1["n_candidates"] > s0["n_candidates"]
     torch.cuda.synchronize()
+    for k_ in ("ids", "scores", "n_valid"):
+        assert torch.equal(sw[k_], sw1[k_]) and torch.equal(sw[k_][:2], sw2[k_])
     ix.set_stage2_mode(0)
     for i, m in enumerate(masks):
         r0 = ix.search(q, W, m)
