@@ -171,8 +171,22 @@ __device__ __forceinline__ int block_sum(int c, int* red, int parity) {
     return tot;
 }
 
+// Sum over the workgroup of a WAVE-UNIFORM count (every lane of a wave passes the same c, e.g. a sum of ballot popcounts):
+// no lane reduction at all -- one LDS word per wave, one barrier.
+__device__ __forceinline__ int block_sum_uniform(int c, int* red, int parity) {
+    if (lane_id() == 0) red[parity * 12 + (threadIdx.x >> 6)] = c;
+    __syncthreads();
+    int tot = 0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) tot += red[parity * 12 + w];
+    return tot;
+}
+
 // Core: every thread holds NPT keys in registers (hi = orderable score, lo = inverted id; hi == lo == 0 marks an empty slot,
 // which no real key can be), n = number of non-empty slots in the workgroup.
+// Every radix step counts with wave BALLOTS (one v_cmp + scalar popcount per key, the wave's count lives in an SGPR) instead of
+// per-lane counters and a 6-shuffle lane reduction: the steps are latency chains -- 34 of them per selection, in every small
+// kernel of a launch's tail -- and the shuffles were most of each link.
 template <int NPT>
 __device__ __forceinline__ int block_topk_regs(const u32 (&hi)[NPT], const u32 (&lo)[NPT], int n, int k, u64* sel, u64* sel_sorted,
                                                int* red) {
@@ -185,20 +199,20 @@ __device__ __forceinline__ int block_topk_regs(const u32 (&hi)[NPT], const u32 (
             const u32 cand = T | (1u << bit);
             int c = 0;
 #pragma unroll
-            for (int i = 0; i < NPT; ++i) c += hi[i] >= cand ? 1 : 0;
-            const int tot = block_sum<NPT>(c, red, parity);
+            for (int i = 0; i < NPT; ++i) c += __popcll(__ballot(hi[i] >= cand));
+            const int tot = block_sum_uniform(c, red, parity);
             parity ^= 1;
             if (tot >= k) T = cand;
         }
         int cg = 0, ce = 0;
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
-            cg += hi[i] > T ? 1 : 0;
-            ce += (hi[i] == T && (hi[i] | lo[i]) != 0u) ? 1 : 0;
+            cg += __popcll(__ballot(hi[i] > T));
+            ce += __popcll(__ballot(hi[i] == T && (hi[i] | lo[i]) != 0u));
         }
-        const int tg = block_sum<NPT>(cg, red, parity);
+        const int tg = block_sum_uniform(cg, red, parity);
         parity ^= 1;
-        const int te = block_sum<NPT>(ce, red, parity);
+        const int te = block_sum_uniform(ce, red, parity);
         parity ^= 1;
         if (tg + te > k) {  // tie on the k-th score: keep the smallest ids (largest inverted ids)
             const int need = k - tg;
@@ -206,8 +220,8 @@ __device__ __forceinline__ int block_topk_regs(const u32 (&hi)[NPT], const u32 (
                 const u32 cand = TL | (1u << bit);
                 int c = 0;
 #pragma unroll
-                for (int i = 0; i < NPT; ++i) c += (hi[i] == T && lo[i] >= cand) ? 1 : 0;
-                const int tot = block_sum<NPT>(c, red, parity);
+                for (int i = 0; i < NPT; ++i) c += __popcll(__ballot(hi[i] == T && lo[i] >= cand));
+                const int tot = block_sum_uniform(c, red, parity);
                 parity ^= 1;
                 if (tot >= need) TL = cand;
             }

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 def test_hybrid_contrastive_loss_golden_on_device(golden_dir):
     """Loss + grad(W, q, d_pos) on cuda:0 == the reference's (plain / BatchNorm over fields / sparse score columns)."""
-    from tests.helpers.loss_check import check_hybrid_loss_golden
+    from helpers.loss_check import check_hybrid_loss_golden
     assert check_hybrid_loss_golden(golden_dir, "cuda:0") == ["plain", "bn", "sparse"]
 
 

@@ -127,7 +127,7 @@ def test_hybrid_contrastive_loss_golden(golden_dir):
     """Training-time scorer + loss (losses.py:176-188, 275-360) against loss value and gradients captured from the
     reference's HybridContrastiveLoss (1-rank group): plain, with BatchNorm over fields, and with sparse score columns behind
     the dense ones (tests/helpers/loss_check.py; the `-m gpu` twin runs the same check on the device)."""
-    from tests.helpers.loss_check import check_hybrid_loss_golden
+    from helpers.loss_check import check_hybrid_loss_golden
     assert check_hybrid_loss_golden(golden_dir, "cpu") == ["plain", "bn", "sparse"]
 
 
