@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised parity stress of stage 1 (all scan kernels, screen on/off) against the C oracle.
+"""Randomised parity stress of stage 1 (all scan kernels, screen on/off) and of the whole scorer (with the screen on: certified
+re-scoring prefix, two-level stage 2) against the C oracle.
     python tools/stress.py [seconds] [seed] [big]      -- prints one line per configuration, exits non-zero on the first mismatch"""
 import os
 import sys
@@ -73,6 +74,8 @@ def main():
         if ok and dtype == "f32" and D * F * E * Q < 3e9 and F * k <= 4096:    # the whole scorer, both stage-1 paths
             W = (rng.standard_normal((E, F)) * 0.05).astype(np.float32)
             mask = (rng.random(F) < 0.8).astype(np.float32)
+            if rng.random() < 0.3:           # masks of any sign (the two-level stage 2 swaps its interval ends under a negative entry)
+                mask = rng.choice(np.array([0.0, 1.0, -1.0, 0.5, 2.0], np.float32), F)
             o = O.c_two_stage(slab, q, W, mask, k1=k, k2=k, sentinel=sentinel)
             for screen in (0, 2):
                 ix.set_screen(screen)
