@@ -45,7 +45,7 @@ typedef struct mfar_index mfar_index;
 
 /* library / device probes (no reference counterpart).  mfar_version() == MFAR_ABI_VERSION of the header the caller was built
  * against, or the caller must refuse the library: the value changes with every signature change. */
-#define MFAR_ABI_VERSION 101
+#define MFAR_ABI_VERSION 102
 int mfar_version(void);
 const char* mfar_last_error(void);
 int mfar_device_count(int* n_out);
@@ -142,18 +142,21 @@ int mfar_search_fused(mfar_index* idx, const float* q, int Q, const float* W, in
  * weights, top-k2 (:685-696), given the stage-1 lists produced by mfar_retrieve_fields.  Device pointers only, nothing
  * synchronises.  `slot` (0/1) selects one of two internal workspaces: with mfar_retrieve_fields(batch i+1) on one stream
  * and mfar_search_stage2(batch i) on another, two batches overlap on the GPU.
+ * field_scores [Q, n_fields, k1] (may be NULL) + sentinel: the lists' exact scores and their padding convention, as
+ * mfar_retrieve_fields / mfar_stage1_finish wrote them.  When given, a candidate's score in the field whose list it came from is
+ * taken from the list instead of being gathered again (stage 1 and stage 2 walk the same fma chain: identical bits).
  */
 int mfar_search_stage2(mfar_index* idx, const float* q, int Q, const float* W, int query_cond, const float* mask, int k1,
-                       int k2, const int64_t* field_ids, int slot, int64_t* ids, float* scores, int32_t* n_valid,
-                       int32_t* n_cand, void* stream);
+                       int k2, const int64_t* field_ids, const float* field_scores, int sentinel, int slot, int64_t* ids,
+                       float* scores, int32_t* n_valid, int32_t* n_cand, void* stream);
 /*
  * The same for a SWEEP of field masks (mask_fields.py:143-170 evaluates baseline + one masked run per field / field type /
  * field name: 2 F + 2 runs that differ in the mask only): masks [n_masks, F]; the candidate union and stage 2 run once, the
  * mixer once per mask.  ids / scores [n_masks, Q, k2], n_valid [n_masks, Q] (may be NULL); device pointers.
  */
 int mfar_search_stage2_masks(mfar_index* idx, const float* q, int Q, const float* W, int query_cond, const float* masks,
-                             int n_masks, int k1, int k2, const int64_t* field_ids, int slot, int64_t* ids, float* scores,
-                             int32_t* n_valid, int32_t* n_cand, void* stream);
+                             int n_masks, int k1, int k2, const int64_t* field_ids, const float* field_scores, int sentinel, int slot,
+                             int64_t* ids, float* scores, int32_t* n_valid, int32_t* n_cand, void* stream);
 
 /*
  * Multi-GPU (row shards + one exchange, replaces the file-based exchange of contrastive.py:491-494,519-536):

@@ -119,6 +119,7 @@ struct mfar_index {
     bool rows16_dirty = true;     // bf16 index: rows were written since the companion was filled
     int stage2_mode = 1;          // 0 = gather every (candidate, field) row from the fp32 slab; 1 = certified two-level stage 2 when available
     DevBuf xa[2], cand2[2], ncand2[2], s2qm[2], s2eps[2], s2stats;   // two-level stage 2 scratch (per pipeline slot) + counters
+    DevBuf kmask[2], src2[2];                                        // ... known pairs (stage-1 scores reused), survivor -> candidate index
     // certified fp16 screen of an fp32 index (mfar_screen.h)
     int screen_mode = 1;          // 0 off, 1 auto, 2 always (when the shapes allow)
     float screen_eps_mult = 1.0f; // test knob: scales the certificate's error bound
@@ -273,7 +274,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
                       &idx->own[0], &idx->own[1], &idx->s_stats, &idx->s_field, &idx->s_mean, &idx->screen, &idx->u_rep, &idx->u_start,
                       &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->xa[0], &idx->xa[1], &idx->cand2[0],
                       &idx->cand2[1], &idx->ncand2[0], &idx->ncand2[1], &idx->s2qm[0], &idx->s2qm[1], &idx->s2eps[0], &idx->s2eps[1],
-                      &idx->s2stats};
+                      &idx->s2stats, &idx->kmask[0], &idx->kmask[1], &idx->src2[0], &idx->src2[1]};
     for (S1Geom* g : {&idx->geom_docs, &idx->geom_screen})
         for (S1Table* t : {&g->all, &g->solo, &g->all_w, &g->solo_w}) {
             t->d_chunks.release();
@@ -1351,8 +1352,13 @@ extern "C" int mfar_retrieve_field(mfar_index* idx, int field, const float* q, i
 struct ApproxArgs {
     const float* qm;   // [Q, MFAR_MAX_FIELDS]
 };
+struct KnownArgs {     // pairs stage 1 already scored exactly (mfar_select.h ScoreParams::kmask)
+    const u32* kmask;
+    const int* ksrc;
+    const float* kval;
+};
 static int run_score(mfar_index* idx, const float* q, int Q, const long long* cand, const int* ncand, int C, float* x,
-                     hipStream_t st, const ApproxArgs* approx = nullptr) {
+                     hipStream_t st, const ApproxArgs* approx = nullptr, const KnownArgs* known = nullptr) {
     ScoreParams p = {};
     p.slab = idx->slab;
     p.field_stride = idx->field_stride;
@@ -1375,6 +1381,11 @@ static int run_score(mfar_index* idx, const float* q, int Q, const long long* ca
     if (gx == 0 || Q == 0) return MFAR_OK;
     p.gslab = idx->gslab.p;
     p.g_row_bytes = (long long)idx->g_row_bytes;
+    if (known) {
+        p.kmask = known->kmask;
+        p.ksrc = known->ksrc;
+        p.kval = known->kval;
+    }
     if (approx) {
         p.sfld = idx->s_field.as<ScreenField>();
         p.qm = approx->qm;
@@ -1506,9 +1517,10 @@ static bool two_level_ok(const mfar_index* idx, int C, int k2, int query_cond, i
 }
 //   cand / ncand [Q, C] / [Q]: the candidates to score (sorted unique ids);  masks [n_masks, F] or nullptr (ones, n_masks = 1)
 //   x [Q, C, F]: exact score vectors of the SURVIVORS, row c of x belongs to (*cand_out)[q, c]
+//   fid / fsc  the stage-1 lists [Q, F, k1] with their exact scores, or fsc == nullptr: no known pairs (every pair is gathered)
 static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* Wd, int query_cond, const float* masks, int n_masks, int k2,
                          const long long* cand, const int* ncand, int C, int slot, float* x, const long long** cand_out,
-                         const int** ncand_out, hipStream_t st) {
+                         const int** ncand_out, const long long* fid, const float* fsc, int k1, int sentinel, hipStream_t st) {
     const int F = idx->F, E = idx->E;
     RETCHK(idx->xa[slot].ensure((size_t)Q * C * F * 4));
     RETCHK(idx->cand2[slot].ensure((size_t)Q * C * 8));
@@ -1531,7 +1543,28 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
     mfar_s2_prep_kernel<<<dim3(Q), dim3(256), 0, st>>>(pp);
     HIPCHK(hipGetLastError());
     const ApproxArgs ap = {pp.qm};
-    RETCHK(run_score(idx, qd, Q, cand, ncand, C, idx->xa[slot].as<float>(), st, &ap));
+    static const bool reuse = !(getenv("MFAR_STAGE2_KNOWN") && atoi(getenv("MFAR_STAGE2_KNOWN")) == 0);   // diagnostic: 0 = gather the known pairs too
+    KnownArgs kn = {nullptr, nullptr, nullptr};
+    if (fsc && fid && reuse) {     // a candidate's score in the field whose list it came from is exact already: not gathered, eps = 0
+        RETCHK(idx->kmask[slot].ensure((size_t)Q * C * 4));
+        RETCHK(idx->src2[slot].ensure((size_t)Q * C * 4));
+        HIPCHK(hipMemsetAsync(idx->kmask[slot].p, 0, (size_t)Q * C * 4, st));
+        KnownParams kp = {};
+        kp.fid = fid;
+        kp.fsc = fsc;
+        kp.cand = cand;
+        kp.n_cand = ncand;
+        kp.xa = idx->xa[slot].as<float>();
+        kp.kmask = idx->kmask[slot].as<u32>();
+        kp.F = F;
+        kp.k = k1;
+        kp.C = C;
+        kp.sentinel = sentinel;
+        mfar_s2_known_kernel<<<dim3(Q), dim3(256), 0, st>>>(kp);
+        HIPCHK(hipGetLastError());
+        kn.kmask = kp.kmask;
+    }
+    RETCHK(run_score(idx, qd, Q, cand, ncand, C, idx->xa[slot].as<float>(), st, &ap, kn.kmask ? &kn : nullptr));
     PruneParams pr = {};
     pr.xa = idx->xa[slot].as<float>();
     pr.cand = cand;
@@ -1542,6 +1575,8 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
     pr.masks = masks;
     pr.cand2 = idx->cand2[slot].as<long long>();
     pr.n_cand2 = idx->ncand2[slot].as<int>();
+    pr.kmask = kn.kmask;
+    pr.src2 = kn.kmask ? idx->src2[slot].as<int>() : nullptr;
     pr.stats = idx->s2stats.as<unsigned long long>();
     pr.C = C;
     pr.F = F;
@@ -1551,7 +1586,9 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
     pr.n_masks = masks ? n_masks : 1;
     mfar_s2_prune_kernel<<<dim3(Q), dim3(256), PRUNE_LDS_BYTES(C, query_cond ? E : 0, F), st>>>(pr);
     HIPCHK(hipGetLastError());
-    RETCHK(run_score(idx, qd, Q, pr.cand2, pr.n_cand2, C, x, st));
+    kn.ksrc = pr.src2;
+    kn.kval = idx->xa[slot].as<float>();
+    RETCHK(run_score(idx, qd, Q, pr.cand2, pr.n_cand2, C, x, st, nullptr, kn.kmask ? &kn : nullptr));
     *cand_out = pr.cand2;
     *ncand_out = pr.n_cand2;
     return MFAR_OK;
@@ -1560,9 +1597,10 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
 // union -> stage 2 -> mixer (one launch per mask), all pointers on the device; `slot` selects one of two internal workspaces so
 // that two batches can be in flight on different streams.  masks [n_masks, F] (nullptr = no mask, n_masks = 1); ids / scores
 // [n_masks, Q, k2], nvd [n_masks, Q] or nullptr.
+//   fsc / sentinel   the lists' exact scores and padding convention, or fsc == nullptr (then no stage-1 score is reused)
 static int run_stage2_mix(mfar_index* idx, const float* qd, int Q, const float* Wd, int query_cond, const float* masks, int n_masks, int k1,
-                          int k2, const long long* fid, int slot, long long* idd, float* scd, int* nvd, int* ncd_out,
-                          hipStream_t st) {
+                          int k2, const long long* fid, const float* fsc, int sentinel, int slot, long long* idd, float* scd, int* nvd,
+                          int* ncd_out, hipStream_t st) {
     const int F = idx->F, E = idx->E, C = F * k1;
     int* ncd = ncd_out;
     if (!ncd) {
@@ -1576,7 +1614,8 @@ static int run_stage2_mix(mfar_index* idx, const float* qd, int Q, const float* 
     const long long* cm = idx->cand[slot].as<long long>();
     const int* nm = ncd;
     if (two_level_ok(idx, C, k2, query_cond, n_masks))
-        RETCHK(run_two_level(idx, qd, Q, Wd, query_cond, masks, n_masks, k2, cm, nm, C, slot, idx->x[slot].as<float>(), &cm, &nm, st));
+        RETCHK(run_two_level(idx, qd, Q, Wd, query_cond, masks, n_masks, k2, cm, nm, C, slot, idx->x[slot].as<float>(), &cm, &nm, fid, fsc, k1,
+                             sentinel, st));
     else
         RETCHK(run_score(idx, qd, Q, cm, nm, C, idx->x[slot].as<float>(), st));
     for (int m = 0; m < n_masks; ++m)
@@ -1625,7 +1664,7 @@ extern "C" int mfar_search_two_stage(mfar_index* idx, const float* q, int Q, con
         ncd = idx->ncand[0].as<int>();
     }
     RETCHK(run_stage1(idx, qd, Q, k1, sentinel, fid, fsc, st));
-    RETCHK(run_stage2_mix(idx, qd, Q, Wd, query_cond, md, 1, k1, k2, fid, 0, idd, scd, nvd, ncd, st));
+    RETCHK(run_stage2_mix(idx, qd, Q, Wd, query_cond, md, 1, k1, k2, fid, fsc, sentinel, 0, idd, scd, nvd, ncd, st));
     RETCHK(copy_back((long long*)ids, idd, (size_t)Q * k2, on_device, st));
     RETCHK(copy_back(scores, scd, (size_t)Q * k2, on_device, st));
     RETCHK(copy_back((int*)n_valid, nvd, (size_t)Q, on_device, st));
@@ -1639,8 +1678,8 @@ extern "C" int mfar_search_two_stage(mfar_index* idx, const float* q, int Q, con
 }
 
 extern "C" int mfar_search_stage2(mfar_index* idx, const float* q, int Q, const float* W, int query_cond, const float* mask,
-                                  int k1, int k2, const int64_t* field_ids, int slot, int64_t* ids, float* scores,
-                                  int32_t* n_valid, int32_t* n_cand, void* stream) {
+                                  int k1, int k2, const int64_t* field_ids, const float* field_scores, int sentinel, int slot, int64_t* ids,
+                                  float* scores, int32_t* n_valid, int32_t* n_cand, void* stream) {
     RETCHK(check_search_common(idx, q, Q, k1));
     const int F = idx->F, E = idx->E, C = F * k1;
     RETCHK(check_mix(Q, C, F, E, k2, q, W, query_cond));
@@ -1648,13 +1687,13 @@ extern "C" int mfar_search_stage2(mfar_index* idx, const float* q, int Q, const 
     if (!ids || !scores || !field_ids) return fail(MFAR_ERR_INVALID, "NULL pointer");
     if (slot < 0 || slot > 1) return fail(MFAR_ERR_INVALID, "slot must be 0 or 1");
     HIPCHK(hipSetDevice(idx->device));
-    return run_stage2_mix(idx, q, Q, W, query_cond, mask, 1, k1, k2, (const long long*)field_ids, slot, (long long*)ids, scores,
-                          (int*)n_valid, (int*)n_cand, (hipStream_t)stream);
+    return run_stage2_mix(idx, q, Q, W, query_cond, mask, 1, k1, k2, (const long long*)field_ids, field_scores, sentinel, slot, (long long*)ids,
+                          scores, (int*)n_valid, (int*)n_cand, (hipStream_t)stream);
 }
 
 extern "C" int mfar_search_stage2_masks(mfar_index* idx, const float* q, int Q, const float* W, int query_cond, const float* masks,
-                                        int n_masks, int k1, int k2, const int64_t* field_ids, int slot, int64_t* ids, float* scores,
-                                        int32_t* n_valid, int32_t* n_cand, void* stream) {
+                                        int n_masks, int k1, int k2, const int64_t* field_ids, const float* field_scores, int sentinel, int slot,
+                                        int64_t* ids, float* scores, int32_t* n_valid, int32_t* n_cand, void* stream) {
     RETCHK(check_search_common(idx, q, Q, k1));
     const int F = idx->F, E = idx->E, C = F * k1;
     RETCHK(check_mix(Q, C, F, E, k2, q, W, query_cond));
@@ -1664,8 +1703,8 @@ extern "C" int mfar_search_stage2_masks(mfar_index* idx, const float* q, int Q, 
     if (slot < 0 || slot > 1) return fail(MFAR_ERR_INVALID, "slot must be 0 or 1");
     HIPCHK(hipSetDevice(idx->device));
     // candidate union and stage 2 once, then one mixer launch per mask over the same scores
-    return run_stage2_mix(idx, q, Q, W, query_cond, masks, n_masks, k1, k2, (const long long*)field_ids, slot, (long long*)ids, scores,
-                          (int*)n_valid, (int*)n_cand, (hipStream_t)stream);
+    return run_stage2_mix(idx, q, Q, W, query_cond, masks, n_masks, k1, k2, (const long long*)field_ids, field_scores, sentinel, slot,
+                          (long long*)ids, scores, (int*)n_valid, (int*)n_cand, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------ fused mode
@@ -1978,7 +2017,8 @@ static int search_owned(mfar_index* idx, const void* gathered_lists, int n_shard
     // the local top-k2 of the OWNED candidates: the two-level stage 2 prunes against the owned set's own k2-th lower bound
     const long long* cm = owned;
     const int* nm = nowned;
-    if (two_level_ok(idx, C, k2, query_cond, n_masks)) RETCHK(run_two_level(idx, q, Q, W, query_cond, mask, n_masks, k2, owned, nowned, C, slot, x, &cm, &nm, st));
+    if (two_level_ok(idx, C, k2, query_cond, n_masks))
+        RETCHK(run_two_level(idx, q, Q, W, query_cond, mask, n_masks, k2, owned, nowned, C, slot, x, &cm, &nm, lids, lsc, k1, sentinel, st));
     else RETCHK(run_score(idx, q, Q, owned, nowned, C, x, st));
     // one top-k payload per mask (a sweep of field masks shares everything up to here: mfar_search_owned_masks)
     for (int m = 0; m < n_masks; ++m) {

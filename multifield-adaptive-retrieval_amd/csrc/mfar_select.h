@@ -456,6 +456,13 @@ struct ScoreParams {
     // so a row with a + eps < a_(k-1) - eps is strictly below k rows of its own list: it can neither enter nor tie into the exact
     // top-k and is NOT gathered (output NaN = "not scored", which mfar_screen_certify_kernel skips).  ~125 of the 192 rows are
     // gathered on the bench corpora.  nullptr: every row is gathered.
+    // all-fields mode of the two-level stage 2: KNOWN pairs.  A candidate's score in the field whose stage-1 list it came from is
+    // already exact (stage 1 and stage 2 walk the same fma chain: identical bits), mfar_s2_known_kernel wrote it into the
+    // approximate table and set bit f of kmask[q, c].  Such a pair is not gathered: the approximate launch (kval == nullptr) leaves
+    // the table entry alone, the exact launch over the SURVIVORS copies it (row c of this launch is row ksrc[q, c] of the table).
+    const u32* kmask;        // [Q, C] or nullptr
+    const int* ksrc;         // [Q, C] or nullptr (identity)
+    const float* kval;       // [Q, C, F] or nullptr
     const float* pre_sc;     // [Q, F, C] approximate scores of the lists
     const float* pre_eps;    // [n_fields, pre_qw] eps in real units (mfar_screen_queries_kernel)
     const ScreenQuery* pre_qinfo;   // [pre_qw]
@@ -621,8 +628,8 @@ __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_kernel(const Scor
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char* ring = smem + w * SCF_WAVE_BYTES;
     // this lane's row
-    bool valid = false;
-    int rr = 0, fld = 0;
+    bool valid = false, known = false;
+    int rr = 0, fld = 0, kc = 0;
     const char* rowbase = (const char*)(SRC == SRC_F32 ? p.slab : p.gslab);  // harmless in-bounds address for invalid rows
     if (idx < p.C * p.F) {
         const int c = p.per_field ? idx % p.C : idx / p.F;
@@ -633,6 +640,11 @@ __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_kernel(const Scor
             long long id = p.cand[p.per_field ? ((size_t)qi * p.F + fl) * p.C + c : (size_t)qi * p.C + c];
             if (p.urep) id = (id >= 0 && id < p.nuniq[f]) ? (long long)p.urep[(size_t)f * p.ustride + id] : -1;   // unique row -> its document
             else id -= p.row_offset;
+            if (p.kmask && !p.per_field) {                      // a pair stage 1 already scored exactly: no gather
+                kc = p.ksrc ? p.ksrc[(size_t)qi * p.C + c] : c;
+                known = kc >= 0 && ((p.kmask[(size_t)qi * p.C + kc] >> f) & 1u);
+                if (known) id = -1;
+            }
             if (p.per_field && p.pre_sc && c >= p.pre_k) {      // provably outside the exact top-k of its list: skip the gather
                 const size_t lb = ((size_t)qi * p.F + fl) * p.C;
                 const float e_sc = p.pre_eps[f * p.pre_qw + qi] * (p.pre_qinfo[qi].scale * p.sfld[f].scale);
@@ -726,7 +738,11 @@ __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_kernel(const Scor
     if (idx < p.C * p.F) {
         float o = acc;
         if (SRC == SRC_F16G && valid) o = acc * p.sfld[fld].inv_scale + p.qm[(size_t)qi * p.qm_stride + fld];   // un-scale (power of two), add q . mean
-        p.out[(size_t)qi * p.C * p.F + idx] = valid ? o : __builtin_nanf("");
+        if (known) {
+            if (p.kval) p.out[(size_t)qi * p.C * p.F + idx] = p.kval[((size_t)qi * p.C + kc) * p.F + fld];      // exact launch: stage 1's bits
+        } else {
+            p.out[(size_t)qi * p.C * p.F + idx] = valid ? o : __builtin_nanf("");
+        }
     }
 }
 
@@ -988,6 +1004,44 @@ __global__ void __launch_bounds__(256) mfar_s2_prep_kernel(const S2PrepParams p)
     }
 }
 
+// Known pairs (see ScoreParams::kmask): every REAL entry (field f, doc d, exact score s) of the query's stage-1 lists -- not the
+// (0, 0.0) padding of a short zero-sentinel list, not the (-1, -inf) padding of the clean variant -- is looked up in the sorted
+// candidate list; xa[q, c, f] = s, bit f of kmask[q, c] set.  Entries whose document is not a candidate of this call (a row another
+// shard owns) are skipped.  grid = Q, block 256; kmask must be zero on entry.
+struct KnownParams {
+    const long long* fid;    // [Q, F, k]
+    const float* fsc;        // [Q, F, k]
+    const long long* cand;   // [Q, C] sorted unique ids, -1 padded
+    const int* n_cand;       // [Q]
+    float* xa;               // [Q, C, F]
+    u32* kmask;              // [Q, C]
+    int F, k, C, sentinel;
+};
+__global__ void __launch_bounds__(256) mfar_s2_known_kernel(const KnownParams p) {
+    const int qi = blockIdx.x;
+    const int nc = min(p.n_cand[qi], p.C);
+    const long long* cq = p.cand + (size_t)qi * p.C;
+    for (int i = threadIdx.x; i < p.F * p.k; i += blockDim.x) {
+        const long long id = p.fid[(size_t)qi * p.F * p.k + i];
+        const float sc = p.fsc[(size_t)qi * p.F * p.k + i];
+        if (id < 0 || (p.sentinel && !(sc > 0.0f))) continue;      // padding
+        int lo = 0, hi = nc - 1, c = -1;
+        while (lo <= hi) {
+            const int mid = (lo + hi) >> 1;
+            const long long v = cq[mid];
+            if (v == id) {
+                c = mid;
+                break;
+            }
+            if (v < id) lo = mid + 1; else hi = mid - 1;
+        }
+        if (c < 0) continue;
+        const int f = i / p.k;
+        p.xa[((size_t)qi * p.C + c) * p.F + f] = sc;
+        atomicOr(&p.kmask[(size_t)qi * p.C + c], 1u << f);
+    }
+}
+
 struct PruneParams {
     const float* xa;         // [Q, C, F] approximate scores (NaN = not scored)
     const long long* cand;   // [Q, C] sorted unique candidate ids (< 0 = empty)
@@ -996,7 +1050,9 @@ struct PruneParams {
     const float* q;          // [Q, E]
     const float* W;          // [E, F] or [F]
     const float* masks;      // [n_masks, F] or nullptr (ones)
+    const u32* kmask;        // [Q, C] or nullptr: bit f = xa[q, c, f] is EXACT (eps = 0 for that pair)
     long long* cand2;        // [Q, C] the survivors in ascending id order, padded with -1
+    int* src2;               // [Q, C] or nullptr: index of survivor j in the candidate list (-1 padded)
     int* n_cand2;            // [Q]
     unsigned long long* stats;   // [2] or nullptr: candidates seen / survivors kept (mfar_stage2_stats)
     int C, F, E, k, query_cond, n_masks;
@@ -1034,9 +1090,10 @@ __global__ void __launch_bounds__(256) mfar_s2_prune_kernel(const PruneParams p)
             const long long id = cq[c];
             if (id < 0) continue;
             const float* xr = xq + (size_t)c * p.F;
+            const u32 km = p.kmask ? p.kmask[(size_t)qi * p.C + c] : 0u;
             float acc = 0.0f;
             for (int f = 0; f < p.F; ++f) {
-                const float v = xr[f], e = eps_s[f], mf = msk[f];
+                const float v = xr[f], e = ((km >> f) & 1u) ? 0.0f : eps_s[f], mf = msk[f];
                 const float end = mf >= 0.0f ? s2_nextdown(v - e) : s1_nextup(v + e);
                 acc = __builtin_fmaf(wgt[f], end * mf, acc);
             }
@@ -1050,9 +1107,10 @@ __global__ void __launch_bounds__(256) mfar_s2_prune_kernel(const PruneParams p)
         for (int c = threadIdx.x; c < nc; c += blockDim.x) {
             if (cq[c] < 0 || surv[c]) continue;
             const float* xr = xq + (size_t)c * p.F;
+            const u32 km = p.kmask ? p.kmask[(size_t)qi * p.C + c] : 0u;
             float acc = 0.0f;
             for (int f = 0; f < p.F; ++f) {
-                const float v = xr[f], e = eps_s[f], mf = msk[f];
+                const float v = xr[f], e = ((km >> f) & 1u) ? 0.0f : eps_s[f], mf = msk[f];
                 const float end = mf >= 0.0f ? s1_nextup(v + e) : s2_nextdown(v - e);
                 acc = __builtin_fmaf(wgt[f], end * mf, acc);
             }
@@ -1077,9 +1135,16 @@ __global__ void __launch_bounds__(256) mfar_s2_prune_kernel(const PruneParams p)
     const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     int pos = wbase + incl - mine;
     long long* out = p.cand2 + (size_t)qi * p.C;
+    int* osrc = p.src2 ? p.src2 + (size_t)qi * p.C : nullptr;
     for (int i = b; i < e_; ++i)
-        if (surv[i]) out[pos++] = cq[i];
-    for (int i = total + threadIdx.x; i < p.C; i += blockDim.x) out[i] = -1;
+        if (surv[i]) {
+            if (osrc) osrc[pos] = i;
+            out[pos++] = cq[i];
+        }
+    for (int i = total + threadIdx.x; i < p.C; i += blockDim.x) {
+        out[i] = -1;
+        if (osrc) osrc[i] = -1;
+    }
     if (threadIdx.x == 0) {
         p.n_cand2[qi] = total;
         if (p.stats) {

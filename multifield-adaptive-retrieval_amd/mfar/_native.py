@@ -59,8 +59,8 @@ SIGNATURES = {
     "mfar_search_two_stage": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mfar_search_fused": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "mfar_payload_bytes": (_i64, [_i, _i, _i]),
-    "mfar_search_stage2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
-    "mfar_search_stage2_masks": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mfar_search_stage2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mfar_search_stage2_masks": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "mfar_search_local": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "mfar_merge_workspace_bytes": (_i64, [_i, _i, _i]),
     "mfar_merge_payloads": (_i, [_i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
@@ -89,7 +89,7 @@ SIGNATURES = {
 
 # MFAR_ABI_VERSION of include/mfar_hip.h these signatures were written against.  A library that reports another value has
 # different argument lists behind the same names (pointers would land in the wrong slots): lib() refuses it.
-ABI_VERSION = 101
+ABI_VERSION = 102
 
 
 def lib():

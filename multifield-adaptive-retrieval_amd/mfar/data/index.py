@@ -231,8 +231,10 @@ class MultiFieldIndex:
         return int(_native.lib().mfar_payload_bytes(int(Q), self.n_fields, int(k1)))
 
     def search_stage2(self, q, W, field_ids, mask=None, k1: int = 100, k2: int = 100, query_cond: bool = True, slot: int = 0,
-                      out=None):
-        """Second half of `search` given the stage-1 lists (device tensors only, asynchronous on the current stream)."""
+                      out=None, field_scores=None, sentinel: bool = True):
+        """Second half of `search` given the stage-1 lists (device tensors only, asynchronous on the current stream).
+        `field_scores` (the lists' exact scores, with their padding convention `sentinel`): when given, stage 2 does not gather a
+        candidate's row again for the field whose list it came from."""
         qa, Wa = _Arg(q, np.float32, self.device), _Arg(W, np.float32, self.device)
         ma = _Arg(mask, np.float32, self.device, allow_none=True)
         fa = _Arg(field_ids, np.int64, self.device)
@@ -244,13 +246,14 @@ class MultiFieldIndex:
         sc = out.get("scores") if out.get("scores") is not None else _empty_like_side(True, self.device, (Q, k2), np.float32)
         nv = out.get("n_valid") if out.get("n_valid") is not None else _empty_like_side(True, self.device, (Q,), np.int32)
         ia, sa, na = _Arg(ids, np.int64, self.device), _Arg(sc, np.float32, self.device), _Arg(nv, np.int32, self.device)
+        fsa = _Arg(field_scores, np.float32, self.device, allow_none=True)
         _native.check(_native.lib().mfar_search_stage2(
-            self._h, qa.ptr, Q, Wa.ptr, int(bool(query_cond)), ma.ptr, int(k1), int(k2), fa.ptr, int(slot),
+            self._h, qa.ptr, Q, Wa.ptr, int(bool(query_cond)), ma.ptr, int(k1), int(k2), fa.ptr, fsa.ptr, int(bool(sentinel)), int(slot),
             ia.ptr, sa.ptr, na.ptr, None, _current_stream(self.device, True)))
         return dict(ids=ids, scores=sc, n_valid=nv)
 
     def search_stage2_masks(self, q, W, field_ids, masks, k1: int = 100, k2: int = 100, query_cond: bool = True, slot: int = 0,
-                            out=None):
+                            out=None, field_scores=None, sentinel: bool = True):
         """`search_stage2` for a sweep of field masks [M, F]: candidate union and stage 2 once, the mixer once per mask
         (include/mfar_hip.h mfar_search_stage2_masks).  -> ids / scores [M, Q, k2], n_valid [M, Q]."""
         qa, Wa = _Arg(q, np.float32, self.device), _Arg(W, np.float32, self.device)
@@ -265,8 +268,9 @@ class MultiFieldIndex:
         sc = out.get("scores") if out.get("scores") is not None else _empty_like_side(True, self.device, (M, Q, k2), np.float32)
         nv = out.get("n_valid") if out.get("n_valid") is not None else _empty_like_side(True, self.device, (M, Q), np.int32)
         ia, sa, na = _Arg(ids, np.int64, self.device), _Arg(sc, np.float32, self.device), _Arg(nv, np.int32, self.device)
+        fsa = _Arg(field_scores, np.float32, self.device, allow_none=True)
         _native.check(_native.lib().mfar_search_stage2_masks(
-            self._h, qa.ptr, Q, Wa.ptr, int(bool(query_cond)), ma.ptr, int(M), int(k1), int(k2), fa.ptr, int(slot),
+            self._h, qa.ptr, Q, Wa.ptr, int(bool(query_cond)), ma.ptr, int(M), int(k1), int(k2), fa.ptr, fsa.ptr, int(bool(sentinel)), int(slot),
             ia.ptr, sa.ptr, na.ptr, None, _current_stream(self.device, True)))
         return dict(ids=ids, scores=sc, n_valid=nv)
 

@@ -136,7 +136,8 @@ class PipelinedSearcher:
                              n_valid=s["n_valid"].view(-1)[:self.M * Q].view(self.M, Q))
             s["dense_Q"] = Q
             if not self.sharded:
-                self.ix.search_stage2_masks(qk, s["W"], s["fid"][:Q], self.masks, self.k1, self.k2, self.query_cond, slot=slot, out=dense)
+                self.ix.search_stage2_masks(qk, s["W"], s["fid"][:Q], self.masks, self.k1, self.k2, self.query_cond, slot=slot, out=dense,
+                                            field_scores=s["fsc"][:Q], sentinel=self.sentinel)
             else:       # (sharded launches always hold Qmax queries)
                 dist = torch.distributed
                 dist.all_gather_into_tensor(s["lists_all"], s["lists"], group=self.group)
@@ -149,7 +150,8 @@ class PipelinedSearcher:
                                       out=dict(ids=dense["ids"][m], scores=dense["scores"][m], n_valid=dense["n_valid"][m]),
                                       any_fail=s["fail"])
         elif not self.sharded:
-            self.ix.search_stage2(qk, s["W"], s["fid"][:Q], s["mask"], self.k1, self.k2, self.query_cond, slot=slot, out=out)
+            self.ix.search_stage2(qk, s["W"], s["fid"][:Q], s["mask"], self.k1, self.k2, self.query_cond, slot=slot, out=out,
+                                  field_scores=s["fsc"][:Q], sentinel=self.sentinel)
         else:
             dist = torch.distributed
             dist.all_gather_into_tensor(s["lists_all"], s["lists"], group=self.group)

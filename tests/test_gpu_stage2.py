@@ -205,3 +205,33 @@ def test_two_level_in_the_lists_first_exchange(idxmod):
         assert np.array_equal(r["n_valid"].cpu().numpy(), ref["n_valid"]), S
         for sh in shards:
             sh.close()
+
+
+def test_two_level_reuses_stage1_scores(idxmod):
+    """Known pairs: a candidate's score in the field whose stage-1 list it came from is taken from the list (`field_scores`), not
+    gathered again.  Same bits with and without the lists' scores and as the full gather, zero-sentinel and clean lists (negative
+    scores, -1 padding), short lists with (0, 0.0) padding; and the path is live -- handing it WRONG list scores changes results."""
+    import torch
+    rng = np.random.default_rng(305)
+    dev = torch.device("cuda:0")
+    for F, D, E, Q, mean in ((6, 9000, 128, 50, 0.3), (4, 5000, 64, 30, -0.35)):
+        slab, q, W = _mk(rng, F, D, E, Q, mean=mean, dup=5)
+        ix = _load(idxmod, slab)
+        qd, Wd = torch.from_numpy(q).to(dev), torch.from_numpy(W).to(dev)
+        md = torch.tensor([1.0] * (F - 1) + [0.0], device=dev)
+        for sentinel in (True, False):
+            fid, fsc = ix.retrieve_fields(qd, 100, sentinel)
+            ix.set_stage2_mode(0)
+            full = ix.search_stage2(qd, Wd, fid, md)
+            ix.set_stage2_mode(1)
+            plain = ix.search_stage2(qd, Wd, fid, md)
+            reuse = ix.search_stage2(qd, Wd, fid, md, field_scores=fsc, sentinel=sentinel)
+            wrong = ix.search_stage2(qd, Wd, fid, md, field_scores=fsc + 1.0, sentinel=sentinel)
+            torch.cuda.synchronize()
+            for k_ in ("ids", "scores", "n_valid"):
+                assert torch.equal(plain[k_], full[k_]) and torch.equal(reuse[k_], full[k_]), (F, sentinel, k_)
+            assert not torch.equal(wrong["scores"], full["scores"]), "the lists' scores are not being used"
+            o = O.c_two_stage(slab, q, W, md.cpu().numpy(), sentinel=sentinel)
+            assert np.array_equal(reuse["ids"].cpu().numpy(), o["ids"])
+            assert np.array_equal(reuse["scores"].cpu().numpy().view(np.uint32), o["scores"].view(np.uint32))
+        ix.close()
