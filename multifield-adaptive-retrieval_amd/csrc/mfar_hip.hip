@@ -88,6 +88,9 @@ struct S1Geom : S1GeomHost {
     }
 };
 
+// Pipeline slots: independent sets of per-launch scratch (stage-1 lists, thresholds, candidate tables, ...).  A caller keeps as many
+// launches in flight as it uses slots (mfar.data.pipeline: 2 by default, MFAR_PIPE_DEPTH up to MFAR_SLOTS).
+#define MFAR_SLOTS 4
 struct mfar_index {
     int device = 0;
     int64_t n_rows = 0, row_offset = 0;
@@ -107,8 +110,8 @@ struct mfar_index {
         DevBuf qt16, qinfo, eps, base, fail, sids, ssc, scnt, sx;        // fp16 screen
         bool screened = false;                                          // decided by the begin phase of the batch
         int qw = 64;                                                    // query columns of the batch's pass (128: wide screen pass)
-    } s1[2];
-    DevBuf fid, fsc, cand[2], ncand[2], x[2], own[2], in[8], out[8];
+    } s1[MFAR_SLOTS];
+    DevBuf fid, fsc, cand[MFAR_SLOTS], ncand[MFAR_SLOTS], x[MFAR_SLOTS], own[MFAR_SLOTS], in[8], out[8];
     // 16-bit GATHER slab (mfar_select.h mfar_score_rows_kernel): row-major [F][n_rows] rows of g_row_bytes.
     //   fp32 index: fp16 of the centred + scaled rows (built with the screen: same mean / scale) -> the approximate level of the
     //               certified two-level stage 2;   bf16 index: the slab's values bit for bit -> every row gather reads whole lines
@@ -118,8 +121,8 @@ struct mfar_index {
     bool gslab_nomem = false;     // it could not be allocated: gathers stay on the scan-ordered slab
     bool rows16_dirty = true;     // bf16 index: rows were written since the companion was filled
     int stage2_mode = 1;          // 0 = gather every (candidate, field) row from the fp32 slab; 1 = certified two-level stage 2 when available
-    DevBuf xa[2], cand2[2], ncand2[2], s2qm[2], s2eps[2], s2stats;   // two-level stage 2 scratch (per pipeline slot) + counters
-    DevBuf kmask[2], src2[2];                                        // ... known pairs (stage-1 scores reused), survivor -> candidate index
+    DevBuf xa[MFAR_SLOTS], cand2[MFAR_SLOTS], ncand2[MFAR_SLOTS], s2qm[MFAR_SLOTS], s2eps[MFAR_SLOTS], s2stats;   // two-level stage 2 scratch (per pipeline slot) + counters
+    DevBuf kmask[MFAR_SLOTS], src2[MFAR_SLOTS];                      // ... known pairs (stage-1 scores reused), survivor -> candidate index
     // certified fp16 screen of an fp32 index (mfar_screen.h)
     int screen_mode = 1;          // 0 off, 1 auto, 2 always (when the shapes allow)
     float screen_eps_mult = 1.0f; // test knob: scales the certificate's error bound
@@ -270,11 +273,12 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     idx->fused_q.release();
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
-    DevBuf* bufs[] = {&idx->fid, &idx->fsc, &idx->cand[0], &idx->cand[1], &idx->ncand[0], &idx->ncand[1], &idx->x[0], &idx->x[1],
-                      &idx->own[0], &idx->own[1], &idx->s_stats, &idx->s_field, &idx->s_mean, &idx->screen, &idx->u_rep, &idx->u_start,
-                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->xa[0], &idx->xa[1], &idx->cand2[0],
-                      &idx->cand2[1], &idx->ncand2[0], &idx->ncand2[1], &idx->s2qm[0], &idx->s2qm[1], &idx->s2eps[0], &idx->s2eps[1],
-                      &idx->s2stats, &idx->kmask[0], &idx->kmask[1], &idx->src2[0], &idx->src2[1]};
+    DevBuf* bufs[] = {&idx->fid, &idx->fsc, &idx->s_stats, &idx->s_field, &idx->s_mean, &idx->screen, &idx->u_rep, &idx->u_start,
+                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->s2stats};
+    for (int i = 0; i < MFAR_SLOTS; ++i)
+        for (DevBuf* b : {&idx->cand[i], &idx->ncand[i], &idx->x[i], &idx->own[i], &idx->xa[i], &idx->cand2[i], &idx->ncand2[i], &idx->s2qm[i],
+                          &idx->s2eps[i], &idx->kmask[i], &idx->src2[i]})
+            b->release();
     for (S1Geom* g : {&idx->geom_docs, &idx->geom_screen})
         for (S1Table* t : {&g->all, &g->solo, &g->all_w, &g->solo_w}) {
             t->d_chunks.release();
@@ -1212,7 +1216,7 @@ static int check_split(const mfar_index* idx, const float* q, int Q, int k, int 
     RETCHK(check_search_common(idx, q, Q, k));
     if (Q > max_split_batch(idx, k))
         return fail(MFAR_ERR_INVALID, "the split-phase entry points take at most mfar_max_split_batch() queries (64; 128 with the wide screened pass)");
-    if (slot < 0 || slot > 1) return fail(MFAR_ERR_INVALID, "slot must be 0 or 1");
+    if (slot < 0 || slot >= MFAR_SLOTS) return fail(MFAR_ERR_INVALID, "slot must be in [0, 4)");
     return MFAR_OK;
 }
 extern "C" int mfar_stage1_begin(mfar_index* idx, const float* q, int Q, int k, int sentinel, int slot, int64_t* field_ids,
@@ -1685,7 +1689,7 @@ extern "C" int mfar_search_stage2(mfar_index* idx, const float* q, int Q, const 
     RETCHK(check_mix(Q, C, F, E, k2, q, W, query_cond));
     if (Q == 0) return MFAR_OK;
     if (!ids || !scores || !field_ids) return fail(MFAR_ERR_INVALID, "NULL pointer");
-    if (slot < 0 || slot > 1) return fail(MFAR_ERR_INVALID, "slot must be 0 or 1");
+    if (slot < 0 || slot >= MFAR_SLOTS) return fail(MFAR_ERR_INVALID, "slot must be in [0, 4)");
     HIPCHK(hipSetDevice(idx->device));
     return run_stage2_mix(idx, q, Q, W, query_cond, mask, 1, k1, k2, (const long long*)field_ids, field_scores, sentinel, slot, (long long*)ids,
                           scores, (int*)n_valid, (int*)n_cand, (hipStream_t)stream);
@@ -1700,7 +1704,7 @@ extern "C" int mfar_search_stage2_masks(mfar_index* idx, const float* q, int Q, 
     if (n_masks <= 0 || !masks) return fail(MFAR_ERR_INVALID, "n_masks must be positive and masks non-NULL");
     if (Q == 0) return MFAR_OK;
     if (!ids || !scores || !field_ids) return fail(MFAR_ERR_INVALID, "NULL pointer");
-    if (slot < 0 || slot > 1) return fail(MFAR_ERR_INVALID, "slot must be 0 or 1");
+    if (slot < 0 || slot >= MFAR_SLOTS) return fail(MFAR_ERR_INVALID, "slot must be in [0, 4)");
     HIPCHK(hipSetDevice(idx->device));
     // candidate union and stage 2 once, then one mixer launch per mask over the same scores
     return run_stage2_mix(idx, q, Q, W, query_cond, masks, n_masks, k1, k2, (const long long*)field_ids, field_scores, sentinel, slot,
@@ -1975,7 +1979,7 @@ static int search_owned(mfar_index* idx, const void* gathered_lists, int n_shard
     const int F = idx->F, E = idx->E, C = F * k1;
     RETCHK(check_mix(Q, C, F, E, k2, q, W, query_cond));
     if (!gathered_lists || !topk || n_shards <= 0 || n_shards > 64) return fail(MFAR_ERR_INVALID, "bad lists / topk / n_shards");
-    if (slot < 0 || slot > 1) return fail(MFAR_ERR_INVALID, "slot must be 0 or 1");
+    if (slot < 0 || slot >= MFAR_SLOTS) return fail(MFAR_ERR_INVALID, "slot must be in [0, 4)");
     if (Q == 0) return MFAR_OK;
     HIPCHK(hipSetDevice(idx->device));
     hipStream_t st = (hipStream_t)stream;

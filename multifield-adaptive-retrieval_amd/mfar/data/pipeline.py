@@ -1,4 +1,4 @@
-"""Two-deep software pipeline over query batches (HIP streams + events through torch).
+"""Software pipeline over query batches, three launches deep (HIP streams + events through torch).
 
 The reference scores one batch at a time, synchronously (reference mfar/modeling/contrastive.py:559-563 -> 669-704).
 On the GPU the per-batch work is one long scan (stage 1: per-field exhaustive top-k) and a chain of short, latency- or
@@ -19,9 +19,9 @@ not depend on its neighbours).  `result()` of a batch that is still waiting laun
     ps = PipelinedSearcher(index, W, mask)
     t0 = ps.submit(q0)            # returns immediately (everything is enqueued asynchronously, or held for coalescing)
     t1 = ps.submit(q1)
-    r0 = ps.result(t0)            # dict(ids, scores, n_valid): valid until 2 * ps.coalesce more batches were submitted
+    r0 = ps.result(t0)            # dict(ids, scores, n_valid): valid until ps.depth * ps.coalesce more batches were submitted
 
-To keep two launches in flight, ask for results `ps.lag` (= 2 * coalesce - 1) submissions late: submit(i); result(i - lag).
+To keep the pipeline full, ask for results `ps.lag` (= depth * coalesce - 1) submissions late: submit(i); result(i - lag).
 `W` / `mask` are read when a launch is issued: call `flush()` before replacing them (mask_fields sweeps).
 
 A screened launch whose certificate failed (include/mfar_hip.h, `any_fail`) is detected in `result()` and redone there
@@ -36,7 +36,7 @@ from mfar.data import index as _index
 
 class PipelinedSearcher:
     def __init__(self, index, W, mask=None, k1: int = 100, k2: int = 100, sentinel: bool = True, query_cond: bool = True,
-                 max_batch: int = 64, group=None, coalesce=None, exchange=None, masks=None):
+                 max_batch: int = 64, group=None, coalesce=None, exchange=None, masks=None, depth=None):
         self.ix, self.W, self.mask = index, W, mask
         # masks [M, F]: a SWEEP of field masks (mask_fields.py:143-170) -- stage 1, the candidate union and stage 2 run once per
         # launch, the mixer once per mask; results then carry a leading mask dimension.  With several ranks the second all-gather
@@ -58,7 +58,17 @@ class PipelinedSearcher:
         import os
         flip = os.environ.get("MFAR_TAIL_PRIORITY", "0") == "1"
         self.main = torch.cuda.Stream(device=self.dev, priority=0 if flip else -1)
-        self.side = torch.cuda.Stream(device=self.dev, priority=-1 if flip else 0)
+        # DEPTH: launches in flight = slots of scratch (include/mfar_hip.h: up to 4).  The wide scan fills the register file, so a
+        # tail only runs in the gaps between scans.  With two slots scan i+2 has to wait for tail i, which scan i+1 kept off the
+        # machine: every gap is as long as one whole tail.  With three (default) the next scan starts as soon as its own sample
+        # pass is through, and the tails of consecutive launches -- on alternating streams -- share the gaps: 50.4 -> 52.0 k q/s at
+        # 1 M x 8, 43.9 -> 47.9 k at 129 k x 22, 159 -> 172 k at the 125 k-row shard; four slots measured below three
+        # (MFAR_PIPE_DEPTH).
+        self.depth = int(depth if depth is not None else os.environ.get("MFAR_PIPE_DEPTH", "3"))
+        if not 2 <= self.depth <= 4:
+            raise ValueError("pipeline depth must be 2, 3 or 4")
+        self.sides = [torch.cuda.Stream(device=self.dev, priority=-1 if flip else 0) for _ in range(2 if self.depth > 2 else 1)]
+        self.side = self.sides[0]
         index.set_repair_mode(True)   # repairs are launched here only after a failure was reported (or when they are frequent)
         self.Qb = int(max_batch)      # queries per submitted batch (at most)
         cap = index.max_split_batch(k1)                       # 128 with the wide screened pass, else 64
@@ -78,14 +88,14 @@ class PipelinedSearcher:
         if coalesce < 1 or coalesce * self.Qb > cap:
             raise ValueError(f"coalesce x max_batch must not exceed {cap} on this index")
         self.coalesce = int(coalesce)
-        self.lag = 2 * self.coalesce - 1
+        self.lag = self.depth * self.coalesce - 1
         self.Qmax = self.Qb * self.coalesce                   # queries per launch
         F, E = index.n_fields, index.dim
         self.n_redone = 0             # launches whose screen certificate failed and that were redone exactly
         self._recent = []             # 1 = redone, over the last 16 checked launches
         self.inline_repair = False    # many failures: let finish() repair on the device instead of reporting (see _check)
         self.slots = []
-        for _ in range(2):
+        for _ in range(self.depth):
             lead = (self.M,) if self.M else ()
             s = dict(q=torch.zeros(self.Qmax, E, device=self.dev),
                      ids=torch.empty(*lead, self.Qmax, k2, dtype=torch.int64, device=self.dev),
@@ -168,12 +178,12 @@ class PipelinedSearcher:
         Q = q.shape[0]
         if Q > self.Qb or (self.sharded and Q != self.Qb):
             raise ValueError("batch size does not fit the pipeline's buffers")
-        slot = self.n_launched & 1
+        slot = self.n_launched % self.depth
         s = self.slots[slot]
         cur = torch.cuda.current_stream(self.dev)
         if not self._pending:
             if not s["checked"]:
-                self._check(self.n_launched - 2)      # the slot's previous launch must be verified before its buffers go
+                self._check(self.n_launched - self.depth)      # the slot's previous launch must be verified before its buffers go
             self.main.wait_event(s["done"])           # the slot's previous tail has finished with these buffers
         self.main.wait_stream(cur)                    # q may have been produced on the caller's stream
         off = sum(p[2] for p in self._pending)
@@ -194,15 +204,16 @@ class PipelinedSearcher:
             self._launch()
 
     def _launch(self):
-        slot = self.n_launched & 1
+        slot = self.n_launched % self.depth
         s = self.slots[slot]
+        side = self.sides[self.n_launched % len(self.sides)]
         Q = sum(p[2] for p in self._pending)
         if self.sharded and Q != self.Qmax:         # fixed payload size: the missing batch repeats the last real query
             with torch.cuda.stream(self.main):       # (an all-zero query cannot be certified -- every row ties at 0 -- and
                 s["q"][Q:].copy_(s["q"][Q - 1:Q].expand(self.Qmax - Q, -1))   # would send the launch through the exact redo)
             Q = self.Qmax
         self._pending = []
-        for tk in [tk for tk, (L, _, _) in self._where.items() if L <= self.n_launched - 2]:
+        for tk in [tk for tk, (L, _, _) in self._where.items() if L <= self.n_launched - self.depth]:
             del self._where[tk]                       # this launch overwrites the results of the slot's previous launch
         s["Q"], s["checked"], s["launch"] = Q, False, self.n_launched
         self.n_launched += 1
@@ -221,8 +232,8 @@ class PipelinedSearcher:
             fid, fsc = self._list_targets(s)
             self.ix.stage1_begin(qk, slot, fid, fsc, self.k1, self.sentinel)
             s["stage1"].record(self.main)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(s["stage1"])
+        with torch.cuda.stream(side):
+            side.wait_event(s["stage1"])
             if self.inline_repair:                    # failed fields are redone by the exact pass inside finish()
                 self.ix.stage1_finish(qk, slot, fid, fsc, self.k1, self.sentinel, any_fail=None)
                 s["fail"].zero_()
@@ -230,13 +241,13 @@ class PipelinedSearcher:
                 self.ix.stage1_finish(qk, slot, fid, fsc, self.k1, self.sentinel, any_fail=s["fail"])
             self._tail(s, slot)
             s["fail_host"].copy_(s["fail"], non_blocking=True)
-            s["done"].record(self.side)
+            s["done"].record(side)
 
     # host side of the certificate: wait for the launch, redo it exactly if its screen could not be proven
     def _check(self, launch: int):
         if launch < 0:
             return
-        slot = launch & 1
+        slot = launch % self.depth
         s = self.slots[slot]
         if s["checked"] or s["launch"] != launch:
             return
@@ -273,10 +284,10 @@ class PipelinedSearcher:
         launch, off, Q = w
         if launch == self.n_launched:                 # still held for coalescing: launch it alone
             self._launch()
-        if launch < self.n_launched - 2:
+        if launch < self.n_launched - self.depth:
             raise ValueError("ticket is no longer in flight")
         self._check(launch)
-        s = self.slots[launch & 1]
+        s = self.slots[launch % self.depth]
         if self.M:      # [M, Q, k2]: the launch's results are laid out densely over its own query count
             QL = s["dense_Q"]
             ids = s["ids"].view(-1)[:self.M * QL * self.k2].view(self.M, QL, self.k2)

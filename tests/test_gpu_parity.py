@@ -1124,7 +1124,7 @@ def test_wide_screen_pass_and_coalescing(idxmod):
         # the pipeline: batches of <= 64 queries, two per launch
         Wd = torch.from_numpy(W).to(dev)
         ps = PipelinedSearcher(ix, Wd, None, max_batch=64)
-        assert ps.coalesce == 2 and ps.lag == 3
+        assert ps.coalesce == 2 and ps.lag == 2 * ps.depth - 1
         cuts = list(range(0, Q, 64)) * 3            # several launches, the last one possibly a single (flushed) batch
         tickets, got = [], []
         for i, c in enumerate(cuts):
