@@ -1125,7 +1125,7 @@ def test_wide_screen_pass_and_coalescing(idxmod):
         Wd = torch.from_numpy(W).to(dev)
         ps = PipelinedSearcher(ix, Wd, None, max_batch=64)
         assert ps.coalesce == 2 and ps.lag == 2 * ps.depth - 1
-        cuts = list(range(0, Q, 64)) * 3            # several launches, the last one possibly a single (flushed) batch
+        cuts = list(range(0, Q, 64)) * 4            # more launches than slots, the last one possibly a single (flushed) batch
         tickets, got = [], []
         for i, c in enumerate(cuts):
             tickets.append(ps.submit(torch.from_numpy(q[c:c + 64]).to(dev)))
