@@ -221,14 +221,20 @@ class PipelinedSearcher:
         self.main.wait_stream(cur)                    # W / mask may have been produced on the caller's stream
         with torch.cuda.stream(self.main):
             qk = s["q"][:Q]
-            s["W"].copy_(self.W)
-            if self.mask is None:
-                s["mask"].fill_(1.0)
-            else:
-                s["mask"].copy_(self.mask.reshape(-1))
-            for t_ in (self.W, self.mask):            # sources allocated on the caller's stream, read on this one
-                if t_ is not None and t_.is_cuda:
-                    t_.record_stream(self.main)
+            # W / mask are snapshotted per slot -- but only when they changed since the slot's last snapshot (same tensor object,
+            # same in-place version counter: the slot keeps a reference, so the address cannot be recycled under it).  Three tiny
+            # copies per launch sat on the scan stream between two scans (~70 us of the ~400 us between them).
+            wkey = (self.W._version, None if self.mask is None else self.mask._version)
+            if s.get("wref") is not self.W or s.get("mref") is not self.mask or s.get("wkey") != wkey:
+                s["W"].copy_(self.W)
+                if self.mask is None:
+                    s["mask"].fill_(1.0)
+                else:
+                    s["mask"].copy_(self.mask.reshape(-1))
+                for t_ in (self.W, self.mask):            # sources allocated on the caller's stream, read on this one
+                    if t_ is not None and t_.is_cuda:
+                        t_.record_stream(self.main)
+                s["wref"], s["mref"], s["wkey"] = self.W, self.mask, wkey
             fid, fsc = self._list_targets(s)
             self.ix.stage1_begin(qk, slot, fid, fsc, self.k1, self.sentinel)
             s["stage1"].record(self.main)
