@@ -483,7 +483,8 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
     static const int sample_div = getenv("MFAR_SAMPLE_DIV") ? std::max(1, atoi(getenv("MFAR_SAMPLE_DIV"))) : 12;
     static const int append_target = getenv("MFAR_APPEND_TARGET") ? std::max(1, atoi(getenv("MFAR_APPEND_TARGET"))) : 130;
     t.k = -1;                                       // invalid until everything below succeeded
-    s1_build_table(g, F, idx->n_cu, k, solo, sample_tiles_max, sample_forced, waves, wgs, sample_div, append_target, t);   // mfar_tables.h
+    static const int group_chunks = getenv("MFAR_MERGE_GROUP") ? std::max(0, atoi(getenv("MFAR_MERGE_GROUP"))) : 0;
+    s1_build_table(g, F, idx->n_cu, k, solo, sample_tiles_max, sample_forced, waves, wgs, sample_div, append_target, t, group_chunks);   // mfar_tables.h
     t.k = -1;
     if (t.two_level) {
         RETCHK(t.d_gchunk.ensure(t.gchunk.size() * sizeof(int)));

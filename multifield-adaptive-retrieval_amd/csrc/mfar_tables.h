@@ -42,8 +42,10 @@ struct S1TableHost {
 //   n_cu    compute units of the device;  wgs  workgroups per CU the grid is sized for
 //   waves   waves per workgroup of the pass: wave blocks published per sampled tile
 //   sample_div / append_target   sample-pass sizing (MFAR_SAMPLE_DIV = 12, MFAR_APPEND_TARGET = 130)
+//   group_chunks   > 0: merge in two levels whenever a field has more chunks than this, in groups of this many chunks -- two
+//                  launches of many small register-resident merges instead of one launch whose workgroups hold 48 keys per thread
 static inline void s1_build_table(const S1GeomHost& g, int F, int n_cu, int k, bool solo, int sample_tiles_max, bool sample_forced,
-                                  int waves, int wgs, int sample_div, int append_target, S1TableHost& t) {
+                                  int waves, int wgs, int sample_div, int append_target, S1TableHost& t, int group_chunks = 0) {
     const long long want = (long long)wgs * n_cu;
     const int cap = std::max(1, std::min(128, (64 * 256) / k));
     long long total_tiles = 0;
@@ -119,7 +121,7 @@ static inline void s1_build_table(const S1GeomHost& g, int F, int n_cu, int k, b
     long long n_chunks = 0;
     for (int f = 0; f < F; ++f) {
         n_chunks += cf[f];
-        if (cf[f] > cap) t.two_level = true;
+        if (cf[f] > cap || (group_chunks > 0 && cf[f] > group_chunks)) t.two_level = true;
         t.max_chunks = std::max(t.max_chunks, cf[f]);
     }
     // tiles per workgroup in the sample pass, per field: more tiles = tighter starting thresholds = fewer appends in the full
@@ -183,7 +185,8 @@ static inline void s1_build_table(const S1GeomHost& g, int F, int n_cu, int k, b
     if (t.two_level) {
         for (int f = 0; f < F; ++f) {
             t.fgroup[f] = (int)t.gfield.size();
-            const int gs = (cf[f] + l2cap - 1) / l2cap;                  // chunks per group (<= cap by construction)
+            int gs = (cf[f] + l2cap - 1) / l2cap;                        // chunks per group (<= cap by construction)
+            if (group_chunks > 0) gs = std::max(gs, std::min(std::min(group_chunks, cap), cf[f]));
             for (int c0 = 0; c0 < cf[f]; c0 += gs) {
                 t.gchunk.push_back(t.fchunk[f] + c0);
                 t.gfield.push_back(f);
