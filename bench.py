@@ -332,7 +332,7 @@ def main():
             ix.set_screen(2)
         if args.stage2 == "full":
             ix.set_stage2_mode(0)
-        # Two-deep pipeline: stage 1 of launch i+1 (main stream) overlaps the tail of launch i (side stream).  Every batch is
+        # Pipeline (mfar/data/pipeline.py, three launches deep): scans back to back on one stream, tails on side streams.  Every batch is
         # still processed completely inside the timed region (the region ends with a full device synchronisation).
         ps = PipelinedSearcher(ix, W, mask, k1=K1, k2=K2, sentinel=True, query_cond=True, max_batch=Q, coalesce=args.coalesce or None,
                                group=lay.group, exchange=True if force_exchange else (lay.exchanges if N > 1 else None))
@@ -516,7 +516,7 @@ def main():
                        "docs": D, "fields": F, "dim": E, "query_batch": Q, "k1": K1, "k2": K2, "timed_queries": args.steps * Q,
                        "parallelism": ("single shard through the exchange path (one-rank RCCL group, diagnostic)" if force_exchange else lay.describe()),
                        "row_shards": lay.R, "replica_groups": lay.G,
-                       "pipeline": (f"2 launches in flight (stage 1 of launch i+1 overlaps the tail of launch i); a launch scans {ps.coalesce} "
+                       "pipeline": (f"{ps.depth} launches in flight (the scans run back to back on one stream, the tails of consecutive launches on alternating streams in the gaps); a launch scans {ps.coalesce} "
                                     f"coalesced batch(es) of {Q} queries" + (" with the wide 128-column screened pass (one fp16 query term)"
                                                                              if ps.Qmax > 64 else "")),
                        "queries_per_launch": ps.Qmax},

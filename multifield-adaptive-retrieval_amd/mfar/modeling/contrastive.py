@@ -433,7 +433,7 @@ class RetrievalTrainingModule(torch.nn.Module):
         was_training = self.training
         self.eval()
         self.on_test_epoch_start()
-        # `lag` batches stay in flight while the next one is tokenised, encoded and submitted (two launches of the pipeline;
+        # `lag` batches stay in flight while the next one is tokenised, encoded and submitted (the launches of the pipeline;
         # with the wide screened pass a launch scans two coalesced batches, mfar/data/pipeline.py)
         pending = deque()
         with torch.no_grad():
