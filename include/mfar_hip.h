@@ -140,7 +140,7 @@ int mfar_search_fused(mfar_index* idx, const float* q, int Q, const float* W, in
 /*
  * Second half of mfar_search_two_stage on its own: union (contrastive.py:678-679) -> stage 2 (:681-683) -> mask, field
  * weights, top-k2 (:685-696), given the stage-1 lists produced by mfar_retrieve_fields.  Device pointers only, nothing
- * synchronises.  `slot` (0/1) selects one of two internal workspaces: with mfar_retrieve_fields(batch i+1) on one stream
+ * synchronises.  `slot` (0 .. 3) selects one of four internal workspaces: with mfar_retrieve_fields(batch i+1) on one stream
  * and mfar_search_stage2(batch i) on another, two batches overlap on the GPU.
  * field_scores [Q, n_fields, k1] (may be NULL) + sentinel: the lists' exact scores and their padding convention, as
  * mfar_retrieve_fields / mfar_stage1_finish wrote them.  When given, a candidate's score in the field whose list it came from is
@@ -214,8 +214,9 @@ int mfar_stream_wait_stage1_start(mfar_index* idx, void* stream);
 
 /*
  * Split-phase stage 1 for pipelined callers (device pointers, Q <= mfar_max_split_batch(), asynchronous on `stream`).
- *   mfar_stage1_begin   query preparation, sample pass, the long scan and the list merge of batch `slot` (two slots,
- *                       0 / 1).  Without the fp16 screen this already leaves the final lists in field_ids / field_scores.
+ *   mfar_stage1_begin   query preparation, sample pass, the long scan and the list merge of batch `slot` (four slots,
+ *                       0 .. 3: a caller keeps as many launches in flight as it uses slots; mfar.data.pipeline uses three).
+ *                       Without the fp16 screen this already leaves the final lists in field_ids / field_scores.
  *   mfar_stage1_finish  with the screen: exact re-scoring of the min(k + 92, 192) screened rows per list and the certificate ->
  *                       field_ids / field_scores [Q, n_fields, k], exactly what mfar_retrieve_fields returns; without:
  *                       nothing.  May run on another stream than begin (the caller orders finish after begin with an
