@@ -88,3 +88,22 @@ def test_python_mirror_keeps_reference_signatures():
     assert list(ps)[:5] == ["encoder", "corpus", "batch_size", "multiprocess", "show_progress"]
     assert list(ps)[5:] == ["as_tensor"] and ps["as_tensor"].default is False
     assert inspect.isabstract(Index)
+
+
+def test_bench_spawns_its_ranks_and_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` with no launcher starts two child ranks (RANK / WORLD_SIZE / MASTER_* in their environment) before
+    anything touches the GPU and relays rank 0's line.  In this container there is no GPU: both ranks fail, the parent must exit
+    non-zero, print NO result line and leave no process behind (the GPU half is tests/test_gpu_multirank.py)."""
+    import subprocess
+    import sys
+    from mfar import _native
+    if _native.device_count() > 0:
+        pytest.skip("GPU present: covered by tests/test_gpu_multirank.py")
+    env = dict(os.environ, MFAR_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--docs", "20000", "--fields", "2", "--dim", "64",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra-legs"], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "rank" in out.stderr and "exited with code" in out.stderr
