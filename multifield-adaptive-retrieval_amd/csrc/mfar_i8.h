@@ -134,8 +134,6 @@ __device__ __forceinline__ void s1_body_i8w(const S1Params& p, const int chunk_i
         for (int s0 = 0; s0 < n_pairs; s0 += X::U) {
 #pragma unroll
             for (int u = 0; u < X::U; ++u) {
-                constexpr int dummy = 0;
-                (void)dummy;
                 // the stage's query pieces landed (own pieces: counted wait -- the RQ - 2 younger stages may stay in flight; the other
                 // waves' pieces: the barrier); its doc registers were loaded before those pieces
                 asm volatile("s_waitcnt vmcnt(%2)\n\ts_barrier" : "+v"(dr0[u % R]), "+v"(dr1[u % R]) : "n"((RQ - 2) * X::LOADS) : "memory");
