@@ -45,7 +45,7 @@ typedef struct mfar_index mfar_index;
 
 /* library / device probes (no reference counterpart).  mfar_version() == MFAR_ABI_VERSION of the header the caller was built
  * against, or the caller must refuse the library: the value changes with every signature change. */
-#define MFAR_ABI_VERSION 103
+#define MFAR_ABI_VERSION 104
 int mfar_version(void);
 const char* mfar_last_error(void);
 int mfar_device_count(int* n_out);
@@ -312,21 +312,6 @@ int mfar_screen_field_info(mfar_index* idx, int field, int64_t* n_unique_rows, i
 int mfar_set_stage2_mode(mfar_index* idx, int mode);
 int mfar_stage2_stats(mfar_index* idx, int* two_level_available, int64_t* gather_slab_bytes, int64_t* n_candidates,
                       int64_t* n_survivors);
-
-/*
- * int8 FIRST LEVEL under the wide screened pass (no reference counterpart; outputs bit-identical with and without it;
- * csrc/mfar_i8.h).  The fp16 screen of an fp32 index is bound by its bytes: this level scans ONE byte per element (a third copy of
- * the unique rows, +25 % of the fp32 slab), keeps per (query, field) a certified superset of the rows that can reach the top-k
- * (interval test with a rigorous quantisation bound), and the fp16 level then gathers only those rows from the gather slab.
- * Everything behind it -- k' best approximate scores, exact re-scoring, certificate, repair -- is the screen's own path.
- *   mode   0 = off (default), 1 = on for blocks of more than 64 queries of an fp32 index whose screen and gather slab are
- *          current (dim a multiple of 128, at most MFAR_MAX_FIELDS / 2 fields); environment default: MFAR_SCREEN_I8.
- * mfar_i8_stats synchronises the device: lists filtered / rows appended by the scan / rows handed to the fp16 level / lists sent
- * to the exact repair pass since the slab was built, rows in the coarse segment, largest residual norm in quantisation steps.
- */
-int mfar_set_i8(mfar_index* idx, int mode);
-int mfar_i8_stats(mfar_index* idx, int* built, int64_t* slab_bytes, int64_t* n_lists, int64_t* n_appended, int64_t* n_survivors,
-                  int64_t* n_failed, int64_t* seg1_rows, float* max_err_rel);
 
 #ifdef __cplusplus
 }

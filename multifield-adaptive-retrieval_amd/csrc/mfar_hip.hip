@@ -15,7 +15,6 @@
 #include "mfar_hip.h"
 #include "mfar_select.h"
 #include "mfar_screen.h"
-#include "mfar_i8.h"
 
 #define MFAR_VERSION MFAR_ABI_VERSION   /* include/mfar_hip.h: bumped on EVERY signature change; mfar/_native.py refuses any other value */
 #define PAYLOAD_MAGIC 0x6d464152 /* "mFAR" */
@@ -109,8 +108,6 @@ struct mfar_index {
     struct S1Slot {
         DevBuf qt, lists, list_cnt, gtau, samp, lists2, list_cnt2;      // any pass (lists2: group lists of a two-level merge)
         DevBuf qt16, qinfo, eps, base, fail, sids, ssc, scnt, sx;        // fp16 screen
-        DevBuf vk8, eps8, s8ids, s8a, s8cnt;                             // int8 first level (mfar_i8.h)
-        bool i8 = false;                                                // the batch's wide pass runs on the int8 slab
         bool screened = false;                                          // decided by the begin phase of the batch
         int qw = 64;                                                    // query columns of the batch's pass (128: wide screen pass)
     } s1[MFAR_SLOTS];
@@ -144,17 +141,6 @@ struct mfar_index {
     bool wide = true;             // blocks of 65 .. 128 queries go through the wide screened pass (MFAR_WIDE=0: always 64 per pass)
     bool repair_sample = false;   // mfar_set_repair_mode: repairs run their own sample pass (see stage1_pass)
     S1Geom geom_docs, geom_screen;
-    // int8 first level under the wide screened pass (mfar_i8.h): 0 off, 1 on when the shapes allow (mfar_set_i8 / MFAR_SCREEN_I8)
-    int i8_mode = 0;
-    float i8_pct = 0.98f;         // rows whose largest |value| lies above this quantile of the field go to segment 1 (MFAR_I8_PCT)
-    DevBuf slab8;                 // int8 tiled slab of the 2 F pseudo-fields (per-field bases: geom_i8, BYTES)
-    size_t slab8_used = 0;
-    bool i8_ok = false;           // slab8 describes the screen slab as it is now
-    bool i8_dirty = true;         // the screen was rebuilt since
-    bool i8_nomem = false;
-    DevBuf i8_fields, i8_map, i8_stats;   // I8Field[2 F]; map8 [F][n_rows]; counters [4]
-    std::vector<I8Field> i8_host;
-    S1Geom geom_i8;
     // fused mode (mfar_search_fused): a one-field companion index of dim F * E over the same rows, built on first use
     mfar_index* fused = nullptr;
     bool fused_dirty = true;      // rows were written since the companion was filled
@@ -200,10 +186,6 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW4_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW4_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_i8w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1IW_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_i8w_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1IW_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_i8w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1IW_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_i8w4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1IW_LDS_BYTES));
     g_attr_done[device] = true;
     return MFAR_OK;
 }
@@ -258,8 +240,6 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     if (const char* e = getenv("MFAR_SCREEN_DEDUP")) idx->screen_dedup = atoi(e) != 0;
     if (const char* e = getenv("MFAR_WIDE")) idx->wide = atoi(e) != 0;
     if (const char* e = getenv("MFAR_STAGE2_PRUNE")) idx->stage2_mode = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("MFAR_SCREEN_I8")) idx->i8_mode = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("MFAR_I8_PCT")) idx->i8_pct = std::min(1.0f, std::max(0.5f, (float)atof(e)));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) idx->n_cu = prop.multiProcessorCount;
     hipError_t e = hipMalloc(&idx->slab, idx->slab_bytes);
@@ -294,13 +274,12 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
     DevBuf* bufs[] = {&idx->fid, &idx->fsc, &idx->s_stats, &idx->s_field, &idx->s_mean, &idx->screen, &idx->u_rep, &idx->u_start,
-                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->s2stats, &idx->slab8, &idx->i8_fields, &idx->i8_map,
-                      &idx->i8_stats};
+                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->s2stats};
     for (int i = 0; i < MFAR_SLOTS; ++i)
         for (DevBuf* b : {&idx->cand[i], &idx->ncand[i], &idx->x[i], &idx->own[i], &idx->xa[i], &idx->cand2[i], &idx->ncand2[i], &idx->s2qm[i],
                           &idx->s2eps[i], &idx->kmask[i], &idx->src2[i]})
             b->release();
-    for (S1Geom* g : {&idx->geom_docs, &idx->geom_screen, &idx->geom_i8})
+    for (S1Geom* g : {&idx->geom_docs, &idx->geom_screen})
         for (S1Table* t : {&g->all, &g->solo, &g->all_w, &g->solo_w}) {
             t->d_chunks.release();
             t->d_fchunk.release();
@@ -312,7 +291,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     for (DevBuf* b : bufs) b->release();
     for (auto& sl : idx->s1) {
         DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.lists2, &sl.list_cnt2, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
-                        &sl.ssc, &sl.scnt, &sl.sx, &sl.vk8, &sl.eps8, &sl.s8ids, &sl.s8a, &sl.s8cnt};
+                        &sl.ssc, &sl.scnt, &sl.sx};
         for (DevBuf* b : sb) b->release();
     }
     for (auto& b : idx->in) b.release();
@@ -497,17 +476,16 @@ static int check_search_common(const mfar_index* idx, const float* q, int Q, int
 // merge holds n_chunks * k keys of one field, which caps the chunks of a field.
 //   waves   waves per workgroup of the pass (4; 8 for the wide pass): wave blocks published per sampled tile
 //   wgs     workgroups per CU the grid is sized for
-static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool solo, int sample_tiles_max, bool sample_forced, int waves, int wgs, hipStream_t st,
-                       int n_fields = 0, const std::vector<char>* light = nullptr, int sample_div_arg = 0) {
+static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool solo, int sample_tiles_max, bool sample_forced, int waves, int wgs, hipStream_t st) {
     if (t.k == k && t.wgs == wgs) return MFAR_OK;
     if (t.k >= 0) HIPCHK(hipDeviceSynchronize());   // a launch in flight may still read the old table
-    const int F = n_fields > 0 ? n_fields : idx->F;   // (the int8 slab holds 2 F pseudo-fields)
+    const int F = idx->F;
     static const int sample_div = getenv("MFAR_SAMPLE_DIV") ? std::max(1, atoi(getenv("MFAR_SAMPLE_DIV"))) : 12;
     static const int append_target = getenv("MFAR_APPEND_TARGET") ? std::max(1, atoi(getenv("MFAR_APPEND_TARGET"))) : 130;
     t.k = -1;                                       // invalid until everything below succeeded
     static const int group_chunks = getenv("MFAR_MERGE_GROUP") ? std::max(0, atoi(getenv("MFAR_MERGE_GROUP"))) : 0;
-    s1_build_table(g, F, idx->n_cu, k, solo, sample_tiles_max, sample_forced, waves, wgs, sample_div_arg > 0 ? sample_div_arg : sample_div, append_target, t,
-                   group_chunks, light);   // mfar_tables.h
+    s1_build_table(g, F, idx->n_cu, k, solo, sample_tiles_max, sample_forced, waves, wgs, sample_div, append_target, t,
+                   group_chunks);   // mfar_tables.h
     t.k = -1;
     if (t.two_level) {
         RETCHK(t.d_gchunk.ensure(t.gchunk.size() * sizeof(int)));
@@ -1029,344 +1007,12 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
         idx->gslab_ok = true;
     }
     idx->screen_dirty = false;
-    idx->i8_dirty = true;
     *ok = true;
     return MFAR_OK;
 }
 
 // the wide pass exists as 6-slot and 4-slot register-ring kernels: the k-steps must divide into one of them
 static bool wide_ok(const mfar_index* idx) { return idx->wide && (idx->n_steps % 6 == 0 || idx->n_steps % 4 == 0); }
-
-
-// ------------------------------------------------------------------------------------------------ int8 first level (mfar_i8.h)
-// doc-ring depth of the int8 pass for this dim (pair stages; the loop is unrolled lcm(ring, 4) times), 0 = no such kernel
-static int i8_ring(const mfar_index* idx) {
-    if (idx->n_steps & 1) return 0;
-    const int np = idx->n_steps >> 1;
-    return np % 12 == 0 ? 6 : (np % 4 == 0 ? 4 : 0);
-}
-static bool i8_wanted(const mfar_index* idx) {
-    return idx->i8_mode != 0 && !idx->i8_nomem && idx->dtype == MFAR_DTYPE_F32 && wide_ok(idx) && i8_ring(idx) != 0 && idx->gslab_ok &&
-           2 * idx->F <= MFAR_MAX_FIELDS && idx->n_rows >= 16384;
-}
-// (re)build the int8 slab from the screen slab.  *ok = false: not available (allocation failed, non-finite rows) -> the wide pass stays on fp16.
-static int ensure_i8(mfar_index* idx, hipStream_t st, bool* ok) {
-    *ok = false;
-    if (!idx->i8_dirty) {
-        *ok = idx->i8_ok;
-        return MFAR_OK;
-    }
-    HIPCHK(hipDeviceSynchronize());
-    idx->i8_ok = false;
-    idx->i8_dirty = false;
-    const int F = idx->F, F8 = 2 * F;
-    const long long n = idx->n_rows;
-    auto nomem = [&]() {
-        (void)hipGetLastError();
-        g_err.clear();
-        idx->i8_nomem = true;
-        idx->slab8.release();
-        idx->i8_map.release();
-        return MFAR_OK;
-    };
-    if (idx->i8_map.ensure((size_t)F * n * 4) != MFAR_OK || idx->i8_fields.ensure((size_t)F8 * sizeof(I8Field)) != MFAR_OK ||
-        idx->i8_stats.ensure(4 * sizeof(int)) != MFAR_OK)
-        return nomem();
-    HIPCHK(hipMemsetAsync(idx->i8_stats.p, 0, 4 * sizeof(int), st));
-    DevBuf rmax, sorted, flag, ex, tmp, err2;
-    int nu_max = 1;
-    for (int f = 0; f < F; ++f) nu_max = std::max(nu_max, idx->n_unique[f]);
-    if (rmax.ensure((size_t)nu_max * 4) != MFAR_OK || sorted.ensure((size_t)nu_max * 4) != MFAR_OK || flag.ensure((size_t)nu_max * 4) != MFAR_OK ||
-        ex.ensure((size_t)nu_max * 4) != MFAR_OK || err2.ensure((size_t)F8 * 4) != MFAR_OK) {
-        for (DevBuf* b : {&rmax, &sorted, &flag, &ex, &err2}) b->release();
-        return nomem();
-    }
-    auto free_tmp = [&]() {
-        for (DevBuf* b : {&rmax, &sorted, &flag, &ex, &tmp, &err2}) b->release();
-    };
-    size_t need = 0, need2 = 0;
-    HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, need, rmax.as<u32>(), sorted.as<u32>(), nu_max, 0, 32, st));
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, need2, flag.as<u32>(), ex.as<u32>(), nu_max, st));
-    if (tmp.ensure(std::max(need, need2) + 256) != MFAR_OK) {
-        free_tmp();
-        return nomem();
-    }
-    idx->i8_host.assign(F8, I8Field{});
-    const S1Geom& gs = idx->geom_screen;
-    for (int f = 0; f < F; ++f) {
-        const int nu = idx->n_unique[f];
-        I8Field a = {}, b = {};
-        a.lam = b.lam = a.inv_lam = b.inv_lam = a.ratio = b.ratio = 1.0f;
-        a.n_rows = nu;
-        if (nu > 0) {
-            const _Float16* scr = (const _Float16*)idx->screen.p + gs.base[f];
-            mfar_i8_rowmax_kernel<<<dim3((unsigned)((nu + 63) / 64)), dim3(256), 0, st>>>(scr, idx->n_steps, nu, rmax.as<float>());
-            HIPCHK(hipGetLastError());
-            size_t cap = tmp.cap;
-            HIPCHK(hipcub::DeviceRadixSort::SortKeys(tmp.p, cap, rmax.as<u32>(), sorted.as<u32>(), nu, 0, 32, st));   // non-negative floats order like their bits
-            const long long ip = nu < 4096 ? nu - 1 : std::min<long long>(nu - 1, (long long)((double)idx->i8_pct * nu));
-            float v[2] = {0.0f, 0.0f};
-            HIPCHK(hipMemcpyAsync(&v[0], sorted.as<float>() + ip, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(&v[1], sorted.as<float>() + (nu - 1), 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            if (!std::isfinite(v[0]) || !std::isfinite(v[1])) {    // a non-finite row: no int8 level for this index
-                free_tmp();
-                return MFAR_OK;
-            }
-            const float cap0 = v[0], mx = v[1];
-            mfar_i8_flag_kernel<<<dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st>>>(rmax.as<float>(), nu, cap0, flag.as<u32>());
-            HIPCHK(hipGetLastError());
-            cap = tmp.cap;
-            HIPCHK(hipcub::DeviceScan::ExclusiveSum(tmp.p, cap, flag.as<u32>(), ex.as<u32>(), nu, st));
-            u32 tail[2] = {0, 0};
-            HIPCHK(hipMemcpyAsync(&tail[0], ex.as<u32>() + (nu - 1), 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(&tail[1], flag.as<u32>() + (nu - 1), 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            const int n1 = (int)(tail[0] + tail[1]), n0 = nu - n1;
-            mfar_i8_map_kernel<<<dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st>>>(flag.as<u32>(), ex.as<u32>(), nu, n0,
-                                                                                        idx->i8_map.as<int>() + (size_t)f * n);
-            HIPCHK(hipGetLastError());
-            a.lam = cap0 > 0.0f ? cap0 / 127.0f : 1.0f;
-            b.lam = mx > 0.0f ? mx / 127.0f : 1.0f;
-            a.inv_lam = 1.0f / a.lam;
-            b.inv_lam = 1.0f / b.lam;
-            b.ratio = b.lam / a.lam;
-            a.n_rows = n0;
-            b.seg_base = n0;
-            b.n_rows = n1;
-        }
-        idx->i8_host[2 * f] = a;
-        idx->i8_host[2 * f + 1] = b;
-    }
-    // geometry of the int8 slab: 2 F pseudo-fields, each padded to whole 256-row tiles; bases in BYTES
-    S1Geom& g = idx->geom_i8;
-    g.reset(F8);
-    long long total = 0;
-    for (int pf = 0; pf < F8; ++pf) {
-        long long blk = ((long long)idx->i8_host[pf].n_rows + 63) / 64;
-        blk = std::max(4LL, ((blk + 3) / 4) * 4);
-        g.n_rows[pf] = idx->i8_host[pf].n_rows;
-        g.base[pf] = total;
-        g.n_tiles[pf] = (int)(blk / 4);
-        total += blk * 64 * idx->E;
-    }
-    if (idx->slab8.ensure((size_t)total) != MFAR_OK) {
-        free_tmp();
-        return nomem();
-    }
-    idx->slab8_used = (size_t)total;
-    HIPCHK(hipMemcpyAsync(idx->i8_fields.p, idx->i8_host.data(), (size_t)F8 * sizeof(I8Field), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(err2.p, 0, (size_t)F8 * 4, st));
-    for (int pf = 0; pf < F8; ++pf) {
-        const int f = pf >> 1;
-        const _Float16* scr = (const _Float16*)idx->screen.p + gs.base[f];
-        mfar_i8_quant_kernel<<<dim3((unsigned)(g.n_tiles[pf] * 8)), dim3(256), 0, st>>>(
-            scr, idx->n_steps, idx->i8_map.as<int>() + (size_t)f * n + idx->i8_host[pf].seg_base, idx->i8_host[pf].n_rows, idx->i8_host[pf].lam,
-            (unsigned char*)idx->slab8.p + g.base[pf], err2.as<u32>() + pf);
-        HIPCHK(hipGetLastError());
-    }
-    mfar_i8_fields_kernel<<<dim3(1), dim3(64), 0, st>>>(idx->i8_fields.as<I8Field>(), err2.as<u32>(), F8, idx->E);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(idx->i8_host.data(), idx->i8_fields.p, (size_t)F8 * sizeof(I8Field), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    free_tmp();
-    bool fin = true;
-    for (int pf = 0; pf < F8; ++pf) fin = fin && std::isfinite(idx->i8_host[pf].err);
-    idx->i8_ok = fin;
-    *ok = fin;
-    return MFAR_OK;
-}
-
-static int launch_i8(int ring, bool sample, unsigned grid, hipStream_t st, const S1Params& p) {
-    const dim3 g(grid), b(S1_THREADS);
-    if (ring == 6) {
-        if (sample) mfar_stage1_i8w_sample_kernel<<<g, b, S1IW_LDS_BYTES, st>>>(p);
-        else mfar_stage1_i8w_kernel<<<g, b, S1IW_LDS_BYTES, st>>>(p);
-    } else {
-        if (sample) mfar_stage1_i8w4_sample_kernel<<<g, b, S1IW_LDS_BYTES, st>>>(p);
-        else mfar_stage1_i8w4_kernel<<<g, b, S1IW_LDS_BYTES, st>>>(p);
-    }
-    HIPCHK(hipGetLastError());
-    return MFAR_OK;
-}
-
-// The wide screened pass of one block of up to 128 queries over ALL fields through the int8 first level: sample pass + thresholds
-// (S1_PREPARE), the int8 scan (S1_SCAN), filter -> fp16 row gathers -> the k' best per list in the screen's format (S1_FINISH:
-// sl.sids / sl.ssc / sl.scnt, what stage1_pass's merge leaves there for the fp16 pass).
-static int stage1_pass_i8(mfar_index* idx, mfar_index::S1Slot& sl, int phases, const float* q_block, int qt_n, int k, int kp, hipStream_t st) {
-    const int F = idx->F, F8 = 2 * F, qw = 128, ring = i8_ring(idx);
-    S1Geom& geom = idx->geom_i8;
-    S1Table& tb = geom.all_w;
-    static const int sample_tiles_env = getenv("MFAR_I8_SAMPLE_TILES") ? atoi(getenv("MFAR_I8_SAMPLE_TILES")) : 0;
-    // a deeper sample than the fp16 pass's (about the same bytes): the thresholds sit 2 eps8 below the sample's k-th best, and a chunk list
-    // that passes the trigger is closed, not compacted.  The coarse segments take their thresholds from the fine ones.
-    std::vector<char> light(F8, 0);
-    for (int pf = 1; pf < F8; pf += 2) light[pf] = 1;
-    RETCHK(build_table(idx, geom, tb, kp, false, sample_tiles_env > 0 ? sample_tiles_env : 6, sample_tiles_env > 0, 4, idx->wgs_per_cu, st, F8, &light, 8));
-    if (phases & S1_PREPARE) {     // shapes the level does not serve (decided once per batch): back to the fp16 pass
-        if (tb.max_chunks * 2 > I8_MAX_CHUNKS || 2 * tb.samp_stride > 4096) {
-            sl.i8 = false;
-            return MFAR_OK;
-        }
-    }
-    RETCHK(sl.lists.ensure((size_t)tb.n_chunks * qw * S1_CAP * sizeof(uint2)));
-    RETCHK(sl.list_cnt.ensure((size_t)tb.n_chunks * qw * sizeof(int)));
-    RETCHK(sl.gtau.ensure((size_t)F8 * qw * sizeof(float)));
-    RETCHK(sl.vk8.ensure((size_t)F8 * qw * sizeof(float)));
-    RETCHK(sl.eps8.ensure((size_t)F8 * qw * sizeof(float)));
-    RETCHK(sl.s8ids.ensure((size_t)qw * F * I8_CAP * 8));
-    RETCHK(sl.s8a.ensure((size_t)qw * F * I8_CAP * 4));
-    RETCHK(sl.s8cnt.ensure((size_t)qw * F * 4));
-    S1Params p = {};
-    p.slab = idx->slab8.p;
-    p.qt = sl.qt16.p;
-    p.lists = sl.lists.as<uint2>();
-    p.list_cnt = sl.list_cnt.as<int>();
-    p.chunks = tb.d_chunks.as<S1Chunk>();
-    p.chunk0 = 0;
-    p.n_launch = tb.n_chunks;
-    p.n_steps = idx->n_steps;
-    p.Q = qt_n;
-    p.qw = qw;
-    p.k = 0;                       // no compaction: lists that pass the trigger are closed (mfar_stage1.h s1_epilogue_finish<., true>)
-    p.tau0 = -INFINITY;
-    p.gtau = nullptr;
-    p.samp_stride = tb.samp_stride;
-    {
-        const char* dbg = getenv("MFAR_S1_DEBUG");
-        p.dbg = dbg ? atoi(dbg) : 0;
-    }
-    const unsigned grid = (unsigned)tb.n_chunks;
-    if (phases & S1_PREPARE) {
-        S1Params ps = p;
-        ps.sample = 2;
-        RETCHK(sl.samp.ensure((size_t)F8 * tb.samp_stride * 2 * qw * sizeof(float)));
-        ps.samp_out = sl.samp.as<float>();
-        RETCHK(launch_i8(ring, true, grid, st, ps));
-        const dim3 tg((qw * F8 + 3) / 4), tb_(256);
-        const int* sn = tb.d_samp_n.as<int>();
-        float* vk = sl.vk8.as<float>();
-        if (2 * tb.samp_stride <= 512) mfar_sample_tau_kernel<8><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, 0, F8, k, -INFINITY, nullptr, vk, qw);
-        else if (2 * tb.samp_stride <= 1024) mfar_sample_tau_kernel<16><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, 0, F8, k, -INFINITY, nullptr, vk, qw);
-        else if (2 * tb.samp_stride <= 2048) mfar_sample_tau_kernel<32><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, 0, F8, k, -INFINITY, nullptr, vk, qw);
-        else mfar_sample_tau_kernel<64><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, 0, F8, k, -INFINITY, nullptr, vk, qw);
-        HIPCHK(hipGetLastError());
-        mfar_i8_prep_kernel<<<dim3((unsigned)((F8 * qw + 255) / 256)), dim3(256), 0, st>>>(sl.eps.as<float>(), sl.qinfo.as<ScreenQuery>(),
-                                                                                        idx->s_field.as<ScreenField>(), idx->i8_fields.as<I8Field>(), vk,
-                                                                                        sl.eps8.as<float>(), sl.gtau.as<float>(), F, qw, idx->E);
-        HIPCHK(hipGetLastError());
-    }
-    p.gtau = sl.gtau.as<float>();
-    hipEvent_t e1 = nullptr;
-    if (phases & S1_SCAN) {
-        if (idx->timing && idx->ev_n < 4096) {
-            if ((int)idx->ev.size() < 2 * (idx->ev_n + 1)) {
-                hipEvent_t a, b;
-                HIPCHK(hipEventCreate(&a));
-                HIPCHK(hipEventCreate(&b));
-                idx->ev.push_back(a);
-                idx->ev.push_back(b);
-            }
-            hipEvent_t e0 = idx->ev[2 * idx->ev_n];
-            e1 = idx->ev[2 * idx->ev_n + 1];
-            idx->ev_n++;
-            HIPCHK(hipEventRecord(e0, st));
-        }
-        if (!idx->mid_ev) HIPCHK(hipEventCreateWithFlags(&idx->mid_ev, hipEventDisableTiming));
-        HIPCHK(hipEventRecord(idx->mid_ev, st));
-        RETCHK(launch_i8(ring, false, grid, st, p));
-        if (e1) HIPCHK(hipEventRecord(e1, st));
-    }
-    if (phases & S1_FINISH) {
-        I8FilterParams fp = {};
-        fp.lists = p.lists;
-        fp.list_cnt = p.list_cnt;
-        fp.fchunk = tb.d_fchunk.as<int>();
-        fp.fl = idx->i8_fields.as<I8Field>();
-        fp.epsA = sl.eps8.as<float>();
-        fp.map8 = idx->i8_map.as<int>();
-        fp.ustride = idx->n_rows;
-        fp.out_ids = sl.s8ids.as<long long>();
-        fp.out_cnt = sl.s8cnt.as<int>();
-        fp.fail = sl.fail.as<int>();
-        fp.stats = idx->i8_stats.as<int>();
-        fp.f0 = 0;
-        fp.nf = F;
-        fp.k = k;
-        fp.qw = qw;
-        mfar_i8_filter_kernel<64><<<dim3(qt_n * F), dim3(256), 0, st>>>(fp);
-        HIPCHK(hipGetLastError());
-        static const bool i8_debug = getenv("MFAR_I8_DEBUG") != nullptr;
-        if (i8_debug) {   // diagnostics (synchronises): what the scan appended, per chunk list and per (query, field)
-            std::vector<int> lc((size_t)tb.n_chunks * qw), sc((size_t)qt_n * F);
-            std::vector<float> tgv((size_t)F8 * qw), ev((size_t)F8 * qw), vkv((size_t)F8 * qw);
-            HIPCHK(hipMemcpyAsync(lc.data(), p.list_cnt, lc.size() * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(sc.data(), sl.s8cnt.p, sc.size() * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(tgv.data(), sl.gtau.p, tgv.size() * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(ev.data(), sl.eps8.p, ev.size() * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(vkv.data(), sl.vk8.p, vkv.size() * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            long long closed = 0, tot = 0;
-            int mx = 0;
-            for (int c = 0; c < tb.n_chunks; ++c)
-                for (int qq = 0; qq < qt_n; ++qq) {
-                    const int v = lc[(size_t)c * qw + qq];
-                    if (v < 0) ++closed;
-                    else {
-                        tot += v;
-                        mx = std::max(mx, v);
-                    }
-                }
-            long long surv = 0;
-            for (int v : sc) surv += v;
-            fprintf(stderr, "[mfar i8] chunks=%d (max per pseudo-field %d) lists=%d closed=%lld appended/(q,f)=%.0f max chunk list=%d survivors/(q,f)=%.0f\n", tb.n_chunks,
-                    tb.max_chunks, qt_n * F, closed, (double)tot / (qt_n * F), mx, (double)surv / (qt_n * F));
-            for (int pf = 0; pf < std::min(F8, 4); ++pf)
-                fprintf(stderr, "[mfar i8]   pf=%d rows=%d lam=%.4g err=%.4g chunks=%d ns=%d | q0: vk=%.6g tg=%.6g eps=%.6g\n", pf, idx->i8_host[pf].n_rows,
-                        idx->i8_host[pf].lam, idx->i8_host[pf].err, tb.fchunk[pf + 1] - tb.fchunk[pf], tb.chunks[tb.fchunk[pf]].ns, vkv[(size_t)pf * qw],
-                        tgv[(size_t)pf * qw], ev[(size_t)pf * qw]);
-        }
-        ScoreParams sp = {};
-        sp.slab = idx->slab;
-        sp.field_stride = idx->field_stride;
-        sp.q = q_block;
-        sp.cand = sl.s8ids.as<long long>();
-        sp.n_cand = nullptr;
-        sp.n_cand_pf = sl.s8cnt.as<int>();
-        sp.out = sl.s8a.as<float>();
-        sp.row_offset = idx->row_offset;
-        sp.n_rows = (int)idx->n_rows;
-        sp.n_steps = idx->n_steps;
-        sp.E = idx->E;
-        sp.F = F;
-        sp.C = I8_CAP;
-        sp.per_field = 1;
-        sp.urep = idx->u_rep.as<int>();
-        sp.nuniq = idx->u_n.as<int>();
-        sp.ustride = idx->n_rows;
-        sp.f0 = 0;
-        sp.gslab = idx->gslab.p;
-        sp.g_row_bytes = (long long)idx->g_row_bytes;
-        sp.sfld = idx->s_field.as<ScreenField>();
-        sp.qm = nullptr;
-        static_assert(I8_CAP % SCF_THREADS == 0, "a block of the row gather must lie inside one list");
-        mfar_score_rows_kernel<SRC_F16G><<<dim3((unsigned)(I8_CAP * F / SCF_THREADS), qt_n), dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(sp);
-        HIPCHK(hipGetLastError());
-        I8SelectParams se = {};
-        se.ids = sl.s8ids.as<long long>();
-        se.a16 = sl.s8a.as<float>();
-        se.cnt = sl.s8cnt.as<int>();
-        se.qinfo = sl.qinfo.as<ScreenQuery>();
-        se.sid = sl.sids.as<long long>();
-        se.ssc = sl.ssc.as<float>();
-        se.scnt = sl.scnt.as<int>();
-        se.nf = F;
-        se.kp = kp;
-        mfar_i8_select_kernel<<<dim3(qt_n * F), dim3(256), 0, st>>>(se);
-        HIPCHK(hipGetLastError());
-    }
-    return MFAR_OK;
-}
 
 // One block of queries (rows q0 .. of q) through stage 1 for fields [f0, f0 + nf): 64 per block, or up to 128 when the
 // wide screened pass applies (more than 64 queries left, screen available).  all pointers are device pointers; fid/fsc are
@@ -1384,8 +1030,6 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         if (screen_wanted(idx, k)) RETCHK(ensure_screen(idx, st, &screened));
         sl.screened = screened;
         sl.qw = (screened && wide_ok(idx) && Q - q0 > 64) ? 128 : 64;
-        sl.i8 = false;
-        if (sl.qw == 128 && f0 == 0 && nf == idx->F && i8_wanted(idx)) RETCHK(ensure_i8(idx, st, &sl.i8));
     }
     const int qw = sl.qw;
     const int qt_n = std::min(qw, Q - q0);
@@ -1429,10 +1073,8 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         HIPCHK(hipGetLastError());
     }
     const S1Out so = {sl.sids.as<long long>(), sl.ssc.as<float>(), sl.scnt.as<int>(), 0, 0, 0};   // lists of unique-row numbers
-    if (sl.i8) RETCHK(stage1_pass_i8(idx, sl, phases, q + (size_t)q0 * idx->E, qt_n, k, kp, st));
-    if (!sl.i8)
-        RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, phases, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
-                           sl.base.as<float>(), nullptr, true, so, st));
+    RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, phases, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
+                       sl.base.as<float>(), nullptr, true, so, st));
     if (!(phases & S1_CERTIFY)) return MFAR_OK;
     // 2. exact scores of those unique rows' representatives (the contract's fma chain over the fp32 slab)
     ScoreParams sp = {};
@@ -1625,37 +1267,6 @@ extern "C" int mfar_stage2_stats(mfar_index* idx, int* two_level_available, int6
     return MFAR_OK;
 }
 
-extern "C" int mfar_set_i8(mfar_index* idx, int mode) {
-    if (!idx || mode < 0 || mode > 1) return fail(MFAR_ERR_INVALID, "i8 mode must be 0 or 1");
-    HIPCHK(hipSetDevice(idx->device));
-    HIPCHK(hipDeviceSynchronize());
-    idx->i8_mode = mode;
-    return MFAR_OK;
-}
-extern "C" int mfar_i8_stats(mfar_index* idx, int* built, int64_t* slab_bytes, int64_t* n_lists, int64_t* n_appended, int64_t* n_survivors,
-                             int64_t* n_failed, int64_t* seg1_rows, float* max_err_rel) {
-    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
-    HIPCHK(hipSetDevice(idx->device));
-    HIPCHK(hipDeviceSynchronize());
-    int c[4] = {0, 0, 0, 0};
-    if (idx->i8_stats.p) HIPCHK(hipMemcpy(c, idx->i8_stats.p, sizeof(c), hipMemcpyDeviceToHost));
-    if (built) *built = idx->i8_ok ? 1 : 0;
-    if (slab_bytes) *slab_bytes = idx->i8_ok ? (int64_t)idx->slab8_used : 0;
-    if (n_lists) *n_lists = c[0];
-    if (n_appended) *n_appended = c[1];
-    if (n_survivors) *n_survivors = c[2];
-    if (n_failed) *n_failed = c[3];
-    long long s1 = 0;
-    float er = 0.0f;
-    if (idx->i8_ok)
-        for (int pf = 0; pf < 2 * idx->F; ++pf) {
-            if (pf & 1) s1 += idx->i8_host[pf].n_rows;
-            if (idx->i8_host[pf].n_rows > 0) er = std::max(er, idx->i8_host[pf].err / std::max(idx->i8_host[pf].lam, 1e-30f));   // residual norm in quantisation steps
-        }
-    if (seg1_rows) *seg1_rows = s1;
-    if (max_err_rel) *max_err_rel = er;
-    return MFAR_OK;
-}
 extern "C" int mfar_set_screen(mfar_index* idx, int mode, float eps_mult) {
     if (!idx || mode < 0 || mode > 2 || !(eps_mult >= 0.0f)) return fail(MFAR_ERR_INVALID, "mode must be 0, 1 or 2 and eps_mult >= 0");
     idx->screen_mode = mode;

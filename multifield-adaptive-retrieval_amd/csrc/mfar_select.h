@@ -457,7 +457,6 @@ struct ScoreParams {
     const float* q;          // [Q, E] row-major
     const long long* cand;   // [Q, C]
     const int* n_cand;       // [Q] or nullptr
-    const int* n_cand_pf;    // per_field mode of mfar_score_rows_kernel: [Q, F] entries per LIST (C must be a multiple of the block size), or nullptr
     float* out;              // [Q, C, F]
     long long row_offset;
     int n_rows, n_steps, E, F, C;
@@ -649,12 +648,6 @@ __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_kernel(const Scor
         if (idx < p.C * p.F) p.out[(size_t)qi * p.C * p.F + idx] = __builtin_nanf("");
         return;
     }
-    int cnt_pf = p.C;     // per-list counts (int8 first level: a block lies inside ONE list; blocks past its end have nothing to do and
-                          // write nothing -- the consumer reads only the first n_cand_pf entries)
-    if (p.per_field && p.n_cand_pf) {
-        cnt_pf = p.n_cand_pf[(size_t)qi * p.F + first / p.C];
-        if (first % p.C >= cnt_pf) return;
-    }
     for (int e = threadIdx.x; e < p.E; e += blockDim.x) qs[e] = p.q[(size_t)qi * p.E + e];
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -669,7 +662,7 @@ __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_kernel(const Scor
         const int fl = p.per_field ? idx / p.C : idx - c * p.F;     // list / field slot of this launch
         const int f = p.per_field ? p.f0 + fl : fl;                 // field of the slab
         fld = f;
-        if (c < nc && c < cnt_pf) {
+        if (c < nc) {
             long long id = p.cand[p.per_field ? ((size_t)qi * p.F + fl) * p.C + c : (size_t)qi * p.C + c];
             if (p.urep) id = (id >= 0 && id < p.nuniq[f]) ? (long long)p.urep[(size_t)f * p.ustride + id] : -1;   // unique row -> its document
             else id -= p.row_offset;
@@ -770,8 +763,8 @@ __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_kernel(const Scor
 #undef SCF_ISSUE
     if (idx < p.C * p.F) {
         float o = acc;
-        // un-scale (power of two), add q . mean; qm == nullptr (int8 first level): the raw sum, in units of the screen's fp16 values
-        if (SRC == SRC_F16G && valid && p.qm) o = acc * p.sfld[fld].inv_scale + p.qm[(size_t)qi * p.qm_stride + fld];
+        // un-scale (power of two), add q . mean
+        if (SRC == SRC_F16G && valid) o = acc * p.sfld[fld].inv_scale + p.qm[(size_t)qi * p.qm_stride + fld];
         if (known) {
             if (p.kval) p.out[(size_t)qi * p.C * p.F + idx] = p.kval[((size_t)qi * p.C + kc) * p.F + fld];      // exact launch: stage 1's bits
         } else {

@@ -307,9 +307,7 @@ __device__ __forceinline__ void s1_epilogue_append(const S1Params& p, const S1St
 }
 // second half; the caller has executed barrier B (slot counters and, on the direct path, the compaction flag of this tile
 // are final) after the appends
-// NC (no compaction; the int8 first level, mfar_i8.h): a list that passes the trigger is CLOSED instead -- tau = +inf, nothing is
-// appended to it any more -- and s1_flush publishes it with count -1
-template <int SCAP, bool NC = false>
+template <int SCAP>
 __device__ __forceinline__ void s1_epilogue_finish(const S1Params& p, const S1State& st, int w, size_t wgq0) {
     const int tid = threadIdx.x, lane = tid & 63;
     if (SCAP) {
@@ -329,12 +327,6 @@ __device__ __forceinline__ void s1_epilogue_finish(const S1Params& p, const S1St
             todo &= todo - 1;
             const int qq = 16 * w + b;
             const int n = __builtin_amdgcn_readlane(nv, b);
-            // (NC: p.k is 0 -- the compaction call stays in the code on purpose: without its register demand in this cold block
-            //  hipcc's allocation of the hot path around it spills 325 VGPRs instead of 37)
-            if (NC && p.k <= 0) {
-                if (lane == 0) st.tau[qq] = __builtin_inff();
-                continue;
-            }
             const float nt = s1_compact(p.lists + (wgq0 + qq) * S1_CAP, n, p.k);
             if (lane == 0) {
                 st.tau[qq] = nt;
@@ -386,7 +378,7 @@ __device__ __forceinline__ void s1_sample_top2(const S1Params& p, const S1Chunk&
 }
 
 // leave at most k entries per query and publish the counts
-template <int SCAP, bool NC = false>
+template <int SCAP>
 __device__ __forceinline__ void s1_flush(const S1Params& p, const S1State& st, int w, size_t wgq0, int qoff = 0) {
     const int lane = threadIdx.x & 63;
     __syncthreads();
@@ -396,9 +388,7 @@ __device__ __forceinline__ void s1_flush(const S1Params& p, const S1State& st, i
     }
     for (int qq = 16 * w; qq < 16 * w + 16; ++qq) {
         int n = __builtin_amdgcn_readfirstlane(min(st.cnt[qq], S1_CAP));
-        if (NC) {
-            if (qoff + qq < p.Q && __builtin_amdgcn_readfirstlane(__float_as_int(st.tau[qq])) == 0x7F800000) n = -1;   // closed
-        } else if (n > p.k) {
+        if (n > p.k) {
             s1_compact(p.lists + (wgq0 + qq) * S1_CAP, n, p.k);
             n = p.k;
         }

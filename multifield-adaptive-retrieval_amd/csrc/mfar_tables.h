@@ -44,11 +44,8 @@ struct S1TableHost {
 //   sample_div / append_target   sample-pass sizing (MFAR_SAMPLE_DIV = 12, MFAR_APPEND_TARGET = 130)
 //   group_chunks   > 0: merge in two levels whenever a field has more chunks than this, in groups of this many chunks -- two
 //                  launches of many small register-resident merges instead of one launch whose workgroups hold 48 keys per thread
-//   light          [F] or nullptr: fields that take their threshold from ANOTHER field's sample (the coarse segments of the int8
-//                  slab, mfar_i8.h): no small-field cut, one sampled tile per chunk -- their share of the grid follows their tiles
 static inline void s1_build_table(const S1GeomHost& g, int F, int n_cu, int k, bool solo, int sample_tiles_max, bool sample_forced,
-                                  int waves, int wgs, int sample_div, int append_target, S1TableHost& t, int group_chunks = 0,
-                                  const std::vector<char>* light = nullptr) {
+                                  int waves, int wgs, int sample_div, int append_target, S1TableHost& t, int group_chunks = 0) {
     const long long want = (long long)wgs * n_cu;
     const int cap = std::max(1, std::min(128, (64 * 256) / k));
     long long total_tiles = 0;
@@ -79,8 +76,7 @@ static inline void s1_build_table(const S1GeomHost& g, int F, int n_cu, int k, b
             const long long lim = std::min<long long>((long long)cap * l2cap, tiles);
             long long c = solo ? want : (want * g.n_tiles[f] + total_tiles / 2) / std::max(1LL, total_tiles);
             c = std::max(1LL, std::min(c, lim));
-            const bool lt = light && (*light)[f];
-            const long long fl = lt ? 1 : std::max(1LL, std::min(8 * tiles < k ? tiles : (std::min(tiles, need_tiles) + 3) / 4, lim));
+            const long long fl = std::max(1LL, std::min(8 * tiles < k ? tiles : (std::min(tiles, need_tiles) + 3) / 4, lim));
             cf[f] = (int)c;
             want_cf[f] = fl;
             if (fl > c) extra += fl - c;
@@ -89,7 +85,7 @@ static inline void s1_build_table(const S1GeomHost& g, int F, int n_cu, int k, b
         // the extra chunks come out of the fields that have more than their own floor; when nobody has (many equal fields),
         // only the fields without a possible threshold are cut (they must be) and the grid grows by those few workgroups
         for (int f = 0; f < F; ++f) {
-            const bool hard = 8LL * std::max(1, g.n_tiles[f]) < k && !(light && (*light)[f]);
+            const bool hard = 8LL * std::max(1, g.n_tiles[f]) < k;
             if (want_cf[f] > cf[f] && (hard || solo || spare >= extra)) {
                 cf[f] = (int)want_cf[f];
                 floor_cf[f] = cf[f];
@@ -142,7 +138,6 @@ static inline void s1_build_table(const S1GeomHost& g, int F, int n_cu, int k, b
     std::vector<int> ns(F, 1);
     t.sample_tiles = 1;
     for (int f = 0; f < F; ++f) {
-        if (light && (*light)[f]) continue;                                          // ns = 1
         const long long tpc = std::max(1LL, (long long)g.n_tiles[f] / cf[f]);      // tiles of the field's shortest chunk
         const long long tpc_hi = std::max(1LL, ((long long)g.n_tiles[f] + cf[f] - 1) / cf[f]);   // ... of its longest
         long long v = std::max(1LL, std::min<long long>(sample_tiles_max, tpc / sample_div));

@@ -85,14 +85,11 @@ SIGNATURES = {
     "mfar_screen_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "mfar_set_stage2_mode": (_i, [_vp, _i]),
     "mfar_stage2_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
-    "mfar_set_i8": (_i, [_vp, _i]),
-    "mfar_i8_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64),
-                           _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_float)]),
 }
 
 # MFAR_ABI_VERSION of include/mfar_hip.h these signatures were written against.  A library that reports another value has
 # different argument lists behind the same names (pointers would land in the wrong slots): lib() refuses it.
-ABI_VERSION = 103
+ABI_VERSION = 104
 
 
 def lib():

@@ -395,18 +395,6 @@ class MultiFieldIndex:
         _native.check(_native.lib().mfar_stage2_stats(self._h, ctypes.byref(ok), ctypes.byref(nbytes), ctypes.byref(nc), ctypes.byref(ns)))
         return dict(two_level=bool(ok.value), gather_slab_bytes=nbytes.value, n_candidates=nc.value, n_survivors=ns.value)
 
-    def set_i8(self, mode: int = 1):
-        """int8 first level under the wide screened pass (include/mfar_hip.h): 0 off, 1 on when the shapes allow.  Outputs are
-        bit-identical either way."""
-        _native.check(_native.lib().mfar_set_i8(self._h, int(mode)))
-
-    def i8_stats(self) -> dict:
-        built, err = ctypes.c_int(), ctypes.c_float()
-        v = [ctypes.c_int64() for _ in range(6)]
-        _native.check(_native.lib().mfar_i8_stats(self._h, ctypes.byref(built), *[ctypes.byref(x) for x in v], ctypes.byref(err)))
-        return dict(built=bool(built.value), slab_bytes=v[0].value, n_lists=v[1].value, n_appended=v[2].value, n_survivors=v[3].value,
-                    n_failed=v[4].value, seg1_rows=v[5].value, max_err_steps=err.value)
-
     def screen_field_info(self, field: int):
         """(distinct vectors of the field = rows the screened pass scans, size of its largest group of identical rows);
         (-1, -1) while no screen is current (include/mfar_hip.h)."""

@@ -22,16 +22,7 @@ static long long n_checked = 0;
 
 static void check_table(const S1GeomHost& g, int F, int n_cu, int k, bool solo, int stm, bool forced, int waves, int wgs, int sdiv, int atgt) {
     S1TableHost t;
-    // every other call marks the odd fields "light" (the coarse segments of the int8 slab, csrc/mfar_i8.h: no small-field cut, one
-    // sampled tile per chunk); the invariants below hold either way
-    static unsigned toggle = 0;
-    std::vector<char> light(F, 0);
-    const bool use_light = (++toggle & 1u) && F >= 2;
-    for (int f = 1; f < F; f += 2) light[f] = 1;
-    s1_build_table(g, F, n_cu, k, solo, stm, forced, waves, wgs, sdiv, atgt, t, 0, use_light ? &light : nullptr);
-    if (use_light)
-        for (int f = 1; f < F; f += 2)
-            for (int c = t.fchunk[f]; c < t.fchunk[f + 1]; ++c) REQUIRE(t.chunks[c].ns == 1);
+    s1_build_table(g, F, n_cu, k, solo, stm, forced, waves, wgs, sdiv, atgt, t, 0);
     ++n_checked;
     const int cap = std::max(1, std::min(128, (64 * 256) / k));
     const int l2cap = std::max(1, std::min(cap, 8192 / k));

@@ -19,7 +19,6 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--queries", type=int, default=64, help="queries per call (more than 64: the wide pass)")
-    ap.add_argument("--i8", type=int, default=0, help="1: the int8 first level under the wide pass")
     a = ap.parse_args()
     import torch
     from mfar import synth
@@ -27,7 +26,6 @@ def main():
     corpus = synth.SyntheticCorpus(a.docs, a.fields, a.dim, n_queries=4096, seed=0xDEADBEEF, device="cuda:0")
     ix = corpus.build_index(idxmod, dtype=a.dtype)
     ix.set_screen(a.screen)
-    ix.set_i8(a.i8)
     for i in range(3):
         ix.retrieve_fields(corpus.queries(i * a.queries, a.queries), a.k, True)
     torch.cuda.synchronize()
@@ -39,7 +37,7 @@ def main():
     dt = (time.perf_counter() - t0) / a.iters * 1e3
     ms, n = ix.stage1_timing()
     print(f"queries={a.queries} dtype={a.dtype} screen={a.screen} dbg={os.environ.get('MFAR_S1_DEBUG', '0')} stage1_total_ms={dt:.3f} main_kernel_ms={ms / max(n, 1):.3f} "
-          f"stats={ix.screen_stats()} i8={ix.i8_stats() if a.i8 else None}")
+          f"stats={ix.screen_stats()}")
 
 
 if __name__ == "__main__":

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity stress of stage 1 (all scan kernels, screen on/off) and of the whole scorer (with the screen on: certified
 re-scoring prefix, two-level stage 2) against the C oracle.
-    python tools/stress.py [seconds] [seed] [big | i8]   -- prints one line per configuration, exits non-zero on the first mismatch
-"i8": shapes the int8 first level serves (dim a multiple of 128, >= 16 384 rows, wide blocks) with the level switched on."""
+    python tools/stress.py [seconds] [seed] [big]   -- prints one line per configuration, exits non-zero on the first mismatch"""
 import os
 import sys
 import time
@@ -25,23 +24,16 @@ def main():
         F = int(rng.integers(1, 10))
         E = int(rng.choice([32, 64, 96, 128, 192, 384, 768]))
         D = int(rng.choice([rng.integers(1, 300), rng.integers(300, 5000), rng.integers(5000, 70000)]))
-        i8 = len(sys.argv) > 3 and sys.argv[3] == "i8"
-        if i8:
-            D = int(rng.integers(16384, 120000))
-            E = int(rng.choice([128, 256, 384, 768]))
-            F = int(rng.integers(1, 5))
-        elif len(sys.argv) > 3:              # "big": long chunks, many compactions / drains
+        if len(sys.argv) > 3:              # "big": long chunks, many compactions / drains
             D = int(rng.integers(20000, 250000))
             E = int(rng.choice([32, 96, 96, 192]))
             F = int(rng.integers(1, 4))
         D = min(D, int(3e7 // (F * E)))
         Q = int(rng.choice([rng.integers(1, 9), 64, rng.integers(9, 131), 128, rng.integers(129, 261)]))   # > 64: wide blocks of 128 + a rest
-        if i8:
-            Q = int(rng.choice([rng.integers(65, 129), 128, rng.integers(129, 261)]))
         k = int(rng.choice([1, 10, 100, 100, 128, rng.integers(1, 129)]))
         sentinel = bool(rng.integers(0, 2))
         mean = float(rng.choice([0.3, -0.4, 0.0, 2.0]))
-        dtype = "bf16" if rng.random() < 0.2 and not i8 else "f32"
+        dtype = "bf16" if rng.random() < 0.2 else "f32"
         mu = rng.standard_normal(E).astype(np.float32)
         mu /= np.linalg.norm(mu)
         slab = (rng.standard_normal((F, D, E)) * 0.5 + mean * mu * 4.0).astype(np.float32)
@@ -56,12 +48,7 @@ def main():
             slab[f] = (slab[f] * 0.01 + ramp).astype(np.float32)
         if kind == 3:                    # tiny values
             slab *= np.float32(1e-12)
-        if i8 and kind == 3:             # (heavy-tailed row norms instead of tiny values: rows for the coarse segment)
-            slab[0] *= np.exp(rng.standard_normal((D, 1)) * 0.8).astype(np.float32)
-            kind = 0
         ix = idxmod.MultiFieldIndex(D, F, E, device=0, dtype=dtype)
-        if i8:
-            ix.set_i8(1)
         for f in range(F):
             ix.write_rows(f, 0, slab[f])
         ref = O.bf16_round(slab) if dtype == "bf16" else slab
@@ -109,9 +96,6 @@ def main():
                 ok = False
                 print("MISMATCH fused", dict(F=F, D=D, E=E, Q=Q, k=k, seed=seed, n=n), flush=True)
         st = ix.screen_stats()
-        if i8:
-            st8 = ix.i8_stats()
-            st["n_checked"] = f"{st.get('n_checked')} i8_lists={st8['n_lists']} i8_failed={st8['n_failed']}"
         ix.close()
         n += 1
         print(f"{n:4d} ok={ok} F={F} D={D} E={E} Q={Q} k={k} sent={int(sentinel)} mean={mean} {dtype} kind={int(kind)} "
