@@ -112,6 +112,10 @@ def s1_kernel_name(dtype, screened, E, wide=False):
     rr = "" if os.environ.get("MFAR_S1_REGRING", "1") == "0" else ("r" if (E // 16) % 6 == 0 else ("r4" if (E // 16) % 4 == 0 else ""))
     if dtype == "bf16" and not screened:
         return f"mfar_stage1_bf16{rr}_kernel"
+    if dtype == "bf16":          # the certified passes over the bf16 slab itself (two bf16 query terms)
+        if wide:
+            return "mfar_stage1_bf16w4_kernel" if (E // 16) % 4 == 0 else "mfar_stage1_bf16w_kernel"
+        return "mfar_stage1_bf16s_kernel" if (E // 16) % 6 == 0 else "mfar_stage1_bf16s4_kernel"
     if screened and wide:
         return "mfar_stage1_f16w_kernel" if (E // 16) % 6 == 0 else "mfar_stage1_f16w4_kernel"
     return f"mfar_stage1_f16{rr}_kernel" if screened else "mfar_stage1_kernel"
@@ -171,8 +175,8 @@ def main():
     ap.add_argument("--wgs-per-cu", type=int, default=0)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="slab storage (default: the exact fp32 path)")
     ap.add_argument("--screen", choices=["auto", "off", "on"], default="auto",
-                    help="certified fp16 screening of stage 1 (bit-identical results; csrc/mfar_screen.h): auto = fp32 indexes; "
-                         "on = also a bf16 index (doubles its footprint)")
+                    help="certified stage 1 (bit-identical results; csrc/mfar_screen.h): an fp32 index scans an fp16 copy of its unique "
+                         "rows, a bf16 index scans its own slab with two bf16 query terms; auto = from 16 384 rows, on = always")
     ap.add_argument("--corpus", choices=["plain", "structured"], default="plain",
                     help="structured: realistic duplicate / norm structure in three of the fields (mfar/synth.py)")
     ap.add_argument("--empty-frac", type=float, default=0.08,
@@ -249,7 +253,7 @@ def main():
     D, F, E, Q = args.docs, args.fields, args.dim, args.batch
     # layout: N ranks = G replica groups x R row shards (R = N unless asked otherwise)
     esz = 2 if args.dtype == "bf16" else 4
-    whole_index_bytes = int(D * F * E * (esz + (2 if (args.dtype == "f32" or args.screen == "on") else 0) + 2) + D * F * 20)
+    whole_index_bytes = int(D * F * E * (esz + (2 if args.dtype == "f32" else 0) + 2) + D * F * 24)      # rows + [fp16 screen] + gather slab + tables
     if args.row_shards == "auto":
         R = choose_row_shards(N, whole_index_bytes, torch.cuda.mem_get_info(local_rank)[0])
         if N > 1:       # every rank must take the same decision: the most conservative one
@@ -479,7 +483,8 @@ def main():
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "algorithmic_bytes_definition": (
                 f"{n_scan_rows} scanned rows x {E} dims x {esize} B: the " +
-                (f"fp16 SCREEN rows of the {args.dtype} index (unique rows per field), read once per launch" if screened else
+                ((f"fp16 SCREEN rows of the fp32 index (unique rows per field), read once per launch" if args.dtype == "f32" else
+                  "rows of the bf16 slab itself (every document; duplicates are scanned and masked), read once per launch") if screened else
                  ("bf16 slab" if args.dtype == "bf16" else "fp32 slab") + ", read once per 64-query batch")),
             "fp32_slab_bytes_per_batch_survey_8d": float(row1 - row0) * F * E * 4,
             "alone": ({"avg_launch_ms": alone_ms, "achieved": bytes_per_launch / (alone_ms * 1e-3) / 1e9,
@@ -509,7 +514,7 @@ def main():
             "value": qps, "unit": "queries/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": ("f32" if args.dtype == "f32" else
-                      ("bf16 docs, fp32 queries; lists and scores = the exact fp32 chain over the bf16 docs (certified fp16 screen)" if screened
+                      ("bf16 docs, fp32 queries; lists and scores = the exact fp32 chain over the bf16 docs (certified two-term bf16 pass over the slab itself)" if screened
                        else "bf16 docs x fp32 queries (3 exact bf16 terms), fp32 accumulate")), "data": "synthetic",
             "config": {"workload": f"synthetic STaRK-amazon-shaped corpus ({args.corpus}" + (f", {args.empty_frac:g} of the field vectors empty" if args.empty_frac != 0.08 else "") + f"), {D} docs x {F} dense fields x {E}d {args.dtype}, "
                                    f"{lay.G} replica group(s) x {lay.R} row shard(s) over {N} GPU(s); two-stage scorer k1=k2=100, zero-sentinel mode",
@@ -521,9 +526,10 @@ def main():
                                                                              if ps.Qmax > 64 else "")),
                        "queries_per_launch": ps.Qmax},
             "rccl": rccl,
-            "stage1": (f"certified fp16 screen of the {args.dtype} slab (min(k+92,192) unique rows per list re-scored with the exact fp32 chain, "
-                       "top-k proven or redone by the exact pass per field)" +
-                       (": outputs bit-identical to the plain fp32 pass" if args.dtype == "f32" else "") if screened else
+            "stage1": ((f"certified fp16 screen of the fp32 slab (min(k+92,192) unique rows per list re-scored with the exact fp32 chain, "
+                        "top-k proven or redone by the exact pass per field): outputs bit-identical to the plain fp32 pass" if args.dtype == "f32" else
+                        "certified pass over the bf16 slab itself (two bf16 query terms, no second copy of the rows; min(k+92,192) unique rows per "
+                        "list re-scored with the exact natural-order chain, top-k proven or redone by the exact pass per field)") if screened else
                        ("exact fp32 MFMA pass" if args.dtype == "f32" else "bf16 slab pass")),
             "screen": ({"lists_certified": (scr["n_checked"] - scr0["n_checked"]) - (scr["n_failed"] - scr0["n_failed"]),
                         "lists_redone_exactly": scr["n_failed"] - scr0["n_failed"], "batches_redone": n_redone_main,

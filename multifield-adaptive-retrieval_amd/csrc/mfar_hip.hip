@@ -107,6 +107,7 @@ struct mfar_index {
     // batch i+1 scans on another (mfar_stage1_begin / mfar_stage1_finish)
     struct S1Slot {
         DevBuf qt, lists, list_cnt, gtau, samp, lists2, list_cnt2;      // any pass (lists2: group lists of a two-level merge)
+        DevBuf unit_ctr;                                                // per-field unit counters of a dynamically distributed scan (mfar_stage1.h)
         DevBuf qt16, qinfo, eps, base, fail, sids, ssc, scnt, sx;        // fp16 screen
         bool screened = false;                                          // decided by the begin phase of the batch
         int qw = 64;                                                    // query columns of the batch's pass (128: wide screen pass)
@@ -136,6 +137,10 @@ struct mfar_index {
     // unique row, start / length of its member run in `members` (local rows grouped by unique row, ascending inside a group)
     DevBuf u_rep, u_start, u_count, u_members, u_n;
     DevBuf u_repof;               // [F][n_rows] representative of every row's group (stage 2 gathers it in the row's place); optional
+    // bf16 index: the certified pass scans the slab itself (no screen slab) and ranks unique rows through these (mfar_screen.h)
+    DevBuf rep_bits;              // [F][n_blk] u64: row is real and the representative of its group
+    DevBuf u_of;                  // [F][n_rows] u32: unique number + 1 of a representative's row
+    bool screen_built = false;    // statistics + unique-row tables (+ the fp16 screen slab of an fp32 index) were built at least once
     std::vector<int> n_unique, largest_group;   // per field (host copies)
     bool screen_dedup = true;     // MFAR_SCREEN_DEDUP=0: every document is its own unique row (diagnostic)
     bool wide = true;             // blocks of 65 .. 128 queries go through the wide screened pass (MFAR_WIDE=0: always 64 per pass)
@@ -186,10 +191,29 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW4_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW4_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HR_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16s_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HR_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16s4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HR4_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16s4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HR4_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BW_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16w_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BW_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BW4_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16w4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BW4_LDS_BYTES));
     g_attr_done[device] = true;
     return MFAR_OK;
 }
 
+#ifdef MFAR_TRACE
+extern "C" int mfar_trace_dump(void* host, int max_rec) {   // experiment builds only
+    int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_trace_n), 4) != hipSuccess) return -1;
+    n = std::min(std::min(n, max_rec), 1 << 17);
+    if (n > 0 && hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), (size_t)n * sizeof(TraceRec)) != hipSuccess) return -1;
+    const int zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), &zero, 4);
+    return n;
+}
+#endif
 extern "C" int mfar_version(void) { return MFAR_VERSION; }
 extern "C" const char* mfar_last_error(void) { return g_err.c_str(); }
 extern "C" int mfar_device_count(int* n_out) {
@@ -274,7 +298,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
     DevBuf* bufs[] = {&idx->fid, &idx->fsc, &idx->s_stats, &idx->s_field, &idx->s_mean, &idx->screen, &idx->u_rep, &idx->u_start,
-                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->s2stats};
+                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->s2stats, &idx->rep_bits, &idx->u_of};
     for (int i = 0; i < MFAR_SLOTS; ++i)
         for (DevBuf* b : {&idx->cand[i], &idx->ncand[i], &idx->x[i], &idx->own[i], &idx->xa[i], &idx->cand2[i], &idx->ncand2[i], &idx->s2qm[i],
                           &idx->s2eps[i], &idx->kmask[i], &idx->src2[i]})
@@ -290,7 +314,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
         }
     for (DevBuf* b : bufs) b->release();
     for (auto& sl : idx->s1) {
-        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.lists2, &sl.list_cnt2, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
+        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.lists2, &sl.list_cnt2, &sl.unit_ctr, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
                         &sl.ssc, &sl.scnt, &sl.sx};
         for (DevBuf* b : sb) b->release();
     }
@@ -515,7 +539,10 @@ struct S1Out {
     int sentinel;     // padding convention of the output lists
     long long row_offset;   // added to the local rows of the lists (0: the lists hold unique-row numbers)
 };
-enum { S1_F32 = 0, S1_BF16 = 1, S1_F16 = 2, S1_F16W = 3 };   // S1_F16W: the wide (128-query, one fp16 term) screen pass
+enum { S1_F32 = 0, S1_BF16 = 1, S1_F16 = 2, S1_F16W = 3, S1_BF16S = 4, S1_BF16W = 5 };
+// S1_F16W: the wide (128-query, one fp16 term) screen pass of an fp32 index; S1_BF16S / S1_BF16W: the certified passes over a bf16
+// slab (two bf16 query terms; 64 / 128 columns)
+static bool s1_is_wide(int kind) { return kind == S1_F16W || kind == S1_BF16W; }
 static int launch_s1(int kind, bool sample, unsigned n_chunks, unsigned wave, hipStream_t st, const S1Params& p_in) {
     S1Params p = p_in;
     p.n_launch = (int)n_chunks;
@@ -534,6 +561,24 @@ static int launch_s1(int kind, bool sample, unsigned n_chunks, unsigned wave, hi
         } else {
             if (sample) mfar_stage1_f16w4_sample_kernel<<<g, b, S1HW4_LDS_BYTES, st>>>(p);
             else mfar_stage1_f16w4_kernel<<<g, b, S1HW4_LDS_BYTES, st>>>(p);
+        }
+    } else if (kind == S1_BF16W) {
+        // the 4-slot ring (50.5 KB of LDS) whenever the k-steps divide by 4: see mfar_stage1.h on LDS fragmentation
+        static const int bw_ring = getenv("MFAR_BF16W_RING") ? atoi(getenv("MFAR_BF16W_RING")) : 0;   // diagnostic: 6 forces the 6-slot ring
+        if (p.n_steps % 4 == 0 && !(bw_ring == 6 && p.n_steps % 6 == 0)) {
+            if (sample) mfar_stage1_bf16w4_sample_kernel<<<g, b, S1BW4_LDS_BYTES, st>>>(p);
+            else mfar_stage1_bf16w4_kernel<<<g, b, S1BW4_LDS_BYTES, st>>>(p);
+        } else {
+            if (sample) mfar_stage1_bf16w_sample_kernel<<<g, b, S1BW_LDS_BYTES, st>>>(p);
+            else mfar_stage1_bf16w_kernel<<<g, b, S1BW_LDS_BYTES, st>>>(p);
+        }
+    } else if (kind == S1_BF16S) {
+        if (p.n_steps % 6 == 0) {
+            if (sample) mfar_stage1_bf16s_sample_kernel<<<g, b, S1HR_LDS_BYTES, st>>>(p);
+            else mfar_stage1_bf16s_kernel<<<g, b, S1HR_LDS_BYTES, st>>>(p);
+        } else {
+            if (sample) mfar_stage1_bf16s4_sample_kernel<<<g, b, S1HR4_LDS_BYTES, st>>>(p);
+            else mfar_stage1_bf16s4_kernel<<<g, b, S1HR4_LDS_BYTES, st>>>(p);
         }
     } else {
         // register-ring variants (docs straight into VGPRs, 25 / 37 KB of LDS) when the k-steps divide into the 6 register slots
@@ -570,12 +615,12 @@ enum { S1_PREPARE = 1, S1_SCAN = 2, S1_FINISH = 4, S1_CERTIFY = 8, S1_ALL = 15 }
 static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, int f0, int nf, int phases, int kind, const void* slab,
                        const void* qt, int qt_n, int k, float tau0, const float* tau_base, const int* only_failed, bool record,
                        const S1Out& o, hipStream_t st) {
-    const int qw = kind == S1_F16W ? 128 : 64;   // query columns of the pass: stride of every per-query table below
+    const int qw = s1_is_wide(kind) ? 128 : 64;   // query columns of the pass: stride of every per-query table below
     // a repair pass (only_failed) uses the finely cut table as well: the workgroups of the fields that did not fail exit at once,
     // and a failed field is then scanned by the whole GPU instead of by its share of one wave (one failed field of eight at 1 M
     // rows: 64 workgroups x 61 tiles at the MFMA-bound rate = several ms; cut into 512 chunks: under 1 ms)
     const bool repair = only_failed != nullptr;
-    const bool solo = nf != idx->F || repair, wide = kind == S1_F16W;
+    const bool solo = nf != idx->F || repair, wide = s1_is_wide(kind);
     S1Table& tb = wide ? (solo ? geom.solo_w : geom.all_w) : (solo ? geom.solo : geom.all);
     static const int sample_tiles_env = getenv("MFAR_SAMPLE_TILES") ? atoi(getenv("MFAR_SAMPLE_TILES")) : 0;
     RETCHK(build_table(idx, geom, tb, k, solo, sample_tiles_env > 0 ? sample_tiles_env : (kind == S1_F32 ? 1 : 2), sample_tiles_env > 0, 4, idx->wgs_per_cu, st));
@@ -600,6 +645,10 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
     p.samp_out = nullptr;
     p.samp_stride = tb.samp_stride;
     p.only_failed = only_failed;
+    if (kind == S1_BF16S || kind == S1_BF16W) {     // documents are scanned, unique rows are ranked (mfar_stage1.h s1_acc_init)
+        p.rep_bits = idx->rep_bits.as<u64>();
+        p.rep_stride = idx->n_blk;
+    }
     {
         const char* dbg = getenv("MFAR_S1_DEBUG");
         p.dbg = dbg ? atoi(dbg) : 0;
@@ -697,7 +746,18 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
         if (!idx->mid_ev) HIPCHK(hipEventCreateWithFlags(&idx->mid_ev, hipEventDisableTiming));
         HIPCHK(hipEventRecord(idx->mid_ev, st));
     }
-    if (phases & S1_SCAN) RETCHK(launch_s1(kind, false, grid, (unsigned)(idx->wgs_per_cu * idx->n_cu), st, p));
+    if (phases & S1_SCAN) {
+        // dynamic work distribution (mfar_stage1.h s1_unit_*): the kernels that have it, full passes that are not repairs
+        static const bool dyn_on = !(getenv("MFAR_S1_DYN") && atoi(getenv("MFAR_S1_DYN")) == 0);
+        static const int unit_tiles = getenv("MFAR_UNIT_TILES") ? std::max(2, atoi(getenv("MFAR_UNIT_TILES"))) : 2;
+        if (dyn_on && !repair && kind == S1_BF16W) {
+            RETCHK(sl.unit_ctr.ensure((size_t)MFAR_MAX_FIELDS * sizeof(int)));
+            HIPCHK(hipMemsetAsync(sl.unit_ctr.p, 0, (size_t)MFAR_MAX_FIELDS * sizeof(int), st));
+            p.unit_ctr = sl.unit_ctr.as<int>();
+            p.unit_tiles = unit_tiles;
+        }
+        RETCHK(launch_s1(kind, false, grid, (unsigned)(idx->wgs_per_cu * idx->n_cu), st, p));
+    }
     if (e1) HIPCHK(hipEventRecord(e1, st));
     if (phases & S1_FINISH) {
         m.out_ids = o.ids;
@@ -736,7 +796,9 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
 // ------------------------------------------------------------------------------------------------ fp16 screen
 static bool screen_wanted(const mfar_index* idx, int k) {
     if (idx->screen_mode == 0 || idx->screen_nomem) return false;
-    if (idx->dtype == MFAR_DTYPE_BF16 && idx->screen_mode < 2) return false;   // bf16 indexes: opt-in (the screen doubles their footprint)
+    // (bf16 indexes: the certified pass scans the bf16 slab itself -- nothing to allocate but the unique-row tables; it needs a
+    //  register-ring kernel for the dim)
+    if (idx->dtype == MFAR_DTYPE_BF16 && idx->n_steps % 4 != 0 && idx->n_steps % 6 != 0) return false;
     if (k + SCREEN_EXTRA_MIN > SCREEN_MAX_KP) return false;
     if (idx->E * 4 > 60 * 1024) return false;   // the re-scoring kernel stages a query row in LDS
     // auto mode stays off for very wide rows: the certificate's fp32-accumulation term (4 E + 66) u32 grows with E while the
@@ -759,7 +821,9 @@ __global__ void mfar_iota_kernel(int* __restrict__ a, int* __restrict__ b, int* 
 }
 
 // Unique rows of one field -> idx->u_* tables of that field; returns the number of unique rows and the largest group.
-static int build_unique_rows(mfar_index* idx, int f, const float* field, DevBuf* tmp, hipStream_t st, int* n_unique_out, int* largest_out) {
+//   bits_out / uof_out   (bf16 index) the field's "real row and representative" bits [n_blk words] and unique number + 1 per row, or nullptr
+static int build_unique_rows(mfar_index* idx, int f, const float* field, DevBuf* tmp, hipStream_t st, int* n_unique_out, int* largest_out,
+                             u64* bits_out, u32* uof_out) {
     const long long n = idx->n_rows;
     int* urep = idx->u_rep.as<int>() + (size_t)f * n;
     int* ustart = idx->u_start.as<int>() + (size_t)f * n;
@@ -770,7 +834,10 @@ static int build_unique_rows(mfar_index* idx, int f, const float* field, DevBuf*
         if (n > 0) {
             mfar_iota_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(urep, ustart, ucount, members, repof, n);
             HIPCHK(hipGetLastError());
+            if (uof_out) mfar_iota1_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(uof_out, n);
         }
+        if (bits_out) mfar_rep_bits_kernel<<<dim3((unsigned)idx->n_blk), dim3(64), 0, st>>>(nullptr, n, bits_out);
+        HIPCHK(hipGetLastError());
         *n_unique_out = (int)n;
         *largest_out = n > 0 ? 1 : 0;
         return MFAR_OK;
@@ -783,7 +850,7 @@ static int build_unique_rows(mfar_index* idx, int f, const float* field, DevBuf*
     u64* k_out = tmp[1].as<u64>();
     u32* v_in = tmp[2].as<u32>();
     u32* v_out = (u32*)members;      // the sorted row numbers ARE the member table
-    u32 *head = tmp[3].as<u32>(), *gid = tmp[4].as<u32>(), *is_rep = tmp[5].as<u32>(), *urank = tmp[6].as<u32>();
+    u32 *head = tmp[3].as<u32>(), *gid = tmp[4].as<u32>(), *is_rep = tmp[5].as<u32>(), *urank = uof_out ? uof_out : tmp[6].as<u32>();
     int* gstart = tmp[7].as<int>();
     mfar_row_hash_kernel<<<dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st>>>(field, idx->n_steps, n, k_in, v_in);
     HIPCHK(hipGetLastError());
@@ -802,6 +869,10 @@ static int build_unique_rows(mfar_index* idx, int f, const float* field, DevBuf*
     HIPCHK(hipGetLastError());
     cap = tmp[8].cap;
     HIPCHK(hipcub::DeviceScan::InclusiveSum(tmp[8].p, cap, is_rep, urank, (int)n, st));
+    if (bits_out) {
+        mfar_rep_bits_kernel<<<dim3((unsigned)idx->n_blk), dim3(64), 0, st>>>(is_rep, n, bits_out);
+        HIPCHK(hipGetLastError());
+    }
     u32 n_groups = 0;
     HIPCHK(hipMemcpyAsync(&n_groups, gid + (n - 1), 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -866,17 +937,21 @@ static int ensure_rows16(mfar_index* idx, hipStream_t st, bool* ok) {
     return MFAR_OK;
 }
 
-// (re)build the screen from the fp32 slab when rows changed: per-field statistics, the unique rows of every field, the fp16
-// slab of those rows.  *ok = false: not available (allocation failed) -> the caller stays on the exact pass.
+// (re)build what the certified stage 1 needs when rows changed.
+//   fp32 index: per-field statistics, the unique rows of every field, the fp16 screen slab of those rows, the fp16 gather slab;
+//   bf16 index: the largest row norm per field, the unique rows (through an fp32 staging copy of one field at a time, so that the
+//               hash / grouping kernels exist once), their "representative" bits and unique numbers -- the scan reads the slab itself.
+// *ok = false: not available (allocation failed) -> the caller stays on the exact pass.
 static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
     *ok = false;
-    if (!idx->screen_dirty && idx->screen.p) {
+    if (!idx->screen_dirty && idx->screen_built) {
         *ok = true;
         return MFAR_OK;
     }
     HIPCHK(hipDeviceSynchronize());   // a rebuild replaces tables that launches in flight may still read
     const int F = idx->F;
     const long long n = idx->n_rows;
+    const bool bf16 = idx->dtype == MFAR_DTYPE_BF16;
     auto nomem = [&]() {
         (void)hipGetLastError();
         g_err.clear();
@@ -887,6 +962,8 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
         idx->u_count.ensure((size_t)F * n * 4) != MFAR_OK || idx->u_members.ensure((size_t)F * n * 4) != MFAR_OK ||
         idx->u_n.ensure((size_t)F * 4) != MFAR_OK)
         return nomem();
+    if (bf16 && (idx->rep_bits.ensure((size_t)F * idx->n_blk * 8) != MFAR_OK || idx->u_of.ensure((size_t)F * std::max<long long>(n, 1) * 4) != MFAR_OK))
+        return nomem();
     if (idx->u_repof.ensure((size_t)F * n * 4) != MFAR_OK) {   // optional: without it stage 2 gathers every row itself
         (void)hipGetLastError();
         g_err.clear();
@@ -896,10 +973,7 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
     RETCHK(idx->s_field.ensure((size_t)F * sizeof(ScreenField)));
     RETCHK(idx->s_mean.ensure((size_t)F * idx->E * sizeof(float)));
     HIPCHK(hipMemsetAsync(idx->s_stats.p, 0, (size_t)F * 2 * sizeof(u32), st));
-    HIPCHK(hipMemsetAsync(idx->s_mean.p, 0, (size_t)F * idx->E * sizeof(float), st));
-    // A bf16 index is screened through an fp32 staging copy of one field at a time (the rows widened exactly, in the fp32
-    // slab's tiled layout), so that every build kernel below exists once.  field_src(f) = the fp32 tiled rows of field f.
-    const bool bf16 = idx->dtype == MFAR_DTYPE_BF16;
+    HIPCHK(hipMemsetAsync(idx->s_mean.p, 0, (size_t)F * idx->E * sizeof(float), st));   // (bf16: the "mean" stays the zero vector)
     DevBuf stage_rows, stage_field;
     if (bf16 && (stage_rows.ensure((size_t)std::max<long long>(n, 1) * idx->E * 4) != MFAR_OK ||
                  stage_field.ensure((size_t)idx->field_stride * 4) != MFAR_OK)) {
@@ -907,6 +981,7 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
         stage_field.release();
         return nomem();
     }
+    // field_src(f) = the fp32 tiled rows of field f (a bf16 field: widened exactly into the staging copy)
     auto field_src = [&](int f, const float** out) -> int {
         if (!bf16) {
             *out = (const float*)idx->slab + (size_t)f * idx->field_stride;
@@ -923,41 +998,58 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
         *out = stage_field.as<float>();
         return MFAR_OK;
     };
-    // pass 1: per-field mean vector and statistics of the centred rows
-    for (int f = 0; f < F; ++f) {
-        const float* src;
-        RETCHK(field_src(f, &src));
-        float* mean_f = idx->s_mean.as<float>() + (size_t)f * idx->E;
-        mfar_screen_mean_kernel<<<dim3((unsigned)((idx->n_blk + 7) / 8), 1), dim3(256), 0, st>>>(src, idx->field_stride, idx->n_steps, idx->n_blk,
-                                                                                                idx->n_rows, mean_f);
+    // pass 1: per-field statistics
+    if (bf16) {
+        for (int f = 0; f < F; ++f) {
+            mfar_direct_stats_kernel<<<dim3((unsigned)idx->n_blk), dim3(128), 0, st>>>((const unsigned short*)idx->slab + (size_t)f * idx->field_stride,
+                                                                                     idx->n_steps, idx->n_rows, idx->s_stats.as<u32>() + 2 * f);
+            HIPCHK(hipGetLastError());
+        }
+        mfar_direct_fields_kernel<<<dim3(1), dim3(64), 0, st>>>(idx->s_stats.as<u32>(), F, idx->s_field.as<ScreenField>());
         HIPCHK(hipGetLastError());
-        mfar_screen_mean_finish_kernel<<<dim3((idx->E + 255) / 256), dim3(256), 0, st>>>(mean_f, idx->E, idx->n_rows);
-        HIPCHK(hipGetLastError());
-        mfar_screen_stats_kernel<<<dim3((unsigned)idx->n_blk, 1), dim3(256), 0, st>>>(src, idx->field_stride, idx->n_steps, idx->n_rows, mean_f,
-                                                                                     idx->s_stats.as<u32>() + 2 * f);
+    } else {
+        // mean vector and statistics of the centred rows
+        for (int f = 0; f < F; ++f) {
+            const float* src = (const float*)idx->slab + (size_t)f * idx->field_stride;
+            float* mean_f = idx->s_mean.as<float>() + (size_t)f * idx->E;
+            mfar_screen_mean_kernel<<<dim3((unsigned)((idx->n_blk + 7) / 8), 1), dim3(256), 0, st>>>(src, idx->field_stride, idx->n_steps, idx->n_blk,
+                                                                                                    idx->n_rows, mean_f);
+            HIPCHK(hipGetLastError());
+            mfar_screen_mean_finish_kernel<<<dim3((idx->E + 255) / 256), dim3(256), 0, st>>>(mean_f, idx->E, idx->n_rows);
+            HIPCHK(hipGetLastError());
+            mfar_screen_stats_kernel<<<dim3((unsigned)idx->n_blk, 1), dim3(256), 0, st>>>(src, idx->field_stride, idx->n_steps, idx->n_rows, mean_f,
+                                                                                         idx->s_stats.as<u32>() + 2 * f);
+            HIPCHK(hipGetLastError());
+        }
+        mfar_screen_scale_kernel<<<dim3(1), dim3(64), 0, st>>>(idx->s_stats.as<u32>(), idx->s_mean.as<float>(), F, idx->E,
+                                                             idx->s_field.as<ScreenField>());
         HIPCHK(hipGetLastError());
     }
-    mfar_screen_scale_kernel<<<dim3(1), dim3(64), 0, st>>>(idx->s_stats.as<u32>(), idx->s_mean.as<float>(), F, idx->E,
-                                                         idx->s_field.as<ScreenField>());
-    HIPCHK(hipGetLastError());
     // pass 2: unique rows, field by field (scratch shared); an fp32 index reads its slab in place
     DevBuf tmp[9];
     int rc = MFAR_OK;
-    std::vector<const float*> srcs(F, nullptr);
     for (int f = 0; f < F && rc == MFAR_OK; ++f) {
-        rc = field_src(f, &srcs[f]);
-        if (rc == MFAR_OK) rc = build_unique_rows(idx, f, srcs[f], tmp, st, &idx->n_unique[f], &idx->largest_group[f]);
+        const float* src = nullptr;
+        rc = field_src(f, &src);
+        if (rc == MFAR_OK)
+            rc = build_unique_rows(idx, f, src, tmp, st, &idx->n_unique[f], &idx->largest_group[f],
+                                   bf16 ? idx->rep_bits.as<u64>() + (size_t)f * idx->n_blk : nullptr, bf16 ? idx->u_of.as<u32>() + (size_t)f * n : nullptr);
         if (bf16) HIPCHK(hipStreamSynchronize(st));   // the staging copy is reused by the next field
     }
     HIPCHK(hipStreamSynchronize(st));
     for (auto& b : tmp) b.release();
-    if (rc == MFAR_ERR_NOMEM) {
-        stage_rows.release();
-        stage_field.release();
-        return nomem();
-    }
+    stage_rows.release();
+    stage_field.release();
+    if (rc == MFAR_ERR_NOMEM) return nomem();
     RETCHK(rc);
     HIPCHK(hipMemcpyAsync(idx->u_n.p, idx->n_unique.data(), (size_t)F * 4, hipMemcpyHostToDevice, st));
+    if (bf16) {
+        idx->screen_used = 0;
+        idx->screen_dirty = false;
+        idx->screen_built = true;
+        *ok = true;
+        return MFAR_OK;
+    }
     // geometry of the screen slab: every field holds its unique rows, padded to whole 256-row tiles
     S1Geom& g = idx->geom_screen;
     g.reset(F);
@@ -970,33 +1062,22 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
         g.n_tiles[f] = (int)(blk / 4);
         total += blk * 64 * idx->E;
     }
-    if (idx->screen.ensure((size_t)total * 2) != MFAR_OK) {
-        stage_rows.release();
-        stage_field.release();
-        return nomem();
-    }
+    if (idx->screen.ensure((size_t)total * 2) != MFAR_OK) return nomem();
     idx->screen_used = (size_t)total * 2;
     // pass 3: the fp16 rows
     for (int f = 0; f < F; ++f) {
-        const float* src;
-        RETCHK(field_src(f, &src));
+        const float* src = (const float*)idx->slab + (size_t)f * idx->field_stride;
         const long long n_gran = (long long)g.n_tiles[f] * 4 * idx->n_steps * 128;
         mfar_screen_build_kernel<<<dim3((unsigned)((n_gran + 255) / 256)), dim3(256), 0, st>>>(
             src, (_Float16*)idx->screen.p + g.base[f], n_gran, idx->n_steps, idx->n_unique[f], idx->u_rep.as<int>() + (size_t)f * n,
             idx->s_mean.as<float>() + (size_t)f * idx->E, idx->s_field.as<ScreenField>() + f);
         HIPCHK(hipGetLastError());
-        if (bf16) HIPCHK(hipStreamSynchronize(st));
-    }
-    if (bf16) {
-        HIPCHK(hipStreamSynchronize(st));
-        stage_rows.release();
-        stage_field.release();
     }
     // the fp16 gather slab of an fp32 index: the same centred + scaled values, every document's row, row-major (the approximate
     // level of the certified two-level stage 2; +50 % of the fp32 slab, optional)
-    if (!bf16) idx->gslab_ok = false;
+    idx->gslab_ok = false;
     static const bool gs_enabled = !(getenv("MFAR_GATHER_SLAB") && atoi(getenv("MFAR_GATHER_SLAB")) == 0);
-    if (!bf16 && gs_enabled && n > 0 && gslab_alloc(idx)) {
+    if (gs_enabled && n > 0 && gslab_alloc(idx)) {
         const long long total = n * (long long)(idx->g_row_bytes / 16);
         for (int f = 0; f < F; ++f) {
             mfar_gslab_build_f16_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(
@@ -1007,6 +1088,7 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
         idx->gslab_ok = true;
     }
     idx->screen_dirty = false;
+    idx->screen_built = true;
     *ok = true;
     return MFAR_OK;
 }
@@ -1052,7 +1134,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         if ((phases & S1_CERTIFY) && any_fail_out) HIPCHK(hipMemsetAsync(any_fail_out, 0, 4, st));
         return MFAR_OK;
     }
-    RETCHK(sl.qt16.ensure((size_t)idx->n_steps * 4096));
+    RETCHK(sl.qt16.ensure((size_t)idx->n_steps * 8192));
     RETCHK(sl.qinfo.ensure(128 * sizeof(ScreenQuery)));
     RETCHK(sl.eps.ensure((size_t)F * 128 * 4));
     RETCHK(sl.base.ensure((size_t)F * 128 * 4));
@@ -1067,14 +1149,25 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     int* fflags = sl.fail.as<int>();
     // 1. screened pass on the fp16 slab of unique rows: the k' best approximate scores per (query, field)
     if (phases & S1_PREPARE) {
-        mfar_screen_queries_kernel<<<dim3(qw), dim3(256), 0, st>>>(q, (_Float16*)sl.qt16.p, sl.qinfo.as<ScreenQuery>(),
-                                                                   idx->s_field.as<ScreenField>(), sl.eps.as<float>(), sl.base.as<float>(),
-                                                                   fflags, q0, Q, idx->E, F, idx->screen_eps_mult, qw);
+        if (bf16)
+            mfar_direct_queries_kernel<<<dim3(qw), dim3(256), 0, st>>>(q, (unsigned short*)sl.qt16.p, sl.qinfo.as<ScreenQuery>(),
+                                                                       idx->s_field.as<ScreenField>(), sl.eps.as<float>(), sl.base.as<float>(),
+                                                                       fflags, q0, Q, idx->E, F, idx->screen_eps_mult, qw);
+        else
+            mfar_screen_queries_kernel<<<dim3(qw), dim3(256), 0, st>>>(q, (_Float16*)sl.qt16.p, sl.qinfo.as<ScreenQuery>(),
+                                                                       idx->s_field.as<ScreenField>(), sl.eps.as<float>(), sl.base.as<float>(),
+                                                                       fflags, q0, Q, idx->E, F, idx->screen_eps_mult, qw);
         HIPCHK(hipGetLastError());
     }
-    const S1Out so = {sl.sids.as<long long>(), sl.ssc.as<float>(), sl.scnt.as<int>(), 0, 0, 0};   // lists of unique-row numbers
-    RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, phases, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
-                       sl.base.as<float>(), nullptr, true, so, st));
+    // lists of unique-row numbers (fp32 index: rows of the screen slab) / of the local rows of group representatives (bf16 index:
+    // the pass scans the documents themselves)
+    const S1Out so = {sl.sids.as<long long>(), sl.ssc.as<float>(), sl.scnt.as<int>(), 0, 0, 0};
+    if (bf16)
+        RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, phases, qw == 128 ? S1_BF16W : S1_BF16S, idx->slab, sl.qt16.p, qt_n, kp, -INFINITY,
+                           sl.base.as<float>(), nullptr, true, so, st));
+    else
+        RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, phases, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
+                           sl.base.as<float>(), nullptr, true, so, st));
     if (!(phases & S1_CERTIFY)) return MFAR_OK;
     // 2. exact scores of those unique rows' representatives (the contract's fma chain over the fp32 slab)
     ScoreParams sp = {};
@@ -1091,8 +1184,11 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     sp.F = nf;
     sp.C = kp;
     sp.per_field = 1;
-    sp.urep = idx->u_rep.as<int>();
-    sp.nuniq = idx->u_n.as<int>();
+    if (bf16) sp.row_offset = 0;            // the lists hold local rows
+    else {
+        sp.urep = idx->u_rep.as<int>();     // ... unique-row numbers: the representative document is gathered
+        sp.nuniq = idx->u_n.as<int>();
+    }
     sp.ustride = idx->n_rows;
     sp.f0 = f0;
     bool rows16 = false;
@@ -1131,6 +1227,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     cp.ustart = idx->u_start.as<int>();
     cp.ucount = idx->u_count.as<int>();
     cp.members = idx->u_members.as<int>();
+    cp.uof = bf16 ? idx->u_of.as<u32>() : nullptr;
     cp.ustride = idx->n_rows;
     cp.row_offset = idx->row_offset;
     cp.f0 = f0;
@@ -1283,7 +1380,7 @@ extern "C" int mfar_get_screen(const mfar_index* idx, int* mode, float* eps_mult
 
 extern "C" int mfar_screen_field_info(mfar_index* idx, int field, int64_t* n_unique_rows, int64_t* largest_group) {
     if (!idx || field < 0 || field >= idx->F) return fail(MFAR_ERR_INVALID, "bad idx / field");
-    const bool built = idx->screen.p && !idx->screen_dirty;
+    const bool built = idx->screen_built && !idx->screen_dirty;
     if (n_unique_rows) *n_unique_rows = built ? idx->n_unique[field] : -1;
     if (largest_group) *largest_group = built ? idx->largest_group[field] : -1;
     return MFAR_OK;
@@ -1292,7 +1389,7 @@ extern "C" int mfar_screen_field_info(mfar_index* idx, int field, int64_t* n_uni
 extern "C" int mfar_screen_stats(mfar_index* idx, int* built, int64_t* screen_bytes, int64_t* n_checked, int64_t* n_failed) {
     if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
     HIPCHK(hipSetDevice(idx->device));
-    const bool have = idx->screen.p && !idx->screen_dirty;
+    const bool have = idx->screen_built && !idx->screen_dirty;
     if (built) *built = have ? 1 : 0;
     if (screen_bytes) *screen_bytes = have ? (int64_t)idx->screen_used : 0;
     if (n_checked) *n_checked = idx->screen_checked;
@@ -1379,7 +1476,7 @@ static int run_score(mfar_index* idx, const float* q, int Q, const long long* ca
     p.F = idx->F;
     p.C = C;
     static const bool use_rep = !(getenv("MFAR_STAGE2_REP") && atoi(getenv("MFAR_STAGE2_REP")) == 0);   // diagnostic: 0 = gather every row itself
-    if (use_rep && idx->screen.p && !idx->screen_dirty && idx->u_repof.p) {   // the unique-row tables describe the rows as they are now
+    if (use_rep && idx->screen_built && !idx->screen_dirty && idx->u_repof.p) {   // the unique-row tables describe the rows as they are now
         p.repof = idx->u_repof.as<int>();
         p.ustride = idx->n_rows;
     }
@@ -1518,7 +1615,7 @@ extern "C" int mfar_mix_topk(int device, const float* cand_scores, const int64_t
 #define S2_MAX_MASKS 2
 static bool two_level_ok(const mfar_index* idx, int C, int k2, int query_cond, int n_masks) {
     if (idx->stage2_mode == 1 && n_masks > S2_MAX_MASKS) return false;
-    return idx->stage2_mode >= 1 && idx->dtype == MFAR_DTYPE_F32 && idx->gslab_ok && idx->screen.p && !idx->screen_dirty && C > k2 &&
+    return idx->stage2_mode >= 1 && idx->dtype == MFAR_DTYPE_F32 && idx->gslab_ok && idx->screen_built && !idx->screen_dirty && C > k2 &&
            k2 <= SEL_MAX_K && PRUNE_LDS_BYTES(C, query_cond ? idx->E : 0, idx->F) <= 160 * 1024;
 }
 //   cand / ncand [Q, C] / [Q]: the candidates to score (sorted unique ids);  masks [n_masks, F] or nullptr (ones, n_masks = 1)

@@ -386,6 +386,129 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// bf16 indexes: the certified pass needs NO second copy of the rows.  The docs of the scan are the index's own bf16 values
+// (exact), the query is split into two bf16 terms Q = hi + mid (|q_i - Q_i| <= 2^-16 |q_i|), every product is exact in fp32:
+//   |approx - exact chain| <= [2^-16 + (4 K + 66) u32 + K u32] sum|q_i||d_i| + tiny        (query residual; fp32 accumulation of
+//   2 K products in any order at 2 u32 per addition; the exact natural-order chain's own K u32; "tiny" covers bf16 / fp32
+//   subnormals that an MFMA may flush: 2^-118 (sqrt(K) (|q|_2 + |d|_2) + K)), with sum|q||d| <= |q|_2 max_row |d|_2, times
+//   SCREEN_SLACK.  No centring, no scaling (bf16 has fp32's exponent range): ScreenField = {1, 1, largest row norm, 0}, the
+//   field mean is the zero vector and ScreenQuery = {1, 1, |q|_2}, so the certify kernel runs unchanged.
+// The pass scans every document but ranks UNIQUE rows: mfar_rep_bits_kernel packs "real row and representative of its group"
+// into one bit per row (S1Params::rep_bits) and uof maps a representative's row to its unique number (CertifyParams::uof).
+// ---------------------------------------------------------------------------------------------------------
+// largest row norm^2 of one bf16 field -> stats[1] (bits; NaN / inf poison the maximum as in mfar_screen_stats_kernel).
+// grid = n_blk, block 128: thread = granule (tid & 1) of row (tid >> 1); the sum of squares does not care about the tile swizzle.
+__global__ void __launch_bounds__(128) mfar_direct_stats_kernel(const unsigned short* __restrict__ field, int n_steps, long long n_rows,
+                                                                u32* __restrict__ stats) {
+    const int rr = threadIdx.x >> 1;
+    const bool live = (long long)blockIdx.x * 64 + rr < n_rows;
+    const unsigned short* tile = field + (size_t)blockIdx.x * n_steps * 1024 + threadIdx.x * 8;
+    float ss = 0.0f;
+    if (live)
+        for (int s = 0; s < n_steps; ++s) {
+            const bf16x8 v = *(const bf16x8*)(tile + (size_t)s * 1024);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float x = bf2f((unsigned short)v[i]);
+                ss = __builtin_fmaf(x, x, ss);
+            }
+        }
+    ss += __shfl_xor(ss, 1);
+    u32 n = __float_as_uint(ss) & 0x7FFFFFFFu;
+    for (int off = 32; off > 0; off >>= 1) n = max(n, (u32)__shfl_xor((int)n, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(&stats[1], n);
+}
+__global__ void mfar_direct_fields_kernel(const u32* __restrict__ stats, int F, ScreenField* __restrict__ sf) {
+    const int f = threadIdx.x;
+    if (f >= F) return;
+    ScreenField o;
+    o.scale = o.inv_scale = 1.0f;
+    o.dnorm_max = sqrtf(__uint_as_float(stats[2 * f + 1])) * 1.0001f;   // (the fp32 sum of squares can be low by K u32 relative)
+    o.mnorm = 0.0f;
+    sf[f] = o;
+}
+// bits[b] bit r = row 64 b + r exists and (is_rep == nullptr or is_rep[row]).  grid = n_words, block 64.
+__global__ void __launch_bounds__(64) mfar_rep_bits_kernel(const u32* __restrict__ is_rep, long long n_rows, u64* __restrict__ bits) {
+    const long long row = (long long)blockIdx.x * 64 + threadIdx.x;
+    const u64 m = __ballot(row < n_rows && (!is_rep || is_rep[row] != 0u));
+    if (threadIdx.x == 0) bits[blockIdx.x] = m;
+}
+__global__ void mfar_iota1_kernel(u32* __restrict__ a, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (u32)i + 1u;
+}
+
+// Queries of one block of qw = 64 / 128 queries for the certified bf16 pass: two bf16 terms per query,
+//   qw == 64:  tiles [n_steps][2 terms][64][16]                 (mfar_stage1_bf16s_kernel);
+//   qw == 128: tiles [n_steps][2 terms][2 query blocks][64][16] (mfar_stage1_bf16w_kernel);
+// eps per (field, query) in real units, tau_base, the batch's fail flags -- as mfar_screen_queries_kernel.  grid = qw, block 256.
+__global__ void __launch_bounds__(256) mfar_direct_queries_kernel(const float* __restrict__ q, unsigned short* __restrict__ qt,
+                                                                  ScreenQuery* __restrict__ qinfo, const ScreenField* __restrict__ sf,
+                                                                  float* __restrict__ eps, float* __restrict__ tau_base,
+                                                                  int* __restrict__ fail_flags, int q0, int Q, int E, int F,
+                                                                  float eps_mult, int qw) {
+    __shared__ float red_s[4];
+    const int r = blockIdx.x;
+    if (r == 0 && (int)threadIdx.x <= MFAR_MAX_FIELDS) fail_flags[threadIdx.x] = 0;
+    const bool live = q0 + r < Q;
+    const float* row = q + (size_t)(q0 + (live ? r : 0)) * E;
+    ScreenField fld = {};
+    if ((int)threadIdx.x < F) fld = sf[threadIdx.x];
+    float ss = 0.0f;
+    const int n_tiles_step = qw == 128 ? 4 : 2;                     // 2 KB tiles per k-step
+    for (int g = threadIdx.x; g < (E >> 3); g += blockDim.x) {
+        const int e = g << 3;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+        if (live) {
+            a = *(const f32x4*)(row + e);
+            b = *(const f32x4*)(row + e + 4);
+        }
+        bf16x8 hi, mid;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float x = i < 4 ? a[i] : b[i - 4];
+            ss = __builtin_fmaf(x, x, ss);
+            const unsigned short hh = f2bf(x);
+            hi[i] = (short)hh;
+            mid[i] = (short)f2bf(x - bf2f(hh));                     // the residual of a round-to-nearest split is exact in fp32
+        }
+        const int step = e >> 4;
+        const size_t in_tile = tiled_offset_bf16(E >> 4, r & 63, e) - (size_t)step * 1024;
+        unsigned short* base = qt + (size_t)step * 1024 * n_tiles_step;
+        if (qw == 128) {                                            // tile = term * 2 + query block
+            *(bf16x8*)(base + (size_t)(r >> 6) * 1024 + in_tile) = hi;
+            *(bf16x8*)(base + (size_t)(2 + (r >> 6)) * 1024 + in_tile) = mid;
+        } else {                                                    // tile = term
+            *(bf16x8*)(base + in_tile) = hi;
+            *(bf16x8*)(base + 1024 + in_tile) = mid;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    ss = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
+    const float qn = sqrtf(ss) * 1.0001f;
+    if (threadIdx.x == 0) {
+        ScreenQuery o;
+        o.scale = o.inv_scale = 1.0f;
+        o.norm = qn;
+        o.pad = 0.0f;
+        qinfo[r] = o;
+    }
+    if ((int)threadIdx.x < F) {
+        const int f = threadIdx.x;
+        const float K = (float)E, u32f = 5.9604645e-8f;
+        const float c_rel = 1.01f * 1.52587890625e-5f + (5.0f * K + 66.0f) * u32f;
+        const float tiny = 3.0e-36f * (sqrtf(K) * (qn + fld.dnorm_max) + K);    // 2^-118 = 3.01e-36
+        float e_ = SCREEN_SLACK * (c_rel * qn * fld.dnorm_max + tiny);
+        e_ *= eps_mult;
+        if (!live) e_ = 0.0f;
+        eps[f * qw + r] = e_;
+        tau_base[f * qw + r] = live ? -__builtin_inff() : __builtin_inff();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Certify: exact top-k DOCUMENTS of the k' re-scored unique rows of one (query, field) + the certificate.
 //   grid = Qt * nf, block 256.
 // ---------------------------------------------------------------------------------------------------------
@@ -408,6 +531,9 @@ struct CertifyParams {
     const int* ustart;
     const int* ucount;
     const int* members;
+    const u32* uof;           // [F][ustride] or nullptr.  The certified pass over a bf16 slab scans documents: its lists hold LOCAL
+                              // ROWS of group representatives, and uof[f][row] - 1 is the row's unique number (mfar_direct_* below);
+                              // nullptr: the lists hold unique-row numbers (the fp16 screen slab of an fp32 index)
     long long ustride;
     long long row_offset;
     int f0, nf, k, kp, q0, sentinel;
@@ -435,8 +561,9 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
     u32 my_u = 0, my_bits = 0;
     bool mine = false;
     if ((int)threadIdx.x < cnt) {
-        const long long u = p.sid[lb + threadIdx.x];
+        long long u = p.sid[lb + threadIdx.x];
         const float s = p.sx[lb + threadIdx.x];
+        if (u >= 0 && p.uof) u = (long long)p.uof[(size_t)f * p.ustride + u] - 1;
         if (u >= 0 && s > tau0) {
             mine = true;
             my_u = (u32)u;
@@ -498,7 +625,8 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
     const int m_out = block_topk_sorted<4>(keys, total, p.k, sel, sorted, red);
     // 3. certificate
     if (threadIdx.x == 0) {
-        bool ok = overflow_s == 0;
+        // (a non-finite bound -- non-finite query or rows -- proves nothing, not even that a short list is complete)
+        bool ok = overflow_s == 0 && p.eps[f * p.qw + ql] < __builtin_inff();
         float a_real = 0.0f, bound = 0.0f;
         if (ok && cnt == p.kp) {  // the list is full: unique rows outside it exist
             const float qm = (qm_s[0] + qm_s[1]) + (qm_s[2] + qm_s[3]);

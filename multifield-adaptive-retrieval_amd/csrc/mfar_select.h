@@ -638,6 +638,10 @@ enum { SRC_F32 = 0, SRC_F16G = 1, SRC_BF16G = 2 };
 template <int SRC>
 __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_kernel(const ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef MFAR_TRACE
+    const unsigned long long tr_t0 = wall_clock64();
+    struct TrEnd { unsigned long long t0; int k; __device__ ~TrEnd() { if (threadIdx.x == 0 && (blockIdx.x & 7) == 0 && (blockIdx.y & 3) == 0) trace_put(k, (int)(blockIdx.y * gridDim.x + blockIdx.x), 0, t0); } } tr_end_ = {tr_t0, 3 + SRC};
+#endif
     float* qs = (float*)(smem + (SCF_THREADS / 64) * SCF_WAVE_BYTES);
     const int qi = blockIdx.y;
     const int nc = p.n_cand ? p.n_cand[qi] : p.C;
@@ -936,6 +940,9 @@ __device__ __forceinline__ void mix_gate_weights(const float* __restrict__ q_row
 
 __global__ void __launch_bounds__(256) mfar_mix_topk_kernel(const MixParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef MFAR_TRACE
+    const unsigned long long tr_t0 = wall_clock64();
+#endif
     const SelLds L = sel_lds(smem, p.C);
     u64* keys = L.keys;
     u64 *sel = L.sel, *sorted = L.sorted;
@@ -967,6 +974,9 @@ __global__ void __launch_bounds__(256) mfar_mix_topk_kernel(const MixParams p) {
         p.scores[(size_t)qi * p.k + r] = r < m ? key_score(sorted[r]) : -__builtin_inff();
     }
     if (threadIdx.x == 0 && p.n_valid) p.n_valid[qi] = m;
+#ifdef MFAR_TRACE
+    if (threadIdx.x == 0) trace_put(2, (int)blockIdx.x, 0, tr_t0);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------

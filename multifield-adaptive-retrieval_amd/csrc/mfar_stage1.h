@@ -22,6 +22,21 @@
 #include "mfar_device.h"
 #include "mfar_tables.h"
 
+#ifdef MFAR_TRACE   // experiment builds only: one record per workgroup (kind, block, xcc << 8 | cu, units, start, end in wall-clock ticks)
+struct TraceRec { int kind, blk, where, units; unsigned long long t0, t1; };
+__device__ TraceRec g_trace[1 << 17];
+__device__ int g_trace_n;
+__device__ __forceinline__ void trace_put(int kind, int blk, int units, unsigned long long t0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int i = atomicAdd(&g_trace_n, 1);
+    if (i < (1 << 17)) {
+        TraceRec r = {kind, blk, (int)(((xcc & 15u) << 8) | ((hw >> 8) & 0xffu)), units, t0, (unsigned long long)wall_clock64()};
+        g_trace[i] = r;
+    }
+}
+#endif
 #define S1_THREADS 256
 #define S1_TILE_ROWS 256                     // rows per workgroup tile (4 waves x 64)
 #define S1_CAP 512                           // list capacity per (workgroup, query)
@@ -85,6 +100,16 @@ struct S1Params {
     const int* only_failed; // [F] or nullptr: workgroups of fields whose flag is 0 exit at once (screen fall-back pass)
     int dbg;                // profiling only (MFAR_S1_DEBUG): 1 = skip the selection epilogue (results invalid; note that
                             // the downstream kernels then have no candidates, so they no longer compete with stage 1)
+    const u64* rep_bits;    // [F][rep_stride] or nullptr: bit r of word b = row 64 b + r of the field is a real row AND the
+                            // representative (lowest member) of its group of bit-identical rows (mfar_screen.h).  The certified
+                            // passes over a bf16 slab scan every document but rank UNIQUE rows: the accumulators of all other
+                            // rows start at -inf (s1_acc_init), so they reach neither the sample nor the lists.
+    long long rep_stride;   // words per field
+    int* unit_ctr;          // [F] zeroed before the launch, or nullptr.  DYNAMIC WORK DISTRIBUTION of a full pass (wide kernels): a
+                            // workgroup is still bound to one field and one list per query (chunk_id), but instead of the fixed
+                            // tile range of its chunk it claims UNITS of unit_tiles consecutive tiles from the field's counter
+                            // until the field is exhausted (s1_unit_* below).  nullptr: the chunk's own range [t0, t1).
+    int unit_tiles;         // >= 2
 };
 
 // Wave-level compaction of one list: keep the k best of n (k < n <= S1_CAP) entries, return the k-th best score.
@@ -208,6 +233,30 @@ __device__ __forceinline__ void s1_mask_rows(int n_rows, int t, int w, f32x16& a
             const int row = row_w + (r & 3) + 8 * (r >> 2);
             if (row >= n_rows) acc00[r] = acc01[r] = -__builtin_inff();
             if (row + 32 >= n_rows) acc10[r] = acc11[r] = -__builtin_inff();
+        }
+    }
+}
+
+// Starting values of the accumulators of one tile: 0, or -inf for the rows the pass must not rank (S1Params::rep_bits).  The
+// 64 flags of the wave's row block arrive by a SCALAR load (its own counter: a vector load here would make hipcc drain the doc
+// ring, which it does not know about, with vmcnt(0)); lane (j, h) holds rows 32 db + (r & 3) + 8 (r >> 2) + 4 h of doc block db.
+__device__ __forceinline__ u64 s1_sload_u64(const u64* ptr) {
+    u64 v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void s1_acc_init(const S1Params& p, const S1Chunk& ck, int t, int w, f32x16& i0, f32x16& i1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) i0[r] = i1[r] = 0.0f;
+    if (p.rep_bits) {   // kernel-uniform
+        const u64 bm = s1_sload_u64(p.rep_bits + (size_t)ck.f * p.rep_stride + (size_t)(4 * t + w));
+        const int sh = 4 * (int)((threadIdx.x & 63) >> 5);
+        const u32 lo = (u32)bm >> sh, hi = (u32)(bm >> 32) >> sh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = (r & 3) + 8 * (r >> 2);
+            i0[r] = ((lo >> b) & 1u) ? 0.0f : -__builtin_inff();
+            i1[r] = ((hi >> b) & 1u) ? 0.0f : -__builtin_inff();
         }
     }
 }
@@ -678,6 +727,8 @@ __device__ __forceinline__ void s1_body_x16(const S1Params& p, const int chunk_i
 // next batch that run beside this pass.  Needs n_steps % R == 0 (register slots are compile-time indices); the host
 // falls back to the LDS-ring kernel otherwise.
 // ---------------------------------------------------------------------------------------------------------------------
+//   MODE 2: bf16 slab scanned by the CERTIFIED pass (mfar_screen.h "bf16 indexes"): queries split into TWO bf16 terms (16 of
+//           their 24 significant bits; the docs are the index's own rows, exact), 64 columns; tiles as in MODE 1.
 template <int MODE, int R>
 struct S1XR {
     static constexpr int TERMS = MODE ? 2 : 3;
@@ -749,7 +800,10 @@ __device__ __forceinline__ void s1_body_x16r(const S1Params& p, const int chunk_
     for (int i = 0; i < R - 1; ++i) S1R_ISSUE(i);
 
     for (int t = t0; t < t1; ++t) {
-        f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+        f32x16 acc00, acc01, acc10, acc11;
+        s1_acc_init(p, ck, t, w, acc00, acc10);
+        acc01 = acc00;
+        acc11 = acc10;
         for (int s0 = 0; s0 < p.n_steps; s0 += R) {
 #pragma unroll
             for (int u = 0; u < R; ++u) {
@@ -773,6 +827,18 @@ __device__ __forceinline__ void s1_body_x16r(const S1Params& p, const int chunk_
                     acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qm1, acc01, 0, 0, 0);
                     acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qm0, acc10, 0, 0, 0);
                     acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qm1, acc11, 0, 0, 0);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qh0, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qh1, acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qh0, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qh1, acc11, 0, 0, 0);
+                } else if (MODE == 2) {
+                    const bf16x8 qh0 = *(const bf16x8*)(curq + off), qh1 = *(const bf16x8*)(curq + 1024 + off);
+                    const bf16x8 ql0 = *(const bf16x8*)(curq + 2048 + off), ql1 = *(const bf16x8*)(curq + 3072 + off);
+                    S1R_ISSUE((u + R - 1) % R);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, ql0, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, ql1, acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, ql0, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, ql1, acc11, 0, 0, 0);
                     acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qh0, acc00, 0, 0, 0);
                     acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, qh1, acc01, 0, 0, 0);
                     acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, qh0, acc10, 0, 0, 0);
@@ -931,6 +997,227 @@ __device__ __forceinline__ void s1_body_f16w(const S1Params& p, const int chunk_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Dynamic work distribution (S1Params::unit_ctr).  A scan grid is ONE wave of workgroups that fill the register file, and a
+// workgroup with a fixed chunk runs for the whole kernel: any workgroup the dispatcher places late -- because the small
+// kernels of the previous launch's tail hold its CU when the scan starts -- ends late by as much, while the CUs of the
+// punctual ones sit half empty (measured: 1.25 M x 16 bf16, scan 7.2 ms alone, 11.5 ms behind a 1.3 ms tail; 129 k x 22: 0.8 ->
+// 1.8 ms).  With units, a late workgroup simply claims fewer of them.  Lists stay per (workgroup, query): the merge does
+// not change, and neither do the results (a list is a set; thresholds only ever drop rows that k' better rows of the same
+// list beat).
+//   * the first unit is claimed synchronously, every further one a whole unit AHEAD by one lane's returning atomic issued in
+//     inline asm (no compiler wait), picked up at the epilogue of the current unit's first tile and published through LDS;
+//   * the prefetch cursor runs R - 1 k-steps ahead of the MFMAs and moves into the published unit when it leaves the current
+//     one; units hold >= 2 tiles except the last of a field, behind which nothing can follow, so a unit is always published
+//     before the cursor needs it.  With no unit to go to the cursor keeps re-reading its last stage (never consumed).
+// ---------------------------------------------------------------------------------------------------------------------
+struct S1Unit {           // workgroup-uniform
+    int t0, t1;           // tiles [t0, t1) of one field; t0 < 0: none
+};
+__device__ __forceinline__ S1Unit s1_unit_of(int u, int U, int n_tiles) {
+    S1Unit r;
+    r.t0 = u * U;
+    r.t1 = min(r.t0 + U, n_tiles);
+    if (u < 0 || r.t0 >= n_tiles) r.t0 = r.t1 = -1;
+    return r;
+}
+// one lane's returning atomic, invisible to hipcc's waitcnt insertion; `raw` is preset to -2 ("not back yet")
+__device__ __forceinline__ void s1_unit_claim_async(int* ctr, int& raw) {
+    const int one = 1;
+    asm volatile("v_mov_b32 %0, -2\n\tglobal_atomic_add %0, %1, %2, off sc0" : "=&v"(raw) : "v"(ctr), "v"(one) : "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// WIDE certified pass over a bf16 slab ("bf16w"): 128 query columns per scan, straight off the index's own bf16 rows -- no fp16
+// copy.  Two bf16 query terms (hi + mid = 16 significant bits; every product exact in fp32) x 128 columns = 16 MFMAs per 2 KB of
+// docs per wave: the slab is read once per 128 queries (the exact bf16 pass: three terms x 64 columns, once per 64), and the
+// only approximation left is the query's third term -- the certificate's eps is ~6x tighter than the fp16 screen's
+// (mfar_screen.h).  Structure of s1_body_f16w; the query stage is 8 KB per k-step ([term][query block][64][16]), two LDS-DMA
+// pieces per wave.  The pass scans every document and ranks unique rows (s1_acc_init).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int R, int SCAP_>
+struct S1BW {
+    static constexpr int Q_STAGE = 8192;
+    static constexpr int LOADS = 4;
+    static constexpr int SCAP = SCAP_;
+    static constexpr int LDS_BYTES = R * Q_STAGE + 2 * S1_STATE_BYTES_(SCAP_);
+};
+
+template <int R, int SCAP_>
+__device__ __forceinline__ void s1_body_bf16w(const S1Params& p, const int chunk_id) {
+    typedef S1BW<R, SCAP_> X;
+    typedef short vec8 __attribute__((ext_vector_type(8)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const qring = smem;
+    const S1State stA = s1_state(smem + R * X::Q_STAGE);
+    const S1State stB = s1_state(smem + R * X::Q_STAGE + S1_STATE_BYTES_(X::SCAP));
+    int* const unit_slot = stA.flag + 2;              // spare (8-byte aligned) words behind the compaction flag
+
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const S1Chunk ck = s1_load_chunk(p, chunk_id);    // workgroup-uniform
+    const int f = ck.f;
+    if (p.only_failed && !p.only_failed[f]) return;
+    const size_t wgq0 = (size_t)chunk_id * p.qw;      // qw == 128
+    s1_state_init(stA, p, f, 0);
+    s1_state_init(stB, p, f, 64);
+#ifdef MFAR_TRACE
+    const unsigned long long tr_t0 = wall_clock64();
+    int tr_units = 0;
+#endif
+
+    // the first unit: the chunk's own tile range, or -- dynamic distribution, full passes only -- claimed from the field's counter
+    const bool dyn = p.unit_ctr != nullptr && !p.sample;
+    const int n_tiles_f = max(1, (ck.n_rows + S1_TILE_ROWS - 1) / S1_TILE_ROWS);
+    int* const ctr = dyn ? p.unit_ctr + f : nullptr;
+    S1Unit cur;
+    cur.t0 = ck.t0;
+    cur.t1 = ck.t1;
+    if (p.sample) cur.t1 = min(cur.t1, cur.t0 + (p.sample == 2 ? ck.ns : p.sample_tiles));
+    if (dyn) {
+        if (tid == 0) *unit_slot = atomicAdd(ctr, 1);
+        __syncthreads();
+        cur = s1_unit_of(__builtin_amdgcn_readfirstlane(*unit_slot), p.unit_tiles, n_tiles_f);
+        __syncthreads();
+    }
+    S1Unit nxt;                                       // the published unit behind `cur`
+    nxt.t0 = nxt.t1 = -1;
+    int raw = -1;                                     // wave 0, lane 0: the pending claim
+
+    // Addresses: a wave-uniform 64-bit base in SGPRs + ONE per-lane 32-bit offset.  The epilogue below needs every VGPR it can
+    // get (8 accumulators + the ring in flight); per-lane 64-bit cursors were spilled around it, and hipcc answers the reload of a
+    // value the k-loop uses with a vmcnt wait INSIDE the loop that drains the doc ring (it does not count the asm loads).
+    const size_t step_bytes = 2048;
+    const size_t tile_jump = (size_t)3 * p.n_steps * step_bytes;
+    const char* const fbase = (const char*)p.slab + (size_t)ck.base * 2 + (size_t)w * p.n_steps * step_bytes;   // block w of tile 0      // uniform
+    const size_t tile_bytes = (size_t)4 * p.n_steps * step_bytes;
+    const char* const qbase = (const char*)p.qt + w * 1024;   // wave w loads pieces w and 4 + w of the 8 KB stage        // uniform
+    const u32 ldsq = (u32)(uintptr_t)qring + (u32)w * 1024u;                                                            // uniform
+    // prefetch cursor (uniform): next stage to issue; tiles of its unit not completely issued yet; whether it has moved into `nxt`
+    const char* dnext = fbase + (size_t)max(cur.t0, 0) * tile_bytes;
+    int s_next = 0, pf_left = cur.t1 - cur.t0, pf_in_next = 0, pf_clamped = cur.t0 < 0 ? 1 : 0;
+    vec8 dr0[R], dr1[R];
+    // per-lane offsets, recomputed from the lane id at every tile (two VALU ops; never worth a spill slot)
+    int lane = tid & 63;
+    int off = (lane & 31) * 32 + ((((lane >> 5) ^ ((lane >> 3) & 1)) & 1) << 4);   // granule of row (32 blk + j), k-half h in a 2 KB tile
+    int l16 = lane * 16;
+#define S1BW_QDMA(VO, SB, M0)                                                                                      \
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(VO), "s"(SB), "s"(M0) : "memory")
+#define S1BW_ISSUE(SLOT)                                                                                  \
+    do {                                                                                                  \
+        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=&v"(dr0[SLOT]) : "v"(off), "s"(dnext) : "memory");               \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024 nt" : "=&v"(dr1[SLOT]) : "v"(off), "s"(dnext) : "memory");   \
+        const char* qs_ = qbase + (size_t)s_next * X::Q_STAGE;                                            \
+        S1BW_QDMA(l16, qs_, ldsq + (u32)((SLOT) * X::Q_STAGE));                                           \
+        S1BW_QDMA(l16, qs_ + 4096, ldsq + (u32)((SLOT) * X::Q_STAGE + 4096));                             \
+        if (!pf_clamped) {                                                                                \
+            dnext += step_bytes;                                                                          \
+            if (++s_next == p.n_steps) {                                                                  \
+                s_next = 0;                                                                               \
+                if (--pf_left > 0) dnext += tile_jump;                                                    \
+                else if (nxt.t0 >= 0 && !pf_in_next) {   /* into the published unit */                    \
+                    dnext = fbase + (size_t)nxt.t0 * tile_bytes;                                          \
+                    pf_left = nxt.t1 - nxt.t0;                                                            \
+                    pf_in_next = 1;                                                                       \
+                } else {                                 /* nothing follows: keep re-reading the last stage */ \
+                    dnext -= step_bytes;                                                                  \
+                    s_next = p.n_steps - 1;                                                               \
+                    pf_clamped = 1;                                                                       \
+                }                                                                                         \
+            }                                                                                             \
+        }                                                                                                 \
+    } while (0)
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) S1BW_ISSUE(i);
+
+    while (cur.t0 >= 0) {
+        if (dyn && w == 0 && (tid & 63) == 0) s1_unit_claim_async(ctr, raw);      // the unit after this one
+        for (int t = cur.t0; t < cur.t1; ++t) {
+            lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(lane));
+            off = (lane & 31) * 32 + ((((lane >> 5) ^ ((lane >> 3) & 1)) & 1) << 4);
+            l16 = lane * 16;
+            // [query block A/B][doc block][query half]
+            f32x16 a00, a01, a10, a11, b00, b01, b10, b11;
+            s1_acc_init(p, ck, t, w, a00, a10);
+            a01 = b00 = b01 = a00;
+            a11 = b10 = b11 = a10;
+            for (int s0 = 0; s0 < p.n_steps; s0 += R) {
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    asm volatile("s_waitcnt vmcnt(%2)\n\ts_barrier" : "+v"(dr0[u]), "+v"(dr1[u]) : "n"((R - 2) * X::LOADS) : "memory");
+                    const char* curq = qring + u * X::Q_STAGE;
+                    const vec8 d0 = dr0[u], d1 = dr1[u];
+                    // tiles of the stage: hi / block A, hi / block B, mid / block A, mid / block B
+                    const bf16x8 ma0 = *(const bf16x8*)(curq + 4096 + off), ma1 = *(const bf16x8*)(curq + 5120 + off);
+                    const bf16x8 mb0 = *(const bf16x8*)(curq + 6144 + off), mb1 = *(const bf16x8*)(curq + 7168 + off);
+                    const bf16x8 ha0 = *(const bf16x8*)(curq + off), ha1 = *(const bf16x8*)(curq + 1024 + off);
+                    const bf16x8 hb0 = *(const bf16x8*)(curq + 2048 + off), hb1 = *(const bf16x8*)(curq + 3072 + off);
+                    S1BW_ISSUE((u + R - 1) % R);
+                    // smallest term first (all products are exact; this keeps the fp32 accumulation tight)
+                    a00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, ma0, a00, 0, 0, 0);
+                    a01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, ma1, a01, 0, 0, 0);
+                    a10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, ma0, a10, 0, 0, 0);
+                    a11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, ma1, a11, 0, 0, 0);
+                    b00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, mb0, b00, 0, 0, 0);
+                    b01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, mb1, b01, 0, 0, 0);
+                    b10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, mb0, b10, 0, 0, 0);
+                    b11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, mb1, b11, 0, 0, 0);
+                    a00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, ha0, a00, 0, 0, 0);
+                    a01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, ha1, a01, 0, 0, 0);
+                    a10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, ha0, a10, 0, 0, 0);
+                    a11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, ha1, a11, 0, 0, 0);
+                    b00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, hb0, b00, 0, 0, 0);
+                    b01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, hb1, b01, 0, 0, 0);
+                    b10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, hb0, b10, 0, 0, 0);
+                    b11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, hb1, b11, 0, 0, 0);
+                }
+            }
+            if (p.dbg & 1) {
+                asm volatile("" ::"v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(b00), "v"(b01), "v"(b10), "v"(b11));
+                if (!dyn) continue;
+            } else if (p.sample == 2) {
+                s1_sample_top2(p, ck, t - cur.t0, t, w, a00, a01, a10, a11, 0);
+                s1_sample_top2(p, ck, t - cur.t0, t, w, b00, b01, b10, b11, 64);
+                continue;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A (see the fp32 body)
+            if (dyn && t == cur.t0 && tid == 0) {         // the claim issued a whole tile ago is back: publish it (read after barrier B)
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw) : "n"((R - 1) * X::LOADS) : "memory");
+                if (raw == -2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw)::"memory");
+                lds_write_b64((u32)(uintptr_t)unit_slot, (u64)(u32)raw);
+            }
+            if (!(p.dbg & 1)) {
+                s1_epilogue_append<X::SCAP>(p, stA, ck.n_rows, t, w, wgq0, a00, a01, a10, a11);
+                s1_epilogue_append<X::SCAP>(p, stB, ck.n_rows, t, w, wgq0 + 64, b00, b01, b10, b11);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier B for both blocks; the accumulators are dead from here
+            if (dyn && t == cur.t0) nxt = s1_unit_of(__builtin_amdgcn_readfirstlane((int)(u32)lds_read_b64((u32)(uintptr_t)unit_slot)), p.unit_tiles, n_tiles_f);
+            if (!(p.dbg & 1)) {
+                s1_epilogue_finish<X::SCAP>(p, stA, w, wgq0);
+                s1_epilogue_finish<X::SCAP>(p, stB, w, wgq0 + 64);
+            }
+        }
+        cur = nxt;
+        nxt.t0 = nxt.t1 = -1;
+        pf_in_next = 0;
+#ifdef MFAR_TRACE
+        ++tr_units;
+#endif
+    }
+#ifdef MFAR_TRACE
+    if (tid == 0 && !p.sample) trace_put(1, (int)blockIdx.x, tr_units, tr_t0);
+#endif
+#undef S1BW_ISSUE
+#undef S1BW_QDMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.sample != 2) {
+        s1_flush<X::SCAP>(p, stA, w, wgq0);
+        s1_flush<X::SCAP>(p, stB, w, wgq0 + 64);
+    }
+}
+
 // The exact passes (fp32, bf16) double as REPAIR passes of the certified screen (only_failed): their table is then cut finely
 // (every field into up to a whole wave of chunks, so that a single failed field is scanned by the whole GPU), but launched as
 // ONE wave of workgroups that walk it -- the workgroups of fields that did not fail would otherwise cost more to dispatch
@@ -972,4 +1259,27 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_sample_kernel(
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_kernel(const S1Params p) { s1_body_f16w<4>(p, p.chunk0 + (int)blockIdx.x); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_sample_kernel(const S1Params p) { s1_body_f16w<4>(p, p.chunk0 + (int)blockIdx.x); }
 #define S1HW_LDS_BYTES (6 * 4096 + 2 * S1_STATE_BYTES_(S1_SCAP_WIDE))
+// certified passes over a bf16 slab: 64 columns x two bf16 terms (register ring of 6 / 4 slots), 128 columns x two terms
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16s_kernel(const S1Params p) { s1_body_x16r<2, 6>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16s_sample_kernel(const S1Params p) { s1_body_x16r<2, 6>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16s4_kernel(const S1Params p) { s1_body_x16r<2, 4>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16s4_sample_kernel(const S1Params p) { s1_body_x16r<2, 4>(p, p.chunk0 + (int)blockIdx.x); }
+// LDS per workgroup decides more than occupancy here.  LDS is allocated first-fit and contiguously: when a scan workgroup is placed
+// while a small workgroup of the previous launch's tail still sits at the bottom of the CU's LDS (a row-gather workgroup holds
+// 35 KB), the free space behind it is split in two once that workgroup leaves, and the CU's SECOND scan workgroup only fits if one
+// fragment holds it: 160 - 35 - 2 x LDS >= 0.  At 66.6 KB (6-slot ring, 16-entry staging) 40 % of the CUs ran ONE scan workgroup
+// for a whole scan (1.25 M x 16: 7.2 ms alone, 11.5 ms in the pipeline; workgroup trace in profiles/r04_a_lds_fragmentation.txt);
+// at 50.5 KB (4-slot ring, measured equal alone) the pipeline runs the scan in 7.5 ms.  Keep every scan kernel under ~60 KB.
+#ifndef S1BW_SCAP6
+#define S1BW_SCAP6 8                         // 6-slot query ring (48 KB): dims whose k-steps do not divide by 4
+#endif
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w_kernel(const S1Params p) { s1_body_bf16w<6, S1BW_SCAP6>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w_sample_kernel(const S1Params p) { s1_body_bf16w<6, S1BW_SCAP6>(p, p.chunk0 + (int)blockIdx.x); }
+#ifndef S1BW_SCAP4
+#define S1BW_SCAP4 16
+#endif
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w4_kernel(const S1Params p) { s1_body_bf16w<4, S1BW_SCAP4>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w4_sample_kernel(const S1Params p) { s1_body_bf16w<4, S1BW_SCAP4>(p, p.chunk0 + (int)blockIdx.x); }
+#define S1BW_LDS_BYTES (6 * 8192 + 2 * S1_STATE_BYTES_(S1BW_SCAP6))
+#define S1BW4_LDS_BYTES (4 * 8192 + 2 * S1_STATE_BYTES_(S1BW_SCAP4))
 #define S1HW4_LDS_BYTES (4 * 4096 + 2 * S1_STATE_BYTES_(S1_SCAP_WIDE))

@@ -14,7 +14,7 @@ import subprocess
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # .../multifield-adaptive-retrieval_amd
-LIB_PATH = os.path.join(_PKG, "lib", "libmfar_hip.so")
+LIB_PATH = os.environ.get("MFAR_LIB_PATH") or os.path.join(_PKG, "lib", "libmfar_hip.so")   # (override: experiment builds)
 CSRC = os.path.join(_PKG, "csrc")
 
 MFAR_OK = 0

@@ -416,7 +416,9 @@ class MultiFieldIndex:
         st = dict(built=bool(built.value), screen_bytes=nbytes.value, n_checked=chk.value, n_failed=bad.value)
         if st["built"]:
             st["unique_rows"] = [self.screen_field_info(f)[0] for f in range(self.n_fields)]
-            st["scan_rows"] = sum(st["unique_rows"])
+            # rows one screened scan reads: the unique rows of the fp16 screen slab (fp32 index) / every document of the bf16
+            # slab itself (bf16 index: no second copy; duplicates are scanned and masked)
+            st["scan_rows"] = sum(st["unique_rows"]) if self.dtype == "f32" else self.n_rows * self.n_fields
         return st
 
 

@@ -68,6 +68,8 @@ class PipelinedSearcher:
         if not 2 <= self.depth <= 4:
             raise ValueError("pipeline depth must be 2, 3 or 4")
         self.sides = [torch.cuda.Stream(device=self.dev, priority=-1 if flip else 0) for _ in range(2 if self.depth > 2 else 1)]
+        if os.environ.get("MFAR_PIPE_SERIAL", "0") == "1":      # diagnostic: tails on the scan stream (no kernel of a tail beside a scan)
+            self.sides = [self.main]
         self.side = self.sides[0]
         index.set_repair_mode(True)   # repairs are launched here only after a failure was reported (or when they are frequent)
         self.Qb = int(max_batch)      # queries per submitted batch (at most)

@@ -37,9 +37,13 @@ def test_ring_registers_are_never_copied_before_their_wait(asm):
     for name, body in _kernels(asm):
         ring = set()
         for line in body:
-            m = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\], v\[\d+:\d+\], off", line)   # the inline-asm ring loads (flat address, no SGPR base)
+            # the inline-asm ring loads (non-temporal): a per-lane 64-bit address, or a per-lane 32-bit offset on an SGPR base
+            m = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\], (?:v\[\d+:\d+\], off|v\d+, s\[\d+:\d+\])(?: offset:\d+)? nt", line)
             if m:
                 ring.update(range(int(m.group(1)), int(m.group(2)) + 1))
+            m = re.search(r"global_atomic_add v(\d+), v\[\d+:\d+\], v\d+, off sc0", line)   # the asynchronous unit claim (s1_unit_claim_async)
+            if m:
+                ring.add(int(m.group(1)))
         if not ring:
             continue                                  # an LDS-ring kernel: docs never sit in registers while in flight
         checked += 1
@@ -50,7 +54,7 @@ def test_ring_registers_are_never_copied_before_their_wait(asm):
             if m:
                 src = range(int(m.group(3)), int(m.group(4) or m.group(3)) + 1)
                 assert not any(r in ring for r in src), f"{name}: '{line.strip()}' reads a doc-ring register"
-    assert checked >= 10, checked                     # f16r / f16r4 / bf16r / bf16r4 / f16w / f16w4, full + sample pass
+    assert checked >= 20, checked                     # f16r / f16r4 / bf16r / bf16r4 / f16w / f16w4 / bf16s / bf16s4 / bf16w / bf16w4, full + sample pass
 
 
 def test_scan_loops_do_not_touch_scratch(asm):

@@ -544,21 +544,25 @@ def test_bf16_sharded_equals_unsharded(idxmod):
 
 def test_bf16_stress_shape_per_gpu(idxmod):
     """BASELINE.json configs[4] (10M docs x 16 fields x 768d bf16 over 8 GPUs) at its PER-GPU shape: 1.25M x 16 x 768 bf16
-    = 30.7 GB (+ the row-major companion for gathers).  Plain bf16 pass: size-independent properties, an EXHAUSTIVE torch check
-    of the stage-1 lists of three queries, re-sharding invariance.  Certified screen (`set_screen(2)`, bench.py --screen on):
-    the same exhaustive check and the oracle (natural-order chain over the bf16 rows, the bf16 contract) bit for bit -- stage-1
-    lists and the final top-100 -- on a row subset that holds every list member; documents returned by both runs carry equal bits."""
+    = 30.7 GB (+ the row-major companion for gathers), on the DEFAULT path: the certified pass over the bf16 slab itself (two bf16
+    query terms; 64 columns here, 128 for larger blocks).  Size-independent properties, an EXHAUSTIVE torch check of the stage-1
+    lists of three queries, and the oracle (natural-order chain over the bf16 rows, the bf16 contract) BIT FOR BIT -- stage-1 lists
+    and the final top-100 -- on a row subset that holds every list member; a block of 128 queries through the wide pass returns the
+    same bits; the plain bf16 MFMA pass (screen off) agrees to its 1e-4; re-sharding invariance."""
     import torch
     from mfar import synth
     D, F, E, Q = 1_250_000, 16, 768, 64
     if torch.cuda.mem_get_info(0)[0] < 130 << 30:
         pytest.skip("needs ~110 GB of free HBM")
-    corpus = synth.SyntheticCorpus(D, F, E, n_queries=Q, seed=0xdeadbeef, device="cuda:0")
+    corpus = synth.SyntheticCorpus(D, F, E, n_queries=2 * Q, seed=0xdeadbeef, device="cuda:0")
     ix = corpus.build_index(idxmod, dtype="bf16")
     q, W = corpus.queries(0, Q), corpus.W
     r1 = ix.search(q, W, None, return_fields=True)
     r2 = ix.search(q, W, None)
     torch.cuda.synchronize()
+    st = ix.screen_stats()
+    assert st["built"] and st["n_checked"] >= 2 * Q * F and st["n_failed"] == 0 and st["screen_bytes"] == 0, st
+    assert ix.stage2_stats()["gather_slab_bytes"] <= ix.slab_bytes * 1.01      # resident rows <= 2.0 x the slab (companion only)
     assert torch.equal(r1["ids"], r2["ids"]) and torch.equal(r1["scores"], r2["scores"])
     sc = r1["scores"].cpu().numpy()
     assert (np.diff(sc, axis=1) <= 0).all() and (r1["n_valid"].cpu().numpy() == 100).all()
@@ -566,17 +570,20 @@ def test_bf16_stress_shape_per_gpu(idxmod):
     assert np.mean([len(set(r1["ids"][i, :20].tolist()) & rel[i]) / len(rel[i]) for i in range(Q)]) > 0.9
     probe = [0, 17, 63]
     _exhaustive_stage1_check(ix, q, r1["field_ids"].cpu().numpy(), r1["field_scores"].cpu().numpy(), probe)
-    # the certified screen over the bf16 rows: lists and final scores are the exact natural-order chain's, bit for bit
-    ix.set_screen(2)
+    with O.chain("natural"):
+        _oracle_check_on_subset(ix, q, W, None, r1, probe)
+    # 128 queries in one call: the wide pass (128 columns per scan); the first 64 are the queries above -- same bits
+    rw = ix.search(corpus.queries(0, 2 * Q), W, None, return_fields=True)
+    torch.cuda.synchronize()
+    for key in ("ids", "scores", "field_ids", "field_scores"):
+        assert torch.equal(rw[key][:Q], r1[key]), key
+    assert ix.screen_stats()["n_failed"] == 0
+    # plain pass vs certified pass: the plain MFMA pass's stage-1 scores agree with the chain to 1e-4, so a list may swap a member
+    # at a near-tied cut-off and with it one final candidate; every document BOTH runs return carries the same exact score bits
+    ix.set_screen(0)
     r3 = ix.search(q, W, None, return_fields=True)
     torch.cuda.synchronize()
-    st = ix.screen_stats()
-    assert st["built"] and st["n_checked"] >= Q * F, st
     _exhaustive_stage1_check(ix, q, r3["field_ids"].cpu().numpy(), r3["field_scores"].cpu().numpy(), probe)
-    with O.chain("natural"):
-        _oracle_check_on_subset(ix, q, W, None, r3, probe)
-    # plain pass vs certified screen: the plain MFMA pass's stage-1 scores agree with the chain to 1e-4, so a list may swap a member
-    # at a near-tied cut-off and with it one final candidate; every document BOTH runs return carries the same exact score bits
     i1, s1, i3, s3 = (r[k].cpu().numpy() for r in (r1, r3) for k in ("ids", "scores"))
     for qi in range(Q):
         common, a, b = np.intersect1d(i1[qi], i3[qi], return_indices=True)
@@ -1229,18 +1236,18 @@ def test_fused_mode_bit_exact_and_recall(idxmod):
 
 
 def test_bf16_index_with_certified_screen(idxmod):
-    """A bf16 index with the screen switched on (opt-in: it doubles the index's footprint): stage 1 scans an fp16 copy of each
-    field's unique rows (wide pass for more than 64 queries), re-scores with the bf16 contract's exact natural-order chain and
-    proves the lists -- which makes them BIT-identical to the oracle (the plain bf16 MFMA pass is only within 1e-4), duplicate
-    groups included; a forced fall-back stays within the plain pass's tolerance."""
+    """A bf16 index runs the CERTIFIED pass by default (from 16 384 rows, like an fp32 index): stage 1 scans the bf16 slab itself --
+    no second copy of the rows -- with the query split into two bf16 terms (64 columns per scan, 128 for blocks of more than 64
+    queries), re-scores the k' best unique rows of every list with the bf16 contract's exact natural-order chain and proves the
+    lists, which makes them BIT-identical to the oracle (the plain three-term MFMA pass is only within 1e-4).  The pass scans every
+    document but ranks unique rows (duplicate groups are masked down to their representative and expanded by the certificate);
+    a forced fall-back (every certificate fails) stays within the plain pass's tolerance."""
     rng = np.random.default_rng(61)
-    for F, D, E, Q, dup in ((3, 30000, 96, 70, 0), (2, 40000, 768, 128, 3000), (1, 20000, 64, 9, 0)):
+    for F, D, E, Q, dup in ((3, 30000, 96, 70, 0), (2, 40000, 768, 128, 3000), (1, 20000, 64, 9, 0), (2, 17000, 128, 200, 500)):
         slab, q, W = _mk(rng, F, D, E, Q, dup=dup)
         rs = O.bf16_round(slab)
         ix = _load_bf16(idxmod, slab)
-        assert ix.max_split_batch(100) == 64           # off by default for bf16 indexes
-        ix.set_screen(2)
-        assert ix.max_split_batch(100) == 128
+        assert ix.max_split_batch(100) == 128          # on by default: the wide pass serves blocks of more than 64 queries
         r = ix.search(q, W, None, return_fields=True)
         with O.chain("natural"):
             o = O.c_two_stage(rs, q, W, None)
@@ -1250,11 +1257,63 @@ def test_bf16_index_with_certified_screen(idxmod):
             assert np.array_equal(r[key].view(np.uint32), o[key].view(np.uint32)), (key, F, D, E, Q)
         st = ix.screen_stats()
         assert st["built"] and st["n_checked"] == Q * F and st["n_failed"] == 0, st
+        assert st["screen_bytes"] == 0 and st["scan_rows"] == D * F          # the scan reads the index's own rows
         if dup:
             assert min(st["unique_rows"]) <= D - dup + 1
+        ix.set_screen(0)                               # the plain bf16 pass: same lists up to its 1e-4
+        rp = ix.search(q, W, None, return_fields=True)
+        assert ix.screen_stats()["n_checked"] == Q * F
+        for f in range(F):
+            O.assert_topk_equivalent(rp["field_ids"][:, f], rp["field_scores"][:, f], o["field_ids"][:, f], o["field_scores"][:, f],
+                                     tol=TOL, what=f"plain bf16 pass f{f}")
         ix.set_screen(2, 1e9)                          # every certificate fails: the plain bf16 pass repairs
         rx = ix.search(q, W, None, return_fields=True)
         for f in range(F):
             O.assert_topk_equivalent(rx["field_ids"][:, f], rx["field_scores"][:, f], o["field_ids"][:, f], o["field_scores"][:, f],
                                      tol=TOL, what=f"bf16 forced fall-back f{f}")
         ix.close()
+
+
+def test_bf16_certified_pass_with_duplicates_on_top(idxmod):
+    """Groups of bit-identical rows at the TOP of every list (a low-cardinality field, Zipf duplicates, the planted best row
+    repeated 300 times), rows written in several pieces and rewritten afterwards, two row shards: the certified bf16 pass ranks
+    each distinct vector once, the certificate expands the groups (score desc, doc id asc) -- no list falls back, every bit is
+    the oracle's."""
+    rng = np.random.default_rng(62)
+    F, D, E, Q = 3, 50000, 192, 96
+    slab, q, W = _mk(rng, F, D, E, Q)
+    texts = (rng.standard_normal((10, E)) * 0.5).astype(np.float32)
+    slab[0] = texts[rng.integers(0, 10, D)]                            # ten distinct vectors in the whole field
+    z = np.minimum((np.exp(rng.random(D) * np.log(D / 4)) - 1).astype(np.int64), D // 4 - 1)
+    slab[1] = slab[1][z]                                               # Zipf-like duplicates
+    best = (q[0] / np.linalg.norm(q[0]) * 6.0).astype(np.float32)
+    slab[2, rng.choice(D, 300, replace=False)] = best                  # 300 copies of the row every query likes best
+    rs = O.bf16_round(slab)
+    with O.chain("natural"):
+        o = O.c_two_stage(rs, q, W, None)
+    ix = _load_bf16(idxmod, slab)
+    r = ix.search(q, W, None, return_fields=True)
+    st = ix.screen_stats()
+    assert st["built"] and st["n_failed"] == 0 and st["unique_rows"][0] == 10 and st["unique_rows"][2] <= D - 299, st
+    for key in ("field_ids", "ids"):
+        assert np.array_equal(r[key], o[key]), key
+    for key in ("field_scores", "scores"):
+        assert np.array_equal(r[key].view(np.uint32), o[key].view(np.uint32)), key
+    # rows rewritten: the tables follow
+    slab[2, 7:11] = best * 1.5
+    ix.write_rows(2, 7, slab[2, 7:11])
+    rs = O.bf16_round(slab)
+    with O.chain("natural"):
+        o2 = O.c_two_stage(rs, q[:64], W, None)
+    r2 = ix.search(q[:64], W, None, return_fields=True)                # 64 queries: the 64-column certified pass
+    assert np.array_equal(r2["field_ids"], o2["field_ids"]) and np.array_equal(r2["scores"].view(np.uint32), o2["scores"].view(np.uint32))
+    assert ix.screen_stats()["n_failed"] == 0
+    ix.close()
+    half = 23000
+    shards = [_load_bf16(idxmod, slab[:, :half]), _load_bf16(idxmod, slab[:, half:], row_offset=half)]
+    import torch
+    qd, Wd = torch.from_numpy(q[:64]).cuda(), torch.from_numpy(W).cuda()
+    rm = idxmod.merge_payloads(torch.cat([s_.search_local(qd) for s_ in shards]), 2, qd, Wd, None, n_fields=F)
+    assert np.array_equal(rm["ids"].cpu().numpy(), o2["ids"]) and np.array_equal(rm["scores"].cpu().numpy().view(np.uint32), o2["scores"].view(np.uint32))
+    for s_ in shards:
+        s_.close()
