@@ -113,8 +113,10 @@ def s1_kernel_name(dtype, screened, E, wide=False):
     if dtype == "bf16" and not screened:
         return f"mfar_stage1_bf16{rr}_kernel"
     if dtype == "bf16":          # the certified passes over the bf16 slab itself (two bf16 query terms)
-        if wide:
+        if wide and os.environ.get("MFAR_BF16_WIDE_TERMS") == "2":
             return "mfar_stage1_bf16w4_kernel" if (E // 16) % 4 == 0 else "mfar_stage1_bf16w_kernel"
+        if wide:                 # docs converted to fp16 in registers, one fp16 query term
+            return "mfar_stage1_bf16c_kernel" if (E // 16) % 6 == 0 else "mfar_stage1_bf16c4_kernel"
         return "mfar_stage1_bf16s_kernel" if (E // 16) % 6 == 0 else "mfar_stage1_bf16s4_kernel"
     if screened and wide:
         return "mfar_stage1_f16w_kernel" if (E // 16) % 6 == 0 else "mfar_stage1_f16w4_kernel"

@@ -133,6 +133,7 @@ struct mfar_index {
     bool screen_nomem = false;    // the screen slab could not be allocated: stay on the exact pass
     long long screen_checked = 0; // (query, field) lists certified so far
     DevBuf s_stats, s_field, s_mean;
+    DevBuf s_field1, s_cvt;       // bf16 index: ScreenField of the two-term passes (scale 1); conversion constants of the converted-docs pass
     // unique rows of every field (mfar_screen.h), each table [F][n_rows] (stride n_rows): representative document of a
     // unique row, start / length of its member run in `members` (local rows grouped by unique row, ascending inside a group)
     DevBuf u_rep, u_start, u_count, u_members, u_n;
@@ -197,6 +198,10 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16s4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HR4_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BW_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16w_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BW_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BC_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16c_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BC_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16c4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BC4_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16c4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BC4_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BW4_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16w4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BW4_LDS_BYTES));
     g_attr_done[device] = true;
@@ -298,7 +303,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
     DevBuf* bufs[] = {&idx->fid, &idx->fsc, &idx->s_stats, &idx->s_field, &idx->s_mean, &idx->screen, &idx->u_rep, &idx->u_start,
-                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->s2stats, &idx->rep_bits, &idx->u_of};
+                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->s2stats, &idx->rep_bits, &idx->u_of, &idx->s_field1, &idx->s_cvt};
     for (int i = 0; i < MFAR_SLOTS; ++i)
         for (DevBuf* b : {&idx->cand[i], &idx->ncand[i], &idx->x[i], &idx->own[i], &idx->xa[i], &idx->cand2[i], &idx->ncand2[i], &idx->s2qm[i],
                           &idx->s2eps[i], &idx->kmask[i], &idx->src2[i]})
@@ -539,10 +544,11 @@ struct S1Out {
     int sentinel;     // padding convention of the output lists
     long long row_offset;   // added to the local rows of the lists (0: the lists hold unique-row numbers)
 };
-enum { S1_F32 = 0, S1_BF16 = 1, S1_F16 = 2, S1_F16W = 3, S1_BF16S = 4, S1_BF16W = 5 };
+enum { S1_F32 = 0, S1_BF16 = 1, S1_F16 = 2, S1_F16W = 3, S1_BF16S = 4, S1_BF16W = 5, S1_BF16C = 6 };
 // S1_F16W: the wide (128-query, one fp16 term) screen pass of an fp32 index; S1_BF16S / S1_BF16W: the certified passes over a bf16
-// slab (two bf16 query terms; 64 / 128 columns)
-static bool s1_is_wide(int kind) { return kind == S1_F16W || kind == S1_BF16W; }
+// slab (two bf16 query terms; 64 / 128 columns); S1_BF16C: 128 columns over the same slab with the docs converted to fp16 in
+// registers and one fp16 query term (half the MFMAs; the default wide pass of a bf16 index)
+static bool s1_is_wide(int kind) { return kind == S1_F16W || kind == S1_BF16W || kind == S1_BF16C; }
 static int launch_s1(int kind, bool sample, unsigned n_chunks, unsigned wave, hipStream_t st, const S1Params& p_in) {
     S1Params p = p_in;
     p.n_launch = (int)n_chunks;
@@ -571,6 +577,14 @@ static int launch_s1(int kind, bool sample, unsigned n_chunks, unsigned wave, hi
         } else {
             if (sample) mfar_stage1_bf16w_sample_kernel<<<g, b, S1BW_LDS_BYTES, st>>>(p);
             else mfar_stage1_bf16w_kernel<<<g, b, S1BW_LDS_BYTES, st>>>(p);
+        }
+    } else if (kind == S1_BF16C) {
+        if (p.n_steps % 6 == 0) {
+            if (sample) mfar_stage1_bf16c_sample_kernel<<<g, b, S1BC_LDS_BYTES, st>>>(p);
+            else mfar_stage1_bf16c_kernel<<<g, b, S1BC_LDS_BYTES, st>>>(p);
+        } else {
+            if (sample) mfar_stage1_bf16c4_sample_kernel<<<g, b, S1BC4_LDS_BYTES, st>>>(p);
+            else mfar_stage1_bf16c4_kernel<<<g, b, S1BC4_LDS_BYTES, st>>>(p);
         }
     } else if (kind == S1_BF16S) {
         if (p.n_steps % 6 == 0) {
@@ -645,9 +659,10 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
     p.samp_out = nullptr;
     p.samp_stride = tb.samp_stride;
     p.only_failed = only_failed;
-    if (kind == S1_BF16S || kind == S1_BF16W) {     // documents are scanned, unique rows are ranked (mfar_stage1.h s1_acc_init)
+    if (kind == S1_BF16S || kind == S1_BF16W || kind == S1_BF16C) {     // documents are scanned, unique rows are ranked (mfar_stage1.h s1_acc_init)
         p.rep_bits = idx->rep_bits.as<u64>();
         p.rep_stride = idx->n_blk;
+        p.cvt = idx->s_cvt.as<uint2>();
     }
     {
         const char* dbg = getenv("MFAR_S1_DEBUG");
@@ -750,7 +765,7 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
         // dynamic work distribution (mfar_stage1.h s1_unit_*): the kernels that have it, full passes that are not repairs
         static const bool dyn_on = !(getenv("MFAR_S1_DYN") && atoi(getenv("MFAR_S1_DYN")) == 0);
         static const int unit_tiles = getenv("MFAR_UNIT_TILES") ? std::max(2, atoi(getenv("MFAR_UNIT_TILES"))) : 2;
-        if (dyn_on && !repair && kind == S1_BF16W) {
+        if (dyn_on && !repair && (kind == S1_BF16W || kind == S1_BF16C)) {
             RETCHK(sl.unit_ctr.ensure((size_t)MFAR_MAX_FIELDS * sizeof(int)));
             HIPCHK(hipMemsetAsync(sl.unit_ctr.p, 0, (size_t)MFAR_MAX_FIELDS * sizeof(int), st));
             p.unit_ctr = sl.unit_ctr.as<int>();
@@ -1005,7 +1020,10 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
                                                                                      idx->n_steps, idx->n_rows, idx->s_stats.as<u32>() + 2 * f);
             HIPCHK(hipGetLastError());
         }
-        mfar_direct_fields_kernel<<<dim3(1), dim3(64), 0, st>>>(idx->s_stats.as<u32>(), F, idx->s_field.as<ScreenField>());
+        RETCHK(idx->s_field1.ensure((size_t)F * sizeof(ScreenField)));
+        RETCHK(idx->s_cvt.ensure((size_t)F * sizeof(uint2)));
+        mfar_direct_fields_kernel<<<dim3(1), dim3(64), 0, st>>>(idx->s_stats.as<u32>(), F, idx->s_field1.as<ScreenField>(), idx->s_field.as<ScreenField>(),
+                                                                idx->s_cvt.as<uint2>());
         HIPCHK(hipGetLastError());
     } else {
         // mean vector and statistics of the centred rows
@@ -1147,23 +1165,29 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     RETCHK(sl.sx.ensure((size_t)128 * F * kp * 4));
     RETCHK(sl.scnt.ensure((size_t)128 * F * 4));
     int* fflags = sl.fail.as<int>();
-    // 1. screened pass on the fp16 slab of unique rows: the k' best approximate scores per (query, field)
+    // bf16 index, which certified pass: 64 columns = two bf16 query terms over the raw rows (scale 1); 128 columns = the rows converted to
+    // fp16 in registers against one fp16 query term (the field's power-of-two scale), or -- MFAR_BF16_WIDE_TERMS=2, diagnostic -- two
+    // bf16 terms at twice the MFMAs
+    static const bool wide_terms2 = getenv("MFAR_BF16_WIDE_TERMS") && atoi(getenv("MFAR_BF16_WIDE_TERMS")) == 2;
+    const int bkind = qw == 128 ? (wide_terms2 ? S1_BF16W : S1_BF16C) : S1_BF16S;
+    const ScreenField* sfield = (bf16 && bkind != S1_BF16C) ? idx->s_field1.as<ScreenField>() : idx->s_field.as<ScreenField>();
+    // 1. screened pass: the k' best approximate scores per (query, field)
     if (phases & S1_PREPARE) {
-        if (bf16)
-            mfar_direct_queries_kernel<<<dim3(qw), dim3(256), 0, st>>>(q, (unsigned short*)sl.qt16.p, sl.qinfo.as<ScreenQuery>(),
-                                                                       idx->s_field.as<ScreenField>(), sl.eps.as<float>(), sl.base.as<float>(),
-                                                                       fflags, q0, Q, idx->E, F, idx->screen_eps_mult, qw);
+        if (bf16 && bkind != S1_BF16C)
+            mfar_direct_queries_kernel<<<dim3(qw), dim3(256), 0, st>>>(q, (unsigned short*)sl.qt16.p, sl.qinfo.as<ScreenQuery>(), sfield,
+                                                                       sl.eps.as<float>(), sl.base.as<float>(), fflags, q0, Q, idx->E, F,
+                                                                       idx->screen_eps_mult, qw);
         else
-            mfar_screen_queries_kernel<<<dim3(qw), dim3(256), 0, st>>>(q, (_Float16*)sl.qt16.p, sl.qinfo.as<ScreenQuery>(),
-                                                                       idx->s_field.as<ScreenField>(), sl.eps.as<float>(), sl.base.as<float>(),
-                                                                       fflags, q0, Q, idx->E, F, idx->screen_eps_mult, qw);
+            mfar_screen_queries_kernel<<<dim3(qw), dim3(256), 0, st>>>(q, (_Float16*)sl.qt16.p, sl.qinfo.as<ScreenQuery>(), sfield,
+                                                                       sl.eps.as<float>(), sl.base.as<float>(), fflags, q0, Q, idx->E, F,
+                                                                       idx->screen_eps_mult, qw, bf16 ? 1 : 0);
         HIPCHK(hipGetLastError());
     }
     // lists of unique-row numbers (fp32 index: rows of the screen slab) / of the local rows of group representatives (bf16 index:
     // the pass scans the documents themselves)
     const S1Out so = {sl.sids.as<long long>(), sl.ssc.as<float>(), sl.scnt.as<int>(), 0, 0, 0};
     if (bf16)
-        RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, phases, qw == 128 ? S1_BF16W : S1_BF16S, idx->slab, sl.qt16.p, qt_n, kp, -INFINITY,
+        RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, phases, bkind, idx->slab, sl.qt16.p, qt_n, kp, -INFINITY,
                            sl.base.as<float>(), nullptr, true, so, st));
     else
         RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, phases, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
@@ -1200,7 +1224,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         sp.pre_qinfo = sl.qinfo.as<ScreenQuery>();
         sp.pre_k = k;
         sp.pre_qw = qw;
-        sp.sfld = idx->s_field.as<ScreenField>();
+        sp.sfld = sfield;
     }
     sp.gslab = idx->gslab.p;
     sp.g_row_bytes = (long long)idx->g_row_bytes;
@@ -1215,7 +1239,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     cp.ssc = sl.ssc.as<float>();
     cp.scnt = sl.scnt.as<int>();
     cp.sx = sl.sx.as<float>();
-    cp.sf = idx->s_field.as<ScreenField>();
+    cp.sf = sfield;
     cp.qinfo = sl.qinfo.as<ScreenQuery>();
     cp.eps = sl.eps.as<float>();
     cp.q = q + (size_t)q0 * idx->E;

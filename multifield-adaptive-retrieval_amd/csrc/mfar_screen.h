@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
                                                                   ScreenQuery* __restrict__ qinfo, const ScreenField* __restrict__ sf,
                                                                   float* __restrict__ eps, float* __restrict__ tau_base,
                                                                   int* __restrict__ fail_flags, int q0, int Q, int E, int F,
-                                                                  float eps_mult, int qw) {
+                                                                  float eps_mult, int qw, int direct) {
     __shared__ float red_a[4], red_s[4];
     const int r = blockIdx.x;
     // a new batch: clear the certificate flags of the fields and the "any" flag ([MFAR_MAX_FIELDS + 1] keeps accumulating statistics)
@@ -371,10 +371,14 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
         const int f = threadIdx.x;
         const ScreenField s = fld;
         const float K = (float)E, u32f = 5.9604645e-8f;
-        const float c_rel = (qw == 128 ? 2.04f : 1.02f) * 4.8828125e-4f + (4.0f * K + 66.0f) * u32f;
+        // direct (the converted-docs pass over a bf16 slab, qw == 128): the docs are exact -- no rounding, no centring (mnorm = 0) -- up
+        // to the clamp of magnitudes below 2^-14 scaled units; what remains is the one-term query rounding
+        const float c16 = direct ? 1.02f : (qw == 128 ? 2.04f : 1.02f);
+        const float c_rel = c16 * 4.8828125e-4f + (4.0f * K + 66.0f) * u32f;
         const float c_abs = u32f * sqrtf(K) * 1.0001f;
+        const float c_doc = direct ? 6.1035156e-5f * 1.001f * sqrtf(K) * 1.0001f : c_abs;      // 2^-14 (1 + u16) |q|_1 / sf
         float e_ = SCREEN_SLACK * (c_rel * qn * s.dnorm_max + K * u32f * qn * (s.dnorm_max + 2.0f * s.mnorm) +
-                                   c_abs * (qn * s.inv_scale + s.dnorm_max / sq));
+                                   c_doc * qn * s.inv_scale + c_abs * s.dnorm_max / sq);
         e_ *= eps_mult;
         if (!live) e_ = 0.0f;
         eps[f * qw + r] = e_;
@@ -404,6 +408,7 @@ __global__ void __launch_bounds__(128) mfar_direct_stats_kernel(const unsigned s
     const bool live = (long long)blockIdx.x * 64 + rr < n_rows;
     const unsigned short* tile = field + (size_t)blockIdx.x * n_steps * 1024 + threadIdx.x * 8;
     float ss = 0.0f;
+    u32 a = 0;
     if (live)
         for (int s = 0; s < n_steps; ++s) {
             const bf16x8 v = *(const bf16x8*)(tile + (size_t)s * 1024);
@@ -411,21 +416,39 @@ __global__ void __launch_bounds__(128) mfar_direct_stats_kernel(const unsigned s
             for (int i = 0; i < 8; ++i) {
                 const float x = bf2f((unsigned short)v[i]);
                 ss = __builtin_fmaf(x, x, ss);
+                a = max(a, __float_as_uint(x) & 0x7FFFFFFFu);      // |x| as bits (NaN bits sit above inf: a non-finite value poisons the maximum)
             }
         }
     ss += __shfl_xor(ss, 1);
     u32 n = __float_as_uint(ss) & 0x7FFFFFFFu;
-    for (int off = 32; off > 0; off >>= 1) n = max(n, (u32)__shfl_xor((int)n, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(&stats[1], n);
+    for (int off = 32; off > 0; off >>= 1) {
+        n = max(n, (u32)__shfl_xor((int)n, off));
+        a = max(a, (u32)__shfl_xor((int)a, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&stats[0], a);
+        atomicMax(&stats[1], n);
+    }
 }
-__global__ void mfar_direct_fields_kernel(const u32* __restrict__ stats, int F, ScreenField* __restrict__ sf) {
+// sf1: the constants of the two-term passes (scale 1);  sfc / cvt: those of the converted-docs pass -- the power-of-two scale that puts
+// the field's largest |value| into [2^13, 2^14) as an fp16 number, and the packed-integer constants of the in-register conversion
+// (mfar_stage1.h s1_bf16x2_to_f16x2): fp16 exponent field = bf16 exponent field - rebias, rebias = 112 - log2(scale); a magnitude
+// below (rebias + 1) << 7 would not be a normal fp16 number and is clamped up to it.
+__global__ void mfar_direct_fields_kernel(const u32* __restrict__ stats, int F, ScreenField* __restrict__ sf1, ScreenField* __restrict__ sfc,
+                                          uint2* __restrict__ cvt) {
     const int f = threadIdx.x;
     if (f >= F) return;
     ScreenField o;
     o.scale = o.inv_scale = 1.0f;
     o.dnorm_max = sqrtf(__uint_as_float(stats[2 * f + 1])) * 1.0001f;   // (the fp32 sum of squares can be low by K u32 relative)
     o.mnorm = 0.0f;
-    sf[f] = o;
+    sf1[f] = o;
+    o.scale = screen_pow2_scale(__uint_as_float(stats[2 * f]));
+    o.inv_scale = 1.0f / o.scale;
+    sfc[f] = o;
+    const int rebias = 112 - ((int)(__float_as_uint(o.scale) >> 23) - 127);       // in [12, 212]: screen_pow2_scale keeps |log2| <= 100
+    const u32 b = (u32)rebias << 7, t = (u32)(rebias + 1) << 7;
+    cvt[f] = make_uint2(t | (t << 16), b | (b << 16));
 }
 // bits[b] bit r = row 64 b + r exists and (is_rep == nullptr or is_rep[row]).  grid = n_words, block 64.
 __global__ void __launch_bounds__(64) mfar_rep_bits_kernel(const u32* __restrict__ is_rep, long long n_rows, u64* __restrict__ bits) {

@@ -105,6 +105,8 @@ struct S1Params {
                             // passes over a bf16 slab scan every document but rank UNIQUE rows: the accumulators of all other
                             // rows start at -inf (s1_acc_init), so they reach neither the sample nor the lists.
     long long rep_stride;   // words per field
+    const uint2* cvt;       // [F] (CV passes over a bf16 slab) per field: x = smallest bf16 magnitude that is a NORMAL fp16 number after the
+                            // field's power-of-two scale, y = the exponent rebias, both replicated in the two halves of a dword
     int* unit_ctr;          // [F] zeroed before the launch, or nullptr.  DYNAMIC WORK DISTRIBUTION of a full pass (wide kernels): a
                             // workgroup is still bound to one field and one list per query (chunk_id), but instead of the fixed
                             // tile range of its chunk it claims UNITS of unit_tiles consecutive tiles from the field's counter
@@ -1035,17 +1037,40 @@ __device__ __forceinline__ void s1_unit_claim_async(int* ctr, int& raw) {
 // (mfar_screen.h).  Structure of s1_body_f16w; the query stage is 8 KB per k-step ([term][query block][64][16]), two LDS-DMA
 // pieces per wave.  The pass scans every document and ranks unique rows (s1_acc_init).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int R, int SCAP_>
+//
+// CV = 1 ("bf16c"): the same scan at HALF the MFMAs.  The bf16 granules are turned into fp16 IN REGISTERS -- a bf16 value has 8
+// significant bits, so under the field's power-of-two scale (largest |value| in [2^13, 2^14)) every value that is a normal fp16
+// number converts exactly; smaller magnitudes are clamped UP to 2^-14 (error <= 2^-14 scaled units per element, in the certificate's
+// eps) -- with five packed-integer VALU ops per dword that issue in the shadow of the MFMAs, and the query is ONE fp16 term of 128
+// columns as in the wide pass of an fp32 index: 8 MFMAs per k-step instead of 16, a 4 KB query stage instead of 8 KB.  eps carries
+// the query rounding (u16) but no doc rounding and no centring (mfar_screen.h).
+template <int R, int SCAP_, int CV>
 struct S1BW {
-    static constexpr int Q_STAGE = 8192;
-    static constexpr int LOADS = 4;
+    static constexpr int Q_STAGE = CV ? 4096 : 8192;
+    static constexpr int LOADS = CV ? 3 : 4;
     static constexpr int SCAP = SCAP_;
     static constexpr int LDS_BYTES = R * Q_STAGE + 2 * S1_STATE_BYTES_(SCAP_);
 };
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// one dword = two bf16 values -> two fp16 values: magnitude clamped up to the smallest normal, exponent rebiased, mantissa moved
+__device__ __forceinline__ u32 s1_bf16x2_to_f16x2(u32 x, u32 tmin2, u32 bias2) {
+    u32 mag = x & 0x7FFF7FFFu;
+    mag = __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(u16x2, mag), __builtin_bit_cast(u16x2, tmin2)));
+    mag = __builtin_bit_cast(u32, (u16x2)(__builtin_bit_cast(u16x2, mag) - __builtin_bit_cast(u16x2, bias2)));
+    mag = __builtin_bit_cast(u32, (u16x2)(__builtin_bit_cast(u16x2, mag) << (u16x2){3, 3}));
+    return (mag & 0x7FFF7FFFu) | (x & ~0x7FFF7FFFu);       // (one v_bfi_b32: the sign bits of x over the converted magnitudes)
+}
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x8 s1_cvt_granule(u32x4 g, u32 tmin2, u32 bias2) {
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = s1_bf16x2_to_f16x2(g[i], tmin2, bias2);
+    return __builtin_bit_cast(f16x8, o);
+}
 
-template <int R, int SCAP_>
+template <int R, int SCAP_, int CV>
 __device__ __forceinline__ void s1_body_bf16w(const S1Params& p, const int chunk_id) {
-    typedef S1BW<R, SCAP_> X;
+    typedef S1BW<R, SCAP_, CV> X;
     typedef short vec8 __attribute__((ext_vector_type(8)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const qring = smem;
@@ -1092,8 +1117,14 @@ __device__ __forceinline__ void s1_body_bf16w(const S1Params& p, const int chunk
     const size_t tile_jump = (size_t)3 * p.n_steps * step_bytes;
     const char* const fbase = (const char*)p.slab + (size_t)ck.base * 2 + (size_t)w * p.n_steps * step_bytes;   // block w of tile 0      // uniform
     const size_t tile_bytes = (size_t)4 * p.n_steps * step_bytes;
-    const char* const qbase = (const char*)p.qt + w * 1024;   // wave w loads pieces w and 4 + w of the 8 KB stage        // uniform
+    const char* const qbase = (const char*)p.qt + w * 1024;   // wave w loads pieces w and 4 + w of the 8 KB stage (CV: piece w of 4 KB)   // uniform
     const u32 ldsq = (u32)(uintptr_t)qring + (u32)w * 1024u;                                                            // uniform
+    u32 tmin2 = 0, bias2 = 0;
+    if (CV) {
+        const uint2 cv = p.cvt[f];
+        tmin2 = __builtin_amdgcn_readfirstlane(cv.x);
+        bias2 = __builtin_amdgcn_readfirstlane(cv.y);
+    }
     // prefetch cursor (uniform): next stage to issue; tiles of its unit not completely issued yet; whether it has moved into `nxt`
     const char* dnext = fbase + (size_t)max(cur.t0, 0) * tile_bytes;
     int s_next = 0, pf_left = cur.t1 - cur.t0, pf_in_next = 0, pf_clamped = cur.t0 < 0 ? 1 : 0;
@@ -1110,7 +1141,7 @@ __device__ __forceinline__ void s1_body_bf16w(const S1Params& p, const int chunk
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024 nt" : "=&v"(dr1[SLOT]) : "v"(off), "s"(dnext) : "memory");   \
         const char* qs_ = qbase + (size_t)s_next * X::Q_STAGE;                                            \
         S1BW_QDMA(l16, qs_, ldsq + (u32)((SLOT) * X::Q_STAGE));                                           \
-        S1BW_QDMA(l16, qs_ + 4096, ldsq + (u32)((SLOT) * X::Q_STAGE + 4096));                             \
+        if (!CV) S1BW_QDMA(l16, qs_ + 4096, ldsq + (u32)((SLOT) * X::Q_STAGE + 4096));                    \
         if (!pf_clamped) {                                                                                \
             dnext += step_bytes;                                                                          \
             if (++s_next == p.n_steps) {                                                                  \
@@ -1149,6 +1180,23 @@ __device__ __forceinline__ void s1_body_bf16w(const S1Params& p, const int chunk
                     asm volatile("s_waitcnt vmcnt(%2)\n\ts_barrier" : "+v"(dr0[u]), "+v"(dr1[u]) : "n"((R - 2) * X::LOADS) : "memory");
                     const char* curq = qring + u * X::Q_STAGE;
                     const vec8 d0 = dr0[u], d1 = dr1[u];
+                    if (CV) {
+                        // tiles of the stage: query block A, query block B (one fp16 term)
+                        const f16x8 qa0 = *(const f16x8*)(curq + off), qa1 = *(const f16x8*)(curq + 1024 + off);
+                        const f16x8 qb0 = *(const f16x8*)(curq + 2048 + off), qb1 = *(const f16x8*)(curq + 3072 + off);
+                        S1BW_ISSUE((u + R - 1) % R);
+                        const f16x8 e0 = s1_cvt_granule(__builtin_bit_cast(u32x4, d0), tmin2, bias2);
+                        a00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qa0, a00, 0, 0, 0);
+                        a01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qa1, a01, 0, 0, 0);
+                        const f16x8 e1 = s1_cvt_granule(__builtin_bit_cast(u32x4, d1), tmin2, bias2);
+                        b00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qb0, b00, 0, 0, 0);
+                        b01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qb1, b01, 0, 0, 0);
+                        a10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, qa0, a10, 0, 0, 0);
+                        a11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, qa1, a11, 0, 0, 0);
+                        b10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, qb0, b10, 0, 0, 0);
+                        b11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, qb1, b11, 0, 0, 0);
+                        continue;
+                    }
                     // tiles of the stage: hi / block A, hi / block B, mid / block A, mid / block B
                     const bf16x8 ma0 = *(const bf16x8*)(curq + 4096 + off), ma1 = *(const bf16x8*)(curq + 5120 + off);
                     const bf16x8 mb0 = *(const bf16x8*)(curq + 6144 + off), mb1 = *(const bf16x8*)(curq + 7168 + off);
@@ -1273,13 +1321,21 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16s4_sample_kerne
 #ifndef S1BW_SCAP6
 #define S1BW_SCAP6 8                         // 6-slot query ring (48 KB): dims whose k-steps do not divide by 4
 #endif
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w_kernel(const S1Params p) { s1_body_bf16w<6, S1BW_SCAP6>(p, p.chunk0 + (int)blockIdx.x); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w_sample_kernel(const S1Params p) { s1_body_bf16w<6, S1BW_SCAP6>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w_kernel(const S1Params p) { s1_body_bf16w<6, S1BW_SCAP6, 0>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w_sample_kernel(const S1Params p) { s1_body_bf16w<6, S1BW_SCAP6, 0>(p, p.chunk0 + (int)blockIdx.x); }
 #ifndef S1BW_SCAP4
 #define S1BW_SCAP4 16
 #endif
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w4_kernel(const S1Params p) { s1_body_bf16w<4, S1BW_SCAP4>(p, p.chunk0 + (int)blockIdx.x); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w4_sample_kernel(const S1Params p) { s1_body_bf16w<4, S1BW_SCAP4>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w4_kernel(const S1Params p) { s1_body_bf16w<4, S1BW_SCAP4, 0>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w4_sample_kernel(const S1Params p) { s1_body_bf16w<4, S1BW_SCAP4, 0>(p, p.chunk0 + (int)blockIdx.x); }
+// converted docs x one fp16 query term (CV = 1): 6-slot ring (24 KB) or 4-slot twin, 16-entry staging areas: 42.5 / 34.5 KB of LDS
+#define S1BC_SCAP 16
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c_kernel(const S1Params p) { s1_body_bf16w<6, S1BC_SCAP, 1>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c_sample_kernel(const S1Params p) { s1_body_bf16w<6, S1BC_SCAP, 1>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c4_kernel(const S1Params p) { s1_body_bf16w<4, S1BC_SCAP, 1>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c4_sample_kernel(const S1Params p) { s1_body_bf16w<4, S1BC_SCAP, 1>(p, p.chunk0 + (int)blockIdx.x); }
+#define S1BC_LDS_BYTES (6 * 4096 + 2 * S1_STATE_BYTES_(S1BC_SCAP))
+#define S1BC4_LDS_BYTES (4 * 4096 + 2 * S1_STATE_BYTES_(S1BC_SCAP))
 #define S1BW_LDS_BYTES (6 * 8192 + 2 * S1_STATE_BYTES_(S1BW_SCAP6))
 #define S1BW4_LDS_BYTES (4 * 8192 + 2 * S1_STATE_BYTES_(S1BW_SCAP4))
 #define S1HW4_LDS_BYTES (4 * 4096 + 2 * S1_STATE_BYTES_(S1_SCAP_WIDE))
