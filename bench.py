@@ -195,7 +195,9 @@ def main():
     ap.add_argument("--sustain-s", type=float, default=1.0, help="length of the sustained leg (same pipeline, >= this many seconds; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the exact-fp32 leg, the structured-corpus leg, the fused leg, "
-                                                                  "the sustained leg and (N > 1) the replica-layout leg")
+                                                                  "the sustained leg, the BASELINE-config legs and (N > 1) the replica-layout leg")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the short legs on BASELINE.json's other configurations "
+                                                                   "(STaRK-prime / STaRK-mag shapes, the per-GPU share of the bf16 stress config)")
     ap.add_argument("--cpu-sample-docs", type=int, default=0, help="0 = the full corpus when host RAM allows, else 100000")
     args = ap.parse_args()
 
@@ -547,6 +549,7 @@ def main():
             "ms_per_launch": dt / args.steps * 1e3 * ps.coalesce,
             "sustained": sustained,
             "recall_at_20": recall20, "ids_checksum": checksum, "index_build_s": t_build, "source_hash": source_hash(),
+            "resident_bytes": ix.resident_bytes(),
             "diagnostic_knobs": {"MFAR_S1_DEBUG": "unset", "screen_eps_mult": eps_mult},
             "roofline": roof,
             "pipeline_hbm": pipe,
@@ -557,6 +560,15 @@ def main():
             line["structured_corpus"] = structured_leg(synth, idxmod, PipelinedSearcher, run, dev, E, Q, torch, np)
         if N == 1 and args.dtype == "f32" and args.corpus == "plain" and not args.no_extra_legs:
             line["fused_mode"] = fused_leg(corpus, ix, [(torch.from_numpy(g),) for g in gathered], args, Q, recall20, torch, np)
+        if N == 1 and args.dtype == "f32" and args.corpus == "plain" and not args.no_extra_legs and not args.no_config_legs:
+            # BASELINE.json configs[1], [2], [4] at their one-GPU shapes, each on its own index, same pipeline, same knobs
+            line["baseline_configs"] = {
+                name: config_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D_, F_, E, dt_, what)
+                for name, D_, F_, dt_, what in (
+                    ("configs[1] STaRK-prime", 129_375, 22, "f32", "STaRK-prime full corpus, all_dense: 129 375 docs x 22 dense fields (schema.py:11-53), fp32"),
+                    ("configs[2] STaRK-mag", 700_244, 5, "f32", "STaRK-mag full corpus: 700 244 docs x 5 dense fields, fp32"),
+                    ("configs[4] bf16 stress, per-GPU share", 1_250_000, 16, "bf16",
+                     "10 M docs x 16 fields x 768d bf16 over 8 GPUs = 1 250 000 rows per GPU (what one rank of the row-sharded run holds)"))}
         if N == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(corpus, ix, args, np, torch)
         sys.stdout.flush()
@@ -564,6 +576,65 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def config_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E, dtype, what, min_s=0.25):
+    """One of BASELINE.json's other configurations at its one-GPU shape: own synthetic corpus and index, the default pipeline, as many
+    timed batches of Q queries as fill `min_s` seconds (at least 24; a 24-step region of a small shape is 15 ms, mostly pipeline ramp);
+    the dominant kernel priced from its HIP events like the headline's."""
+    t0 = time.perf_counter()
+    cp = synth.SyntheticCorpus(D, F, E, n_queries=4096, seed=0xDEADBEEF, device=str(dev))
+    ix = cp.build_index(idxmod, dtype=dtype)
+    ps = PipelinedSearcher(ix, cp.W, torch.ones(F, device=dev), k1=K1, k2=K2, max_batch=Q)
+    run(ps, cp, list(range(2 * ps.coalesce * ps.depth)), None)      # scratch of every slot allocated, screen / tables / gather slab built
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    first = 2 * ps.coalesce * ps.depth
+    t0 = time.perf_counter()
+    run(ps, cp, list(range(first, first + 24)), None)
+    torch.cuda.synchronize()
+    steps = int(min(1024, max(24, min_s / max((time.perf_counter() - t0) / 24, 1e-6))))
+    steps -= steps % ps.coalesce
+    s0, st0 = ix.screen_stats(), ix.stage2_stats()
+    keep = []
+    ix.set_timing(True)
+    t0 = time.perf_counter()
+    run(ps, cp, list(range(first, first + steps)), keep)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, n = ix.stage1_timing()
+    ix.set_timing(False)
+    s1, st1 = ix.screen_stats(), ix.stage2_stats()
+    screened = bool(s1["built"])
+    rec = []
+    for i, (ids, _, _) in enumerate(keep):
+        ids = ids.cpu().numpy()
+        rel = cp.qrels((first + i) * Q, Q)
+        rec += [len(set(ids[j, :20].tolist()) & rel[j]) / len(rel[j]) for j in range(Q)]
+    scan_rows = s1.get("scan_rows", D * F) if screened else D * F
+    esize = 2 if (dtype == "bf16" or screened) else 4
+    bytes_per_launch = float(scan_rows) * E * esize
+    kern = s1_kernel_name(dtype, screened, E, wide=ps.Qmax > 64)
+    avg_ms = ms / max(1, n)
+    out = {"workload": what + "; synthetic STaRK-shaped rows (mfar/synth.py), two-stage scorer k1=k2=100, zero-sentinel mode",
+           "docs": D, "fields": F, "dim": E, "dtype": dtype, "steps": steps, "query_batch": Q, "queries_per_launch": ps.Qmax,
+           "queries_per_s": steps * Q / dt, "ms_per_step": dt / steps * 1e3,
+           "roofline": {"bound": "hbm", "kernel": kern, "avg_launch_ms": avg_ms, "launches": n, "algorithmic_bytes_per_launch": bytes_per_launch,
+                        "achieved": bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": bytes_per_launch / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if avg_ms > 0 else 0.0,
+                        "hbm_bound_queries_per_s": ps.Qmax / (bytes_per_launch / (PEAK_HBM_GBS * 1e9)),
+                        "algorithmic_bytes_definition": f"{scan_rows} scanned rows x {E} dims x {esize} B, read once per launch of {ps.Qmax} queries"},
+           "lists_certified": (s1["n_checked"] - s0["n_checked"]) - (s1["n_failed"] - s0["n_failed"]),
+           "lists_redone_exactly": s1["n_failed"] - s0["n_failed"], "batches_redone": ps.n_redone,
+           "stage2": ({"candidates_per_query": (st1["n_candidates"] - st0["n_candidates"]) / (steps * Q),
+                       "survivors_per_query": (st1["n_survivors"] - st0["n_survivors"]) / (steps * Q)}
+                      if st1["two_level"] and st1["n_candidates"] > st0["n_candidates"] else "every (candidate, field) row gathered"),
+           "resident_bytes": ix.resident_bytes(), "recall_at_20": float(np.mean(rec)), "index_build_s": t_build}
+    del ps
+    ix.close()
+    del cp
+    torch.cuda.empty_cache()
+    return out
 
 
 def structured_leg(synth, idxmod, PipelinedSearcher, run, dev, E, Q, torch, np):

@@ -63,6 +63,10 @@ int mfar_index_create(mfar_index** out, int device, int64_t n_rows_local, int64_
 void mfar_index_destroy(mfar_index* idx);
 int mfar_index_info(const mfar_index* idx, int64_t* n_rows_local, int64_t* row_offset, int* n_fields, int* dim,
                     int* dtype, int64_t* slab_bytes);
+/* HBM the handle keeps resident between searches, by part: the rows (the slab), the fp16 screen slab of an fp32 index, the 16-bit
+ * row-major gather slab (fp32 index: the approximate level of stage 2; bf16 index: the whole-line companion), and the unique-row
+ * tables / statistics of the certified stage 1.  Per-launch scratch is not counted.  No reference counterpart. */
+int mfar_index_resident_bytes(const mfar_index* idx, int64_t* rows, int64_t* screen, int64_t* gather, int64_t* tables);
 
 /*
  * Write n row-major fp32 vectors src[n, dim] into field `field`, local rows [local_row0, local_row0 + n).

@@ -39,12 +39,13 @@ static int fail(int code, const std::string& msg) {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    int ensure(size_t bytes) {
+    // exact: no growth slack (the big resident buffers of an index -- screen slab, gather slab, unique-row tables -- are sized once)
+    int ensure(size_t bytes, bool exact = false) {
         if (bytes <= cap) return MFAR_OK;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        size_t want = bytes + (bytes >> 3) + 256;
+        size_t want = exact ? ((bytes + 255) & ~(size_t)255) : bytes + (bytes >> 3) + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
             p = nullptr;
@@ -338,6 +339,21 @@ extern "C" int mfar_index_info(const mfar_index* idx, int64_t* n_rows_local, int
     if (dim) *dim = idx->E;
     if (dtype) *dtype = idx->dtype;
     if (slab_bytes) *slab_bytes = (int64_t)idx->slab_bytes;
+    return MFAR_OK;
+}
+
+extern "C" int mfar_index_resident_bytes(const mfar_index* idx, int64_t* rows, int64_t* screen, int64_t* gather, int64_t* tables) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    if (rows) *rows = (int64_t)idx->slab_bytes;
+    if (screen) *screen = (int64_t)idx->screen.cap;
+    if (gather) *gather = (int64_t)idx->gslab.cap;
+    if (tables) {
+        size_t t = 0;
+        for (const DevBuf* b : {&idx->u_rep, &idx->u_start, &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->rep_bits, &idx->u_of, &idx->s_stats,
+                                &idx->s_field, &idx->s_mean, &idx->s_field1, &idx->s_cvt})
+            t += b->cap;
+        *tables = (int64_t)t;
+    }
     return MFAR_OK;
 }
 
@@ -917,7 +933,7 @@ static bool gslab_alloc(mfar_index* idx) {
     if (idx->gslab_nomem) return false;
     idx->g_row_bytes = GSLAB_ROW_BYTES(idx->E);
     const size_t need = (size_t)idx->F * (size_t)std::max<int64_t>(idx->n_rows, 1) * idx->g_row_bytes;
-    if (idx->gslab.ensure(need) != MFAR_OK) {
+    if (idx->gslab.ensure(need, true) != MFAR_OK) {
         (void)hipGetLastError();
         g_err.clear();
         idx->gslab.release();
@@ -973,13 +989,13 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
         idx->screen_nomem = true;
         return MFAR_OK;
     };
-    if (idx->u_rep.ensure((size_t)F * n * 4) != MFAR_OK || idx->u_start.ensure((size_t)F * n * 4) != MFAR_OK ||
-        idx->u_count.ensure((size_t)F * n * 4) != MFAR_OK || idx->u_members.ensure((size_t)F * n * 4) != MFAR_OK ||
+    if (idx->u_rep.ensure((size_t)F * n * 4, true) != MFAR_OK || idx->u_start.ensure((size_t)F * n * 4, true) != MFAR_OK ||
+        idx->u_count.ensure((size_t)F * n * 4, true) != MFAR_OK || idx->u_members.ensure((size_t)F * n * 4, true) != MFAR_OK ||
         idx->u_n.ensure((size_t)F * 4) != MFAR_OK)
         return nomem();
-    if (bf16 && (idx->rep_bits.ensure((size_t)F * idx->n_blk * 8) != MFAR_OK || idx->u_of.ensure((size_t)F * std::max<long long>(n, 1) * 4) != MFAR_OK))
+    if (bf16 && (idx->rep_bits.ensure((size_t)F * idx->n_blk * 8, true) != MFAR_OK || idx->u_of.ensure((size_t)F * std::max<long long>(n, 1) * 4, true) != MFAR_OK))
         return nomem();
-    if (idx->u_repof.ensure((size_t)F * n * 4) != MFAR_OK) {   // optional: without it stage 2 gathers every row itself
+    if (idx->u_repof.ensure((size_t)F * n * 4, true) != MFAR_OK) {   // optional: without it stage 2 gathers every row itself
         (void)hipGetLastError();
         g_err.clear();
         idx->u_repof.release();
@@ -1080,7 +1096,7 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
         g.n_tiles[f] = (int)(blk / 4);
         total += blk * 64 * idx->E;
     }
-    if (idx->screen.ensure((size_t)total * 2) != MFAR_OK) return nomem();
+    if (idx->screen.ensure((size_t)total * 2, true) != MFAR_OK) return nomem();
     idx->screen_used = (size_t)total * 2;
     // pass 3: the fp16 rows
     for (int f = 0; f < F; ++f) {

@@ -50,6 +50,7 @@ SIGNATURES = {
     "mfar_index_create": (_i, [_c.POINTER(_vp), _i, _i64, _i64, _i, _i, _i]),
     "mfar_index_destroy": (None, [_vp]),
     "mfar_index_info": (_i, [_vp, _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i64)]),
+    "mfar_index_resident_bytes": (_i, [_vp, _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64)]),
     "mfar_index_write_rows": (_i, [_vp, _i, _i64, _i64, _vp, _i, _vp]),
     "mfar_index_read_rows": (_i, [_vp, _i, _i64, _i64, _vp, _i, _vp]),
     "mfar_retrieve_fields": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),

@@ -132,6 +132,15 @@ class MultiFieldIndex:
         return v.value
 
     # ---- rows in / out (MemoryMapDict.__setitem__ / .file, data/util.py:37-41) ----
+    def resident_bytes(self) -> dict:
+        """HBM the index keeps between searches: rows (slab), fp16 screen slab, 16-bit gather slab, unique-row tables; `ratio` = all of
+        it over the rows alone (include/mfar_hip.h)."""
+        v = [ctypes.c_int64() for _ in range(4)]
+        _native.check(_native.lib().mfar_index_resident_bytes(self._h, *[ctypes.byref(x) for x in v]))
+        rows, screen, gather, tables = (x.value for x in v)
+        return dict(rows=rows, screen=screen, gather=gather, tables=tables, total=rows + screen + gather + tables,
+                    ratio=(rows + screen + gather + tables) / max(1, rows))
+
     def write_rows(self, field: int, local_row0: int, rows) -> None:
         a = _Arg(rows, np.float32, self.device)
         shape = tuple(a.keep.shape)
