@@ -314,6 +314,18 @@ int mfar_screen_field_info(mfar_index* idx, int field, int64_t* n_unique_rows, i
  * mfar_stage2_stats synchronises the device: candidates the prune kernel has seen / survivors it kept since the handle was created.
  */
 int mfar_set_stage2_mode(mfar_index* idx, int mode);
+/*
+ * SCORE DUMP (no reference counterpart; outputs bit-identical with and without it).  The approximate level of the two-level stage 2
+ * normally gathers one 16-bit row per (candidate, field) pair.  When queries x candidates exceeds a field's rows -- many fields, small
+ * corpora, the row shards of a multi-GPU run -- the wide screened pass of stage 1 instead WRITES every approximate score it computes
+ * (rows x 128 queries x 4 bytes per field and launch, per pipeline slot) and stage 2 reads its pairs out of that table, bounded by the
+ * screened pass's own eps (csrc/mfar_select.h: mfar_s2_lookup_kernel): 129 375 x 22 moves 1.5 + 0.4 GB instead of 7.9 GB per 128 queries.
+ *   mode   0 = never, 1 = when the dump moves less than two thirds of the gathers' bytes (default; environment MFAR_S2_DUMP),
+ *          2 = whenever the wide pass of an fp32 index with a current screen runs.
+ * mfar_stage2_dump_info: would a launch with list depth k1 use it; bytes one launch writes; launches that read it so far.
+ */
+int mfar_set_stage2_dump(mfar_index* idx, int mode);
+int mfar_stage2_dump_info(mfar_index* idx, int k1, int* wanted, int64_t* bytes_per_launch, int64_t* n_launches);
 int mfar_stage2_stats(mfar_index* idx, int* two_level_available, int64_t* gather_slab_bytes, int64_t* n_candidates,
                       int64_t* n_survivors);
 

@@ -109,6 +109,11 @@ struct mfar_index {
     struct S1Slot {
         DevBuf qt, lists, list_cnt, gtau, samp, lists2, list_cnt2;      // any pass (lists2: group lists of a two-level merge)
         DevBuf unit_ctr;                                                // per-field unit counters of a dynamically distributed scan (mfar_stage1.h)
+        DevBuf dump;                                                    // score dump of the wide screened pass (mfar_select.h mfar_s2_lookup_kernel)
+        bool dump_on = false;                                           // this batch's scan writes it
+        bool dump_ready = false;                                        // ... and has been launched: stage 2 of (dump_q, dump_Q) may read it, once
+        const float* dump_q = nullptr;
+        int dump_Q = 0;
         DevBuf qt16, qinfo, eps, base, fail, sids, ssc, scnt, sx;        // fp16 screen
         bool screened = false;                                          // decided by the begin phase of the batch
         int qw = 64;                                                    // query columns of the batch's pass (128: wide screen pass)
@@ -134,6 +139,9 @@ struct mfar_index {
     bool screen_nomem = false;    // the screen slab could not be allocated: stay on the exact pass
     long long screen_checked = 0; // (query, field) lists certified so far
     DevBuf s_stats, s_field, s_mean;
+    DevBuf dump_base;             // [F] first row of every field in the screen slab (= in a score dump)
+    int dump_mode = 1;            // 0 never, 1 when it moves fewer bytes than the row gathers (dump_wanted), 2 whenever possible
+    long long dump_launches = 0;
     DevBuf s_field1, s_cvt;       // bf16 index: ScreenField of the two-term passes (scale 1); conversion constants of the converted-docs pass
     // unique rows of every field (mfar_screen.h), each table [F][n_rows] (stride n_rows): representative document of a
     // unique row, start / length of its member run in `members` (local rows grouped by unique row, ascending inside a group)
@@ -270,6 +278,7 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     if (const char* e = getenv("MFAR_SCREEN_DEDUP")) idx->screen_dedup = atoi(e) != 0;
     if (const char* e = getenv("MFAR_WIDE")) idx->wide = atoi(e) != 0;
     if (const char* e = getenv("MFAR_STAGE2_PRUNE")) idx->stage2_mode = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("MFAR_S2_DUMP")) idx->dump_mode = std::max(0, std::min(2, atoi(e)));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) idx->n_cu = prop.multiProcessorCount;
     hipError_t e = hipMalloc(&idx->slab, idx->slab_bytes);
@@ -304,7 +313,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
     DevBuf* bufs[] = {&idx->fid, &idx->fsc, &idx->s_stats, &idx->s_field, &idx->s_mean, &idx->screen, &idx->u_rep, &idx->u_start,
-                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->s2stats, &idx->rep_bits, &idx->u_of, &idx->s_field1, &idx->s_cvt};
+                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->s2stats, &idx->rep_bits, &idx->u_of, &idx->s_field1, &idx->s_cvt, &idx->dump_base};
     for (int i = 0; i < MFAR_SLOTS; ++i)
         for (DevBuf* b : {&idx->cand[i], &idx->ncand[i], &idx->x[i], &idx->own[i], &idx->xa[i], &idx->cand2[i], &idx->ncand2[i], &idx->s2qm[i],
                           &idx->s2eps[i], &idx->kmask[i], &idx->src2[i]})
@@ -320,7 +329,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
         }
     for (DevBuf* b : bufs) b->release();
     for (auto& sl : idx->s1) {
-        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.lists2, &sl.list_cnt2, &sl.unit_ctr, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
+        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.lists2, &sl.list_cnt2, &sl.unit_ctr, &sl.dump, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
                         &sl.ssc, &sl.scnt, &sl.sx};
         for (DevBuf* b : sb) b->release();
     }
@@ -675,6 +684,10 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
     p.samp_out = nullptr;
     p.samp_stride = tb.samp_stride;
     p.only_failed = only_failed;
+    if (kind == S1_F16W && sl.dump_on && nf == idx->F && !repair) {
+        p.dump = sl.dump.as<float>();
+        p.dump_base = idx->dump_base.as<long long>();
+    }
     if (kind == S1_BF16S || kind == S1_BF16W || kind == S1_BF16C) {     // documents are scanned, unique rows are ranked (mfar_stage1.h s1_acc_init)
         p.rep_bits = idx->rep_bits.as<u64>();
         p.rep_stride = idx->n_blk;
@@ -993,8 +1006,13 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
         idx->u_count.ensure((size_t)F * n * 4, true) != MFAR_OK || idx->u_members.ensure((size_t)F * n * 4, true) != MFAR_OK ||
         idx->u_n.ensure((size_t)F * 4) != MFAR_OK)
         return nomem();
-    if (bf16 && (idx->rep_bits.ensure((size_t)F * idx->n_blk * 8, true) != MFAR_OK || idx->u_of.ensure((size_t)F * std::max<long long>(n, 1) * 4, true) != MFAR_OK))
-        return nomem();
+    if (bf16 && idx->rep_bits.ensure((size_t)F * idx->n_blk * 8, true) != MFAR_OK) return nomem();
+    if (idx->u_of.ensure((size_t)F * std::max<long long>(n, 1) * 4, true) != MFAR_OK) {
+        if (bf16) return nomem();
+        (void)hipGetLastError();      // fp32 index: optional (without it stage 2 cannot read the scan's score dump)
+        g_err.clear();
+        idx->u_of.release();
+    }
     if (idx->u_repof.ensure((size_t)F * n * 4, true) != MFAR_OK) {   // optional: without it stage 2 gathers every row itself
         (void)hipGetLastError();
         g_err.clear();
@@ -1067,7 +1085,7 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
         rc = field_src(f, &src);
         if (rc == MFAR_OK)
             rc = build_unique_rows(idx, f, src, tmp, st, &idx->n_unique[f], &idx->largest_group[f],
-                                   bf16 ? idx->rep_bits.as<u64>() + (size_t)f * idx->n_blk : nullptr, bf16 ? idx->u_of.as<u32>() + (size_t)f * n : nullptr);
+                                   bf16 ? idx->rep_bits.as<u64>() + (size_t)f * idx->n_blk : nullptr, idx->u_of.p ? idx->u_of.as<u32>() + (size_t)f * n : nullptr);
         if (bf16) HIPCHK(hipStreamSynchronize(st));   // the staging copy is reused by the next field
     }
     HIPCHK(hipStreamSynchronize(st));
@@ -1098,6 +1116,13 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
     }
     if (idx->screen.ensure((size_t)total * 2, true) != MFAR_OK) return nomem();
     idx->screen_used = (size_t)total * 2;
+    {
+        std::vector<long long> db(F);
+        for (int f = 0; f < F; ++f) db[f] = g.base[f] / idx->E;
+        RETCHK(idx->dump_base.ensure((size_t)F * sizeof(long long)));
+        HIPCHK(hipMemcpyAsync(idx->dump_base.p, db.data(), (size_t)F * sizeof(long long), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
     // pass 3: the fp16 rows
     for (int f = 0; f < F; ++f) {
         const float* src = (const float*)idx->slab + (size_t)f * idx->field_stride;
@@ -1130,6 +1155,21 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
 // the wide pass exists as 6-slot and 4-slot register-ring kernels: the k-steps must divide into one of them
 static bool wide_ok(const mfar_index* idx) { return idx->wide && (idx->n_steps % 6 == 0 || idx->n_steps % 4 == 0); }
 
+// Should the wide screened pass of this index write its score dump for stage 2 (mfar_select.h mfar_s2_lookup_kernel)?  The dump costs
+// rows x 512 bytes of writes per launch (+ one 64-byte sector per looked-up pair); the row gathers it replaces cost 128 queries x
+// (F k1 candidates) x F fields x E x 2 bytes.  Auto: when the dump moves less than a third of that -- measured: 129 375 x 22 (1.8 GB against
+// 9.5 GB) 48.3 k -> 64.2 k queries/s; the 125 k x 8 row shard (0.56 against 1.26 GB) 185 k -> 182 k: the dump's looser bound keeps ~15 %
+// more survivors and its stores sit in the scan; 1 M x 8 (4.1 against 1.26 GB) 51.6 k -> 39.8 k.
+static bool dump_wanted(const mfar_index* idx, int k1) {
+    if (idx->dump_mode == 0 || idx->dtype != MFAR_DTYPE_F32 || !idx->u_of.p || !idx->u_repof.p || !idx->screen_built || idx->screen_dirty ||
+        idx->stage2_mode < 1 || !idx->gslab_ok)
+        return false;
+    if (idx->dump_mode == 2) return true;
+    const double dump = (double)(idx->screen_used / 2 / (size_t)idx->E) * 512.0 + 128.0 * idx->F * k1 * idx->F * 64.0;
+    const double gather = 128.0 * idx->F * k1 * idx->F * (double)idx->g_row_bytes;
+    return dump * 3.0 < gather;
+}
+
 // One block of queries (rows q0 .. of q) through stage 1 for fields [f0, f0 + nf): 64 per block, or up to 128 when the
 // wide screened pass applies (more than 64 queries left, screen available).  all pointers are device pointers; fid/fsc are
 // [Q, nf, k].  *n_done (may be nullptr) = queries of this block.
@@ -1146,6 +1186,15 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         if (screen_wanted(idx, k)) RETCHK(ensure_screen(idx, st, &screened));
         sl.screened = screened;
         sl.qw = (screened && wide_ok(idx) && Q - q0 > 64) ? 128 : 64;
+        // the wide pass of an fp32 index over all fields may leave its scores behind for stage 2 (one block of queries: the dump holds
+        // the launch that wrote it last)
+        sl.dump_on = sl.qw == 128 && !bf16 && f0 == 0 && nf == idx->F && q0 == 0 && Q <= 128 && dump_wanted(idx, k);
+        sl.dump_ready = false;
+        if (sl.dump_on && sl.dump.ensure(idx->screen_used / 2 / (size_t)idx->E * 512, true) != MFAR_OK) {
+            (void)hipGetLastError();
+            g_err.clear();
+            sl.dump_on = false;
+        }
     }
     const int qw = sl.qw;
     const int qt_n = std::min(qw, Q - q0);
@@ -1208,6 +1257,11 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     else
         RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, phases, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
                            sl.base.as<float>(), nullptr, true, so, st));
+    if ((phases & S1_SCAN) && sl.dump_on) {
+        sl.dump_ready = true;
+        sl.dump_q = q + (size_t)q0 * idx->E;
+        sl.dump_Q = qt_n;
+    }
     if (!(phases & S1_CERTIFY)) return MFAR_OK;
     // 2. exact scores of those unique rows' representatives (the contract's fma chain over the fp32 slab)
     ScoreParams sp = {};
@@ -1385,6 +1439,19 @@ extern "C" int mfar_set_stage2_mode(mfar_index* idx, int mode) {
     if (!idx || mode < 0 || mode > 2)
         return fail(MFAR_ERR_INVALID, "mode must be 0 (gather every row), 1 (certified two-level stage 2) or 2 (also for sweeps of many masks)");
     idx->stage2_mode = mode;
+    return MFAR_OK;
+}
+
+extern "C" int mfar_set_stage2_dump(mfar_index* idx, int mode) {
+    if (!idx || mode < 0 || mode > 2) return fail(MFAR_ERR_INVALID, "mode must be 0 (never), 1 (when it moves fewer bytes) or 2 (whenever possible)");
+    idx->dump_mode = mode;
+    return MFAR_OK;
+}
+extern "C" int mfar_stage2_dump_info(mfar_index* idx, int k1, int* wanted, int64_t* bytes_per_launch, int64_t* n_launches) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    if (wanted) *wanted = dump_wanted(idx, k1) ? 1 : 0;
+    if (bytes_per_launch) *bytes_per_launch = idx->screen_built && idx->dtype == MFAR_DTYPE_F32 ? (int64_t)(idx->screen_used / 2 / (size_t)idx->E * 512) : 0;
+    if (n_launches) *n_launches = idx->dump_launches;
     return MFAR_OK;
 }
 
@@ -1674,6 +1741,10 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
         RETCHK(idx->s2stats.ensure(2 * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(idx->s2stats.p, 0, 2 * sizeof(unsigned long long), st));
     }
+    // the approximate level: this slot's scan left every score it computed behind (same queries, used once), or 16-bit row gathers
+    mfar_index::S1Slot& sl = idx->s1[slot];
+    const bool from_dump = sl.dump_ready && sl.dump_q == qd && sl.dump_Q == Q && Q <= 128 && idx->u_of.p && idx->u_repof.p;
+    sl.dump_ready = false;
     S2PrepParams pp = {};
     pp.q = qd;
     pp.mean = idx->s_mean.as<float>();
@@ -1683,6 +1754,10 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
     pp.E = E;
     pp.F = F;
     pp.eps_mult = idx->screen_eps_mult;
+    if (from_dump) {
+        pp.eps_src = sl.eps.as<float>();
+        pp.eps_qw = 128;
+    }
     mfar_s2_prep_kernel<<<dim3(Q), dim3(256), 0, st>>>(pp);
     HIPCHK(hipGetLastError());
     const ApproxArgs ap = {pp.qm};
@@ -1707,7 +1782,30 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
         HIPCHK(hipGetLastError());
         kn.kmask = kp.kmask;
     }
-    RETCHK(run_score(idx, qd, Q, cand, ncand, C, idx->xa[slot].as<float>(), st, &ap, kn.kmask ? &kn : nullptr));
+    if (from_dump) {
+        S2LookupParams lp = {};
+        lp.dump = sl.dump.as<float>();
+        lp.dump_base = idx->dump_base.as<long long>();
+        lp.cand = cand;
+        lp.n_cand = ncand;
+        lp.repof = idx->u_repof.as<int>();
+        lp.uof = idx->u_of.as<u32>();
+        lp.ustride = idx->n_rows;
+        lp.row_offset = idx->row_offset;
+        lp.sf = idx->s_field.as<ScreenField>();
+        lp.qinfo = sl.qinfo.as<ScreenQuery>();
+        lp.qm = pp.qm;
+        lp.kmask = kn.kmask;
+        lp.xa = idx->xa[slot].as<float>();
+        lp.n_rows = (int)idx->n_rows;
+        lp.F = F;
+        lp.C = C;
+        mfar_s2_lookup_kernel<<<dim3((unsigned)(((size_t)C * F + 255) / 256), Q), dim3(256), 0, st>>>(lp);
+        HIPCHK(hipGetLastError());
+        idx->dump_launches++;
+    } else {
+        RETCHK(run_score(idx, qd, Q, cand, ncand, C, idx->xa[slot].as<float>(), st, &ap, kn.kmask ? &kn : nullptr));
+    }
     PruneParams pr = {};
     pr.xa = idx->xa[slot].as<float>();
     pr.cand = cand;

@@ -1011,6 +1011,8 @@ struct S2PrepParams {
     float* eps;              // [Q, MFAR_MAX_FIELDS]
     int E, F;
     float eps_mult;          // test knob (mfar_set_screen): scales the bound; 1 = rigorous
+    const float* eps_src;    // [F, eps_qw] or nullptr: the approximate level comes from the scan's SCORE DUMP (mfar_s2_lookup_kernel) -- its
+    int eps_qw;              // bound is the screened pass's own eps(q, f) (mfar_screen_queries_kernel, real units, eps_mult applied there)
 };
 __global__ void __launch_bounds__(256) mfar_s2_prep_kernel(const S2PrepParams p) {
     __shared__ float part[MFAR_MAX_FIELDS + 1][4];
@@ -1036,9 +1038,51 @@ __global__ void __launch_bounds__(256) mfar_s2_prep_kernel(const S2PrepParams p)
         float e_ = S2_SLACK * (c_rel * qn * s.dnorm_max + 1.01f * (K + 1.0f) * u32f * qn * (s.dnorm_max + s.mnorm) + 1.01f * K * u32f * qn * s.mnorm +
                                u32f * sqrtf(K) * 1.0001f * qn * s.inv_scale);
         e_ *= p.eps_mult;
+        if (p.eps_src) e_ = p.eps_src[f * p.eps_qw + qi];
         p.eps[(size_t)qi * MFAR_MAX_FIELDS + f] = e_;
         p.qm[(size_t)qi * MFAR_MAX_FIELDS + f] = (part[f][0] + part[f][1]) + (part[f][2] + part[f][3]);
     }
+}
+
+// Approximate level of stage 2 from the scan's SCORE DUMP (S1Params::dump).  Stage 2 needs C * F (candidate, field) scores per query;
+// when queries x candidates exceeds the rows of a field -- many fields, small corpora or shards: 129 k x 22 gathers 7.9 GB of fp16 rows
+// per 128 queries, 1.9 x what the scan itself reads -- it is cheaper to let the wide screened pass WRITE every score it computes anyway
+// (rows x 128 x 4 bytes per field) and to pick the pairs out of that table: one 4-byte read per pair instead of a 1.5 KB row.
+//   xa[q, c, f] = dump[row u of field f][q] / (sq sf) + q . mean(f),   u = unique row of the candidate's group in field f;
+// the bound on |xa - exact| is the screened pass's own eps(q, f) (the certificate's), so mfar_s2_prune_kernel runs unchanged.
+// Known pairs (kmask) keep the exact score mfar_s2_known_kernel wrote.  grid = (ceil(C F / 256), Q), block 256.
+struct S2LookupParams {
+    const float* dump;             // [rows of the screen slab][128]
+    const long long* dump_base;    // [F] first row of a field
+    const long long* cand;         // [Q, C]
+    const int* n_cand;             // [Q]
+    const int* repof;              // [F][ustride] representative of a row's group
+    const u32* uof;                // [F][ustride] unique number + 1 of a representative
+    long long ustride, row_offset;
+    const ScreenField* sf;
+    const ScreenQuery* qinfo;      // [128]
+    const float* qm;               // [Q, MFAR_MAX_FIELDS]
+    const u32* kmask;              // [Q, C] or nullptr
+    float* xa;                     // [Q, C, F]
+    int n_rows, F, C;
+};
+__global__ void __launch_bounds__(256) mfar_s2_lookup_kernel(const S2LookupParams p) {
+    const int qi = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.C * p.F) return;
+    const int c = idx / p.F, f = idx - c * p.F;
+    float o = __builtin_nanf("");
+    if (c < min(p.n_cand[qi], p.C)) {
+        if (p.kmask && ((p.kmask[(size_t)qi * p.C + c] >> f) & 1u)) return;       // exact already
+        const long long id = p.cand[(size_t)qi * p.C + c] - p.row_offset;
+        if (id >= 0 && id < p.n_rows) {
+            const int rep = p.repof[(size_t)f * p.ustride + id];
+            const long long u = (long long)p.uof[(size_t)f * p.ustride + rep] - 1;
+            const float a = p.dump[((size_t)p.dump_base[f] + (size_t)u) * 128 + qi];
+            o = (a * p.qinfo[qi].inv_scale) * p.sf[f].inv_scale + p.qm[(size_t)qi * MFAR_MAX_FIELDS + f];
+        }
+    }
+    p.xa[(size_t)qi * p.C * p.F + idx] = o;
 }
 
 // Known pairs (see ScoreParams::kmask): every REAL entry (field f, doc d, exact score s) of the query's stage-1 lists -- not the

@@ -105,6 +105,11 @@ struct S1Params {
                             // passes over a bf16 slab scan every document but rank UNIQUE rows: the accumulators of all other
                             // rows start at -inf (s1_acc_init), so they reach neither the sample nor the lists.
     long long rep_stride;   // words per field
+    float* dump;            // or nullptr.  SCORE DUMP of the wide fp16 screen pass (mfar_stage1_f16w_kernel): every approximate score of the
+                            // launch, [scanned row of the slab][128 query columns] fp32 in scaled units, 512 bytes per row; field f's
+                            // rows start at dump_base[f] (in rows).  Stage 2 of a many-field / small-corpus index reads its approximate
+                            // level from here instead of gathering 16-bit rows (mfar_select.h mfar_s2_lookup_kernel).
+    const long long* dump_base;   // [F]
     const uint2* cvt;       // [F] (CV passes over a bf16 slab) per field: x = smallest bf16 magnitude that is a NORMAL fp16 number after the
                             // field's power-of-two scale, y = the exponent rebias, both replicated in the two halves of a dword
     int* unit_ctr;          // [F] zeroed before the launch, or nullptr.  DYNAMIC WORK DISTRIBUTION of a full pass (wide kernels): a
@@ -982,6 +987,31 @@ __device__ __forceinline__ void s1_body_f16w(const S1Params& p, const int chunk_
             s1_sample_top2(p, ck, t - t0, t, w, a00, a01, a10, a11, 0);
             s1_sample_top2(p, ck, t - t0, t, w, b00, b01, b10, b11, 64);
             continue;
+        }
+        if (p.dump && !p.sample) {
+            // score dump: row (32 db + (r & 3) + 8 (r >> 2) + 4 h) of the wave's block, query column 64 blk + 32 x + j.  One SGPR base per
+            // (doc block, r >> 2), one per-lane offset, the rest in the immediate; a store instruction covers two rows x 32 consecutive
+            // queries (two full 128-byte lines).  Issued BEFORE the selection epilogue so that the stores have left the vmcnt queue by the
+            // time the next tile's counted waits look at it.
+            const u32 voff = (u32)(h * 4 * 512 + j * 4);
+            const char* const dtile = (const char*)p.dump + ((size_t)p.dump_base[f] + (size_t)t * S1_TILE_ROWS + (size_t)w * 64) * 512;
+#define S1W_DUMP4(ACC, DB, Q0)                                                                                                  \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                                          \
+        const char* sb_ = dtile + (size_t)(32 * (DB) + 8 * g_) * 512;                                                           \
+        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(ACC[4 * g_ + 0]), "s"(sb_), "n"((Q0)) : "memory");           \
+        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(ACC[4 * g_ + 1]), "s"(sb_), "n"((Q0) + 512) : "memory");     \
+        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(ACC[4 * g_ + 2]), "s"(sb_), "n"((Q0) + 1024) : "memory");    \
+        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(ACC[4 * g_ + 3]), "s"(sb_), "n"((Q0) + 1536) : "memory");    \
+    }
+            S1W_DUMP4(a00, 0, 0)
+            S1W_DUMP4(a01, 0, 128)
+            S1W_DUMP4(a10, 1, 0)
+            S1W_DUMP4(a11, 1, 128)
+            S1W_DUMP4(b00, 0, 256)
+            S1W_DUMP4(b01, 0, 384)
+            S1W_DUMP4(b10, 1, 256)
+            S1W_DUMP4(b11, 1, 384)
+#undef S1W_DUMP4
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A (see the fp32 body)
         s1_epilogue_append<X::SCAP>(p, stA, ck.n_rows, t, w, wgq0, a00, a01, a10, a11);

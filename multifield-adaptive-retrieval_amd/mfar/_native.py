@@ -85,6 +85,8 @@ SIGNATURES = {
     "mfar_screen_field_info": (_i, [_vp, _i, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "mfar_screen_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "mfar_set_stage2_mode": (_i, [_vp, _i]),
+    "mfar_set_stage2_dump": (_i, [_vp, _i]),
+    "mfar_stage2_dump_info": (_i, [_vp, _i, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "mfar_stage2_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
 }
 

@@ -399,6 +399,16 @@ class MultiFieldIndex:
         of any size.  Outputs are bit-identical in every mode."""
         _native.check(_native.lib().mfar_set_stage2_mode(self._h, int(mode)))
 
+    def set_stage2_dump(self, mode: int = 1):
+        """Score dump of the wide screened pass as the approximate level of stage 2 (include/mfar_hip.h): 0 never, 1 when it moves
+        fewer bytes than the row gathers, 2 whenever possible.  Outputs are bit-identical in every mode."""
+        _native.check(_native.lib().mfar_set_stage2_dump(self._h, int(mode)))
+
+    def stage2_dump_info(self, k1: int = 100) -> dict:
+        w, b, n = ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64()
+        _native.check(_native.lib().mfar_stage2_dump_info(self._h, int(k1), ctypes.byref(w), ctypes.byref(b), ctypes.byref(n)))
+        return dict(wanted=bool(w.value), bytes_per_launch=b.value, n_launches=n.value)
+
     def stage2_stats(self) -> dict:
         ok, nbytes, nc, ns = ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         _native.check(_native.lib().mfar_stage2_stats(self._h, ctypes.byref(ok), ctypes.byref(nbytes), ctypes.byref(nc), ctypes.byref(ns)))

@@ -235,3 +235,69 @@ def test_two_level_reuses_stage1_scores(idxmod):
             assert np.array_equal(reuse["ids"].cpu().numpy(), o["ids"])
             assert np.array_equal(reuse["scores"].cpu().numpy().view(np.uint32), o["scores"].view(np.uint32))
         ix.close()
+
+
+def test_score_dump_level_equals_row_gathers_and_oracle(idxmod):
+    """The approximate level read from the wide screened pass's SCORE DUMP (include/mfar_hip.h "SCORE DUMP"; forced with
+    set_stage2_dump(2)) instead of 16-bit row gathers: blocks of 65 .. 128 queries use it (info counter), prune, and return the bits of
+    the gather path, of the full fp32 gather and of the oracle -- duplicates (the dump is indexed by UNIQUE row), masks of any sign, both
+    sentinel modes, a mask sweep, hostile eps (everything survives), the split-phase pipeline over three slots, two row shards."""
+    import torch
+    rng = np.random.default_rng(305)
+    for F, D, E, Q, mean, dup in ((22, 20000, 128, 128, 0.2, 300), (8, 17000, 768, 100, 0.3, 7), (3, 30000, 96, 65, -0.2, 0)):
+        slab, q, W = _mk(rng, F, D, E, Q, mean=mean, dup=dup)
+        mask = rng.choice(np.array([0.0, 1.0, -1.0, 0.5, 1.0, 1.0], np.float32), F)
+        ix = _load(idxmod, slab)
+        for sentinel in (True, False):
+            o = O.c_two_stage(slab, q, W, mask, sentinel=sentinel)
+            ix.set_stage2_dump(0)
+            r_g = ix.search(q, W, mask, sentinel=sentinel)
+            assert ix.stage2_dump_info()["n_launches"] == 0 or sentinel is False
+            n0 = ix.stage2_dump_info()["n_launches"]
+            ix.set_stage2_dump(2)
+            s0 = ix.stage2_stats()
+            r_d = ix.search(q, W, mask, sentinel=sentinel)
+            s1 = ix.stage2_stats()
+            info = ix.stage2_dump_info()
+            assert info["n_launches"] == n0 + 1 and info["bytes_per_launch"] >= F * D * 512 * 0.5, info
+            if sentinel and mean > 0:
+                assert s1["n_survivors"] - s0["n_survivors"] < 0.7 * (s1["n_candidates"] - s0["n_candidates"])      # the dump's bound prunes too
+            _same(r_d, r_g, (F, D, E, sentinel, "dump vs gathers"))
+            assert np.array_equal(r_d["ids"], o["ids"]) and np.array_equal(r_d["scores"].view(np.uint32), o["scores"].view(np.uint32))
+        # more than 128 queries in one call: the dump would only hold the last block -- the gather path serves the call, same bits
+        q2 = np.concatenate([q, q, q])[:168]
+        n0 = ix.stage2_dump_info()["n_launches"]
+        r2 = ix.search(q2, W, mask)
+        assert ix.stage2_dump_info()["n_launches"] == n0
+        o2 = O.c_two_stage(slab, q2, W, mask)
+        assert np.array_equal(r2["ids"], o2["ids"]) and np.array_equal(r2["scores"].view(np.uint32), o2["scores"].view(np.uint32))
+        # hostile bound: every candidate survives, still the same bits
+        ix.set_screen(2, 1e9)
+        r3 = ix.search(q, W, mask)
+        o3 = O.c_two_stage(slab, q, W, mask)
+        assert np.array_equal(r3["ids"], o3["ids"]) and np.array_equal(r3["scores"].view(np.uint32), o3["scores"].view(np.uint32))
+        ix.set_screen(2, 1.0)
+        ix.close()
+    # the pipeline (three slots, coalesced launches of 128) and two row shards through the single-process exchange kernels
+    from mfar.data.pipeline import PipelinedSearcher
+    F, D, E = 6, 40000, 128
+    slab, _, W = _mk(rng, F, D, E, 1, dup=11)
+    ix = _load(idxmod, slab)
+    ix.set_stage2_dump(2)
+    dev = torch.device("cuda:0")
+    Wd = torch.from_numpy(W).to(dev)
+    qs = [(rng.standard_normal((64, E)) * 0.5 + 0.3).astype(np.float32) for _ in range(10)]
+    ps = PipelinedSearcher(ix, Wd, None, max_batch=64)
+    tk, got = [], []
+    for i, qq in enumerate(qs):
+        tk.append(ps.submit(torch.from_numpy(qq).to(dev)))
+        if i >= ps.lag:
+            got.append({k: v.clone() for k, v in ps.result(tk[i - ps.lag]).items()})
+    for t in tk[len(got):]:
+        got.append({k: v.clone() for k, v in ps.result(t).items()})
+    torch.cuda.synchronize()
+    assert ix.stage2_dump_info()["n_launches"] >= 5 and ps.n_redone == 0
+    for qq, g in zip(qs, got):
+        o = O.c_two_stage(slab, qq, W, None)
+        assert np.array_equal(g["ids"].cpu().numpy(), o["ids"]) and np.array_equal(g["scores"].cpu().numpy().view(np.uint32), o["scores"].view(np.uint32))
+    ix.close()
