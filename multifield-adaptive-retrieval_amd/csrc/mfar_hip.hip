@@ -171,6 +171,10 @@ static int set_kernel_attrs(int device) {
     if (g_attr_done[device]) return MFAR_OK;
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f32r_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1FR_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f32r_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1FR_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f32r4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1FR4_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f32r4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1FR4_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_lists_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_lists_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_merge_lists_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -582,7 +586,16 @@ static int launch_s1(int kind, bool sample, unsigned n_chunks, unsigned wave, hi
     const unsigned grid = p.only_failed ? std::min(n_chunks, wave) : n_chunks;
     const dim3 g(grid), b(S1_THREADS);
     if (kind == S1_F32) {
-        if (sample) mfar_stage1_sample_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
+        // register-ring variant (docs straight into VGPRs) when the k-steps divide into 6 or 4 register slots; MFAR_S1_REGRING=0: LDS ring
+        static const bool regring32 = !(getenv("MFAR_S1_REGRING") && atoi(getenv("MFAR_S1_REGRING")) == 0);
+        static const int f32_ring = getenv("MFAR_F32_RING") ? atoi(getenv("MFAR_F32_RING")) : 0;       // diagnostic: 4 forces the 4-slot twin
+        if (regring32 && p.n_steps % 6 == 0 && !(f32_ring == 4 && p.n_steps % 4 == 0)) {
+            if (sample) mfar_stage1_f32r_sample_kernel<<<g, b, S1FR_LDS_BYTES, st>>>(p);
+            else mfar_stage1_f32r_kernel<<<g, b, S1FR_LDS_BYTES, st>>>(p);
+        } else if (regring32 && p.n_steps % 4 == 0) {
+            if (sample) mfar_stage1_f32r4_sample_kernel<<<g, b, S1FR4_LDS_BYTES, st>>>(p);
+            else mfar_stage1_f32r4_kernel<<<g, b, S1FR4_LDS_BYTES, st>>>(p);
+        } else if (sample) mfar_stage1_sample_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
         else mfar_stage1_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
     } else if (kind == S1_F16W) {
         static const int w_ring = getenv("MFAR_WIDE_RING") ? atoi(getenv("MFAR_WIDE_RING")) : 0;   // diagnostic: 4 forces the 4-slot twin

@@ -884,6 +884,134 @@ __device__ __forceinline__ void s1_body_x16r(const S1Params& p, const int chunk_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Register-ring variant of the EXACT fp32 pass ("f32r").  v_mfma_f32_32x32x2_f32 takes its A operand from one VGPR per lane: lane
+// (j, h) supplies row 32 db + j, dim k = h, and the four MFMAs x = 0 .. 3 of a fragment consume dims 8 g + 4 h + x -- 16 contiguous
+// bytes of the row's 128-byte line in the fp32 slab (mfar_device.h).  So the docs do not need LDS here either: every lane loads its
+// four 16-byte pieces of a k-step (two doc blocks x two fragments) straight into one of R register slots, R - 1 k-steps ahead; only
+// the shared 4 KB query tile still goes through an LDS ring.  The chain order is the contract's (fragment 0 then 1, x ascending):
+// bits unchanged.  Why: the LDS-DMA doc stream of s1_body_f32 costs MFMA issue slots -- the same MFMA sequence sustains 150-155
+// TFLOP/s from registers and 119-130 beside an LDS-DMA stream at this kernel's ratio (profiles/r03_e_mfma_f32_clock_probe.txt).
+// Addresses: a wave-uniform base in SGPRs + per-lane 32-bit offsets (j * 128 + h * 16, and + 4096 for the second doc block: the
+// 13-bit immediate cannot carry it); the two k-steps of a pair read the same lines, the second time from L2.  Needs n_steps % R == 0.
+// (A variant that also took the QUERY fragments straight from memory -- no LDS, no barrier in the loop -- hung on the GPU and was
+// dropped unexplained: round 4.)
+// ---------------------------------------------------------------------------------------------------------------------
+#define S1_SCAP_F32R 32
+template <int R>
+struct S1FR {
+    static constexpr int LOADS = 5;                          // 4 doc pieces + the wave's quarter of the query tile
+    static constexpr int SCAP = S1_SCAP_F32R;
+    static constexpr int LDS_BYTES = R * 4096 + S1_STATE_BYTES_(S1_SCAP_F32R);
+};
+template <int R>
+__device__ __forceinline__ void s1_body_f32r(const S1Params& p, const int chunk_id) {
+    typedef S1FR<R> X;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const qring = smem;
+    const S1State st = s1_state(smem + R * 4096);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    const S1Chunk ck = s1_load_chunk(p, chunk_id);    // workgroup-uniform
+    const int f = ck.f;
+    if (p.only_failed && !p.only_failed[f]) return;   // workgroup-uniform
+    const int t0 = ck.t0;
+    int t1 = ck.t1;
+    if (p.sample) t1 = min(t1, t0 + (p.sample == 2 ? ck.ns : p.sample_tiles));
+    const size_t wgq0 = (size_t)chunk_id * p.qw;
+    s1_state_init(st, p, f);
+
+    // query fragments in the 4 KB LDS image of a k-step: row (32 blk + j), dims 8 g + 4 h .. + 3 (chunk c = 2 g + h, swizzled)
+    const int sw = (j >> 2) & 3;
+    const int off_g0 = j * 64 + (((0 + h) ^ sw) << 4);
+    const int off_g1 = j * 64 + (((2 + h) ^ sw) << 4);
+    // docs: this lane's piece of row (32 db + j) inside the 8 KB tile of a k-step pair
+    const u32 voff0 = (u32)(j * 128 + h * 16), voff1 = voff0 + 4096u;
+    const size_t step_bytes = 4096;
+    const size_t tile_jump = (size_t)3 * p.n_steps * step_bytes;       // from the end of the wave's block to its block of the next tile
+    const char* dblk = (const char*)p.slab + (size_t)ck.base * 4 + ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes;        // uniform
+    const char* const dlast_blk = (const char*)p.slab + (size_t)ck.base * 4 + ((size_t)(4 * (t1 - 1) + w) * p.n_steps) * step_bytes;
+    const char* const qbase = (const char*)p.qt + w * 1024;                                                              // uniform
+    const u32 ldsq = (u32)(uintptr_t)qring + (u32)w * 1024u;
+    const u32 l16 = (u32)lane * 16u;
+    int s_next = 0, pf_clamped = 0;
+    f32x4 dr[R][4];
+#define S1FR_ISSUE(SLOT)                                                                                   \
+    do {                                                                                                   \
+        const char* src_ = dblk + (size_t)(s_next >> 1) * 8192 + (size_t)(s_next & 1) * 64;                \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dr[SLOT][0]) : "v"(voff0), "s"(src_) : "memory");            \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=&v"(dr[SLOT][1]) : "v"(voff0), "s"(src_) : "memory");  \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dr[SLOT][2]) : "v"(voff1), "s"(src_) : "memory");            \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=&v"(dr[SLOT][3]) : "v"(voff1), "s"(src_) : "memory");  \
+        const char* qs_ = qbase + (size_t)s_next * step_bytes;                                             \
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(l16), "s"(qs_), "s"(ldsq + (u32)((SLOT) * 4096)) : "memory"); \
+        if (!pf_clamped && ++s_next == p.n_steps) {                                                        \
+            if (dblk == dlast_blk) {            /* past the chunk: keep re-reading its last stage (never consumed) */ \
+                s_next = p.n_steps - 1;                                                                    \
+                pf_clamped = 1;                                                                            \
+            } else {                                                                                       \
+                s_next = 0;                                                                                \
+                dblk += (size_t)p.n_steps * step_bytes + tile_jump;                                        \
+            }                                                                                              \
+        }                                                                                                  \
+    } while (0)
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) S1FR_ISSUE(i);
+
+    for (int t = t0; t < t1; ++t) {
+        f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};  // [doc block][query block]
+        for (int s0 = 0; s0 < p.n_steps; s0 += R) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                asm volatile("s_waitcnt vmcnt(%4)\n\ts_barrier"
+                             : "+v"(dr[u][0]), "+v"(dr[u][1]), "+v"(dr[u][2]), "+v"(dr[u][3])
+                             : "n"((R - 2) * X::LOADS)
+                             : "memory");
+                const char* curq = qring + u * 4096;
+                const f32x4 q00 = *(const f32x4*)(curq + off_g0);
+                const f32x4 q01 = *(const f32x4*)(curq + off_g1);
+                const f32x4 q10 = *(const f32x4*)(curq + 2048 + off_g0);
+                const f32x4 q11 = *(const f32x4*)(curq + 2048 + off_g1);
+                const f32x4 d00 = dr[u][0], d01 = dr[u][1], d10 = dr[u][2], d11 = dr[u][3];
+                // every wave is past the barrier: slot (u + R - 1) % R (the previous stage) is free
+                S1FR_ISSUE((u + R - 1) % R);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(d00[x], q00[x], acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(d00[x], q10[x], acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(d10[x], q00[x], acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(d10[x], q10[x], acc11, 0, 0, 0);
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(d01[x], q01[x], acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(d01[x], q11[x], acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(d11[x], q01[x], acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(d11[x], q11[x], acc11, 0, 0, 0);
+                }
+            }
+        }
+        if (p.dbg & 1) {
+            asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11));
+            continue;
+        }
+        if (p.sample == 2) {
+            s1_sample_top2(p, ck, t - t0, t, w, acc00, acc01, acc10, acc11);
+            continue;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A (see the fp32 body)
+        s1_epilogue<X::SCAP>(p, st, ck.n_rows, t, w, wgq0, acc00, acc01, acc10, acc11);
+    }
+#undef S1FR_ISSUE
+    // the stages issued past the end are still in flight: no LDS-DMA write may land after the workgroup has left
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.sample != 2) s1_flush<X::SCAP>(p, st, w, wgq0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // WIDE fp16 screen pass ("f16w"): 128 query columns per scan.  The screened pass is HBM-bound with the MFMA pipe at ~40 %
 // (two fp16 query terms x 64 queries = 8 MFMAs per 2 KB of docs per wave).  Spending the same 8 MFMAs on ONE fp16 term of
 // 128 queries reads the screen slab once per 128 queries instead of once per 64: half the scan bytes per query at the same
@@ -1310,6 +1438,12 @@ __device__ __forceinline__ void s1_body_bf16w(const S1Params& p, const int chunk
 // separately (the sample pass scans 1 tile per workgroup and is ~30x shorter).
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_f32) }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_sample_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_f32) }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f32r_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_f32r<6>) }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f32r_sample_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_f32r<6>) }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f32r4_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_f32r<4>) }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f32r4_sample_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_f32r<4>) }
+#define S1FR_LDS_BYTES (6 * 4096 + S1_STATE_BYTES_(S1_SCAP_F32R))
+#define S1FR4_LDS_BYTES (4 * 4096 + S1_STATE_BYTES_(S1_SCAP_F32R))
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_x16<0>) }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16_sample_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_x16<0>) }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16_kernel(const S1Params p) { s1_body_x16<1>(p, p.chunk0 + (int)blockIdx.x); }
