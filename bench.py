@@ -223,6 +223,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("MFAR_BENCH_KILL_RANK") == str(rank) and world > 1:      # test hook: this rank dies before it joins the group
+        raise SystemExit(f"rank {rank}: MFAR_BENCH_KILL_RANK")
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     N = world

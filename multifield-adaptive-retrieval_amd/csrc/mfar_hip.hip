@@ -588,13 +588,14 @@ static int launch_s1(int kind, bool sample, unsigned n_chunks, unsigned wave, hi
     if (kind == S1_F32) {
         // register-ring variant (docs straight into VGPRs) when the k-steps divide into 6 or 4 register slots; MFAR_S1_REGRING=0: LDS ring
         static const bool regring32 = !(getenv("MFAR_S1_REGRING") && atoi(getenv("MFAR_S1_REGRING")) == 0);
-        static const int f32_ring = getenv("MFAR_F32_RING") ? atoi(getenv("MFAR_F32_RING")) : 0;       // diagnostic: 4 forces the 4-slot twin
-        if (regring32 && p.n_steps % 6 == 0 && !(f32_ring == 4 && p.n_steps % 4 == 0)) {
-            if (sample) mfar_stage1_f32r_sample_kernel<<<g, b, S1FR_LDS_BYTES, st>>>(p);
-            else mfar_stage1_f32r_kernel<<<g, b, S1FR_LDS_BYTES, st>>>(p);
-        } else if (regring32 && p.n_steps % 4 == 0) {
+        static const int f32_ring = getenv("MFAR_F32_RING") ? atoi(getenv("MFAR_F32_RING")) : 0;       // diagnostic: 6 forces the 6-slot ring
+        // (4 slots: 237 VGPRs and no spills; 6 slots: 256 and 9 spilled around the epilogue -- measured equal, 6.91 / 6.93 ms at 1 M x 8 x 768)
+        if (regring32 && p.n_steps % 4 == 0 && !(f32_ring == 6 && p.n_steps % 6 == 0)) {
             if (sample) mfar_stage1_f32r4_sample_kernel<<<g, b, S1FR4_LDS_BYTES, st>>>(p);
             else mfar_stage1_f32r4_kernel<<<g, b, S1FR4_LDS_BYTES, st>>>(p);
+        } else if (regring32 && p.n_steps % 6 == 0) {
+            if (sample) mfar_stage1_f32r_sample_kernel<<<g, b, S1FR_LDS_BYTES, st>>>(p);
+            else mfar_stage1_f32r_kernel<<<g, b, S1FR_LDS_BYTES, st>>>(p);
         } else if (sample) mfar_stage1_sample_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
         else mfar_stage1_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
     } else if (kind == S1_F16W) {

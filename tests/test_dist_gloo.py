@@ -142,7 +142,7 @@ def _layout_worker(rank, world, port, tmp, R):
     lay = ReplicaLayout(world, rank, R)
     lay.make_groups()
     rng = np.random.default_rng(321)
-    F, D, E, Q, NB = 3, 803, 32, 4, 6
+    F, D, E, Q, NB = 3, 803, 32, 4, (6 if world == 4 else 11)      # (11 batches over 8 / 4 / 2 groups: an uneven deal)
     slab = (rng.standard_normal((F, D, E)) * 0.5 + 0.1).astype(np.float32)
     qs = rng.standard_normal((NB, Q, E)).astype(np.float32)
     W = (rng.standard_normal((E, F)) * 0.1).astype(np.float32)
@@ -156,6 +156,10 @@ def _layout_worker(rank, world, port, tmp, R):
         else:                                   # R = 1: a full replica answers alone, no collective at all
             from oracle import mfar_oracle as O
             out[b] = O.c_two_stage(slab, qs[b], W, None)
+    if world == 8 and R == 8:
+        assert lay.group is None and lay.G == 1                          # one group: the default process group carries the exchange
+    if world == 8 and R in (2, 4):
+        assert dist.get_world_size(lay.group) == R and dist.get_rank(lay.group) == lay.shard_index
     np.savez(os.path.join(tmp, f"lay{R}_rank{rank}.npz"), batches=np.array(sorted(out), np.int64), r0=r0, r1=r1,
              ids=np.stack([out[b]["ids"] for b in sorted(out)]) if out else np.zeros((0, Q, 100), np.int64),
              scores=np.stack([out[b]["scores"] for b in sorted(out)]) if out else np.zeros((0, Q, 100), np.float32))
@@ -163,20 +167,22 @@ def _layout_worker(rank, world, port, tmp, R):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("R", [1, 2, 4])
-def test_replica_groups_times_row_shards_over_gloo(tmp_path, R):
-    """mfar/data/sharded.py ReplicaLayout with 4 gloo ranks: N = G groups x R row shards for R in {1, 2, 4}.  Batches are dealt
-    round-robin to the groups (contrastive.py:200), a group's ranks hold the reference's row split of the corpus (:470) and
-    exchange only among themselves; whatever R, every batch gets the unsharded oracle's ids and score bits, exactly once per
-    group member."""
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,R", [(4, 1), (4, 2), (4, 4), (8, 8), (8, 4), (8, 2), (8, 1)])
+def test_replica_groups_times_row_shards_over_gloo(tmp_path, world, R):
+    """mfar/data/sharded.py ReplicaLayout with 4 and with EIGHT gloo ranks (the node size the driver's scaling run uses; the GPU box
+    admits at most six processes on its card, so the eight-rank control flow -- group creation for 1 x 8 / 2 x 4 / 4 x 2 / 8 x 1, the
+    row split, batch dealing, the exchange inside a group -- is exercised here, on the CPU, with the oracle-backed double): N = G groups
+    x R row shards.  Batches are dealt round-robin to the groups (contrastive.py:200), a group's ranks hold the reference's row split
+    of the corpus (:470) and exchange only among themselves; whatever R, every batch gets the unsharded oracle's ids and score bits,
+    exactly once per group member."""
     import hashlib
-    world, port = 4, 30300 + (os.getpid() % 300) + 7 * R
+    port = 30300 + (os.getpid() % 300) + 7 * R + 61 * world
     mp.spawn(_layout_worker, args=(world, port, str(tmp_path), R), nprocs=world, join=True)
     from oracle import mfar_oracle as O
     from mfar.data.sharded import ReplicaLayout, choose_row_shards
     rng = np.random.default_rng(321)
-    F, D, E, Q, NB = 3, 803, 32, 4, 6
+    F, D, E, Q, NB = 3, 803, 32, 4, (6 if world == 4 else 11)
     slab = (rng.standard_normal((F, D, E)) * 0.5 + 0.1).astype(np.float32)
     qs = rng.standard_normal((NB, Q, E)).astype(np.float32)
     W = (rng.standard_normal((E, F)) * 0.1).astype(np.float32)

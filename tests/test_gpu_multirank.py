@@ -90,6 +90,35 @@ def test_replica_group_layouts_match_single_rank(R):
     assert four["ids_checksum"] == one["ids_checksum"] and four["recall_at_20"] == one["recall_at_20"]
 
 
+@pytest.mark.parametrize("R", [5, 1])
+def test_five_ranks_on_one_gpu_odd_world_and_padded_launch(R):
+    """The largest world this pool admits on one card (six processes may hold the GPU: five ranks + this test process) -- the
+    eight-rank layouts run on the CPU in tests/test_dist_gloo.py.  Five ranks, an ODD world: row shards of unequal size (70 000 / 5
+    is even, so 5 steps x 64 queries leave every group a short last launch with --row-shards 1, and the single group of --row-shards 5
+    pads its last coalesced launch), every rank named in the proof block, ids of every step equal to the single-rank run's."""
+    one = _bench(1, {"MFAR_BENCH_DUMP_IDS": "1"}, extra_args=["--steps", "5"])
+    five = _bench(5, {"MFAR_BENCH_BACKEND": "gloo", "MFAR_BENCH_SHARE_GPU": "1", "MFAR_BENCH_DUMP_IDS": "1"}, launcher=False,
+                  extra_args=["--steps", "5", "--row-shards", str(R)])
+    assert five["n_gpus"] == 5 and five["rccl"]["world_size"] == 5 and five["rccl"]["allreduce_of_ones"] == 5.0
+    assert len({r["pid"] for r in five["rccl"]["ranks"]}) == 5
+    assert five["config"]["row_shards"] == R and five["config"]["replica_groups"] == 5 // R
+    rows = [r["rows"] for r in five["rccl"]["ranks"]]
+    assert rows == ([[70000 * i // 5, 70000 * (i + 1) // 5] for i in range(5)] if R == 5 else [[0, 70000]] * 5)
+    assert five["ids_checksum"] == one["ids_checksum"] and five["recall_at_20"] == one["recall_at_20"]
+
+
+def test_bench_fails_when_one_of_four_ranks_dies():
+    """One rank of four exits while the others are inside the run (a rank-specific failure, not a shared refusal): the launcher
+    terminates the rest and returns non-zero, no line is printed, nothing hangs."""
+    env = dict(os.environ, MFAR_BENCH_BACKEND="gloo", MFAR_BENCH_SHARE_GPU="1", MFAR_BENCH_KILL_RANK="2")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--docs", "20000", "--fields", "2", "--dim", "64",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra-legs"], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "rank 2 exited" in out.stderr
+
+
 def test_exchange_path_over_rccl_with_one_rank():
     """RCCL itself: a one-rank nccl process group on cuda:0 carries the two all-gathers of every launch of the pipelined
     searcher's exchange path (fp32 index with the wide screened pass, bf16 index); results equal the plain search bit for bit."""
