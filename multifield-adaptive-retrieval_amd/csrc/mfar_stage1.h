@@ -1278,7 +1278,7 @@ __device__ __forceinline__ void s1_body_bf16w(const S1Params& p, const int chunk
     const char* const qbase = (const char*)p.qt + w * 1024;   // wave w loads pieces w and 4 + w of the 8 KB stage (CV: piece w of 4 KB)   // uniform
     const u32 ldsq = (u32)(uintptr_t)qring + (u32)w * 1024u;                                                            // uniform
     u32 tmin2 = 0, bias2 = 0;
-    if (CV) {
+    if (CV == 1) {
         const uint2 cv = p.cvt[f];
         tmin2 = __builtin_amdgcn_readfirstlane(cv.x);
         bias2 = __builtin_amdgcn_readfirstlane(cv.y);
@@ -1343,10 +1343,10 @@ __device__ __forceinline__ void s1_body_bf16w(const S1Params& p, const int chunk
                         const f16x8 qa0 = *(const f16x8*)(curq + off), qa1 = *(const f16x8*)(curq + 1024 + off);
                         const f16x8 qb0 = *(const f16x8*)(curq + 2048 + off), qb1 = *(const f16x8*)(curq + 3072 + off);
                         S1BW_ISSUE((u + R - 1) % R);
-                        const f16x8 e0 = s1_cvt_granule(__builtin_bit_cast(u32x4, d0), tmin2, bias2);
+                        const f16x8 e0 = CV == 2 ? __builtin_bit_cast(f16x8, d0) : s1_cvt_granule(__builtin_bit_cast(u32x4, d0), tmin2, bias2);
                         a00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qa0, a00, 0, 0, 0);
                         a01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qa1, a01, 0, 0, 0);
-                        const f16x8 e1 = s1_cvt_granule(__builtin_bit_cast(u32x4, d1), tmin2, bias2);
+                        const f16x8 e1 = CV == 2 ? __builtin_bit_cast(f16x8, d1) : s1_cvt_granule(__builtin_bit_cast(u32x4, d1), tmin2, bias2);
                         b00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qb0, b00, 0, 0, 0);
                         b01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qb1, b01, 0, 0, 0);
                         a10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, qa0, a10, 0, 0, 0);
@@ -1387,6 +1387,31 @@ __device__ __forceinline__ void s1_body_bf16w(const S1Params& p, const int chunk
                 s1_sample_top2(p, ck, t - cur.t0, t, w, a00, a01, a10, a11, 0);
                 s1_sample_top2(p, ck, t - cur.t0, t, w, b00, b01, b10, b11, 64);
                 continue;
+            }
+            if (CV == 2 && p.dump && !p.sample) {
+                // score dump (S1Params::dump): row (32 db + (r & 3) + 8 (r >> 2) + 4 h) of the wave's block, query column 64 blk + 32 x + j.
+                // One SGPR base per (doc block, r >> 2), one per-lane offset, the rest in the immediate; a store instruction covers two
+                // rows x 32 consecutive queries (two full 128-byte lines).  Issued BEFORE the selection epilogue so that the stores have
+                // left the vmcnt queue by the time the next tile's counted waits look at it.
+                const u32 voff = (u32)((lane >> 5) * 4 * 512 + (lane & 31) * 4);
+                const char* const dtile = (const char*)p.dump + ((size_t)p.dump_base[f] + (size_t)t * S1_TILE_ROWS + (size_t)w * 64) * 512;
+#define S1W_DUMP4(ACC, DB, Q0)                                                                                                  \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                                          \
+        const char* sb_ = dtile + (size_t)(32 * (DB) + 8 * g_) * 512;                                                           \
+        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(ACC[4 * g_ + 0]), "s"(sb_), "n"((Q0)) : "memory");           \
+        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(ACC[4 * g_ + 1]), "s"(sb_), "n"((Q0) + 512) : "memory");     \
+        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(ACC[4 * g_ + 2]), "s"(sb_), "n"((Q0) + 1024) : "memory");    \
+        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(ACC[4 * g_ + 3]), "s"(sb_), "n"((Q0) + 1536) : "memory");    \
+    }
+                S1W_DUMP4(a00, 0, 0)
+                S1W_DUMP4(a01, 0, 128)
+                S1W_DUMP4(a10, 1, 0)
+                S1W_DUMP4(a11, 1, 128)
+                S1W_DUMP4(b00, 0, 256)
+                S1W_DUMP4(b01, 0, 384)
+                S1W_DUMP4(b10, 1, 256)
+                S1W_DUMP4(b11, 1, 384)
+#undef S1W_DUMP4
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A (see the fp32 body)
             if (dyn && t == cur.t0 && tid == 0) {         // the claim issued a whole tile ago is back: publish it (read after barrier B)
@@ -1498,6 +1523,16 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c_kernel(const 
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c_sample_kernel(const S1Params p) { s1_body_bf16w<6, S1BC_SCAP, 1>(p, p.chunk0 + (int)blockIdx.x); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c4_kernel(const S1Params p) { s1_body_bf16w<4, S1BC_SCAP, 1>(p, p.chunk0 + (int)blockIdx.x); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c4_sample_kernel(const S1Params p) { s1_body_bf16w<4, S1BC_SCAP, 1>(p, p.chunk0 + (int)blockIdx.x); }
+// the same body over the fp16 SCREEN slab of an fp32 index (CV = 2: the granules are fp16 already): the wide pass of the headline
+#ifndef S1FV_SCAP
+#define S1FV_SCAP 32
+#endif
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16v_kernel(const S1Params p) { s1_body_bf16w<6, S1FV_SCAP, 2>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16v_sample_kernel(const S1Params p) { s1_body_bf16w<6, S1FV_SCAP, 2>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16v4_kernel(const S1Params p) { s1_body_bf16w<4, S1FV_SCAP, 2>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16v4_sample_kernel(const S1Params p) { s1_body_bf16w<4, S1FV_SCAP, 2>(p, p.chunk0 + (int)blockIdx.x); }
+#define S1FV_LDS_BYTES (6 * 4096 + 2 * S1_STATE_BYTES_(S1FV_SCAP))
+#define S1FV4_LDS_BYTES (4 * 4096 + 2 * S1_STATE_BYTES_(S1FV_SCAP))
 #define S1BC_LDS_BYTES (6 * 4096 + 2 * S1_STATE_BYTES_(S1BC_SCAP))
 #define S1BC4_LDS_BYTES (4 * 4096 + 2 * S1_STATE_BYTES_(S1BC_SCAP))
 #define S1BW_LDS_BYTES (6 * 8192 + 2 * S1_STATE_BYTES_(S1BW_SCAP6))
