@@ -360,7 +360,7 @@ def main():
     # Setup, not warm-up: the first batches allocate the pipeline's scratch (both slots) and build the fp16 screen slab and the
     # gather slab of an fp32 index (one pass over the corpus each, part of index construction).  --warmup steps follow as asked.
     t_rows = time.time() - t_build0 - t_synth  # rows generated on the device and written into the tiled slab (mfar_index_write_rows)
-    run(ps, corpus, lay.my_batches(0, 2 * lay.G * ps.coalesce), None)
+    run(ps, corpus, lay.my_batches(0, max(2, ps.depth) * lay.G * ps.coalesce), None)      # (every slot of the pipeline has launched once)
     torch.cuda.synchronize()
     t_build = time.time() - t_build0
     # what a weight update costs (training-time validation re-encodes the corpus and rebuilds): rows of one field rewritten -> searchable

@@ -211,10 +211,6 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16s4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HR4_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BW_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16w_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BW_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16v_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1FV_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16v_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1FV_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16v4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1FV4_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16v4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1FV4_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BC_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16c_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BC_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16c4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BC4_LDS_BYTES));
@@ -602,15 +598,6 @@ static int launch_s1(int kind, bool sample, unsigned n_chunks, unsigned wave, hi
             else mfar_stage1_f32r_kernel<<<g, b, S1FR_LDS_BYTES, st>>>(p);
         } else if (sample) mfar_stage1_sample_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
         else mfar_stage1_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
-    } else if (kind == S1_F16W && getenv("MFAR_F16W_V") && atoi(getenv("MFAR_F16W_V")) == 1) {     // experiment: the unified wide body
-        static const int w_ring = getenv("MFAR_WIDE_RING") ? atoi(getenv("MFAR_WIDE_RING")) : 0;
-        if (p.n_steps % 6 == 0 && !(w_ring == 4 && p.n_steps % 4 == 0)) {
-            if (sample) mfar_stage1_f16v_sample_kernel<<<g, b, S1FV_LDS_BYTES, st>>>(p);
-            else mfar_stage1_f16v_kernel<<<g, b, S1FV_LDS_BYTES, st>>>(p);
-        } else {
-            if (sample) mfar_stage1_f16v4_sample_kernel<<<g, b, S1FV4_LDS_BYTES, st>>>(p);
-            else mfar_stage1_f16v4_kernel<<<g, b, S1FV4_LDS_BYTES, st>>>(p);
-        }
     } else if (kind == S1_F16W) {
         static const int w_ring = getenv("MFAR_WIDE_RING") ? atoi(getenv("MFAR_WIDE_RING")) : 0;   // diagnostic: 4 forces the 4-slot twin
         if (p.n_steps % 6 == 0 && !(w_ring == 4 && p.n_steps % 4 == 0)) {
@@ -821,8 +808,7 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
         // dynamic work distribution (mfar_stage1.h s1_unit_*): the kernels that have it, full passes that are not repairs
         static const bool dyn_on = !(getenv("MFAR_S1_DYN") && atoi(getenv("MFAR_S1_DYN")) == 0);
         static const int unit_tiles = getenv("MFAR_UNIT_TILES") ? std::max(2, atoi(getenv("MFAR_UNIT_TILES"))) : 2;
-        static const bool f16w_v = getenv("MFAR_F16W_V") && atoi(getenv("MFAR_F16W_V")) == 1;
-        if (dyn_on && !repair && (kind == S1_BF16W || kind == S1_BF16C || (kind == S1_F16W && f16w_v))) {
+        if (dyn_on && !repair && s1_is_wide(kind)) {
             RETCHK(sl.unit_ctr.ensure((size_t)MFAR_MAX_FIELDS * sizeof(int)));
             HIPCHK(hipMemsetAsync(sl.unit_ctr.p, 0, (size_t)MFAR_MAX_FIELDS * sizeof(int), st));
             p.unit_ctr = sl.unit_ctr.as<int>();

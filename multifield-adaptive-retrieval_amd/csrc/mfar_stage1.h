@@ -1012,151 +1012,25 @@ __device__ __forceinline__ void s1_body_f32r(const S1Params& p, const int chunk_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// WIDE fp16 screen pass ("f16w"): 128 query columns per scan.  The screened pass is HBM-bound with the MFMA pipe at ~40 %
-// (two fp16 query terms x 64 queries = 8 MFMAs per 2 KB of docs per wave).  Spending the same 8 MFMAs on ONE fp16 term of
-// 128 queries reads the screen slab once per 128 queries instead of once per 64: half the scan bytes per query at the same
-// MFMA load.  The price is the query rounding error (u16 |q_i| per element instead of u16^2), which the certificate's
-// bound accounts for (mfar_screen.h: eps roughly doubles; the re-scored margin k' - k is as wide as before).
-// Same structure as s1_body_x16r<1, R>: 4 waves, two workgroups per CU, docs in a register ring, the 4 KB query stage (two
-// 64-query blocks x 2 KB) in an LDS ring, 8 accumulators (128 VGPRs), one selection state per 64-query block; the append
+// WIDE passes: 128 query columns per scan (s1_body_wide below; kernels mfar_stage1_f16w_* over the fp16 screen slab of an fp32 index,
+// mfar_stage1_bf16c_* / bf16w_* over a bf16 slab).  The 64-column screened pass is HBM-bound with the MFMA pipe at ~40 % (two fp16
+// query terms x 64 queries = 8 MFMAs per 2 KB of docs per wave).  Spending the same 8 MFMAs on ONE fp16 term of 128 queries reads the
+// slab once per 128 queries instead of once per 64: half the scan bytes per query at the same MFMA load.  The price is the query
+// rounding error (u16 |q_i| per element instead of u16^2), which the certificate's bound accounts for (mfar_screen.h: eps roughly
+// doubles; the re-scored margin k' - k is as wide as before).  4 waves, two workgroups per CU, docs in a register ring, the query
+// stage (two 64-query blocks x 2 KB) in an LDS ring, 8 accumulators (128 VGPRs), one selection state per 64-query block; the append
 // half of the epilogue runs for both blocks before anything register-hungry (drain, compaction) does.
-// Shapes that were measured and dropped (1 M x 8 x 768, 2.0-2.3 ms per launch for this one): ONE workgroup per CU -- 8 waves
-// of 32 rows x 128 queries (184 VGPRs, no spills: 3.2 ms) or these 4 waves with a 12-slot ring and 512 VGPRs (3.6 ms): with a
-// single barrier domain per CU every late load stalls the whole CU.  The price of this shape is its register file: 256 VGPRs
-// x 2 waves per SIMD leave no room for the small kernels of the neighbouring launches, which therefore run between the
-// scans, not beside them (the 64-column pass, 221 VGPRs, does leave room).
+// Shapes that were measured and dropped (1 M x 8 x 768, 2.0-2.3 ms per launch for this one): ONE workgroup per CU -- 8 waves of 32
+// rows x 128 queries (184 VGPRs, no spills: 3.2 ms) or these 4 waves with a 12-slot ring and 512 VGPRs (3.6 ms): with a single barrier
+// domain per CU every late load stalls the whole CU.  The price of this shape is its register file: 256 VGPRs x 2 waves per SIMD
+// leave no room for the small kernels of the neighbouring launches, which therefore run between the scans, not beside them.
+// Round 4: wave-uniform address bases in SGPRs + one per-lane 32-bit offset (no 64-bit VALU address arithmetic in the loop, fewer
+// spills around the epilogue) and dynamic work distribution: 2.10-2.13 -> 1.99-2.02 ms per launch at 1 M x 8 x 768 (0.67 -> 0.71 of
+// 8 TB/s).
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef S1_SCAP_WIDE
 #define S1_SCAP_WIDE 32
-template <int R>
-struct S1W {
-    static constexpr int Q_STAGE = 4096;
-    static constexpr int LOADS = 3;
-    static constexpr int SCAP = S1_SCAP_WIDE;
-    static constexpr int LDS_BYTES = R * Q_STAGE + 2 * S1_STATE_BYTES_(SCAP);
-};
-
-template <int R>
-__device__ __forceinline__ void s1_body_f16w(const S1Params& p, const int chunk_id) {
-    typedef S1W<R> X;
-    typedef short vec8 __attribute__((ext_vector_type(8)));
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const qring = smem;
-    const S1State stA = s1_state(smem + R * X::Q_STAGE);
-    const S1State stB = s1_state(smem + R * X::Q_STAGE + S1_STATE_BYTES_(X::SCAP));
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, h = lane >> 5;
-
-    const S1Chunk ck = s1_load_chunk(p, chunk_id);    // workgroup-uniform
-    const int f = ck.f;
-    if (p.only_failed && !p.only_failed[f]) return;
-    const int t0 = ck.t0;
-    int t1 = ck.t1;
-    if (p.sample) t1 = min(t1, t0 + (p.sample == 2 ? ck.ns : p.sample_tiles));
-    const size_t wgq0 = (size_t)chunk_id * p.qw;      // qw == 128
-    s1_state_init(stA, p, f, 0);
-    s1_state_init(stB, p, f, 64);
-
-    const int off = j * 32 + ((h ^ ((j >> 3) & 1)) << 4);
-    const size_t step_bytes = 2048;
-    const size_t tile_jump = (size_t)3 * p.n_steps * step_bytes;
-    const char* dnext = (const char*)p.slab + (size_t)ck.base * 2 + ((size_t)(4 * t0 + w) * p.n_steps) * step_bytes + off;
-    const char* const qbase = (const char*)p.qt + lane * 16 + w * 1024;   // wave w loads piece w of the 4 KB stage
-    int s_next = 0;
-    const char* const dlast = (const char*)p.slab + (size_t)ck.base * 2 +
-                              ((size_t)(4 * (t1 - 1) + w) * p.n_steps + (p.n_steps - 1)) * step_bytes + off;
-    vec8 dr0[R], dr1[R];
-#define S1W_QDMA(S, D)                                                                                           \
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(S), "s"(__builtin_amdgcn_readfirstlane((int)(u32)(uintptr_t)(D))) : "memory")
-#define S1W_ISSUE(SLOT)                                                                                   \
-    do {                                                                                                  \
-        asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(dr0[SLOT]) : "v"(dnext) : "memory");    \
-        asm volatile("global_load_dwordx4 %0, %1, off offset:1024 nt" : "=&v"(dr1[SLOT]) : "v"(dnext) : "memory"); \
-        S1W_QDMA(qbase + (size_t)s_next * X::Q_STAGE, qring + (SLOT) * X::Q_STAGE + w * 1024);             \
-        const char* nx_ = dnext + step_bytes;                                                             \
-        if (++s_next == p.n_steps) {                                                                      \
-            s_next = 0;                                                                                   \
-            nx_ += tile_jump;                                                                             \
-        }                                                                                                 \
-        dnext = (unsigned long long)nx_ <= (unsigned long long)dlast ? nx_ : dlast;                       \
-    } while (0)
-#pragma unroll
-    for (int i = 0; i < R - 1; ++i) S1W_ISSUE(i);
-
-    for (int t = t0; t < t1; ++t) {
-        // [query block A/B][doc block][query half]
-        f32x16 a00 = {0}, a01 = {0}, a10 = {0}, a11 = {0}, b00 = {0}, b01 = {0}, b10 = {0}, b11 = {0};
-        for (int s0 = 0; s0 < p.n_steps; s0 += R) {
-#pragma unroll
-            for (int u = 0; u < R; ++u) {
-                asm volatile("s_waitcnt vmcnt(%2)\n\ts_barrier" : "+v"(dr0[u]), "+v"(dr1[u]) : "n"((R - 2) * X::LOADS) : "memory");
-                const char* curq = qring + u * X::Q_STAGE;
-                const f16x8 e0 = __builtin_bit_cast(f16x8, dr0[u]), e1 = __builtin_bit_cast(f16x8, dr1[u]);
-                const f16x8 qa0 = *(const f16x8*)(curq + off), qa1 = *(const f16x8*)(curq + 1024 + off);
-                const f16x8 qb0 = *(const f16x8*)(curq + 2048 + off), qb1 = *(const f16x8*)(curq + 3072 + off);
-                S1W_ISSUE((u + R - 1) % R);
-                a00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qa0, a00, 0, 0, 0);
-                a01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qa1, a01, 0, 0, 0);
-                a10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, qa0, a10, 0, 0, 0);
-                a11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, qa1, a11, 0, 0, 0);
-                b00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qb0, b00, 0, 0, 0);
-                b01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, qb1, b01, 0, 0, 0);
-                b10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, qb0, b10, 0, 0, 0);
-                b11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, qb1, b11, 0, 0, 0);
-            }
-        }
-        if (p.dbg & 1) {
-            asm volatile("" ::"v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(b00), "v"(b01), "v"(b10), "v"(b11));
-            continue;
-        }
-        if (p.sample == 2) {
-            s1_sample_top2(p, ck, t - t0, t, w, a00, a01, a10, a11, 0);
-            s1_sample_top2(p, ck, t - t0, t, w, b00, b01, b10, b11, 64);
-            continue;
-        }
-        if (p.dump && !p.sample) {
-            // score dump: row (32 db + (r & 3) + 8 (r >> 2) + 4 h) of the wave's block, query column 64 blk + 32 x + j.  One SGPR base per
-            // (doc block, r >> 2), one per-lane offset, the rest in the immediate; a store instruction covers two rows x 32 consecutive
-            // queries (two full 128-byte lines).  Issued BEFORE the selection epilogue so that the stores have left the vmcnt queue by the
-            // time the next tile's counted waits look at it.
-            const u32 voff = (u32)(h * 4 * 512 + j * 4);
-            const char* const dtile = (const char*)p.dump + ((size_t)p.dump_base[f] + (size_t)t * S1_TILE_ROWS + (size_t)w * 64) * 512;
-#define S1W_DUMP4(ACC, DB, Q0)                                                                                                  \
-    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                                          \
-        const char* sb_ = dtile + (size_t)(32 * (DB) + 8 * g_) * 512;                                                           \
-        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(ACC[4 * g_ + 0]), "s"(sb_), "n"((Q0)) : "memory");           \
-        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(ACC[4 * g_ + 1]), "s"(sb_), "n"((Q0) + 512) : "memory");     \
-        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(ACC[4 * g_ + 2]), "s"(sb_), "n"((Q0) + 1024) : "memory");    \
-        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(ACC[4 * g_ + 3]), "s"(sb_), "n"((Q0) + 1536) : "memory");    \
-    }
-            S1W_DUMP4(a00, 0, 0)
-            S1W_DUMP4(a01, 0, 128)
-            S1W_DUMP4(a10, 1, 0)
-            S1W_DUMP4(a11, 1, 128)
-            S1W_DUMP4(b00, 0, 256)
-            S1W_DUMP4(b01, 0, 384)
-            S1W_DUMP4(b10, 1, 256)
-            S1W_DUMP4(b11, 1, 384)
-#undef S1W_DUMP4
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A (see the fp32 body)
-        s1_epilogue_append<X::SCAP>(p, stA, ck.n_rows, t, w, wgq0, a00, a01, a10, a11);
-        s1_epilogue_append<X::SCAP>(p, stB, ck.n_rows, t, w, wgq0 + 64, b00, b01, b10, b11);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier B for both blocks; the accumulators are dead from here
-        s1_epilogue_finish<X::SCAP>(p, stA, w, wgq0);
-        s1_epilogue_finish<X::SCAP>(p, stB, w, wgq0 + 64);
-    }
-#undef S1W_ISSUE
-#undef S1W_QDMA
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (p.sample != 2) {
-        s1_flush<X::SCAP>(p, stA, w, wgq0);
-        s1_flush<X::SCAP>(p, stB, w, wgq0 + 64);
-    }
-}
-
+#endif
 // ---------------------------------------------------------------------------------------------------------------------
 // Dynamic work distribution (S1Params::unit_ctr).  A scan grid is ONE wave of workgroups that fill the register file, and a
 // workgroup with a fixed chunk runs for the whole kernel: any workgroup the dispatcher places late -- because the small
@@ -1192,7 +1066,7 @@ __device__ __forceinline__ void s1_unit_claim_async(int* ctr, int& raw) {
 // copy.  Two bf16 query terms (hi + mid = 16 significant bits; every product exact in fp32) x 128 columns = 16 MFMAs per 2 KB of
 // docs per wave: the slab is read once per 128 queries (the exact bf16 pass: three terms x 64 columns, once per 64), and the
 // only approximation left is the query's third term -- the certificate's eps is ~6x tighter than the fp16 screen's
-// (mfar_screen.h).  Structure of s1_body_f16w; the query stage is 8 KB per k-step ([term][query block][64][16]), two LDS-DMA
+// (mfar_screen.h).  The query stage is 8 KB per k-step ([term][query block][64][16]), two LDS-DMA
 // pieces per wave.  The pass scans every document and ranks unique rows (s1_acc_init).
 // ---------------------------------------------------------------------------------------------------------------------
 //
@@ -1227,7 +1101,7 @@ __device__ __forceinline__ f16x8 s1_cvt_granule(u32x4 g, u32 tmin2, u32 bias2) {
 }
 
 template <int R, int SCAP_, int CV>
-__device__ __forceinline__ void s1_body_bf16w(const S1Params& p, const int chunk_id) {
+__device__ __forceinline__ void s1_body_wide(const S1Params& p, const int chunk_id) {
     typedef S1BW<R, SCAP_, CV> X;
     typedef short vec8 __attribute__((ext_vector_type(8)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1490,11 +1364,12 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r4_kernel(const
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16r4_sample_kernel(const S1Params p) { S1_CHUNK_LOOP(s1_body_x16r<0 S1_COMMA  4>) }
 #define S1HR4_LDS_BYTES (4 * 4096 + S1_STATE_BYTES_(S1_SCAP_REG))
 #define S1BR4_LDS_BYTES (4 * 6144 + S1_STATE_BYTES_(S1_SCAP_REG / 2))
-// wide fp16 screen pass (128 queries, one fp16 term): 6-slot ring for k-steps divisible by 6, 4-slot twin otherwise
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_kernel(const S1Params p) { s1_body_f16w<6>(p, p.chunk0 + (int)blockIdx.x); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_sample_kernel(const S1Params p) { s1_body_f16w<6>(p, p.chunk0 + (int)blockIdx.x); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_kernel(const S1Params p) { s1_body_f16w<4>(p, p.chunk0 + (int)blockIdx.x); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_sample_kernel(const S1Params p) { s1_body_f16w<4>(p, p.chunk0 + (int)blockIdx.x); }
+// wide fp16 screen pass (128 queries, one fp16 term; CV = 2: the granules are fp16 already): 6-slot ring for k-steps divisible by 6,
+// 4-slot twin otherwise
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_kernel(const S1Params p) { s1_body_wide<6, S1_SCAP_WIDE, 2>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_sample_kernel(const S1Params p) { s1_body_wide<6, S1_SCAP_WIDE, 2>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_kernel(const S1Params p) { s1_body_wide<4, S1_SCAP_WIDE, 2>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_sample_kernel(const S1Params p) { s1_body_wide<4, S1_SCAP_WIDE, 2>(p, p.chunk0 + (int)blockIdx.x); }
 #define S1HW_LDS_BYTES (6 * 4096 + 2 * S1_STATE_BYTES_(S1_SCAP_WIDE))
 // certified passes over a bf16 slab: 64 columns x two bf16 terms (register ring of 6 / 4 slots), 128 columns x two terms
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16s_kernel(const S1Params p) { s1_body_x16r<2, 6>(p, p.chunk0 + (int)blockIdx.x); }
@@ -1510,29 +1385,19 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16s4_sample_kerne
 #ifndef S1BW_SCAP6
 #define S1BW_SCAP6 8                         // 6-slot query ring (48 KB): dims whose k-steps do not divide by 4
 #endif
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w_kernel(const S1Params p) { s1_body_bf16w<6, S1BW_SCAP6, 0>(p, p.chunk0 + (int)blockIdx.x); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w_sample_kernel(const S1Params p) { s1_body_bf16w<6, S1BW_SCAP6, 0>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w_kernel(const S1Params p) { s1_body_wide<6, S1BW_SCAP6, 0>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w_sample_kernel(const S1Params p) { s1_body_wide<6, S1BW_SCAP6, 0>(p, p.chunk0 + (int)blockIdx.x); }
 #ifndef S1BW_SCAP4
 #define S1BW_SCAP4 16
 #endif
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w4_kernel(const S1Params p) { s1_body_bf16w<4, S1BW_SCAP4, 0>(p, p.chunk0 + (int)blockIdx.x); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w4_sample_kernel(const S1Params p) { s1_body_bf16w<4, S1BW_SCAP4, 0>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w4_kernel(const S1Params p) { s1_body_wide<4, S1BW_SCAP4, 0>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16w4_sample_kernel(const S1Params p) { s1_body_wide<4, S1BW_SCAP4, 0>(p, p.chunk0 + (int)blockIdx.x); }
 // converted docs x one fp16 query term (CV = 1): 6-slot ring (24 KB) or 4-slot twin, 16-entry staging areas: 42.5 / 34.5 KB of LDS
 #define S1BC_SCAP 16
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c_kernel(const S1Params p) { s1_body_bf16w<6, S1BC_SCAP, 1>(p, p.chunk0 + (int)blockIdx.x); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c_sample_kernel(const S1Params p) { s1_body_bf16w<6, S1BC_SCAP, 1>(p, p.chunk0 + (int)blockIdx.x); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c4_kernel(const S1Params p) { s1_body_bf16w<4, S1BC_SCAP, 1>(p, p.chunk0 + (int)blockIdx.x); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c4_sample_kernel(const S1Params p) { s1_body_bf16w<4, S1BC_SCAP, 1>(p, p.chunk0 + (int)blockIdx.x); }
-// the same body over the fp16 SCREEN slab of an fp32 index (CV = 2: the granules are fp16 already): the wide pass of the headline
-#ifndef S1FV_SCAP
-#define S1FV_SCAP 32
-#endif
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16v_kernel(const S1Params p) { s1_body_bf16w<6, S1FV_SCAP, 2>(p, p.chunk0 + (int)blockIdx.x); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16v_sample_kernel(const S1Params p) { s1_body_bf16w<6, S1FV_SCAP, 2>(p, p.chunk0 + (int)blockIdx.x); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16v4_kernel(const S1Params p) { s1_body_bf16w<4, S1FV_SCAP, 2>(p, p.chunk0 + (int)blockIdx.x); }
-__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16v4_sample_kernel(const S1Params p) { s1_body_bf16w<4, S1FV_SCAP, 2>(p, p.chunk0 + (int)blockIdx.x); }
-#define S1FV_LDS_BYTES (6 * 4096 + 2 * S1_STATE_BYTES_(S1FV_SCAP))
-#define S1FV4_LDS_BYTES (4 * 4096 + 2 * S1_STATE_BYTES_(S1FV_SCAP))
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c_kernel(const S1Params p) { s1_body_wide<6, S1BC_SCAP, 1>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c_sample_kernel(const S1Params p) { s1_body_wide<6, S1BC_SCAP, 1>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c4_kernel(const S1Params p) { s1_body_wide<4, S1BC_SCAP, 1>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c4_sample_kernel(const S1Params p) { s1_body_wide<4, S1BC_SCAP, 1>(p, p.chunk0 + (int)blockIdx.x); }
 #define S1BC_LDS_BYTES (6 * 4096 + 2 * S1_STATE_BYTES_(S1BC_SCAP))
 #define S1BC4_LDS_BYTES (4 * 4096 + 2 * S1_STATE_BYTES_(S1BC_SCAP))
 #define S1BW_LDS_BYTES (6 * 8192 + 2 * S1_STATE_BYTES_(S1BW_SCAP6))
