@@ -119,7 +119,7 @@ def s1_kernel_name(dtype, screened, E, wide=False):
             return "mfar_stage1_bf16c_kernel" if (E // 16) % 6 == 0 else "mfar_stage1_bf16c4_kernel"
         return "mfar_stage1_bf16s_kernel" if (E // 16) % 6 == 0 else "mfar_stage1_bf16s4_kernel"
     if screened and wide:
-        return "mfar_stage1_f16w_kernel" if (E // 16) % 6 == 0 else "mfar_stage1_f16w4_kernel"
+        return "mfar_stage1_f16w4_kernel" if (E // 16) % 4 == 0 and os.environ.get("MFAR_WIDE_RING") != "6" else "mfar_stage1_f16w_kernel"
     return f"mfar_stage1_f16{rr}_kernel" if screened else "mfar_stage1_kernel"
 
 

@@ -599,13 +599,15 @@ static int launch_s1(int kind, bool sample, unsigned n_chunks, unsigned wave, hi
         } else if (sample) mfar_stage1_sample_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
         else mfar_stage1_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
     } else if (kind == S1_F16W) {
-        static const int w_ring = getenv("MFAR_WIDE_RING") ? atoi(getenv("MFAR_WIDE_RING")) : 0;   // diagnostic: 4 forces the 4-slot twin
-        if (p.n_steps % 6 == 0 && !(w_ring == 4 && p.n_steps % 4 == 0)) {
-            if (sample) mfar_stage1_f16w_sample_kernel<<<g, b, S1HW_LDS_BYTES, st>>>(p);
-            else mfar_stage1_f16w_kernel<<<g, b, S1HW_LDS_BYTES, st>>>(p);
-        } else {
+        // 4-slot ring whenever the k-steps divide by 4 (round 4, with the SGPR-addressed body: 14 spilled VGPRs instead of 27, 50.8 KB of LDS
+        // instead of 58.8; same run, interleaved: 1 M x 8 52.0-52.3 k against 51.6-52.2 k q/s sustained, 129 375 x 22 68.3 k against 66.0 k)
+        static const int w_ring = getenv("MFAR_WIDE_RING") ? atoi(getenv("MFAR_WIDE_RING")) : 0;   // diagnostic: 6 forces the 6-slot ring
+        if (p.n_steps % 4 == 0 && !(w_ring == 6 && p.n_steps % 6 == 0)) {
             if (sample) mfar_stage1_f16w4_sample_kernel<<<g, b, S1HW4_LDS_BYTES, st>>>(p);
             else mfar_stage1_f16w4_kernel<<<g, b, S1HW4_LDS_BYTES, st>>>(p);
+        } else {
+            if (sample) mfar_stage1_f16w_sample_kernel<<<g, b, S1HW_LDS_BYTES, st>>>(p);
+            else mfar_stage1_f16w_kernel<<<g, b, S1HW_LDS_BYTES, st>>>(p);
         }
     } else if (kind == S1_BF16W) {
         // the 4-slot ring (50.5 KB of LDS) whenever the k-steps divide by 4: see mfar_stage1.h on LDS fragmentation
