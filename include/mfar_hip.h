@@ -325,6 +325,19 @@ int mfar_set_stage2_mode(mfar_index* idx, int mode);
  * mfar_stage2_dump_info: would a launch with list depth k1 use it; bytes one launch writes; launches that read it so far.
  */
 int mfar_set_stage2_dump(mfar_index* idx, int mode);
+/*
+ * ROW MODE of the certified screen (no reference counterpart; outputs bit-identical with and without it).  The certificate bounds every
+ * unscanned row of a field with the field's LARGEST centred row norm; one outlier row -- or a heavy-tailed field -- then makes lists fail
+ * that a per-row bound would prove.  A field whose largest norm exceeds 1.5 x the mean norm is ELIGIBLE: its wide screened pass can rank
+ * rows by approx + eps(row norm), an upper bound of the exact score, and the certificate then needs no field-wide norm (csrc/mfar_screen.h
+ * "ROW MODE").  It costs the scan ~7 % (its own kernel instantiation), so it is switched on only when it pays:
+ *   mode   0 = never, 1 = auto (default; environment MFAR_SCREEN_ROW_MODE): eligible fields are activated by mfar_row_mode_activate, which
+ *          mfar.data.pipeline.PipelinedSearcher calls when a launch reports a failed certificate; 2 = eligible fields are always active.
+ * mfar_row_mode_info: bit f of the masks = field f is eligible / active (valid once the screen is built).
+ */
+int mfar_set_row_mode(mfar_index* idx, int mode);
+int mfar_row_mode_activate(mfar_index* idx);
+int mfar_row_mode_info(const mfar_index* idx, uint32_t* eligible_fields, uint32_t* active_fields);
 int mfar_stage2_dump_info(mfar_index* idx, int k1, int* wanted, int64_t* bytes_per_launch, int64_t* n_launches);
 int mfar_stage2_stats(mfar_index* idx, int* two_level_available, int64_t* gather_slab_bytes, int64_t* n_candidates,
                       int64_t* n_survivors);

@@ -26,6 +26,9 @@ struct ScreenField {
     float inv_scale;
     float dnorm_max;     // largest 2-norm of a centred row of the field (inf / NaN when the field holds non-finite values)
     float mnorm;         // 2-norm of the field's mean vector
+    float dnorm_mean;    // mean 2-norm of the field's centred rows
+    float row_mode;      // != 0: heavy-tailed row norms (dnorm_max > 1.5 dnorm_mean): the screened pass ranks rows by their UPPER bound
+                         // approx + eps(row norm) instead of approx, and the certificate needs no global norm (mfar_screen.h "ROW MODE")
 };
 struct ScreenQuery {     // per query of the current block of 64 / 128 queries (mfar_screen_queries_kernel)
     float scale, inv_scale, norm, pad;

@@ -110,11 +110,14 @@ struct mfar_index {
         DevBuf qt, lists, list_cnt, gtau, samp, lists2, list_cnt2;      // any pass (lists2: group lists of a two-level merge)
         DevBuf unit_ctr;                                                // per-field unit counters of a dynamically distributed scan (mfar_stage1.h)
         DevBuf dump;                                                    // score dump of the wide screened pass (mfar_select.h mfar_s2_lookup_kernel)
+        bool row_mode = false;                                          // ROW MODE decided by the begin phase of the batch, with the fields it covers
+        u32 row_mask = 0;                                               // (latched: the index's mask may change while the batch is in flight)
         bool dump_on = false;                                           // this batch's scan writes it
         bool dump_ready = false;                                        // ... and has been launched: stage 2 of (dump_q, dump_Q) may read it, once
         const float* dump_q = nullptr;
         int dump_Q = 0;
         DevBuf qt16, qinfo, eps, base, fail, sids, ssc, scnt, sx;        // fp16 screen
+        DevBuf arow, eps_cert;                                          // ... ROW MODE: per (field, query) factor of the row norm / what is left of eps
         bool screened = false;                                          // decided by the begin phase of the batch
         int qw = 64;                                                    // query columns of the batch's pass (128: wide screen pass)
     } s1[MFAR_SLOTS];
@@ -139,7 +142,12 @@ struct mfar_index {
     bool screen_nomem = false;    // the screen slab could not be allocated: stay on the exact pass
     long long screen_checked = 0; // (query, field) lists certified so far
     DevBuf s_stats, s_field, s_mean;
-    DevBuf dump_base;             // [F] first row of every field in the screen slab (= in a score dump)
+    DevBuf dump_base;             // [F] first row of every field in the screen slab (= in a score dump, = in s_rnorm)
+    DevBuf s_rnorm, s_nsum;       // ROW MODE (mfar_screen.h): centred 2-norm of every row of the screen slab; per-field sum of the norms
+    u32 row_mask = 0;             // fields whose scans run in row mode now
+    u32 row_eligible = 0;         // fields with heavy-tailed row norms (host copy of ScreenField::row_mode)
+    int row_mode_setting = 1;     // 0 never, 1 auto: eligible fields are activated once a certificate has failed (mfar_row_mode_activate; the
+                                  // pipelined searcher calls it), 2 always.  MFAR_SCREEN_ROW_MODE
     int dump_mode = 1;            // 0 never, 1 when it moves fewer bytes than the row gathers (dump_wanted), 2 whenever possible
     long long dump_launches = 0;
     DevBuf s_field1, s_cvt;       // bf16 index: ScreenField of the two-term passes (scale 1); conversion constants of the converted-docs pass
@@ -205,6 +213,10 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW4_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW4_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w_rm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW_RM_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w_rm_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW_RM_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w4_rm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW4_RM_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_f16w4_rm_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HW4_RM_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HR_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16s_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HR_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16s4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1HR4_LDS_BYTES));
@@ -283,6 +295,7 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     if (const char* e = getenv("MFAR_WIDE")) idx->wide = atoi(e) != 0;
     if (const char* e = getenv("MFAR_STAGE2_PRUNE")) idx->stage2_mode = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MFAR_S2_DUMP")) idx->dump_mode = std::max(0, std::min(2, atoi(e)));
+    if (const char* e = getenv("MFAR_SCREEN_ROW_MODE")) idx->row_mode_setting = std::max(0, std::min(2, atoi(e)));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) idx->n_cu = prop.multiProcessorCount;
     hipError_t e = hipMalloc(&idx->slab, idx->slab_bytes);
@@ -317,7 +330,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
     DevBuf* bufs[] = {&idx->fid, &idx->fsc, &idx->s_stats, &idx->s_field, &idx->s_mean, &idx->screen, &idx->u_rep, &idx->u_start,
-                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->s2stats, &idx->rep_bits, &idx->u_of, &idx->s_field1, &idx->s_cvt, &idx->dump_base};
+                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->s2stats, &idx->rep_bits, &idx->u_of, &idx->s_field1, &idx->s_cvt, &idx->dump_base, &idx->s_rnorm, &idx->s_nsum};
     for (int i = 0; i < MFAR_SLOTS; ++i)
         for (DevBuf* b : {&idx->cand[i], &idx->ncand[i], &idx->x[i], &idx->own[i], &idx->xa[i], &idx->cand2[i], &idx->ncand2[i], &idx->s2qm[i],
                           &idx->s2eps[i], &idx->kmask[i], &idx->src2[i]})
@@ -333,7 +346,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
         }
     for (DevBuf* b : bufs) b->release();
     for (auto& sl : idx->s1) {
-        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.lists2, &sl.list_cnt2, &sl.unit_ctr, &sl.dump, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
+        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.lists2, &sl.list_cnt2, &sl.unit_ctr, &sl.dump, &sl.arow, &sl.eps_cert, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
                         &sl.ssc, &sl.scnt, &sl.sx};
         for (DevBuf* b : sb) b->release();
     }
@@ -602,7 +615,13 @@ static int launch_s1(int kind, bool sample, unsigned n_chunks, unsigned wave, hi
         // 4-slot ring whenever the k-steps divide by 4 (round 4, with the SGPR-addressed body: 14 spilled VGPRs instead of 27, 50.8 KB of LDS
         // instead of 58.8; same run, interleaved: 1 M x 8 52.0-52.3 k against 51.6-52.2 k q/s sustained, 129 375 x 22 68.3 k against 66.0 k)
         static const int w_ring = getenv("MFAR_WIDE_RING") ? atoi(getenv("MFAR_WIDE_RING")) : 0;   // diagnostic: 6 forces the 6-slot ring
-        if (p.n_steps % 4 == 0 && !(w_ring == 6 && p.n_steps % 6 == 0)) {
+        const bool r4 = p.n_steps % 4 == 0 && !(w_ring == 6 && p.n_steps % 6 == 0);
+        if (p.arow) {              // ROW MODE twins
+            if (r4 && sample) mfar_stage1_f16w4_rm_sample_kernel<<<g, b, S1HW4_RM_LDS_BYTES, st>>>(p);
+            else if (r4) mfar_stage1_f16w4_rm_kernel<<<g, b, S1HW4_RM_LDS_BYTES, st>>>(p);
+            else if (sample) mfar_stage1_f16w_rm_sample_kernel<<<g, b, S1HW_RM_LDS_BYTES, st>>>(p);
+            else mfar_stage1_f16w_rm_kernel<<<g, b, S1HW_RM_LDS_BYTES, st>>>(p);
+        } else if (r4) {
             if (sample) mfar_stage1_f16w4_sample_kernel<<<g, b, S1HW4_LDS_BYTES, st>>>(p);
             else mfar_stage1_f16w4_kernel<<<g, b, S1HW4_LDS_BYTES, st>>>(p);
         } else {
@@ -700,6 +719,12 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
     p.samp_out = nullptr;
     p.samp_stride = tb.samp_stride;
     p.only_failed = only_failed;
+    if (kind == S1_F16W && sl.row_mode && !repair && sl.arow.p) {     // ROW MODE (mfar_screen.h); the 64-column pass keeps the field-wide bound
+        p.arow = sl.arow.as<float>();
+        p.rnorm = idx->s_rnorm.as<float>();
+        p.row_mask = sl.row_mask;
+        p.dump_base = idx->dump_base.as<long long>();
+    }
     if (kind == S1_F16W && sl.dump_on && nf == idx->F && !repair) {
         p.dump = sl.dump.as<float>();
         p.dump_base = idx->dump_base.as<long long>();
@@ -1039,7 +1064,8 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
     RETCHK(idx->s_mean.ensure((size_t)F * idx->E * sizeof(float)));
     HIPCHK(hipMemsetAsync(idx->s_stats.p, 0, (size_t)F * 2 * sizeof(u32), st));
     HIPCHK(hipMemsetAsync(idx->s_mean.p, 0, (size_t)F * idx->E * sizeof(float), st));   // (bf16: the "mean" stays the zero vector)
-    DevBuf stage_rows, stage_field;
+    DevBuf stage_rows, stage_field, rnorm_doc;
+    if (bf16) idx->row_mask = idx->row_eligible = 0;
     if (bf16 && (stage_rows.ensure((size_t)std::max<long long>(n, 1) * idx->E * 4) != MFAR_OK ||
                  stage_field.ensure((size_t)idx->field_stride * 4) != MFAR_OK)) {
         stage_rows.release();
@@ -1076,7 +1102,16 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
                                                                 idx->s_cvt.as<uint2>());
         HIPCHK(hipGetLastError());
     } else {
-        // mean vector and statistics of the centred rows
+        // mean vector and statistics of the centred rows (+ every row's norm: ROW MODE)
+        RETCHK(idx->s_nsum.ensure((size_t)F * sizeof(float)));
+        HIPCHK(hipMemsetAsync(idx->s_nsum.p, 0, (size_t)F * sizeof(float), st));
+        const bool rows_ok = idx->row_mode_setting != 0 && (idx->n_steps % 4 == 0 || idx->n_steps % 6 == 0) &&
+                             rnorm_doc.ensure((size_t)F * std::max<long long>(n, 1) * sizeof(float)) == MFAR_OK;
+        if (!rows_ok) {
+            (void)hipGetLastError();
+            g_err.clear();
+            rnorm_doc.release();
+        }
         for (int f = 0; f < F; ++f) {
             const float* src = (const float*)idx->slab + (size_t)f * idx->field_stride;
             float* mean_f = idx->s_mean.as<float>() + (size_t)f * idx->E;
@@ -1086,12 +1121,25 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
             mfar_screen_mean_finish_kernel<<<dim3((idx->E + 255) / 256), dim3(256), 0, st>>>(mean_f, idx->E, idx->n_rows);
             HIPCHK(hipGetLastError());
             mfar_screen_stats_kernel<<<dim3((unsigned)idx->n_blk, 1), dim3(256), 0, st>>>(src, idx->field_stride, idx->n_steps, idx->n_rows, mean_f,
-                                                                                         idx->s_stats.as<u32>() + 2 * f);
+                                                                                         idx->s_stats.as<u32>() + 2 * f,
+                                                                                         rows_ok ? rnorm_doc.as<float>() + (size_t)f * n : nullptr,
+                                                                                         idx->s_nsum.as<float>() + f);
             HIPCHK(hipGetLastError());
         }
         mfar_screen_scale_kernel<<<dim3(1), dim3(64), 0, st>>>(idx->s_stats.as<u32>(), idx->s_mean.as<float>(), F, idx->E,
-                                                             idx->s_field.as<ScreenField>());
+                                                             idx->s_field.as<ScreenField>(), idx->s_nsum.as<float>(), idx->n_rows, rows_ok ? 1 : 0);
         HIPCHK(hipGetLastError());
+        {
+            std::vector<ScreenField> hf(F);
+            HIPCHK(hipMemcpyAsync(hf.data(), idx->s_field.p, (size_t)F * sizeof(ScreenField), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            const u32 was_active = idx->row_mask;
+            idx->row_eligible = 0;
+            for (int f = 0; f < F; ++f)
+                if (hf[f].row_mode != 0.0f) idx->row_eligible |= 1u << f;
+            // a rebuild keeps what was activated; mode 2 activates every eligible field at once
+            idx->row_mask = idx->row_mode_setting == 2 ? idx->row_eligible : (was_active ? idx->row_eligible : 0u);
+        }
     }
     // pass 2: unique rows, field by field (scratch shared); an fp32 index reads its slab in place
     DevBuf tmp[9];
@@ -1138,6 +1186,21 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
         RETCHK(idx->dump_base.ensure((size_t)F * sizeof(long long)));
         HIPCHK(hipMemcpyAsync(idx->dump_base.p, db.data(), (size_t)F * sizeof(long long), hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st));
+        // ROW MODE: the norm of every row of the screen slab (unique rows, padded to whole tiles), only when some field needs it
+        if (idx->row_eligible && rnorm_doc.p && idx->s_rnorm.ensure((size_t)(total / idx->E) * sizeof(float), true) == MFAR_OK) {
+            for (int f = 0; f < F; ++f) {
+                const long long n_pad = (long long)g.n_tiles[f] * 256;
+                mfar_rownorm_gather_kernel<<<dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st>>>(
+                    rnorm_doc.as<float>() + (size_t)f * n, idx->u_rep.as<int>() + (size_t)f * n, idx->n_unique[f], n_pad, idx->s_rnorm.as<float>() + db[f]);
+                HIPCHK(hipGetLastError());
+            }
+            HIPCHK(hipStreamSynchronize(st));
+        } else if (idx->row_eligible) {
+            (void)hipGetLastError();
+            g_err.clear();
+            idx->row_mask = idx->row_eligible = 0;     // no table: every field keeps its field-wide bound (ScreenField::row_mode is ignored without arow)
+        }
+        rnorm_doc.release();
     }
     // pass 3: the fp16 rows
     for (int f = 0; f < F; ++f) {
@@ -1246,6 +1309,19 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     RETCHK(sl.sx.ensure((size_t)128 * F * kp * 4));
     RETCHK(sl.scnt.ensure((size_t)128 * F * 4));
     int* fflags = sl.fail.as<int>();
+    // ROW MODE: some field of this fp32 index ranks its rows by upper bounds (heavy-tailed row norms)
+    if (phases & S1_PREPARE) {
+        sl.row_mode = !bf16 && qw == 128 && idx->row_mask != 0 && idx->s_rnorm.p != nullptr;     // (the wide pass has the row-norm code)
+        sl.row_mask = sl.row_mode ? idx->row_mask : 0u;
+    }
+    const bool row_mode = sl.row_mode;
+    if (row_mode) {
+        RETCHK(sl.arow.ensure((size_t)F * 128 * 4));
+        RETCHK(sl.eps_cert.ensure((size_t)F * 128 * 4));
+    } else if (sl.arow.p) {
+        sl.arow.release();          // (the flag stage1_pass looks at)
+        sl.eps_cert.release();
+    }
     // bf16 index, which certified pass: 64 columns = two bf16 query terms over the raw rows (scale 1); 128 columns = the rows converted to
     // fp16 in registers against one fp16 query term (the field's power-of-two scale), or -- MFAR_BF16_WIDE_TERMS=2, diagnostic -- two
     // bf16 terms at twice the MFMAs
@@ -1261,7 +1337,8 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         else
             mfar_screen_queries_kernel<<<dim3(qw), dim3(256), 0, st>>>(q, (_Float16*)sl.qt16.p, sl.qinfo.as<ScreenQuery>(), sfield,
                                                                        sl.eps.as<float>(), sl.base.as<float>(), fflags, q0, Q, idx->E, F,
-                                                                       idx->screen_eps_mult, qw, bf16 ? 1 : 0);
+                                                                       idx->screen_eps_mult, qw, bf16 ? 1 : 0, row_mode ? sl.arow.as<float>() : nullptr,
+                                                                       row_mode ? sl.eps_cert.as<float>() : nullptr, sl.row_mask);
         HIPCHK(hipGetLastError());
     }
     // lists of unique-row numbers (fp32 index: rows of the screen slab) / of the local rows of group representatives (bf16 index:
@@ -1328,6 +1405,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     cp.sf = sfield;
     cp.qinfo = sl.qinfo.as<ScreenQuery>();
     cp.eps = sl.eps.as<float>();
+    cp.eps_cert = row_mode ? sl.eps_cert.as<float>() : nullptr;
     cp.q = q + (size_t)q0 * idx->E;
     cp.mean = idx->s_mean.as<float>();
     cp.E = idx->E;
@@ -1455,6 +1533,25 @@ extern "C" int mfar_set_stage2_mode(mfar_index* idx, int mode) {
     if (!idx || mode < 0 || mode > 2)
         return fail(MFAR_ERR_INVALID, "mode must be 0 (gather every row), 1 (certified two-level stage 2) or 2 (also for sweeps of many masks)");
     idx->stage2_mode = mode;
+    return MFAR_OK;
+}
+
+extern "C" int mfar_set_row_mode(mfar_index* idx, int mode) {
+    if (!idx || mode < 0 || mode > 2) return fail(MFAR_ERR_INVALID, "mode must be 0 (never), 1 (auto: after a failed certificate) or 2 (always)");
+    idx->row_mode_setting = mode;
+    if (mode == 0) idx->row_mask = 0;
+    if (mode == 2) idx->row_mask = idx->row_eligible;
+    return MFAR_OK;
+}
+extern "C" int mfar_row_mode_activate(mfar_index* idx) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    if (idx->row_mode_setting != 0) idx->row_mask = idx->row_eligible;
+    return MFAR_OK;
+}
+extern "C" int mfar_row_mode_info(const mfar_index* idx, uint32_t* eligible_fields, uint32_t* active_fields) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    if (eligible_fields) *eligible_fields = idx->row_eligible;
+    if (active_fields) *active_fields = idx->row_mask;
     return MFAR_OK;
 }
 

@@ -71,9 +71,10 @@ __global__ void mfar_screen_mean_finish_kernel(float* __restrict__ acc, int n, l
 // stats[2f] = max |value| bits, stats[2f+1] = max row norm^2 bits (non-negative floats order like their bit patterns;
 // NaN bits are above inf bits, so a non-finite value poisons the field's maximum as intended).
 // ---------------------------------------------------------------------------------------------------------
+//   rnorm [n_rows] or nullptr: the centred 2-norm of every row (leaning up like dnorm_max);  nsum: sum of those norms (any order: a statistic)
 __global__ void __launch_bounds__(256) mfar_screen_stats_kernel(const float* __restrict__ slab, long long field_stride, int n_steps,
                                                                 long long n_rows, const float* __restrict__ mean,
-                                                                u32* __restrict__ stats) {
+                                                                u32* __restrict__ stats, float* __restrict__ rnorm, float* __restrict__ nsum) {
     const int f = blockIdx.y;
     const int rr = threadIdx.x >> 2, pp = threadIdx.x & 3;   // thread = quarter pp (8 floats) of row rr's 128-byte line per k-step pair
     const bool live = (long long)blockIdx.x * 64 + rr < n_rows;   // padding rows are not part of the field
@@ -95,15 +96,26 @@ __global__ void __launch_bounds__(256) mfar_screen_stats_kernel(const float* __r
     // threads 4r .. 4r+3 hold the four quarters of row r
     ss += __shfl_xor(ss, 1);
     ss += __shfl_xor(ss, 2);
+    const float rn = sqrtf(ss) * 1.0001f;
+    if (rnorm && live && pp == 0) rnorm[(long long)blockIdx.x * 64 + rr] = rn;
+    float part = (live && pp == 0) ? rn : 0.0f;
     u32 a = __float_as_uint(amax), n = __float_as_uint(ss) & 0x7FFFFFFFu;
     for (int off = 32; off > 0; off >>= 1) {
         a = max(a, (u32)__shfl_xor((int)a, off));
         n = max(n, (u32)__shfl_xor((int)n, off));
+        part += __shfl_xor(part, off);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicMax(&stats[2 * f], a);
         atomicMax(&stats[2 * f + 1], n);
+        if (nsum) atomicAdd(nsum, part);
     }
+}
+// rows of the screen slab are UNIQUE rows: out[u] = rnorm[urep[u]] (padding rows: 0).  grid = ceil(n_pad / 256), block 256.
+__global__ void __launch_bounds__(256) mfar_rownorm_gather_kernel(const float* __restrict__ rnorm, const int* __restrict__ urep, int n_unique,
+                                                                  long long n_pad, float* __restrict__ out) {
+    const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < n_pad) out[u] = u < n_unique ? rnorm[urep[u]] : 0.0f;
 }
 
 // power-of-two scale that puts `amax` into [2^13, 2^14); 1 for zero / non-finite input
@@ -116,7 +128,7 @@ __device__ __forceinline__ float screen_pow2_scale(float amax) {
 }
 
 __global__ void mfar_screen_scale_kernel(const u32* __restrict__ stats, const float* __restrict__ mean, int F, int E,
-                                         ScreenField* __restrict__ sf) {
+                                         ScreenField* __restrict__ sf, const float* __restrict__ nsum, long long n_rows, int row_mode_allowed) {
     const int f = threadIdx.x;
     if (f >= F) return;
     const float amax = __uint_as_float(stats[2 * f]);
@@ -129,6 +141,9 @@ __global__ void mfar_screen_scale_kernel(const u32* __restrict__ stats, const fl
     // the fp32 sums of squares can be low by K u32 relative: lean up, the bound must not shrink
     o.dnorm_max = sqrtf(n2) * 1.0001f;
     o.mnorm = sqrtf(m2) * 1.0001f;
+    o.dnorm_mean = (nsum && n_rows > 0) ? nsum[f] / (float)n_rows : o.dnorm_max;
+    // ROW MODE (below): worth its epilogue cost only when the largest norm is far above the typical one
+    o.row_mode = (row_mode_allowed && o.dnorm_max < __builtin_inff() && o.dnorm_max > 1.5f * o.dnorm_mean) ? 1.0f : 0.0f;
     sf[f] = o;
 }
 
@@ -290,7 +305,8 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
                                                                   ScreenQuery* __restrict__ qinfo, const ScreenField* __restrict__ sf,
                                                                   float* __restrict__ eps, float* __restrict__ tau_base,
                                                                   int* __restrict__ fail_flags, int q0, int Q, int E, int F,
-                                                                  float eps_mult, int qw, int direct) {
+                                                                  float eps_mult, int qw, int direct, float* __restrict__ arow,
+                                                                  float* __restrict__ eps_cert, u32 row_mask) {
     __shared__ float red_a[4], red_s[4];
     const int r = blockIdx.x;
     // a new batch: clear the certificate flags of the fields and the "any" flag ([MFAR_MAX_FIELDS + 1] keeps accumulating statistics)
@@ -377,11 +393,21 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
         const float c_rel = c16 * 4.8828125e-4f + (4.0f * K + 66.0f) * u32f;
         const float c_abs = u32f * sqrtf(K) * 1.0001f;
         const float c_doc = direct ? 6.1035156e-5f * 1.001f * sqrtf(K) * 1.0001f : c_abs;      // 2^-14 (1 + u16) |q|_1 / sf
-        float e_ = SCREEN_SLACK * (c_rel * qn * s.dnorm_max + K * u32f * qn * (s.dnorm_max + 2.0f * s.mnorm) +
-                                   c_doc * qn * s.inv_scale + c_abs * s.dnorm_max / sq);
+        const float e_rest = K * u32f * qn * (s.dnorm_max + 2.0f * s.mnorm) + c_doc * qn * s.inv_scale + c_abs * s.dnorm_max / sq;
+        float e_ = SCREEN_SLACK * (c_rel * qn * s.dnorm_max + e_rest);
         e_ *= eps_mult;
         if (!live) e_ = 0.0f;
         eps[f * qw + r] = e_;
+        // ROW MODE.  The dominant term of the bound is c_rel |q|_2 |c_row|_2 -- per ROW once the row's own norm replaces the field's
+        // largest.  The scan then adds arow * |c_row| to every score (scaled units; mfar_stage1.h s1_row_bound), so its lists are ranked
+        // by an UPPER bound of the exact score up to the row-independent rest, and the certificate compares the k'-th upper bound +
+        // eps_cert with the exact k-th best.  eps (above) stays the field-wide bound: |upper bound - exact| <= 2 eps for every row, which
+        // is all the re-scoring prefix rule and stage 2 need.  (1.001: the fp32 rounding of the added term itself.)
+        if (arow) {
+            const bool rm = ((row_mask >> f) & 1u) != 0u && live;         // (the fields whose scans add the row term in this batch)
+            arow[f * qw + r] = rm ? 1.001f * SCREEN_SLACK * eps_mult * c_rel * qn * (sq * s.scale) : 0.0f;
+            eps_cert[f * qw + r] = rm ? SCREEN_SLACK * eps_mult * e_rest : e_;
+        }
         // starting threshold of the screened pass: none for live queries (the zero sentinel of index.py:192-193 is applied
         // to the EXACT scores by the certify kernel; deciding it here would need q.m on the critical path), +inf for the
         // padding queries of a short batch so that they append nothing
@@ -442,6 +468,8 @@ __global__ void mfar_direct_fields_kernel(const u32* __restrict__ stats, int F, 
     o.scale = o.inv_scale = 1.0f;
     o.dnorm_max = sqrtf(__uint_as_float(stats[2 * f + 1])) * 1.0001f;   // (the fp32 sum of squares can be low by K u32 relative)
     o.mnorm = 0.0f;
+    o.dnorm_mean = o.dnorm_max;
+    o.row_mode = 0.0f;
     sf1[f] = o;
     o.scale = screen_pow2_scale(__uint_as_float(stats[2 * f]));
     o.inv_scale = 1.0f / o.scale;
@@ -543,7 +571,9 @@ struct CertifyParams {
     const float* sx;          // [64, nf, kp] exact scores of those rows' representatives (NaN = not scored)
     const ScreenField* sf;    // [F]
     const ScreenQuery* qinfo;
-    const float* eps;         // [F, qw]
+    const float* eps;         // [F, qw] field-wide bound
+    const float* eps_cert;    // [F, qw] or nullptr (= eps): what the certificate adds to the k'-th list score (ROW MODE: the lists hold upper
+                              // bounds that already carry the row-dependent part)
     const float* q;           // [Qt, E] the block's queries (row-major)
     const float* mean;        // [F, E] field means: q . mean is added back to the centred approximate scores
     int E;
@@ -654,7 +684,7 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
         if (ok && cnt == p.kp) {  // the list is full: unique rows outside it exist
             const float qm = (qm_s[0] + qm_s[1]) + (qm_s[2] + qm_s[3]);
             a_real = (p.ssc[lb + p.kp - 1] * p.qinfo[ql].inv_scale) * p.sf[f].inv_scale + qm;
-            bound = a_real + p.eps[f * p.qw + ql];                   // every outside row scores <= bound (exactly)
+            bound = a_real + (p.eps_cert ? p.eps_cert : p.eps)[f * p.qw + ql];   // every outside row scores <= bound (exactly)
             if (m_out == p.k) ok = bound < key_score(sorted[p.k - 1]); // ... strictly below the exact k-th best DOCUMENT
             else ok = bound <= tau0;                               // ... or cannot pass the sentinel at all
         }

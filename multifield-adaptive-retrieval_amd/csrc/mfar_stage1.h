@@ -105,6 +105,9 @@ struct S1Params {
                             // passes over a bf16 slab scan every document but rank UNIQUE rows: the accumulators of all other
                             // rows start at -inf (s1_acc_init), so they reach neither the sample nor the lists.
     long long rep_stride;   // words per field
+    const float* arow;      // [F, qw] or nullptr.  ROW MODE of the certified screen (mfar_screen.h): fields whose bit is set in row_mask rank rows
+    const float* rnorm;     // by approx + arow[f, query] * rnorm[row] -- an upper bound of the exact score up to a row-independent rest -- where
+    u32 row_mask;           // rnorm [rows of the scanned slab] is the row's centred 2-norm (field f's rows start at dump_base[f])
     float* dump;            // or nullptr.  SCORE DUMP of the wide fp16 screen pass (mfar_stage1_f16w_kernel): every approximate score of the
                             // launch, [scanned row of the slab][128 query columns] fp32 in scaled units, 512 bytes per row; field f's
                             // rows start at dump_base[f] (in rows).  Stage 2 of a many-field / small-corpus index reads its approximate
@@ -1011,6 +1014,35 @@ __device__ __forceinline__ void s1_body_f32r(const S1Params& p, const int chunk_
     if (p.sample != 2) s1_flush<X::SCAP>(p, st, w, wgq0);
 }
 
+// ROW MODE (S1Params::arow): acc[db][x][r] += A_x * |c_row| for the wave's 64 rows.  The norms arrive one per lane (lane = row of the
+// block, loaded at the start of the tile), are parked in a 256-byte LDS area of the wave and read back in the accumulator layout: lane
+// (j, h) holds rows 32 db + 8 g + 4 h + i (i = 0 .. 3) in elements r = 4 g + i -- four consecutive floats per (db, g).
+__device__ __forceinline__ void lds_write_b32(u32 addr, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ f32x4 lds_read_b128(u32 addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void s1_row_norms_park(u32 area, float nr) {
+    lds_write_b32(area + (u32)(threadIdx.x & 63) * 4u, nr);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void s1_row_bound(u32 area, float A0, float A1, f32x16& x00, f32x16& x01, f32x16& x10, f32x16& x11) {
+    const u32 hb = (u32)((threadIdx.x & 63) >> 5) * 16u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 n0 = lds_read_b128(area + (u32)(8 * g) * 4u + hb);
+        const f32x4 n1 = lds_read_b128(area + (u32)(32 + 8 * g) * 4u + hb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x00[4 * g + i] = __builtin_fmaf(A0, n0[i], x00[4 * g + i]);
+            x01[4 * g + i] = __builtin_fmaf(A1, n0[i], x01[4 * g + i]);
+            x10[4 * g + i] = __builtin_fmaf(A0, n1[i], x10[4 * g + i]);
+            x11[4 * g + i] = __builtin_fmaf(A1, n1[i], x11[4 * g + i]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // WIDE passes: 128 query columns per scan (s1_body_wide below; kernels mfar_stage1_f16w_* over the fp16 screen slab of an fp32 index,
 // mfar_stage1_bf16c_* / bf16w_* over a bf16 slab).  The 64-column screened pass is HBM-bound with the MFMA pipe at ~40 % (two fp16
@@ -1081,7 +1113,7 @@ struct S1BW {
     static constexpr int Q_STAGE = CV ? 4096 : 8192;
     static constexpr int LOADS = CV ? 3 : 4;
     static constexpr int SCAP = SCAP_;
-    static constexpr int LDS_BYTES = R * Q_STAGE + 2 * S1_STATE_BYTES_(SCAP_);
+    static constexpr int LDS_BYTES = R * Q_STAGE + 2 * S1_STATE_BYTES_(SCAP_);             // (ROW MODE kernels: + 1 KB, the four waves' row-norm areas)
 };
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // one dword = two bf16 values -> two fp16 values: magnitude clamped up to the smallest normal, exponent rebiased, mantissa moved
@@ -1100,7 +1132,9 @@ __device__ __forceinline__ f16x8 s1_cvt_granule(u32x4 g, u32 tmin2, u32 bias2) {
     return __builtin_bit_cast(f16x8, o);
 }
 
-template <int R, int SCAP_, int CV>
+// ROWM = 1: the ROW MODE instantiation (its own kernels, mfar_stage1_f16w*_rm_kernel): the extra registers of the row-norm code would
+// otherwise cost the common path 70 more spilled VGPRs.
+template <int R, int SCAP_, int CV, int ROWM = 0>
 __device__ __forceinline__ void s1_body_wide(const S1Params& p, const int chunk_id) {
     typedef S1BW<R, SCAP_, CV> X;
     typedef short vec8 __attribute__((ext_vector_type(8)));
@@ -1151,6 +1185,24 @@ __device__ __forceinline__ void s1_body_wide(const S1Params& p, const int chunk_
     const size_t tile_bytes = (size_t)4 * p.n_steps * step_bytes;
     const char* const qbase = (const char*)p.qt + w * 1024;   // wave w loads pieces w and 4 + w of the 8 KB stage (CV: piece w of 4 KB)   // uniform
     const u32 ldsq = (u32)(uintptr_t)qring + (u32)w * 1024u;                                                            // uniform
+    // ROW MODE: this field ranks by upper bounds (S1Params::arow); the lane's four query columns' factors, fetched before the ring starts
+    const bool row_on = ROWM && p.arow != nullptr && ((p.row_mask >> f) & 1u) != 0u;
+    float rA0 = 0.0f, rA1 = 0.0f, rB0 = 0.0f, rB1 = 0.0f, nr = 0.0f;
+    const u32 rarea = (u32)(uintptr_t)(smem + R * X::Q_STAGE + 2 * S1_STATE_BYTES_(X::SCAP)) + (u32)w * 256u;
+    const float* rn_field = nullptr;
+    if (row_on) {
+        const unsigned long long rb_ = (unsigned long long)(p.rnorm + p.dump_base[f]);
+        rn_field = (const float*)(((unsigned long long)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(rb_ >> 32)) << 32) |
+                                  (u32)__builtin_amdgcn_readfirstlane((int)(u32)rb_));
+    }
+    if (row_on) {
+        const float* ar = p.arow + (size_t)f * p.qw + (tid & 31);
+        rA0 = ar[0];
+        rA1 = ar[32];
+        rB0 = ar[64];
+        rB1 = ar[96];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rA0), "+v"(rA1), "+v"(rB0), "+v"(rB1)::"memory");
+    }
     u32 tmin2 = 0, bias2 = 0;
     if (CV == 1) {
         const uint2 cv = p.cvt[f];
@@ -1201,6 +1253,10 @@ __device__ __forceinline__ void s1_body_wide(const S1Params& p, const int chunk_
             asm volatile("" : "+v"(lane));
             off = (lane & 31) * 32 + ((((lane >> 5) ^ ((lane >> 3) & 1)) & 1) << 4);
             l16 = lane * 16;
+            if (row_on) {      // this lane's row of the wave's block: its norm (arrives long before the epilogue: loads return in order)
+                const float* rs_ = rn_field + ((size_t)t * S1_TILE_ROWS + (size_t)w * 64);
+                asm volatile("global_load_dword %0, %1, %2" : "=&v"(nr) : "v"(lane * 4), "s"(rs_) : "memory");
+            }
             // [query block A/B][doc block][query half]
             f32x16 a00, a01, a10, a11, b00, b01, b10, b11;
             s1_acc_init(p, ck, t, w, a00, a10);
@@ -1254,14 +1310,6 @@ __device__ __forceinline__ void s1_body_wide(const S1Params& p, const int chunk_
                     b11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, hb1, b11, 0, 0, 0);
                 }
             }
-            if (p.dbg & 1) {
-                asm volatile("" ::"v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(b00), "v"(b01), "v"(b10), "v"(b11));
-                if (!dyn) continue;
-            } else if (p.sample == 2) {
-                s1_sample_top2(p, ck, t - cur.t0, t, w, a00, a01, a10, a11, 0);
-                s1_sample_top2(p, ck, t - cur.t0, t, w, b00, b01, b10, b11, 64);
-                continue;
-            }
             if (CV == 2 && p.dump && !p.sample) {
                 // score dump (S1Params::dump): row (32 db + (r & 3) + 8 (r >> 2) + 4 h) of the wave's block, query column 64 blk + 32 x + j.
                 // One SGPR base per (doc block, r >> 2), one per-lane offset, the rest in the immediate; a store instruction covers two
@@ -1286,6 +1334,20 @@ __device__ __forceinline__ void s1_body_wide(const S1Params& p, const int chunk_
                 S1W_DUMP4(b10, 1, 256)
                 S1W_DUMP4(b11, 1, 384)
 #undef S1W_DUMP4
+            }
+            if (row_on) {      // (after the dump, which holds the plain approximate scores)
+                asm volatile("" : "+v"(nr)::"memory");
+                s1_row_norms_park(rarea, nr);
+                s1_row_bound(rarea, rA0, rA1, a00, a01, a10, a11);
+                s1_row_bound(rarea, rB0, rB1, b00, b01, b10, b11);
+            }
+            if (p.dbg & 1) {
+                asm volatile("" ::"v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(b00), "v"(b01), "v"(b10), "v"(b11));
+                if (!dyn) continue;
+            } else if (p.sample == 2) {
+                s1_sample_top2(p, ck, t - cur.t0, t, w, a00, a01, a10, a11, 0);
+                s1_sample_top2(p, ck, t - cur.t0, t, w, b00, b01, b10, b11, 64);
+                continue;
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier A (see the fp32 body)
             if (dyn && t == cur.t0 && tid == 0) {         // the claim issued a whole tile ago is back: publish it (read after barrier B)
@@ -1370,6 +1432,11 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_kernel(const S
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_sample_kernel(const S1Params p) { s1_body_wide<6, S1_SCAP_WIDE, 2>(p, p.chunk0 + (int)blockIdx.x); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_kernel(const S1Params p) { s1_body_wide<4, S1_SCAP_WIDE, 2>(p, p.chunk0 + (int)blockIdx.x); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_sample_kernel(const S1Params p) { s1_body_wide<4, S1_SCAP_WIDE, 2>(p, p.chunk0 + (int)blockIdx.x); }
+// ... and their ROW MODE twins (indexes with a heavy-tailed field)
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_rm_kernel(const S1Params p) { s1_body_wide<6, S1_SCAP_WIDE, 2, 1>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_rm_sample_kernel(const S1Params p) { s1_body_wide<6, S1_SCAP_WIDE, 2, 1>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_rm_kernel(const S1Params p) { s1_body_wide<4, S1_SCAP_WIDE, 2, 1>(p, p.chunk0 + (int)blockIdx.x); }
+__global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_rm_sample_kernel(const S1Params p) { s1_body_wide<4, S1_SCAP_WIDE, 2, 1>(p, p.chunk0 + (int)blockIdx.x); }
 #define S1HW_LDS_BYTES (6 * 4096 + 2 * S1_STATE_BYTES_(S1_SCAP_WIDE))
 // certified passes over a bf16 slab: 64 columns x two bf16 terms (register ring of 6 / 4 slots), 128 columns x two terms
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16s_kernel(const S1Params p) { s1_body_x16r<2, 6>(p, p.chunk0 + (int)blockIdx.x); }
@@ -1403,3 +1470,5 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c4_sample_kerne
 #define S1BW_LDS_BYTES (6 * 8192 + 2 * S1_STATE_BYTES_(S1BW_SCAP6))
 #define S1BW4_LDS_BYTES (4 * 8192 + 2 * S1_STATE_BYTES_(S1BW_SCAP4))
 #define S1HW4_LDS_BYTES (4 * 4096 + 2 * S1_STATE_BYTES_(S1_SCAP_WIDE))
+#define S1HW_RM_LDS_BYTES (S1HW_LDS_BYTES + 1024)
+#define S1HW4_RM_LDS_BYTES (S1HW4_LDS_BYTES + 1024)

@@ -85,6 +85,9 @@ SIGNATURES = {
     "mfar_screen_field_info": (_i, [_vp, _i, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "mfar_screen_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "mfar_set_stage2_mode": (_i, [_vp, _i]),
+    "mfar_set_row_mode": (_i, [_vp, _i]),
+    "mfar_row_mode_activate": (_i, [_vp]),
+    "mfar_row_mode_info": (_i, [_vp, _c.POINTER(_c.c_uint32), _c.POINTER(_c.c_uint32)]),
     "mfar_set_stage2_dump": (_i, [_vp, _i]),
     "mfar_stage2_dump_info": (_i, [_vp, _i, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "mfar_stage2_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),

@@ -399,6 +399,19 @@ class MultiFieldIndex:
         of any size.  Outputs are bit-identical in every mode."""
         _native.check(_native.lib().mfar_set_stage2_mode(self._h, int(mode)))
 
+    def set_row_mode(self, mode: int = 1):
+        """ROW MODE of the certified screen (include/mfar_hip.h): heavy-tailed fields rank rows by a per-row upper bound.  0 never, 1 auto
+        (activated after a failed certificate: `activate_row_mode`, called by PipelinedSearcher), 2 always.  Same output bits."""
+        _native.check(_native.lib().mfar_set_row_mode(self._h, int(mode)))
+
+    def activate_row_mode(self):
+        _native.check(_native.lib().mfar_row_mode_activate(self._h))
+
+    def row_mode_info(self) -> dict:
+        e, a = ctypes.c_uint32(), ctypes.c_uint32()
+        _native.check(_native.lib().mfar_row_mode_info(self._h, ctypes.byref(e), ctypes.byref(a)))
+        return dict(eligible=[f for f in range(self.n_fields) if (e.value >> f) & 1], active=[f for f in range(self.n_fields) if (a.value >> f) & 1])
+
     def set_stage2_dump(self, mode: int = 1):
         """Score dump of the wide screened pass as the approximate level of stage 2 (include/mfar_hip.h): 0 never, 1 when it moves
         fewer bytes than the row gathers, 2 whenever possible.  Outputs are bit-identical in every mode."""

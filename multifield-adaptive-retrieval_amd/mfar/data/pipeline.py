@@ -272,6 +272,9 @@ class PipelinedSearcher:
         if not failed:
             return
         self.n_redone += 1
+        # a certificate failed on this data: fields with heavy-tailed row norms switch to per-row bounds from the next launch on
+        # (include/mfar_hip.h "ROW MODE"; a no-op when no field is eligible.  Same decision on every rank: the flags are all-reduced.)
+        self.ix.activate_row_mode()
         torch.cuda.synchronize(self.dev)              # the redo uses the index's slot-0 scratch: nothing else may be in flight
         # the non-split entry points repair a failed certificate themselves: screened pass again, then the exact fp32 pass
         # for the failed fields only (cheaper than switching the screen off for the whole launch)

@@ -1317,3 +1317,47 @@ def test_bf16_certified_pass_with_duplicates_on_top(idxmod):
     assert np.array_equal(rm["ids"].cpu().numpy(), o2["ids"]) and np.array_equal(rm["scores"].cpu().numpy().view(np.uint32), o2["scores"].view(np.uint32))
     for s_ in shards:
         s_.close()
+
+
+def test_row_mode_certifies_heavy_tailed_fields(idxmod):
+    """ROW MODE of the certified screen (csrc/mfar_screen.h): a field whose largest centred row norm is far above the typical one ranks
+    its rows by approx + eps(row norm) -- an upper bound of the exact score -- so the certificate no longer pays for the field's worst
+    row.  Three fields: Gaussian, Pareto(3)-scaled spread (norms up to 30 x typical), a handful of huge outliers.  With the mode on,
+    every list of the wide pass is certified and every bit equals the oracle; with MFAR_SCREEN_ROW_MODE=0 semantics (set through the
+    eps knob: the field-wide bound) lists fail and are repaired to the same bits.  The 64-column pass (field-wide bound) agrees."""
+    rng = np.random.default_rng(77)
+    F, D, E, Q = 3, 60000, 256, 128
+    mu = rng.standard_normal(E).astype(np.float32)
+    mu /= np.linalg.norm(mu)
+    slab = (rng.standard_normal((F, D, E)) * 0.04 + mu).astype(np.float32)
+    scale = np.minimum((1.0 - rng.random((D, 1))) ** (-1.0 / 3.0), 30.0).astype(np.float32)
+    slab[1] = ((slab[1] - mu) * scale + mu).astype(np.float32)
+    out = rng.choice(D, 12, replace=False)
+    slab[2, out] = (mu + rng.standard_normal((12, E)) * 2.0).astype(np.float32)          # a dozen rows 50 x the typical spread
+    q = (rng.standard_normal((Q, E)) * 0.04 + mu).astype(np.float32)
+    W = (rng.standard_normal((E, F)) * 0.05).astype(np.float32)
+    o = O.c_two_stage(slab, q, W, None)
+    ix = _load(idxmod, slab)
+    ix.set_screen(2)
+    r0 = ix.search(q, W, None, return_fields=True)       # auto: nothing activated yet -- field-wide bounds, failed lists repaired exactly
+    info = ix.row_mode_info()
+    assert info["eligible"] == [1, 2] and info["active"] == [], info
+    n_failed_plain = ix.screen_stats()["n_failed"]
+    ix.activate_row_mode()                               # (what PipelinedSearcher does when a launch reports a failed certificate)
+    assert ix.row_mode_info()["active"] == [1, 2]
+    r = ix.search(q, W, None, return_fields=True)
+    st = ix.screen_stats()
+    assert st["built"] and st["n_checked"] == 2 * Q * F, st
+    for rr in (r0, r):
+        for key in ("field_ids", "ids"):
+            assert np.array_equal(rr[key], o[key]), key
+        for key in ("field_scores", "scores"):
+            assert np.array_equal(rr[key].view(np.uint32), o[key].view(np.uint32)), key
+    assert st["n_failed"] == n_failed_plain, st           # the heavy-tailed fields certify: no new failure with per-row bounds
+    assert n_failed_plain > 0, "the test corpus no longer defeats the field-wide bound: make it harsher"
+    ix.set_row_mode(0)
+    assert ix.row_mode_info()["active"] == []
+    ix.set_row_mode(2)
+    r64 = ix.search(q[:64], W, None, return_fields=True)      # the 64-column pass: field-wide bound, same bits (repairs allowed)
+    assert np.array_equal(r64["field_ids"], o["field_ids"][:64]) and np.array_equal(r64["scores"].view(np.uint32), o["scores"][:64].view(np.uint32))
+    ix.close()
