@@ -88,6 +88,19 @@ __device__ __forceinline__ int wave_reserve(int* counter, bool pred) {
     return base + mbcnt(m);
 }
 
+// The same for `cnt` slots per lane (every lane calls it; cnt may be 0): a lane's slots are consecutive, one LDS atomic per wave.
+__device__ __forceinline__ int wave_reserve_n(int* counter, int cnt) {
+    int incl = cnt;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane_id() >= off) incl += v;
+    }
+    int base = 0;
+    if (lane_id() == 63) base = lds_add_rtn(counter, incl);
+    base = __shfl(base, 63);
+    return base + incl - cnt;
+}
+
 // Deterministic exp(x) for x <= 0 (same operation sequence as mfar_oracle_exp in the oracle).
 __device__ __forceinline__ float mfar_exp(float x) {
     if (!(x > -80.0f)) return 0.0f;
@@ -187,9 +200,17 @@ __device__ __forceinline__ int block_sum_uniform(int c, int* red, int parity) {
 
 // Core: every thread holds NPT keys in registers (hi = orderable score, lo = inverted id; hi == lo == 0 marks an empty slot,
 // which no real key can be), n = number of non-empty slots in the workgroup.
-// Every radix step counts with wave BALLOTS (one v_cmp + scalar popcount per key, the wave's count lives in an SGPR) instead of
-// per-lane counters and a 6-shuffle lane reduction: the steps are latency chains -- 34 of them per selection, in every small
-// kernel of a launch's tail -- and the shuffles were most of each link.
+//
+// The k-th largest score is found by HISTOGRAM levels instead of one counting step per bit (round 4; a workgroup-level trace of the
+// list merge showed 35 us of its 60 in the 25-34 counting steps, each a ballot sweep over every key plus a barrier):
+//   1. bits on which ALL keys agree need no work: scores of one list share sign, exponent and usually the first mantissa bits;
+//   2. one sweep builds a 256-bin histogram (LDS atomics) of the next 8 bits below the highest differing one; wave 0 scans it
+//      from the top and finds the bin that holds the k-th key and how many keys lie above it;  repeated on the next 8 bits while that
+//      bin holds more than 512 keys (clustered scores, mixed signs);
+//   3. the bin's keys (<= 512) are compacted to LDS and wave 0 alone finishes the descent on their remaining bits with ballots --
+//      no barriers, 8 values per lane;
+//   4. ties on the k-th score (rare) refine on the id half with the counting steps below.
+// Four sweeps over the keys and a handful of barriers replace 34 of each; results are identical (the k-th key is unique).
 template <int NPT>
 __device__ __forceinline__ int block_topk_regs(const u32 (&hi)[NPT], const u32 (&lo)[NPT], int n, int k, u64* sel, u64* sel_sorted,
                                                int* red) {
@@ -198,25 +219,127 @@ __device__ __forceinline__ int block_topk_regs(const u32 (&hi)[NPT], const u32 (
     if (n > k) {
         m = k;
         int parity = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-            const u32 cand = T | (1u << bit);
-            int c = 0;
-#pragma unroll
-            for (int i = 0; i < NPT; ++i) c += __popcll(__ballot(hi[i] >= cand));
-            const int tot = block_sum_uniform(c, red, parity);
-            parity ^= 1;
-            if (tot >= k) T = cand;
-        }
-        int cg = 0, ce = 0;
+        int* const hist = (int*)sel_sorted;     // [256]; the output arrays are free until the selection is known
+        u32* const binv = (u32*)sel;            // [512]
+        u32 any1 = 0u, all1 = 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
-            cg += __popcll(__ballot(hi[i] > T));
-            ce += __popcll(__ballot(hi[i] == T && (hi[i] | lo[i]) != 0u));
+            const bool live = (hi[i] | lo[i]) != 0u;
+            any1 |= live ? hi[i] : 0u;
+            all1 &= live ? hi[i] : 0xFFFFFFFFu;
         }
-        const int tg = block_sum_uniform(cg, red, parity);
-        parity ^= 1;
-        const int te = block_sum_uniform(ce, red, parity);
-        parity ^= 1;
+        for (int off = 32; off > 0; off >>= 1) {
+            any1 |= (u32)__shfl_xor((int)any1, off);
+            all1 &= (u32)__shfl_xor((int)all1, off);
+        }
+        if (lane_id() == 0) {               // the two parity rows of the counting steps double as scratch here
+            red[threadIdx.x >> 6] = (int)any1;
+            red[12 + (threadIdx.x >> 6)] = (int)all1;
+        }
+        __syncthreads();
+        {
+            const int nw = (blockDim.x + 63) >> 6;
+            any1 = 0u;
+            all1 = 0xFFFFFFFFu;
+            for (int w = 0; w < nw; ++w) {
+                any1 |= (u32)red[w];
+                all1 &= (u32)red[12 + w];
+            }
+        }
+        const u32 diff = any1 ^ all1;
+        int tg = 0, te = n;                 // keys above T / equal to T once T is final (diff == 0: every score is the same)
+        T = all1;
+        if (diff != 0u) {                   // workgroup-uniform
+            int sh_top = 32 - __builtin_clz(diff);      // bits [31 .. sh_top) are common
+            T = sh_top < 32 ? (all1 >> sh_top) << sh_top : 0u;
+            int above = 0, nb = n, sh = sh_top;
+            while (true) {
+                const int W = sh_top < 8 ? sh_top : 8;
+                sh = sh_top - W;
+                for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+                if (threadIdx.x == 0) red[28] = 0;
+                __syncthreads();            // also orders the reads of red[0 .. 24) above before the next writers
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) {
+                    const bool in = (hi[i] | lo[i]) != 0u && (sh_top >= 32 || ((hi[i] ^ T) >> sh_top) == 0u);
+                    if (in) atomicAdd(&hist[(hi[i] >> sh) & ((1u << W) - 1u)], 1);
+                }
+                __syncthreads();
+                if (threadIdx.x < 64) {     // wave 0: the bin of the (k - above)-th largest key among the nb keys under the prefix
+                    const int need = k - above;
+                    const int l = (int)threadIdx.x;
+                    const int h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+                    const int mine = h0 + h1 + h2 + h3;
+                    int suf = mine;         // inclusive suffix sum over lanes >= l
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const int v = __shfl_down(suf, off);
+                        if (l + off < 64) suf += v;
+                    }
+                    const u64 ok = __ballot(suf >= need);      // lanes 0 .. L (suf never grows with the lane); need <= nb: lane 0 is set
+                    const int L = 63 - __builtin_clzll(ok);
+                    if (l == L) {
+                        int ab = suf - mine, B;
+                        if (ab + h3 >= need) B = 3;
+                        else if ((ab += h3) + h2 >= need) B = 2;
+                        else if ((ab += h2) + h1 >= need) B = 1;
+                        else { ab += h1; B = 0; }
+                        red[25] = 4 * l + B;
+                        red[26] = ab;
+                        red[27] = B == 3 ? h3 : B == 2 ? h2 : B == 1 ? h1 : h0;
+                    }
+                }
+                __syncthreads();
+                T |= (u32)red[25] << sh;
+                above += red[26];
+                nb = red[27];
+                sh_top = sh;
+                if (sh == 0 || nb <= 512) break;
+            }
+            tg = above;
+            te = nb;
+            if (sh > 0) {                   // finish on the bin's keys alone
+                int cnt = 0;
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) cnt += ((hi[i] | lo[i]) != 0u && ((hi[i] ^ T) >> sh) == 0u) ? 1 : 0;
+                int pos = wave_reserve_n(&red[28], cnt);      // one LDS atomic per wave, not one per key
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) {
+                    const bool in = (hi[i] | lo[i]) != 0u && ((hi[i] ^ T) >> sh) == 0u;
+                    if (in) binv[pos++] = hi[i];
+                }
+                __syncthreads();
+                if (threadIdx.x < 64) {
+                    u32 v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (int)threadIdx.x + 64 * j < nb ? binv[threadIdx.x + 64 * j] : 0u;   // 0 < every key of the bin
+                    const int need = k - above;
+                    u32 t = T;
+                    for (int bit = sh - 1; bit >= 0; --bit) {
+                        const u32 cand = t | (1u << bit);
+                        int c = 0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) c += __popcll(__ballot(v[j] >= cand));
+                        if (c >= need) t = cand;
+                    }
+                    int cg = 0, ce = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        cg += __popcll(__ballot(v[j] > t));
+                        ce += __popcll(__ballot(v[j] == t));
+                    }
+                    if (threadIdx.x == 0) {
+                        red[29] = (int)t;
+                        red[30] = above + cg;
+                        red[31] = ce;
+                    }
+                }
+                __syncthreads();
+                T = (u32)red[29];
+                tg = red[30];
+                te = red[31];
+            }
+        }
+        __syncthreads();
         if (tg + te > k) {  // tie on the k-th score: keep the smallest ids (largest inverted ids)
             const int need = k - tg;
             for (int bit = 31; bit >= 0; --bit) {
@@ -232,11 +355,19 @@ __device__ __forceinline__ int block_topk_regs(const u32 (&hi)[NPT], const u32 (
     }
     if (threadIdx.x == 0) red[24] = 0;
     __syncthreads();
+    {
+        int cnt = 0;
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-        const bool keep = (hi[i] | lo[i]) != 0u && (hi[i] > T || (hi[i] == T && lo[i] >= TL));
-        const int pos = wave_reserve(&red[24], keep);
-        if (keep && pos < k) sel[pos] = ((u64)hi[i] << 32) | lo[i];
+        for (int i = 0; i < NPT; ++i) cnt += ((hi[i] | lo[i]) != 0u && (hi[i] > T || (hi[i] == T && lo[i] >= TL))) ? 1 : 0;
+        int pos = wave_reserve_n(&red[24], cnt);
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const bool keep = (hi[i] | lo[i]) != 0u && (hi[i] > T || (hi[i] == T && lo[i] >= TL));
+            if (keep) {
+                if (pos < k) sel[pos] = ((u64)hi[i] << 32) | lo[i];
+                ++pos;
+            }
+        }
     }
     __syncthreads();
     // rank by counting (keys are unique)

@@ -212,21 +212,39 @@ __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams
 // One selection over the N real entries of the field's chunk lists, NPT keys per thread (N <= NPT * TPB): entry e of the
 // concatenated lists goes to thread e % TPB, register e / TPB; its chunk is found by bisection in the exclusive prefix `pre` of the
 // chunk counts (LDS).  All loads of a thread are independent.
+#ifdef MFAR_TRACE
+__shared__ unsigned long long g_tr_merge0;
+#endif
 template <int NPT, int TPB>
 __device__ __forceinline__ int merge_regs_select(const MergeParams& p, const int* pre, int n_chunks, int c_lo, int ql, int N, u64* sel, u64* sorted,
                                                  int* red) {
     uint2 e[NPT];
+    // chunk of entry en = largest c with pre[c] <= en (empty chunks repeat their neighbour's prefix).  n_chunks <= 128: seven branch-free
+    // bisection steps, written STEP-major over groups of eight entries -- the eight LDS reads of a step are independent and wait once;
+    // entry-major, the compiler waited on every one of the 7 * NPT reads in turn (14 of the merge's 23 us load phase).
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-        const int s_ = (int)threadIdx.x + TPB * i;
-        const int en = s_ < N ? s_ : 0;
-        int lo_ = 0, hi_ = n_chunks;                  // largest c with pre[c] <= en (empty chunks repeat their neighbour's prefix)
-        while (hi_ - lo_ > 1) {
-            const int mid = (lo_ + hi_) >> 1;
-            if (pre[mid] <= en) lo_ = mid;
-            else hi_ = mid;
+    for (int g = 0; g < NPT; g += 8) {
+        int lo_[8], en[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s_ = (int)threadIdx.x + TPB * (g + j);
+            en[j] = s_ < N ? s_ : 0;
+            lo_[j] = 0;
         }
-        e[i] = p.lists[((size_t)(c_lo + lo_) * p.qw + ql) * S1_CAP + (N > 0 ? en - pre[lo_] : 0)];
+#pragma unroll
+        for (int st = 64; st > 0; st >>= 1) {
+            int pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = pre[lo_[j] + st < n_chunks ? lo_[j] + st : 0];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lo_[j] = (lo_[j] + st < n_chunks && pv[j] <= en[j]) ? lo_[j] + st : lo_[j];
+        }
+        int pb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[j] = pre[lo_[j]];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (g + j < NPT) e[g + j] = p.lists[((size_t)(c_lo + lo_[j]) * p.qw + ql) * S1_CAP + (N > 0 ? en[j] - pb[j] : 0)];
     }
     u32 hi[NPT], lo[NPT];
 #pragma unroll
@@ -236,7 +254,15 @@ __device__ __forceinline__ int merge_regs_select(const MergeParams& p, const int
         lo[i] = ok ? 0xFFFFFFFFu - e[i].y : 0u;
         asm volatile("" : "+v"(hi[i]), "+v"(lo[i]));   // keep the keys materialised: the selection re-reads them 34 times
     }
+#ifdef MFAR_TRACE
+    const unsigned long long tr_l = wall_clock64();
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) trace_put(11, (int)blockIdx.x, N, g_tr_merge0);
+    const int mm_ = block_topk_regs<NPT>(hi, lo, N, p.k, sel, sorted, red);
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) trace_put(12, (int)blockIdx.x, NPT, tr_l);
+    return mm_;
+#else
     return block_topk_regs<NPT>(hi, lo, N, p.k, sel, sorted, red);
+#endif
 }
 
 // Register-resident variant for n_chunks * k <= 256 * NPT and n_chunks <= 128: the keys never pass through LDS (6 KB of static LDS
@@ -251,6 +277,9 @@ __device__ __forceinline__ void merge_lists_regs_body(const MergeParams& p) {
     const int ql = blockIdx.x / p.nf, fo = blockIdx.x - ql * p.nf, f = p.f0 + fo;
     if (p.only_failed && !p.only_failed[p.gfield ? p.gfield[f] : f]) return;   // workgroup-uniform
     const int c_lo = p.fchunk[f], n_chunks = p.fchunk[f + 1] - c_lo;
+#ifdef MFAR_TRACE
+    const unsigned long long tr_a = wall_clock64();
+#endif
     // exclusive prefix of the chunk counts (n_chunks <= 128: the first two waves)
     if (threadIdx.x < 128) {
         const int c = (int)threadIdx.x < n_chunks ? max(0, min(p.list_cnt[(size_t)(c_lo + threadIdx.x) * p.qw + ql], p.k)) : 0;
@@ -267,6 +296,11 @@ __device__ __forceinline__ void merge_lists_regs_body(const MergeParams& p) {
     if (threadIdx.x == 0) pre[128] = wtot[0] + wtot[1];
     __syncthreads();
     const int N = pre[128];
+#ifdef MFAR_TRACE
+    if (threadIdx.x == 0) g_tr_merge0 = wall_clock64();
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) trace_put(10, (int)blockIdx.x, N, tr_a);
+    __syncthreads();
+#endif
     int m;
     if (NPT > 8 && N <= 8 * TPB) m = merge_regs_select<8, TPB>(p, pre, n_chunks, c_lo, ql, N, sel, sorted, red);
     else if (NPT > 16 && N <= 16 * TPB) m = merge_regs_select<(NPT > 16 ? 16 : NPT), TPB>(p, pre, n_chunks, c_lo, ql, N, sel, sorted, red);
@@ -281,6 +315,9 @@ __device__ __forceinline__ void merge_lists_regs_body(const MergeParams& p) {
         return;
     }
     if (!p.out_ids) return;
+#ifdef MFAR_TRACE
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) trace_put(13, (int)blockIdx.x, m, tr_a);
+#endif
     const size_t ob = ((size_t)(p.q0 + ql) * p.nf + fo) * p.k;
     for (int i = threadIdx.x; i < p.k; i += blockDim.x) {
         if (i < m) {

@@ -70,6 +70,11 @@ def main():
             print(f"   group at {s[sl][0]:9.0f} us  n={cuts[i + 1] - cuts[i]:5d}  starts +[{np.percentile(s[sl] - s[sl][0], 50):7.0f} {np.percentile(s[sl] - s[sl][0], 90):7.0f} {(s[sl] - s[sl][0]).max():7.0f}]"
                   f"  ends +[{np.percentile(e[sl] - s[sl][0], 1):7.0f} {np.percentile(e[sl] - s[sl][0], 50):7.0f} {(e[sl] - s[sl][0]).max():7.0f}]  dur med {np.median(d):7.0f} max {d.max():7.0f}"
                   + (f"  units [{u[sl].min()} {int(np.median(u[sl]))} {u[sl].max()}]" if kind == 1 else ""))
+    for kind, name in ((10, "merge: prefix of chunk counts"), (11, "merge: bisection + entry loads"), (12, "merge: selection"), (13, "merge: whole workgroup (units = m)")):
+        r = rec[rec["kind"] == kind]
+        if len(r):
+            d = (r["t1"] - r["t0"]).astype(np.float64) * tick
+            print(f"-- {name}: n={len(r)} dur us p10/50/90/max = {np.percentile(d, 10):.1f} {np.median(d):.1f} {np.percentile(d, 90):.1f} {d.max():.1f}  units med {int(np.median(r['units']))}")
 
 
 if __name__ == "__main__":
