@@ -1126,6 +1126,9 @@ __device__ __forceinline__ u32 s1_bf16x2_to_f16x2(u32 x, u32 tmin2, u32 bias2) {
 }
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f16x8 s1_cvt_granule(u32x4 g, u32 tmin2, u32 bias2) {
+#ifdef MFAR_EXP_NOCVT      // timing experiment only (wrong results): what the conversion costs
+    return __builtin_bit_cast(f16x8, g);
+#endif
     u32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = s1_bf16x2_to_f16x2(g[i], tmin2, bias2);
