@@ -21,7 +21,7 @@ Prints ONE JSON line on rank 0:
                        figure (D*F*E*4 per batch) so nobody reads the screen's rate as "fp32 slab at > HBM peak": the
                        speed comes from a proven-exact byte cut (every list certified or redone), not from the kernel.
   roofline_exact_fp32  a short second leg of the SAME run with the screen off: the exhaustive fp32 MFMA pass
-                       (`mfar_stage1_kernel`, 2*D*F*E*64 flops per launch against the 157.3 TFLOP/s fp32 MFMA peak).
+                       (`mfar_stage1_f32r4_kernel`, 2*D*F*E*64 flops per launch against the 157.3 TFLOP/s fp32 MFMA peak).
                        Same output bits as the default leg (asserted on the last batch).
   cpu_baseline         the oracle's torch port of the reference algorithm (same torch ops as the reference's CPU path) on
                        this box's host cores, on the FULL corpus when host RAM allows; every GPU-vs-port difference is
@@ -120,7 +120,14 @@ def s1_kernel_name(dtype, screened, E, wide=False):
         return "mfar_stage1_bf16s_kernel" if (E // 16) % 6 == 0 else "mfar_stage1_bf16s4_kernel"
     if screened and wide:
         return "mfar_stage1_f16w4_kernel" if (E // 16) % 4 == 0 and os.environ.get("MFAR_WIDE_RING") != "6" else "mfar_stage1_f16w_kernel"
-    return f"mfar_stage1_f16{rr}_kernel" if screened else "mfar_stage1_kernel"
+    if screened:
+        return f"mfar_stage1_f16{rr}_kernel"
+    # the exact fp32 pass: docs straight into a 4-slot (preferred) or 6-slot register ring, the LDS-ring kernel for other widths
+    if os.environ.get("MFAR_S1_REGRING", "1") == "0":
+        return "mfar_stage1_kernel"
+    if (E // 16) % 4 == 0 and not (os.environ.get("MFAR_F32_RING") == "6" and (E // 16) % 6 == 0):
+        return "mfar_stage1_f32r4_kernel"
+    return "mfar_stage1_f32r_kernel" if (E // 16) % 6 == 0 else "mfar_stage1_kernel"
 
 
 def spawn_ranks(n: int) -> int:
@@ -417,13 +424,13 @@ def main():
         if not same:
             raise SystemExit("the certified screen and the exhaustive fp32 pass returned different bits")
         fl = 2.0 * (row1 - row0) * F * E * 64
-        exact_leg = {"bound": "mfma", "kernel": "mfar_stage1_kernel", "achieved": fl / (ex_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+        exact_leg = {"bound": "mfma", "kernel": s1_kernel_name("f32", False, E), "achieved": fl / (ex_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": fl / (ex_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": ex_ms, "launches": ex_n,
                      "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": float(row1 - row0) * F * E * 4,
                      "hbm_GBps_algorithmic": float(row1 - row0) * F * E * 4 / (ex_ms * 1e-3) / 1e9,
                      "queries_per_s": ex_steps * Q / ex_dt, "ms_per_step": ex_dt / ex_steps * 1e3,
                      "ids_and_score_bits_identical_to_default_leg": True,
-                     **profile_counters("mfar_stage1_kernel", (D, F, E, Q, N))}
+                     **profile_counters(s1_kernel_name("f32", False, E), (D, F, E, Q, N))}
 
     # ---- N > 1: the other corner of the layout in the same run -- N full replicas, batches dealt round-robin, no exchange (the
     #      reference's query-sharded search) -- when the main leg row-sharded and the whole index fits one GPU

@@ -34,6 +34,16 @@ from mfar import _native
 from mfar.data import index as _index
 
 
+_STREAMS = {}
+
+
+def _shared_stream(torch, dev, role: str, priority: int):
+    key = (dev.index, role, priority)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(device=dev, priority=priority)
+    return _STREAMS[key]
+
+
 class PipelinedSearcher:
     def __init__(self, index, W, mask=None, k1: int = 100, k2: int = 100, sentinel: bool = True, query_cond: bool = True,
                  max_batch: int = 64, group=None, coalesce=None, exchange=None, masks=None, depth=None):
@@ -57,7 +67,11 @@ class PipelinedSearcher:
         # tail's workgroups then take the CU slots a finely cut scan grid frees while it runs; measured)
         import os
         flip = os.environ.get("MFAR_TAIL_PRIORITY", "0") == "1"
-        self.main = torch.cuda.Stream(device=self.dev, priority=0 if flip else -1)
+        # ONE set of streams per device and process, shared by every searcher: HIP maps streams onto a handful of hardware queues round-robin,
+        # and the streams of the sixth searcher a process creates land on queues its own other streams already use -- scan and tail then
+        # serialise (bench.py's BASELINE-config legs, run after five other legs: 62 k q/s against 70 k for the same shape in a fresh
+        # process, the scan kernel itself unchanged).  Searchers alive at the same time merely take turns.
+        self.main = _shared_stream(torch, self.dev, "main", 0 if flip else -1)
         # DEPTH: launches in flight = slots of scratch (include/mfar_hip.h: up to 4).  The wide scan fills the register file, so a
         # tail only runs in the gaps between scans.  With two slots scan i+2 has to wait for tail i, which scan i+1 kept off the
         # machine: every gap is as long as one whole tail.  With three (default) the next scan starts as soon as its own sample
@@ -67,7 +81,7 @@ class PipelinedSearcher:
         self.depth = int(depth if depth is not None else os.environ.get("MFAR_PIPE_DEPTH", "3"))
         if not 2 <= self.depth <= 4:
             raise ValueError("pipeline depth must be 2, 3 or 4")
-        self.sides = [torch.cuda.Stream(device=self.dev, priority=-1 if flip else 0) for _ in range(2 if self.depth > 2 else 1)]
+        self.sides = [_shared_stream(torch, self.dev, f"side{i}", -1 if flip else 0) for i in range(2 if self.depth > 2 else 1)]
         if os.environ.get("MFAR_PIPE_SERIAL", "0") == "1":      # diagnostic: tails on the scan stream (no kernel of a tail beside a scan)
             self.sides = [self.main]
         self.side = self.sides[0]
