@@ -226,6 +226,46 @@ def test_mixer_bit_exact_and_golden(golden_dir, idxmod):
     np.testing.assert_allclose(got, z["eval_out"][0], rtol=0, atol=TOL)
 
 
+def test_selection_edge_cases_through_the_mixer(idxmod):
+    """The selection every top-k kernel shares (mfar_device.h block_topk_regs: common-prefix skip, 256-bin histogram levels, the k-th
+    key's bin finished by one wave, id refinement on ties) on the key sets that stress each branch, driven through `mfar_mix_topk` with
+    one field (its mixed score is weight x candidate score, so the keys are what the test writes): all scores equal; a block of more
+    than 512 equal scores around the k-th rank; 4096 scores that differ only in their lowest mantissa bits; two tight clusters of
+    opposite sign (the k-th key's bin stays above 512 keys for several levels); huge dynamic range with zeros and denormals; n = k + 1,
+    n = k, n < k."""
+    rng = np.random.default_rng(67)
+    C = 4096
+    rows = []
+    rows.append(np.full(C, 1.25, np.float32))                                                        # all equal
+    a = rng.standard_normal(C).astype(np.float32)
+    a[rng.choice(C, 1000, replace=False)] = np.float32(np.sort(a)[-60])                              # 1000 copies of the 60th best
+    rows.append(a)
+    rows.append((np.float32(1.0) + np.arange(C, dtype=np.float32) * np.float32(2.0 ** -23))[rng.permutation(C)])   # low mantissa bits only
+    b = np.concatenate([5.0 + rng.random(2000) * 2.0 ** -10, -3.0 + rng.random(2096) * 2.0 ** -10]).astype(np.float32)
+    rows.append(b[rng.permutation(C)])                                                                # two tight clusters
+    c = (rng.standard_normal(C) * np.exp(rng.uniform(-80, 80, C))).astype(np.float32)
+    c[:50] = 0.0
+    c[50:80] = np.float32(1e-42)                                                                      # denormals
+    c[80:100] = np.float32(-1e-42)
+    rows.append(c[rng.permutation(C)])
+    rows.append(np.round(rng.standard_normal(C) * 3).astype(np.float32))                              # few distinct values: ties everywhere
+    x = np.stack(rows)[:, :, None].astype(np.float32)
+    Q = x.shape[0]
+    ids = np.stack([rng.permutation(100000)[:C] for _ in range(Q)]).astype(np.int64)
+    w1 = np.array([1.0], dtype=np.float32)
+    for k in (1, 37, 100, 128):
+        for n in (C, 2049, 513, k + 1, k, max(1, k - 3)):
+            ncand = np.full(Q, n, dtype=np.int32)
+            r = idxmod.mix_topk(x, ids, None, w1, None, ncand, k=k, query_cond=False)
+            for i in range(Q):
+                mixed = O.c_mix(x[i, :n], O.c_gate(np.zeros(1, np.float32), w1, query_cond=False))
+                oi, osc = O.canon(ids[i, :n], mixed)
+                m = min(n, k)
+                assert r["n_valid"][i] == m, (k, n, i)
+                assert np.array_equal(r["ids"][i, :m], oi[:m]), (k, n, i)
+                assert np.array_equal(r["scores"][i, :m].view(np.uint32), osc[:m].view(np.uint32)), (k, n, i)
+
+
 def test_two_stage_bit_exact_vs_oracle(idxmod):
     rng = np.random.default_rng(5)
     for F, D, E, Q, mean, masked in [(1, 900, 32, 4, 0.3, []), (4, 1200, 32, 6, 0.3, [1]), (8, 700, 64, 5, -0.4, [2, 3]),
