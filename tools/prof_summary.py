@@ -71,7 +71,8 @@ if "--counters-json" in sys.argv:
         for fn in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
             in_off = (os.sep + "off" + os.sep) in fn
             for r in csv.DictReader(open(fn)):
-                if in_off != short(r["Kernel_Name"]).startswith("mfar_stage1_kernel") and os.path.isdir(os.path.join(d, "off")): continue
+                exact = short(r["Kernel_Name"]).startswith(("mfar_stage1_kernel", "mfar_stage1_f32r"))      # the exact fp32 scan kernels
+                if in_off != exact and os.path.isdir(os.path.join(d, "off")): continue
                 k = short(r["Kernel_Name"])
                 if "mfar" not in k: continue
                 acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
