@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity stress of stage 1 (all scan kernels, screen on/off) and of the whole scorer (with the screen on: certified
 re-scoring prefix, two-level stage 2) against the C oracle.
-    python tools/stress.py [seconds] [seed] [big]   -- prints one line per configuration, exits non-zero on the first mismatch"""
+    python tests/stress.py [seconds] [seed] [big]   -- prints one line per configuration, exits non-zero on the first mismatch"""
 import os
 import sys
 import time
