@@ -7,6 +7,7 @@ B="--no-cpu-baseline --no-extra-legs"
 # the driver-shaped run (every leg, BASELINE config legs included) and the default 64-step run
 python $R/bench.py --steps 20 --warmup 3 > $O/bench_driver_shape.json 2> $O/bench.err
 python $R/bench.py --no-cpu-baseline --no-config-legs > $O/bench.json 2>> $O/bench.err
+python $R/bench.py > $O/bench_default.json 2>> $O/bench.err        # exactly what the driver runs at N = 1
 line() { python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); r=d['roofline']; c=d['config']
