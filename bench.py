@@ -108,28 +108,6 @@ def pipeline_traffic(shape, s1_kernel, sample_kernel) -> dict:
     return None
 
 
-def s1_kernel_name(dtype, screened, E, wide=False):
-    rr = "" if os.environ.get("MFAR_S1_REGRING", "1") == "0" else ("r" if (E // 16) % 6 == 0 else ("r4" if (E // 16) % 4 == 0 else ""))
-    if dtype == "bf16" and not screened:
-        return f"mfar_stage1_bf16{rr}_kernel"
-    if dtype == "bf16":          # the certified passes over the bf16 slab itself (two bf16 query terms)
-        if wide and os.environ.get("MFAR_BF16_WIDE_TERMS") == "2":
-            return "mfar_stage1_bf16w4_kernel" if (E // 16) % 4 == 0 else "mfar_stage1_bf16w_kernel"
-        if wide:                 # docs converted to fp16 in registers, one fp16 query term
-            return "mfar_stage1_bf16c_kernel" if (E // 16) % 6 == 0 else "mfar_stage1_bf16c4_kernel"
-        return "mfar_stage1_bf16s_kernel" if (E // 16) % 6 == 0 else "mfar_stage1_bf16s4_kernel"
-    if screened and wide:
-        return "mfar_stage1_f16w4_kernel" if (E // 16) % 4 == 0 and os.environ.get("MFAR_WIDE_RING") != "6" else "mfar_stage1_f16w_kernel"
-    if screened:
-        return f"mfar_stage1_f16{rr}_kernel"
-    # the exact fp32 pass: docs straight into a 4-slot (preferred) or 6-slot register ring, the LDS-ring kernel for other widths
-    if os.environ.get("MFAR_S1_REGRING", "1") == "0":
-        return "mfar_stage1_kernel"
-    if (E // 16) % 4 == 0 and not (os.environ.get("MFAR_F32_RING") == "6" and (E // 16) % 6 == 0):
-        return "mfar_stage1_f32r4_kernel"
-    return "mfar_stage1_f32r_kernel" if (E // 16) % 6 == 0 else "mfar_stage1_kernel"
-
-
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` with no launcher: start N ranks of this script as CHILD processes (one per GPU, RANK /
     LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) before anything in this process has touched the GPU, relay rank 0's
@@ -266,7 +244,10 @@ def main():
     D, F, E, Q = args.docs, args.fields, args.dim, args.batch
     # layout: N ranks = G replica groups x R row shards (R = N unless asked otherwise)
     esz = 2 if args.dtype == "bf16" else 4
-    whole_index_bytes = int(D * F * E * (esz + (2 if args.dtype == "f32" else 0) + 2) + D * F * 24)      # rows + [fp16 screen] + gather slab + tables
+    # rows + [fp16 screen] + gather slab + tables (+ row norms) + the score dumps of three pipeline slots on the shapes that use them
+    # (many fields over few rows: rows x 512 B per slot, mfar_set_stage2_dump's one-third rule)
+    dump_slot = D * F * 512 if (args.dtype == "f32" and 3.0 * (D * F * 512 + 128 * F * K1 * F * 64) < 128.0 * F * K1 * F * E * 2) else 0
+    whole_index_bytes = int(D * F * E * (esz + (2 if args.dtype == "f32" else 0) + 2) + D * F * 28 + 3 * dump_slot)
     if args.row_shards == "auto":
         R = choose_row_shards(N, whole_index_bytes, torch.cuda.mem_get_info(local_rank)[0])
         if N > 1:       # every rank must take the same decision: the most conservative one
@@ -380,6 +361,7 @@ def main():
     run(ps, corpus, lay.my_batches(0, args.warmup), None)
     scr0, st2_0 = ix.screen_stats(), ix.stage2_stats()
     dt, s1_avg_ms, s1_n, my_steps = timed(ps, ix, corpus, lay, args.warmup, args.steps, results)
+    s1_kernel = ix.last_stage1_kernel()                      # the scan kernel the library actually launched (ROW MODE, ring choice, ... included)
     scr, st2 = ix.screen_stats(), ix.stage2_stats()
     screened = bool(scr["built"])                            # stage 1 ran on the fp16 screen slab of the index
 
@@ -418,19 +400,20 @@ def main():
         ex_res = []
         ex_steps = min(8, args.steps)
         ex_dt, ex_ms, ex_n, _ = timed(ps_ex, ix, corpus, lay, args.warmup + args.steps - ex_steps, ex_steps, ex_res)
+        ex_kernel = ix.last_stage1_kernel()
         del ps_ex
         ix.set_screen(1)
         same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(results[-ex_steps:], ex_res))
         if not same:
             raise SystemExit("the certified screen and the exhaustive fp32 pass returned different bits")
         fl = 2.0 * (row1 - row0) * F * E * 64
-        exact_leg = {"bound": "mfma", "kernel": s1_kernel_name("f32", False, E), "achieved": fl / (ex_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+        exact_leg = {"bound": "mfma", "kernel": ex_kernel, "achieved": fl / (ex_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": fl / (ex_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": ex_ms, "launches": ex_n,
                      "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": float(row1 - row0) * F * E * 4,
                      "hbm_GBps_algorithmic": float(row1 - row0) * F * E * 4 / (ex_ms * 1e-3) / 1e9,
                      "queries_per_s": ex_steps * Q / ex_dt, "ms_per_step": ex_dt / ex_steps * 1e3,
                      "ids_and_score_bits_identical_to_default_leg": True,
-                     **profile_counters(s1_kernel_name("f32", False, E), (D, F, E, Q, N))}
+                     **profile_counters(ex_kernel, (D, F, E, Q, N))}
 
     # ---- N > 1: the other corner of the layout in the same run -- N full replicas, batches dealt round-robin, no exchange (the
     #      reference's query-sharded search) -- when the main leg row-sharded and the whole index fits one GPU
@@ -492,7 +475,6 @@ def main():
         n_scan_rows = scr.get("scan_rows", (row1 - row0) * F) if screened else (row1 - row0) * F
         esize = 2 if (args.dtype == "bf16" or screened) else 4
         bytes_per_launch = float(n_scan_rows) * E * esize        # the scanned rows are read once per batch
-        s1_kernel = s1_kernel_name(args.dtype, screened, E, wide=ps.Qmax > 64)
         achieved_tf = flops_per_launch / (s1_avg_ms * 1e-3) / 1e12 if s1_avg_ms > 0 else 0.0
         gbps = bytes_per_launch / (s1_avg_ms * 1e-3) / 1e9 if s1_avg_ms > 0 else 0.0
         counters = profile_counters(s1_kernel, (D, F, E, Q, N))
@@ -594,6 +576,11 @@ def main():
                     ("configs[2] STaRK-mag", 700_244, 5, "f32", "STaRK-mag full corpus: 700 244 docs x 5 dense fields, fp32"),
                     ("configs[4] bf16 stress, per-GPU share", 1_250_000, 16, "bf16",
                      "10 M docs x 16 fields x 768d bf16 over 8 GPUs = 1 250 000 rows per GPU (what one rank of the row-sharded run holds)"))}
+        if N == 1 and args.dtype == "f32" and args.corpus == "plain" and not args.no_extra_legs and not args.no_config_legs:
+            line["clustered_corpus"] = clustered_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E)
+        if N == 1 and dist is None and not args.no_extra_legs and (sustained or args.sustain_s <= 0):
+            line["exchange_overhead"] = exchange_leg(ix, corpus, W, mask, PipelinedSearcher, run, Q, torch, max(256, args.steps),
+                                                     sustained["queries_per_s"] if sustained else qps)
         if N == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(corpus, ix, args, np, torch)
         sys.stdout.flush()
@@ -603,12 +590,13 @@ def main():
         dist.destroy_process_group()
 
 
-def config_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E, dtype, what, min_s=0.25):
+def config_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E, dtype, what, min_s=0.25, corpus_kwargs=None, exact_steps=4):
     """One of BASELINE.json's other configurations at its one-GPU shape: own synthetic corpus and index, the default pipeline, as many
     timed batches of Q queries as fill `min_s` seconds (at least 24; a 24-step region of a small shape is 15 ms, mostly pipeline ramp);
-    the dominant kernel priced from its HIP events like the headline's."""
+    the dominant kernel priced from its HIP events like the headline's, `alone` = the same scans with nothing beside them, and the
+    same BITS gate as the headline: the last `exact_steps` batches again with the screen off (fp32 index: the exhaustive fp32 MFMA pass)."""
     t0 = time.perf_counter()
-    cp = synth.SyntheticCorpus(D, F, E, n_queries=4096, seed=0xDEADBEEF, device=str(dev))
+    cp = synth.SyntheticCorpus(D, F, E, n_queries=4096, seed=0xDEADBEEF, device=str(dev), **(corpus_kwargs or {}))
     ix = cp.build_index(idxmod, dtype=dtype)
     ps = PipelinedSearcher(ix, cp.W, torch.ones(F, device=dev), k1=K1, k2=K2, max_batch=Q)
     run(ps, cp, list(range(2 * ps.coalesce * ps.depth)), None)      # scratch of every slot allocated, screen / tables / gather slab built
@@ -628,6 +616,7 @@ def config_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E
     dt = time.perf_counter() - t0
     ms, n = ix.stage1_timing()
     ix.set_timing(False)
+    kern = ix.last_stage1_kernel()
     s1, st1 = ix.screen_stats(), ix.stage2_stats()
     screened = bool(s1["built"])
     keep = []
@@ -638,10 +627,51 @@ def config_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E
         ids = ids.cpu().numpy()
         rel = cp.qrels((first + i) * Q, Q)
         rec += [len(set(ids[j, :20].tolist()) & rel[j]) / len(rel[j]) for j in range(Q)]
+    # the dominant kernel with nothing beside it (scans issued serially on one stream)
+    alone_ms = None
+    if screened:
+        nq = ps.Qmax // Q
+        ix.set_timing(True)
+        for i in range(4):
+            ix.retrieve_fields(torch.cat([cp.queries((first + i * nq + j) * Q, Q) for j in range(nq)]), K1, True)
+        torch.cuda.synchronize()
+        ms_a, n_a = ix.stage1_timing()
+        ix.set_timing(False)
+        alone_ms = ms_a / max(1, n_a)
+    info = ix.auto_off_info()
+    res_bytes = ix.resident_bytes()
+    # bits gate: the last `exact_steps` of the kept batches again with the screen off
+    bits_same = None
+    exact_what = None
+    if screened and exact_steps:
+        ix.set_screen(0)
+        ex = []
+        run(PipelinedSearcher(ix, cp.W, torch.ones(F, device=dev), k1=K1, k2=K2, max_batch=Q), cp, list(range(first + 8 - exact_steps, first + 8)), ex)
+        torch.cuda.synchronize()
+        ix.set_screen(1)
+        if dtype == "f32":
+            bits_same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) for a, b in zip(keep[-exact_steps:], ex))
+            exact_what = "the exhaustive fp32 MFMA pass (screen off): ids, score bits and n_valid of the last %d batches" % exact_steps
+            if not bits_same:
+                raise SystemExit(f"config leg {D} x {F} {dtype}: the certified default path and the exhaustive pass returned different bits")
+        else:
+            # a bf16 index has no exhaustive pass with the chain's bits (its plain MFMA pass sums the exact products in another order): every
+            # document both runs return must carry the same score bits, and the result sets may differ by near-ties at a list cut-off only
+            common, same = 0, True
+            for (ia, sa, _), (ib, sb, _) in zip(keep[-exact_steps:], ex):
+                ia, sa, ib, sb = ia.cpu().numpy(), sa.cpu().numpy(), ib.cpu().numpy(), sb.cpu().numpy()
+                for j in range(Q):
+                    _, x, y = np.intersect1d(ia[j], ib[j], return_indices=True)
+                    common += x.size
+                    same = same and bool(np.array_equal(sa[j][x].view(np.uint32), sb[j][y].view(np.uint32)))
+            bits_same = bool(same and common >= 0.98 * exact_steps * Q * K2)
+            exact_what = (f"the plain bf16 MFMA pass (screen off; stage-1 scores within 1e-4 of the chain): {common} of {exact_steps * Q * K2} final "
+                          "documents in common, score bits of every common document equal")
+            if not bits_same:
+                raise SystemExit(f"config leg {D} x {F} bf16: certified and plain pass disagree beyond cut-off near-ties")
     scan_rows = s1.get("scan_rows", D * F) if screened else D * F
     esize = 2 if (dtype == "bf16" or screened) else 4
     bytes_per_launch = float(scan_rows) * E * esize
-    kern = s1_kernel_name(dtype, screened, E, wide=ps.Qmax > 64)
     avg_ms = ms / max(1, n)
     out = {"workload": what + "; synthetic STaRK-shaped rows (mfar/synth.py), two-stage scorer k1=k2=100, zero-sentinel mode",
            "docs": D, "fields": F, "dim": E, "dtype": dtype, "steps": steps, "query_batch": Q, "queries_per_launch": ps.Qmax,
@@ -649,19 +679,133 @@ def config_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E
            "roofline": {"bound": "hbm", "kernel": kern, "avg_launch_ms": avg_ms, "launches": n, "algorithmic_bytes_per_launch": bytes_per_launch,
                         "achieved": bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": bytes_per_launch / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if avg_ms > 0 else 0.0,
+                        "alone": ({"avg_launch_ms": alone_ms, "frac": bytes_per_launch / (alone_ms * 1e-3) / 1e9 / PEAK_HBM_GBS} if alone_ms else None),
                         "hbm_bound_queries_per_s": ps.Qmax / (bytes_per_launch / (PEAK_HBM_GBS * 1e9)),
                         "algorithmic_bytes_definition": f"{scan_rows} scanned rows x {E} dims x {esize} B, read once per launch of {ps.Qmax} queries"},
            "lists_certified": (s1["n_checked"] - s0["n_checked"]) - (s1["n_failed"] - s0["n_failed"]),
            "lists_redone_exactly": s1["n_failed"] - s0["n_failed"], "batches_redone": ps.n_redone,
+           "fields_switched_off": info["off"], "inline_repair": info["inline_repair"],
+           "ids_and_score_bits_identical_to_exact": bits_same, "exact_leg": exact_what,
            "stage2": ({"candidates_per_query": (st1["n_candidates"] - st0["n_candidates"]) / (steps * Q),
-                       "survivors_per_query": (st1["n_survivors"] - st0["n_survivors"]) / (steps * Q)}
+                       "survivors_per_query": (st1["n_survivors"] - st0["n_survivors"]) / (steps * Q),
+                       "score_dump": ix.stage2_dump_info()["wanted"]}
                       if st1["two_level"] and st1["n_candidates"] > st0["n_candidates"] else "every (candidate, field) row gathered"),
-           "resident_bytes": ix.resident_bytes(), "recall_at_20": float(np.mean(rec)), "index_build_s": t_build}
+           "resident_bytes": res_bytes, "recall_at_20": float(np.mean(rec)), "index_build_s": t_build}
     del ps
     ix.close()
     del cp
     torch.cuda.empty_cache()
     return out
+
+
+def clustered_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E, min_s=0.4):
+    """The certified screen's WORST case at the headline shape: every field is made of clusters of ~235 near-duplicate (not identical) rows
+    (mfar/synth.py "clustered"), so nearly every certificate fails.  The library switches the failing fields off (include/mfar_hip.h
+    "AUTO-OFF"): reported are the rate while it is still learning (failures repaired), the steady rate afterwards, the rate of the same
+    index with the screen off, their ratio, and the bits of the default path against the screen-off path."""
+    cp = synth.SyntheticCorpus(D, F, E, n_queries=4096, seed=0xDEADBEEF, device=str(dev), field_kinds=["clustered"] * F)
+    ix = cp.build_index(idxmod)
+    ones = torch.ones(F, device=dev)
+    ps = PipelinedSearcher(ix, cp.W, ones, k1=K1, k2=K2, max_batch=Q)
+    s0 = ix.screen_stats()
+    t0 = time.perf_counter()
+    n_learn = 40                                   # 20 launches: the fields are switched off after 12 failed ones
+    run(ps, cp, list(range(n_learn)), None)
+    torch.cuda.synchronize()
+    dt_learn = time.perf_counter() - t0
+    info0 = ix.auto_off_info()
+    s1 = ix.screen_stats()
+    t0 = time.perf_counter()
+    run(ps, cp, list(range(n_learn, n_learn + 8)), None)
+    torch.cuda.synchronize()
+    steps = int(min(512, max(16, min_s / max((time.perf_counter() - t0) / 8, 1e-6))))
+    steps -= steps % ps.coalesce
+    keep = []
+    t0 = time.perf_counter()
+    run(ps, cp, list(range(n_learn, n_learn + steps)), None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    run(ps, cp, list(range(n_learn, n_learn + 4)), keep)
+    torch.cuda.synchronize()
+    s2, info = ix.screen_stats(), ix.auto_off_info()
+    n_redone = ps.n_redone
+    del ps
+    ix.set_screen(0)
+    ps0 = PipelinedSearcher(ix, cp.W, ones, k1=K1, k2=K2, max_batch=Q)
+    run(ps0, cp, list(range(4)), None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(ps0, cp, list(range(n_learn, n_learn + steps)), None)
+    torch.cuda.synchronize()
+    dt0 = time.perf_counter() - t0
+    ex = []
+    run(ps0, cp, list(range(n_learn, n_learn + 4)), ex)
+    torch.cuda.synchronize()
+    same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) for a, b in zip(keep, ex))
+    rec = []
+    for i, (ids, _, _) in enumerate(keep):
+        ids = ids.cpu().numpy()
+        rel = cp.qrels((n_learn + i) * Q, Q)
+        rec += [len(set(ids[j, :20].tolist()) & rel[j]) / len(rel[j]) for j in range(Q)]
+    out = {"docs": D, "fields": F, "dim": E, "field_kinds": cp.field_kinds,
+           "what": "every field: ~235 near-duplicate, non-identical rows per cluster -- the top 192 approximate scores of a list tie inside the error bound",
+           "learning": {"batches": n_learn, "queries_per_s": n_learn * Q / dt_learn, "lists_redone_exactly": s1["n_failed"] - s0["n_failed"],
+                        "lists_checked": s1["n_checked"] - s0["n_checked"], "fields_switched_off_after": info0["off"], "inline_repair": info0["inline_repair"]},
+           "steps": steps, "queries_per_s": steps * Q / dt, "queries_per_s_screen_off": steps * Q / dt0,
+           "ratio_to_screen_off": (steps * Q / dt) / (steps * Q / dt0),
+           "fields_switched_off": info["off"], "probe_launches": info["n_probes"], "lists_redone_exactly_steady": s2["n_failed"] - s1["n_failed"],
+           "batches_redone": n_redone, "ids_and_score_bits_identical_to_screen_off": bool(same), "recall_at_20": float(np.mean(rec))}
+    del ps0
+    ix.close()
+    del cp
+    torch.cuda.empty_cache()
+    if not same:
+        raise SystemExit(f"clustered corpus: default path and screen-off path differ: {out}")
+    return out
+
+
+def exchange_leg(ix, corpus, W, mask, PipelinedSearcher, run, Q, torch, steps, base_qps):
+    """What the multi-GPU machinery itself costs on this box: the same index and batches through the lists-first EXCHANGE path
+    (mfar/data/pipeline.py: two all-gathers per launch, owned scoring, top-k merge with the certificate flag) over a ONE-rank RCCL group.
+    No xGMI hop is involved -- this prices the extra kernels, the collectives' launch overhead and the stream choreography."""
+    import torch.distributed as dist
+    created = False
+    try:
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29513")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{ix.device}"))
+            created = True
+        ps = PipelinedSearcher(ix, W, mask, k1=K1, k2=K2, max_batch=Q, exchange=True)
+        a, b = [], []
+        run(ps, corpus, list(range(2 * ps.depth * ps.coalesce)), None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(ps, corpus, list(range(8, 8 + steps)), None)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        run(ps, corpus, [8, 9], a)
+        del ps
+        ps1 = PipelinedSearcher(ix, W, mask, k1=K1, k2=K2, max_batch=Q)
+        run(ps1, corpus, [8, 9], b)
+        torch.cuda.synchronize()
+        same = all(torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) for x, y in zip(a, b))
+        out = {"backend": "nccl (= RCCL), one rank", "steps": steps, "queries_per_s": steps * Q / dt, "queries_per_s_without_exchange": base_qps,
+               "overhead": 1.0 - (steps * Q / dt) / base_qps, "bits_identical_to_the_plain_pipeline": bool(same)}
+        if not same:
+            raise SystemExit("exchange path over a one-rank RCCL group returned different bits")
+        return out
+    except SystemExit:
+        raise
+    except Exception as e:                      # no RCCL on this box / port taken: report, do not fail the headline
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        if created:
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
 
 
 def structured_leg(synth, idxmod, PipelinedSearcher, run, dev, E, Q, torch, np):

@@ -45,7 +45,7 @@ typedef struct mfar_index mfar_index;
 
 /* library / device probes (no reference counterpart).  mfar_version() == MFAR_ABI_VERSION of the header the caller was built
  * against, or the caller must refuse the library: the value changes with every signature change. */
-#define MFAR_ABI_VERSION 104
+#define MFAR_ABI_VERSION 105
 int mfar_version(void);
 const char* mfar_last_error(void);
 int mfar_device_count(int* n_out);
@@ -64,9 +64,11 @@ void mfar_index_destroy(mfar_index* idx);
 int mfar_index_info(const mfar_index* idx, int64_t* n_rows_local, int64_t* row_offset, int* n_fields, int* dim,
                     int* dtype, int64_t* slab_bytes);
 /* HBM the handle keeps resident between searches, by part: the rows (the slab), the fp16 screen slab of an fp32 index, the 16-bit
- * row-major gather slab (fp32 index: the approximate level of stage 2; bf16 index: the whole-line companion), and the unique-row
- * tables / statistics of the certified stage 1.  Per-launch scratch is not counted.  No reference counterpart. */
-int mfar_index_resident_bytes(const mfar_index* idx, int64_t* rows, int64_t* screen, int64_t* gather, int64_t* tables);
+ * row-major gather slab (fp32 index: the approximate level of stage 2; bf16 index: the whole-line companion), the unique-row
+ * tables / statistics / row norms of the certified stage 1, and the score dumps of the pipeline slots that use one (rows of the
+ * screen slab x 512 bytes per slot, only on shapes whose stage 2 reads them: mfar_set_stage2_dump).  Other per-launch scratch
+ * (lists, candidate tables: MBs) is not counted.  Any pointer may be NULL.  No reference counterpart. */
+int mfar_index_resident_bytes(const mfar_index* idx, int64_t* rows, int64_t* screen, int64_t* gather, int64_t* tables, int64_t* dumps);
 
 /*
  * Write n row-major fp32 vectors src[n, dim] into field `field`, local rows [local_row0, local_row0 + n).
@@ -268,6 +270,9 @@ int mfar_stage1_finish(mfar_index* idx, const float* q, int Q, int k, int sentin
  * mfar_stage1_timing() synchronises the recorded events and returns their summed duration and the launch count. */
 int mfar_set_timing(mfar_index* idx, int enable);
 int mfar_stage1_timing(mfar_index* idx, double* total_ms_out, int* n_launches_out);
+/* Name of the scan kernel the most recent stage-1 launch of this handle ran (the one the timing events bracket): which of the
+ * instantiations was chosen depends on the dtype, the dim, the block width, ROW MODE and AUTO-OFF.  "" before the first launch. */
+const char* mfar_last_stage1_kernel(const mfar_index* idx);
 /* Tunable: workgroups per CU for the stage-1 kernel (default 2). */
 int mfar_set_wgs_per_cu(mfar_index* idx, int wgs);
 
@@ -280,10 +285,13 @@ int mfar_set_wgs_per_cu(mfar_index* idx, int wgs);
  * that no other row can enter or tie into the exact top-k; a field whose proof fails is re-done by the exact fp32 pass over
  * the documents on the device (csrc/mfar_screen.h).  The screen slab (at most +50 % HBM) is built lazily by the first search
  * after rows were written.
- *   mode      0 = off, 1 = auto (default; fp32 indexes with >= 16384 rows, dim <= 2560, k <= 128), 2 = whenever the shapes allow.
- *             Environment default: MFAR_SCREEN.  A bf16 index is screened only in mode 2 (opt-in: the fp16 copy doubles its
- *             footprint): its lists then equal the exact natural-order fp32 chain over the bf16 rows bit for bit (the plain
- *             bf16 MFMA pass agrees with that chain to 1e-4), and the wide pass applies (1.75x the plain pass's throughput).
+ *   mode      0 = off, 1 = auto (default; indexes with >= 16384 rows, dim <= 2560, k <= 128), 2 = whenever the shapes allow.
+ *             Environment default: MFAR_SCREEN.
+ *             A bf16 index takes the same certified stage 1 in the same modes WITHOUT a second copy of its rows: the scan reads the
+ *             bf16 slab itself (blocks of <= 64 queries: two bf16 query terms; 65 .. 128: the docs converted to fp16 in registers
+ *             against one fp16 term), ranks unique rows through one bit per row, re-scores from the row-major bf16 companion.  Its
+ *             certified lists equal the exact natural-order fp32 chain over the bf16 rows bit for bit; see "bf16 contract" below for
+ *             the lists that are not certified.
  *   eps_mult  multiplies the error bound of the proof; 1 = rigorous.  Test knob: a huge value makes every proof fail
  *             (exercises the exact fall-back), 0 disables the proof (NOT exact any more).
  * mfar_screen_stats synchronises the device: built = the screen slab is current, screen_bytes = its size,
@@ -320,7 +328,7 @@ int mfar_set_stage2_mode(mfar_index* idx, int mode);
  * corpora, the row shards of a multi-GPU run -- the wide screened pass of stage 1 instead WRITES every approximate score it computes
  * (rows x 128 queries x 4 bytes per field and launch, per pipeline slot) and stage 2 reads its pairs out of that table, bounded by the
  * screened pass's own eps (csrc/mfar_select.h: mfar_s2_lookup_kernel): 129 375 x 22 moves 1.5 + 0.4 GB instead of 7.9 GB per 128 queries.
- *   mode   0 = never, 1 = when the dump moves less than two thirds of the gathers' bytes (default; environment MFAR_S2_DUMP),
+ *   mode   0 = never, 1 = when the dump moves less than ONE THIRD of the gathers' bytes (default; environment MFAR_S2_DUMP),
  *          2 = whenever the wide pass of an fp32 index with a current screen runs.
  * mfar_stage2_dump_info: would a launch with list depth k1 use it; bytes one launch writes; launches that read it so far.
  */
@@ -336,6 +344,26 @@ int mfar_set_stage2_dump(mfar_index* idx, int mode);
  * mfar_row_mode_info: bit f of the masks = field f is eligible / active (valid once the screen is built).
  */
 int mfar_set_row_mode(mfar_index* idx, int mode);
+/*
+ * AUTO-OFF and inline repair: the worst case of the certified screen (no reference counterpart; outputs bit-identical in every state).
+ * A certificate fails when more than k' - k unique rows of a field score within ~2 eps of the list's k-th best -- clusters of
+ * near-duplicate rows (not bit-identical, so the unique-row build keeps them apart) do that list after list, and every failure costs the
+ * exact pass of that field on top of the screen.  The library therefore reads the certificate flags of finished launches (copied to
+ * pinned host memory behind the certify kernel, picked up by a later call; nothing waits) and decides per FIELD: a field that failed in
+ * >= off_fails of its last 16 screened launches is switched OFF -- the screen leaves it out and the exact fp32 pass writes its lists
+ * directly, on the scan stream; every probe_every-th launch screens it anyway (quietly) and two clean probes in a row switch it back on.
+ * With every field off a launch is the exact pass and nothing else, i.e. the screen can cost a hostile corpus the probes (< 1 %), not 2x.
+ * Independently, when >= 4 of the last 16 launches reported a failure among the fields that are on, mfar_stage1_finish repairs on the
+ * device even when asked to report only (and reports a clean batch); it returns to reporting when at most one of the last 16 failed.
+ *   mode         0 = never switch a field off, 1 = auto (default; environment MFAR_SCREEN_AUTO_OFF).  fp32 indexes.
+ *   off_fails    1 .. 16 failed launches of the last 16 (0 = keep; default 12: a field that fails less often is cheaper screened + repaired)
+ *   probe_every  launches between probes (0 = keep; default 64)
+ * mfar_auto_off_info: bit f of off_fields = field f is off now; fields switched off / back on, probe launches so far; whether finish
+ * currently repairs inline.  Any pointer may be NULL.
+ */
+int mfar_set_auto_off(mfar_index* idx, int mode, int off_fails, int probe_every);
+int mfar_auto_off_info(mfar_index* idx, uint32_t* off_fields, int64_t* n_switched_off, int64_t* n_switched_on, int64_t* n_probes,
+                       int* inline_repair);
 int mfar_row_mode_activate(mfar_index* idx);
 int mfar_row_mode_info(const mfar_index* idx, uint32_t* eligible_fields, uint32_t* active_fields);
 int mfar_stage2_dump_info(mfar_index* idx, int k1, int* wanted, int64_t* bytes_per_launch, int64_t* n_launches);

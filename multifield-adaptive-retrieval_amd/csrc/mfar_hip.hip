@@ -77,15 +77,18 @@ static bool g_attr_done[16] = {false};
 struct S1Table : S1TableHost {       // mfar_tables.h + the device copies
     DevBuf d_chunks, d_fchunk, d_samp_n;
     DevBuf d_gchunk, d_fgroup, d_gfield;
+    u32 skip = 0;                    // built without these fields (AUTO-OFF: they get no chunks)
 };
 struct S1Geom : S1GeomHost {
     S1Table all, solo;
     S1Table all_w, solo_w;   // the wide pass keeps its own tables (same rule today; its list depth k' may differ from a 64-column pass in flight)
+    S1Table all_skip, all_w_skip;   // the all-fields tables WITHOUT the fields that are switched off (rebuilt when that set changes; the
+                                    // full tables stay for the probe launches)
     void reset(int F) {
         n_rows.assign(F, 0);
         base.assign(F, 0);
         n_tiles.assign(F, 0);
-        all.k = solo.k = all_w.k = solo_w.k = -1;
+        all.k = solo.k = all_w.k = solo_w.k = all_skip.k = all_w_skip.k = -1;
     }
 };
 
@@ -120,6 +123,16 @@ struct mfar_index {
         DevBuf arow, eps_cert;                                          // ... ROW MODE: per (field, query) factor of the row norm / what is left of eps
         bool screened = false;                                          // decided by the begin phase of the batch
         int qw = 64;                                                    // query columns of the batch's pass (128: wide screen pass)
+        // AUTO-OFF, latched by the begin phase: fields whose lists the exact pass writes in this batch / fields its screen leaves out
+        // (equal, except in a probe launch, which screens everything)
+        u32 exact_mask = 0, skip_mask = 0;
+        DevBuf off_flags;                                               // [MFAR_MAX_FIELDS] device copy of exact_mask, one int per field
+        // feedback: the batch's certificate flags, copied to pinned host memory behind the certify kernel and read by a LATER call once
+        // the event has completed (never waited for)
+        int* fb_host = nullptr;                                         // [SCREEN_FLAGS] pinned
+        hipEvent_t fb_ev = nullptr;
+        bool fb_pending = false;
+        u32 fb_screened = 0, fb_probed = 0;                             // fields screened for real / as a probe in that batch
     } s1[MFAR_SLOTS];
     DevBuf fid, fsc, cand[MFAR_SLOTS], ncand[MFAR_SLOTS], x[MFAR_SLOTS], own[MFAR_SLOTS], in[8], out[8];
     // 16-bit GATHER slab (mfar_select.h mfar_score_rows_kernel): row-major [F][n_rows] rows of g_row_bytes.
@@ -163,12 +176,27 @@ struct mfar_index {
     bool screen_dedup = true;     // MFAR_SCREEN_DEDUP=0: every document is its own unique row (diagnostic)
     bool wide = true;             // blocks of 65 .. 128 queries go through the wide screened pass (MFAR_WIDE=0: always 64 per pass)
     bool repair_sample = false;   // mfar_set_repair_mode: repairs run their own sample pass (see stage1_pass)
+    // AUTO-OFF (see "adaptive policy" below): fields whose certificates keep failing are scanned by the exact pass only
+    struct AutoOff {
+        int mode = 1;             // 0 never, 1 auto.  MFAR_SCREEN_AUTO_OFF
+        int off_fails = 12;       // a field is switched off when this many of its last 16 screened launches failed
+        int probe_every = 64;     // every n-th screened launch also screens the switched-off fields (quietly: the exact pass's lists stand)
+        int on_clean = 2;         // consecutive clean probes that switch a field back on
+        unsigned short hist[MFAR_MAX_FIELDS] = {0};
+        unsigned char clean[MFAR_MAX_FIELDS] = {0};
+        unsigned short any_hist = 0;
+        int any_n = 0;
+        long long launches = 0, n_off = 0, n_on = 0, n_probes = 0;
+    } ao;
+    u32 off_mask = 0;             // fields that are switched off now
+    bool inline_repair = false;   // failures are frequent: mfar_stage1_finish repairs on the device even when asked to report only
     S1Geom geom_docs, geom_screen;
     // fused mode (mfar_search_fused): a one-field companion index of dim F * E over the same rows, built on first use
     mfar_index* fused = nullptr;
     bool fused_dirty = true;      // rows were written since the companion was filled
     DevBuf fused_q;               // folded queries [Q, F * E]
     hipEvent_t mid_ev = nullptr;  // recorded right before the full stage-1 kernel is launched
+    const char* last_s1_kernel = "";   // the scan kernel the last timed stage-1 launch ran (mfar_last_stage1_kernel)
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
     int ev_n = 0;
@@ -296,6 +324,7 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     if (const char* e = getenv("MFAR_STAGE2_PRUNE")) idx->stage2_mode = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MFAR_S2_DUMP")) idx->dump_mode = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("MFAR_SCREEN_ROW_MODE")) idx->row_mode_setting = std::max(0, std::min(2, atoi(e)));
+    if (const char* e = getenv("MFAR_SCREEN_AUTO_OFF")) idx->ao.mode = atoi(e) != 0 ? 1 : 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) idx->n_cu = prop.multiProcessorCount;
     hipError_t e = hipMalloc(&idx->slab, idx->slab_bytes);
@@ -336,7 +365,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
                           &idx->s2eps[i], &idx->kmask[i], &idx->src2[i]})
             b->release();
     for (S1Geom* g : {&idx->geom_docs, &idx->geom_screen})
-        for (S1Table* t : {&g->all, &g->solo, &g->all_w, &g->solo_w}) {
+        for (S1Table* t : {&g->all, &g->solo, &g->all_w, &g->solo_w, &g->all_skip, &g->all_w_skip}) {
             t->d_chunks.release();
             t->d_fchunk.release();
             t->d_samp_n.release();
@@ -346,6 +375,9 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
         }
     for (DevBuf* b : bufs) b->release();
     for (auto& sl : idx->s1) {
+        if (sl.fb_host) (void)hipHostFree(sl.fb_host);
+        if (sl.fb_ev) (void)hipEventDestroy(sl.fb_ev);
+        sl.off_flags.release();
         DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.lists2, &sl.list_cnt2, &sl.unit_ctr, &sl.dump, &sl.arow, &sl.eps_cert, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
                         &sl.ssc, &sl.scnt, &sl.sx};
         for (DevBuf* b : sb) b->release();
@@ -368,7 +400,7 @@ extern "C" int mfar_index_info(const mfar_index* idx, int64_t* n_rows_local, int
     return MFAR_OK;
 }
 
-extern "C" int mfar_index_resident_bytes(const mfar_index* idx, int64_t* rows, int64_t* screen, int64_t* gather, int64_t* tables) {
+extern "C" int mfar_index_resident_bytes(const mfar_index* idx, int64_t* rows, int64_t* screen, int64_t* gather, int64_t* tables, int64_t* dumps) {
     if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
     if (rows) *rows = (int64_t)idx->slab_bytes;
     if (screen) *screen = (int64_t)idx->screen.cap;
@@ -376,9 +408,14 @@ extern "C" int mfar_index_resident_bytes(const mfar_index* idx, int64_t* rows, i
     if (tables) {
         size_t t = 0;
         for (const DevBuf* b : {&idx->u_rep, &idx->u_start, &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->rep_bits, &idx->u_of, &idx->s_stats,
-                                &idx->s_field, &idx->s_mean, &idx->s_field1, &idx->s_cvt})
+                                &idx->s_field, &idx->s_mean, &idx->s_field1, &idx->s_cvt, &idx->s_rnorm, &idx->s_nsum, &idx->dump_base})
             t += b->cap;
         *tables = (int64_t)t;
+    }
+    if (dumps) {      // the score dumps of the pipeline slots that have used one (released when the shape stops wanting them)
+        size_t t = 0;
+        for (const auto& sl : idx->s1) t += sl.dump.cap;
+        *dumps = (int64_t)t;
     }
     return MFAR_OK;
 }
@@ -405,6 +442,7 @@ extern "C" int mfar_set_timing(mfar_index* idx, int enable) {
     return MFAR_OK;
 }
 
+extern "C" const char* mfar_last_stage1_kernel(const mfar_index* idx) { return idx ? idx->last_s1_kernel : ""; }
 extern "C" int mfar_stage1_timing(mfar_index* idx, double* total_ms_out, int* n_launches_out) {
     if (!idx || !total_ms_out || !n_launches_out) return fail(MFAR_ERR_INVALID, "NULL argument");
     HIPCHK(hipSetDevice(idx->device));
@@ -547,8 +585,13 @@ static int check_search_common(const mfar_index* idx, const float* q, int Q, int
 // merge holds n_chunks * k keys of one field, which caps the chunks of a field.
 //   waves   waves per workgroup of the pass (4; 8 for the wide pass): wave blocks published per sampled tile
 //   wgs     workgroups per CU the grid is sized for
-static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool solo, int sample_tiles_max, bool sample_forced, int waves, int wgs, hipStream_t st) {
-    if (t.k == k && t.wgs == wgs) return MFAR_OK;
+//   skip    fields the table leaves out (no chunks: mfar_tables.h)
+static int build_table(mfar_index* idx, const S1Geom& g_in, S1Table& t, int k, bool solo, int sample_tiles_max, bool sample_forced, int waves, int wgs, hipStream_t st,
+                       u32 skip = 0) {
+    if (t.k == k && t.wgs == wgs && t.skip == skip) return MFAR_OK;
+    S1GeomHost g = g_in;
+    for (int f = 0; f < idx->F; ++f)
+        if ((skip >> f) & 1u) g.n_tiles[f] = 0;
     if (t.k >= 0) HIPCHK(hipDeviceSynchronize());   // a launch in flight may still read the old table
     const int F = idx->F;
     static const int sample_div = getenv("MFAR_SAMPLE_DIV") ? std::max(1, atoi(getenv("MFAR_SAMPLE_DIV"))) : 12;
@@ -574,6 +617,7 @@ static int build_table(mfar_index* idx, const S1Geom& g, S1Table& t, int k, bool
     HIPCHK(hipMemcpyAsync(t.d_samp_n.p, t.samp_n.data(), F * sizeof(int), hipMemcpyHostToDevice, st));
     t.k = k;
     t.wgs = wgs;
+    t.skip = skip;
     return MFAR_OK;
 }
 
@@ -591,89 +635,91 @@ enum { S1_F32 = 0, S1_BF16 = 1, S1_F16 = 2, S1_F16W = 3, S1_BF16S = 4, S1_BF16W 
 // slab (two bf16 query terms; 64 / 128 columns); S1_BF16C: 128 columns over the same slab with the docs converted to fp16 in
 // registers and one fp16 query term (half the MFMAs; the default wide pass of a bf16 index)
 static bool s1_is_wide(int kind) { return kind == S1_F16W || kind == S1_BF16W || kind == S1_BF16C; }
-static int launch_s1(int kind, bool sample, unsigned n_chunks, unsigned wave, hipStream_t st, const S1Params& p_in) {
+static int launch_s1(int kind, bool sample, unsigned n_chunks, unsigned wave, hipStream_t st, const S1Params& p_in, const char** name_out = nullptr) {
     S1Params p = p_in;
     p.n_launch = (int)n_chunks;
     // a repair pass walks its finely cut table with one wave of workgroups (mfar_stage1.h S1_CHUNK_LOOP); any other launch: one
     // workgroup per chunk
     const unsigned grid = p.only_failed ? std::min(n_chunks, wave) : n_chunks;
     const dim3 g(grid), b(S1_THREADS);
+    const char* name = "";
     if (kind == S1_F32) {
         // register-ring variant (docs straight into VGPRs) when the k-steps divide into 6 or 4 register slots; MFAR_S1_REGRING=0: LDS ring
         static const bool regring32 = !(getenv("MFAR_S1_REGRING") && atoi(getenv("MFAR_S1_REGRING")) == 0);
         static const int f32_ring = getenv("MFAR_F32_RING") ? atoi(getenv("MFAR_F32_RING")) : 0;       // diagnostic: 6 forces the 6-slot ring
         // (4 slots: 237 VGPRs and no spills; 6 slots: 256 and 9 spilled around the epilogue -- measured equal, 6.91 / 6.93 ms at 1 M x 8 x 768)
         if (regring32 && p.n_steps % 4 == 0 && !(f32_ring == 6 && p.n_steps % 6 == 0)) {
-            if (sample) mfar_stage1_f32r4_sample_kernel<<<g, b, S1FR4_LDS_BYTES, st>>>(p);
-            else mfar_stage1_f32r4_kernel<<<g, b, S1FR4_LDS_BYTES, st>>>(p);
+            if (sample) { name = "mfar_stage1_f32r4_sample_kernel"; mfar_stage1_f32r4_sample_kernel<<<g, b, S1FR4_LDS_BYTES, st>>>(p); }
+            else { name = "mfar_stage1_f32r4_kernel"; mfar_stage1_f32r4_kernel<<<g, b, S1FR4_LDS_BYTES, st>>>(p); }
         } else if (regring32 && p.n_steps % 6 == 0) {
-            if (sample) mfar_stage1_f32r_sample_kernel<<<g, b, S1FR_LDS_BYTES, st>>>(p);
-            else mfar_stage1_f32r_kernel<<<g, b, S1FR_LDS_BYTES, st>>>(p);
-        } else if (sample) mfar_stage1_sample_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
-        else mfar_stage1_kernel<<<g, b, S1_LDS_BYTES, st>>>(p);
+            if (sample) { name = "mfar_stage1_f32r_sample_kernel"; mfar_stage1_f32r_sample_kernel<<<g, b, S1FR_LDS_BYTES, st>>>(p); }
+            else { name = "mfar_stage1_f32r_kernel"; mfar_stage1_f32r_kernel<<<g, b, S1FR_LDS_BYTES, st>>>(p); }
+        } else if (sample) { name = "mfar_stage1_sample_kernel"; mfar_stage1_sample_kernel<<<g, b, S1_LDS_BYTES, st>>>(p); }
+        else { name = "mfar_stage1_kernel"; mfar_stage1_kernel<<<g, b, S1_LDS_BYTES, st>>>(p); }
     } else if (kind == S1_F16W) {
         // 4-slot ring whenever the k-steps divide by 4 (round 4, with the SGPR-addressed body: 14 spilled VGPRs instead of 27, 50.8 KB of LDS
         // instead of 58.8; same run, interleaved: 1 M x 8 52.0-52.3 k against 51.6-52.2 k q/s sustained, 129 375 x 22 68.3 k against 66.0 k)
         static const int w_ring = getenv("MFAR_WIDE_RING") ? atoi(getenv("MFAR_WIDE_RING")) : 0;   // diagnostic: 6 forces the 6-slot ring
         const bool r4 = p.n_steps % 4 == 0 && !(w_ring == 6 && p.n_steps % 6 == 0);
         if (p.arow) {              // ROW MODE twins
-            if (r4 && sample) mfar_stage1_f16w4_rm_sample_kernel<<<g, b, S1HW4_RM_LDS_BYTES, st>>>(p);
-            else if (r4) mfar_stage1_f16w4_rm_kernel<<<g, b, S1HW4_RM_LDS_BYTES, st>>>(p);
-            else if (sample) mfar_stage1_f16w_rm_sample_kernel<<<g, b, S1HW_RM_LDS_BYTES, st>>>(p);
-            else mfar_stage1_f16w_rm_kernel<<<g, b, S1HW_RM_LDS_BYTES, st>>>(p);
+            if (r4 && sample) { name = "mfar_stage1_f16w4_rm_sample_kernel"; mfar_stage1_f16w4_rm_sample_kernel<<<g, b, S1HW4_RM_LDS_BYTES, st>>>(p); }
+            else if (r4) { name = "mfar_stage1_f16w4_rm_kernel"; mfar_stage1_f16w4_rm_kernel<<<g, b, S1HW4_RM_LDS_BYTES, st>>>(p); }
+            else if (sample) { name = "mfar_stage1_f16w_rm_sample_kernel"; mfar_stage1_f16w_rm_sample_kernel<<<g, b, S1HW_RM_LDS_BYTES, st>>>(p); }
+            else { name = "mfar_stage1_f16w_rm_kernel"; mfar_stage1_f16w_rm_kernel<<<g, b, S1HW_RM_LDS_BYTES, st>>>(p); }
         } else if (r4) {
-            if (sample) mfar_stage1_f16w4_sample_kernel<<<g, b, S1HW4_LDS_BYTES, st>>>(p);
-            else mfar_stage1_f16w4_kernel<<<g, b, S1HW4_LDS_BYTES, st>>>(p);
+            if (sample) { name = "mfar_stage1_f16w4_sample_kernel"; mfar_stage1_f16w4_sample_kernel<<<g, b, S1HW4_LDS_BYTES, st>>>(p); }
+            else { name = "mfar_stage1_f16w4_kernel"; mfar_stage1_f16w4_kernel<<<g, b, S1HW4_LDS_BYTES, st>>>(p); }
         } else {
-            if (sample) mfar_stage1_f16w_sample_kernel<<<g, b, S1HW_LDS_BYTES, st>>>(p);
-            else mfar_stage1_f16w_kernel<<<g, b, S1HW_LDS_BYTES, st>>>(p);
+            if (sample) { name = "mfar_stage1_f16w_sample_kernel"; mfar_stage1_f16w_sample_kernel<<<g, b, S1HW_LDS_BYTES, st>>>(p); }
+            else { name = "mfar_stage1_f16w_kernel"; mfar_stage1_f16w_kernel<<<g, b, S1HW_LDS_BYTES, st>>>(p); }
         }
     } else if (kind == S1_BF16W) {
         // the 4-slot ring (50.5 KB of LDS) whenever the k-steps divide by 4: see mfar_stage1.h on LDS fragmentation
         static const int bw_ring = getenv("MFAR_BF16W_RING") ? atoi(getenv("MFAR_BF16W_RING")) : 0;   // diagnostic: 6 forces the 6-slot ring
         if (p.n_steps % 4 == 0 && !(bw_ring == 6 && p.n_steps % 6 == 0)) {
-            if (sample) mfar_stage1_bf16w4_sample_kernel<<<g, b, S1BW4_LDS_BYTES, st>>>(p);
-            else mfar_stage1_bf16w4_kernel<<<g, b, S1BW4_LDS_BYTES, st>>>(p);
+            if (sample) { name = "mfar_stage1_bf16w4_sample_kernel"; mfar_stage1_bf16w4_sample_kernel<<<g, b, S1BW4_LDS_BYTES, st>>>(p); }
+            else { name = "mfar_stage1_bf16w4_kernel"; mfar_stage1_bf16w4_kernel<<<g, b, S1BW4_LDS_BYTES, st>>>(p); }
         } else {
-            if (sample) mfar_stage1_bf16w_sample_kernel<<<g, b, S1BW_LDS_BYTES, st>>>(p);
-            else mfar_stage1_bf16w_kernel<<<g, b, S1BW_LDS_BYTES, st>>>(p);
+            if (sample) { name = "mfar_stage1_bf16w_sample_kernel"; mfar_stage1_bf16w_sample_kernel<<<g, b, S1BW_LDS_BYTES, st>>>(p); }
+            else { name = "mfar_stage1_bf16w_kernel"; mfar_stage1_bf16w_kernel<<<g, b, S1BW_LDS_BYTES, st>>>(p); }
         }
     } else if (kind == S1_BF16C) {
         if (p.n_steps % 6 == 0) {
-            if (sample) mfar_stage1_bf16c_sample_kernel<<<g, b, S1BC_LDS_BYTES, st>>>(p);
-            else mfar_stage1_bf16c_kernel<<<g, b, S1BC_LDS_BYTES, st>>>(p);
+            if (sample) { name = "mfar_stage1_bf16c_sample_kernel"; mfar_stage1_bf16c_sample_kernel<<<g, b, S1BC_LDS_BYTES, st>>>(p); }
+            else { name = "mfar_stage1_bf16c_kernel"; mfar_stage1_bf16c_kernel<<<g, b, S1BC_LDS_BYTES, st>>>(p); }
         } else {
-            if (sample) mfar_stage1_bf16c4_sample_kernel<<<g, b, S1BC4_LDS_BYTES, st>>>(p);
-            else mfar_stage1_bf16c4_kernel<<<g, b, S1BC4_LDS_BYTES, st>>>(p);
+            if (sample) { name = "mfar_stage1_bf16c4_sample_kernel"; mfar_stage1_bf16c4_sample_kernel<<<g, b, S1BC4_LDS_BYTES, st>>>(p); }
+            else { name = "mfar_stage1_bf16c4_kernel"; mfar_stage1_bf16c4_kernel<<<g, b, S1BC4_LDS_BYTES, st>>>(p); }
         }
     } else if (kind == S1_BF16S) {
         if (p.n_steps % 6 == 0) {
-            if (sample) mfar_stage1_bf16s_sample_kernel<<<g, b, S1HR_LDS_BYTES, st>>>(p);
-            else mfar_stage1_bf16s_kernel<<<g, b, S1HR_LDS_BYTES, st>>>(p);
+            if (sample) { name = "mfar_stage1_bf16s_sample_kernel"; mfar_stage1_bf16s_sample_kernel<<<g, b, S1HR_LDS_BYTES, st>>>(p); }
+            else { name = "mfar_stage1_bf16s_kernel"; mfar_stage1_bf16s_kernel<<<g, b, S1HR_LDS_BYTES, st>>>(p); }
         } else {
-            if (sample) mfar_stage1_bf16s4_sample_kernel<<<g, b, S1HR4_LDS_BYTES, st>>>(p);
-            else mfar_stage1_bf16s4_kernel<<<g, b, S1HR4_LDS_BYTES, st>>>(p);
+            if (sample) { name = "mfar_stage1_bf16s4_sample_kernel"; mfar_stage1_bf16s4_sample_kernel<<<g, b, S1HR4_LDS_BYTES, st>>>(p); }
+            else { name = "mfar_stage1_bf16s4_kernel"; mfar_stage1_bf16s4_kernel<<<g, b, S1HR4_LDS_BYTES, st>>>(p); }
         }
     } else {
         // register-ring variants (docs straight into VGPRs, 25 / 37 KB of LDS) when the k-steps divide into the 6 register slots
         static const bool regring = !(getenv("MFAR_S1_REGRING") && atoi(getenv("MFAR_S1_REGRING")) == 0);
         const int R = !regring ? 0 : (p.n_steps % 6 == 0 && (kind != S1_F16 || S1HR_R == 6) ? 6 : (p.n_steps % 4 == 0 ? 4 : 0));
         if (kind == S1_BF16) {
-            if (R == 6 && sample) mfar_stage1_bf16r_sample_kernel<<<g, b, S1BR_LDS_BYTES, st>>>(p);
-            else if (R == 6) mfar_stage1_bf16r_kernel<<<g, b, S1BR_LDS_BYTES, st>>>(p);
-            else if (R == 4 && sample) mfar_stage1_bf16r4_sample_kernel<<<g, b, S1BR4_LDS_BYTES, st>>>(p);
-            else if (R == 4) mfar_stage1_bf16r4_kernel<<<g, b, S1BR4_LDS_BYTES, st>>>(p);
-            else if (sample) mfar_stage1_bf16_sample_kernel<<<g, b, S1B_LDS_BYTES, st>>>(p);
-            else mfar_stage1_bf16_kernel<<<g, b, S1B_LDS_BYTES, st>>>(p);
+            if (R == 6 && sample) { name = "mfar_stage1_bf16r_sample_kernel"; mfar_stage1_bf16r_sample_kernel<<<g, b, S1BR_LDS_BYTES, st>>>(p); }
+            else if (R == 6) { name = "mfar_stage1_bf16r_kernel"; mfar_stage1_bf16r_kernel<<<g, b, S1BR_LDS_BYTES, st>>>(p); }
+            else if (R == 4 && sample) { name = "mfar_stage1_bf16r4_sample_kernel"; mfar_stage1_bf16r4_sample_kernel<<<g, b, S1BR4_LDS_BYTES, st>>>(p); }
+            else if (R == 4) { name = "mfar_stage1_bf16r4_kernel"; mfar_stage1_bf16r4_kernel<<<g, b, S1BR4_LDS_BYTES, st>>>(p); }
+            else if (sample) { name = "mfar_stage1_bf16_sample_kernel"; mfar_stage1_bf16_sample_kernel<<<g, b, S1B_LDS_BYTES, st>>>(p); }
+            else { name = "mfar_stage1_bf16_kernel"; mfar_stage1_bf16_kernel<<<g, b, S1B_LDS_BYTES, st>>>(p); }
         } else {
-            if (R == 6 && sample) mfar_stage1_f16r_sample_kernel<<<g, b, S1HR_LDS_BYTES, st>>>(p);
-            else if (R == 6) mfar_stage1_f16r_kernel<<<g, b, S1HR_LDS_BYTES, st>>>(p);
-            else if (R == 4 && sample) mfar_stage1_f16r4_sample_kernel<<<g, b, S1HR4_LDS_BYTES, st>>>(p);
-            else if (R == 4) mfar_stage1_f16r4_kernel<<<g, b, S1HR4_LDS_BYTES, st>>>(p);
-            else if (sample) mfar_stage1_f16_sample_kernel<<<g, b, S1H_LDS_BYTES, st>>>(p);
-            else mfar_stage1_f16_kernel<<<g, b, S1H_LDS_BYTES, st>>>(p);
+            if (R == 6 && sample) { name = "mfar_stage1_f16r_sample_kernel"; mfar_stage1_f16r_sample_kernel<<<g, b, S1HR_LDS_BYTES, st>>>(p); }
+            else if (R == 6) { name = "mfar_stage1_f16r_kernel"; mfar_stage1_f16r_kernel<<<g, b, S1HR_LDS_BYTES, st>>>(p); }
+            else if (R == 4 && sample) { name = "mfar_stage1_f16r4_sample_kernel"; mfar_stage1_f16r4_sample_kernel<<<g, b, S1HR4_LDS_BYTES, st>>>(p); }
+            else if (R == 4) { name = "mfar_stage1_f16r4_kernel"; mfar_stage1_f16r4_kernel<<<g, b, S1HR4_LDS_BYTES, st>>>(p); }
+            else if (sample) { name = "mfar_stage1_f16_sample_kernel"; mfar_stage1_f16_sample_kernel<<<g, b, S1H_LDS_BYTES, st>>>(p); }
+            else { name = "mfar_stage1_f16_kernel"; mfar_stage1_f16_kernel<<<g, b, S1H_LDS_BYTES, st>>>(p); }
         }
     }
+    if (name_out) *name_out = name;
     HIPCHK(hipGetLastError());
     return MFAR_OK;
 }
@@ -686,18 +732,22 @@ static int launch_s1(int kind, bool sample, unsigned n_chunks, unsigned wave, hi
 //   phases     S1_PREPARE (sample pass + thresholds) | S1_SCAN (the full pass) | S1_FINISH (list merge); the three may be
 //              issued by separate calls on different streams (ordered by the caller), all with the same arguments
 enum { S1_PREPARE = 1, S1_SCAN = 2, S1_FINISH = 4, S1_CERTIFY = 8, S1_ALL = 15 };   // S1_CERTIFY: stage1_block only
+//   skip       fields (of an all-fields pass) that are left out: no chunks, empty lists (AUTO-OFF)
+//   force_sample  a restricted pass (only_failed) that is certain to scan its fields: always with its own sample pass
 static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, int f0, int nf, int phases, int kind, const void* slab,
                        const void* qt, int qt_n, int k, float tau0, const float* tau_base, const int* only_failed, bool record,
-                       const S1Out& o, hipStream_t st) {
+                       const S1Out& o, hipStream_t st, u32 skip = 0, bool force_sample = false) {
     const int qw = s1_is_wide(kind) ? 128 : 64;   // query columns of the pass: stride of every per-query table below
     // a repair pass (only_failed) uses the finely cut table as well: the workgroups of the fields that did not fail exit at once,
     // and a failed field is then scanned by the whole GPU instead of by its share of one wave (one failed field of eight at 1 M
     // rows: 64 workgroups x 61 tiles at the MFMA-bound rate = several ms; cut into 512 chunks: under 1 ms)
     const bool repair = only_failed != nullptr;
     const bool solo = nf != idx->F || repair, wide = s1_is_wide(kind);
-    S1Table& tb = wide ? (solo ? geom.solo_w : geom.all_w) : (solo ? geom.solo : geom.all);
+    if (solo) skip = 0;
+    S1Table& tb = wide ? (solo ? geom.solo_w : (skip ? geom.all_w_skip : geom.all_w)) : (solo ? geom.solo : (skip ? geom.all_skip : geom.all));
     static const int sample_tiles_env = getenv("MFAR_SAMPLE_TILES") ? atoi(getenv("MFAR_SAMPLE_TILES")) : 0;
-    RETCHK(build_table(idx, geom, tb, k, solo, sample_tiles_env > 0 ? sample_tiles_env : (kind == S1_F32 ? 1 : 2), sample_tiles_env > 0, 4, idx->wgs_per_cu, st));
+    RETCHK(build_table(idx, geom, tb, k, solo, sample_tiles_env > 0 ? sample_tiles_env : (kind == S1_F32 ? 1 : 2), sample_tiles_env > 0, 4, idx->wgs_per_cu, st,
+                       skip));
     const int c_lo = tb.fchunk[f0], c_hi = tb.fchunk[f0 + nf];
     RETCHK(sl.lists.ensure((size_t)tb.n_chunks * qw * S1_CAP * sizeof(uint2)));
     RETCHK(sl.list_cnt.ensure((size_t)tb.n_chunks * qw * sizeof(int)));
@@ -752,6 +802,7 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
     m.qw = qw;
     m.cnt_out = nullptr;
     m.only_failed = only_failed;
+    m.skip_mask = skip;
     // one merge launch: `n_lists` = most lists a workgroup of it merges, grid = (query, list owner) pairs
     auto launch_merge = [&](const MergeParams& mp, int n_lists, int owners) -> int {
         const int n_keys = n_lists * k;
@@ -780,7 +831,7 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
     // ... or, with short chunks, whenever it yields thresholds for most of the rows: a tile without one costs 8 x a normal tile in
     // the full pass (90 % empty 129 k x 22: 2.4 tiles per chunk, scan 0.85 ms without the sample pass)
     const bool use_sample = (tb.total_tiles >= (long long)sample_min_tiles * tb.n_chunks || 2 * tb.thresholded_tiles >= tb.total_tiles) &&
-                            !(p.dbg & 2) && (!repair || idx->repair_sample);
+                            !(p.dbg & 2) && (!repair || idx->repair_sample || force_sample);
     const bool light_sample = use_sample && 2 * tb.samp_stride <= 4096;
     p.sample_tiles = light_sample ? tb.sample_tiles : 1;
     if (light_sample) {
@@ -841,7 +892,7 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
             p.unit_ctr = sl.unit_ctr.as<int>();
             p.unit_tiles = unit_tiles;
         }
-        RETCHK(launch_s1(kind, false, grid, (unsigned)(idx->wgs_per_cu * idx->n_cu), st, p));
+        RETCHK(launch_s1(kind, false, grid, (unsigned)(idx->wgs_per_cu * idx->n_cu), st, p, record ? &idx->last_s1_kernel : nullptr));
     }
     if (e1) HIPCHK(hipEventRecord(e1, st));
     if (phases & S1_FINISH) {
@@ -1249,6 +1300,74 @@ static bool dump_wanted(const mfar_index* idx, int k1) {
     return dump * 3.0 < gather;
 }
 
+// ------------------------------------------------------------------------------------------------ adaptive policy of the certified screen
+// The certificate is data dependent.  A list fails when more than k' - k of its field's unique rows sit within ~2 eps of the k-th best
+// score -- near-duplicate rows (product variants, templated texts, one text encoded in different batches: not bit-identical, so the
+// unique-row build cannot merge them) do exactly that, list after list.  Every failure costs the exact pass of that field ON TOP of the
+// screen, and a caller that only asked for a report pays a pipeline drain and a second launch.  Three decisions keep the worst case at the
+// price of the exact pass, all taken from the certificate flags of launches that have FINISHED (copied to pinned host memory behind the
+// certify kernel, picked up by a later call once their event has completed; nothing waits):
+//   * AUTO-OFF, per field: a field that failed in >= off_fails of its last 16 screened launches is switched off -- the screen's chunk
+//     table leaves it out (the other fields share the whole grid), and the exact fp32 pass writes its lists straight from the begin phase,
+//     on the scan stream.  Every probe_every-th launch screens it anyway (a PROBE: certificate evaluated, lists discarded); on_clean clean
+//     probes in a row switch it back on.  With every field off a launch is the exact pass and nothing else.
+//   * inline repair: when >= 4 of the last 16 launches had a failure among the fields that are ON, mfar_stage1_finish repairs on the
+//     device even when asked to report only (no drain, nothing done twice); back to reporting when at most one of the last 16 had.
+//   * ROW MODE (mfar_screen.h) is activated for eligible fields by the first failure.
+// Results do not depend on any of this: a list is either certified or written by the exact pass.
+__global__ void mfar_mask_flags_kernel(int* __restrict__ flags, u32 mask) {
+    if (threadIdx.x < MFAR_MAX_FIELDS) flags[threadIdx.x] = (int)((mask >> threadIdx.x) & 1u);
+}
+static void consume_feedback(mfar_index* idx) {
+    for (auto& sl : idx->s1) {
+        if (!sl.fb_pending || hipEventQuery(sl.fb_ev) != hipSuccess) continue;
+        sl.fb_pending = false;
+        mfar_index::AutoOff& a = idx->ao;
+        const int* h = sl.fb_host;
+        for (int f = 0; f < idx->F; ++f) {
+            const u32 bit = 1u << f;
+            if (sl.fb_screened & bit) {
+                a.hist[f] = (unsigned short)((a.hist[f] << 1) | (h[f] ? 1 : 0));
+                if (a.mode && !(idx->off_mask & bit) && __builtin_popcount(a.hist[f]) >= a.off_fails) {
+                    idx->off_mask |= bit;
+                    a.clean[f] = 0;
+                    a.n_off++;
+                }
+            }
+            if ((sl.fb_probed & bit) && (idx->off_mask & bit)) {
+                if (h[MFAR_MAX_FIELDS + 2 + f]) a.clean[f] = 0;
+                else if (++a.clean[f] >= a.on_clean) {
+                    idx->off_mask &= ~bit;
+                    a.hist[f] = 0;
+                    a.n_on++;
+                }
+            }
+        }
+        if (sl.fb_screened) {
+            const bool any = h[MFAR_MAX_FIELDS] != 0;
+            a.any_hist = (unsigned short)((a.any_hist << 1) | (any ? 1 : 0));
+            a.any_n = std::min(16, a.any_n + 1);
+            const int n_bad = __builtin_popcount(a.any_hist);
+            if (n_bad >= 4) idx->inline_repair = true;
+            else if (n_bad <= 1 && a.any_n >= 16) idx->inline_repair = false;
+            if (any && idx->row_mode_setting == 1) idx->row_mask = idx->row_eligible;
+        }
+    }
+}
+// behind the certify kernel of a batch: its flags -> pinned host memory, event behind the copy
+static int post_feedback(mfar_index* idx, mfar_index::S1Slot& sl, u32 screened, u32 probed, hipStream_t st) {
+    if (!sl.fb_host) {
+        HIPCHK(hipHostMalloc((void**)&sl.fb_host, SCREEN_FLAGS * sizeof(int), hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&sl.fb_ev, hipEventDisableTiming));
+    }
+    HIPCHK(hipMemcpyAsync(sl.fb_host, sl.fail.p, SCREEN_FLAGS * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(sl.fb_ev, st));
+    sl.fb_pending = true;
+    sl.fb_screened = screened;
+    sl.fb_probed = probed;
+    return MFAR_OK;
+}
+
 // One block of queries (rows q0 .. of q) through stage 1 for fields [f0, f0 + nf): 64 per block, or up to 128 when the
 // wide screened pass applies (more than 64 queries left, screen available).  all pointers are device pointers; fid/fsc are
 // [Q, nf, k].  *n_done (may be nullptr) = queries of this block.
@@ -1261,21 +1380,33 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     const int F = idx->F, kp = std::min(k + SCREEN_EXTRA, SCREEN_MAX_KP);
     const bool bf16 = idx->dtype == MFAR_DTYPE_BF16;
     if (phases & S1_PREPARE) {
+        consume_feedback(idx);
         bool screened = false;
         if (screen_wanted(idx, k)) RETCHK(ensure_screen(idx, st, &screened));
         sl.screened = screened;
         sl.qw = (screened && wide_ok(idx) && Q - q0 > 64) ? 128 : 64;
+        // AUTO-OFF (all-fields passes of an fp32 index): which fields the exact pass writes / the screen leaves out in this batch
+        sl.exact_mask = sl.skip_mask = 0;
+        if (screened && !bf16 && f0 == 0 && nf == idx->F && idx->ao.mode) {
+            sl.exact_mask = idx->off_mask & (F >= 32 ? 0xFFFFFFFFu : ((1u << F) - 1u));
+            const bool probe = sl.exact_mask != 0 && ++idx->ao.launches % idx->ao.probe_every == 0;
+            if (probe) idx->ao.n_probes++;
+            sl.skip_mask = probe ? 0u : sl.exact_mask;
+        }
         // the wide pass of an fp32 index over all fields may leave its scores behind for stage 2 (one block of queries: the dump holds
-        // the launch that wrote it last)
-        sl.dump_on = sl.qw == 128 && !bf16 && f0 == 0 && nf == idx->F && q0 == 0 && Q <= 128 && dump_wanted(idx, k);
+        // the launch that wrote it last; a launch that leaves fields out has no scores for them)
+        sl.dump_on = sl.qw == 128 && !bf16 && f0 == 0 && nf == idx->F && q0 == 0 && Q <= 128 && sl.skip_mask == 0 && dump_wanted(idx, k);
         sl.dump_ready = false;
         if (sl.dump_on && sl.dump.ensure(idx->screen_used / 2 / (size_t)idx->E * 512, true) != MFAR_OK) {
             (void)hipGetLastError();
             g_err.clear();
             sl.dump_on = false;
         }
+        if (!sl.dump_on && sl.dump.p && !dump_wanted(idx, k)) sl.dump.release();      // the shape no longer wants it (rows rewritten, mode changed)
     }
     const int qw = sl.qw;
+    const u32 all_mask = F >= 32 ? 0xFFFFFFFFu : ((1u << F) - 1u);
+    const bool none_screened = sl.screened && sl.skip_mask == all_mask;          // every field is switched off: the exact pass is the launch
     const int qt_n = std::min(qw, Q - q0);
     if (n_done) *n_done = qt_n;
     RETCHK(sl.qt.ensure((size_t)idx->n_steps * (bf16 ? 8192 : 4096)));
@@ -1301,8 +1432,8 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     RETCHK(sl.eps.ensure((size_t)F * 128 * 4));
     RETCHK(sl.base.ensure((size_t)F * 128 * 4));
     if (!sl.fail.p) {
-        RETCHK(sl.fail.ensure((size_t)(MFAR_MAX_FIELDS + 2) * 4));
-        HIPCHK(hipMemsetAsync(sl.fail.p, 0, (size_t)(MFAR_MAX_FIELDS + 2) * 4, st));
+        RETCHK(sl.fail.ensure((size_t)SCREEN_FLAGS * 4));
+        HIPCHK(hipMemsetAsync(sl.fail.p, 0, (size_t)SCREEN_FLAGS * 4, st));
     }
     RETCHK(sl.sids.ensure((size_t)128 * F * kp * 8));
     RETCHK(sl.ssc.ensure((size_t)128 * F * kp * 4));
@@ -1344,12 +1475,36 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     // lists of unique-row numbers (fp32 index: rows of the screen slab) / of the local rows of group representatives (bf16 index:
     // the pass scans the documents themselves)
     const S1Out so = {sl.sids.as<long long>(), sl.ssc.as<float>(), sl.scnt.as<int>(), 0, 0, 0};
+    // AUTO-OFF: the exact fp32 pass writes the final lists of the switched-off fields, here, on the scan stream, ahead of the screened scan
+    // of the others (it shares the slot's chunk-list scratch with it: same stream, so one after the other).  A restricted pass walks the
+    // finely cut table with the whole GPU, like a repair; with every field off it is the plain all-fields pass.
+    if (sl.exact_mask && (phases & S1_SCAN)) {
+        const bool all_off = sl.exact_mask == all_mask;
+        if (!all_off) {
+            RETCHK(sl.off_flags.ensure(MFAR_MAX_FIELDS * sizeof(int)));
+            mfar_mask_flags_kernel<<<dim3(1), dim3(64), 0, st>>>(sl.off_flags.as<int>(), sl.exact_mask);
+            HIPCHK(hipGetLastError());
+        }
+        for (int b0 = 0; b0 < qt_n; b0 += 64) {
+            const int total = 64 * (idx->E / 4);
+            mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, sl.qt.as<float>(), q0 + b0, Q, idx->E);
+            HIPCHK(hipGetLastError());
+            const S1Out o = {fid, fsc, nullptr, q0 + b0, sentinel, idx->row_offset};
+            RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, S1_ALL, S1_F32, idx->slab, sl.qt.p, std::min(64, qt_n - b0), k, tau0, nullptr,
+                               all_off ? nullptr : sl.off_flags.as<int>(), none_screened, o, st, 0, true));
+        }
+    }
+    if (none_screened) {
+        // nothing to screen, re-score or certify (the flags were cleared by the query kernel: the feedback of this batch reports no field)
+        if ((phases & S1_CERTIFY) && any_fail_out) HIPCHK(hipMemsetAsync(any_fail_out, 0, 4, st));
+        return MFAR_OK;
+    }
     if (bf16)
         RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, phases, bkind, idx->slab, sl.qt16.p, qt_n, kp, -INFINITY,
                            sl.base.as<float>(), nullptr, true, so, st));
     else
         RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, phases, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
-                           sl.base.as<float>(), nullptr, true, so, st));
+                           sl.base.as<float>(), nullptr, true, so, st, sl.skip_mask));
     if ((phases & S1_SCAN) && sl.dump_on) {
         sl.dump_ready = true;
         sl.dump_q = q + (size_t)q0 * idx->E;
@@ -1425,6 +1580,8 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     cp.q0 = q0;
     cp.sentinel = sentinel;
     cp.qw = qw;
+    cp.skip_mask = sl.skip_mask;
+    cp.quiet_mask = sl.exact_mask & ~sl.skip_mask;        // a probe launch: switched-off fields that were screened anyway
     static const bool cert_debug = getenv("MFAR_CERT_DEBUG") != nullptr;
     DevBuf dbg;
     if (cert_debug) {
@@ -1443,7 +1600,12 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
                         f0 + i % nf, h[8 * i + 1], h[8 * i + 2], h[8 * i + 3], h[8 * i + 4], h[8 * i + 5], h[8 * i + 6], h[8 * i + 7]);
         dbg.release();
     }
-    idx->screen_checked += (long long)qt_n * nf;
+    {
+        u32 fields = 0;
+        for (int f = f0; f < f0 + nf; ++f) fields |= 1u << f;
+        idx->screen_checked += (long long)qt_n * __builtin_popcount(fields & ~sl.exact_mask);
+        RETCHK(post_feedback(idx, sl, fields & ~sl.exact_mask, fields & cp.quiet_mask, st));
+    }
     if (any_fail_out) {   // report only: the caller repairs
         HIPCHK(hipMemcpyAsync(any_fail_out, fflags + MFAR_MAX_FIELDS, 4, hipMemcpyDeviceToDevice, st));
         return MFAR_OK;
@@ -1524,8 +1686,34 @@ extern "C" int mfar_stage1_finish(mfar_index* idx, const float* q, int Q, int k,
     if (Q == 0) return MFAR_OK;
     if (!field_ids || !field_scores) return fail(MFAR_ERR_INVALID, "output pointer is NULL");
     HIPCHK(hipSetDevice(idx->device));
-    return stage1_block(idx, slot, S1_CERTIFY | (merge_in_finish() ? S1_FINISH : 0), q, Q, 0, k, sentinel, 0, idx->F, (long long*)field_ids,
-                        field_scores, (int*)any_fail, (hipStream_t)stream);
+    // failures are frequent on this data (adaptive policy above): repair on the device, report a clean batch
+    const bool inline_rep = any_fail && idx->inline_repair;
+    RETCHK(stage1_block(idx, slot, S1_CERTIFY | (merge_in_finish() ? S1_FINISH : 0), q, Q, 0, k, sentinel, 0, idx->F, (long long*)field_ids,
+                        field_scores, inline_rep ? nullptr : (int*)any_fail, (hipStream_t)stream));
+    if (inline_rep) HIPCHK(hipMemsetAsync(any_fail, 0, 4, (hipStream_t)stream));
+    return MFAR_OK;
+}
+
+extern "C" int mfar_set_auto_off(mfar_index* idx, int mode, int off_fails, int probe_every) {
+    if (!idx || mode < 0 || mode > 1 || off_fails < 0 || off_fails > 16 || probe_every < 0)
+        return fail(MFAR_ERR_INVALID, "mode must be 0 or 1, off_fails in [0, 16] (0 = default), probe_every >= 0 (0 = default)");
+    idx->ao.mode = mode;
+    if (off_fails) idx->ao.off_fails = off_fails;
+    if (probe_every) idx->ao.probe_every = std::max(2, probe_every);
+    if (mode == 0) idx->off_mask = 0;
+    return MFAR_OK;
+}
+extern "C" int mfar_auto_off_info(mfar_index* idx, uint32_t* off_fields, int64_t* n_switched_off, int64_t* n_switched_on, int64_t* n_probes,
+                                  int* inline_repair) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    HIPCHK(hipSetDevice(idx->device));
+    consume_feedback(idx);
+    if (off_fields) *off_fields = idx->off_mask;
+    if (n_switched_off) *n_switched_off = idx->ao.n_off;
+    if (n_switched_on) *n_switched_on = idx->ao.n_on;
+    if (n_probes) *n_probes = idx->ao.n_probes;
+    if (inline_repair) *inline_repair = idx->inline_repair ? 1 : 0;
+    return MFAR_OK;
 }
 
 static bool two_level_ok(const mfar_index* idx, int C, int k2, int query_cond, int n_masks);

@@ -37,6 +37,7 @@
                                  // costs ~1 % and makes a failed certificate -- a 0.9 ms exact pass per field -- rarer)
 #define SCREEN_MAX_KP S1_MAX_DEPTH   // the stage-1 lists compact to k', which must leave room for one tile of appends
 #define SCREEN_SLACK 1.25f
+#define SCREEN_FLAGS (2 * MFAR_MAX_FIELDS + 2)   // ints of a batch's certificate flags (CertifyParams::fail)
 
 // struct ScreenField: mfar_device.h (shared with the gather-slab kernels of mfar_select.h)
 // struct ScreenQuery: mfar_device.h
@@ -311,6 +312,7 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
     const int r = blockIdx.x;
     // a new batch: clear the certificate flags of the fields and the "any" flag ([MFAR_MAX_FIELDS + 1] keeps accumulating statistics)
     if (r == 0 && (int)threadIdx.x <= MFAR_MAX_FIELDS) fail_flags[threadIdx.x] = 0;
+    if (r == 0 && (int)threadIdx.x < MFAR_MAX_FIELDS) fail_flags[MFAR_MAX_FIELDS + 2 + threadIdx.x] = 0;      // ... and the probe flags
     const bool live = q0 + r < Q;
     const float* row = q + (size_t)(q0 + (live ? r : 0)) * E;
     // ONE round of global loads (this kernel opens a batch on the critical path, usually while the previous batch's gathers
@@ -501,6 +503,7 @@ __global__ void __launch_bounds__(256) mfar_direct_queries_kernel(const float* _
     __shared__ float red_s[4];
     const int r = blockIdx.x;
     if (r == 0 && (int)threadIdx.x <= MFAR_MAX_FIELDS) fail_flags[threadIdx.x] = 0;
+    if (r == 0 && (int)threadIdx.x < MFAR_MAX_FIELDS) fail_flags[MFAR_MAX_FIELDS + 2 + threadIdx.x] = 0;      // ... and the probe flags
     const bool live = q0 + r < Q;
     const float* row = q + (size_t)(q0 + (live ? r : 0)) * E;
     ScreenField fld = {};
@@ -579,7 +582,11 @@ struct CertifyParams {
     int E;
     long long* out_ids;       // [Q, nf, k]
     float* out_scores;
-    int* fail;                // [F] field flags, [MFAR_MAX_FIELDS] = any, [MFAR_MAX_FIELDS + 1] = failed (query, field) pairs (statistics)
+    int* fail;                // [F] field flags, [MFAR_MAX_FIELDS] = any, [MFAR_MAX_FIELDS + 1] = failed (query, field) pairs (statistics),
+                              // [MFAR_MAX_FIELDS + 2 + f] = probe flags (quiet_mask): SCREEN_FLAGS ints in all
+    u32 skip_mask;            // bit f: field f was not screened in this batch (switched off: the exact pass wrote its lists) -- nothing to do
+    u32 quiet_mask;           // bit f: field f is switched off but was screened as a PROBE: evaluate the certificate, record a failure in
+                              // the probe flags only, write no lists (the exact pass's lists stand)
     // unique-row tables (per field f at offset f * ustride): ustart / ucount index `members` (local rows, grouped, ascending)
     const int* ustart;
     const int* ucount;
@@ -599,6 +606,8 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
     __shared__ float qm_s[4];
     __shared__ int total_s, overflow_s;
     const int ql = blockIdx.x / p.nf, fo = blockIdx.x - ql * p.nf, f = p.f0 + fo;
+    if ((p.skip_mask >> f) & 1u) return;                 // workgroup-uniform
+    const bool quiet = ((p.quiet_mask >> f) & 1u) != 0u;
     const size_t lb = ((size_t)ql * p.nf + fo) * p.kp;
     const int cnt = min(p.scnt[ql * p.nf + fo], p.kp);
     const float tau0 = p.sentinel ? 0.0f : -__builtin_inff();
@@ -699,12 +708,14 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
             d[6] = (float)m_out;
             d[7] = (float)overflow_s + 10.0f * (float)n + 10000.0f * (float)total;
         }
-        if (!ok) {
+        if (!ok && quiet) atomicOr(&p.fail[MFAR_MAX_FIELDS + 2 + f], 1);
+        else if (!ok) {
             atomicOr(&p.fail[f], 1);
             atomicOr(&p.fail[MFAR_MAX_FIELDS], 1);
             atomicAdd(&p.fail[MFAR_MAX_FIELDS + 1], 1);
         }
     }
+    if (quiet) return;
     const size_t ob = ((size_t)(p.q0 + ql) * p.nf + fo) * p.k;
     for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
         if (r < m_out) {

@@ -122,7 +122,24 @@ struct MergeParams {
     const int* gfield;    // [n_groups] or nullptr
     uint2* out_lists;     // [n_groups * qw][S1_CAP] or nullptr
     int* out_cnt;         // [n_groups * qw]
+    u32 skip_mask;        // bit f: field f has no chunks in this pass's table (switched off, mfar_hip.hip AUTO-OFF): its lists are
+                          // written EMPTY without touching the chunk lists (a field without chunks has no slots there to read)
 };
+// the outputs of an empty merged list (query ql, output field slot fo, field f)
+__device__ __forceinline__ void merge_write_empty(const MergeParams& p, int ql, int fo, int f) {
+    if (p.tau_out && threadIdx.x == 0) p.tau_out[f * p.qw + ql] = -__builtin_inff();
+    if (p.cnt_out && threadIdx.x == 0) p.cnt_out[ql * p.nf + fo] = 0;
+    if (p.out_lists) {
+        if (threadIdx.x == 0) p.out_cnt[(size_t)f * p.qw + ql] = 0;
+        return;
+    }
+    if (!p.out_ids) return;
+    const size_t ob = ((size_t)(p.q0 + ql) * p.nf + fo) * p.k;
+    for (int r = threadIdx.x; r < p.k; r += blockDim.x) {
+        p.out_ids[ob + r] = p.sentinel ? 0 : -1;
+        p.out_scores[ob + r] = p.sentinel ? 0.0f : -__builtin_inff();
+    }
+}
 // LDS carve-up shared by the selection kernels (everything in the dynamic region: 16-byte aligned base)
 //   keys[n_keys] u64 | sel[SEL_MAX_K] u64 | sorted[SEL_MAX_K] u64 | red[32] int | misc[4] int
 #define SEL_MAX_K 256   // internal depth limit (the screened stage-1 pass keeps k + 64 rows; the ABI limit is MFAR_MAX_K)
@@ -151,6 +168,10 @@ __global__ void __launch_bounds__(256) mfar_merge_lists_kernel(const MergeParams
     const SelLds L = sel_lds(smem, p.max_chunks * p.k);
     const int ql = blockIdx.x / p.nf, fo = blockIdx.x - ql * p.nf, f = p.f0 + fo;
     if (p.only_failed && !p.only_failed[p.gfield ? p.gfield[f] : f]) return;   // workgroup-uniform
+    if ((p.skip_mask >> (p.gfield ? p.gfield[f] : f)) & 1u) {                  // workgroup-uniform
+        merge_write_empty(p, ql, fo, f);
+        return;
+    }
     const int c_lo = p.fchunk[f], n_chunks = p.fchunk[f + 1] - c_lo;
     // chunk counts first (LDS), then the entries eight chunks at a time: the global loads of a round are independent,
     // so their latencies overlap instead of adding up
@@ -276,6 +297,10 @@ __device__ __forceinline__ void merge_lists_regs_body(const MergeParams& p) {
     __shared__ int red[36], pre[129], wtot[2];
     const int ql = blockIdx.x / p.nf, fo = blockIdx.x - ql * p.nf, f = p.f0 + fo;
     if (p.only_failed && !p.only_failed[p.gfield ? p.gfield[f] : f]) return;   // workgroup-uniform
+    if ((p.skip_mask >> (p.gfield ? p.gfield[f] : f)) & 1u) {                  // workgroup-uniform
+        merge_write_empty(p, ql, fo, f);
+        return;
+    }
     const int c_lo = p.fchunk[f], n_chunks = p.fchunk[f + 1] - c_lo;
 #ifdef MFAR_TRACE
     const unsigned long long tr_a = wall_clock64();

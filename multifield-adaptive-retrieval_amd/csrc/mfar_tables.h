@@ -44,6 +44,9 @@ struct S1TableHost {
 //   sample_div / append_target   sample-pass sizing (MFAR_SAMPLE_DIV = 12, MFAR_APPEND_TARGET = 130)
 //   group_chunks   > 0: merge in two levels whenever a field has more chunks than this, in groups of this many chunks -- two
 //                  launches of many small register-resident merges instead of one launch whose workgroups hold 48 keys per thread
+// A field with n_tiles == 0 is NOT SCANNED by this table: it gets no chunk (fchunk[f] == fchunk[f + 1]), no sample slot and no
+// share of the grid -- the fields the certified screen has switched off (mfar_hip.hip "AUTO-OFF"); the list merge writes their
+// lists empty (MergeParams::skip_mask).
 static inline void s1_build_table(const S1GeomHost& g, int F, int n_cu, int k, bool solo, int sample_tiles_max, bool sample_forced,
                                   int waves, int wgs, int sample_div, int append_target, S1TableHost& t, int group_chunks = 0) {
     const long long want = (long long)wgs * n_cu;
@@ -72,6 +75,11 @@ static inline void s1_build_table(const S1GeomHost& g, int F, int n_cu, int k, b
         std::vector<long long> want_cf(F);
         long long extra = 0, spare = 0;
         for (int f = 0; f < F; ++f) {
+            if (g.n_tiles[f] == 0) {               // not scanned
+                cf[f] = 0;
+                want_cf[f] = 0;
+                continue;
+            }
             const long long tiles = std::max(1, g.n_tiles[f]);
             const long long lim = std::min<long long>((long long)cap * l2cap, tiles);
             long long c = solo ? want : (want * g.n_tiles[f] + total_tiles / 2) / std::max(1LL, total_tiles);
@@ -85,7 +93,7 @@ static inline void s1_build_table(const S1GeomHost& g, int F, int n_cu, int k, b
         // the extra chunks come out of the fields that have more than their own floor; when nobody has (many equal fields),
         // only the fields without a possible threshold are cut (they must be) and the grid grows by those few workgroups
         for (int f = 0; f < F; ++f) {
-            const bool hard = 8LL * std::max(1, g.n_tiles[f]) < k;
+            const bool hard = g.n_tiles[f] > 0 && 8LL * g.n_tiles[f] < k;
             if (want_cf[f] > cf[f] && (hard || solo || spare >= extra)) {
                 cf[f] = (int)want_cf[f];
                 floor_cf[f] = cf[f];
@@ -104,6 +112,7 @@ static inline void s1_build_table(const S1GeomHost& g, int F, int n_cu, int k, b
                 int best = -1;
                 double key = 0.0;
                 for (int f = 0; f < F; ++f) {
+                    if (cf[f] == 0) continue;      // a field that is not scanned takes no part in the balance
                     const long long tiles = std::max(1, g.n_tiles[f]);
                     const long long lim = std::min<long long>((long long)cap * l2cap, tiles);
                     const double tpc = (double)tiles / cf[f];
@@ -138,6 +147,7 @@ static inline void s1_build_table(const S1GeomHost& g, int F, int n_cu, int k, b
     std::vector<int> ns(F, 1);
     t.sample_tiles = 1;
     for (int f = 0; f < F; ++f) {
+        if (cf[f] == 0) continue;
         const long long tpc = std::max(1LL, (long long)g.n_tiles[f] / cf[f]);      // tiles of the field's shortest chunk
         const long long tpc_hi = std::max(1LL, ((long long)g.n_tiles[f] + cf[f] - 1) / cf[f]);   // ... of its longest
         long long v = std::max(1LL, std::min<long long>(sample_tiles_max, tpc / sample_div));

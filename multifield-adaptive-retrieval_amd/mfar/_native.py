@@ -50,7 +50,7 @@ SIGNATURES = {
     "mfar_index_create": (_i, [_c.POINTER(_vp), _i, _i64, _i64, _i, _i, _i]),
     "mfar_index_destroy": (None, [_vp]),
     "mfar_index_info": (_i, [_vp, _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i64)]),
-    "mfar_index_resident_bytes": (_i, [_vp, _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64)]),
+    "mfar_index_resident_bytes": (_i, [_vp, _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64)]),
     "mfar_index_write_rows": (_i, [_vp, _i, _i64, _i64, _vp, _i, _vp]),
     "mfar_index_read_rows": (_i, [_vp, _i, _i64, _i64, _vp, _i, _vp]),
     "mfar_retrieve_fields": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
@@ -74,6 +74,7 @@ SIGNATURES = {
     "mfar_stream_wait_stage1_start": (_i, [_vp, _vp]),
     "mfar_set_timing": (_i, [_vp, _i]),
     "mfar_stage1_timing": (_i, [_vp, _c.POINTER(_c.c_double), _c.POINTER(_i)]),
+    "mfar_last_stage1_kernel": (_c.c_char_p, [_vp]),
     "mfar_set_wgs_per_cu": (_i, [_vp, _i]),
     "mfar_stage1_begin": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mfar_stage1_finish": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -87,6 +88,8 @@ SIGNATURES = {
     "mfar_set_stage2_mode": (_i, [_vp, _i]),
     "mfar_set_row_mode": (_i, [_vp, _i]),
     "mfar_row_mode_activate": (_i, [_vp]),
+    "mfar_set_auto_off": (_i, [_vp, _i, _i, _i]),
+    "mfar_auto_off_info": (_i, [_vp, _c.POINTER(_c.c_uint32), _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i)]),
     "mfar_row_mode_info": (_i, [_vp, _c.POINTER(_c.c_uint32), _c.POINTER(_c.c_uint32)]),
     "mfar_set_stage2_dump": (_i, [_vp, _i]),
     "mfar_stage2_dump_info": (_i, [_vp, _i, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
@@ -95,7 +98,7 @@ SIGNATURES = {
 
 # MFAR_ABI_VERSION of include/mfar_hip.h these signatures were written against.  A library that reports another value has
 # different argument lists behind the same names (pointers would land in the wrong slots): lib() refuses it.
-ABI_VERSION = 104
+ABI_VERSION = 105
 
 
 def lib():

@@ -133,13 +133,13 @@ class MultiFieldIndex:
 
     # ---- rows in / out (MemoryMapDict.__setitem__ / .file, data/util.py:37-41) ----
     def resident_bytes(self) -> dict:
-        """HBM the index keeps between searches: rows (slab), fp16 screen slab, 16-bit gather slab, unique-row tables; `ratio` = all of
-        it over the rows alone (include/mfar_hip.h)."""
-        v = [ctypes.c_int64() for _ in range(4)]
+        """HBM the index keeps between searches: rows (slab), fp16 screen slab, 16-bit gather slab, unique-row tables + row norms, the
+        score dumps of the pipeline slots that use one; `ratio` = all of it over the rows alone (include/mfar_hip.h)."""
+        v = [ctypes.c_int64() for _ in range(5)]
         _native.check(_native.lib().mfar_index_resident_bytes(self._h, *[ctypes.byref(x) for x in v]))
-        rows, screen, gather, tables = (x.value for x in v)
-        return dict(rows=rows, screen=screen, gather=gather, tables=tables, total=rows + screen + gather + tables,
-                    ratio=(rows + screen + gather + tables) / max(1, rows))
+        rows, screen, gather, tables, dumps = (x.value for x in v)
+        total = rows + screen + gather + tables + dumps
+        return dict(rows=rows, screen=screen, gather=gather, tables=tables, dumps=dumps, total=total, ratio=total / max(1, rows))
 
     def write_rows(self, field: int, local_row0: int, rows) -> None:
         a = _Arg(rows, np.float32, self.device)
@@ -371,6 +371,10 @@ class MultiFieldIndex:
         _native.check(_native.lib().mfar_stage1_timing(self._h, ctypes.byref(tot), ctypes.byref(n)))
         return tot.value, n.value
 
+    def last_stage1_kernel(self) -> str:
+        """Name of the scan kernel the most recent timed stage-1 launch ran (include/mfar_hip.h)."""
+        return _native.lib().mfar_last_stage1_kernel(self._h).decode()
+
     def set_wgs_per_cu(self, n: int):
         _native.check(_native.lib().mfar_set_wgs_per_cu(self._h, int(n)))
 
@@ -412,9 +416,20 @@ class MultiFieldIndex:
         _native.check(_native.lib().mfar_row_mode_info(self._h, ctypes.byref(e), ctypes.byref(a)))
         return dict(eligible=[f for f in range(self.n_fields) if (e.value >> f) & 1], active=[f for f in range(self.n_fields) if (a.value >> f) & 1])
 
+    def set_auto_off(self, mode: int = 1, off_fails: int = 0, probe_every: int = 0):
+        """AUTO-OFF of the certified screen (include/mfar_hip.h): a field whose certificates failed in `off_fails` of its last 16 screened
+        launches is scanned by the exact pass only, re-probed every `probe_every` launches (0 = keep the current value).  Same bits."""
+        _native.check(_native.lib().mfar_set_auto_off(self._h, int(mode), int(off_fails), int(probe_every)))
+
+    def auto_off_info(self) -> dict:
+        m, a, b, c, r = ctypes.c_uint32(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        _native.check(_native.lib().mfar_auto_off_info(self._h, ctypes.byref(m), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(r)))
+        return dict(off=[f for f in range(self.n_fields) if (m.value >> f) & 1], n_switched_off=a.value, n_switched_on=b.value,
+                    n_probes=c.value, inline_repair=bool(r.value))
+
     def set_stage2_dump(self, mode: int = 1):
         """Score dump of the wide screened pass as the approximate level of stage 2 (include/mfar_hip.h): 0 never, 1 when it moves
-        fewer bytes than the row gathers, 2 whenever possible.  Outputs are bit-identical in every mode."""
+        less than a third of the row gathers' bytes, 2 whenever possible.  Outputs are bit-identical in every mode."""
         _native.check(_native.lib().mfar_set_stage2_dump(self._h, int(mode)))
 
     def stage2_dump_info(self, k1: int = 100) -> dict:

@@ -26,7 +26,9 @@ To keep the pipeline full, ask for results `ps.lag` (= depth * coalesce - 1) sub
 
 A screened launch whose certificate failed (include/mfar_hip.h, `any_fail`) is detected in `result()` and redone there
 through the non-split entry points (which repair the failed fields with the exact pass), so what `result()` returns is
-always the exact answer.
+always the exact answer.  Data on which certificates keep failing does not keep paying for that: the library switches to
+repairing on the device, and switches fields whose lists fail launch after launch off altogether (exact pass only, re-probed
+now and then) -- include/mfar_hip.h "AUTO-OFF and inline repair".
 """
 import torch
 
@@ -38,9 +40,13 @@ _STREAMS = {}
 
 
 def _shared_stream(torch, dev, role: str, priority: int):
-    key = (dev.index, role, priority)
+    """ONE stream per (device, role, priority) and process.  Searchers that are alive at the same time share them: their launches are
+    ordered on the scan stream and simply take turns (two searchers do not overlap each other; each still overlaps its own scans and
+    tails).  The device is normalised to an explicit index, so 'cuda' and 'cuda:0' name the same set."""
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (int(index), role, priority)
     if key not in _STREAMS:
-        _STREAMS[key] = torch.cuda.Stream(device=dev, priority=priority)
+        _STREAMS[key] = torch.cuda.Stream(device=torch.device("cuda", int(index)), priority=priority)
     return _STREAMS[key]
 
 
@@ -108,8 +114,6 @@ class PipelinedSearcher:
         self.Qmax = self.Qb * self.coalesce                   # queries per launch
         F, E = index.n_fields, index.dim
         self.n_redone = 0             # launches whose screen certificate failed and that were redone exactly
-        self._recent = []             # 1 = redone, over the last 16 checked launches
-        self.inline_repair = False    # many failures: let finish() repair on the device instead of reporting (see _check)
         self.slots = []
         for _ in range(self.depth):
             lead = (self.M,) if self.M else ()
@@ -257,11 +261,11 @@ class PipelinedSearcher:
             s["stage1"].record(self.main)
         with torch.cuda.stream(side):
             side.wait_event(s["stage1"])
-            if self.inline_repair:                    # failed fields are redone by the exact pass inside finish()
-                self.ix.stage1_finish(qk, slot, fid, fsc, self.k1, self.sentinel, any_fail=None)
-                s["fail"].zero_()
-            else:
-                self.ix.stage1_finish(qk, slot, fid, fsc, self.k1, self.sentinel, any_fail=s["fail"])
+            # finish REPORTS a failed certificate (the flag is read in _check, which then redoes the launch).  When failures are frequent on
+            # this data the library repairs on the device instead and reports a clean launch; fields that keep failing are switched off
+            # altogether (include/mfar_hip.h "AUTO-OFF and inline repair"): both decisions are taken inside the library from the flags of
+            # finished launches and both are reversible, so nothing here latches.
+            self.ix.stage1_finish(qk, slot, fid, fsc, self.k1, self.sentinel, any_fail=s["fail"])
             self._tail(s, slot)
             s["fail_host"].copy_(s["fail"], non_blocking=True)
             s["done"].record(side)
@@ -277,17 +281,12 @@ class PipelinedSearcher:
         s["done"].synchronize()
         s["checked"] = True
         failed = int(s["fail_host"][0]) != 0
-        # A redo costs a pipeline drain plus a second pass.  When certificates fail often on this data (a quarter of the last
-        # 16 launches), stop reporting and let finish() repair on the device: the exact kernel then stalls the side stream
-        # until the next scan is through, but nothing is done twice.  (Same decision on every rank: the flags are all-reduced.)
-        self._recent = (self._recent + [1 if failed else 0])[-16:]
-        if sum(self._recent) >= 4:
-            self.inline_repair = True
         if not failed:
             return
+        # A redo costs a pipeline drain plus a second pass: rare by construction (see _launch).
         self.n_redone += 1
         # a certificate failed on this data: fields with heavy-tailed row norms switch to per-row bounds from the next launch on
-        # (include/mfar_hip.h "ROW MODE"; a no-op when no field is eligible.  Same decision on every rank: the flags are all-reduced.)
+        # (include/mfar_hip.h "ROW MODE"; a no-op when no field is eligible; the library does the same from its own feedback)
         self.ix.activate_row_mode()
         torch.cuda.synchronize(self.dev)              # the redo uses the index's slot-0 scratch: nothing else may be in flight
         # the non-split entry points repair a failed certificate themselves: screened pass again, then the exact fp32 pass
@@ -302,6 +301,20 @@ class PipelinedSearcher:
             self.ix.retrieve_lists(qk, s["lists"], self.k1, self.sentinel)
         self._tail(s, slot)
         torch.cuda.current_stream(self.dev).synchronize()
+
+    def lists(self, ticket: int):
+        """The stage-1 lists of a batch whose `result()` has been taken and is still valid: (field_ids [Q, F, k1] int64, field_scores
+        [Q, F, k1] f32), views into the launch's slot.  Single-shard searchers only (a sharded launch keeps its lists in the exchange payload)."""
+        if self.sharded:
+            raise ValueError("lists() is for single-shard searchers")
+        w = self._where.get(ticket)
+        if w is None:
+            raise ValueError("ticket is no longer (or not yet) in flight")
+        launch, off, Q = w
+        s = self.slots[launch % self.depth]
+        if s["launch"] != launch or not s["checked"]:
+            raise ValueError("take result(ticket) first")
+        return s["fid"][off:off + Q], s["fsc"][off:off + Q]
 
     def result(self, ticket: int):
         w = self._where.get(ticket)

@@ -20,6 +20,13 @@ is encoded to bit-identical rows):
   * "heavy"   distinct rows whose spread around the mean is Pareto(3)-scaled: a heavy tail of row norms (what a per-field
               error bound of the certified screen has to survive).
 
+`corpus="clustered"` (or an explicit `field_kinds=[...]` with "clustered" entries) is the HOSTILE case of the certified screen:
+  * "clustered"  D rows in D / 256 clusters (~235 non-empty members each): a row is its cluster's centre (a distinct text vector, as
+              above) plus noise 1e-4 of the field's spread -- product variants, templated texts, one text encoded in different batches.
+              The rows are NOT bit-identical (the unique-row build keeps every one), but at fp16 resolution the members of a cluster
+              score alike: the best cluster fills the k' = 192 approximate candidates of nearly every list, the k-th .. k'-th gap is far inside the error
+              bound and the certificate fails list after list (include/mfar_hip.h "AUTO-OFF and inline repair").
+
 Rows are generated on the GPU in aligned chunks whose random stream depends only on (seed, field, chunk id), so any
 row-sharding of the corpus produces bit-identical vectors.
 """
@@ -32,7 +39,7 @@ CHUNK = 32768  # rows per generation chunk (aligned to global row numbers)
 class SyntheticCorpus:
     def __init__(self, n_docs: int, n_fields: int, dim: int, n_queries: int = 4096, seed: int = 0xDEADBEEF,
                  device: str = "cuda:0", empty_frac: float = 0.08, sigma: float = 0.04, pull: float = 0.8,
-                 structured: bool = False):
+                 structured: bool = False, field_kinds=None):
         self.D, self.F, self.E, self.NQ = int(n_docs), int(n_fields), int(dim), int(n_queries)
         self.seed, self.device = int(seed), torch.device(device)
         self.empty_frac, self.sigma, self.pull = float(empty_frac), float(sigma), float(pull)
@@ -45,7 +52,12 @@ class SyntheticCorpus:
         self.empty_vec = (self.mu.cpu() * 0.6 + 0.02 * torch.randn(self.F, self.E, generator=g)).to(self.device)
         kinds = ["plain", "zipf", "plain", "lowcard", "plain", "heavy", "plain", "plain"]
         self.field_kinds = [kinds[f % 8] if structured else "plain" for f in range(self.F)]
-        if structured:      # text tables: the vector of text t is mu + sigma * (A[t % 4096] + B[t // 4096]) / sqrt(2)
+        if field_kinds is not None:      # explicit kinds, one per field ("plain" | "zipf" | "lowcard" | "heavy" | "clustered")
+            if len(field_kinds) != self.F or any(k not in ("plain", "zipf", "lowcard", "heavy", "clustered") for k in field_kinds):
+                raise ValueError("field_kinds: one of plain / zipf / lowcard / heavy / clustered per field")
+            self.field_kinds = list(field_kinds)
+        if any(k in ("zipf", "lowcard", "clustered") for k in self.field_kinds):
+            # text tables: the vector of text t is mu + sigma * (A[t % 4096] + B[t // 4096]) / sqrt(2)
             g2 = torch.Generator(device="cpu")
             g2.manual_seed(self.seed ^ 0x5EED)
             self._tab_a = torch.randn(4096, self.E, generator=g2).to(self.device)
@@ -97,6 +109,11 @@ class SyntheticCorpus:
             u = torch.rand(CHUNK, 1, generator=g, device=self.device)
             scale = (1.0 - u).clamp_min(1e-6).pow(-1.0 / 3.0).clamp_max(30.0)            # Pareto(3) >= 1
             x = torch.randn(CHUNK, self.E, generator=g, device=self.device) * (self.sigma * scale) + self.mu
+        elif kind == "clustered":
+            n_cl = max(4, self.D // 256)
+            t = torch.randint(0, n_cl, (CHUNK,), generator=g, device=self.device) + 104729 * (f + 1)      # other fields, other clusters
+            x = (self._tab_a[t % 4096] + self._tab_b[(t // 4096) % 4096]) * (self.sigma * 0.70710678) + self.mu
+            x = x + torch.randn(CHUNK, self.E, generator=g, device=self.device) * (self.sigma * 1e-4)
         else:
             n_texts = 10 if kind == "lowcard" else max(16, self.D // 4)
             u = torch.rand(CHUNK, generator=g, device=self.device)

@@ -28,13 +28,19 @@ static void check_table(const S1GeomHost& g, int F, int n_cu, int k, bool solo, 
     const int l2cap = std::max(1, std::min(cap, 8192 / k));
     REQUIRE(t.k == k && t.wgs == wgs);
     REQUIRE((int)t.fchunk.size() == F + 1 && (int)t.samp_n.size() == F && t.fchunk[0] == 0);
-    REQUIRE(t.n_chunks == (int)t.chunks.size() && t.fchunk[F] == t.n_chunks && t.n_chunks >= F);
+    int n_scanned = 0;
+    for (int f = 0; f < F; ++f) n_scanned += g.n_tiles[f] > 0;
+    REQUIRE(t.n_chunks == (int)t.chunks.size() && t.fchunk[F] == t.n_chunks && t.n_chunks >= n_scanned);
     long long tiles = 0;
     int max_cf = 0, stride = 0;
     bool need_two = false;
     for (int f = 0; f < F; ++f) {
         const int c0 = t.fchunk[f], c1 = t.fchunk[f + 1];
-        REQUIRE(c1 > c0);                                              // every field is scanned by at least one workgroup
+        if (g.n_tiles[f] == 0) {                                       // a field the table does not scan (switched off): nothing at all
+            REQUIRE(c1 == c0 && t.samp_n[f] == 0);
+            continue;
+        }
+        REQUIRE(c1 > c0);                                              // every scanned field is scanned by at least one workgroup
         REQUIRE(c1 - c0 <= std::max(1, g.n_tiles[f]));                 // no empty chunks
         REQUIRE((long long)(c1 - c0) <= (long long)cap * l2cap);        // what a (two-level) merge can hold
         max_cf = std::max(max_cf, c1 - c0);
@@ -62,6 +68,10 @@ static void check_table(const S1GeomHost& g, int F, int n_cu, int k, bool solo, 
         REQUIRE((int)t.gfield.size() == t.n_groups && (int)t.gchunk.size() == t.n_groups + 1 && t.gchunk[t.n_groups] == t.n_chunks);
         int mg = 0, mgc = 0;
         for (int f = 0; f < F; ++f) {
+            if (g.n_tiles[f] == 0) {
+                REQUIRE(t.fgroup[f + 1] == t.fgroup[f]);
+                continue;
+            }
             REQUIRE(t.fgroup[f + 1] > t.fgroup[f] && t.gchunk[t.fgroup[f]] == t.fchunk[f]);
             mg = std::max(mg, t.fgroup[f + 1] - t.fgroup[f]);
             for (int gi = t.fgroup[f]; gi < t.fgroup[f + 1]; ++gi) {
@@ -75,7 +85,7 @@ static void check_table(const S1GeomHost& g, int F, int n_cu, int k, bool solo, 
     if (!solo) {
         const long long want = (long long)wgs * n_cu;
         long long floors = 0;
-        for (int f = 0; f < F; ++f) floors += std::min<long long>(std::max(1, g.n_tiles[f]), (3LL * k + 7) / 8 + 4);
+        for (int f = 0; f < F; ++f) floors += g.n_tiles[f] == 0 ? 0 : std::min<long long>(g.n_tiles[f], (3LL * k + 7) / 8 + 4);
         REQUIRE(t.n_chunks <= want + floors + F);                      // the grid stays about one wave of workgroups
     }
 }
@@ -143,7 +153,13 @@ int main(int argc, char** argv) {
         }
         const int k = (int)U(1, 192), n_cu = (int)U(1, 304), wgs = (int)U(1, 8), waves = U(0, 1) ? 4 : 8;
         const bool solo = U(0, 3) == 0, forced = U(0, 7) == 0;
-        check_table(geom(rows, 32 * (int)U(1, 64)), F, n_cu, k, solo, forced ? (int)U(1, 9) : (int)U(1, 2), forced, waves, wgs, (int)U(1, 24), (int)U(1, 400));
+        S1GeomHost gg = geom(rows, 32 * (int)U(1, 64));
+        if (U(0, 3) == 0) {                                          // some fields switched off (not scanned), at least one left
+            const int keep = (int)U(0, F - 1);
+            for (int f = 0; f < F; ++f)
+                if (f != keep && U(0, 1)) gg.n_tiles[f] = 0;
+        }
+        check_table(gg, F, n_cu, k, solo, forced ? (int)U(1, 9) : (int)U(1, 2), forced, waves, wgs, (int)U(1, 24), (int)U(1, 400));
         check_layouts((int)U(0, 128), F, (int)U(1, 128), (int)U(1, 128));
     }
     std::printf("OK %lld tables and layouts checked\n", n_checked);

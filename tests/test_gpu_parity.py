@@ -101,6 +101,40 @@ def _oracle_check_on_subset(ix, q, W, mask, r, queries, n_random=3000, seed=0):
         assert np.array_equal(o["scores"][j].view(np.uint32), sc[qi].view(np.uint32)), ("final score bits", qi)
 
 
+def _timed_path_check(idxmod, ix, corpus, W, mask, probe, first_batch=0, oracle_chain=None):
+    """The path bench.py TIMES, at whatever shape `ix` has: 128 queries submitted as two 64-query batches to a default
+    PipelinedSearcher (three launches in flight, two batches coalesced into ONE launch of the wide 128-column scan, the automatic
+    score-dump policy -- nothing forced), against (1) the synchronous 64-query search of each half (the 64-column kernels): ids, score
+    bits, n_valid and the per-field lists must be equal, and (2) the C oracle, bit for bit, for the `probe` queries of the first half
+    (stage-1 lists proven complete by the exhaustive torch scan, then O.c_two_stage on the union rows).  Returns the searcher."""
+    import contextlib
+    import torch
+    from mfar.data.pipeline import PipelinedSearcher
+    Q = 64
+    ps = PipelinedSearcher(ix, W, mask, max_batch=Q)
+    assert ps.depth == 3 and ps.coalesce == 2 and ps.Qmax == 128, (ps.depth, ps.coalesce, ps.Qmax)      # the bench's configuration
+    halves = [corpus.queries((first_batch + j) * Q, Q) for j in range(2)]
+    tickets = [ps.submit(h) for h in halves]
+    got = []
+    for t in tickets:
+        r = {k: v.clone() for k, v in ps.result(t).items()}
+        fid, fsc = ps.lists(t)
+        r.update(field_ids=fid.clone(), field_scores=fsc.clone())
+        got.append(r)
+    torch.cuda.synchronize()
+    assert ps.n_redone == 0
+    for h, g in zip(halves, got):
+        ref = ix.search(h, W, mask, return_fields=True)
+        torch.cuda.synchronize()
+        for key in ("ids", "scores", "n_valid", "field_ids", "field_scores"):
+            assert torch.equal(g[key], ref[key]), ("pipelined 128-column launch vs synchronous 64-query search", key)
+    fid, fsc = got[0]["field_ids"].cpu().numpy(), got[0]["field_scores"].cpu().numpy()
+    _exhaustive_stage1_check(ix, halves[0], fid, fsc, probe)
+    with (oracle_chain if oracle_chain is not None else contextlib.nullcontext()):
+        _oracle_check_on_subset(ix, halves[0], W, mask, got[0], probe)
+    return ps
+
+
 def test_rows_roundtrip_tiled_layout(idxmod):
     rng = np.random.default_rng(0)
     for D, E in [(1, 32), (63, 32), (64, 64), (65, 96), (257, 768), (1000, 32)]:
@@ -392,7 +426,7 @@ def test_full_size_properties(idxmod):
         pytest.skip("needs ~80 GB of free HBM")
     from mfar import synth
     D, F, E, Q = 1_000_000, 8, 768, 64
-    corpus = synth.SyntheticCorpus(D, F, E, n_queries=Q, seed=0xdeadbeef, device="cuda:0")
+    corpus = synth.SyntheticCorpus(D, F, E, n_queries=2 * Q, seed=0xdeadbeef, device="cuda:0")
     ix = corpus.build_index(idxmod)
     q, W = corpus.queries(0, Q), corpus.W
     r1 = ix.search(q, W, None, return_fields=True)
@@ -432,6 +466,10 @@ def test_full_size_properties(idxmod):
     fid, fsc = r1["field_ids"].cpu().numpy(), r1["field_scores"].cpu().numpy()
     _exhaustive_stage1_check(ix, q, fid, fsc, queries)
     _oracle_check_on_subset(ix, q, W, None, r1, queries)
+    # ... and the path bench.py times at this shape: the wide 128-column scan (mfar_stage1_f16w4_kernel) through the pipeline
+    ps = _timed_path_check(idxmod, ix, corpus, W, None, queries)
+    assert not ix.stage2_dump_info()["wanted"]                 # (1 M x 8: the automatic policy keeps stage 2 on the gather slab)
+    del ps
     ix.close()
 
 
@@ -478,7 +516,7 @@ def test_baseline_config_shapes(idxmod, name, D, F, n_shards):
     need = D * F * E * 4 * (2 if n_shards > 1 else 1) + (8 << 30)
     if torch.cuda.mem_get_info(0)[0] < need:
         pytest.skip("not enough free HBM")
-    corpus = synth.SyntheticCorpus(D, F, E, n_queries=Q, seed=0xdeadbeef, device="cuda:0")
+    corpus = synth.SyntheticCorpus(D, F, E, n_queries=2 * Q, seed=0xdeadbeef, device="cuda:0")
     q, W = corpus.queries(0, Q), corpus.W
     mask = torch.ones(F, device="cuda:0")
     mask[F // 2] = 0
@@ -496,6 +534,13 @@ def test_baseline_config_shapes(idxmod, name, D, F, n_shards):
     queries = [0, 9, 18, 27, 36, 45, 54, 63]
     _exhaustive_stage1_check(ix, q, fid, fsc, queries)
     _oracle_check_on_subset(ix, q, W, mask, r, queries)
+    # the path bench.py times at this shape (its `baseline_configs` legs): default pipeline, wide scan, automatic dump policy
+    d0 = ix.stage2_dump_info()
+    ps = _timed_path_check(idxmod, ix, corpus, W, mask, queries)
+    d1 = ix.stage2_dump_info()
+    if name == "stark-prime":      # 22 fields x 129 375 rows: stage 2's approximate level reads the scan's score dump (mfar_s2_lookup_kernel)
+        assert d1["wanted"] and d1["n_launches"] > d0["n_launches"], (d0, d1)
+    del ps
     if n_shards > 1:
         ix.close()
         bounds = [D * g // n_shards for g in range(n_shards + 1)]
@@ -504,6 +549,21 @@ def test_baseline_config_shapes(idxmod, name, D, F, n_shards):
         rm = idxmod.merge_payloads(payloads, n_shards, q, W, mask, n_fields=F)
         torch.cuda.synchronize()
         assert np.array_equal(rm["ids"].cpu().numpy(), ids) and np.array_equal(rm["scores"].cpu().numpy().view(np.uint32), sc.view(np.uint32))
+        # the exchange path of the row-sharded run, as PipelinedSearcher issues it per launch: 128 queries through every shard's WIDE scan
+        # (mfar_retrieve_lists), all lists "gathered", every shard scores the candidates it owns (mfar_search_owned), top-k payloads merged
+        q2 = corpus.queries(0, 2 * Q)
+        nl, nt = shards[0].lists_bytes(2 * Q), shards[0].topk_bytes(2 * Q)
+        lists_all = torch.empty(n_shards * nl, dtype=torch.uint8, device="cuda:0")
+        for g, sh in enumerate(shards):
+            assert sh.max_split_batch(100) == 128
+            sh.retrieve_lists(q2, lists_all[g * nl:(g + 1) * nl], 100, True)
+        topk_all = torch.empty(n_shards * nt, dtype=torch.uint8, device="cuda:0")
+        for g, sh in enumerate(shards):
+            sh.search_owned(lists_all, n_shards, q2, W, topk_all[g * nt:(g + 1) * nt], mask)
+        rx = idxmod.merge_topk(topk_all, n_shards, 2 * Q)
+        torch.cuda.synchronize()
+        assert np.array_equal(rx["ids"][:Q].cpu().numpy(), ids), "lists-first exchange over 8 row shards (first half == the unsharded search)"
+        assert np.array_equal(rx["scores"][:Q].cpu().numpy().view(np.uint32), sc.view(np.uint32))
         for s in shards:
             s.close()
     else:
@@ -618,6 +678,9 @@ def test_bf16_stress_shape_per_gpu(idxmod):
     for key in ("ids", "scores", "field_ids", "field_scores"):
         assert torch.equal(rw[key][:Q], r1[key]), key
     assert ix.screen_stats()["n_failed"] == 0
+    # the path bench.py times at this shape (mfar_stage1_bf16c_kernel through the default pipeline): halves == the 64-column search, oracle bits
+    ps = _timed_path_check(idxmod, ix, corpus, W, None, probe, oracle_chain=O.chain("natural"))
+    del ps
     # plain pass vs certified pass: the plain MFMA pass's stage-1 scores agree with the chain to 1e-4, so a list may swap a member
     # at a near-tied cut-off and with it one final candidate; every document BOTH runs return carries the same exact score bits
     ix.set_screen(0)
@@ -916,8 +979,10 @@ def test_pipelined_searcher_with_screen_and_redo(idxmod):
                 got.append({k: v.clone() for k, v in ps.result(tickets[i - 1]).items()})
         got.append({k: v.clone() for k, v in ps.result(tickets[-1]).items()})
         torch.cuda.synchronize()
-        # every batch fails with the impossible proof; after 4 redone batches the searcher switches to on-device repair
-        assert (4 <= ps.n_redone <= len(qs) and ps.inline_repair) if expect_redo else (ps.n_redone == 0 and not ps.inline_repair), ps.n_redone
+        # every batch fails with the impossible proof: the first launches are redone by result(); once the library has seen four failed
+        # launches (the redone ones count) it repairs on the device and reports clean launches (include/mfar_hip.h "inline repair")
+        inline = ix.auto_off_info()["inline_repair"]
+        assert (1 <= ps.n_redone <= len(qs) and inline) if expect_redo else (ps.n_redone == 0 and not inline), (ps.n_redone, inline)
         assert ix.screen_setting == (2, pytest.approx(eps_mult))
         for w, g in zip(want, got):
             assert np.array_equal(g["ids"].cpu().numpy(), w["ids"])
@@ -1400,4 +1465,80 @@ def test_row_mode_certifies_heavy_tailed_fields(idxmod):
     ix.set_row_mode(2)
     r64 = ix.search(q[:64], W, None, return_fields=True)      # the 64-column pass: field-wide bound, same bits (repairs allowed)
     assert np.array_equal(r64["field_ids"], o["field_ids"][:64]) and np.array_equal(r64["scores"].view(np.uint32), o["scores"][:64].view(np.uint32))
+    ix.close()
+
+
+def test_auto_off_switches_clustered_fields_to_the_exact_pass(idxmod):
+    """The certified screen's worst case: two of eight fields are CLUSTERED -- ~235 near-duplicate, non-identical rows per
+    cluster, so the k' = 192 approximate candidates of nearly every list tie inside the error bound and the certificate fails launch after
+    launch.  The library reads the flags of finished launches and (1) repairs on the device instead of reporting, (2) switches exactly those
+    two fields off: their lists then come from the exact fp32 pass, the screen scans the other six only.  Oracle bits before and after the
+    switch; probes switch the fields back on once their rows are replaced by plain ones."""
+    import torch
+    from mfar import synth
+    from mfar.data.pipeline import PipelinedSearcher
+    D, F, E, Q = 60_000, 8, 128, 64
+    kinds = ["plain", "plain", "clustered", "plain", "plain", "clustered", "plain", "plain"]
+    corpus = synth.SyntheticCorpus(D, F, E, n_queries=40 * Q, seed=0xdeadbeef, device="cuda:0", field_kinds=kinds)
+    ix = corpus.build_index(idxmod)
+    W = corpus.W
+    mask = torch.ones(F, device="cuda:0")
+    mask[3] = 0
+    slab = np.stack([corpus.rows(f, 0, D).cpu().numpy() for f in range(F)])
+    Wn, mn = W.cpu().numpy(), mask.cpu().numpy()
+
+    def run(first, n):
+        ps = PipelinedSearcher(ix, W, mask, max_batch=Q)
+        out, tickets = [], []
+        for j in range(n):
+            tickets.append(ps.submit(corpus.queries((first + j) * Q, Q)))
+            if j >= ps.lag:
+                out.append({k: v.clone() for k, v in ps.result(tickets[j - ps.lag]).items()})
+        for t in tickets[max(0, n - ps.lag):]:
+            out.append({k: v.clone() for k, v in ps.result(t).items()})
+        torch.cuda.synchronize()
+        return ps, out
+
+    def check(first, outs, which):
+        for j in which:
+            o = O.c_two_stage(slab, corpus.queries((first + j) * Q, Q).cpu().numpy(), Wn, mn)
+            assert np.array_equal(outs[j]["ids"].cpu().numpy(), o["ids"]), ("ids", first + j)
+            assert np.array_equal(outs[j]["scores"].cpu().numpy().view(np.uint32), o["scores"].view(np.uint32)), ("score bits", first + j)
+
+    assert ix.auto_off_info()["off"] == []
+    ps, outs = run(0, 36)                                     # 18 launches of 128 queries (+ the redone ones)
+    info = ix.auto_off_info()
+    assert info["off"] == [2, 5], info                        # exactly the clustered fields
+    assert info["inline_repair"] or ps.n_redone <= 6, (info, ps.n_redone)
+    check(0, outs, [0, 1, 34, 35])                            # before the switch (screen + repair) and after it (exact pass for 2, 5)
+    # steady state: the screen runs over six fields and none of ITS lists fails; the lists of 2 and 5 are the exact pass's
+    st0 = ix.screen_stats()
+    r = ix.search(corpus.queries(36 * Q, 2 * Q), W, mask, return_fields=True)      # the synchronous entry point takes the same path
+    torch.cuda.synchronize()
+    st1 = ix.screen_stats()
+    assert st1["n_failed"] == st0["n_failed"] and st1["n_checked"] - st0["n_checked"] == 2 * Q * 6, (st0, st1)
+    o = O.c_two_stage(slab, corpus.queries(36 * Q, 2 * Q).cpu().numpy(), Wn, mn)
+    assert np.array_equal(r["field_ids"].cpu().numpy(), o["field_ids"]) and np.array_equal(r["ids"].cpu().numpy(), o["ids"])
+    assert np.array_equal(r["field_scores"].cpu().numpy().view(np.uint32), o["field_scores"].view(np.uint32))
+    assert np.array_equal(r["scores"].cpu().numpy().view(np.uint32), o["scores"].view(np.uint32))
+    # switching the policy off screens everything again (and repairs): same bits
+    ix.set_auto_off(0)
+    assert ix.auto_off_info()["off"] == []
+    r0 = ix.search(corpus.queries(36 * Q, 2 * Q), W, mask)
+    torch.cuda.synchronize()
+    assert torch.equal(r0["ids"], r["ids"]) and torch.equal(r0["scores"], r["scores"])
+    # back on: plain rows in the two fields, a probe every second launch -> two clean probes each switch them on again
+    ix.set_auto_off(1, 0, 2)
+    _, _ = run(0, 36)
+    assert ix.auto_off_info()["off"] == [2, 5]
+    plain = synth.SyntheticCorpus(D, F, E, n_queries=Q, seed=7, device="cuda:0")
+    for f in (2, 5):
+        rows = plain.rows(f, 0, D)
+        ix.write_rows(f, 0, rows)
+        slab[f] = rows.cpu().numpy()
+    n_on0 = ix.auto_off_info()["n_switched_on"]
+    ps, outs = run(40, 16)
+    info = ix.auto_off_info()
+    assert info["off"] == [] and info["n_switched_on"] == n_on0 + 2 and info["n_probes"] >= 2, info
+    check(40, outs, [0, 15])
     ix.close()
