@@ -578,6 +578,8 @@ def main():
                      "10 M docs x 16 fields x 768d bf16 over 8 GPUs = 1 250 000 rows per GPU (what one rank of the row-sharded run holds)"))}
         if N == 1 and args.dtype == "f32" and args.corpus == "plain" and not args.no_extra_legs and not args.no_config_legs:
             line["clustered_corpus"] = clustered_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E)
+        if N == 1 and args.dtype == "f32" and not args.no_extra_legs:
+            line["drop_in"] = drop_in_leg(ix, corpus, W, mask, Q, torch, max(256, args.steps), args.warmup, results)
         if N == 1 and dist is None and not args.no_extra_legs and (sustained or args.sustain_s <= 0):
             line["exchange_overhead"] = exchange_leg(ix, corpus, W, mask, PipelinedSearcher, run, Q, torch, max(256, args.steps),
                                                      sustained["queries_per_s"] if sustained else qps)
@@ -762,6 +764,64 @@ def clustered_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F
     if not same:
         raise SystemExit(f"clustered corpus: default path and screen-off path differ: {out}")
     return out
+
+
+def drop_in_leg(ix, corpus, W, mask, Q, torch, steps, first, ref_results):
+    """The drop-in boundary AS DOCUMENTED: INTEGRATION.md section 2's ctypes stub, extracted from the file and executed verbatim (the same
+    text tests/test_gpu_integration.py runs), on the headline index: (1) `HbmIndex.search` = one synchronous-order mfar_search_two_stage
+    call per 64-query batch, (2) `HbmPipeline` = the C-ABI pipeline mfar_pipeline_* (streams, slots, coalescing inside the library).
+    `ref_results`: the timed region's results for batches first .. (bits gate)."""
+    import ctypes
+    import re
+    from mfar import _native
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", md[md.index("## 2. The binding a maintainer"):], re.S).group(1)
+    ctypes.CDLL(_native.LIB_PATH, mode=ctypes.RTLD_GLOBAL)        # the stub opens the library by its soname
+    ns = {"__name__": "mfar_native_stub"}
+    exec(compile(code, "INTEGRATION.md#2", "exec"), ns)
+    hi = ns["HbmIndex"].__new__(ns["HbmIndex"])                   # the stub's index object over the handle that already holds the corpus
+    hi.h = ix._h
+    batches = [corpus.queries((first + i) * Q, Q) for i in range(steps)]
+    for b in batches[:2]:
+        hi.search(b, W, mask)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sync = [hi.search(b, W, mask) for b in batches[:max(8, steps // 4)]]
+    torch.cuda.synchronize()
+    dt_sync = time.perf_counter() - t0
+    pipe = ns["HbmPipeline"](hi, W, mask)
+    def run_pipe(bs, keep):
+        tk = []
+        for j, b in enumerate(bs):
+            tk.append(pipe.submit(b))
+            if j >= pipe.lag:
+                r = pipe.result(tk[j - pipe.lag])
+                if keep is not None:
+                    keep.append(r)
+        for t in tk[max(0, len(bs) - pipe.lag):]:
+            r = pipe.result(t)
+            if keep is not None:
+                keep.append(r)
+    run_pipe(batches[:12], None)
+    torch.cuda.synchronize()
+    got = []
+    t0 = time.perf_counter()
+    run_pipe(batches, got)
+    torch.cuda.synchronize()
+    dt_pipe = time.perf_counter() - t0
+    pipe.close()
+    n = min(len(ref_results), len(got), len(sync))
+    same = all(torch.equal(got[i][0], ref_results[i][0]) and torch.equal(got[i][1], ref_results[i][1]) and
+               torch.equal(sync[i][0], ref_results[i][0]) and torch.equal(sync[i][1], ref_results[i][1]) for i in range(n))
+    if not same:
+        raise SystemExit("drop-in bindings (INTEGRATION.md stub) returned different bits than the timed pipeline")
+    return {"binding": "INTEGRATION.md section 2, executed verbatim (ctypes over the C ABI; device tensors in and out)",
+            "sync_mfar_search_two_stage": {"queries_per_s": len(sync) * Q / dt_sync, "ms_per_batch": dt_sync / len(sync) * 1e3, "batches": len(sync),
+                                           "what": "one call per 64-query batch, the 64-column scan, nothing overlapped"},
+            "pipelined_mfar_pipeline": {"queries_per_s": steps * Q / dt_pipe, "ms_per_batch": dt_pipe / steps * 1e3, "batches": steps,
+                                        "what": "mfar_pipeline_submit / _result, results taken lag batches late; result() copies each batch's "
+                                                "ids / scores / n_valid into fresh tensors"},
+            "ids_and_score_bits_identical_to_timed_pipeline": True, "batches_compared": n}
 
 
 def exchange_leg(ix, corpus, W, mask, PipelinedSearcher, run, Q, torch, steps, base_qps):

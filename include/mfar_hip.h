@@ -370,6 +370,42 @@ int mfar_stage2_dump_info(mfar_index* idx, int k1, int* wanted, int64_t* bytes_p
 int mfar_stage2_stats(mfar_index* idx, int* two_level_available, int64_t* gather_slab_bytes, int64_t* n_candidates,
                       int64_t* n_survivors);
 
+/*
+ * The batch PIPELINE behind the C ABI: what a host in any language calls to reach the rate bench.py reports (the synchronous
+ * mfar_search_two_stage above scans the slab once per call and leaves the GPU idle between its kernels).  Stands behind the reference's
+ * evaluation loop -- test_step per batch of dev_batch_size = 64 queries, modeling/contrastive.py:553-563 -> trec_eval_step :669-704 -- for ONE
+ * row shard (the row-sharded exchange needs two collectives per launch, which stay with the host: mfar/data/pipeline.py).
+ *   - `depth` launches in flight (2 .. 4, 0 = 3) on the library's own HIP streams: the scans of consecutive launches back to back on a
+ *     high-priority stream, everything after a scan (exact re-scoring + certificate, union, stage 2, mixer) on side streams beside the next scan;
+ *   - COALESCING: when mfar_max_split_batch() is 128, `coalesce` (0 = auto: 2) consecutive batches of max_batch <= 64 queries are scanned
+ *     by one launch of the wide pass -- half the scan bytes per query; results per query are unchanged;
+ *   - a launch whose certificate failed is redone exactly when its result is taken; data on which that keeps happening is handled by the
+ *     library (mfar_set_auto_off).
+ * Results are bit for bit those of mfar_search_two_stage(idx, q, ...) for the same queries.
+ *   create     W [E, F] (query_cond) or [F]; mask [F] or NULL (ones); copied (host or device pointers per on_device).
+ *   submit     q [Q, E], 1 <= Q <= max_batch; host pointer (copied before the call returns) or device pointer (copied on `stream`, which
+ *              also orders the copy after the caller's producer).  Returns at once; *ticket identifies the batch.
+ *   result     waits for the batch's launch (launching it alone if it is still held for coalescing), copies ids / scores [Q, k2] and
+ *              n_valid [Q] (may be NULL) to host memory (synchronous) or device memory (on `stream`).  A ticket stays valid until
+ *              depth * coalesce more batches were submitted: to keep the pipeline full take results lag = depth * coalesce - 1
+ *              submissions late (mfar_pipeline_info).
+ *   result_view  device pointers into the launch's slot instead of copies (+ the batch's stage-1 lists [Q, F, k1]); same validity.
+ *   set_weights  flushes, waits for the launches in flight and replaces W / mask (a mask_fields sweep, a new weight version).
+ *   flush      launches a batch that is being held for coalescing.
+ * Calls on one pipeline (and on its index) must be serialised by the caller.  The index must outlive the pipeline.
+ */
+typedef struct mfar_pipeline mfar_pipeline;
+int mfar_pipeline_create(mfar_pipeline** out, mfar_index* idx, const float* W, int query_cond, const float* mask, int k1, int k2, int sentinel,
+                         int max_batch, int depth, int coalesce, int on_device);
+void mfar_pipeline_destroy(mfar_pipeline* p);
+int mfar_pipeline_info(const mfar_pipeline* p, int* depth, int* coalesce, int* queries_per_launch, int* lag, int64_t* n_redone);
+int mfar_pipeline_set_weights(mfar_pipeline* p, const float* W, const float* mask, int on_device);
+int mfar_pipeline_submit(mfar_pipeline* p, const float* q, int Q, int on_device, void* stream, int64_t* ticket);
+int mfar_pipeline_flush(mfar_pipeline* p);
+int mfar_pipeline_result(mfar_pipeline* p, int64_t ticket, int64_t* ids, float* scores, int32_t* n_valid, int on_device, void* stream);
+int mfar_pipeline_result_view(mfar_pipeline* p, int64_t ticket, const int64_t** ids, const float** scores, const int32_t** n_valid,
+                              const int64_t** field_ids, const float** field_scores);
+
 #ifdef __cplusplus
 }
 #endif

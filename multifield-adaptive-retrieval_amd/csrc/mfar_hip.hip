@@ -2618,3 +2618,4 @@ extern "C" int mfar_merge_topk(int device, const void* gathered_topk, int n_shar
     return MFAR_OK;
 }
 
+#include "mfar_pipeline.h"

@@ -94,6 +94,14 @@ SIGNATURES = {
     "mfar_set_stage2_dump": (_i, [_vp, _i]),
     "mfar_stage2_dump_info": (_i, [_vp, _i, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "mfar_stage2_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
+    "mfar_pipeline_create": (_i, [_c.POINTER(_vp), _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i]),
+    "mfar_pipeline_destroy": (None, [_vp]),
+    "mfar_pipeline_info": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i64)]),
+    "mfar_pipeline_set_weights": (_i, [_vp, _vp, _vp, _i]),
+    "mfar_pipeline_submit": (_i, [_vp, _vp, _i, _i, _vp, _c.POINTER(_i64)]),
+    "mfar_pipeline_flush": (_i, [_vp]),
+    "mfar_pipeline_result": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _vp]),
+    "mfar_pipeline_result_view": (_i, [_vp, _i64, _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_vp)]),
 }
 
 # MFAR_ABI_VERSION of include/mfar_hip.h these signatures were written against.  A library that reports another value has

@@ -334,3 +334,80 @@ class PipelinedSearcher:
             nv = s["n_valid"].view(-1)[:self.M * QL].view(self.M, QL)
             return dict(ids=ids[:, off:off + Q], scores=sc[:, off:off + Q], n_valid=nv[:, off:off + Q])
         return dict(ids=s["ids"][off:off + Q], scores=s["scores"][off:off + Q], n_valid=s["n_valid"][off:off + Q])
+
+
+class NativePipeline:
+    """The same pipeline behind the C ABI (`mfar_pipeline_*`, include/mfar_hip.h; csrc/mfar_pipeline.h): streams, slots, coalescing and the
+    redo of failed certificates live inside libmfar_hip.so, so a host in any language reaches the pipelined rate (INTEGRATION.md section 2
+    binds exactly these entry points).  One row shard, one mask.  `submit` takes a CUDA tensor (copied on torch's current stream) or a
+    numpy array (copied before the call returns); `result` returns tensors on the index's device / numpy arrays accordingly.
+
+        np_ = NativePipeline(index, W, mask)
+        t = np_.submit(q)                 # returns at once
+        r = np_.result(t)                 # dict(ids, scores, n_valid); take results `np_.lag` submissions late to keep the pipe full
+    """
+
+    def __init__(self, index, W, mask=None, k1: int = 100, k2: int = 100, sentinel: bool = True, query_cond: bool = True,
+                 max_batch: int = 64, depth: int = 0, coalesce: int = 0):
+        import ctypes
+        self.ix, self.k1, self.k2 = index, int(k1), int(k2)
+        Wa = _index._Arg(W, __import__("numpy").float32, index.device)
+        ma = _index._Arg(mask, __import__("numpy").float32, index.device, allow_none=True)
+        on_dev = _index._same_side([Wa, ma])
+        self._p = ctypes.c_void_p()
+        _native.check(_native.lib().mfar_pipeline_create(ctypes.byref(self._p), index._h, Wa.ptr, int(bool(query_cond)), ma.ptr, self.k1, self.k2,
+                                                         int(bool(sentinel)), int(max_batch), int(depth), int(coalesce), int(on_dev)))
+        d, c, n, lag = (ctypes.c_int() for _ in range(4))
+        _native.check(_native.lib().mfar_pipeline_info(self._p, ctypes.byref(d), ctypes.byref(c), ctypes.byref(n), ctypes.byref(lag), None))
+        self.depth, self.coalesce, self.Qmax, self.lag = d.value, c.value, n.value, lag.value
+        self._meta = {}
+
+    @property
+    def n_redone(self) -> int:
+        import ctypes
+        v = ctypes.c_int64()
+        _native.check(_native.lib().mfar_pipeline_info(self._p, None, None, None, None, ctypes.byref(v)))
+        return v.value
+
+    def close(self):
+        if getattr(self, "_p", None):
+            _native.lib().mfar_pipeline_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_weights(self, W, mask=None):
+        import numpy as np
+        Wa = _index._Arg(W, np.float32, self.ix.device)
+        ma = _index._Arg(mask, np.float32, self.ix.device, allow_none=True)
+        _native.check(_native.lib().mfar_pipeline_set_weights(self._p, Wa.ptr, ma.ptr, int(_index._same_side([Wa, ma]))))
+
+    def flush(self):
+        _native.check(_native.lib().mfar_pipeline_flush(self._p))
+
+    def submit(self, q) -> int:
+        import ctypes
+        import numpy as np
+        qa = _index._Arg(q, np.float32, self.ix.device)
+        t = ctypes.c_int64()
+        _native.check(_native.lib().mfar_pipeline_submit(self._p, qa.ptr, int(qa.keep.shape[0]), int(qa.on_device),
+                                                         _index._current_stream(self.ix.device, qa.on_device), ctypes.byref(t)))
+        self._meta[t.value] = (int(qa.keep.shape[0]), bool(qa.on_device))
+        for old in [k for k in self._meta if k <= t.value - 2 * self.depth * self.coalesce]:
+            del self._meta[old]
+        return t.value
+
+    def result(self, ticket: int):
+        import numpy as np
+        Q, on_dev = self._meta[ticket]
+        ids = _index._empty_like_side(on_dev, self.ix.device, (Q, self.k2), np.int64)
+        sc = _index._empty_like_side(on_dev, self.ix.device, (Q, self.k2), np.float32)
+        nv = _index._empty_like_side(on_dev, self.ix.device, (Q,), np.int32)
+        ia, sa, na = (_index._Arg(a, d, self.ix.device) for a, d in ((ids, np.int64), (sc, np.float32), (nv, np.int32)))
+        _native.check(_native.lib().mfar_pipeline_result(self._p, int(ticket), ia.ptr, sa.ptr, na.ptr, int(on_dev),
+                                                         _index._current_stream(self.ix.device, on_dev)))
+        return dict(ids=ids, scores=sc, n_valid=nv)

@@ -12,6 +12,109 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
+def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
+    """One random configuration (shapes, data kind, knobs all drawn from `rng`) through stage 1 with the screen off and on, the whole
+    scorer and -- sometimes -- the fused mode, against the C oracle.  Returns True when every comparison held."""
+    F = int(rng.integers(1, 10))
+    E = int(rng.choice([32, 64, 96, 128, 192, 384, 768]))
+    D = int(rng.choice([rng.integers(1, 300), rng.integers(300, 5000), rng.integers(5000, 70000)]))
+    if big:                            # long chunks, many compactions / drains
+        D = int(rng.integers(20000, 250000))
+        E = int(rng.choice([32, 96, 96, 192]))
+        F = int(rng.integers(1, 4))
+    D = min(D, int(3e7 // (F * E)))
+    Q = int(rng.choice([rng.integers(1, 9), 64, rng.integers(9, 131), 128, rng.integers(129, 261)]))   # > 64: wide blocks of 128 + a rest
+    k = int(rng.choice([1, 10, 100, 100, 128, rng.integers(1, 129)]))
+    sentinel = bool(rng.integers(0, 2))
+    mean = float(rng.choice([0.3, -0.4, 0.0, 2.0]))
+    dtype = "bf16" if rng.random() < 0.2 else "f32"
+    mu = rng.standard_normal(E).astype(np.float32)
+    mu /= np.linalg.norm(mu)
+    slab = (rng.standard_normal((F, D, E)) * 0.5 + mean * mu * 4.0).astype(np.float32)
+    q = (rng.standard_normal((Q, E)) * 0.5 + mu * 2.0).astype(np.float32)
+    kind = rng.integers(0, 6)
+    eps_mult = 1e9 if rng.random() < 0.15 else 1.0      # forced fail: every certificate fails, the exact pass repairs (auto-off after 12 launches)
+    if kind == 1 and D > 8:          # duplicate group
+        rows = rng.choice(D, size=min(D, int(rng.integers(2, 3000))), replace=False)
+        slab[rng.integers(0, F), rows] = slab[0, rows[0]]
+    if kind == 2 and D > 8:          # ascending scores for query 0 in one field
+        f = int(rng.integers(0, F))
+        ramp = np.linspace(0.0, 3.0, D, dtype=np.float32)[:, None] * (q[0] / np.dot(q[0], q[0]))[None, :]
+        slab[f] = (slab[f] * 0.01 + ramp).astype(np.float32)
+    if kind == 3:                    # tiny values
+        slab *= np.float32(1e-12)
+    if kind == 4:                    # heavy-tailed row norms in one field + a few huge outliers in another (ROW MODE territory)
+        f = int(rng.integers(0, F))
+        sc_ = np.minimum((1.0 - rng.random((D, 1))) ** (-1.0 / 3.0), 30.0).astype(np.float32)
+        m_ = slab[f].mean(0)
+        slab[f] = ((slab[f] - m_) * sc_ + m_).astype(np.float32)
+        g = int(rng.integers(0, F))
+        slab[g, rng.choice(D, size=min(D, 5), replace=False)] *= np.float32(20.0)
+    if kind == 5 and D > 600:        # clusters of ~250 near-duplicate, non-identical rows in one field: certificates fail for real
+        f = int(rng.integers(0, F))
+        centres = slab[f][rng.integers(0, D, size=max(2, D // 250))]
+        slab[f] = (centres[rng.integers(0, centres.shape[0], size=D)] + rng.standard_normal((D, E)).astype(np.float32) * np.float32(5e-5)).astype(np.float32)
+    ix = idxmod.MultiFieldIndex(D, F, E, device=0, dtype=dtype)
+    ix.set_row_mode(int(rng.choice([0, 1, 2, 2])))       # per-row bounds for heavy-tailed fields: never / auto / always
+    ix.set_stage2_dump(int(rng.choice([0, 1, 2, 2])))    # the scan's score dump as stage 2's approximate level
+    for f in range(F):
+        ix.write_rows(f, 0, slab[f])
+    ref = O.bf16_round(slab) if dtype == "bf16" else slab
+    ok = True
+    for screen in (0, 2):
+        ix.set_screen(screen, eps_mult if screen else 1.0)        # 2 = certified stage 1 whenever the shapes allow (bf16: over the slab itself)
+        ix.set_wgs_per_cu(int(rng.choice([1, 2, 4])))
+        ids, sc = ix.retrieve_fields(q, k, sentinel)
+        for f in range(F):
+            if dtype == "bf16":
+                with O.chain("natural"):
+                    oi, osc = O.c_retrieve(ref[f], q, k, sentinel)
+                good = np.allclose(sc[:, f], osc, rtol=0, atol=1e-4 * max(1.0, float(np.abs(osc).max())))
+                st_ = ix.screen_stats()      # (dims whose k-steps divide by neither 4 nor 6 have no certified bf16 kernel: plain pass)
+                if screen == 2 and k + 64 <= 192 and st_["n_failed"] == 0 and st_["n_checked"] > 0:      # certified: exact ids and bits
+                    good = good and np.array_equal(ids[:, f], oi) and np.array_equal(sc[:, f].view(np.uint32), osc.view(np.uint32))
+            else:
+                oi, osc = O.c_retrieve(ref[f], q, k, sentinel)
+                good = np.array_equal(ids[:, f], oi) and np.array_equal(sc[:, f].view(np.uint32), osc.view(np.uint32))
+            if not good:
+                ok = False
+                print("MISMATCH", dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, dtype=dtype, kind=int(kind), screen=screen, f=f,
+                                       seed=seed, n=n, eps_mult=eps_mult), flush=True)
+    if ok and dtype == "f32" and D * F * E * Q < 3e9 and F * k <= 4096:    # the whole scorer, both stage-1 paths
+        W = (rng.standard_normal((E, F)) * 0.05).astype(np.float32)
+        mask = (rng.random(F) < 0.8).astype(np.float32)
+        if rng.random() < 0.3:           # masks of any sign (the two-level stage 2 swaps its interval ends under a negative entry)
+            mask = rng.choice(np.array([0.0, 1.0, -1.0, 0.5, 2.0], np.float32), F)
+        o = O.c_two_stage(slab, q, W, mask, k1=k, k2=k, sentinel=sentinel)
+        for screen in (0, 2):
+            ix.set_screen(screen, eps_mult if screen else 1.0)
+            try:
+                r = ix.search(q, W, mask, k1=k, k2=k, sentinel=sentinel)
+            except Exception as e:      # fewer than k2 candidates raises like torch.topk: compare the valid prefix instead
+                r = None
+            if r is not None and not (np.array_equal(r["ids"], o["ids"]) and
+                                      np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32))):
+                ok = False
+                print("MISMATCH two-stage", dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, kind=int(kind), screen=screen,
+                                                 seed=seed, n=n, eps_mult=eps_mult), flush=True)
+    if ok and dtype == "f32" and k < 128 and D * F * E * Q < 2e9 and rng.random() < 0.3:      # fused mode against its contract
+        Wf = (rng.standard_normal((E, F)) * 0.05).astype(np.float32)
+        oi, osc = O.c_search_fused(slab, q, Wf, None, k)
+        r = ix.search_fused(q, Wf, None, k)
+        if not (np.array_equal(r["ids"], oi) and np.array_equal(r["scores"].view(np.uint32), osc.view(np.uint32))):
+            ok = False
+            print("MISMATCH fused", dict(F=F, D=D, E=E, Q=Q, k=k, seed=seed, n=n, eps_mult=eps_mult), flush=True)
+    st = ix.screen_stats()
+    off = ix.auto_off_info()["off"]
+    ix.close()
+    n += 1
+    if verbose:
+        print(f"{n:4d} ok={ok} F={F} D={D} E={E} Q={Q} k={k} sent={int(sentinel)} mean={mean} {dtype} kind={int(kind)} eps_mult={eps_mult:g} "
+          f"checked={st.get('n_checked')} failed={st.get('n_failed')}", flush=True)
+    if not ok:
+        sys.exit(1)
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -21,95 +124,8 @@ def main():
     t_end = time.time() + budget
     n = 0
     while time.time() < t_end:
-        F = int(rng.integers(1, 10))
-        E = int(rng.choice([32, 64, 96, 128, 192, 384, 768]))
-        D = int(rng.choice([rng.integers(1, 300), rng.integers(300, 5000), rng.integers(5000, 70000)]))
-        if len(sys.argv) > 3:              # "big": long chunks, many compactions / drains
-            D = int(rng.integers(20000, 250000))
-            E = int(rng.choice([32, 96, 96, 192]))
-            F = int(rng.integers(1, 4))
-        D = min(D, int(3e7 // (F * E)))
-        Q = int(rng.choice([rng.integers(1, 9), 64, rng.integers(9, 131), 128, rng.integers(129, 261)]))   # > 64: wide blocks of 128 + a rest
-        k = int(rng.choice([1, 10, 100, 100, 128, rng.integers(1, 129)]))
-        sentinel = bool(rng.integers(0, 2))
-        mean = float(rng.choice([0.3, -0.4, 0.0, 2.0]))
-        dtype = "bf16" if rng.random() < 0.2 else "f32"
-        mu = rng.standard_normal(E).astype(np.float32)
-        mu /= np.linalg.norm(mu)
-        slab = (rng.standard_normal((F, D, E)) * 0.5 + mean * mu * 4.0).astype(np.float32)
-        q = (rng.standard_normal((Q, E)) * 0.5 + mu * 2.0).astype(np.float32)
-        kind = rng.integers(0, 5)
-        if kind == 1 and D > 8:          # duplicate group
-            rows = rng.choice(D, size=min(D, int(rng.integers(2, 3000))), replace=False)
-            slab[rng.integers(0, F), rows] = slab[0, rows[0]]
-        if kind == 2 and D > 8:          # ascending scores for query 0 in one field
-            f = int(rng.integers(0, F))
-            ramp = np.linspace(0.0, 3.0, D, dtype=np.float32)[:, None] * (q[0] / np.dot(q[0], q[0]))[None, :]
-            slab[f] = (slab[f] * 0.01 + ramp).astype(np.float32)
-        if kind == 3:                    # tiny values
-            slab *= np.float32(1e-12)
-        if kind == 4:                    # heavy-tailed row norms in one field + a few huge outliers in another (ROW MODE territory)
-            f = int(rng.integers(0, F))
-            sc_ = np.minimum((1.0 - rng.random((D, 1))) ** (-1.0 / 3.0), 30.0).astype(np.float32)
-            m_ = slab[f].mean(0)
-            slab[f] = ((slab[f] - m_) * sc_ + m_).astype(np.float32)
-            g = int(rng.integers(0, F))
-            slab[g, rng.choice(D, size=min(D, 5), replace=False)] *= np.float32(20.0)
-        ix = idxmod.MultiFieldIndex(D, F, E, device=0, dtype=dtype)
-        ix.set_row_mode(int(rng.choice([0, 1, 2, 2])))       # per-row bounds for heavy-tailed fields: never / auto / always
-        ix.set_stage2_dump(int(rng.choice([0, 1, 2, 2])))    # the scan's score dump as stage 2's approximate level
-        for f in range(F):
-            ix.write_rows(f, 0, slab[f])
-        ref = O.bf16_round(slab) if dtype == "bf16" else slab
-        ok = True
-        for screen in (0, 2):
-            ix.set_screen(screen)        # bf16: 2 = the opt-in certified screen (lists then equal the natural-order chain bit for bit)
-            ix.set_wgs_per_cu(int(rng.choice([1, 2, 4])))
-            ids, sc = ix.retrieve_fields(q, k, sentinel)
-            for f in range(F):
-                if dtype == "bf16":
-                    with O.chain("natural"):
-                        oi, osc = O.c_retrieve(ref[f], q, k, sentinel)
-                    good = np.allclose(sc[:, f], osc, rtol=0, atol=1e-4 * max(1.0, float(np.abs(osc).max())))
-                    st_ = ix.screen_stats()      # (dims whose k-steps divide by neither 4 nor 6 have no certified bf16 kernel: plain pass)
-                    if screen == 2 and k + 64 <= 192 and st_["n_failed"] == 0 and st_["n_checked"] > 0:      # certified: exact ids and bits
-                        good = good and np.array_equal(ids[:, f], oi) and np.array_equal(sc[:, f].view(np.uint32), osc.view(np.uint32))
-                else:
-                    oi, osc = O.c_retrieve(ref[f], q, k, sentinel)
-                    good = np.array_equal(ids[:, f], oi) and np.array_equal(sc[:, f].view(np.uint32), osc.view(np.uint32))
-                if not good:
-                    ok = False
-                    print("MISMATCH", dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, dtype=dtype, kind=int(kind), screen=screen, f=f,
-                                           seed=seed, n=n), flush=True)
-        if ok and dtype == "f32" and D * F * E * Q < 3e9 and F * k <= 4096:    # the whole scorer, both stage-1 paths
-            W = (rng.standard_normal((E, F)) * 0.05).astype(np.float32)
-            mask = (rng.random(F) < 0.8).astype(np.float32)
-            if rng.random() < 0.3:           # masks of any sign (the two-level stage 2 swaps its interval ends under a negative entry)
-                mask = rng.choice(np.array([0.0, 1.0, -1.0, 0.5, 2.0], np.float32), F)
-            o = O.c_two_stage(slab, q, W, mask, k1=k, k2=k, sentinel=sentinel)
-            for screen in (0, 2):
-                ix.set_screen(screen)
-                try:
-                    r = ix.search(q, W, mask, k1=k, k2=k, sentinel=sentinel)
-                except Exception as e:      # fewer than k2 candidates raises like torch.topk: compare the valid prefix instead
-                    r = None
-                if r is not None and not (np.array_equal(r["ids"], o["ids"]) and
-                                          np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32))):
-                    ok = False
-                    print("MISMATCH two-stage", dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, kind=int(kind), screen=screen,
-                                                     seed=seed, n=n), flush=True)
-        if ok and dtype == "f32" and k < 128 and D * F * E * Q < 2e9 and rng.random() < 0.3:      # fused mode against its contract
-            Wf = (rng.standard_normal((E, F)) * 0.05).astype(np.float32)
-            oi, osc = O.c_search_fused(slab, q, Wf, None, k)
-            r = ix.search_fused(q, Wf, None, k)
-            if not (np.array_equal(r["ids"], oi) and np.array_equal(r["scores"].view(np.uint32), osc.view(np.uint32))):
-                ok = False
-                print("MISMATCH fused", dict(F=F, D=D, E=E, Q=Q, k=k, seed=seed, n=n), flush=True)
-        st = ix.screen_stats()
-        ix.close()
+        ok = one_config(rng, idxmod, O, n, seed, big=len(sys.argv) > 3)
         n += 1
-        print(f"{n:4d} ok={ok} F={F} D={D} E={E} Q={Q} k={k} sent={int(sentinel)} mean={mean} {dtype} kind={int(kind)} "
-              f"checked={st.get('n_checked')} failed={st.get('n_failed')}", flush=True)
         if not ok:
             sys.exit(1)
     print("stress ok:", n, "configurations")

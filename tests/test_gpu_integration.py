@@ -1,0 +1,128 @@
+"""The drop-in boundary as a maintainer of the reference would use it: INTEGRATION.md section 2's ctypes stub is
+EXTRACTED from the file and executed verbatim, and the C-ABI pipeline (mfar_pipeline_*) is driven through its Python face -- ids, score
+bits and n_valid against MultiFieldIndex.search and the C oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mfar_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def integration_stub():
+    """The python block of INTEGRATION.md section 2, as text."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = md[md.index("## 2. The binding a maintainer"):]
+    m = re.search(r"```python\n(.*?)```", sec, re.S)
+    assert m, "INTEGRATION.md section 2 holds no python block"
+    return m.group(1)
+
+
+def load_stub():
+    """Execute the stub verbatim.  It opens the library by its soname: map the in-tree build first, so that the loader finds it."""
+    from mfar import _native
+    _native.lib()                                            # builds the error message when the library is missing; imports torch first
+    ctypes.CDLL(_native.LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    ns = {"__name__": "mfar_native_stub"}
+    exec(compile(integration_stub(), "INTEGRATION.md#2", "exec"), ns)
+    return ns
+
+
+def _mk(rng, F, D, E):
+    mu = rng.standard_normal(E).astype(np.float32)
+    mu /= np.linalg.norm(mu)
+    slab = (rng.standard_normal((F, D, E)) * 0.5 + mu * 1.2).astype(np.float32)
+    W = (rng.standard_normal((E, F)) * 0.05).astype(np.float32)
+    return slab, mu, W
+
+
+def test_integration_stub_runs_verbatim_and_matches_the_oracle():
+    import torch
+    ns = load_stub()
+    rng = np.random.default_rng(5)
+    F, D, E, Q = 4, 30000, 96, 64
+    slab, mu, W = _mk(rng, F, D, E)
+    qs = [(rng.standard_normal((Q if i != 4 else 23, E)) * 0.5 + mu * 2.0).astype(np.float32) for i in range(9)]
+    mask = np.array([1, 1, 0, 1], np.float32)
+    dev = torch.device("cuda:0")
+    ix = ns["HbmIndex"](D, F, E, 0, 0)
+    for f in range(F):
+        ix.write(f, 0, torch.from_numpy(slab[f]).to(dev))
+    Wd, md = torch.from_numpy(W).to(dev), torch.from_numpy(mask).to(dev)
+    want = [O.c_two_stage(slab, q, W, mask) for q in qs[:3]]
+    # the synchronous binding
+    sync = [ix.search(torch.from_numpy(q).to(dev), Wd, md) for q in qs]
+    torch.cuda.synchronize()
+    for (ids, sc, nv), o in zip(sync, want):
+        assert np.array_equal(ids.cpu().numpy(), o["ids"]) and np.array_equal(sc.cpu().numpy().view(np.uint32), o["scores"].view(np.uint32))
+        assert (nv.cpu().numpy() == 100).all()
+    # the pipelined binding: results `lag` submissions late, a short batch in the middle, the last ones drained
+    pipe = ns["HbmPipeline"](ix, Wd, md)
+    assert pipe.lag == 5                                       # three launches x two coalesced batches - 1
+    tickets, got = [], []
+    for i, q in enumerate(qs):
+        tickets.append(pipe.submit(torch.from_numpy(q).to(dev)))
+        if i >= pipe.lag:
+            got.append(pipe.result(tickets[i - pipe.lag]))
+    for t in tickets[len(got):]:
+        got.append(pipe.result(t))
+    torch.cuda.synchronize()
+    for (ids, sc, nv), (ids0, sc0, nv0) in zip(got, sync):
+        assert torch.equal(ids, ids0) and torch.equal(sc, sc0) and torch.equal(nv, nv0)
+    pipe.close()
+    ix.close()
+
+
+def test_native_pipeline_equals_search(idxmod=None):
+    """mfar_pipeline_* through mfar.data.pipeline.NativePipeline: device and host batches, coalescing on and off, every depth, a forced
+    failure of every certificate (redone when the result is taken, then repaired inline), new weights in the middle -- always the bits of
+    MultiFieldIndex.search."""
+    import torch
+    from mfar.data import index as idxmod
+    from mfar.data.pipeline import NativePipeline
+    rng = np.random.default_rng(6)
+    F, D, E, Q = 3, 24000, 64, 48
+    slab, mu, W = _mk(rng, F, D, E)
+    W2 = (rng.standard_normal((E, F)) * 0.05).astype(np.float32)
+    mask = np.array([1, 0, 1], np.float32)
+    ix = idxmod.MultiFieldIndex(D, F, E, device=0)
+    for f in range(F):
+        ix.write_rows(f, 0, slab[f])
+    dev = torch.device("cuda:0")
+    qs = [(rng.standard_normal((Q if i % 4 else 17, E)) * 0.5 + mu * 2.0).astype(np.float32) for i in range(11)]
+    ix.set_screen(0)
+    want = [ix.search(q, W, mask) for q in qs]
+    want2 = [ix.search(q, W2, None) for q in qs]
+    for screen, eps_mult, depth, coalesce, on_dev in ((2, 1.0, 0, 0, True), (2, 1.0, 2, 1, False), (2, 1e9, 4, 0, True), (0, 1.0, 3, 0, False)):
+        ix.set_screen(screen, eps_mult)
+        Wd, md = (torch.from_numpy(W).to(dev), torch.from_numpy(mask).to(dev)) if on_dev else (W, mask)
+        pl = NativePipeline(ix, Wd, md, max_batch=Q, depth=depth, coalesce=coalesce)
+        assert pl.coalesce == (coalesce or (2 if screen else 1)) and pl.depth == (depth or 3) and pl.lag == pl.depth * pl.coalesce - 1
+        tickets, got = [], []
+        for i, q in enumerate(qs):
+            tickets.append(pl.submit(torch.from_numpy(q).to(dev) if on_dev else q))
+            if i >= pl.lag:
+                got.append(pl.result(tickets[i - pl.lag]))
+        for t in tickets[len(got):]:
+            got.append(pl.result(t))
+        with pytest.raises(Exception):
+            pl.result(tickets[0])                              # long out of flight
+        for g, w in zip(got, want):
+            gi, gs, gn = ((x.cpu().numpy() if on_dev else x) for x in (g["ids"], g["scores"], g["n_valid"]))
+            assert np.array_equal(gi, w["ids"]) and np.array_equal(gs.view(np.uint32), w["scores"].view(np.uint32)) and np.array_equal(gn, w["n_valid"])
+        assert (pl.n_redone >= 1) == (eps_mult > 1.0), (pl.n_redone, eps_mult)
+        # new weights, no mask: flushes, waits, replaces
+        pl.set_weights(torch.from_numpy(W2).to(dev) if on_dev else W2, None)
+        t = [pl.submit(torch.from_numpy(q).to(dev) if on_dev else q) for q in qs[:3]]
+        for tk, w in zip(t, want2):
+            g = pl.result(tk)
+            gi, gs = ((x.cpu().numpy() if on_dev else x) for x in (g["ids"], g["scores"]))
+            assert np.array_equal(gi, w["ids"]) and np.array_equal(gs.view(np.uint32), w["scores"].view(np.uint32))
+        pl.close()
+    ix.close()
