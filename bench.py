@@ -184,6 +184,8 @@ def main():
     ap.add_argument("--no-config-legs", action="store_true", help="skip the short legs on BASELINE.json's other configurations "
                                                                    "(STaRK-prime / STaRK-mag shapes, the per-GPU share of the bf16 stress config)")
     ap.add_argument("--cpu-sample-docs", type=int, default=0, help="0 = the full corpus when host RAM allows, else 100000")
+    ap.add_argument("--no-encode-leg", action="store_true", help="skip the corpus-encode / mask-sweep leg (tools/encode_bench.py)")
+    ap.add_argument("--encode-docs", type=int, default=50000, help="records of the corpus-encode leg")
     args = ap.parse_args()
 
     # `--gpus N` without a launcher: this process only spawns the ranks (before anything initialises the GPU)
@@ -580,6 +582,11 @@ def main():
             line["clustered_corpus"] = clustered_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E)
         if N == 1 and args.dtype == "f32" and not args.no_extra_legs:
             line["drop_in"] = drop_in_leg(ix, corpus, W, mask, Q, torch, max(256, args.steps), args.warmup, results)
+        if N == 1 and args.dtype == "f32" and args.corpus == "plain" and not args.no_extra_legs and not args.no_config_legs and not args.no_encode_leg:
+            # corpus encode (on_eval_start) + mask-sweep reuse on 50 k STaRK-prime-shaped records x the 22 prime fields
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import encode_bench
+            line["encode_pipeline"] = encode_bench.run(args.encode_docs, 256)
         if N == 1 and dist is None and not args.no_extra_legs and (sustained or args.sustain_s <= 0):
             line["exchange_overhead"] = exchange_leg(ix, corpus, W, mask, PipelinedSearcher, run, Q, torch, max(256, args.steps),
                                                      sustained["queries_per_s"] if sustained else qps)

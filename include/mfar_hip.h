@@ -292,6 +292,16 @@ int mfar_set_wgs_per_cu(mfar_index* idx, int wgs);
  *             against one fp16 term), ranks unique rows through one bit per row, re-scores from the row-major bf16 companion.  Its
  *             certified lists equal the exact natural-order fp32 chain over the bf16 rows bit for bit; see "bf16 contract" below for
  *             the lists that are not certified.
+ *   bf16 contract: which bits a bf16 index returns, and when.  The contract of a bf16 index is the natural-order fp32 fma chain over the
+ *             stored bf16 values (what stage 2 and the mixer always compute).  With the certified stage 1 in use -- modes 1 and 2, ANY
+ *             number of rows (the scan reads the slab itself, there is nothing to allocate), dims whose k-steps (dim / 16) divide by 4 or
+ *             6 -- EVERY per-field list carries exactly those bits: a list is either certified, or written by the exhaustive chain pass
+ *             (csrc/mfar_exact16.h: the same chain on the VALUs for every document of the field, ~30x the time of the screened scan, run
+ *             only for fields whose certificate failed or that AUTO-OFF has switched off).  Results therefore do not depend on how the
+ *             rows are sharded, on which lists happened to fail, or on the batch composition.  The plain three-term MFMA pass sums the
+ *             same exact products in the matrix core's own order and agrees with the chain to ~1e-4: it is what answers in mode 0, for
+ *             the other dims, and when the unique-row tables cannot be allocated -- there list members at a near-tied cut-off and the
+ *             lists' score bits may differ from the chain's (final scores of common documents stay bit-identical: stage 2 recomputes them).
  *   eps_mult  multiplies the error bound of the proof; 1 = rigorous.  Test knob: a huge value makes every proof fail
  *             (exercises the exact fall-back), 0 disables the proof (NOT exact any more).
  * mfar_screen_stats synchronises the device: built = the screen slab is current, screen_bytes = its size,

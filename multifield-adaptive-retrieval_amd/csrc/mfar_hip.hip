@@ -15,6 +15,7 @@
 #include "mfar_hip.h"
 #include "mfar_select.h"
 #include "mfar_screen.h"
+#include "mfar_exact16.h"
 
 #define MFAR_VERSION MFAR_ABI_VERSION   /* include/mfar_hip.h: bumped on EVERY signature change; mfar/_native.py refuses any other value */
 #define PAYLOAD_MAGIC 0x6d464152 /* "mFAR" */
@@ -127,6 +128,7 @@ struct mfar_index {
         // (equal, except in a probe launch, which screens everything)
         u32 exact_mask = 0, skip_mask = 0;
         DevBuf off_flags;                                               // [MFAR_MAX_FIELDS] device copy of exact_mask, one int per field
+        DevBuf chain;                                                   // bf16 index: scores of the exhaustive chain pass (mfar_exact16.h), [CHAIN_QB][rows]
         // feedback: the batch's certificate flags, copied to pinned host memory behind the certify kernel and read by a LATER call once
         // the event has completed (never waited for)
         int* fb_host = nullptr;                                         // [SCREEN_FLAGS] pinned
@@ -257,6 +259,9 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16c4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BC4_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BW4_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16w4_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1BW4_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_chain_scan_bf16_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_chain_scan_bf16_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_chain_scan_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     g_attr_done[device] = true;
     return MFAR_OK;
 }
@@ -378,6 +383,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
         if (sl.fb_host) (void)hipHostFree(sl.fb_host);
         if (sl.fb_ev) (void)hipEventDestroy(sl.fb_ev);
         sl.off_flags.release();
+        sl.chain.release();
         DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.lists2, &sl.list_cnt2, &sl.unit_ctr, &sl.dump, &sl.arow, &sl.eps_cert, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
                         &sl.ssc, &sl.scnt, &sl.sx};
         for (DevBuf* b : sb) b->release();
@@ -942,6 +948,9 @@ static bool screen_wanted(const mfar_index* idx, int k) {
     // to E = 2048, 2 of 11 264 at 2560, 380 at 3072 -- and ONE failed list sends its whole field through the exact pass, so at
     // 3072 every launch pays the screen AND the exact pass.  mfar_set_screen(2) still forces the screen.
     if (idx->screen_mode < 2 && idx->E > 2560) return false;
+    // a bf16 index takes the certified pass at ANY size: its lists then carry the chain's bits whatever the shard size (the plain MFMA pass
+    // sums in another order), and it needs no second copy of the rows
+    if (idx->dtype == MFAR_DTYPE_BF16 && idx->n_rows >= 1) return true;
     return idx->screen_mode >= 2 || idx->n_rows >= 16384;
 }
 
@@ -1300,6 +1309,52 @@ static bool dump_wanted(const mfar_index* idx, int k1) {
     return dump * 3.0 < gather;
 }
 
+// ------------------------------------------------------------------------------------------------ bf16 index: the exhaustive chain pass
+// (mfar_exact16.h) for queries q0 .. q0 + nq of fields [f0, f0 + nf) whose flag is set (flags == nullptr: every field) -> final lists.
+static int exact16_pass(mfar_index* idx, mfar_index::S1Slot& sl, const float* q, int q0, int nq, int k, int sentinel, int f0, int nf, long long* fid,
+                        float* fsc, const int* flags, hipStream_t st) {
+    const long long n_pad = idx->n_blk * 64;
+    RETCHK(sl.chain.ensure((size_t)CHAIN_QB * n_pad * sizeof(float), true));
+    ChainScanParams sp = {};
+    sp.slab = (const unsigned short*)idx->slab;
+    sp.field_stride = idx->field_stride;
+    sp.q = q;
+    sp.scores = sl.chain.as<float>();
+    sp.flags = flags;
+    sp.n_steps = idx->n_steps;
+    sp.E = idx->E;
+    sp.n_blk = idx->n_blk;
+    sp.n_pad = n_pad;
+    ChainSelectParams cp = {};
+    cp.scores = sl.chain.as<float>();
+    cp.flags = flags;
+    cp.out_ids = fid;
+    cp.out_scores = fsc;
+    cp.n_rows = idx->n_rows;
+    cp.n_pad = n_pad;
+    cp.row_offset = idx->row_offset;
+    cp.nf = nf;
+    cp.k = k;
+    cp.sentinel = sentinel;
+    const int QT = idx->E <= 1024 ? 32 : (idx->E <= 4096 ? 8 : 2);
+    const dim3 sg((unsigned)((idx->n_blk + 3) / 4)), sb(256);
+    const size_t lds = (size_t)QT * idx->E * 4;
+    for (int f = f0; f < f0 + nf; ++f)
+        for (int b0 = 0; b0 < nq; b0 += CHAIN_QB) {
+            sp.field = cp.field = f;
+            sp.q0 = cp.q0 = q0 + b0;
+            sp.nq = std::min(CHAIN_QB, nq - b0);
+            cp.fo = f - f0;
+            if (QT == 32) mfar_chain_scan_bf16_kernel<32><<<sg, sb, lds, st>>>(sp);
+            else if (QT == 8) mfar_chain_scan_bf16_kernel<8><<<sg, sb, lds, st>>>(sp);
+            else mfar_chain_scan_bf16_kernel<2><<<sg, sb, lds, st>>>(sp);
+            HIPCHK(hipGetLastError());
+            mfar_chain_select_kernel<<<dim3(sp.nq), dim3(256), 0, st>>>(cp);
+            HIPCHK(hipGetLastError());
+        }
+    return MFAR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ adaptive policy of the certified screen
 // The certificate is data dependent.  A list fails when more than k' - k of its field's unique rows sit within ~2 eps of the k-th best
 // score -- near-duplicate rows (product variants, templated texts, one text encoded in different batches: not bit-identical, so the
@@ -1328,7 +1383,10 @@ static void consume_feedback(mfar_index* idx) {
             const u32 bit = 1u << f;
             if (sl.fb_screened & bit) {
                 a.hist[f] = (unsigned short)((a.hist[f] << 1) | (h[f] ? 1 : 0));
-                if (a.mode && !(idx->off_mask & bit) && __builtin_popcount(a.hist[f]) >= a.off_fails) {
+                // (a bf16 index repairs with the VALU chain pass, ~30x a screened scan: switching a field off saves only the screen's share,
+                //  so it takes a field that fails EVERY launch)
+                const int off_fails = idx->dtype == MFAR_DTYPE_BF16 ? 16 : a.off_fails;
+                if (a.mode && !(idx->off_mask & bit) && __builtin_popcount(a.hist[f]) >= off_fails) {
                     idx->off_mask |= bit;
                     a.clean[f] = 0;
                     a.n_off++;
@@ -1387,7 +1445,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         sl.qw = (screened && wide_ok(idx) && Q - q0 > 64) ? 128 : 64;
         // AUTO-OFF (all-fields passes of an fp32 index): which fields the exact pass writes / the screen leaves out in this batch
         sl.exact_mask = sl.skip_mask = 0;
-        if (screened && !bf16 && f0 == 0 && nf == idx->F && idx->ao.mode) {
+        if (screened && f0 == 0 && nf == idx->F && idx->ao.mode) {
             sl.exact_mask = idx->off_mask & (F >= 32 ? 0xFFFFFFFFu : ((1u << F) - 1u));
             const bool probe = sl.exact_mask != 0 && ++idx->ao.launches % idx->ao.probe_every == 0;
             if (probe) idx->ao.n_probes++;
@@ -1485,7 +1543,8 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
             mfar_mask_flags_kernel<<<dim3(1), dim3(64), 0, st>>>(sl.off_flags.as<int>(), sl.exact_mask);
             HIPCHK(hipGetLastError());
         }
-        for (int b0 = 0; b0 < qt_n; b0 += 64) {
+        if (bf16) RETCHK(exact16_pass(idx, sl, q, q0, qt_n, k, sentinel, f0, nf, fid, fsc, all_off ? nullptr : sl.off_flags.as<int>(), st));
+        for (int b0 = 0; b0 < qt_n && !bf16; b0 += 64) {
             const int total = 64 * (idx->E / 4);
             mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, sl.qt.as<float>(), q0 + b0, Q, idx->E);
             HIPCHK(hipGetLastError());
@@ -1612,17 +1671,14 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     }
     // 4. fall-back: the exact fp32 pass over the DOCUMENTS of the fields whose certificate failed (workgroups of other
     //    fields exit at once)
+    // (bf16 index: the exhaustive CHAIN pass -- the plain MFMA pass would leave other bits in the repaired lists, mfar_exact16.h)
+    if (bf16) return exact16_pass(idx, sl, q, q0, qt_n, k, sentinel, f0, nf, fid, fsc, fflags, st);
     for (int b0 = 0; b0 < qt_n; b0 += 64) {   // the exact pass takes 64 queries at a time
-        if (bf16) {
-            const int total = 64 * (idx->E / 8);
-            mfar_tile_queries_bf16_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, sl.qt.as<unsigned short>(), q0 + b0, Q, idx->E);
-        } else {
-            const int total = 64 * (idx->E / 4);
-            mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, sl.qt.as<float>(), q0 + b0, Q, idx->E);
-        }
+        const int total = 64 * (idx->E / 4);
+        mfar_tile_queries_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(q, sl.qt.as<float>(), q0 + b0, Q, idx->E);
         HIPCHK(hipGetLastError());
         const S1Out o = {fid, fsc, nullptr, q0 + b0, sentinel, idx->row_offset};
-        RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, S1_ALL, bf16 ? S1_BF16 : S1_F32, idx->slab, sl.qt.p, std::min(64, qt_n - b0), k, tau0,
+        RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, S1_ALL, S1_F32, idx->slab, sl.qt.p, std::min(64, qt_n - b0), k, tau0,
                            nullptr, fflags, false, o, st));
     }
     return MFAR_OK;

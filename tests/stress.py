@@ -71,7 +71,7 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
                     oi, osc = O.c_retrieve(ref[f], q, k, sentinel)
                 good = np.allclose(sc[:, f], osc, rtol=0, atol=1e-4 * max(1.0, float(np.abs(osc).max())))
                 st_ = ix.screen_stats()      # (dims whose k-steps divide by neither 4 nor 6 have no certified bf16 kernel: plain pass)
-                if screen == 2 and k + 64 <= 192 and st_["n_failed"] == 0 and st_["n_checked"] > 0:      # certified: exact ids and bits
+                if screen == 2 and k + 64 <= 192 and st_["n_checked"] > 0:      # certified OR repaired by the chain pass: exact ids and bits
                     good = good and np.array_equal(ids[:, f], oi) and np.array_equal(sc[:, f].view(np.uint32), osc.view(np.uint32))
             else:
                 oi, osc = O.c_retrieve(ref[f], q, k, sentinel)
@@ -107,12 +107,10 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
     st = ix.screen_stats()
     off = ix.auto_off_info()["off"]
     ix.close()
-    n += 1
-    if verbose:
-        print(f"{n:4d} ok={ok} F={F} D={D} E={E} Q={Q} k={k} sent={int(sentinel)} mean={mean} {dtype} kind={int(kind)} eps_mult={eps_mult:g} "
-          f"checked={st.get('n_checked')} failed={st.get('n_failed')}", flush=True)
-    if not ok:
-        sys.exit(1)
+    if verbose or not ok:
+        print(f"{n + 1:4d} ok={ok} F={F} D={D} E={E} Q={Q} k={k} sent={int(sentinel)} mean={mean} {dtype} kind={int(kind)} eps_mult={eps_mult:g} "
+              f"checked={st.get('n_checked')} failed={st.get('n_failed')} off={off}", flush=True)
+    return ok
 
 
 def main():

@@ -119,9 +119,8 @@ def test_native_pipeline_equals_search(idxmod=None):
         assert (pl.n_redone >= 1) == (eps_mult > 1.0), (pl.n_redone, eps_mult)
         # new weights, no mask: flushes, waits, replaces
         pl.set_weights(torch.from_numpy(W2).to(dev) if on_dev else W2, None)
-        t = [pl.submit(torch.from_numpy(q).to(dev) if on_dev else q) for q in qs[:3]]
-        for tk, w in zip(t, want2):
-            g = pl.result(tk)
+        for q, w in zip(qs[:3], want2):
+            g = pl.result(pl.submit(torch.from_numpy(q).to(dev) if on_dev else q))      # (taken at once: a held batch is launched alone)
             gi, gs = ((x.cpu().numpy() if on_dev else x) for x in (g["ids"], g["scores"]))
             assert np.array_equal(gi, w["ids"]) and np.array_equal(gs.view(np.uint32), w["scores"].view(np.uint32))
         pl.close()

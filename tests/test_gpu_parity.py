@@ -1542,3 +1542,42 @@ def test_auto_off_switches_clustered_fields_to_the_exact_pass(idxmod):
     assert info["off"] == [] and info["n_switched_on"] == n_on0 + 2 and info["n_probes"] >= 2, info
     check(40, outs, [0, 15])
     ix.close()
+
+
+def test_bf16_lists_carry_the_chain_bits_whatever_path_wrote_them(idxmod):
+    """The bf16 contract: with the certified stage 1 in use -- the default at ANY index size -- every list of a bf16 index carries
+    the natural-order chain's bits: certified by the screen, or written by the exhaustive chain pass (csrc/mfar_exact16.h) when a certificate
+    fails.  Checked against the oracle bit for bit for: a tiny index (under the fp32 screen's 16 384-row threshold), every certificate forced
+    to fail, a clustered field whose certificates fail for real, both sentinel modes, 64- and 128-column blocks; and a row-sharded run with a
+    small last shard equals the unsharded one (a failing list in ONE shard no longer changes bits)."""
+    rng = np.random.default_rng(77)
+    for F, D, E, Q in ((3, 700, 64, 9), (2, 30000, 96, 100), (4, 20000, 128, 64)):
+        slab, q, W = _mk(rng, F, D, E, Q, mean=0.2, dup=7)
+        if D >= 20000:          # field 0: clusters of ~250 near-duplicates (not identical even after the bf16 rounding: distinct low bits)
+            centres = slab[0][rng.integers(0, D, size=D // 250)]
+            slab[0] = centres[rng.integers(0, centres.shape[0], size=D)] * (1.0 + rng.integers(-3, 4, size=(D, E)).astype(np.float32) * np.float32(2.0 ** -8))
+        rs = O.bf16_round(slab)
+        ix = _load_bf16(idxmod, slab)
+        for sentinel in (True, False):
+            with O.chain("natural"):
+                o = O.c_two_stage(rs, q, W, None, sentinel=sentinel)
+            for eps_mult in (1.0, 1e9):
+                ix.set_screen(1, eps_mult)
+                r = ix.search(q, W, None, sentinel=sentinel, return_fields=True)
+                for key in ("field_ids", "ids"):
+                    assert np.array_equal(r[key], o[key]), (F, D, E, Q, sentinel, eps_mult, key)
+                for key in ("field_scores", "scores"):
+                    assert np.array_equal(r[key].view(np.uint32), o[key].view(np.uint32)), (F, D, E, Q, sentinel, eps_mult, key)
+        st = ix.screen_stats()
+        assert st["built"] and st["n_failed"] >= Q * F, st           # the forced failures went through the chain pass
+        ix.close()
+        # two row shards, the second one small: same bits as the unsharded search
+        cut = D - 300
+        with O.chain("natural"):
+            o = O.c_two_stage(rs, q, W, None)
+        shards = [_load_bf16(idxmod, slab[:, :cut]), _load_bf16(idxmod, slab[:, cut:], row_offset=cut)]
+        payloads = np.concatenate([sh.search_local(q) for sh in shards])
+        rm = idxmod.merge_payloads(payloads, 2, q, W, None)
+        assert np.array_equal(rm["ids"], o["ids"]) and np.array_equal(rm["scores"].view(np.uint32), o["scores"].view(np.uint32)), (F, D, E)
+        for sh in shards:
+            sh.close()

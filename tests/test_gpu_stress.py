@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed,big,n_configs", [(101, False, 14), (202, False, 14), (303, False, 14), (404, True, 4)])
+@pytest.mark.parametrize("seed,big,n_configs", [(101, False, 60), (202, False, 60), (303, False, 60), (404, True, 12)])
 def test_stress_slice(seed, big, n_configs):
     import stress
     from mfar.data import index as idxmod
