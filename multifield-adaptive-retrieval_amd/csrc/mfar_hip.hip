@@ -122,6 +122,7 @@ struct mfar_index {
         int dump_Q = 0;
         DevBuf qt16, qinfo, eps, base, fail, sids, ssc, scnt, sx;        // fp16 screen
         DevBuf arow, eps_cert;                                          // ... ROW MODE: per (field, query) factor of the row norm / what is left of eps
+        DevBuf dinv, dstep, eps_dump;                                   // ... SCORE DUMP: 1 / B, B / 32767 and the approximate level's bound per (field, query)
         bool screened = false;                                          // decided by the begin phase of the batch
         int qw = 64;                                                    // query columns of the batch's pass (128: wide screen pass)
         // AUTO-OFF, latched by the begin phase: fields whose lists the exact pass writes in this batch / fields its screen leaves out
@@ -172,7 +173,7 @@ struct mfar_index {
     DevBuf u_repof;               // [F][n_rows] representative of every row's group (stage 2 gathers it in the row's place); optional
     // bf16 index: the certified pass scans the slab itself (no screen slab) and ranks unique rows through these (mfar_screen.h)
     DevBuf rep_bits;              // [F][n_blk] u64: row is real and the representative of its group
-    DevBuf u_of;                  // [F][n_rows] u32: unique number + 1 of a representative's row
+    DevBuf u_of;                  // [F][n_rows] u32: unique number + 1 of the row's group (every row, when u_repof exists; else representatives only)
     bool screen_built = false;    // statistics + unique-row tables (+ the fp16 screen slab of an fp32 index) were built at least once
     std::vector<int> n_unique, largest_group;   // per field (host copies)
     bool screen_dedup = true;     // MFAR_SCREEN_DEDUP=0: every document is its own unique row (diagnostic)
@@ -384,7 +385,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
         if (sl.fb_ev) (void)hipEventDestroy(sl.fb_ev);
         sl.off_flags.release();
         sl.chain.release();
-        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.lists2, &sl.list_cnt2, &sl.unit_ctr, &sl.dump, &sl.arow, &sl.eps_cert, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
+        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.lists2, &sl.list_cnt2, &sl.unit_ctr, &sl.dump, &sl.arow, &sl.eps_cert, &sl.dinv, &sl.dstep, &sl.eps_dump, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
                         &sl.ssc, &sl.scnt, &sl.sx};
         for (DevBuf* b : sb) b->release();
     }
@@ -782,7 +783,8 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
         p.dump_base = idx->dump_base.as<long long>();
     }
     if (kind == S1_F16W && sl.dump_on && nf == idx->F && !repair) {
-        p.dump = sl.dump.as<float>();
+        p.dump = sl.dump.p;
+        p.dump_inv = sl.dinv.as<float>();
         p.dump_base = idx->dump_base.as<long long>();
     }
     if (kind == S1_BF16S || kind == S1_BF16W || kind == S1_BF16C) {     // documents are scanned, unique rows are ranked (mfar_stage1.h s1_acc_init)
@@ -954,6 +956,15 @@ static bool screen_wanted(const mfar_index* idx, int k) {
     return idx->screen_mode >= 2 || idx->n_rows >= 16384;
 }
 
+// uof[row] = unique number + 1 of the row's group, for every row (in: valid for representatives only; a representative is its own repof,
+// so its entry is never written while others read it)
+__global__ void mfar_uof_all_kernel(long long n, const int* __restrict__ repof, u32* __restrict__ uof) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int r = repof[i];
+        if (r != (int)i) uof[i] = uof[r];
+    }
+}
 __global__ void mfar_iota_kernel(int* __restrict__ a, int* __restrict__ b, int* __restrict__ c, int* __restrict__ d, int* __restrict__ e, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -1026,6 +1037,10 @@ static int build_unique_rows(mfar_index* idx, int f, const float* field, DevBuf*
     if (repof) {
         mfar_rep_of_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n, gid, gstart, v_out, repof);
         HIPCHK(hipGetLastError());
+        if (uof_out) {      // every row gets its GROUP's unique number (a representative keeps its own): one table look-up per stage-2 pair
+            mfar_uof_all_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n, repof, uof_out);
+            HIPCHK(hipGetLastError());
+        }
     }
     // largest group (statistics only)
     cap = tmp[8].cap;
@@ -1295,7 +1310,7 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
 static bool wide_ok(const mfar_index* idx) { return idx->wide && (idx->n_steps % 6 == 0 || idx->n_steps % 4 == 0); }
 
 // Should the wide screened pass of this index write its score dump for stage 2 (mfar_select.h mfar_s2_lookup_kernel)?  The dump costs
-// rows x 512 bytes of writes per launch (+ one 64-byte sector per looked-up pair); the row gathers it replaces cost 128 queries x
+// rows x 256 bytes of writes per launch (16-bit codes; + one 64-byte sector per looked-up pair); the row gathers it replaces cost 128 queries x
 // (F k1 candidates) x F fields x E x 2 bytes.  Auto: when the dump moves less than a third of that -- measured: 129 375 x 22 (1.8 GB against
 // 9.5 GB) 48.3 k -> 64.2 k queries/s; the 125 k x 8 row shard (0.56 against 1.26 GB) 185 k -> 182 k: the dump's looser bound keeps ~15 %
 // more survivors and its stores sit in the scan; 1 M x 8 (4.1 against 1.26 GB) 51.6 k -> 39.8 k.
@@ -1304,7 +1319,7 @@ static bool dump_wanted(const mfar_index* idx, int k1) {
         idx->stage2_mode < 1 || !idx->gslab_ok)
         return false;
     if (idx->dump_mode == 2) return true;
-    const double dump = (double)(idx->screen_used / 2 / (size_t)idx->E) * 512.0 + 128.0 * idx->F * k1 * idx->F * 64.0;
+    const double dump = (double)(idx->screen_used / 2 / (size_t)idx->E) * 256.0 + 128.0 * idx->F * k1 * idx->F * 64.0;
     const double gather = 128.0 * idx->F * k1 * idx->F * (double)idx->g_row_bytes;
     return dump * 3.0 < gather;
 }
@@ -1455,7 +1470,8 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         // the launch that wrote it last; a launch that leaves fields out has no scores for them)
         sl.dump_on = sl.qw == 128 && !bf16 && f0 == 0 && nf == idx->F && q0 == 0 && Q <= 128 && sl.skip_mask == 0 && dump_wanted(idx, k);
         sl.dump_ready = false;
-        if (sl.dump_on && sl.dump.ensure(idx->screen_used / 2 / (size_t)idx->E * 512, true) != MFAR_OK) {
+        if (sl.dump_on && (sl.dump.ensure(idx->screen_used / 2 / (size_t)idx->E * 256, true) != MFAR_OK || sl.dinv.ensure((size_t)F * 128 * 4) != MFAR_OK ||
+                           sl.dstep.ensure((size_t)F * 128 * 4) != MFAR_OK || sl.eps_dump.ensure((size_t)F * 128 * 4) != MFAR_OK)) {
             (void)hipGetLastError();
             g_err.clear();
             sl.dump_on = false;
@@ -1527,7 +1543,8 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
             mfar_screen_queries_kernel<<<dim3(qw), dim3(256), 0, st>>>(q, (_Float16*)sl.qt16.p, sl.qinfo.as<ScreenQuery>(), sfield,
                                                                        sl.eps.as<float>(), sl.base.as<float>(), fflags, q0, Q, idx->E, F,
                                                                        idx->screen_eps_mult, qw, bf16 ? 1 : 0, row_mode ? sl.arow.as<float>() : nullptr,
-                                                                       row_mode ? sl.eps_cert.as<float>() : nullptr, sl.row_mask);
+                                                                       row_mode ? sl.eps_cert.as<float>() : nullptr, sl.row_mask,
+                                                                       sl.dump_on ? sl.dinv.as<float>() : nullptr, sl.dstep.as<float>(), sl.eps_dump.as<float>());
         HIPCHK(hipGetLastError());
     }
     // lists of unique-row numbers (fp32 index: rows of the screen slab) / of the local rows of group representatives (bf16 index:
@@ -1807,7 +1824,7 @@ extern "C" int mfar_set_stage2_dump(mfar_index* idx, int mode) {
 extern "C" int mfar_stage2_dump_info(mfar_index* idx, int k1, int* wanted, int64_t* bytes_per_launch, int64_t* n_launches) {
     if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
     if (wanted) *wanted = dump_wanted(idx, k1) ? 1 : 0;
-    if (bytes_per_launch) *bytes_per_launch = idx->screen_built && idx->dtype == MFAR_DTYPE_F32 ? (int64_t)(idx->screen_used / 2 / (size_t)idx->E * 512) : 0;
+    if (bytes_per_launch) *bytes_per_launch = idx->screen_built && idx->dtype == MFAR_DTYPE_F32 ? (int64_t)(idx->screen_used / 2 / (size_t)idx->E * 256) : 0;
     if (n_launches) *n_launches = idx->dump_launches;
     return MFAR_OK;
 }
@@ -2112,7 +2129,7 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
     pp.F = F;
     pp.eps_mult = idx->screen_eps_mult;
     if (from_dump) {
-        pp.eps_src = sl.eps.as<float>();
+        pp.eps_src = sl.eps_dump.as<float>();      // the screened pass's eps + the dump's quantisation step
         pp.eps_qw = 128;
     }
     mfar_s2_prep_kernel<<<dim3(Q), dim3(256), 0, st>>>(pp);
@@ -2141,7 +2158,8 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
     }
     if (from_dump) {
         S2LookupParams lp = {};
-        lp.dump = sl.dump.as<float>();
+        lp.dump = sl.dump.as<unsigned short>();
+        lp.dump_step = sl.dstep.as<float>();
         lp.dump_base = idx->dump_base.as<long long>();
         lp.cand = cand;
         lp.n_cand = ncand;
@@ -2192,6 +2210,35 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
     return MFAR_OK;
 }
 
+// bf16 index, full gather with KNOWN pairs: a candidate's score in the field whose stage-1 list it came from is the chain's bits already
+// whenever the certified stage 1 wrote the lists (certified, or the exhaustive chain pass: include/mfar_hip.h "bf16 contract") -- stage 2
+// walks the same chain, so the pair is copied from the list instead of being gathered again (-1/F of the stage-2 rows).
+static bool bf16_lists_are_chain_exact(const mfar_index* idx, int k) {
+    return idx->dtype == MFAR_DTYPE_BF16 && screen_wanted(idx, k) && idx->screen_built && !idx->screen_dirty;
+}
+static int run_score_known(mfar_index* idx, const float* qd, int Q, const long long* cand, const int* ncand, int C, int slot, float* x,
+                           const long long* fid, const float* fsc, int k1, int sentinel, hipStream_t st) {
+    static const bool reuse = !(getenv("MFAR_STAGE2_KNOWN") && atoi(getenv("MFAR_STAGE2_KNOWN")) == 0);
+    if (!reuse || !fid || !fsc || !bf16_lists_are_chain_exact(idx, k1)) return run_score(idx, qd, Q, cand, ncand, C, x, st);
+    RETCHK(idx->kmask[slot].ensure((size_t)Q * C * 4));
+    HIPCHK(hipMemsetAsync(idx->kmask[slot].p, 0, (size_t)Q * C * 4, st));
+    KnownParams kp = {};
+    kp.fid = fid;
+    kp.fsc = fsc;
+    kp.cand = cand;
+    kp.n_cand = ncand;
+    kp.xa = x;                      // (the known pairs go straight into the final score table)
+    kp.kmask = idx->kmask[slot].as<u32>();
+    kp.F = idx->F;
+    kp.k = k1;
+    kp.C = C;
+    kp.sentinel = sentinel;
+    mfar_s2_known_kernel<<<dim3(Q), dim3(256), 0, st>>>(kp);
+    HIPCHK(hipGetLastError());
+    const KnownArgs kn = {kp.kmask, nullptr, nullptr};
+    return run_score(idx, qd, Q, cand, ncand, C, x, st, nullptr, &kn);
+}
+
 // union -> stage 2 -> mixer (one launch per mask), all pointers on the device; `slot` selects one of two internal workspaces so
 // that two batches can be in flight on different streams.  masks [n_masks, F] (nullptr = no mask, n_masks = 1); ids / scores
 // [n_masks, Q, k2], nvd [n_masks, Q] or nullptr.
@@ -2215,7 +2262,7 @@ static int run_stage2_mix(mfar_index* idx, const float* qd, int Q, const float* 
         RETCHK(run_two_level(idx, qd, Q, Wd, query_cond, masks, n_masks, k2, cm, nm, C, slot, idx->x[slot].as<float>(), &cm, &nm, fid, fsc, k1,
                              sentinel, st));
     else
-        RETCHK(run_score(idx, qd, Q, cm, nm, C, idx->x[slot].as<float>(), st));
+        RETCHK(run_score_known(idx, qd, Q, cm, nm, C, slot, idx->x[slot].as<float>(), fid, fsc, k1, sentinel, st));
     for (int m = 0; m < n_masks; ++m)
         RETCHK(run_mix(idx->x[slot].as<float>(), cm, nm, qd, Wd, query_cond, masks ? masks + (size_t)m * F : nullptr, Q, C, F, E, k2,
                        idd + (size_t)m * Q * k2, scd + (size_t)m * Q * k2, nvd ? nvd + (size_t)m * Q : nullptr, st));
@@ -2617,7 +2664,7 @@ static int search_owned(mfar_index* idx, const void* gathered_lists, int n_shard
     const int* nm = nowned;
     if (two_level_ok(idx, C, k2, query_cond, n_masks))
         RETCHK(run_two_level(idx, q, Q, W, query_cond, mask, n_masks, k2, owned, nowned, C, slot, x, &cm, &nm, lids, lsc, k1, sentinel, st));
-    else RETCHK(run_score(idx, q, Q, owned, nowned, C, x, st));
+    else RETCHK(run_score(idx, q, Q, owned, nowned, C, x, st));      // (merged lists of ALL shards: another shard's list may come from its plain bf16 pass)
     // one top-k payload per mask (a sweep of field masks shares everything up to here: mfar_search_owned_masks)
     for (int m = 0; m < n_masks; ++m) {
         char* tb = (char*)topk + (size_t)m * TL.total;

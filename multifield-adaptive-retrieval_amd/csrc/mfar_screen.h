@@ -307,7 +307,8 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
                                                                   float* __restrict__ eps, float* __restrict__ tau_base,
                                                                   int* __restrict__ fail_flags, int q0, int Q, int E, int F,
                                                                   float eps_mult, int qw, int direct, float* __restrict__ arow,
-                                                                  float* __restrict__ eps_cert, u32 row_mask) {
+                                                                  float* __restrict__ eps_cert, u32 row_mask, float* __restrict__ dump_inv,
+                                                                  float* __restrict__ dump_step, float* __restrict__ eps_dump) {
     __shared__ float red_a[4], red_s[4];
     const int r = blockIdx.x;
     // a new batch: clear the certificate flags of the fields and the "any" flag ([MFAR_MAX_FIELDS + 1] keeps accumulating statistics)
@@ -409,6 +410,15 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
             const bool rm = ((row_mask >> f) & 1u) != 0u && live;         // (the fields whose scans add the row term in this batch)
             arow[f * qw + r] = rm ? 1.001f * SCREEN_SLACK * eps_mult * c_rel * qn * (sq * s.scale) : 0.0f;
             eps_cert[f * qw + r] = rm ? SCREEN_SLACK * eps_mult * e_rest : e_;
+        }
+        // SCORE DUMP (S1Params::dump): the scan stores a / B as a 16-bit signed-normalised code, B >= |a| for every row: the MFMA sums
+        // products of the fp16 query tile (2-norm <= sq |q| (1 + u16)) and fp16 rows (2-norm <= sf max|c| (1 + u16) + tiny) in fp32.  The
+        // code's error, B / 65534 in scaled units, joins the bound of stage 2's approximate level (eps_dump, real units).
+        if (dump_inv) {
+            const float B = 1.01f * (sq * qn) * (s.scale * s.dnorm_max);
+            dump_inv[f * qw + r] = live && B > 0.0f && B < __builtin_inff() ? 1.0f / B : 0.0f;
+            dump_step[f * qw + r] = live && B > 0.0f ? B * (1.0f / 32767.0f) : 0.0f;        // (B = inf: codes 0 x inf = NaN = "unknown", survives)
+            eps_dump[f * qw + r] = e_ + eps_mult * SCREEN_SLACK * 1.03f * qn * s.dnorm_max * (1.0f / 65534.0f);
         }
         // starting threshold of the screened pass: none for live queries (the zero sentinel of index.py:192-193 is applied
         // to the EXACT scores by the certify kernel; deciding it here would need q.m on the critical path), +inf for the

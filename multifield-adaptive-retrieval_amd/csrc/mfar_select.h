@@ -1109,17 +1109,19 @@ __global__ void __launch_bounds__(256) mfar_s2_prep_kernel(const S2PrepParams p)
 // Approximate level of stage 2 from the scan's SCORE DUMP (S1Params::dump).  Stage 2 needs C * F (candidate, field) scores per query;
 // when queries x candidates exceeds the rows of a field -- many fields, small corpora or shards: 129 k x 22 gathers 7.9 GB of fp16 rows
 // per 128 queries, 1.9 x what the scan itself reads -- it is cheaper to let the wide screened pass WRITE every score it computes anyway
-// (rows x 128 x 4 bytes per field) and to pick the pairs out of that table: one 4-byte read per pair instead of a 1.5 KB row.
+// (rows x 128 x 2 bytes per field: 16-bit codes) and to pick the pairs out of that table: one 2-byte read per pair instead of a 1.5 KB row.
 //   xa[q, c, f] = dump[row u of field f][q] / (sq sf) + q . mean(f),   u = unique row of the candidate's group in field f;
-// the bound on |xa - exact| is the screened pass's own eps(q, f) (the certificate's), so mfar_s2_prune_kernel runs unchanged.
+// the bound on |xa - exact| is the screened pass's own eps(q, f) (the certificate's) + the code's quantisation step, so
+// mfar_s2_prune_kernel runs unchanged.
 // Known pairs (kmask) keep the exact score mfar_s2_known_kernel wrote.  grid = (ceil(C F / 256), Q), block 256.
 struct S2LookupParams {
-    const float* dump;             // [rows of the screen slab][128]
+    const unsigned short* dump;    // [row pairs of the screen slab][128][2] signed-normalised 16-bit codes (S1Params::dump)
+    const float* dump_step;        // [F, 128] B / 32767: code -> scaled units
     const long long* dump_base;    // [F] first row of a field
     const long long* cand;         // [Q, C]
     const int* n_cand;             // [Q]
-    const int* repof;              // [F][ustride] representative of a row's group
-    const u32* uof;                // [F][ustride] unique number + 1 of a representative
+    const int* repof;              // [F][ustride] representative of a row's group (unused: uof covers every row)
+    const u32* uof;                // [F][ustride] unique number + 1 of the row's group
     long long ustride, row_offset;
     const ScreenField* sf;
     const ScreenQuery* qinfo;      // [128]
@@ -1138,9 +1140,9 @@ __global__ void __launch_bounds__(256) mfar_s2_lookup_kernel(const S2LookupParam
         if (p.kmask && ((p.kmask[(size_t)qi * p.C + c] >> f) & 1u)) return;       // exact already
         const long long id = p.cand[(size_t)qi * p.C + c] - p.row_offset;
         if (id >= 0 && id < p.n_rows) {
-            const int rep = p.repof[(size_t)f * p.ustride + id];
-            const long long u = (long long)p.uof[(size_t)f * p.ustride + rep] - 1;
-            const float a = p.dump[((size_t)p.dump_base[f] + (size_t)u) * 128 + qi];
+            const long long u = (long long)p.uof[(size_t)f * p.ustride + id] - 1;        // the row's group (mfar_uof_all_kernel)
+            const size_t ru = (size_t)p.dump_base[f] + (size_t)u;
+            const float a = (float)(short)p.dump[(ru >> 1) * 256 + (size_t)qi * 2 + (ru & 1)] * p.dump_step[f * 128 + qi];
             o = (a * p.qinfo[qi].inv_scale) * p.sf[f].inv_scale + p.qm[(size_t)qi * MFAR_MAX_FIELDS + f];
         }
     }

@@ -108,10 +108,13 @@ struct S1Params {
     const float* arow;      // [F, qw] or nullptr.  ROW MODE of the certified screen (mfar_screen.h): fields whose bit is set in row_mask rank rows
     const float* rnorm;     // by approx + arow[f, query] * rnorm[row] -- an upper bound of the exact score up to a row-independent rest -- where
     u32 row_mask;           // rnorm [rows of the scanned slab] is the row's centred 2-norm (field f's rows start at dump_base[f])
-    float* dump;            // or nullptr.  SCORE DUMP of the wide fp16 screen pass (mfar_stage1_f16w_kernel): every approximate score of the
-                            // launch, [scanned row of the slab][128 query columns] fp32 in scaled units, 512 bytes per row; field f's
-                            // rows start at dump_base[f] (in rows).  Stage 2 of a many-field / small-corpus index reads its approximate
-                            // level from here instead of gathering 16-bit rows (mfar_select.h mfar_s2_lookup_kernel).
+    void* dump;             // or nullptr.  SCORE DUMP of the wide fp16 screen pass (mfar_stage1_f16w_kernel): every approximate score of the
+                            // launch as a 16-bit signed-normalised code, a = code / 32767 * B(query, field) with B >= |a| (dump_inv = 1 / B:
+                            // mfar_screen_queries_kernel), laid out [row pair][128 query columns][2 rows] -- 256 bytes per scanned row; field
+                            // f's rows start at dump_base[f] (in rows, even).  Stage 2 of a many-field / small-corpus index reads its
+                            // approximate level from here instead of gathering 16-bit rows (mfar_select.h mfar_s2_lookup_kernel); the
+                            // quantisation (<= B / 65534) is part of that level's error bound.
+    const float* dump_inv;  // [F, 128] 1 / B
     const long long* dump_base;   // [F]
     const uint2* cvt;       // [F] (CV passes over a bf16 slab) per field: x = smallest bf16 magnitude that is a NORMAL fp16 number after the
                             // field's power-of-two scale, y = the exponent rebias, both replicated in the two halves of a dword
@@ -1206,6 +1209,12 @@ __device__ __forceinline__ void s1_body_wide(const S1Params& p, const int chunk_
         rB1 = ar[96];
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(rA0), "+v"(rA1), "+v"(rB0), "+v"(rB1)::"memory");
     }
+    // SCORE DUMP: the field's 128 quantisation factors, parked in LDS (the epilogue has no VGPR to keep them in)
+    float* const dinv_s = (float*)(smem + R * X::Q_STAGE + 2 * S1_STATE_BYTES_(X::SCAP) + (ROWM ? 1024 : 0));
+    if (CV == 2 && p.dump && !p.sample) {              // kernel-uniform
+        if (tid < 128) dinv_s[tid] = p.dump_inv[(size_t)f * 128 + tid];
+        __syncthreads();
+    }
     u32 tmin2 = 0, bias2 = 0;
     if (CV == 1) {
         const uint2 cv = p.cvt[f];
@@ -1315,27 +1324,41 @@ __device__ __forceinline__ void s1_body_wide(const S1Params& p, const int chunk_
             }
             if (CV == 2 && p.dump && !p.sample) {
                 // score dump (S1Params::dump): row (32 db + (r & 3) + 8 (r >> 2) + 4 h) of the wave's block, query column 64 blk + 32 x + j.
-                // One SGPR base per (doc block, r >> 2), one per-lane offset, the rest in the immediate; a store instruction covers two
-                // rows x 32 consecutive queries (two full 128-byte lines).  Issued BEFORE the selection epilogue so that the stores have
-                // left the vmcnt queue by the time the next tile's counted waits look at it.
-                const u32 voff = (u32)((lane >> 5) * 4 * 512 + (lane & 31) * 4);
-                const char* const dtile = (const char*)p.dump + ((size_t)p.dump_base[f] + (size_t)t * S1_TILE_ROWS + (size_t)w * 64) * 512;
-#define S1W_DUMP4(ACC, DB, Q0)                                                                                                  \
+                // Two rows of one query column share a dword (registers r, r + 1 of an accumulator: rows 2 m, 2 m + 1), as 16-bit
+                // signed-normalised codes of a / B (v_cvt_pknorm_i16_f32).  One SGPR base per (doc block, r >> 2), one per-lane offset, the
+                // rest in the immediate; a store instruction covers two row PAIRS x 32 consecutive queries (two full 128-byte lines).
+                // Issued BEFORE the selection epilogue so that the stores have left the vmcnt queue by the time the next tile's counted
+                // waits look at it.
+                const u32 voff = (u32)((lane >> 5) * 2 * 512 + (lane & 31) * 4);
+                const char* const dtile = (const char*)p.dump + ((((size_t)p.dump_base[f] + (size_t)t * S1_TILE_ROWS + (size_t)w * 64)) >> 1) * 512;
+#define S1W_DUMP4(ACC, DB, Q0, INV)                                                                                             \
     _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                                          \
-        const char* sb_ = dtile + (size_t)(32 * (DB) + 8 * g_) * 512;                                                           \
-        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(ACC[4 * g_ + 0]), "s"(sb_), "n"((Q0)) : "memory");           \
-        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(ACC[4 * g_ + 1]), "s"(sb_), "n"((Q0) + 512) : "memory");     \
-        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(ACC[4 * g_ + 2]), "s"(sb_), "n"((Q0) + 1024) : "memory");    \
-        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(ACC[4 * g_ + 3]), "s"(sb_), "n"((Q0) + 1536) : "memory");    \
+        const char* sb_ = dtile + (size_t)(16 * (DB) + 4 * g_) * 512;                                                           \
+        const u32 c0_ = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pknorm_i16(ACC[4 * g_ + 0] * (INV), ACC[4 * g_ + 1] * (INV))); \
+        const u32 c1_ = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pknorm_i16(ACC[4 * g_ + 2] * (INV), ACC[4 * g_ + 3] * (INV))); \
+        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(c0_), "s"(sb_), "n"((Q0)) : "memory");           \
+        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(c1_), "s"(sb_), "n"((Q0) + 512) : "memory");     \
     }
-                S1W_DUMP4(a00, 0, 0)
-                S1W_DUMP4(a01, 0, 128)
-                S1W_DUMP4(a10, 1, 0)
-                S1W_DUMP4(a11, 1, 128)
-                S1W_DUMP4(b00, 0, 256)
-                S1W_DUMP4(b01, 0, 384)
-                S1W_DUMP4(b10, 1, 256)
-                S1W_DUMP4(b11, 1, 384)
+                {
+                    const float i0_ = dinv_s[lane & 31];
+                    S1W_DUMP4(a00, 0, 0, i0_)
+                    S1W_DUMP4(a10, 1, 0, i0_)
+                }
+                {
+                    const float i1_ = dinv_s[32 + (lane & 31)];
+                    S1W_DUMP4(a01, 0, 128, i1_)
+                    S1W_DUMP4(a11, 1, 128, i1_)
+                }
+                {
+                    const float i2_ = dinv_s[64 + (lane & 31)];
+                    S1W_DUMP4(b00, 0, 256, i2_)
+                    S1W_DUMP4(b10, 1, 256, i2_)
+                }
+                {
+                    const float i3_ = dinv_s[96 + (lane & 31)];
+                    S1W_DUMP4(b01, 0, 384, i3_)
+                    S1W_DUMP4(b11, 1, 384, i3_)
+                }
 #undef S1W_DUMP4
             }
             if (row_on) {      // (after the dump, which holds the plain approximate scores)
@@ -1440,7 +1463,7 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_rm_kernel(cons
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w_rm_sample_kernel(const S1Params p) { s1_body_wide<6, S1_SCAP_WIDE, 2, 1>(p, p.chunk0 + (int)blockIdx.x); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_rm_kernel(const S1Params p) { s1_body_wide<4, S1_SCAP_WIDE, 2, 1>(p, p.chunk0 + (int)blockIdx.x); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_f16w4_rm_sample_kernel(const S1Params p) { s1_body_wide<4, S1_SCAP_WIDE, 2, 1>(p, p.chunk0 + (int)blockIdx.x); }
-#define S1HW_LDS_BYTES (6 * 4096 + 2 * S1_STATE_BYTES_(S1_SCAP_WIDE))
+#define S1HW_LDS_BYTES (6 * 4096 + 2 * S1_STATE_BYTES_(S1_SCAP_WIDE) + 512)      // + the score dump's 128 factors
 // certified passes over a bf16 slab: 64 columns x two bf16 terms (register ring of 6 / 4 slots), 128 columns x two terms
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16s_kernel(const S1Params p) { s1_body_x16r<2, 6>(p, p.chunk0 + (int)blockIdx.x); }
 __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16s_sample_kernel(const S1Params p) { s1_body_x16r<2, 6>(p, p.chunk0 + (int)blockIdx.x); }
@@ -1472,6 +1495,6 @@ __global__ void __launch_bounds__(S1_THREADS, 2) mfar_stage1_bf16c4_sample_kerne
 #define S1BC4_LDS_BYTES (4 * 4096 + 2 * S1_STATE_BYTES_(S1BC_SCAP))
 #define S1BW_LDS_BYTES (6 * 8192 + 2 * S1_STATE_BYTES_(S1BW_SCAP6))
 #define S1BW4_LDS_BYTES (4 * 8192 + 2 * S1_STATE_BYTES_(S1BW_SCAP4))
-#define S1HW4_LDS_BYTES (4 * 4096 + 2 * S1_STATE_BYTES_(S1_SCAP_WIDE))
+#define S1HW4_LDS_BYTES (4 * 4096 + 2 * S1_STATE_BYTES_(S1_SCAP_WIDE) + 512)
 #define S1HW_RM_LDS_BYTES (S1HW_LDS_BYTES + 1024)
 #define S1HW4_RM_LDS_BYTES (S1HW4_LDS_BYTES + 1024)
