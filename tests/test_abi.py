@@ -107,3 +107,18 @@ def test_bench_spawns_its_ranks_and_fails_loudly_without_a_gpu():
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert "rank" in out.stderr and "exited with code" in out.stderr
+
+
+def test_integration_stub_compiles_and_names_only_declared_symbols():
+    """INTEGRATION.md section 2 (executed verbatim on the GPU box by tests/test_gpu_integration.py): here, without a GPU, the block must
+    compile, pin the header's ABI number and call nothing the header does not declare."""
+    import re
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", md[md.index("## 2. The binding a maintainer"):], re.S).group(1)
+    compile(code, "INTEGRATION.md#2", "exec")
+    header = open(os.path.join(ROOT, "include", "mfar_hip.h")).read()
+    abi = int(re.search(r"#define MFAR_ABI_VERSION (\d+)", header).group(1))
+    assert f"mfar_version() == {abi}" in code
+    used = set(re.findall(r"_L\.(mfar_\w+)", code))
+    assert used and all(re.search(r"\b%s\(" % name, header) for name in used), sorted(used)
+    assert {"mfar_pipeline_create", "mfar_pipeline_submit", "mfar_pipeline_result", "mfar_search_two_stage"} <= used
