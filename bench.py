@@ -176,6 +176,8 @@ def main():
                     help="R row shards per replica group (N = G groups x R shards, mfar/data/sharded.py ReplicaLayout): 0 = N (the "
                          "north-star layout: one group, every batch crosses xGMI), 1 = N full replicas (the reference's "
                          "query-sharded search), 'auto' = the smallest R whose share of the index fits the free HBM")
+    ap.add_argument("--pipeline", choices=["native", "python"], default="native",
+                    help="single-shard legs: the C-ABI pipeline mfar_pipeline_* (default) or mfar.data.pipeline.PipelinedSearcher")
     ap.add_argument("--coalesce", type=int, default=0, help="batches scanned per launch (0 = auto: 2 when the wide screened pass is available)")
     ap.add_argument("--sustain-s", type=float, default=1.0, help="length of the sustained leg (same pipeline, >= this many seconds; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -240,8 +242,12 @@ def main():
 
     from mfar import synth
     from mfar.data import index as idxmod
-    from mfar.data.pipeline import PipelinedSearcher
+    from mfar.data.pipeline import NativePipeline, PipelinedSearcher as PyPipelinedSearcher
     from mfar.data.sharded import ReplicaLayout, choose_row_shards
+    # which face of the batch pipeline times the single-shard legs: the C-ABI one (mfar_pipeline_*: streams, slots, coalescing and the redo
+    # inside libmfar_hip.so -- what INTEGRATION.md binds) or the Python one (mfar/data/pipeline.py; always used for the row-sharded exchange)
+    native = args.pipeline == "native"
+    PipelinedSearcher = NativePipeline if native else PyPipelinedSearcher
 
     D, F, E, Q = args.docs, args.fields, args.dim, args.batch
     # layout: N ranks = G replica groups x R row shards (R = N unless asked otherwise)
@@ -336,8 +342,11 @@ def main():
             ix.set_stage2_mode(0)
         # Pipeline (mfar/data/pipeline.py, three launches deep): scans back to back on one stream, tails on side streams.  Every batch is
         # still processed completely inside the timed region (the region ends with a full device synchronisation).
-        ps = PipelinedSearcher(ix, W, mask, k1=K1, k2=K2, sentinel=True, query_cond=True, max_batch=Q, coalesce=args.coalesce or None,
-                               group=lay.group, exchange=True if force_exchange else (lay.exchanges if N > 1 else None))
+        if native and N == 1 and not force_exchange:
+            ps = NativePipeline(ix, W, mask, k1=K1, k2=K2, sentinel=True, query_cond=True, max_batch=Q, coalesce=args.coalesce or 0)
+        else:
+            ps = PyPipelinedSearcher(ix, W, mask, k1=K1, k2=K2, sentinel=True, query_cond=True, max_batch=Q, coalesce=args.coalesce or None,
+                                     group=lay.group, exchange=True if force_exchange else (lay.exchanges if N > 1 else None))
         return ix, ps, row0, row1
 
     lay = ReplicaLayout(N, rank, R)
@@ -530,7 +539,9 @@ def main():
                        "pipeline": (f"{ps.depth} launches in flight (the scans run back to back on one stream, the tails of consecutive launches on alternating streams in the gaps); a launch scans {ps.coalesce} "
                                     f"coalesced batch(es) of {Q} queries" + (" with the wide 128-column screened pass (one fp16 query term)"
                                                                              if ps.Qmax > 64 else "")),
-                       "queries_per_launch": ps.Qmax},
+                       "queries_per_launch": ps.Qmax,
+                       "pipeline_face": ("C ABI: mfar_pipeline_submit / _result (csrc/mfar_pipeline.h), driven through ctypes" if isinstance(ps, NativePipeline)
+                                         else "mfar.data.pipeline.PipelinedSearcher (split-phase C-ABI entry points driven from Python)")},
             "rccl": rccl,
             "stage1": ((f"certified fp16 screen of the fp32 slab (min(k+92,192) unique rows per list re-scored with the exact fp32 chain, "
                         "top-k proven or redone by the exact pass per field): outputs bit-identical to the plain fp32 pass" if args.dtype == "f32" else
@@ -588,7 +599,7 @@ def main():
             import encode_bench
             line["encode_pipeline"] = encode_bench.run(args.encode_docs, 256)
         if N == 1 and dist is None and not args.no_extra_legs and (sustained or args.sustain_s <= 0):
-            line["exchange_overhead"] = exchange_leg(ix, corpus, W, mask, PipelinedSearcher, run, Q, torch, max(256, args.steps),
+            line["exchange_overhead"] = exchange_leg(ix, corpus, W, mask, PyPipelinedSearcher, run, Q, torch, max(256, args.steps),
                                                      sustained["queries_per_s"] if sustained else qps)
         if N == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(corpus, ix, args, np, torch)

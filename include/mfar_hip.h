@@ -415,6 +415,8 @@ int mfar_pipeline_flush(mfar_pipeline* p);
 int mfar_pipeline_result(mfar_pipeline* p, int64_t ticket, int64_t* ids, float* scores, int32_t* n_valid, int on_device, void* stream);
 int mfar_pipeline_result_view(mfar_pipeline* p, int64_t ticket, const int64_t** ids, const float** scores, const int32_t** n_valid,
                               const int64_t** field_ids, const float** field_scores);
+/* the batch's stage-1 lists [Q, n_fields, k1] copied out like mfar_pipeline_result does for the final lists */
+int mfar_pipeline_lists(mfar_pipeline* p, int64_t ticket, int64_t* field_ids, float* field_scores, int on_device, void* stream);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,7 @@ static int pipe_streams(int device, PipeStreams** out) {
 
 struct mfar_pipeline {
     mfar_index* idx = nullptr;
+    int device = 0;
     PipeStreams* st = nullptr;
     int k1 = 100, k2 = 100, sentinel = 1, query_cond = 1;
     int Qb = 64, coalesce = 1, depth = 3, Qmax = 64;
@@ -116,10 +117,8 @@ static int pipe_check(mfar_pipeline* p, long long launch) {
 
 extern "C" void mfar_pipeline_destroy(mfar_pipeline* p) {
     if (!p) return;
-    if (p->idx) {
-        (void)hipSetDevice(p->idx->device);
-        (void)hipDeviceSynchronize();
-    }
+    (void)hipSetDevice(p->device);        // (never through p->idx: the index may be gone already)
+    (void)hipDeviceSynchronize();
     for (auto& s : p->slots) {
         for (DevBuf* b : {&s.q, &s.ids, &s.scores, &s.n_valid, &s.fid, &s.fsc, &s.fail}) b->release();
         if (s.fail_host) (void)hipHostFree(s.fail_host);
@@ -161,6 +160,7 @@ extern "C" int mfar_pipeline_create(mfar_pipeline** out, mfar_index* idx, const 
     mfar_pipeline* p = new (std::nothrow) mfar_pipeline();
     if (!p) return fail(MFAR_ERR_NOMEM, "host allocation failed");
     p->idx = idx;
+    p->device = idx->device;
     p->k1 = k1;
     p->k2 = k2;
     p->sentinel = sentinel != 0;
@@ -293,5 +293,23 @@ extern "C" int mfar_pipeline_result_view(mfar_pipeline* p, int64_t ticket, const
     if (n_valid) *n_valid = s.n_valid.as<int>() + ww.off;
     if (field_ids) *field_ids = (const int64_t*)(s.fid.as<long long>() + (size_t)ww.off * fk);
     if (field_scores) *field_scores = s.fsc.as<float>() + (size_t)ww.off * fk;
+    return MFAR_OK;
+}
+
+// The batch's stage-1 lists [Q, F, k1] copied out (host: synchronous; device: on `stream`), same validity as its result.
+extern "C" int mfar_pipeline_lists(mfar_pipeline* p, int64_t ticket, int64_t* field_ids, float* field_scores, int on_device, void* stream) {
+    if (!field_ids || !field_scores) return fail(MFAR_ERR_INVALID, "output pointer is NULL");
+    const int64_t* fi = nullptr;
+    const float* fs = nullptr;
+    RETCHK(mfar_pipeline_result_view(p, ticket, nullptr, nullptr, nullptr, &fi, &fs));
+    int Q = 0;
+    for (const auto& x : p->where)
+        if (x.ticket == ticket) Q = x.Q;
+    hipStream_t st = on_device ? (hipStream_t)stream : p->st->copy;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    const size_t n = (size_t)Q * p->idx->F * p->k1;
+    HIPCHK(hipMemcpyAsync(field_ids, fi, n * 8, kind, st));
+    HIPCHK(hipMemcpyAsync(field_scores, fs, n * 4, kind, st));
+    if (!on_device) HIPCHK(hipStreamSynchronize(st));
     return MFAR_OK;
 }

@@ -101,6 +101,7 @@ SIGNATURES = {
     "mfar_pipeline_submit": (_i, [_vp, _vp, _i, _i, _vp, _c.POINTER(_i64)]),
     "mfar_pipeline_flush": (_i, [_vp]),
     "mfar_pipeline_result": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _vp]),
+    "mfar_pipeline_lists": (_i, [_vp, _i64, _vp, _vp, _i, _vp]),
     "mfar_pipeline_result_view": (_i, [_vp, _i64, _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_vp)]),
 }
 

@@ -116,6 +116,11 @@ class MultiFieldIndex:
 
     def close(self):
         if getattr(self, "_h", None):
+            for ref in getattr(self, "_pipelines", []):      # pipelines over this handle go first (mfar.data.pipeline.NativePipeline)
+                pl = ref()
+                if pl is not None:
+                    pl.close()
+            self._pipelines = []
             _native.lib().mfar_index_destroy(self._h)
             self._h = None
 

@@ -361,6 +361,10 @@ class NativePipeline:
         _native.check(_native.lib().mfar_pipeline_info(self._p, ctypes.byref(d), ctypes.byref(c), ctypes.byref(n), ctypes.byref(lag), None))
         self.depth, self.coalesce, self.Qmax, self.lag = d.value, c.value, n.value, lag.value
         self._meta = {}
+        import weakref
+        if not hasattr(index, "_pipelines"):
+            index._pipelines = []
+        index._pipelines.append(weakref.ref(self))       # the index closes its pipelines before it goes
 
     @property
     def n_redone(self) -> int:
@@ -411,3 +415,14 @@ class NativePipeline:
         _native.check(_native.lib().mfar_pipeline_result(self._p, int(ticket), ia.ptr, sa.ptr, na.ptr, int(on_dev),
                                                          _index._current_stream(self.ix.device, on_dev)))
         return dict(ids=ids, scores=sc, n_valid=nv)
+
+    def lists(self, ticket: int):
+        """The stage-1 lists of a batch whose result is still valid: (field_ids [Q, F, k1] int64, field_scores [Q, F, k1] f32), copies."""
+        import numpy as np
+        Q, on_dev = self._meta[ticket]
+        shape = (Q, self.ix.n_fields, self.k1)
+        fid = _index._empty_like_side(on_dev, self.ix.device, shape, np.int64)
+        fsc = _index._empty_like_side(on_dev, self.ix.device, shape, np.float32)
+        fa, sa = _index._Arg(fid, np.int64, self.ix.device), _index._Arg(fsc, np.float32, self.ix.device)
+        _native.check(_native.lib().mfar_pipeline_lists(self._p, int(ticket), fa.ptr, sa.ptr, int(on_dev), _index._current_stream(self.ix.device, on_dev)))
+        return fid, fsc

@@ -109,25 +109,30 @@ def _timed_path_check(idxmod, ix, corpus, W, mask, probe, first_batch=0, oracle_
     (stage-1 lists proven complete by the exhaustive torch scan, then O.c_two_stage on the union rows).  Returns the searcher."""
     import contextlib
     import torch
-    from mfar.data.pipeline import PipelinedSearcher
+    from mfar.data.pipeline import NativePipeline, PipelinedSearcher
     Q = 64
-    ps = PipelinedSearcher(ix, W, mask, max_batch=Q)
-    assert ps.depth == 3 and ps.coalesce == 2 and ps.Qmax == 128, (ps.depth, ps.coalesce, ps.Qmax)      # the bench's configuration
     halves = [corpus.queries((first_batch + j) * Q, Q) for j in range(2)]
-    tickets = [ps.submit(h) for h in halves]
-    got = []
-    for t in tickets:
-        r = {k: v.clone() for k, v in ps.result(t).items()}
-        fid, fsc = ps.lists(t)
-        r.update(field_ids=fid.clone(), field_scores=fsc.clone())
-        got.append(r)
+    refs = [ix.search(h, W, mask, return_fields=True) for h in halves]
     torch.cuda.synchronize()
-    assert ps.n_redone == 0
-    for h, g in zip(halves, got):
-        ref = ix.search(h, W, mask, return_fields=True)
+    # both faces of the pipeline: the C-ABI one (mfar_pipeline_*: what bench.py's headline and INTEGRATION.md's binding drive) and the
+    # Python one (mfar/data/pipeline.py: the row-sharded exchange and the mask sweeps build on it)
+    for cls in (NativePipeline, PipelinedSearcher):
+        ps = cls(ix, W, mask, max_batch=Q)
+        assert ps.depth == 3 and ps.coalesce == 2 and ps.Qmax == 128, (cls.__name__, ps.depth, ps.coalesce, ps.Qmax)      # the bench's configuration
+        tickets = [ps.submit(h) for h in halves]
+        got = []
+        for t in tickets:
+            r = {k: v.clone() for k, v in ps.result(t).items()}
+            fid, fsc = ps.lists(t)
+            r.update(field_ids=fid.clone(), field_scores=fsc.clone())
+            got.append(r)
         torch.cuda.synchronize()
-        for key in ("ids", "scores", "n_valid", "field_ids", "field_scores"):
-            assert torch.equal(g[key], ref[key]), ("pipelined 128-column launch vs synchronous 64-query search", key)
+        assert ps.n_redone == 0
+        for g, ref in zip(got, refs):
+            for key in ("ids", "scores", "n_valid", "field_ids", "field_scores"):
+                assert torch.equal(g[key], ref[key]), (cls.__name__, "pipelined 128-column launch vs synchronous 64-query search", key)
+        if cls is NativePipeline:
+            ps.close()
     fid, fsc = got[0]["field_ids"].cpu().numpy(), got[0]["field_scores"].cpu().numpy()
     _exhaustive_stage1_check(ix, halves[0], fid, fsc, probe)
     with (oracle_chain if oracle_chain is not None else contextlib.nullcontext()):
