@@ -164,8 +164,9 @@ def main():
     ap.add_argument("--screen", choices=["auto", "off", "on"], default="auto",
                     help="certified stage 1 (bit-identical results; csrc/mfar_screen.h): an fp32 index scans an fp16 copy of its unique "
                          "rows, a bf16 index scans its own slab with two bf16 query terms; auto = from 16 384 rows, on = always")
-    ap.add_argument("--corpus", choices=["plain", "structured"], default="plain",
-                    help="structured: realistic duplicate / norm structure in three of the fields (mfar/synth.py)")
+    ap.add_argument("--corpus", choices=["plain", "structured", "clustered"], default="plain",
+                    help="structured: realistic duplicate / norm structure in three of the fields; clustered: every field made of clusters of "
+                         "~235 near-duplicate, non-identical rows -- the certified screen's worst case (mfar/synth.py)")
     ap.add_argument("--empty-frac", type=float, default=0.08,
                     help="share of (document, field) pairs that hold the field's empty-text vector (real STaRK fields are sparse; "
                          "0.08 = the headline corpus)")
@@ -284,7 +285,8 @@ def main():
     n_q_total = max(Q, min(max(4096, (args.steps + args.warmup) * Q), 65536, D // 16))
     t_build0 = time.time()
     corpus = synth.SyntheticCorpus(D, F, E, n_queries=n_q_total, seed=0xDEADBEEF, device=str(dev),
-                                   structured=(args.corpus == "structured"), empty_frac=args.empty_frac)
+                                   structured=(args.corpus == "structured"), empty_frac=args.empty_frac,
+                                   field_kinds=(["clustered"] * F if args.corpus == "clustered" else None))
     W = corpus.W
     mask = torch.ones(F, device=dev)
     torch.cuda.synchronize()
@@ -548,6 +550,7 @@ def main():
                         "certified pass over the bf16 slab itself (two bf16 query terms, no second copy of the rows; min(k+92,192) unique rows per "
                         "list re-scored with the exact natural-order chain, top-k proven or redone by the exact pass per field)") if screened else
                        ("exact fp32 MFMA pass" if args.dtype == "f32" else "bf16 slab pass")),
+            "adaptive": ix.auto_off_info(),
             "screen": ({"lists_certified": (scr["n_checked"] - scr0["n_checked"]) - (scr["n_failed"] - scr0["n_failed"]),
                         "lists_redone_exactly": scr["n_failed"] - scr0["n_failed"], "batches_redone": n_redone_main,
                         "screen_slab_bytes": scr["screen_bytes"], "unique_rows_per_field": scr.get("unique_rows")} if screened else None),

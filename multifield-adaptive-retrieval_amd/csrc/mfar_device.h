@@ -30,6 +30,9 @@ struct ScreenField {
     float row_mode;      // != 0: heavy-tailed row norms (dnorm_max > 1.5 dnorm_mean): the screened pass ranks rows by their UPPER bound
                          // approx + eps(row norm) instead of approx, and the certificate needs no global norm (mfar_screen.h "ROW MODE")
 };
+// u_of entries of an fp32 index (mfar_screen.h mfar_uof_norm_code_kernel): low 22 bits = unique number + 1, top 10 bits = norm code
+#define UOF_NORM_SHIFT 22
+#define UOF_INDEX_MASK ((1u << UOF_NORM_SHIFT) - 1u)
 struct ScreenQuery {     // per query of the current block of 64 / 128 queries (mfar_screen_queries_kernel)
     float scale, inv_scale, norm, pad;
 };

@@ -122,7 +122,7 @@ struct mfar_index {
         int dump_Q = 0;
         DevBuf qt16, qinfo, eps, base, fail, sids, ssc, scnt, sx;        // fp16 screen
         DevBuf arow, eps_cert;                                          // ... ROW MODE: per (field, query) factor of the row norm / what is left of eps
-        DevBuf dinv, dstep, eps_dump;                                   // ... SCORE DUMP: 1 / B, B / 32767 and the approximate level's bound per (field, query)
+        DevBuf dinv, dstep, eps_dump, darel;                            // ... SCORE DUMP: 1 / B, B / 32767, the approximate level's bound per (field, query), its row-norm share
         bool screened = false;                                          // decided by the begin phase of the batch
         int qw = 64;                                                    // query columns of the batch's pass (128: wide screen pass)
         // AUTO-OFF, latched by the begin phase: fields whose lists the exact pass writes in this batch / fields its screen leaves out
@@ -149,6 +149,7 @@ struct mfar_index {
     int stage2_mode = 1;          // 0 = gather every (candidate, field) row from the fp32 slab; 1 = certified two-level stage 2 when available
     DevBuf xa[MFAR_SLOTS], cand2[MFAR_SLOTS], ncand2[MFAR_SLOTS], s2qm[MFAR_SLOTS], s2eps[MFAR_SLOTS], s2stats;   // two-level stage 2 scratch (per pipeline slot) + counters
     DevBuf kmask[MFAR_SLOTS], src2[MFAR_SLOTS];                      // ... known pairs (stage-1 scores reused), survivor -> candidate index
+    DevBuf xe[MFAR_SLOTS];                                           // ... per-pair bounds of the score dump's level (row norms)
     // certified fp16 screen of an fp32 index (mfar_screen.h)
     int screen_mode = 1;          // 0 off, 1 auto, 2 always (when the shapes allow)
     float screen_eps_mult = 1.0f; // test knob: scales the certificate's error bound
@@ -174,6 +175,7 @@ struct mfar_index {
     // bf16 index: the certified pass scans the slab itself (no screen slab) and ranks unique rows through these (mfar_screen.h)
     DevBuf rep_bits;              // [F][n_blk] u64: row is real and the representative of its group
     DevBuf u_of;                  // [F][n_rows] u32: unique number + 1 of the row's group (every row, when u_repof exists; else representatives only)
+    bool uof_packed = false;      // fp32 index: the entries carry a 10-bit row-norm code in their top bits (mfar_uof_norm_code_kernel)
     bool screen_built = false;    // statistics + unique-row tables (+ the fp16 screen slab of an fp32 index) were built at least once
     std::vector<int> n_unique, largest_group;   // per field (host copies)
     bool screen_dedup = true;     // MFAR_SCREEN_DEDUP=0: every document is its own unique row (diagnostic)
@@ -368,7 +370,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
                       &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->s2stats, &idx->rep_bits, &idx->u_of, &idx->s_field1, &idx->s_cvt, &idx->dump_base, &idx->s_rnorm, &idx->s_nsum};
     for (int i = 0; i < MFAR_SLOTS; ++i)
         for (DevBuf* b : {&idx->cand[i], &idx->ncand[i], &idx->x[i], &idx->own[i], &idx->xa[i], &idx->cand2[i], &idx->ncand2[i], &idx->s2qm[i],
-                          &idx->s2eps[i], &idx->kmask[i], &idx->src2[i]})
+                          &idx->s2eps[i], &idx->kmask[i], &idx->src2[i], &idx->xe[i]})
             b->release();
     for (S1Geom* g : {&idx->geom_docs, &idx->geom_screen})
         for (S1Table* t : {&g->all, &g->solo, &g->all_w, &g->solo_w, &g->all_skip, &g->all_w_skip}) {
@@ -385,7 +387,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
         if (sl.fb_ev) (void)hipEventDestroy(sl.fb_ev);
         sl.off_flags.release();
         sl.chain.release();
-        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.lists2, &sl.list_cnt2, &sl.unit_ctr, &sl.dump, &sl.arow, &sl.eps_cert, &sl.dinv, &sl.dstep, &sl.eps_dump, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
+        DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.lists2, &sl.list_cnt2, &sl.unit_ctr, &sl.dump, &sl.arow, &sl.eps_cert, &sl.dinv, &sl.dstep, &sl.eps_dump, &sl.darel, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
                         &sl.ssc, &sl.scnt, &sl.sx};
         for (DevBuf* b : sb) b->release();
     }
@@ -1275,6 +1277,17 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
             g_err.clear();
             idx->row_mask = idx->row_eligible = 0;     // no table: every field keeps its field-wide bound (ScreenField::row_mode is ignored without arow)
         }
+        // every row's norm as a 10-bit code inside its u_of entry (the score dump's look-up reads the entry anyway: per-row bounds for free)
+        idx->uof_packed = false;
+        if (idx->u_of.p && *std::max_element(idx->n_unique.begin(), idx->n_unique.end()) < (int)UOF_INDEX_MASK - 1) {
+            for (int f = 0; f < F; ++f) {
+                mfar_uof_norm_code_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(
+                    n, rnorm_doc.p ? rnorm_doc.as<float>() + (size_t)f * n : nullptr, idx->s_field.as<ScreenField>() + f, idx->u_of.as<u32>() + (size_t)f * n);
+                HIPCHK(hipGetLastError());
+            }
+            HIPCHK(hipStreamSynchronize(st));
+            idx->uof_packed = true;
+        }
         rnorm_doc.release();
     }
     // pass 3: the fp16 rows
@@ -1471,7 +1484,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         sl.dump_on = sl.qw == 128 && !bf16 && f0 == 0 && nf == idx->F && q0 == 0 && Q <= 128 && sl.skip_mask == 0 && dump_wanted(idx, k);
         sl.dump_ready = false;
         if (sl.dump_on && (sl.dump.ensure(idx->screen_used / 2 / (size_t)idx->E * 256, true) != MFAR_OK || sl.dinv.ensure((size_t)F * 128 * 4) != MFAR_OK ||
-                           sl.dstep.ensure((size_t)F * 128 * 4) != MFAR_OK || sl.eps_dump.ensure((size_t)F * 128 * 4) != MFAR_OK)) {
+                           sl.dstep.ensure((size_t)F * 128 * 4) != MFAR_OK || sl.eps_dump.ensure((size_t)F * 128 * 4) != MFAR_OK || sl.darel.ensure((size_t)F * 128 * 4) != MFAR_OK)) {
             (void)hipGetLastError();
             g_err.clear();
             sl.dump_on = false;
@@ -1544,7 +1557,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
                                                                        sl.eps.as<float>(), sl.base.as<float>(), fflags, q0, Q, idx->E, F,
                                                                        idx->screen_eps_mult, qw, bf16 ? 1 : 0, row_mode ? sl.arow.as<float>() : nullptr,
                                                                        row_mode ? sl.eps_cert.as<float>() : nullptr, sl.row_mask,
-                                                                       sl.dump_on ? sl.dinv.as<float>() : nullptr, sl.dstep.as<float>(), sl.eps_dump.as<float>());
+                                                                       sl.dump_on ? sl.dinv.as<float>() : nullptr, sl.dstep.as<float>(), sl.eps_dump.as<float>(), sl.darel.as<float>());
         HIPCHK(hipGetLastError());
     }
     // lists of unique-row numbers (fp32 index: rows of the screen slab) / of the local rows of group representatives (bf16 index:
@@ -2160,6 +2173,11 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
         S2LookupParams lp = {};
         lp.dump = sl.dump.as<unsigned short>();
         lp.dump_step = sl.dstep.as<float>();
+        RETCHK(idx->xe[slot].ensure((size_t)Q * C * F * 4));
+        lp.eps_dump = sl.eps_dump.as<float>();
+        lp.dump_arel = sl.darel.as<float>();
+        lp.xe = idx->xe[slot].as<float>();
+        lp.uof_packed = idx->uof_packed ? 1 : 0;
         lp.dump_base = idx->dump_base.as<long long>();
         lp.cand = cand;
         lp.n_cand = ncand;
@@ -2186,6 +2204,7 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
     pr.cand = cand;
     pr.n_cand = ncand;
     pr.eps = pp.eps;
+    pr.xe = from_dump ? idx->xe[slot].as<float>() : nullptr;
     pr.q = qd;
     pr.W = Wd;
     pr.masks = masks;

@@ -119,6 +119,22 @@ __global__ void __launch_bounds__(256) mfar_rownorm_gather_kernel(const float* _
     if (u < n_pad) out[u] = u < n_unique ? rnorm[urep[u]] : 0.0f;
 }
 
+// fp32 index: the centred 2-norm of every row, as a 10-bit code in the top bits of its u_of entry (unique number + 1 < 2^22):
+// |c_row| <= dnorm_max * (code + 1) / 1024.  The score dump's look-up reads the entry anyway and gets a PER-ROW error bound for free
+// (mfar_select.h mfar_s2_lookup_kernel).  Rows without a norm (no table) keep code 1023 = the field-wide bound.
+__global__ void __launch_bounds__(256) mfar_uof_norm_code_kernel(long long n, const float* __restrict__ rnorm, const ScreenField* __restrict__ sf,
+                                                                 u32* __restrict__ uof) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 code = 1023u;
+    const float dmax = sf->dnorm_max;
+    if (rnorm && dmax > 0.0f && dmax < __builtin_inff()) {
+        const float x = rnorm[i] * (1024.0f / dmax) * 1.0001f;       // code + 1 >= x  =>  the coded norm is an upper bound
+        if (x >= 0.0f && x < 1023.0f) code = (u32)x;
+    }
+    uof[i] = (uof[i] & UOF_INDEX_MASK) | (code << UOF_NORM_SHIFT);
+}
+
 // power-of-two scale that puts `amax` into [2^13, 2^14); 1 for zero / non-finite input
 __device__ __forceinline__ float screen_pow2_scale(float amax) {
     const u32 b = __float_as_uint(amax) & 0x7FFFFFFFu;
@@ -308,7 +324,8 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
                                                                   int* __restrict__ fail_flags, int q0, int Q, int E, int F,
                                                                   float eps_mult, int qw, int direct, float* __restrict__ arow,
                                                                   float* __restrict__ eps_cert, u32 row_mask, float* __restrict__ dump_inv,
-                                                                  float* __restrict__ dump_step, float* __restrict__ eps_dump) {
+                                                                  float* __restrict__ dump_step, float* __restrict__ eps_dump,
+                                                                  float* __restrict__ dump_arel) {
     __shared__ float red_a[4], red_s[4];
     const int r = blockIdx.x;
     // a new batch: clear the certificate flags of the fields and the "any" flag ([MFAR_MAX_FIELDS + 1] keeps accumulating statistics)
@@ -419,6 +436,9 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
             dump_inv[f * qw + r] = live && B > 0.0f && B < __builtin_inff() ? 1.0f / B : 0.0f;
             dump_step[f * qw + r] = live && B > 0.0f ? B * (1.0f / 32767.0f) : 0.0f;        // (B = inf: codes 0 x inf = NaN = "unknown", survives)
             eps_dump[f * qw + r] = e_ + eps_mult * SCREEN_SLACK * 1.03f * qn * s.dnorm_max * (1.0f / 65534.0f);
+            // the part of the bound that follows the ROW's norm, per 1/1024 of the field's largest: a row whose coded norm is
+            // (code + 1) / 1024 of it gets eps_dump - dump_arel * (1023 - code)   (0.9999: the subtraction's own rounding)
+            dump_arel[f * qw + r] = live ? 0.9999f * eps_mult * SCREEN_SLACK * c_rel * qn * s.dnorm_max * (1.0f / 1024.0f) : 0.0f;
         }
         // starting threshold of the screened pass: none for live queries (the zero sentinel of index.py:192-193 is applied
         // to the EXACT scores by the certify kernel; deciding it here would need q.m on the critical path), +inf for the

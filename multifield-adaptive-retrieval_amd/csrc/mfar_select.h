@@ -1117,6 +1117,10 @@ __global__ void __launch_bounds__(256) mfar_s2_prep_kernel(const S2PrepParams p)
 struct S2LookupParams {
     const unsigned short* dump;    // [row pairs of the screen slab][128][2] signed-normalised 16-bit codes (S1Params::dump)
     const float* dump_step;        // [F, 128] B / 32767: code -> scaled units
+    const float* eps_dump;         // [F, 128] the level's field-wide bound (real units)
+    const float* dump_arel;        // [F, 128] its row-norm share per 1/1024 of the field's largest norm
+    float* xe;                     // [Q, C, F] out: the PER-PAIR bound, from the 10-bit norm code in the pair's u_of entry
+    int uof_packed;                // the entries carry norm codes (else: plain unique numbers, field-wide bound)
     const long long* dump_base;    // [F] first row of a field
     const long long* cand;         // [Q, C]
     const int* n_cand;             // [Q]
@@ -1140,7 +1144,10 @@ __global__ void __launch_bounds__(256) mfar_s2_lookup_kernel(const S2LookupParam
         if (p.kmask && ((p.kmask[(size_t)qi * p.C + c] >> f) & 1u)) return;       // exact already
         const long long id = p.cand[(size_t)qi * p.C + c] - p.row_offset;
         if (id >= 0 && id < p.n_rows) {
-            const long long u = (long long)p.uof[(size_t)f * p.ustride + id] - 1;        // the row's group (mfar_uof_all_kernel)
+            const u32 ent = p.uof[(size_t)f * p.ustride + id];                            // the row's group (mfar_uof_all_kernel) + norm code
+            const long long u = (long long)(p.uof_packed ? (ent & UOF_INDEX_MASK) : ent) - 1;
+            const u32 code = p.uof_packed ? (ent >> UOF_NORM_SHIFT) : 1023u;
+            p.xe[(size_t)qi * p.C * p.F + idx] = p.eps_dump[f * 128 + qi] - p.dump_arel[f * 128 + qi] * (float)(1023u - code);
             const size_t ru = (size_t)p.dump_base[f] + (size_t)u;
             const float a = (float)(short)p.dump[(ru >> 1) * 256 + (size_t)qi * 2 + (ru & 1)] * p.dump_step[f * 128 + qi];
             o = (a * p.qinfo[qi].inv_scale) * p.sf[f].inv_scale + p.qm[(size_t)qi * MFAR_MAX_FIELDS + f];
@@ -1192,6 +1199,7 @@ struct PruneParams {
     const long long* cand;   // [Q, C] sorted unique candidate ids (< 0 = empty)
     const int* n_cand;       // [Q]
     const float* eps;        // [Q, MFAR_MAX_FIELDS]
+    const float* xe;         // [Q, C, F] or nullptr: per-PAIR bounds (the score dump's level: row norms), used instead of eps
     const float* q;          // [Q, E]
     const float* W;          // [E, F] or [F]
     const float* masks;      // [n_masks, F] or nullptr (ones)
@@ -1235,10 +1243,11 @@ __global__ void __launch_bounds__(256) mfar_s2_prune_kernel(const PruneParams p)
             const long long id = cq[c];
             if (id < 0) continue;
             const float* xr = xq + (size_t)c * p.F;
+            const float* er = p.xe ? p.xe + ((size_t)qi * p.C + c) * p.F : nullptr;
             const u32 km = p.kmask ? p.kmask[(size_t)qi * p.C + c] : 0u;
             float acc = 0.0f;
             for (int f = 0; f < p.F; ++f) {
-                const float v = xr[f], e = ((km >> f) & 1u) ? 0.0f : eps_s[f], mf = msk[f];
+                const float v = xr[f], e = ((km >> f) & 1u) ? 0.0f : (er ? er[f] : eps_s[f]), mf = msk[f];
                 const float end = mf >= 0.0f ? s2_nextdown(v - e) : s1_nextup(v + e);
                 acc = __builtin_fmaf(wgt[f], end * mf, acc);
             }
@@ -1252,10 +1261,11 @@ __global__ void __launch_bounds__(256) mfar_s2_prune_kernel(const PruneParams p)
         for (int c = threadIdx.x; c < nc; c += blockDim.x) {
             if (cq[c] < 0 || surv[c]) continue;
             const float* xr = xq + (size_t)c * p.F;
+            const float* er = p.xe ? p.xe + ((size_t)qi * p.C + c) * p.F : nullptr;
             const u32 km = p.kmask ? p.kmask[(size_t)qi * p.C + c] : 0u;
             float acc = 0.0f;
             for (int f = 0; f < p.F; ++f) {
-                const float v = xr[f], e = ((km >> f) & 1u) ? 0.0f : eps_s[f], mf = msk[f];
+                const float v = xr[f], e = ((km >> f) & 1u) ? 0.0f : (er ? er[f] : eps_s[f]), mf = msk[f];
                 const float end = mf >= 0.0f ? s1_nextup(v + e) : s2_nextdown(v - e);
                 acc = __builtin_fmaf(wgt[f], end * mf, acc);
             }

@@ -1,13 +1,13 @@
 # on the GPU box: rocprofv3 evidence for the default bench -> gpurun_out/prof_round/   (copy what is to be judged into profiles/)
-#   bash tools/prof_round.sh            (~6 GPU-minutes)
+#   bash tools/prof_round.sh            (~15 GPU-minutes)
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_round; mkdir -p $O
 B="--no-cpu-baseline --no-extra-legs"
 # the driver-shaped run (every leg, BASELINE config legs included) and the default 64-step run
-python $R/bench.py --steps 20 --warmup 3 > $O/bench_driver_shape.json 2> $O/bench.err
+python $R/bench.py --steps 20 --warmup 5 > $O/bench_driver_shape.json 2> $O/bench.err      # the driver's command, every leg
 python $R/bench.py --no-cpu-baseline --no-config-legs > $O/bench.json 2>> $O/bench.err
-python $R/bench.py > $O/bench_default.json 2>> $O/bench.err        # exactly what the driver runs at N = 1
+python $R/bench.py --no-encode-leg > $O/bench_default.json 2>> $O/bench.err        # `python bench.py` (64 steps) without the 60 s encode leg
 line() { python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); r=d['roofline']; c=d['config']
@@ -26,12 +26,15 @@ for scr in auto off; do
   python $R/bench.py $B --dtype bf16 --screen $scr 2>> $O/bench.err | line "bf16 screen=$scr" >> $O/shapes.txt
 done
 # the STaRK-prime shape with sparse fields (most documents lack most of its 22 fields), the structured field kinds, no score dump
-for extra in "--empty-frac 0.7" "--empty-frac 0.9" "--corpus structured"; do
+for extra in "--empty-frac 0.7" "--empty-frac 0.9" "--corpus structured" "--corpus clustered"; do
   python $R/bench.py $B --docs 129375 --fields 22 $extra 2>> $O/bench.err | line "$extra" >> $O/shapes.txt
 done
 MFAR_S2_DUMP=0 python $R/bench.py $B --docs 129375 --fields 22 2>> $O/bench.err | line "MFAR_S2_DUMP=0" >> $O/shapes.txt
 python $R/bench.py $B --screen off 2>> $O/bench.err | line "--screen off" >> $O/shapes.txt
 python $R/bench.py $B --coalesce 1 2>> $O/bench.err | line "--coalesce 1" >> $O/shapes.txt
+python $R/bench.py $B --pipeline python 2>> $O/bench.err | line "--pipeline python" >> $O/shapes.txt
+python $R/bench.py $B --corpus clustered --steps 256 2>> $O/bench.err | line "--corpus clustered" >> $O/shapes.txt
+python $R/bench.py $B --corpus clustered --steps 256 --screen off 2>> $O/bench.err | line "--corpus clustered --screen off" >> $O/shapes.txt
 # kernel trace + stats of the default leg alone (the extra legs launch the same kernels on other shapes and would skew the averages)
 rocprofv3 --kernel-trace --stats -d /tmp/kt -o r1 --output-format csv -- python $R/bench.py --steps 16 --warmup 2 $B > $O/bench_under_rocprof.json 2>/dev/null
 # counters: one pass each; default leg, then the exact fp32 pass (--screen off) into a sub-directory of the same pass
