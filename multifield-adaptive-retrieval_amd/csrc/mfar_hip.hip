@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "mfar_hip.h"
+#include "mfar_policy.h"
 #include "mfar_select.h"
 #include "mfar_screen.h"
 #include "mfar_exact16.h"
@@ -181,20 +182,7 @@ struct mfar_index {
     bool screen_dedup = true;     // MFAR_SCREEN_DEDUP=0: every document is its own unique row (diagnostic)
     bool wide = true;             // blocks of 65 .. 128 queries go through the wide screened pass (MFAR_WIDE=0: always 64 per pass)
     bool repair_sample = false;   // mfar_set_repair_mode: repairs run their own sample pass (see stage1_pass)
-    // AUTO-OFF (see "adaptive policy" below): fields whose certificates keep failing are scanned by the exact pass only
-    struct AutoOff {
-        int mode = 1;             // 0 never, 1 auto.  MFAR_SCREEN_AUTO_OFF
-        int off_fails = 12;       // a field is switched off when this many of its last 16 screened launches failed
-        int probe_every = 64;     // every n-th screened launch also screens the switched-off fields (quietly: the exact pass's lists stand)
-        int on_clean = 2;         // consecutive clean probes that switch a field back on
-        unsigned short hist[MFAR_MAX_FIELDS] = {0};
-        unsigned char clean[MFAR_MAX_FIELDS] = {0};
-        unsigned short any_hist = 0;
-        int any_n = 0;
-        long long launches = 0, n_off = 0, n_on = 0, n_probes = 0;
-    } ao;
-    u32 off_mask = 0;             // fields that are switched off now
-    bool inline_repair = false;   // failures are frequent: mfar_stage1_finish repairs on the device even when asked to report only
+    ScreenPolicy pol;             // AUTO-OFF, inline repair (mfar_policy.h): fed with the certificate flags of finished launches
     S1Geom geom_docs, geom_screen;
     // fused mode (mfar_search_fused): a one-field companion index of dim F * E over the same rows, built on first use
     mfar_index* fused = nullptr;
@@ -332,7 +320,7 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     if (const char* e = getenv("MFAR_STAGE2_PRUNE")) idx->stage2_mode = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MFAR_S2_DUMP")) idx->dump_mode = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("MFAR_SCREEN_ROW_MODE")) idx->row_mode_setting = std::max(0, std::min(2, atoi(e)));
-    if (const char* e = getenv("MFAR_SCREEN_AUTO_OFF")) idx->ao.mode = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("MFAR_SCREEN_AUTO_OFF")) idx->pol.set_mode(atoi(e) != 0 ? 1 : 0);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) idx->n_cu = prop.multiProcessorCount;
     hipError_t e = hipMalloc(&idx->slab, idx->slab_bytes);
@@ -1405,39 +1393,9 @@ static void consume_feedback(mfar_index* idx) {
     for (auto& sl : idx->s1) {
         if (!sl.fb_pending || hipEventQuery(sl.fb_ev) != hipSuccess) continue;
         sl.fb_pending = false;
-        mfar_index::AutoOff& a = idx->ao;
         const int* h = sl.fb_host;
-        for (int f = 0; f < idx->F; ++f) {
-            const u32 bit = 1u << f;
-            if (sl.fb_screened & bit) {
-                a.hist[f] = (unsigned short)((a.hist[f] << 1) | (h[f] ? 1 : 0));
-                // (a bf16 index repairs with the VALU chain pass, ~30x a screened scan: switching a field off saves only the screen's share,
-                //  so it takes a field that fails EVERY launch)
-                const int off_fails = idx->dtype == MFAR_DTYPE_BF16 ? 16 : a.off_fails;
-                if (a.mode && !(idx->off_mask & bit) && __builtin_popcount(a.hist[f]) >= off_fails) {
-                    idx->off_mask |= bit;
-                    a.clean[f] = 0;
-                    a.n_off++;
-                }
-            }
-            if ((sl.fb_probed & bit) && (idx->off_mask & bit)) {
-                if (h[MFAR_MAX_FIELDS + 2 + f]) a.clean[f] = 0;
-                else if (++a.clean[f] >= a.on_clean) {
-                    idx->off_mask &= ~bit;
-                    a.hist[f] = 0;
-                    a.n_on++;
-                }
-            }
-        }
-        if (sl.fb_screened) {
-            const bool any = h[MFAR_MAX_FIELDS] != 0;
-            a.any_hist = (unsigned short)((a.any_hist << 1) | (any ? 1 : 0));
-            a.any_n = std::min(16, a.any_n + 1);
-            const int n_bad = __builtin_popcount(a.any_hist);
-            if (n_bad >= 4) idx->inline_repair = true;
-            else if (n_bad <= 1 && a.any_n >= 16) idx->inline_repair = false;
-            if (any && idx->row_mode_setting == 1) idx->row_mask = idx->row_eligible;
-        }
+        const bool failed = idx->pol.feed(idx->F, h, h + MFAR_MAX_FIELDS + 2, h[MFAR_MAX_FIELDS], sl.fb_screened, sl.fb_probed, idx->dtype == MFAR_DTYPE_BF16);
+        if (failed && idx->row_mode_setting == 1) idx->row_mask = idx->row_eligible;       // ROW MODE for heavy-tailed fields (mfar_screen.h)
     }
 }
 // behind the certify kernel of a batch: its flags -> pinned host memory, event behind the copy
@@ -1473,12 +1431,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         sl.qw = (screened && wide_ok(idx) && Q - q0 > 64) ? 128 : 64;
         // AUTO-OFF (all-fields passes of an fp32 index): which fields the exact pass writes / the screen leaves out in this batch
         sl.exact_mask = sl.skip_mask = 0;
-        if (screened && f0 == 0 && nf == idx->F && idx->ao.mode) {
-            sl.exact_mask = idx->off_mask & (F >= 32 ? 0xFFFFFFFFu : ((1u << F) - 1u));
-            const bool probe = sl.exact_mask != 0 && ++idx->ao.launches % idx->ao.probe_every == 0;
-            if (probe) idx->ao.n_probes++;
-            sl.skip_mask = probe ? 0u : sl.exact_mask;
-        }
+        if (screened && f0 == 0 && nf == idx->F) idx->pol.plan(F, &sl.exact_mask, &sl.skip_mask);
         // the wide pass of an fp32 index over all fields may leave its scores behind for stage 2 (one block of queries: the dump holds
         // the launch that wrote it last; a launch that leaves fields out has no scores for them)
         sl.dump_on = sl.qw == 128 && !bf16 && f0 == 0 && nf == idx->F && q0 == 0 && Q <= 128 && sl.skip_mask == 0 && dump_wanted(idx, k);
@@ -1773,7 +1726,7 @@ extern "C" int mfar_stage1_finish(mfar_index* idx, const float* q, int Q, int k,
     if (!field_ids || !field_scores) return fail(MFAR_ERR_INVALID, "output pointer is NULL");
     HIPCHK(hipSetDevice(idx->device));
     // failures are frequent on this data (adaptive policy above): repair on the device, report a clean batch
-    const bool inline_rep = any_fail && idx->inline_repair;
+    const bool inline_rep = any_fail && idx->pol.inline_repair;
     RETCHK(stage1_block(idx, slot, S1_CERTIFY | (merge_in_finish() ? S1_FINISH : 0), q, Q, 0, k, sentinel, 0, idx->F, (long long*)field_ids,
                         field_scores, inline_rep ? nullptr : (int*)any_fail, (hipStream_t)stream));
     if (inline_rep) HIPCHK(hipMemsetAsync(any_fail, 0, 4, (hipStream_t)stream));
@@ -1783,10 +1736,9 @@ extern "C" int mfar_stage1_finish(mfar_index* idx, const float* q, int Q, int k,
 extern "C" int mfar_set_auto_off(mfar_index* idx, int mode, int off_fails, int probe_every) {
     if (!idx || mode < 0 || mode > 1 || off_fails < 0 || off_fails > 16 || probe_every < 0)
         return fail(MFAR_ERR_INVALID, "mode must be 0 or 1, off_fails in [0, 16] (0 = default), probe_every >= 0 (0 = default)");
-    idx->ao.mode = mode;
-    if (off_fails) idx->ao.off_fails = off_fails;
-    if (probe_every) idx->ao.probe_every = std::max(2, probe_every);
-    if (mode == 0) idx->off_mask = 0;
+    idx->pol.set_mode(mode);
+    if (off_fails) idx->pol.off_fails = off_fails;
+    if (probe_every) idx->pol.probe_every = std::max(2, probe_every);
     return MFAR_OK;
 }
 extern "C" int mfar_auto_off_info(mfar_index* idx, uint32_t* off_fields, int64_t* n_switched_off, int64_t* n_switched_on, int64_t* n_probes,
@@ -1794,11 +1746,11 @@ extern "C" int mfar_auto_off_info(mfar_index* idx, uint32_t* off_fields, int64_t
     if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
     HIPCHK(hipSetDevice(idx->device));
     consume_feedback(idx);
-    if (off_fields) *off_fields = idx->off_mask;
-    if (n_switched_off) *n_switched_off = idx->ao.n_off;
-    if (n_switched_on) *n_switched_on = idx->ao.n_on;
-    if (n_probes) *n_probes = idx->ao.n_probes;
-    if (inline_repair) *inline_repair = idx->inline_repair ? 1 : 0;
+    if (off_fields) *off_fields = idx->pol.off_mask;
+    if (n_switched_off) *n_switched_off = idx->pol.n_off;
+    if (n_switched_on) *n_switched_on = idx->pol.n_on;
+    if (n_probes) *n_probes = idx->pol.n_probes;
+    if (inline_repair) *inline_repair = idx->pol.inline_repair ? 1 : 0;
     return MFAR_OK;
 }
 

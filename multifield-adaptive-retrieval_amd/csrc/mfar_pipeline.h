@@ -86,7 +86,7 @@ static int pipe_launch(mfar_pipeline* p) {
     HIPCHK(hipStreamWaitEvent(side, s.stage1, 0));
     // finish REPORTS a failed certificate (read in pipe_check); when failures are frequent the library repairs on the device instead and
     // switches fields that keep failing off (mfar_hip.hip "adaptive policy"): nothing here latches
-    const bool inline_rep = idx->inline_repair;
+    const bool inline_rep = idx->pol.inline_repair;
     RETCHK(stage1_block(idx, slot, S1_CERTIFY | (merge_in_finish() ? S1_FINISH : 0), s.q.as<float>(), Q, 0, p->k1, p->sentinel, 0, idx->F,
                         s.fid.as<long long>(), s.fsc.as<float>(), inline_rep ? nullptr : s.fail.as<int>(), side));
     if (inline_rep) HIPCHK(hipMemsetAsync(s.fail.p, 0, 4, side));

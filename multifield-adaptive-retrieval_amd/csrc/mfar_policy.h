@@ -1,0 +1,83 @@
+// mfar_policy.h -- the adaptive policy of the certified screen as a host-only state machine (plain C++: mfar_hip.hip drives it from the
+// certificate flags of finished launches; tests/host/policy_sim.cpp runs it on the CPU under ASan / UBSan, tests/test_host_policy.py).
+//
+// The certificate is data dependent.  A list fails when more than k' - k of its field's unique rows sit within ~2 eps of the k-th best score:
+// clusters of near-duplicate rows (not bit-identical, so the unique-row build keeps them apart) do that list after list, and every failure
+// costs the exact pass of that field ON TOP of the screen; a caller that only asked for a report also pays a pipeline drain and a second
+// launch.  Three decisions bound the worst case at the price of the exact pass; none of them latches, none changes a result bit:
+//   * AUTO-OFF, per field: >= off_fails failures in the field's last 16 screened launches -> the field is switched off (the screen's chunk
+//     table leaves it out, the exact pass writes its lists from the begin phase).  Every probe_every-th launch that has a switched-off field
+//     screens it anyway (a PROBE: certificate evaluated, lists discarded); on_clean clean probes in a row switch it back on.
+//   * inline repair: >= 4 of the last 16 screened launches had a failure among the fields that were ON -> mfar_stage1_finish repairs on the
+//     device even when asked to report only; <= 1 of the last 16 (a full window) -> back to reporting.
+//   * the first observed failure tells the caller to activate ROW MODE for eligible fields (feed() returns true).
+#pragma once
+#include <cstdint>
+
+#define MFAR_POLICY_MAX_FIELDS 32
+struct ScreenPolicy {
+    int mode = 1;             // 0 never switch a field off, 1 auto
+    int off_fails = 12;       // failures of the last 16 screened launches that switch a field off
+    int probe_every = 64;     // launches (with a switched-off field) between probes
+    int on_clean = 2;         // consecutive clean probes that switch a field back on
+    unsigned short hist[MFAR_POLICY_MAX_FIELDS] = {0};      // per field: 1 = failed, newest in bit 0
+    unsigned char clean[MFAR_POLICY_MAX_FIELDS] = {0};
+    unsigned short any_hist = 0;
+    int any_n = 0;
+    long long launches = 0, n_off = 0, n_on = 0, n_probes = 0;
+    uint32_t off_mask = 0;    // fields that are switched off now
+    bool inline_repair = false;
+
+    // Begin of a screened all-fields launch over F fields: *exact = fields whose lists the exact pass writes in this launch, *skip = fields
+    // its screen leaves out (equal, except in a probe launch, which screens everything).
+    void plan(int F, uint32_t* exact, uint32_t* skip) {
+        const uint32_t all = F >= 32 ? 0xFFFFFFFFu : ((1u << F) - 1u);
+        *exact = mode ? (off_mask & all) : 0u;
+        bool probe = false;
+        if (*exact) {
+            probe = ++launches % probe_every == 0;
+            if (probe) n_probes++;
+        }
+        *skip = probe ? 0u : *exact;
+    }
+
+    // The flags of a FINISHED launch: flags[f] != 0 = a list of field f failed (fields in `screened`: screened for real, i.e. ON at the
+    // time), probe_flags[f] != 0 = the quiet probe of switched-off field f failed (fields in `probed`), any != 0 = some ON field failed.
+    //   strict   a field is only switched off when it failed in ALL of its last 16 launches (bf16 indexes: their exact pass is the VALU
+    //            chain pass, ~30x a screened scan, so switching off saves only the screen's share)
+    // Returns true when the launch had a failure among the ON fields.
+    bool feed(int F, const int* flags, const int* probe_flags, int any, uint32_t screened, uint32_t probed, bool strict) {
+        for (int f = 0; f < F && f < MFAR_POLICY_MAX_FIELDS; ++f) {
+            const uint32_t bit = 1u << f;
+            if (screened & bit) {
+                hist[f] = (unsigned short)((hist[f] << 1) | (flags[f] ? 1 : 0));
+                const int need = strict ? 16 : off_fails;
+                if (mode && !(off_mask & bit) && __builtin_popcount(hist[f]) >= need) {
+                    off_mask |= bit;
+                    clean[f] = 0;
+                    n_off++;
+                }
+            }
+            if ((probed & bit) && (off_mask & bit)) {
+                if (probe_flags[f]) clean[f] = 0;
+                else if (++clean[f] >= on_clean) {
+                    off_mask &= ~bit;
+                    hist[f] = 0;
+                    n_on++;
+                }
+            }
+        }
+        if (!screened) return false;
+        any_hist = (unsigned short)((any_hist << 1) | (any ? 1 : 0));
+        if (any_n < 16) any_n++;
+        const int n_bad = __builtin_popcount(any_hist);
+        if (n_bad >= 4) inline_repair = true;
+        else if (n_bad <= 1 && any_n >= 16) inline_repair = false;
+        return any != 0;
+    }
+
+    void set_mode(int m) {
+        mode = m;
+        if (!m) off_mask = 0;
+    }
+};
