@@ -125,3 +125,42 @@ def test_native_pipeline_equals_search(idxmod=None):
             assert np.array_equal(gi, w["ids"]) and np.array_equal(gs.view(np.uint32), w["scores"].view(np.uint32))
         pl.close()
     ix.close()
+
+
+def test_plain_c_host_over_the_abi(tmp_path):
+    """No Python, no torch on the host side: tests/host/abi_client.c (C11, gcc) includes include/mfar_hip.h, links libmfar_hip.so, builds an
+    index from host memory and runs both the synchronous scorer and the batch pipeline on host buffers.  It checks pipeline == synchronous
+    itself; here its outputs are compared with the C oracle bit for bit."""
+    import shutil
+    import subprocess
+    from mfar import _native
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    _native.lib()
+    exe, out = str(tmp_path / "abi_client"), str(tmp_path / "out.bin")
+    libdir = os.path.dirname(_native.LIB_PATH)
+    subprocess.check_call([gcc, "-std=c11", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "host", "abi_client.c"), "-L", libdir, "-lmfar_hip", f"-Wl,-rpath,{libdir}", "-o", exe])
+    D, F, E, Q, NB = 20000, 3, 64, 40, 7
+    r = subprocess.run([exe, out, str(D), str(F), str(E), str(Q), str(NB)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("OK "), (r.stdout, r.stderr[-2000:])
+    assert "coalesce=2" in r.stdout and "queries_per_launch=80" in r.stdout, r.stdout      # 20 000 rows: screened, wide pass, two batches per launch
+    raw = np.fromfile(out, dtype=np.uint8)
+    hdr = raw[:20].view(np.int32)
+    assert hdr.tolist() == [D, F, E, Q, NB]
+    o = 20
+    def take(n, dt):
+        nonlocal o
+        a = raw[o:o + n * np.dtype(dt).itemsize].view(dt)
+        o += n * np.dtype(dt).itemsize
+        return a
+    slab = take(F * D * E, np.float32).reshape(F, D, E)
+    W = take(E * F, np.float32).reshape(E, F)
+    mask = take(F, np.float32)
+    q = take(NB * Q * E, np.float32).reshape(NB, Q, E)
+    ids = take(NB * Q * 100, np.int64).reshape(NB, Q, 100)
+    sc = take(NB * Q * 100, np.float32).reshape(NB, Q, 100)
+    for b in (0, NB - 1):
+        ref = O.c_two_stage(slab, q[b], W, mask)
+        assert np.array_equal(ids[b], ref["ids"]) and np.array_equal(sc[b].view(np.uint32), ref["scores"].view(np.uint32)), b
