@@ -122,3 +122,37 @@ def test_integration_stub_compiles_and_names_only_declared_symbols():
     used = set(re.findall(r"_L\.(mfar_\w+)", code))
     assert used and all(re.search(r"\b%s\(" % name, header) for name in used), sorted(used)
     assert {"mfar_pipeline_create", "mfar_pipeline_submit", "mfar_pipeline_result", "mfar_search_two_stage"} <= used
+
+
+def test_argument_validation_returns_error_codes_without_a_device():
+    """Every entry point validates its arguments before it touches the device: bad shapes come back as MFAR_ERR_INVALID with a message --
+    on this box too, where there is no GPU (the valid calls then fail with MFAR_ERR_HIP / INVALID 'no such device', never with a crash)."""
+    import ctypes
+    from mfar import _native
+    L = _native.lib()
+    h = ctypes.c_void_p()
+    bad = [dict(n=-1), dict(F=0), dict(F=33), dict(E=0), dict(E=48), dict(dt=7), dict(off=-5), dict(n=2 ** 32)]
+    for kw in bad:
+        a = dict(dev=0, n=100, off=0, F=4, E=64, dt=0)
+        a.update(kw)
+        rc = L.mfar_index_create(ctypes.byref(h), a["dev"], a["n"], a["off"], a["F"], a["E"], a["dt"])
+        assert rc == -1 and not h.value, (kw, rc)
+        assert len(L.mfar_last_error()) > 0
+    assert L.mfar_index_create(None, 0, 100, 0, 4, 64, 0) == -1
+    # NULL handles / pointers
+    assert L.mfar_index_write_rows(None, 0, 0, 1, None, 0, None) == -1
+    assert L.mfar_retrieve_fields(None, None, 1, 100, 1, None, None, 0, None) == -1
+    assert L.mfar_search_two_stage(None, None, 1, None, 1, None, 100, 100, 1, None, None, None, None, None, None, 0, None) == -1
+    assert L.mfar_pipeline_create(None, None, None, 1, None, 100, 100, 1, 64, 0, 0, 0) == -1
+    p = ctypes.c_void_p()
+    assert L.mfar_pipeline_create(ctypes.byref(p), None, None, 1, None, 100, 100, 1, 64, 0, 0, 0) == -1 and not p.value
+    t = ctypes.c_int64()
+    assert L.mfar_pipeline_submit(None, None, 1, 0, None, ctypes.byref(t)) == -1
+    assert L.mfar_pipeline_result(None, 0, None, None, None, 0, None) == -1
+    assert L.mfar_pipeline_flush(None) == -1
+    L.mfar_pipeline_destroy(None)                                   # no-ops on NULL
+    L.mfar_index_destroy(None)
+    assert L.mfar_set_auto_off(None, 1, 0, 0) == -1 and L.mfar_set_screen(None, 1, 1.0) == -1
+    # pure size helpers need no device
+    assert L.mfar_payload_bytes(64, 8, 100) > 0 and L.mfar_lists_bytes(64, 8, 100) > 0 and L.mfar_topk_bytes(64, 100) > 0
+    assert L.mfar_payload_bytes(-1, 8, 100) == 0 and L.mfar_max_split_batch(None, 100) == 0

@@ -164,3 +164,54 @@ def test_plain_c_host_over_the_abi(tmp_path):
     for b in (0, NB - 1):
         ref = O.c_two_stage(slab, q[b], W, mask)
         assert np.array_equal(ids[b], ref["ids"]) and np.array_equal(sc[b].view(np.uint32), ref["scores"].view(np.uint32)), b
+
+
+def test_abi_error_paths_on_the_device():
+    """Invalid requests against a LIVE index come back as error codes with a message (no crash, no partial launch): the same error
+    behaviour the Python mirror turns into exceptions."""
+    import ctypes
+    from mfar import _native
+    from mfar.data import index as idxmod
+    L = _native.lib()
+    rng = np.random.default_rng(9)
+    F, D, E = 3, 20000, 64
+    ix = idxmod.MultiFieldIndex(D, F, E, device=0)
+    for f in range(F):
+        ix.write_rows(f, 0, rng.standard_normal((D, E)).astype(np.float32))
+    h = ix._h
+    q = np.ascontiguousarray(rng.standard_normal((64, E)).astype(np.float32))
+    W = np.ascontiguousarray(rng.standard_normal((E, F)).astype(np.float32))
+    ids, sc, nv = np.empty((64, 100), np.int64), np.empty((64, 100), np.float32), np.empty(64, np.int32)
+    P = lambda a: a.ctypes.data
+    two = lambda **kw: L.mfar_search_two_stage(h, kw.get("q", P(q)), kw.get("Q", 64), kw.get("W", P(W)), 1, None, kw.get("k1", 100), kw.get("k2", 100), 1,
+                                               kw.get("ids", P(ids)), P(sc), P(nv), None, None, None, 0, None)
+    assert two() == 0
+    for kw in (dict(k1=0), dict(k1=129), dict(k2=0), dict(k2=129), dict(Q=-1), dict(q=None), dict(W=None), dict(ids=None)):
+        assert two(**kw) == -1 and len(L.mfar_last_error()) > 0, kw
+    assert L.mfar_index_write_rows(h, F, 0, 1, P(q), 0, None) == -1            # field out of range
+    assert L.mfar_index_write_rows(h, 0, D - 1, 2, P(q), 0, None) == -1        # rows past the shard
+    assert L.mfar_retrieve_field(h, -1, P(q), 64, 100, 1, P(ids), P(sc), 0, None) == -1
+    assert L.mfar_stage1_begin(h, P(q), 64, 100, 1, 4, P(ids), P(sc), None) == -1      # slot out of range
+    assert L.mfar_set_screen(h, 3, 1.0) == -1 and L.mfar_set_stage2_dump(h, 9) == -1 and L.mfar_set_auto_off(h, 2, 0, 0) == -1
+    # the pipeline
+    p = ctypes.c_void_p()
+    mk = lambda **kw: L.mfar_pipeline_create(ctypes.byref(p), h, P(W), 1, None, kw.get("k1", 100), 100, 1, kw.get("mb", 64), kw.get("depth", 0), kw.get("co", 0), 0)
+    for kw in (dict(mb=0), dict(mb=129), dict(depth=1), dict(depth=5), dict(co=3), dict(k1=0)):
+        assert mk(**kw) == -1 and not p.value, kw
+    assert mk() == 0 and p.value
+    t = ctypes.c_int64()
+    assert L.mfar_pipeline_submit(p, P(q), 65, 0, None, ctypes.byref(t)) == -1 and L.mfar_pipeline_submit(p, P(q), 0, 0, None, ctypes.byref(t)) == -1
+    assert L.mfar_pipeline_submit(p, None, 64, 0, None, ctypes.byref(t)) == -1
+    assert L.mfar_pipeline_result(p, 0, P(ids), P(sc), P(nv), 0, None) == -1           # nothing submitted yet
+    tickets = []
+    for _ in range(9):
+        assert L.mfar_pipeline_submit(p, P(q), 64, 0, None, ctypes.byref(t)) == 0
+        tickets.append(t.value)
+    assert L.mfar_pipeline_result(p, tickets[0], P(ids), P(sc), P(nv), 0, None) == -1  # overwritten long ago
+    assert L.mfar_pipeline_result(p, tickets[-1], None, P(sc), P(nv), 0, None) == -1   # NULL output
+    ids2, sc2 = np.empty_like(ids), np.empty_like(sc)
+    assert L.mfar_pipeline_result(p, tickets[-1], P(ids2), P(sc2), None, 0, None) == 0 # (the held batch is launched alone)
+    assert np.array_equal(ids2, ids) and np.array_equal(sc2.view(np.uint32), sc.view(np.uint32))
+    assert L.mfar_pipeline_result(p, 10 ** 6, P(ids2), P(sc2), None, 0, None) == -1
+    L.mfar_pipeline_destroy(p)
+    ix.close()
