@@ -831,6 +831,28 @@ def drop_in_leg(ix, corpus, W, mask, Q, torch, steps, first, ref_results):
     torch.cuda.synchronize()
     dt_pipe = time.perf_counter() - t0
     pipe.close()
+    # the same pipeline fed from HOST memory (what a non-torch host does, tests/host/abi_client.c): queries copied in by submit (196 KB per
+    # batch), ids / scores / n_valid copied out by result (77 KB) -- the PCIe-inclusive rate
+    from mfar.data.pipeline import NativePipeline
+    hq = [b.cpu().numpy() for b in batches[:min(steps, 128)]]
+    hp = NativePipeline(ix, W.cpu().numpy(), mask.cpu().numpy(), k1=K1, k2=K2, max_batch=Q)
+    def run_host(bs):
+        tk, out = [], []
+        for j, b in enumerate(bs):
+            tk.append(hp.submit(b))
+            if j >= hp.lag:
+                out.append(hp.result(tk[j - hp.lag]))
+        for t in tk[max(0, len(bs) - hp.lag):]:
+            out.append(hp.result(t))
+        return out
+    run_host(hq[:12])
+    t0 = time.perf_counter()
+    hgot = run_host(hq)
+    dt_host = time.perf_counter() - t0
+    hp.close()
+    same_host = all(bool((hgot[i]["ids"] == ref_results[i][0].cpu().numpy()).all()) for i in range(min(len(hgot), len(ref_results))))
+    if not same_host:
+        raise SystemExit("host-buffer pipeline returned different ids than the timed pipeline")
     n = min(len(ref_results), len(got), len(sync))
     same = all(torch.equal(got[i][0], ref_results[i][0]) and torch.equal(got[i][1], ref_results[i][1]) and
                torch.equal(sync[i][0], ref_results[i][0]) and torch.equal(sync[i][1], ref_results[i][1]) for i in range(n))
@@ -842,6 +864,9 @@ def drop_in_leg(ix, corpus, W, mask, Q, torch, steps, first, ref_results):
             "pipelined_mfar_pipeline": {"queries_per_s": steps * Q / dt_pipe, "ms_per_batch": dt_pipe / steps * 1e3, "batches": steps,
                                         "what": "mfar_pipeline_submit / _result, results taken lag batches late; result() copies each batch's "
                                                 "ids / scores / n_valid into fresh tensors"},
+            "pipelined_host_buffers": {"queries_per_s": len(hq) * Q / dt_host, "ms_per_batch": dt_host / len(hq) * 1e3, "batches": len(hq),
+                                       "what": "mfar_pipeline_* with HOST pointers in and out (pageable numpy buffers: H2D 196 KB + D2H 77 KB per batch "
+                                               "inside the calls): the PCIe-inclusive rate; never `value`"},
             "ids_and_score_bits_identical_to_timed_pipeline": True, "batches_compared": n}
 
 
