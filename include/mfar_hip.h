@@ -397,8 +397,11 @@ int mfar_stage2_stats(mfar_index* idx, int* two_level_available, int64_t* gather
  *              also orders the copy after the caller's producer).  Returns at once; *ticket identifies the batch.
  *   result     waits for the batch's launch (launching it alone if it is still held for coalescing), copies ids / scores [Q, k2] and
  *              n_valid [Q] (may be NULL) to host memory (synchronous) or device memory (on `stream`).  A ticket stays valid until
- *              depth * coalesce more batches were submitted: to keep the pipeline full take results lag = depth * coalesce - 1
- *              submissions late (mfar_pipeline_info).
+ *              `depth` LATER launches have started.  A launch starts when it holds `coalesce` batches -- so, left alone, a ticket is
+ *              valid until depth * coalesce more batches were submitted: to keep the pipeline full take results lag = depth * coalesce
+ *              - 1 submissions late (mfar_pipeline_info) -- or EARLY, with what it holds, on flush / set_weights / the result of a batch
+ *              it still holds: a caller who cuts launches short counts launches, not submissions.  Results of tickets submitted
+ *              before a set_weights are those of the weights they were submitted under.
  *   result_view  device pointers into the launch's slot instead of copies (+ the batch's stage-1 lists [Q, F, k1]); same validity.
  *   set_weights  flushes, waits for the launches in flight and replaces W / mask (a mask_fields sweep, a new weight version).
  *   flush      launches a batch that is being held for coalescing.

@@ -12,6 +12,99 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
+def _pipeline_section(rng, ix, slab, q, W, mask, o, k, sentinel, eps_mult, O, what):
+    """The C-ABI batch pipeline (mfar_pipeline_*, the path bench.py times) over the same queries cut into RAGGED batches: random depth /
+    coalescing / batch limit, host or device buffers, results taken late, at once or out of order, a weight change half-way (earlier tickets
+    must keep the old weights' results), forced certificate failures (the redo path) -- every batch bit for bit the oracle's rows."""
+    import torch
+    from mfar.data.pipeline import NativePipeline
+    Q = q.shape[0]
+    max_batch = int(rng.choice([1, 3, 17, 64, 64, rng.integers(1, 65)]))
+    depth, coalesce = int(rng.choice([0, 0, 2, 3, 4])), int(rng.choice([0, 0, 1, 2]))
+    on_dev = bool(rng.integers(0, 2))
+    ix.set_screen(int(rng.choice([0, 2, 2])), eps_mult)
+    if coalesce * max_batch > ix.max_split_batch(k):        # (no wide pass for this index: an explicit request would be refused)
+        coalesce = int(rng.choice([0, 1]))
+    cuts, at = [], 0
+    while at < Q:
+        nq = int(min(Q - at, rng.integers(1, max_batch + 1)))
+        cuts.append((at, nq))
+        at += nq
+    change_at = int(rng.integers(1, len(cuts))) if len(cuts) > 1 and rng.random() < 0.4 else -1
+    o2 = None
+    if change_at >= 0:
+        W2 = (rng.standard_normal(W.shape) * 0.05).astype(np.float32)
+        mask2 = (rng.random(mask.shape[0]) < 0.7).astype(np.float32)
+        if not mask2.any():
+            mask2[0] = 1.0
+        o2 = O.c_two_stage(slab, q, W2, mask2, k1=k, k2=k, sentinel=sentinel)
+    dev = torch.device("cuda", 0)
+    put = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)) if on_dev else (lambda a: np.ascontiguousarray(a))
+    get = (lambda t: t.cpu().numpy()) if on_dev else (lambda a: a)
+    pl = NativePipeline(ix, put(W), put(mask), k1=k, k2=k, sentinel=sentinel, max_batch=max_batch, depth=depth, coalesce=coalesce)
+    # the validity rule of include/mfar_hip.h, modelled here: a batch belongs to the launch that was open when it was submitted; a launch
+    # starts when it holds `coalesce` batches, or early -- flush / set_weights / the result of a batch still held; a ticket is valid until
+    # `depth` LATER launches have started
+    late = int(rng.integers(0, 2 * pl.depth * pl.coalesce))      # how long results are left lying (the model below takes them when it must)
+    pending, ok = [], True
+    st = dict(launched=0, held=0)
+
+    def take(j):
+        nonlocal ok
+        t, a, nq, oo, _, launch = pending[j]
+        if launch == st["launched"]:                  # still held: taking it starts its launch alone
+            before_a_launch(skip=pending[j])
+            st["launched"] += 1
+            st["held"] = 0
+        j = next(j_ for j_, x_ in enumerate(pending) if x_[0] == t)
+        pending.pop(j)
+        r = pl.result(t)
+        ids, sc, nv = get(r["ids"]), get(r["scores"]), get(r["n_valid"])
+        onv = oo["n_valid"][a:a + nq]
+        same = np.array_equal(nv, onv)
+        for j_ in range(nq if same else 0):          # (entries behind n_valid are padding)
+            v = int(onv[j_])
+            same = same and np.array_equal(ids[j_, :v], oo["ids"][a + j_, :v]) and \
+                np.array_equal(sc[j_, :v].view(np.uint32), oo["scores"][a + j_, :v].view(np.uint32))
+        if not same:
+            ok = False
+            print("MISMATCH pipeline", dict(what, batch=(a, nq), max_batch=max_batch, depth=pl.depth, coalesce=pl.coalesce, on_dev=on_dev, late=late,
+                                            change_at=change_at), flush=True)
+
+    def before_a_launch(skip=None):                   # the tickets the next launch's start would retire
+        for e in [e for e in pending if e is not skip and e[5] <= st["launched"] - pl.depth]:
+            take(next(j_ for j_, x_ in enumerate(pending) if x_ is e))
+
+    for i, (a, nq) in enumerate(cuts):
+        if i == change_at:
+            if st["held"]:
+                before_a_launch()
+                st["launched"] += 1
+                st["held"] = 0
+            pl.set_weights(put(W2), put(mask2))       # flushes and drains; tickets submitted before it keep the old weights' rows
+        if st["held"] + 1 == pl.coalesce:
+            before_a_launch()
+        pending.append((pl.submit(put(q[a:a + nq])), a, nq, o2 if (change_at >= 0 and i >= change_at) else o, i, st["launched"]))
+        st["held"] += 1
+        if st["held"] == pl.coalesce:
+            st["launched"] += 1
+            st["held"] = 0
+        due = [e for e in pending if e[4] <= i - late]
+        rng.shuffle(due)
+        for e in due:
+            if any(x_ is e for x_ in pending):
+                take(next(j_ for j_, x_ in enumerate(pending) if x_ is e))
+        if pending and rng.random() < 0.3:                       # and now and then one that is not due yet
+            take(int(rng.integers(0, len(pending))))
+    while pending:
+        take(int(rng.integers(0, len(pending))))
+    if on_dev:
+        torch.cuda.synchronize()
+    note = f"d{pl.depth}c{pl.coalesce}b{max_batch}n{len(cuts)}{'D' if on_dev else 'H'}{'w' if change_at >= 0 else ''}r{pl.n_redone}"
+    pl.close()
+    return ok, note
+
+
 def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
     """One random configuration (shapes, data kind, knobs all drawn from `rng`) through stage 1 with the screen off and on, the whole
     scorer and -- sometimes -- the fused mode, against the C oracle.  Returns True when every comparison held."""
@@ -80,6 +173,7 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
                 ok = False
                 print("MISMATCH", dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, dtype=dtype, kind=int(kind), screen=screen, f=f,
                                        seed=seed, n=n, eps_mult=eps_mult), flush=True)
+    pipe_ok, pipe_note = False, "-"
     if ok and dtype == "f32" and D * F * E * Q < 3e9 and F * k <= 4096:    # the whole scorer, both stage-1 paths
         W = (rng.standard_normal((E, F)) * 0.05).astype(np.float32)
         mask = (rng.random(F) < 0.8).astype(np.float32)
@@ -92,11 +186,15 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
                 r = ix.search(q, W, mask, k1=k, k2=k, sentinel=sentinel)
             except Exception as e:      # fewer than k2 candidates raises like torch.topk: compare the valid prefix instead
                 r = None
+            pipe_ok = r is not None
             if r is not None and not (np.array_equal(r["ids"], o["ids"]) and
                                       np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32))):
                 ok = False
                 print("MISMATCH two-stage", dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, kind=int(kind), screen=screen,
                                                  seed=seed, n=n, eps_mult=eps_mult), flush=True)
+    if ok and pipe_ok and rng.random() < 0.6:
+        ok, pipe_note = _pipeline_section(rng, ix, slab, q, W, mask, o, k, sentinel, eps_mult, O,
+                               dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, kind=int(kind), seed=seed, n=n, eps_mult=eps_mult))
     if ok and dtype == "f32" and k < 128 and D * F * E * Q < 2e9 and rng.random() < 0.3:      # fused mode against its contract
         Wf = (rng.standard_normal((E, F)) * 0.05).astype(np.float32)
         oi, osc = O.c_search_fused(slab, q, Wf, None, k)
@@ -109,7 +207,7 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
     ix.close()
     if verbose or not ok:
         print(f"{n + 1:4d} ok={ok} F={F} D={D} E={E} Q={Q} k={k} sent={int(sentinel)} mean={mean} {dtype} kind={int(kind)} eps_mult={eps_mult:g} "
-              f"checked={st.get('n_checked')} failed={st.get('n_failed')} off={off}", flush=True)
+              f"checked={st.get('n_checked')} failed={st.get('n_failed')} off={off} pipe={pipe_note}", flush=True)
     return ok
 
 
