@@ -1,7 +1,8 @@
 """A bounded, seeded slice of tests/stress.py inside the -m gpu suite: every scan kernel family (fp32 exact, fp16 screen
 64 / 128 columns, bf16 certified and plain), all data kinds (plain, duplicate groups, ramps, tiny values, heavy-tailed norms, clusters of
 near-duplicates), screen off / auto-forced on / every certificate forced to fail, ROW MODE and score-dump settings drawn per configuration,
-the whole scorer and the fused mode -- every comparison bit for bit against the C oracle (bf16 plain pass: its 1e-4).  The long randomised run
+the whole scorer, the C-ABI pipeline over ragged batches (random depth / coalescing, host or device buffers, late and out-of-order results, a
+weight change half-way) and the fused mode -- every comparison bit for bit against the C oracle (bf16 plain pass: its 1e-4).  The long randomised run
 stays `python tests/stress.py <seconds> <seed> [big]` (profiles/*_stress_tail.txt)."""
 import time
 
