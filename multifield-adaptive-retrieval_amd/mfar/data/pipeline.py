@@ -19,7 +19,8 @@ not depend on its neighbours).  `result()` of a batch that is still waiting laun
     ps = PipelinedSearcher(index, W, mask)
     t0 = ps.submit(q0)            # returns immediately (everything is enqueued asynchronously, or held for coalescing)
     t1 = ps.submit(q1)
-    r0 = ps.result(t0)            # dict(ids, scores, n_valid): valid until ps.depth * ps.coalesce more batches were submitted
+    r0 = ps.result(t0)            # dict(ids, scores, n_valid): valid until ps.depth LATER launches started (a launch = ps.coalesce batches,
+                                  # fewer when a result / flush / set_weights cut it short: include/mfar_hip.h)
 
 To keep the pipeline full, ask for results `ps.lag` (= depth * coalesce - 1) submissions late: submit(i); result(i - lag).
 `W` / `mask` are read when a launch is issued: call `flush()` before replacing them (mask_fields sweeps).
