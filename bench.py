@@ -836,19 +836,25 @@ def drop_in_leg(ix, corpus, W, mask, Q, torch, steps, first, ref_results):
     from mfar.data.pipeline import NativePipeline
     hq = [b.cpu().numpy() for b in batches[:min(steps, 128)]]
     hp = NativePipeline(ix, W.cpu().numpy(), mask.cpu().numpy(), k1=K1, k2=K2, max_batch=Q)
+    lat = []                 # submit -> result in the caller's host memory, per batch, at full load (results taken `lag` batches late)
+
     def run_host(bs):
-        tk, out = [], []
+        tk, ts, out = [], [], []
         for j, b in enumerate(bs):
+            ts.append(time.perf_counter())
             tk.append(hp.submit(b))
             if j >= hp.lag:
                 out.append(hp.result(tk[j - hp.lag]))
-        for t in tk[max(0, len(bs) - hp.lag):]:
-            out.append(hp.result(t))
+                lat.append(time.perf_counter() - ts[j - hp.lag])
+        for j in range(max(0, len(bs) - hp.lag), len(bs)):
+            out.append(hp.result(tk[j]))
         return out
     run_host(hq[:12])
+    lat.clear()
     t0 = time.perf_counter()
     hgot = run_host(hq)
     dt_host = time.perf_counter() - t0
+    lat_ms = sorted(x * 1e3 for x in lat)
     hp.close()
     same_host = all(bool((hgot[i]["ids"] == ref_results[i][0].cpu().numpy()).all()) for i in range(min(len(hgot), len(ref_results))))
     if not same_host:
@@ -866,7 +872,9 @@ def drop_in_leg(ix, corpus, W, mask, Q, torch, steps, first, ref_results):
                                                 "ids / scores / n_valid into fresh tensors"},
             "pipelined_host_buffers": {"queries_per_s": len(hq) * Q / dt_host, "ms_per_batch": dt_host / len(hq) * 1e3, "batches": len(hq),
                                        "what": "mfar_pipeline_* with HOST pointers in and out (pageable numpy buffers: H2D 196 KB + D2H 77 KB per batch "
-                                               "inside the calls): the PCIe-inclusive rate; never `value`"},
+                                               "inside the calls): the PCIe-inclusive rate; never `value`",
+                                       "latency_ms_submit_to_result_at_full_load": {"p50": lat_ms[len(lat_ms) // 2], "p99": lat_ms[min(len(lat_ms) - 1, int(len(lat_ms) * 0.99))],
+                                                                                    "max": lat_ms[-1], "batches_in_flight": hp.lag + 1}},
             "ids_and_score_bits_identical_to_timed_pipeline": True, "batches_compared": n}
 
 
