@@ -215,3 +215,45 @@ def test_abi_error_paths_on_the_device():
     assert L.mfar_pipeline_result(p, 10 ** 6, P(ids2), P(sc2), None, 0, None) == -1
     L.mfar_pipeline_destroy(p)
     ix.close()
+
+
+def test_result_view_and_stream_helper():
+    """The two entry points no Python wrapper uses: mfar_pipeline_result_view (device pointers into the launch's slot: what a zero-copy
+    consumer reads) must show the bytes mfar_pipeline_result / _lists copy out, and mfar_stream_wait_stage1_start must order a caller's
+    stream behind the begin phase of the last launch (and be a no-op before any launch)."""
+    import torch
+    from mfar import _native
+    from mfar.data import index as idxmod
+    from mfar.data.pipeline import NativePipeline
+    rng = np.random.default_rng(12)
+    F, D, E, Q, k = 3, 20000, 64, 40, 100
+    slab, mu, W = _mk(rng, F, D, E)
+    ix = idxmod.MultiFieldIndex(D, F, E, device=0)
+    lib = _native.lib()
+    side = torch.cuda.Stream(device=0)
+    assert lib.mfar_stream_wait_stage1_start(ix._h, ctypes.c_void_p(side.cuda_stream)) == 0       # nothing launched yet
+    for f in range(F):
+        ix.write_rows(f, 0, slab[f])
+    ix.set_screen(2)
+    q = (rng.standard_normal((Q, E)) * 0.5 + mu * 2.0).astype(np.float32)
+    pl = NativePipeline(ix, W, None, max_batch=64)
+    t0, t1 = pl.submit(q), pl.submit(q[::-1].copy())
+    assert lib.mfar_stream_wait_stage1_start(ix._h, ctypes.c_void_p(side.cuda_stream)) == 0
+    side.synchronize()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    for t, qq in ((t0, q), (t1, q[::-1])):
+        r = pl.result(t)
+        fid, fsc = pl.lists(t)
+        ptrs = [ctypes.c_void_p() for _ in range(5)]
+        assert lib.mfar_pipeline_result_view(pl._p, ctypes.c_int64(t), *[ctypes.byref(p) for p in ptrs]) == 0
+        torch.cuda.synchronize()
+        for p, want in zip(ptrs, (r["ids"], r["scores"], r["n_valid"], fid, fsc)):
+            got = np.empty_like(want)
+            assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), p, got.nbytes, 2) == 0       # hipMemcpyDeviceToHost
+            assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+        ref = ix.search(np.ascontiguousarray(qq), W, None)
+        assert np.array_equal(r["ids"], ref["ids"]) and np.array_equal(r["scores"].view(np.uint32), ref["scores"].view(np.uint32))
+    assert lib.mfar_pipeline_result_view(pl._p, ctypes.c_int64(t1 + 5), *[None] * 5) != 0                      # not a ticket
+    pl.close()
+    ix.close()
