@@ -1586,3 +1586,39 @@ def test_bf16_lists_carry_the_chain_bits_whatever_path_wrote_them(idxmod):
         assert np.array_equal(rm["ids"], o["ids"]) and np.array_equal(rm["scores"].view(np.uint32), o["scores"].view(np.uint32)), (F, D, E)
         for sh in shards:
             sh.close()
+
+
+def test_limits_of_fields_and_list_depth(idxmod):
+    """The widest call the ABI takes: MFAR_MAX_FIELDS = 32 fields x k1 = 128 = 4096 candidates per query (the union's and the mixer's LDS
+    budget), k2 = 128 = SEL_MAX_K -- synchronous scorer and C-ABI pipeline against the oracle, screen on and off, a ragged 70-query call
+    (one wide block + a rest); one past either limit is refused with an error, not truncated."""
+    from mfar import _native
+    from mfar.data.pipeline import NativePipeline
+    rng = np.random.default_rng(44)
+    F, D, E, Q, k = 32, 20000, 64, 70, 128
+    slab, q, W = _mk(rng, F, D, E, Q, mean=0.2, dup=3)
+    mask = (rng.random(F) < 0.8).astype(np.float32)
+    ix = _load(idxmod, slab)
+    o = O.c_two_stage(slab, q, W, mask, k1=k, k2=k, sentinel=True)
+    assert (o["n_cand"] > 3000).any()                               # the candidate lists really are near the 4096 limit
+    for screen in (2, 0):
+        ix.set_screen(screen)
+        r = ix.search(q, W, mask, k1=k, k2=k)
+        assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32)), screen
+        pl = NativePipeline(ix, W, mask, k1=k, k2=k, max_batch=64)
+        t0, t1 = pl.submit(q[:64]), pl.submit(q[64:])
+        for t, a, b in ((t0, 0, 64), (t1, 64, Q)):
+            g = pl.result(t)
+            assert np.array_equal(g["ids"], o["ids"][a:b]) and np.array_equal(g["scores"].view(np.uint32), o["scores"][a:b].view(np.uint32)), (screen, a)
+        pl.close()
+    st = ix.screen_stats()
+    assert st["n_checked"] > 0 and st["n_failed"] == 0, st
+    with pytest.raises(_native.MfarError):
+        ix.search(q, W, mask, k1=129, k2=100)                       # 32 x 129 > 4096
+    with pytest.raises(_native.MfarError):
+        NativePipeline(ix, W, mask, k1=129, k2=100, max_batch=64)
+    with pytest.raises(_native.MfarError):
+        ix.search(q, W, mask, k1=100, k2=129)                       # k2 > SEL_MAX_K
+    with pytest.raises(Exception):
+        idxmod.MultiFieldIndex(100, 33, E, device=0)                # n_fields > MFAR_MAX_FIELDS
+    ix.close()
