@@ -241,12 +241,13 @@ class RetrievalTrainingModule(torch.nn.Module):
                 for group in batches():                                          # one forward per group (contrastive.py:483-489)
                     yield from candidate_encoding_stream(self.encoder, group, batch_size=len(group), multiprocess=False,
                                                          show_progress=False, as_tensor=True)
-            stream = stream_all()
-            got, vecs = [], []
             # MFAR_ENCODE_AUTOCAST=bf16|fp16: run the corpus-encode forwards under autocast ("bf16 encoder").  Off by
             # default: the reference encodes the corpus in fp32 (its precision plugin wraps the steps, not on_test_epoch_start);
             # the rows written to the slab are fp32 either way.
             ac = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(os.environ.get("MFAR_ENCODE_AUTOCAST", "").lower())
+            fast = self._encode_texts_prefetched(uniq, order, emb_u, bs, budget, max_len, ac)
+            stream = stream_all() if not fast else iter(())
+            got, vecs = [], []
             with torch.autocast(device_type=self.device.type, dtype=ac, enabled=ac is not None):
                 for i, v in stream:
                     got.append(i)
@@ -265,6 +266,100 @@ class RetrievalTrainingModule(torch.nn.Module):
             torch.cuda.synchronize(self.device)
         _barrier()                                                               # :491 (no memmap reopen needed)
         self._corpus_encoded = True
+
+    @torch.no_grad()
+    def _encode_texts_prefetched(self, uniq, order, emb_u, bs, budget, max_len, ac) -> bool:
+        """The corpus encode with the host side off the critical path (profiles/r05_p_encode_*: under bf16 autocast the GPU was busy 40 % of
+        an encode, the rest was `PreTrainedTokenizerFast.__call__`'s per-sequence Python and synchronous copies).  A producer thread
+        tokenises chunks of 8192 texts (ordered by characters) with the Rust tokenizer directly (`backend_tokenizer.encode_batch`: releases
+        the GIL, every text tokenised exactly ONCE), cuts them into batches by TRUE token counts under the same token budget as the generic
+        path, pads with numpy into pinned buffers and queues them; this thread copies asynchronously, runs the forward and scatters the
+        rows.  Same tokens as `encoder.tokenize` (special tokens, longest-first truncation at `max_len`); batch composition differs from the
+        generic path as it does between any two budgets.  Returns False (nothing done) when the tokenizer has no Rust backend or
+        MFAR_ENCODE_PREFETCH=0: the caller then takes the generic path (`candidate_encoding_stream`)."""
+        import itertools
+        import queue
+        import threading
+        import numpy as np
+        tok = getattr(self.encoder, "tokenizer", None)
+        be = getattr(tok, "backend_tokenizer", None)
+        if be is None or os.environ.get("MFAR_ENCODE_PREFETCH", "1") == "0" or not hasattr(be, "encode_batch") or not uniq:
+            return False
+        pad_id = int(tok.pad_token_id or 0)
+        want_types = "token_type_ids" in (getattr(tok, "model_input_names", None) or ())
+        dev = self.device
+        pin = dev.type == "cuda"
+        q_out: "queue.Queue" = queue.Queue(maxsize=6)
+        stop = threading.Event()
+        CHUNK = 8192
+
+        def produce():
+            try:
+                be.enable_truncation(max_length=max_len)            # (PreTrainedTokenizerFast resets both on its next __call__)
+                be.no_padding()
+                c0 = c1 = 0
+                while c1 < len(order):
+                    if stop.is_set():
+                        return
+                    c0, c1 = c1, min(len(order), c1 + (1024 if c1 == 0 else 2048 if c1 == 1024 else CHUNK))   # a short first chunk: the GPU starts early
+                    idxs = np.asarray(order[c0:c1], np.int64)
+                    ids = [e.ids for e in be.encode_batch([uniq[i] for i in idxs], add_special_tokens=True)]
+                    lens = np.fromiter((len(x) for x in ids), np.int64, len(ids))
+                    flat = np.fromiter(itertools.chain.from_iterable(ids), np.int64, int(lens.sum()))
+                    starts = np.concatenate(([0], np.cumsum(lens)[:-1]))
+                    o2 = np.argsort(lens, kind="stable")
+                    pos = 0
+                    while pos < len(o2) and not stop.is_set():
+                        n = min(bs, len(o2) - pos)
+                        if budget:
+                            n = min(4096, len(o2) - pos)
+                            while n > bs and n * int(lens[o2[pos + n - 1]]) > budget:     # lengths ascend: the last text is the longest
+                                n = max(bs, (n * 3) // 4)
+                        sel = o2[pos:pos + n]
+                        L = max(1, int(lens[sel[-1]]))
+                        valid = np.arange(L)[None, :] < lens[sel][:, None]
+                        arr = np.full((n, L), pad_id, np.int64)
+                        src = (starts[sel][:, None] + np.arange(L)[None, :])[valid]
+                        arr[valid] = flat[src]
+                        feats = {"input_ids": torch.from_numpy(arr), "attention_mask": torch.from_numpy(valid.astype(np.int64))}
+                        rows = torch.from_numpy(idxs[sel])
+                        if pin:
+                            feats = {k: v.pin_memory() for k, v in feats.items()}
+                            rows = rows.pin_memory()
+                        q_out.put((feats, rows))
+                        pos += n
+                q_out.put(None)
+            except BaseException as e:                                # surfaces in the consumer
+                q_out.put(e)
+
+        th = threading.Thread(target=produce, name="mfar-encode-prefetch", daemon=True)
+        th.start()
+        was_training = self.encoder.training
+        self.encoder.eval()
+        try:
+            with torch.autocast(device_type=dev.type, dtype=ac, enabled=ac is not None):
+                while True:
+                    item = q_out.get()
+                    if item is None:
+                        break
+                    if isinstance(item, BaseException):
+                        raise item
+                    feats, rows = item
+                    f = {k: v.to(dev, non_blocking=True) for k, v in feats.items()}
+                    if want_types:
+                        f["token_type_ids"] = torch.zeros_like(f["input_ids"])
+                    emb_u[rows.to(dev, non_blocking=True)] = self.encoder(f)["sentence_embedding"].float()
+        finally:
+            stop.set()
+            while th.is_alive():                                      # (an exception above: free a queue slot so that the producer sees `stop`)
+                try:
+                    q_out.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            th.join()
+            if was_training:
+                self.encoder.train()
+        return True
 
     # ------------------------------------------------------------------ scoring (contrastive.py:669-704)
     def _get_searcher(self):

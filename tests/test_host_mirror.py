@@ -423,3 +423,46 @@ def test_merge_of_shard_lists_equals_the_oracle_merge():
         for f in range(F):
             wi, ws = O.c_merge_lists(ids[:, q, f], sc[:, q, f], True)
             assert np.array_equal(gi[q, f].numpy(), wi) and np.array_equal(gs[q, f].numpy(), ws), (q, f)
+
+
+def test_prefetched_corpus_encode_equals_the_generic_path(monkeypatch):
+    """RetrievalTrainingModule._encode_texts_prefetched (the corpus encode with tokenisation on a producer thread, Rust tokenizer called
+    directly): the same tokens as `encoder.tokenize` -- special tokens, truncation at the encoder's limit -- hence, text by text, the rows of
+    `encoder.encode`; every row written exactly once whatever the token budget; off by MFAR_ENCODE_PREFETCH=0 or without a Rust backend."""
+    import types
+    import torch
+    from mfar.modeling.contrastive import RetrievalTrainingModule
+    from mfar.modeling.util import prepare_model
+    _, enc, _ = prepare_model("random-init:32x1")
+    enc.max_seq_length = 24
+    rng = np.random.default_rng(5)
+    words = ["alpha", "beta", "gamma", "delta", "x", "retrieval", "field", "a.b,c"]
+    uniq = [""] + [" ".join(rng.choice(words, size=int(n))) for n in rng.integers(1, 30, size=150)]      # some far beyond 24 tokens
+    uniq = list(dict.fromkeys(uniq))
+    order = sorted(range(len(uniq)), key=lambda i: len(uniq[i]))
+    stub = types.SimpleNamespace(encoder=enc, device=torch.device("cpu"))
+    E = enc.get_sentence_embedding_dimension()
+    want = torch.stack([enc.encode([t], batch_size=1, convert_to_tensor=True)[0] for t in uniq])           # every text alone
+    alone = torch.full((len(uniq), E), float("nan"))
+    assert RetrievalTrainingModule._encode_texts_prefetched(stub, uniq, order, alone, 1, 0, 24, None)      # budget 0, batch size 1: alone
+    assert torch.equal(alone, want)
+    for bs, budget in ((4, 0), (4, 4 * 24), (16, 16 * 24)):
+        got = torch.full((len(uniq), E), float("nan"))
+        assert RetrievalTrainingModule._encode_texts_prefetched(stub, uniq, order, got, bs, budget, 24, None)
+        assert not torch.isnan(got).any()
+        assert torch.allclose(got, want, atol=2e-5, rtol=0), float((got - want).abs().max())
+    # several producer chunks (1024, 2048, then 8192 texts): every row still written once, to the generic path's values
+    many = list(dict.fromkeys(" ".join(rng.choice(words, size=int(n))) + f" {i}" for i, n in enumerate(rng.integers(1, 6, size=3400))))
+    order_m = sorted(range(len(many)), key=lambda i: len(many[i]))
+    got = torch.full((len(many), E), float("nan"))
+    assert RetrievalTrainingModule._encode_texts_prefetched(stub, many, order_m, got, 64, 64 * 24, 24, None)
+    ref = enc.encode(many, batch_size=64, convert_to_tensor=True)
+    assert not torch.isnan(got).any() and torch.allclose(got, ref, atol=2e-5, rtol=0)
+    # the tokenizer's own settings are not left changed for the generic path
+    ids = enc.tokenize([uniq[-1], "x"])["input_ids"]
+    assert ids.shape[1] <= 24 and ids.shape[0] == 2
+    monkeypatch.setenv("MFAR_ENCODE_PREFETCH", "0")
+    assert not RetrievalTrainingModule._encode_texts_prefetched(stub, uniq, order, alone, 1, 0, 24, None)
+    monkeypatch.delenv("MFAR_ENCODE_PREFETCH")
+    stub.encoder = types.SimpleNamespace(tokenizer=object())                                               # no Rust backend
+    assert not RetrievalTrainingModule._encode_texts_prefetched(stub, uniq, order, alone, 1, 0, 24, None)
