@@ -190,13 +190,13 @@ class RetrievalTrainingModule(torch.nn.Module):
         r0, r1 = shard_bounds(self.n_docs, rank, n)                             # contrastive.py:470
         segment = self.corpus[r0:r1]
         bs = self.dev_batch_size
-        for key, field in self.field_info.items():
-            if field.field_type != FieldType.DENSE:
-                continue                                                         # sparse fields were indexed at start-up (BM25)
+        dense = [(key, field) for key, field in self.field_info.items() if field.field_type == FieldType.DENSE]   # sparse fields were indexed at start-up (BM25)
+
+        def prepare(field):
+            """A field's texts, host side only (runs one field AHEAD on a helper thread, beside the previous field's forwards)."""
             docs = format_documents(segment, field.name, field.dataset)          # contrastive.py:473-475
             if self.prefix:
                 docs = [(i, field.name + ": " + t) for i, t in docs]            # :476-481
-            vec = self.vectors_dict[key]
             # Encode every DISTINCT text of the field once, shortest first (length-bucketed batches: no padding to the
             # longest document of an arbitrary corpus slice), then gather the rows in corpus order.  A text that occurs more
             # than once -- above all "": documents that lack the field, format.py:58-59 -- gets bit-identical rows, which
@@ -205,6 +205,15 @@ class RetrievalTrainingModule(torch.nn.Module):
             uniq = list(dict.fromkeys(texts))
             slot = {t: i for i, t in enumerate(uniq)}
             order = sorted(range(len(uniq)), key=lambda i: len(uniq[i]))
+            return docs, texts, uniq, slot, order
+
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(1)
+        ahead = pool.submit(prepare, dense[0][1]) if dense else None
+        for j, (key, field) in enumerate(dense):
+            docs, texts, uniq, slot, order = ahead.result()
+            ahead = pool.submit(prepare, dense[j + 1][1]) if j + 1 < len(dense) else None
+            vec = self.vectors_dict[key]
             emb_u = torch.empty(len(uniq), self.slab.dim, device=self.device)
             # Batches by TOKEN budget, not by count: `dev_batch_size` texts of `max_seq_length` tokens is the largest forward the
             # caller sized memory for; short texts (names, types, the relation fields of STaRK-prime) are launch-bound at 64 per
@@ -262,6 +271,7 @@ class RetrievalTrainingModule(torch.nn.Module):
             for b in range(0, len(docs), step):
                 vec.write_block(docs[b][0], emb_u.index_select(0, rows[b:b + step]).contiguous())   # straight into the HBM slab
             del emb_u
+        pool.shutdown(wait=True)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         _barrier()                                                               # :491 (no memmap reopen needed)
