@@ -193,7 +193,7 @@ class RetrievalTrainingModule(torch.nn.Module):
         dense = [(key, field) for key, field in self.field_info.items() if field.field_type == FieldType.DENSE]   # sparse fields were indexed at start-up (BM25)
 
         def prepare(field):
-            """A field's texts, host side only (runs one field AHEAD on a helper thread, beside the previous field's forwards)."""
+            """A field's texts, host side only (on the producer thread of the prefetched path: beside the previous field's forwards)."""
             docs = format_documents(segment, field.name, field.dataset)          # contrastive.py:473-475
             if self.prefix:
                 docs = [(i, field.name + ": " + t) for i, t in docs]            # :476-481
@@ -207,20 +207,23 @@ class RetrievalTrainingModule(torch.nn.Module):
             order = sorted(range(len(uniq)), key=lambda i: len(uniq[i]))
             return docs, texts, uniq, slot, order
 
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(1)
-        ahead = pool.submit(prepare, dense[0][1]) if dense else None
-        for j, (key, field) in enumerate(dense):
-            docs, texts, uniq, slot, order = ahead.result()
-            ahead = pool.submit(prepare, dense[j + 1][1]) if j + 1 < len(dense) else None
+        # Batches by TOKEN budget, not by count: `dev_batch_size` texts of `max_seq_length` tokens is the largest forward the
+        # caller sized memory for; short texts (names, types, the relation fields of STaRK-prime) are launch-bound at 64 per
+        # forward, so a batch takes as many of them as fit that budget (at least dev_batch_size; MFAR_ENCODE_TOKEN_BUDGET=0:
+        # always dev_batch_size).  Lengths ascend, so the last text of a batch is its longest.
+        max_len = int(self.encoder.get_max_seq_length())
+        budget = bs * max_len if os.environ.get("MFAR_ENCODE_TOKEN_BUDGET", "1") != "0" else 0
+        # MFAR_ENCODE_AUTOCAST=bf16|fp16: run the corpus-encode forwards under autocast ("bf16 encoder").  Off by
+        # default: the reference encodes the corpus in fp32 (its precision plugin wraps the steps, not on_test_epoch_start);
+        # the rows written to the slab are fp32 either way.
+        ac = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(os.environ.get("MFAR_ENCODE_AUTOCAST", "").lower())
+        if dense and self._prefetch_backend() is not None:
+            self._encode_fields_prefetched(dense, prepare, bs, budget, max_len, ac)
+            dense = []                                       # (nothing left for the generic loop below)
+        for key, field in dense:                             # generic path: a tokenizer without a Rust backend, or MFAR_ENCODE_PREFETCH=0
+            docs, texts, uniq, slot, order = prepare(field)
             vec = self.vectors_dict[key]
             emb_u = torch.empty(len(uniq), self.slab.dim, device=self.device)
-            # Batches by TOKEN budget, not by count: `dev_batch_size` texts of `max_seq_length` tokens is the largest forward the
-            # caller sized memory for; short texts (names, types, the relation fields of STaRK-prime) are launch-bound at 64 per
-            # forward, so a batch takes as many of them as fit that budget (at least dev_batch_size; MFAR_ENCODE_TOKEN_BUDGET=0:
-            # always dev_batch_size).  Lengths ascend, so the last text of a batch is its longest.
-            max_len = int(self.encoder.get_max_seq_length())
-            budget = bs * max_len if os.environ.get("MFAR_ENCODE_TOKEN_BUDGET", "1") != "0" else 0
 
             def batches():
                 pos = 0
@@ -250,12 +253,7 @@ class RetrievalTrainingModule(torch.nn.Module):
                 for group in batches():                                          # one forward per group (contrastive.py:483-489)
                     yield from candidate_encoding_stream(self.encoder, group, batch_size=len(group), multiprocess=False,
                                                          show_progress=False, as_tensor=True)
-            # MFAR_ENCODE_AUTOCAST=bf16|fp16: run the corpus-encode forwards under autocast ("bf16 encoder").  Off by
-            # default: the reference encodes the corpus in fp32 (its precision plugin wraps the steps, not on_test_epoch_start);
-            # the rows written to the slab are fp32 either way.
-            ac = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(os.environ.get("MFAR_ENCODE_AUTOCAST", "").lower())
-            fast = self._encode_texts_prefetched(uniq, order, emb_u, bs, budget, max_len, ac)
-            stream = stream_all() if not fast else iter(())
+            stream = stream_all()
             got, vecs = [], []
             with torch.autocast(device_type=self.device.type, dtype=ac, enabled=ac is not None):
                 for i, v in stream:
@@ -266,99 +264,96 @@ class RetrievalTrainingModule(torch.nn.Module):
                         got, vecs = [], []
             if got:
                 emb_u[torch.tensor(got, device=self.device)] = torch.stack(vecs).float()
-            rows = torch.tensor([slot[t] for t in texts], device=self.device)
-            step = max(bs, 65536)
-            for b in range(0, len(docs), step):
-                vec.write_block(docs[b][0], emb_u.index_select(0, rows[b:b + step]).contiguous())   # straight into the HBM slab
+            self._write_field(vec, docs, emb_u, torch.tensor([slot[t] for t in texts], device=self.device), bs)
             del emb_u
-        pool.shutdown(wait=True)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         _barrier()                                                               # :491 (no memmap reopen needed)
         self._corpus_encoded = True
 
-    @torch.no_grad()
-    def _encode_texts_prefetched(self, uniq, order, emb_u, bs, budget, max_len, ac) -> bool:
-        """The corpus encode with the host side off the critical path (profiles/r05_p_encode_*: under bf16 autocast the GPU was busy 40 % of
-        an encode, the rest was `PreTrainedTokenizerFast.__call__`'s per-sequence Python and synchronous copies).  A producer thread
-        tokenises chunks of 8192 texts (ordered by characters) with the Rust tokenizer directly (`backend_tokenizer.encode_batch`: releases
-        the GIL, every text tokenised exactly ONCE), cuts them into batches by TRUE token counts under the same token budget as the generic
-        path, pads with numpy into pinned buffers and queues them; this thread copies asynchronously, runs the forward and scatters the
-        rows.  Same tokens as `encoder.tokenize` (special tokens, longest-first truncation at `max_len`); batch composition differs from the
-        generic path as it does between any two budgets.  Returns False (nothing done) when the tokenizer has no Rust backend or
-        MFAR_ENCODE_PREFETCH=0: the caller then takes the generic path (`candidate_encoding_stream`)."""
-        import itertools
-        import queue
-        import threading
-        import numpy as np
+    # -- the corpus encode with the host side off the critical path ---------------------------------------------------------------------
+    # profiles/r05_p_encode_*: under bf16 autocast the GPU was busy 40 % of an encode; the rest was `PreTrainedTokenizerFast.__call__`'s
+    # per-sequence Python (16.5 of 29 s, 3 s of them in Rust), synchronous copies and the preparation of each field's texts.  A PRODUCER
+    # thread now does all of that: it formats a field's texts, tokenises chunks of them (ordered by characters) with the Rust tokenizer
+    # directly (`backend_tokenizer.encode_batch`: releases the GIL, every text tokenised exactly ONCE), cuts them into batches by TRUE
+    # token counts under the same token budget as the generic path, pads with numpy into pinned buffers and queues them -- across field
+    # boundaries, so the GPU does not drain between fields; the calling thread copies asynchronously, runs the forwards and scatters the
+    # rows.  Same tokens as `encoder.tokenize` (special tokens, longest-first truncation at `max_len`); batch composition differs from
+    # the generic path as it does between any two budgets.
+    def _prefetch_backend(self):
+        """The Rust tokenizer behind `encoder.tokenizer`, or None (no fast tokenizer, or MFAR_ENCODE_PREFETCH=0): generic path."""
         tok = getattr(self.encoder, "tokenizer", None)
         be = getattr(tok, "backend_tokenizer", None)
-        if be is None or os.environ.get("MFAR_ENCODE_PREFETCH", "1") == "0" or not hasattr(be, "encode_batch") or not uniq:
-            return False
-        pad_id = int(tok.pad_token_id or 0)
-        want_types = "token_type_ids" in (getattr(tok, "model_input_names", None) or ())
-        dev = self.device
-        pin = dev.type == "cuda"
-        q_out: "queue.Queue" = queue.Queue(maxsize=6)
-        stop = threading.Event()
-        CHUNK = 8192
+        if be is None or os.environ.get("MFAR_ENCODE_PREFETCH", "1") == "0" or not hasattr(be, "encode_batch"):
+            return None
+        return be
 
-        def produce():
+    def _token_batches(self, uniq, order, bs, budget, max_len, stop):
+        """Producer side: yields (features on the host, rows of `uniq` they belong to) for every text of `uniq`, each exactly once."""
+        import itertools
+        import numpy as np
+        tok = self.encoder.tokenizer
+        be = tok.backend_tokenizer
+        pad_id = int(tok.pad_token_id or 0)
+        pin = self.device.type == "cuda"
+        be.enable_truncation(max_length=max_len)            # (PreTrainedTokenizerFast resets both on its next __call__)
+        be.no_padding()
+        c1 = 0
+        while c1 < len(order) and not stop.is_set():
+            c0, c1 = c1, min(len(order), c1 + (1024 if c1 == 0 else 2048 if c1 == 1024 else 8192))   # a short first chunk: the GPU starts early
+            idxs = np.asarray(order[c0:c1], np.int64)
+            ids = [e.ids for e in be.encode_batch([uniq[i] for i in idxs], add_special_tokens=True)]
+            lens = np.fromiter((len(x) for x in ids), np.int64, len(ids))
+            flat = np.fromiter(itertools.chain.from_iterable(ids), np.int64, int(lens.sum()))
+            starts = np.concatenate(([0], np.cumsum(lens)[:-1]))
+            o2 = np.argsort(lens, kind="stable")
+            pos = 0
+            while pos < len(o2) and not stop.is_set():
+                n = min(bs, len(o2) - pos)
+                if budget:
+                    n = min(4096, len(o2) - pos)
+                    while n > bs and n * int(lens[o2[pos + n - 1]]) > budget:     # lengths ascend: the last text is the longest
+                        n = max(bs, (n * 3) // 4)
+                sel = o2[pos:pos + n]
+                L = max(1, int(lens[sel[-1]]))
+                valid = np.arange(L)[None, :] < lens[sel][:, None]
+                arr = np.full((n, L), pad_id, np.int64)
+                arr[valid] = flat[(starts[sel][:, None] + np.arange(L)[None, :])[valid]]
+                feats = {"input_ids": torch.from_numpy(arr), "attention_mask": torch.from_numpy(valid.astype(np.int64))}
+                rows = torch.from_numpy(idxs[sel])
+                if pin:
+                    feats = {k: v.pin_memory() for k, v in feats.items()}
+                    rows = rows.pin_memory()
+                yield feats, rows
+                pos += n
+
+    def _consume(self, produce, on_item, ac) -> None:
+        """Runs `produce(put, stop)` on a thread and hands every item it puts to `on_item` on this one, under the autocast setting."""
+        import queue
+        import threading
+        q_out: "queue.Queue" = queue.Queue(maxsize=8)
+        stop = threading.Event()
+
+        def run():
             try:
-                be.enable_truncation(max_length=max_len)            # (PreTrainedTokenizerFast resets both on its next __call__)
-                be.no_padding()
-                c0 = c1 = 0
-                while c1 < len(order):
-                    if stop.is_set():
-                        return
-                    c0, c1 = c1, min(len(order), c1 + (1024 if c1 == 0 else 2048 if c1 == 1024 else CHUNK))   # a short first chunk: the GPU starts early
-                    idxs = np.asarray(order[c0:c1], np.int64)
-                    ids = [e.ids for e in be.encode_batch([uniq[i] for i in idxs], add_special_tokens=True)]
-                    lens = np.fromiter((len(x) for x in ids), np.int64, len(ids))
-                    flat = np.fromiter(itertools.chain.from_iterable(ids), np.int64, int(lens.sum()))
-                    starts = np.concatenate(([0], np.cumsum(lens)[:-1]))
-                    o2 = np.argsort(lens, kind="stable")
-                    pos = 0
-                    while pos < len(o2) and not stop.is_set():
-                        n = min(bs, len(o2) - pos)
-                        if budget:
-                            n = min(4096, len(o2) - pos)
-                            while n > bs and n * int(lens[o2[pos + n - 1]]) > budget:     # lengths ascend: the last text is the longest
-                                n = max(bs, (n * 3) // 4)
-                        sel = o2[pos:pos + n]
-                        L = max(1, int(lens[sel[-1]]))
-                        valid = np.arange(L)[None, :] < lens[sel][:, None]
-                        arr = np.full((n, L), pad_id, np.int64)
-                        src = (starts[sel][:, None] + np.arange(L)[None, :])[valid]
-                        arr[valid] = flat[src]
-                        feats = {"input_ids": torch.from_numpy(arr), "attention_mask": torch.from_numpy(valid.astype(np.int64))}
-                        rows = torch.from_numpy(idxs[sel])
-                        if pin:
-                            feats = {k: v.pin_memory() for k, v in feats.items()}
-                            rows = rows.pin_memory()
-                        q_out.put((feats, rows))
-                        pos += n
+                produce(q_out.put, stop)
                 q_out.put(None)
             except BaseException as e:                                # surfaces in the consumer
                 q_out.put(e)
 
-        th = threading.Thread(target=produce, name="mfar-encode-prefetch", daemon=True)
+        th = threading.Thread(target=run, name="mfar-encode-prefetch", daemon=True)
         th.start()
         was_training = self.encoder.training
         self.encoder.eval()
         try:
-            with torch.autocast(device_type=dev.type, dtype=ac, enabled=ac is not None):
+            with torch.autocast(device_type=self.device.type, dtype=ac, enabled=ac is not None):
                 while True:
                     item = q_out.get()
                     if item is None:
                         break
                     if isinstance(item, BaseException):
                         raise item
-                    feats, rows = item
-                    f = {k: v.to(dev, non_blocking=True) for k, v in feats.items()}
-                    if want_types:
-                        f["token_type_ids"] = torch.zeros_like(f["input_ids"])
-                    emb_u[rows.to(dev, non_blocking=True)] = self.encoder(f)["sentence_embedding"].float()
+                    on_item(item)
         finally:
             stop.set()
             while th.is_alive():                                      # (an exception above: free a queue slot so that the producer sees `stop`)
@@ -369,7 +364,61 @@ class RetrievalTrainingModule(torch.nn.Module):
             th.join()
             if was_training:
                 self.encoder.train()
+
+    def _forward_rows(self, feats, rows, emb_u) -> None:
+        dev = self.device
+        f = {k: v.to(dev, non_blocking=True) for k, v in feats.items()}
+        if "token_type_ids" in (getattr(self.encoder.tokenizer, "model_input_names", None) or ()):
+            f["token_type_ids"] = torch.zeros_like(f["input_ids"])
+        emb_u[rows.to(dev, non_blocking=True)] = self.encoder(f)["sentence_embedding"].float()
+
+    @torch.no_grad()
+    def _encode_texts_prefetched(self, uniq, order, emb_u, bs, budget, max_len, ac) -> bool:
+        """One list of distinct texts -> rows of `emb_u` through the producer / consumer pair above.  Returns False (nothing done) when the
+        tokenizer has no Rust backend or MFAR_ENCODE_PREFETCH=0: the caller then takes the generic path (`candidate_encoding_stream`)."""
+        if self._prefetch_backend() is None or not uniq:
+            return False
+
+        def produce(put, stop):
+            for item in self._token_batches(uniq, order, bs, budget, max_len, stop):
+                put(item)
+        self._consume(produce, lambda item: self._forward_rows(item[0], item[1], emb_u), ac)
         return True
+
+    @torch.no_grad()
+    def _encode_fields_prefetched(self, dense, prepare, bs, budget, max_len, ac) -> None:
+        """Every dense field through ONE producer: field j + 1 is formatted and tokenised while field j's forwards run, and the queue holds
+        batches across the boundary -- the GPU does not drain between fields."""
+        import numpy as np
+        cur = {}
+
+        def produce(put, stop):
+            for key, field in dense:
+                if stop.is_set():
+                    return
+                docs, texts, uniq, slot, order = prepare(field)
+                put(("field", key, docs, len(uniq), np.fromiter((slot[t] for t in texts), np.int64, len(texts))))
+                for feats, rows in self._token_batches(uniq, order, bs, budget, max_len, stop):
+                    put(("batch", feats, rows))
+                put(("end",))
+
+        def on_item(item):
+            if item[0] == "field":
+                _, cur["key"], cur["docs"], n_uniq, cur["rows"] = item
+                cur["emb"] = torch.empty(n_uniq, self.slab.dim, device=self.device)
+            elif item[0] == "batch":
+                self._forward_rows(item[1], item[2], cur["emb"])
+            else:
+                self._write_field(self.vectors_dict[cur["key"]], cur["docs"], cur["emb"], torch.from_numpy(cur["rows"]).to(self.device), bs)
+                cur.clear()
+        self._consume(produce, on_item, ac)
+
+    @staticmethod
+    def _write_field(vec, docs, emb_u, rows, bs) -> None:
+        """Rows of the distinct texts -> the field's rows in corpus order, straight into the HBM slab."""
+        step = max(bs, 65536)
+        for b in range(0, len(docs), step):
+            vec.write_block(docs[b][0], emb_u.index_select(0, rows[b:b + step]).contiguous())
 
     # ------------------------------------------------------------------ scoring (contrastive.py:669-704)
     def _get_searcher(self):

@@ -440,29 +440,52 @@ def test_prefetched_corpus_encode_equals_the_generic_path(monkeypatch):
     uniq = [""] + [" ".join(rng.choice(words, size=int(n))) for n in rng.integers(1, 30, size=150)]      # some far beyond 24 tokens
     uniq = list(dict.fromkeys(uniq))
     order = sorted(range(len(uniq)), key=lambda i: len(uniq[i]))
-    stub = types.SimpleNamespace(encoder=enc, device=torch.device("cpu"))
+    class Stub:                                                       # the methods under test on an object that is not a LightningModule
+        pass
+    for name in ("_prefetch_backend", "_token_batches", "_consume", "_forward_rows", "_encode_texts_prefetched", "_encode_fields_prefetched"):
+        setattr(Stub, name, getattr(RetrievalTrainingModule, name))
+    Stub._write_field = staticmethod(RetrievalTrainingModule._write_field)
+    stub = Stub()
+    stub.encoder, stub.device = enc, torch.device("cpu")
     E = enc.get_sentence_embedding_dimension()
     want = torch.stack([enc.encode([t], batch_size=1, convert_to_tensor=True)[0] for t in uniq])           # every text alone
     alone = torch.full((len(uniq), E), float("nan"))
-    assert RetrievalTrainingModule._encode_texts_prefetched(stub, uniq, order, alone, 1, 0, 24, None)      # budget 0, batch size 1: alone
+    assert stub._encode_texts_prefetched(uniq, order, alone, 1, 0, 24, None)      # budget 0, batch size 1: alone
     assert torch.equal(alone, want)
     for bs, budget in ((4, 0), (4, 4 * 24), (16, 16 * 24)):
         got = torch.full((len(uniq), E), float("nan"))
-        assert RetrievalTrainingModule._encode_texts_prefetched(stub, uniq, order, got, bs, budget, 24, None)
+        assert stub._encode_texts_prefetched(uniq, order, got, bs, budget, 24, None)
         assert not torch.isnan(got).any()
         assert torch.allclose(got, want, atol=2e-5, rtol=0), float((got - want).abs().max())
     # several producer chunks (1024, 2048, then 8192 texts): every row still written once, to the generic path's values
     many = list(dict.fromkeys(" ".join(rng.choice(words, size=int(n))) + f" {i}" for i, n in enumerate(rng.integers(1, 6, size=3400))))
     order_m = sorted(range(len(many)), key=lambda i: len(many[i]))
     got = torch.full((len(many), E), float("nan"))
-    assert RetrievalTrainingModule._encode_texts_prefetched(stub, many, order_m, got, 64, 64 * 24, 24, None)
+    assert stub._encode_texts_prefetched(many, order_m, got, 64, 64 * 24, 24, None)
     ref = enc.encode(many, batch_size=64, convert_to_tensor=True)
     assert not torch.isnan(got).any() and torch.allclose(got, ref, atol=2e-5, rtol=0)
+    # all fields through ONE producer: rows land in corpus order in each field's vectors, repeated texts get the one row of their text
+    written = {}
+    stub.slab = types.SimpleNamespace(dim=E)
+    stub.vectors_dict = {k: types.SimpleNamespace(write_block=lambda first, block, k=k: written.setdefault(k, []).append((first, block.clone())))
+                         for k in ("a", "b")}
+    corpus = {"a": [uniq[i % 7] for i in range(40)], "b": [uniq[(3 * i) % len(uniq)] for i in range(40)]}
+
+    def prepare(field):
+        docs = [(100 + i, t) for i, t in enumerate(corpus[field])]
+        texts = [t for _, t in docs]
+        u = list(dict.fromkeys(texts))
+        return docs, texts, u, {t: i for i, t in enumerate(u)}, sorted(range(len(u)), key=lambda i: len(u[i]))
+    stub._encode_fields_prefetched([("a", "a"), ("b", "b")], prepare, 1, 0, 24, None)
+    index_of = {t: i for i, t in enumerate(uniq)}
+    for k in ("a", "b"):
+        assert [first for first, _ in written[k]] == [100]
+        assert torch.equal(written[k][0][1], torch.stack([want[index_of[t]] for t in corpus[k]])), k
     # the tokenizer's own settings are not left changed for the generic path
     ids = enc.tokenize([uniq[-1], "x"])["input_ids"]
     assert ids.shape[1] <= 24 and ids.shape[0] == 2
     monkeypatch.setenv("MFAR_ENCODE_PREFETCH", "0")
-    assert not RetrievalTrainingModule._encode_texts_prefetched(stub, uniq, order, alone, 1, 0, 24, None)
+    assert not stub._encode_texts_prefetched(uniq, order, alone, 1, 0, 24, None)
     monkeypatch.delenv("MFAR_ENCODE_PREFETCH")
     stub.encoder = types.SimpleNamespace(tokenizer=object())                                               # no Rust backend
-    assert not RetrievalTrainingModule._encode_texts_prefetched(stub, uniq, order, alone, 1, 0, 24, None)
+    assert not stub._encode_texts_prefetched(uniq, order, alone, 1, 0, 24, None)
