@@ -3,7 +3,7 @@
 batches over and over.  Reports queries/s per 5-second window (clock / thermal drift) and compares EVERY result with the first pass's
 result of the same batch, ids and score bits -- a race anywhere in the pipeline (slots, streams, coalescing, the adaptive policy's
 feedback) would show up as a run-to-run difference.
-    python tools/soak.py [--seconds 60] [--docs 1000000 --fields 8 --dim 768]"""
+    python tools/soak.py [--seconds 60] [--docs 1000000 --fields 8 --dim 768 --dtype f32]"""
 import argparse
 import json
 import os
@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--docs", type=int, default=1_000_000)
     ap.add_argument("--fields", type=int, default=8)
     ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     a = ap.parse_args()
     import numpy as np
     from mfar import synth
@@ -30,7 +31,7 @@ def main():
     import bench
     Q, NB = 64, 32
     corpus = synth.SyntheticCorpus(a.docs, a.fields, a.dim, n_queries=Q * NB, seed=0xdeadbeef, device="cuda:0")
-    ix = corpus.build_index(idxmod)
+    ix = corpus.build_index(idxmod, dtype=a.dtype)
     W = corpus.W.cpu().numpy()
     qs = [corpus.queries(j * Q, Q).cpu().numpy() for j in range(NB)]
     pl = NativePipeline(ix, W, np.ones(a.fields, np.float32), max_batch=Q)
@@ -63,7 +64,7 @@ def main():
     for t, b in tickets:
         pl.result(t)
     st = ix.screen_stats()
-    out = {"shape": [a.docs, a.fields, a.dim], "seconds": round(time.perf_counter() - t0, 1), "batches": j, "queries": j * Q,
+    out = {"shape": [a.docs, a.fields, a.dim], "dtype": a.dtype, "stage1_kernel": ix.last_stage1_kernel(), "seconds": round(time.perf_counter() - t0, 1), "batches": j, "queries": j * Q,
            "queries_per_s_per_5s_window": windows, "min_over_max": round(min(windows) / max(windows), 4),
            "batches_compared_with_their_first_result": n_cmp, "different": n_diff, "launches_redone": pl.n_redone,
            "lists_checked": st.get("n_checked"), "lists_failed": st.get("n_failed"), "source_hash": bench.source_hash()}
