@@ -105,6 +105,65 @@ def _pipeline_section(rng, ix, slab, q, W, mask, o, k, sentinel, eps_mult, O, wh
     return ok, note
 
 
+def _sharded_section(rng, idxmod, slab, q, W, mask, o, k, sentinel, eps_mult, what):
+    """The multi-GPU data path in ONE process: the corpus cut into S RAGGED row shards (tiny ones included), one index per shard with its
+    row offset, then the lists-first exchange exactly as the ranks run it -- every shard's stage-1 lists into the "all-gathered" buffer
+    (mfar_retrieve_lists), every shard merges them and scores the candidates it owns (mfar_search_owned), the local top-k payloads are merged
+    (mfar_merge_topk) -- and the single-payload variant (mfar_search_local + mfar_merge_payloads) for the first block: the oracle's rows of
+    the UNSHARDED corpus, bit for bit."""
+    import torch
+    F, D, E = slab.shape
+    S = int(rng.choice([2, 3, 5, 8]))
+    if D < 2 * S:
+        return True, "-"
+    bounds = [0] + sorted(int(x) for x in rng.choice(np.arange(1, D), size=S - 1, replace=False)) + [D]
+    dev = torch.device("cuda", 0)
+    shards = []
+    for g in range(S):
+        lo, hi = bounds[g], bounds[g + 1]
+        sh = idxmod.MultiFieldIndex(hi - lo, F, E, device=0, row_offset=lo)
+        for f in range(F):
+            sh.write_rows(f, 0, np.ascontiguousarray(slab[f, lo:hi]))
+        sh.set_screen(int(rng.choice([0, 2, 2])), eps_mult)
+        shards.append(sh)
+    Wd, md = torch.from_numpy(W).to(dev), torch.from_numpy(mask).to(dev)
+    ok = True
+    Qb = 64
+    for b0 in range(0, q.shape[0], Qb):
+        qb = torch.from_numpy(np.ascontiguousarray(q[b0:b0 + Qb])).to(dev)
+        nq = qb.shape[0]
+        nl, nt = shards[0].lists_bytes(nq, k), shards[0].topk_bytes(nq, k)
+        lists_all = torch.empty(S * nl, dtype=torch.uint8, device=dev)
+        for g, sh in enumerate(shards):
+            sh.retrieve_lists(qb, lists_all[g * nl:(g + 1) * nl], k, sentinel)
+        topk_all = torch.empty(S * nt, dtype=torch.uint8, device=dev)
+        for g, sh in enumerate(shards):
+            sh.search_owned(lists_all, S, qb, Wd, topk_all[g * nt:(g + 1) * nt], md, k1=k, k2=k, sentinel=sentinel)
+        rx = idxmod.merge_topk(topk_all, S, nq, k2=k)
+        results = [("lists-first", rx)]
+        if b0 == 0:
+            npay = shards[0].payload_bytes(nq, k)
+            pay = torch.empty(S * npay, dtype=torch.uint8, device=dev)
+            for g, sh in enumerate(shards):
+                sh.search_local(qb, k1=k, sentinel=sentinel, payload=pay[g * npay:(g + 1) * npay])
+            results.append(("payloads", idxmod.merge_payloads(pay, S, qb, Wd, md, n_fields=F, k1=k, k2=k, sentinel=sentinel)))
+        torch.cuda.synchronize()
+        for name, r in results:
+            ids, sc, nv = (r[x].cpu().numpy() for x in ("ids", "scores", "n_valid"))
+            onv = o["n_valid"][b0:b0 + nq]
+            same = np.array_equal(nv, onv)
+            for j_ in range(nq if same else 0):
+                v = int(onv[j_])
+                same = same and np.array_equal(ids[j_, :v], o["ids"][b0 + j_, :v]) and \
+                    np.array_equal(sc[j_, :v].view(np.uint32), o["scores"][b0 + j_, :v].view(np.uint32))
+            if not same:
+                ok = False
+                print("MISMATCH sharded", name, dict(what, bounds=bounds, block=b0), flush=True)
+    for sh in shards:
+        sh.close()
+    return ok, f"S{S}min{min(bounds[g + 1] - bounds[g] for g in range(S))}"
+
+
 def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
     """One random configuration (shapes, data kind, knobs all drawn from `rng`) through stage 1 with the screen off and on, the whole
     scorer and -- sometimes -- the fused mode, against the C oracle.  Returns True when every comparison held."""
@@ -195,6 +254,10 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
     if ok and pipe_ok and rng.random() < 0.6:
         ok, pipe_note = _pipeline_section(rng, ix, slab, q, W, mask, o, k, sentinel, eps_mult, O,
                                dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, kind=int(kind), seed=seed, n=n, eps_mult=eps_mult))
+    shard_note = "-"
+    if ok and pipe_ok and rng.random() < 0.35:
+        ok, shard_note = _sharded_section(rng, idxmod, slab, q, W, mask, o, k, sentinel, eps_mult,
+                                          dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, kind=int(kind), seed=seed, n=n, eps_mult=eps_mult))
     if ok and dtype == "f32" and k < 128 and D * F * E * Q < 2e9 and rng.random() < 0.3:      # fused mode against its contract
         Wf = (rng.standard_normal((E, F)) * 0.05).astype(np.float32)
         oi, osc = O.c_search_fused(slab, q, Wf, None, k)
@@ -207,7 +270,7 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
     ix.close()
     if verbose or not ok:
         print(f"{n + 1:4d} ok={ok} F={F} D={D} E={E} Q={Q} k={k} sent={int(sentinel)} mean={mean} {dtype} kind={int(kind)} eps_mult={eps_mult:g} "
-              f"checked={st.get('n_checked')} failed={st.get('n_failed')} off={off} pipe={pipe_note}", flush=True)
+              f"checked={st.get('n_checked')} failed={st.get('n_failed')} off={off} pipe={pipe_note} shards={shard_note}", flush=True)
     return ok
 
 
