@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Randomised parity stress of stage 1 (all scan kernels, screen on/off) and of the whole scorer (with the screen on: certified
-re-scoring prefix, two-level stage 2) against the C oracle.
+"""Randomised parity stress of stage 1 (all scan kernels, screen on/off), of the whole scorer (with the screen on: certified
+re-scoring prefix, two-level stage 2), of the C-ABI batch pipeline over ragged batches and of the multi-GPU data path over ragged row
+shards (in one process) against the C oracle -- fp32 indexes, and bf16 indexes wherever their bit contract applies.
     python tests/stress.py [seconds] [seed] [big]   -- prints one line per configuration, exits non-zero on the first mismatch"""
 import os
 import sys
@@ -12,7 +13,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
-def _pipeline_section(rng, ix, slab, q, W, mask, o, k, sentinel, eps_mult, O, what):
+def _pipeline_section(rng, ix, slab, q, W, mask, o, k, sentinel, eps_mult, O, dtype, what):
     """The C-ABI batch pipeline (mfar_pipeline_*, the path bench.py times) over the same queries cut into RAGGED batches: random depth /
     coalescing / batch limit, host or device buffers, results taken late, at once or out of order, a weight change half-way (earlier tickets
     must keep the old weights' results), forced certificate failures (the redo path) -- every batch bit for bit the oracle's rows."""
@@ -22,7 +23,7 @@ def _pipeline_section(rng, ix, slab, q, W, mask, o, k, sentinel, eps_mult, O, wh
     max_batch = int(rng.choice([1, 3, 17, 64, 64, rng.integers(1, 65)]))
     depth, coalesce = int(rng.choice([0, 0, 2, 3, 4])), int(rng.choice([0, 0, 1, 2]))
     on_dev = bool(rng.integers(0, 2))
-    ix.set_screen(int(rng.choice([0, 2, 2])), eps_mult)
+    ix.set_screen(int(rng.choice([0, 2, 2])) if dtype == "f32" else 2, eps_mult)
     if coalesce * max_batch > ix.max_split_batch(k):        # (no wide pass for this index: an explicit request would be refused)
         coalesce = int(rng.choice([0, 1]))
     cuts, at = [], 0
@@ -37,7 +38,9 @@ def _pipeline_section(rng, ix, slab, q, W, mask, o, k, sentinel, eps_mult, O, wh
         mask2 = (rng.random(mask.shape[0]) < 0.7).astype(np.float32)
         if not mask2.any():
             mask2[0] = 1.0
-        o2 = O.c_two_stage(slab, q, W2, mask2, k1=k, k2=k, sentinel=sentinel)
+        import contextlib
+        with (O.chain("natural") if dtype == "bf16" else contextlib.nullcontext()):      # (`slab` holds the bf16-rounded rows then)
+            o2 = O.c_two_stage(slab, q, W2, mask2, k1=k, k2=k, sentinel=sentinel)
     dev = torch.device("cuda", 0)
     put = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)) if on_dev else (lambda a: np.ascontiguousarray(a))
     get = (lambda t: t.cpu().numpy()) if on_dev else (lambda a: a)
@@ -105,7 +108,7 @@ def _pipeline_section(rng, ix, slab, q, W, mask, o, k, sentinel, eps_mult, O, wh
     return ok, note
 
 
-def _sharded_section(rng, idxmod, slab, q, W, mask, o, k, sentinel, eps_mult, what):
+def _sharded_section(rng, idxmod, slab, q, W, mask, o, k, sentinel, eps_mult, dtype, what):
     """The multi-GPU data path in ONE process: the corpus cut into S RAGGED row shards (tiny ones included), one index per shard with its
     row offset, then the lists-first exchange exactly as the ranks run it -- every shard's stage-1 lists into the "all-gathered" buffer
     (mfar_retrieve_lists), every shard merges them and scores the candidates it owns (mfar_search_owned), the local top-k payloads are merged
@@ -121,10 +124,10 @@ def _sharded_section(rng, idxmod, slab, q, W, mask, o, k, sentinel, eps_mult, wh
     shards = []
     for g in range(S):
         lo, hi = bounds[g], bounds[g + 1]
-        sh = idxmod.MultiFieldIndex(hi - lo, F, E, device=0, row_offset=lo)
+        sh = idxmod.MultiFieldIndex(hi - lo, F, E, device=0, row_offset=lo, dtype=dtype)
         for f in range(F):
             sh.write_rows(f, 0, np.ascontiguousarray(slab[f, lo:hi]))
-        sh.set_screen(int(rng.choice([0, 2, 2])), eps_mult)
+        sh.set_screen(int(rng.choice([0, 2, 2])) if dtype == "f32" else 2, eps_mult)      # (bf16: the contract holds under the certified stage 1)
         shards.append(sh)
     Wd, md = torch.from_numpy(W).to(dev), torch.from_numpy(mask).to(dev)
     ok = True
@@ -213,6 +216,7 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
         ix.write_rows(f, 0, slab[f])
     ref = O.bf16_round(slab) if dtype == "bf16" else slab
     ok = True
+    bf16_exact = False           # bf16: the certified stage 1 is in use for this shape -> every list carries the natural-order chain's bits
     for screen in (0, 2):
         ix.set_screen(screen, eps_mult if screen else 1.0)        # 2 = certified stage 1 whenever the shapes allow (bf16: over the slab itself)
         ix.set_wgs_per_cu(int(rng.choice([1, 2, 4])))
@@ -224,6 +228,7 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
                 good = np.allclose(sc[:, f], osc, rtol=0, atol=1e-4 * max(1.0, float(np.abs(osc).max())))
                 st_ = ix.screen_stats()      # (dims whose k-steps divide by neither 4 nor 6 have no certified bf16 kernel: plain pass)
                 if screen == 2 and k + 64 <= 192 and st_["n_checked"] > 0:      # certified OR repaired by the chain pass: exact ids and bits
+                    bf16_exact = True
                     good = good and np.array_equal(ids[:, f], oi) and np.array_equal(sc[:, f].view(np.uint32), osc.view(np.uint32))
             else:
                 oi, osc = O.c_retrieve(ref[f], q, k, sentinel)
@@ -233,13 +238,18 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
                 print("MISMATCH", dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, dtype=dtype, kind=int(kind), screen=screen, f=f,
                                        seed=seed, n=n, eps_mult=eps_mult), flush=True)
     pipe_ok, pipe_note = False, "-"
-    if ok and dtype == "f32" and D * F * E * Q < 3e9 and F * k <= 4096:    # the whole scorer, both stage-1 paths
+    screens = (0, 2) if dtype == "f32" else (2,)      # (a bf16 index in mode 0 answers from the plain pass: its 1e-4, no bit contract)
+    if ok and (dtype == "f32" or bf16_exact) and D * F * E * Q < 3e9 and F * k <= 4096:    # the whole scorer, both stage-1 paths
         W = (rng.standard_normal((E, F)) * 0.05).astype(np.float32)
         mask = (rng.random(F) < 0.8).astype(np.float32)
         if rng.random() < 0.3:           # masks of any sign (the two-level stage 2 swaps its interval ends under a negative entry)
             mask = rng.choice(np.array([0.0, 1.0, -1.0, 0.5, 2.0], np.float32), F)
-        o = O.c_two_stage(slab, q, W, mask, k1=k, k2=k, sentinel=sentinel)
-        for screen in (0, 2):
+        if dtype == "f32":
+            o = O.c_two_stage(slab, q, W, mask, k1=k, k2=k, sentinel=sentinel)
+        else:
+            with O.chain("natural"):
+                o = O.c_two_stage(ref, q, W, mask, k1=k, k2=k, sentinel=sentinel)
+        for screen in screens:
             ix.set_screen(screen, eps_mult if screen else 1.0)
             try:
                 r = ix.search(q, W, mask, k1=k, k2=k, sentinel=sentinel)
@@ -252,11 +262,11 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
                 print("MISMATCH two-stage", dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, kind=int(kind), screen=screen,
                                                  seed=seed, n=n, eps_mult=eps_mult), flush=True)
     if ok and pipe_ok and rng.random() < 0.6:
-        ok, pipe_note = _pipeline_section(rng, ix, slab, q, W, mask, o, k, sentinel, eps_mult, O,
+        ok, pipe_note = _pipeline_section(rng, ix, ref, q, W, mask, o, k, sentinel, eps_mult, O, dtype,
                                dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, kind=int(kind), seed=seed, n=n, eps_mult=eps_mult))
     shard_note = "-"
     if ok and pipe_ok and rng.random() < 0.35:
-        ok, shard_note = _sharded_section(rng, idxmod, slab, q, W, mask, o, k, sentinel, eps_mult,
+        ok, shard_note = _sharded_section(rng, idxmod, slab, q, W, mask, o, k, sentinel, eps_mult, dtype,
                                           dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, kind=int(kind), seed=seed, n=n, eps_mult=eps_mult))
     if ok and dtype == "f32" and k < 128 and D * F * E * Q < 2e9 and rng.random() < 0.3:      # fused mode against its contract
         Wf = (rng.standard_normal((E, F)) * 0.05).astype(np.float32)
