@@ -108,6 +108,43 @@ def _pipeline_section(rng, ix, slab, q, W, mask, o, k, sentinel, eps_mult, O, dt
     return ok, note
 
 
+def _mask_sweep_section(rng, ix, ref, q, W, k, sentinel, eps_mult, O, dtype, what):
+    """mask_fields' sweep (mfar_search_stage2_masks): the union and stage 2 once, the mixer once per mask, for M random masks (any sign,
+    all-zero included), with and without the lists' exact scores as known pairs, stage-2 modes 0 / 1 / 2 (full gather / two-level up to two
+    masks / two-level over the union of every mask's survivors) -- each mask's rows against the oracle run with that mask."""
+    import contextlib
+    import torch
+    F = ref.shape[0]
+    dev = torch.device("cuda", 0)
+    M = int(rng.choice([1, 2, 3, 7]))
+    masks = rng.choice(np.array([0.0, 1.0, 1.0, 1.0, -1.0, 0.5, 2.0], np.float32), size=(M, F)).astype(np.float32)
+    if rng.random() < 0.2:
+        masks[int(rng.integers(0, M))] = 0.0
+    ix.set_screen(int(rng.choice([0, 2, 2])) if dtype == "f32" else 2, eps_mult)
+    ix.set_stage2_mode(int(rng.choice([0, 1, 2])))
+    ok = True
+    for b0 in range(0, q.shape[0], 128):
+        qb = np.ascontiguousarray(q[b0:b0 + 128])
+        qd, Wd, md = torch.from_numpy(qb).to(dev), torch.from_numpy(W).to(dev), torch.from_numpy(masks).to(dev)
+        fid, fsc = ix.retrieve_fields(qd, k, sentinel)
+        known = bool(rng.integers(0, 2))
+        sw = ix.search_stage2_masks(qd, Wd, fid, md, k1=k, k2=k, field_scores=fsc if known else None, sentinel=sentinel)
+        torch.cuda.synchronize()
+        for m in range(M):
+            with (O.chain("natural") if dtype == "bf16" else contextlib.nullcontext()):
+                oo = O.c_two_stage(ref, qb, W, masks[m], k1=k, k2=k, sentinel=sentinel)
+            ids, sc, nv = sw["ids"][m].cpu().numpy(), sw["scores"][m].cpu().numpy(), sw["n_valid"][m].cpu().numpy()
+            same = np.array_equal(nv, oo["n_valid"])
+            for j_ in range(qb.shape[0] if same else 0):
+                v = int(oo["n_valid"][j_])
+                same = same and np.array_equal(ids[j_, :v], oo["ids"][j_, :v]) and np.array_equal(sc[j_, :v].view(np.uint32), oo["scores"][j_, :v].view(np.uint32))
+            if not same:
+                ok = False
+                print("MISMATCH mask sweep", dict(what, M=M, mask=masks[m].tolist(), known=known, block=b0), flush=True)
+    ix.set_stage2_mode(1)
+    return ok, f"M{M}"
+
+
 def _sharded_section(rng, idxmod, slab, q, W, mask, o, k, sentinel, eps_mult, dtype, what):
     """The multi-GPU data path in ONE process: the corpus cut into S RAGGED row shards (tiny ones included), one index per shard with its
     row offset, then the lists-first exchange exactly as the ranks run it -- every shard's stage-1 lists into the "all-gathered" buffer
@@ -264,6 +301,10 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
     if ok and pipe_ok and rng.random() < 0.6:
         ok, pipe_note = _pipeline_section(rng, ix, ref, q, W, mask, o, k, sentinel, eps_mult, O, dtype,
                                dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, kind=int(kind), seed=seed, n=n, eps_mult=eps_mult))
+    sweep_note = "-"
+    if ok and pipe_ok and rng.random() < 0.3 and D * F * E * Q < 1e9:
+        ok, sweep_note = _mask_sweep_section(rng, ix, ref, q, W, k, sentinel, eps_mult, O, dtype,
+                                             dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, kind=int(kind), seed=seed, n=n, eps_mult=eps_mult))
     shard_note = "-"
     if ok and pipe_ok and rng.random() < 0.35:
         ok, shard_note = _sharded_section(rng, idxmod, slab, q, W, mask, o, k, sentinel, eps_mult, dtype,
@@ -280,7 +321,7 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
     ix.close()
     if verbose or not ok:
         print(f"{n + 1:4d} ok={ok} F={F} D={D} E={E} Q={Q} k={k} sent={int(sentinel)} mean={mean} {dtype} kind={int(kind)} eps_mult={eps_mult:g} "
-              f"checked={st.get('n_checked')} failed={st.get('n_failed')} off={off} pipe={pipe_note} shards={shard_note}", flush=True)
+              f"checked={st.get('n_checked')} failed={st.get('n_failed')} off={off} pipe={pipe_note} sweep={sweep_note} shards={shard_note}", flush=True)
     return ok
 
 

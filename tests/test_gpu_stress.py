@@ -2,7 +2,7 @@
 64 / 128 columns, bf16 certified and plain), all data kinds (plain, duplicate groups, ramps, tiny values, heavy-tailed norms, clusters of
 near-duplicates), screen off / auto-forced on / every certificate forced to fail, ROW MODE and score-dump settings drawn per configuration,
 the whole scorer, the C-ABI pipeline over ragged batches (random depth / coalescing, host or device buffers, late and out-of-order results, a
-weight change half-way), the multi-GPU data path in one process (S ragged row shards down to single rows: lists-first exchange and the
+weight change half-way), mask_fields' sweep (1 - 7 random masks per call), the multi-GPU data path in one process (S ragged row shards down to single rows: lists-first exchange and the
 single-payload variant) and the fused mode -- every comparison bit for bit against the C oracle (bf16 plain pass: its 1e-4).  The long randomised run
 stays `python tests/stress.py <seconds> <seed> [big]` (profiles/*_stress_tail.txt)."""
 import time
