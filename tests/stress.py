@@ -254,26 +254,38 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
     ref = O.bf16_round(slab) if dtype == "bf16" else slab
     ok = True
     bf16_exact = False           # bf16: the certified stage 1 is in use for this shape -> every list carries the natural-order chain's bits
-    for screen in (0, 2):
-        ix.set_screen(screen, eps_mult if screen else 1.0)        # 2 = certified stage 1 whenever the shapes allow (bf16: over the slab itself)
-        ix.set_wgs_per_cu(int(rng.choice([1, 2, 4])))
-        ids, sc = ix.retrieve_fields(q, k, sentinel)
-        for f in range(F):
-            if dtype == "bf16":
-                with O.chain("natural"):
-                    oi, osc = O.c_retrieve(ref[f], q, k, sentinel)
-                good = np.allclose(sc[:, f], osc, rtol=0, atol=1e-4 * max(1.0, float(np.abs(osc).max())))
-                st_ = ix.screen_stats()      # (dims whose k-steps divide by neither 4 nor 6 have no certified bf16 kernel: plain pass)
-                if screen == 2 and k + 64 <= 192 and st_["n_checked"] > 0:      # certified OR repaired by the chain pass: exact ids and bits
-                    bf16_exact = True
-                    good = good and np.array_equal(ids[:, f], oi) and np.array_equal(sc[:, f].view(np.uint32), osc.view(np.uint32))
-            else:
-                oi, osc = O.c_retrieve(ref[f], q, k, sentinel)
-                good = np.array_equal(ids[:, f], oi) and np.array_equal(sc[:, f].view(np.uint32), osc.view(np.uint32))
-            if not good:
-                ok = False
-                print("MISMATCH", dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, dtype=dtype, kind=int(kind), screen=screen, f=f,
-                                       seed=seed, n=n, eps_mult=eps_mult), flush=True)
+    n_updates = int(rng.choice([0, 0, 1, 2]))     # rows REPLACED after the first round of checks (a re-encoded field, a few edited rows)
+    for update in range(n_updates + 1):
+      if update:
+        f_ = int(rng.integers(0, F))
+        a_ = int(rng.integers(0, D))
+        b_ = int(min(D, a_ + rng.choice([1, 7, 300, D])))
+        new = (rng.standard_normal((b_ - a_, E)) * 0.5 + mean * mu * 4.0).astype(np.float32)
+        if rng.random() < 0.3:
+            new[:] = slab[f_, int(rng.integers(0, D))]                     # ... copies of one existing row: a duplicate group appears
+        slab[f_, a_:b_] = new
+        ix.write_rows(f_, a_, new)
+        ref = O.bf16_round(slab) if dtype == "bf16" else slab
+      for screen in (0, 2):
+          ix.set_screen(screen, eps_mult if screen else 1.0)        # 2 = certified stage 1 whenever the shapes allow (bf16: over the slab itself)
+          ix.set_wgs_per_cu(int(rng.choice([1, 2, 4])))
+          ids, sc = ix.retrieve_fields(q, k, sentinel)
+          for f in range(F):
+              if dtype == "bf16":
+                  with O.chain("natural"):
+                      oi, osc = O.c_retrieve(ref[f], q, k, sentinel)
+                  good = np.allclose(sc[:, f], osc, rtol=0, atol=1e-4 * max(1.0, float(np.abs(osc).max())))
+                  st_ = ix.screen_stats()      # (dims whose k-steps divide by neither 4 nor 6 have no certified bf16 kernel: plain pass)
+                  if screen == 2 and k + 64 <= 192 and st_["n_checked"] > 0:      # certified OR repaired by the chain pass: exact ids and bits
+                      bf16_exact = True
+                      good = good and np.array_equal(ids[:, f], oi) and np.array_equal(sc[:, f].view(np.uint32), osc.view(np.uint32))
+              else:
+                  oi, osc = O.c_retrieve(ref[f], q, k, sentinel)
+                  good = np.array_equal(ids[:, f], oi) and np.array_equal(sc[:, f].view(np.uint32), osc.view(np.uint32))
+              if not good:
+                  ok = False
+                  print("MISMATCH", dict(F=F, D=D, E=E, Q=Q, k=k, sentinel=sentinel, mean=mean, dtype=dtype, kind=int(kind), screen=screen, f=f,
+                                         seed=seed, n=n, eps_mult=eps_mult), flush=True)
     pipe_ok, pipe_note = False, "-"
     screens = (0, 2) if dtype == "f32" else (2,)      # (a bf16 index in mode 0 answers from the plain pass: its 1e-4, no bit contract)
     if ok and (dtype == "f32" or bf16_exact) and D * F * E * Q < 3e9 and F * k <= 4096:    # the whole scorer, both stage-1 paths
@@ -320,7 +332,7 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
     off = ix.auto_off_info()["off"]
     ix.close()
     if verbose or not ok:
-        print(f"{n + 1:4d} ok={ok} F={F} D={D} E={E} Q={Q} k={k} sent={int(sentinel)} mean={mean} {dtype} kind={int(kind)} eps_mult={eps_mult:g} "
+        print(f"{n + 1:4d} ok={ok} F={F} D={D} E={E} Q={Q} k={k} sent={int(sentinel)} mean={mean} {dtype} kind={int(kind)} eps_mult={eps_mult:g} upd={n_updates} "
               f"checked={st.get('n_checked')} failed={st.get('n_failed')} off={off} pipe={pipe_note} sweep={sweep_note} shards={shard_note}", flush=True)
     return ok
 
