@@ -481,6 +481,24 @@ def test_prefetched_corpus_encode_equals_the_generic_path(monkeypatch):
     for k in ("a", "b"):
         assert [first for first, _ in written[k]] == [100]
         assert torch.equal(written[k][0][1], torch.stack([want[index_of[t]] for t in corpus[k]])), k
+    # a failing forward surfaces here and the producer thread is gone when it does (no batch left behind a full queue)
+    import threading
+
+    class Boom(RuntimeError):
+        pass
+    calls = {"n": 0}
+    real_forward = enc.forward
+
+    def failing(features):
+        calls["n"] += 1
+        if calls["n"] == 3:
+            raise Boom("forward failed")
+        return real_forward(features)
+    enc.forward = failing
+    with pytest.raises(Boom):
+        stub._encode_texts_prefetched(many, order_m, torch.empty(len(many), E), 8, 0, 24, None)
+    enc.forward = real_forward
+    assert not [t for t in threading.enumerate() if t.name == "mfar-encode-prefetch"]
     # the tokenizer's own settings are not left changed for the generic path
     ids = enc.tokenize([uniq[-1], "x"])["input_ids"]
     assert ids.shape[1] <= 24 and ids.shape[0] == 2
