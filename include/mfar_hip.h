@@ -390,7 +390,10 @@ int mfar_stage2_stats(mfar_index* idx, int* two_level_available, int64_t* gather
  *   - COALESCING: when mfar_max_split_batch() is 128, `coalesce` (0 = auto: 2) consecutive batches of max_batch <= 64 queries are scanned
  *     by one launch of the wide pass -- half the scan bytes per query; results per query are unchanged;
  *   - a launch whose certificate failed is redone exactly when its result is taken; data on which that keeps happening is handled by the
- *     library (mfar_set_auto_off).
+ *     library (mfar_set_auto_off);
+ *   - a launch that could not be enqueued (submit / flush / result returned MFAR_ERR_NOMEM or MFAR_ERR_HIP from inside the launch) keeps its
+ *     batches: their tickets stay registered (*ticket is written before the launch is attempted) and the launch is run, synchronously, when
+ *     one of its results is taken or its slot comes round again -- or the error repeats there.  Nothing half-done is ever returned.
  * Results are bit for bit those of mfar_search_two_stage(idx, q, ...) for the same queries.
  *   create     W [E, F] (query_cond) or [F]; mask [F] or NULL (ones); copied (host or device pointers per on_device).
  *   submit     q [Q, E], 1 <= Q <= max_batch; host pointer (copied before the call returns) or device pointer (copied on `stream`, which

@@ -29,8 +29,10 @@ static int fail(int code, const std::string& msg) {
 #define HIPCHK(expr)                                                                                  \
     do {                                                                                              \
         hipError_t e_ = (expr);                                                                       \
-        if (e_ != hipSuccess)                                                                         \
+        if (e_ != hipSuccess) {                                                                       \
+            (void)hipGetLastError(); /* reported HERE: not left behind for the next call's launch check */ \
             return fail(MFAR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+        }                                                                                             \
     } while (0)
 #define RETCHK(expr)            \
     do {                        \
@@ -51,6 +53,7 @@ struct DevBuf {
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
             p = nullptr;
+            (void)hipGetLastError();      // the failed allocation is REPORTED here; left sticky it would fail the caller's next launch check
             return fail(MFAR_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
         }
         cap = want;
@@ -325,8 +328,10 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) idx->n_cu = prop.multiProcessorCount;
     hipError_t e = hipMalloc(&idx->slab, idx->slab_bytes);
     if (e != hipSuccess) {
+        const size_t wanted = idx->slab_bytes;
         delete idx;
-        return fail(MFAR_ERR_NOMEM, std::string("hipMalloc(slab ") + std::to_string(idx->slab_bytes) + " B): " + hipGetErrorString(e));
+        (void)hipGetLastError();
+        return fail(MFAR_ERR_NOMEM, std::string("hipMalloc(slab ") + std::to_string(wanted) + " B): " + hipGetErrorString(e));
     }
     e = hipMemset(idx->slab, 0, idx->slab_bytes);
     if (e != hipSuccess) {

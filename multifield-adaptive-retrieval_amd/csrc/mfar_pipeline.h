@@ -47,6 +47,7 @@ struct mfar_pipeline {
         hipEvent_t stage1 = nullptr, done = nullptr, copied = nullptr;
         int Q = 0;
         bool checked = true;
+        bool failed = false;              // pipe_launch returned an error part-way (out of memory ...): nothing valid was enqueued for this launch
         long long launch = -1;
     } slots[PIPE_MAX_DEPTH];
     struct Where {
@@ -78,6 +79,7 @@ static int pipe_launch(mfar_pipeline* p) {
     s.Q = Q;
     s.checked = false;
     s.launch = p->n_launched;
+    s.failed = true;                 // until everything below is enqueued: a launch that errors out is redone by pipe_check, never read as is
     p->n_launched++;
     RETCHK(stage1_block(idx, slot, S1_PREPARE | S1_SCAN | (merge_in_finish() ? 0 : S1_FINISH), s.q.as<float>(), Q, 0, p->k1, p->sentinel, 0, idx->F,
                         s.fid.as<long long>(), s.fsc.as<float>(), nullptr, p->st->main));
@@ -93,6 +95,7 @@ static int pipe_launch(mfar_pipeline* p) {
     RETCHK(pipe_tail(p, s, slot, side));
     HIPCHK(hipMemcpyAsync(s.fail_host, s.fail.p, 4, hipMemcpyDeviceToHost, side));
     HIPCHK(hipEventRecord(s.done, side));
+    s.failed = false;
     return MFAR_OK;
 }
 
@@ -102,9 +105,21 @@ static int pipe_check(mfar_pipeline* p, long long launch) {
     const int slot = (int)(launch % p->depth);
     mfar_pipeline::Slot& s = p->slots[slot];
     if (s.checked || s.launch != launch) return MFAR_OK;
+    if (s.failed) {                  // the launch never made it onto the streams (its error went to the caller of submit / flush): the batch's
+        HIPCHK(hipDeviceSynchronize());      // queries are in the slot, so it is run now, synchronously -- or the error repeats
+        RETCHK(run_stage1(p->idx, s.q.as<float>(), s.Q, p->k1, p->sentinel, s.fid.as<long long>(), s.fsc.as<float>(), p->st->main));
+        RETCHK(pipe_tail(p, s, slot, p->st->main));
+        HIPCHK(hipStreamSynchronize(p->st->main));
+        s.failed = false;
+        s.checked = true;
+        p->n_redone++;
+        return MFAR_OK;
+    }
     HIPCHK(hipEventSynchronize(s.done));
-    s.checked = true;
-    if (s.fail_host[0] == 0) return MFAR_OK;
+    if (s.fail_host[0] == 0) {
+        s.checked = true;
+        return MFAR_OK;
+    }
     p->n_redone++;
     if (p->idx->row_mode_setting != 0) p->idx->row_mask = p->idx->row_eligible;
     HIPCHK(hipDeviceSynchronize());                 // the redo uses the index's slot-0 stage-1 scratch: nothing else may be in flight
@@ -112,6 +127,8 @@ static int pipe_check(mfar_pipeline* p, long long launch) {
     RETCHK(run_stage1(p->idx, s.q.as<float>(), s.Q, p->k1, p->sentinel, s.fid.as<long long>(), s.fsc.as<float>(), p->st->main));
     RETCHK(pipe_tail(p, s, slot, p->st->main));
     HIPCHK(hipStreamSynchronize(p->st->main));
+    s.fail_host[0] = 0;
+    s.checked = true;                // (only now: a redo that errors out is attempted again, its half-written slot never returned)
     return MFAR_OK;
 }
 

@@ -238,7 +238,8 @@ class PipelinedSearcher:
         for tk in [tk for tk, (L, _, _) in self._where.items() if L <= self.n_launched - self.depth]:
             del self._where[tk]                       # this launch overwrites the results of the slot's previous launch
         s["Q"], s["checked"], s["launch"] = Q, False, self.n_launched
-        self.n_launched += 1
+        s["failed"] = True            # until everything below is enqueued: a launch that raises part-way (out of memory ...) is redone by
+        self.n_launched += 1          # _check when its result is taken, never read as is
         cur = torch.cuda.current_stream(self.dev)
         self.main.wait_stream(cur)                    # W / mask may have been produced on the caller's stream
         with torch.cuda.stream(self.main):
@@ -270,6 +271,7 @@ class PipelinedSearcher:
             self._tail(s, slot)
             s["fail_host"].copy_(s["fail"], non_blocking=True)
             s["done"].record(side)
+        s["failed"] = False
 
     # host side of the certificate: wait for the launch, redo it exactly if its screen could not be proven
     def _check(self, launch: int):
@@ -279,10 +281,13 @@ class PipelinedSearcher:
         s = self.slots[slot]
         if s["checked"] or s["launch"] != launch:
             return
-        s["done"].synchronize()
-        s["checked"] = True
-        failed = int(s["fail_host"][0]) != 0
+        if s.get("failed"):           # never made it onto the streams (the error went to the caller of submit): run it now, or raise again
+            failed = True
+        else:
+            s["done"].synchronize()
+            failed = int(s["fail_host"][0]) != 0
         if not failed:
+            s["checked"] = True
             return
         # A redo costs a pipeline drain plus a second pass: rare by construction (see _launch).
         self.n_redone += 1
@@ -302,6 +307,7 @@ class PipelinedSearcher:
             self.ix.retrieve_lists(qk, s["lists"], self.k1, self.sentinel)
         self._tail(s, slot)
         torch.cuda.current_stream(self.dev).synchronize()
+        s["checked"], s["failed"] = True, False
 
     def lists(self, ticket: int):
         """The stage-1 lists of a batch whose `result()` has been taken and is still valid: (field_ids [Q, F, k1] int64, field_scores
@@ -398,10 +404,16 @@ class NativePipeline:
         import ctypes
         import numpy as np
         qa = _index._Arg(q, np.float32, self.ix.device)
-        t = ctypes.c_int64()
-        _native.check(_native.lib().mfar_pipeline_submit(self._p, qa.ptr, int(qa.keep.shape[0]), int(qa.on_device),
-                                                         _index._current_stream(self.ix.device, qa.on_device), ctypes.byref(t)))
-        self._meta[t.value] = (int(qa.keep.shape[0]), bool(qa.on_device))
+        t = ctypes.c_int64(-1)
+        rc = _native.lib().mfar_pipeline_submit(self._p, qa.ptr, int(qa.keep.shape[0]), int(qa.on_device),
+                                                _index._current_stream(self.ix.device, qa.on_device), ctypes.byref(t))
+        if t.value >= 0:                 # (registered even when the launch itself failed: the library runs it when the result is taken)
+            self._meta[t.value] = (int(qa.keep.shape[0]), bool(qa.on_device))
+        try:
+            _native.check(rc)
+        except _native.MfarError as e:
+            e.ticket = t.value if t.value >= 0 else None
+            raise
         for old in [k for k in self._meta if k <= t.value - 2 * self.depth * self.coalesce]:
             del self._meta[old]
         return t.value

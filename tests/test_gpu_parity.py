@@ -1622,3 +1622,95 @@ def test_limits_of_fields_and_list_depth(idxmod):
     with pytest.raises(Exception):
         idxmod.MultiFieldIndex(100, 33, E, device=0)                # n_fields > MFAR_MAX_FIELDS
     ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_full_hbm_degrades_to_the_exact_pass(idxmod, dtype):
+    """HBM nearly full when a query arrives.  (1) Not even the call's scratch fits: a clean MFAR_ERR_NOMEM, no stale HIP error left behind --
+    the next call works; (1b) the same through the C-ABI pipeline: the launch that could not be enqueued keeps its batch, the error repeats
+    while memory is short, the batch is run when its result is taken afterwards; (2) a little more room: the screen's big buffers (fp16 copy,
+    gather slab) cannot all be allocated -- a clean error or the oracle's rows from whatever could be built, and the right rows once memory
+    is back."""
+    import contextlib
+    import torch
+    from mfar import _native
+    from mfar.data.pipeline import NativePipeline
+    rng = np.random.default_rng(71)
+    F, D, E, Q = 4, 120_000, 256, 9
+    mu = rng.standard_normal(E).astype(np.float32)
+    mu /= np.linalg.norm(mu)
+    slab = (rng.standard_normal((F, D, E), dtype=np.float32) * 0.5 + 0.3 * mu * 4.0).astype(np.float32)
+    q = (rng.standard_normal((Q, E)) * 0.5 + mu * 2.0).astype(np.float32)
+    W = (rng.standard_normal((E, F)) * 0.05).astype(np.float32)
+    ref = O.bf16_round(slab) if dtype == "bf16" else slab
+    with (O.chain("natural") if dtype == "bf16" else contextlib.nullcontext()):
+        o = O.c_two_stage(ref, q, W, None)
+
+    def right(r, what):
+        if dtype == "f32":
+            assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32)), what
+        else:
+            O.assert_topk_equivalent(r["ids"], r["scores"], o["ids"], o["scores"], tol=TOL, what=what)
+
+    def fresh():
+        ix = idxmod.MultiFieldIndex(D, F, E, device=0, dtype=dtype)
+        for f in range(F):
+            ix.write_rows(f, 0, slab[f])
+        torch.cuda.synchronize()
+        return ix
+
+    torch.cuda.empty_cache()
+    room = F * D * E * 4 + (4 << 30)                 # one index at a time, its screen + gather slab, a pipeline's scratch (3 slots x ~0.3 GB)
+    big = torch.empty(torch.cuda.mem_get_info(0)[0] - room, dtype=torch.uint8, device="cuda:0")     # (one huge allocation for the whole test)
+
+    def squeeze(keep_mb):
+        torch.cuda.empty_cache()
+        return torch.empty(max(0, torch.cuda.mem_get_info(0)[0] - (keep_mb << 20)), dtype=torch.uint8, device="cuda:0")
+
+    try:
+        # (1)
+        ix = fresh()
+        hog = squeeze(24)
+        with pytest.raises(_native.MfarError) as err:
+            ix.search(q, W, None)
+        assert "NOMEM" in str(err.value) or "out of memory" in str(err.value), str(err.value)
+        del hog
+        torch.cuda.empty_cache()
+        right(ix.search(q, W, None), "after a failed call")
+        ix.close()
+        # (1b)
+        ix = fresh()
+        pl = NativePipeline(ix, W, None, max_batch=16, coalesce=1)
+        hog = squeeze(24)
+        with pytest.raises(_native.MfarError) as err:
+            pl.submit(q)
+        ticket = err.value.ticket
+        assert ticket is not None
+        with pytest.raises(_native.MfarError):
+            pl.result(ticket)                           # still no memory: the error repeats, nothing half-done comes back
+        del hog
+        torch.cuda.empty_cache()
+        got = [pl.result(ticket), pl.result(pl.submit(q))]      # memory is back: the kept batch is run now; new batches flow
+        assert pl.n_redone >= 1
+        for g in got:
+            right(g, "pipeline after a failed launch")
+        pl.close()
+        ix.close()
+        # (2)
+        for keep_mb in (260, 520):
+            ix = fresh()
+            hog = squeeze(keep_mb)
+            r = None
+            try:
+                r = ix.search(q, W, None)
+            except _native.MfarError as e:
+                assert "NOMEM" in str(e) or "out of memory" in str(e), str(e)
+            del hog
+            torch.cuda.empty_cache()
+            if r is not None:
+                right(r, f"under memory pressure, {keep_mb} MB free")
+            right(ix.search(q, W, None), f"after memory pressure, {keep_mb} MB")
+            ix.close()
+    finally:
+        del big
+        torch.cuda.empty_cache()
