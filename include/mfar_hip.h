@@ -18,7 +18,8 @@
  *     (contrastive.py:247-248, modeling/util.py:80-81); they must fit 32 bits (row_offset + n_rows < 2^32-1).
  *   - ordering everywhere: (score descending, doc id ascending)  -- the canonical tie-break; the reference's
  *     own tie order is unspecified (unstable torch.topk, hash-ordered set: contrastive.py:679,696).
- *   - calls on one handle must be serialised by the caller (one handle per process per GPU).
+ *   - calls on one handle (an index and the pipelines over it) must be serialised by the caller; DIFFERENT handles may be driven from
+ *     different host threads at the same time (they share the device's streams inside the library, nothing else).
  */
 #ifndef MFAR_HIP_H
 #define MFAR_HIP_H

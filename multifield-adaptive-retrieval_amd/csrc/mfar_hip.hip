@@ -198,8 +198,10 @@ struct mfar_index {
     int ev_n = 0;
 };
 
+static std::mutex g_attr_mu;               // (handles may be created from different host threads)
 static int set_kernel_attrs(int device) {
     if (device < 0 || device >= 16) return fail(MFAR_ERR_INVALID, "device index out of range");
+    std::lock_guard<std::mutex> lk(g_attr_mu);
     if (g_attr_done[device]) return MFAR_OK;
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1_LDS_BYTES));

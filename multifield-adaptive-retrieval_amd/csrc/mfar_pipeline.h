@@ -18,7 +18,9 @@ struct PipeStreams {            // one set per device and process, shared by eve
     bool ok = false;
 };
 static PipeStreams g_pipe_streams[16];
+static std::mutex g_pipe_streams_mu;      // (handles may be created from different host threads)
 static int pipe_streams(int device, PipeStreams** out) {
+    std::lock_guard<std::mutex> lk(g_pipe_streams_mu);
     PipeStreams& s = g_pipe_streams[device];
     if (!s.ok) {
         int least = 0, greatest = 0;

@@ -257,3 +257,49 @@ def test_result_view_and_stream_helper():
     assert lib.mfar_pipeline_result_view(pl._p, ctypes.c_int64(t1 + 5), *[None] * 5) != 0                      # not a ticket
     pl.close()
     ix.close()
+
+
+def test_two_indexes_from_two_host_threads():
+    """Different handles may be driven from different host threads at once (include/mfar_hip.h): two threads, each with its OWN index (an
+    fp32 and a bf16 one, different shapes) and its own C-ABI pipeline, created and used concurrently -- first-use initialisation included --
+    every result against the synchronous search of the same index."""
+    import threading
+    from mfar.data import index as idxmod
+    from mfar.data.pipeline import NativePipeline
+    errors, barrier = [], threading.Barrier(2)
+
+    def worker(seed, F, D, E, dtype):
+        try:
+            rng = np.random.default_rng(seed)
+            slab, mu, W = _mk(rng, F, D, E)
+            barrier.wait()                                   # both create their index (and the library's per-device state) together
+            ix = idxmod.MultiFieldIndex(D, F, E, device=0, dtype=dtype)
+            for f in range(F):
+                ix.write_rows(f, 0, slab[f])
+            ix.set_screen(2)
+            qs = [(rng.standard_normal((32, E)) * 0.5 + mu * 2.0).astype(np.float32) for _ in range(40)]
+            pl = NativePipeline(ix, W, None, max_batch=32)
+            tickets, got = [], []
+            for i, q in enumerate(qs):
+                tickets.append(pl.submit(q))
+                if i >= pl.lag:
+                    got.append(pl.result(tickets[i - pl.lag]))
+            got += [pl.result(t) for t in tickets[len(got):]]
+            pl.close()
+            for q, g in zip(qs, got):
+                ref = ix.search(q, W, None)
+                if not (np.array_equal(g["ids"], ref["ids"]) and np.array_equal(g["scores"].view(np.uint32), ref["scores"].view(np.uint32))):
+                    errors.append((seed, "result differs from the synchronous search"))
+                    break
+            ix.close()
+        except Exception as e:                               # noqa: BLE001 -- reported by the main thread
+            errors.append((seed, repr(e)))
+
+    for rep in range(4):
+        threads = [threading.Thread(target=worker, args=a) for a in ((10 * rep + 1, 3, 30000, 64, "f32"), (10 * rep + 2, 5, 21000, 96, "bf16"))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in threads)
+        assert not errors, (rep, errors)
