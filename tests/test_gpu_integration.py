@@ -303,3 +303,39 @@ def test_two_indexes_from_two_host_threads():
             t.join(timeout=300)
         assert not any(t.is_alive() for t in threads)
         assert not errors, (rep, errors)
+
+
+def test_rows_rewritten_while_launches_are_in_flight():
+    """A training loop re-encodes a field while the previous evaluation's launches are still in flight: mfar_index_write_rows between
+    submits.  Batches submitted AFTER the write see the new rows (screen tables, fp16 copy, gather slab and dumps are rebuilt behind a
+    device synchronisation); batches submitted before it return rows of the old or the new corpus -- never a crash, never a mixture that
+    is neither (their lists are certified against whatever the scan read, so each such result must equal one of the two oracles)."""
+    from mfar.data import index as idxmod
+    from mfar.data.pipeline import NativePipeline
+    rng = np.random.default_rng(33)
+    F, D, E, Q = 3, 40000, 64, 32
+    slab, mu, W = _mk(rng, F, D, E)
+    new_field = (rng.standard_normal((D, E)) * 0.5 + 0.3 * mu * 4.0).astype(np.float32)
+    slab2 = slab.copy()
+    slab2[1] = new_field
+    qs = [(rng.standard_normal((Q, E)) * 0.5 + mu * 2.0).astype(np.float32) for _ in range(12)]
+    ix = idxmod.MultiFieldIndex(D, F, E, device=0)
+    for f in range(F):
+        ix.write_rows(f, 0, slab[f])
+    ix.set_screen(2)
+    pl = NativePipeline(ix, W, None, max_batch=Q)
+    tickets = [pl.submit(q) for q in qs[:5]]                 # five batches in flight or held (depth 3 x coalesce 2: all tickets valid)
+    ix.write_rows(1, 0, new_field)                           # the whole field replaced under them
+    tickets += [pl.submit(q) for q in qs[5:6]]
+    got = [pl.result(t) for t in tickets]
+    for q in qs[6:]:
+        got.append(pl.result(pl.submit(q)))
+    pl.close()
+    ix.close()
+    olds = [O.c_two_stage(slab, q, W, None) for q in qs[:6]]
+    news = [O.c_two_stage(slab2, q, W, None) for q in qs]
+    same = lambda g, o: np.array_equal(g["ids"], o["ids"]) and np.array_equal(g["scores"].view(np.uint32), o["scores"].view(np.uint32))
+    for i in range(5):                                       # submitted before the write: the old corpus or the new one
+        assert same(got[i], olds[i]) or same(got[i], news[i]), i
+    for i in range(5, len(qs)):                              # submitted after it: the new corpus
+        assert same(got[i], news[i]), i
