@@ -1714,3 +1714,44 @@ def test_full_hbm_degrades_to_the_exact_pass(idxmod, dtype):
     finally:
         del big
         torch.cuda.empty_cache()
+
+
+def test_degenerate_sizes_and_one_large_call(idxmod):
+    """An EMPTY index, one row, two rows (fewer rows than k, lists shorter than k1, a final list shorter than k2) through the synchronous
+    scorer and the C-ABI pipeline, both padding conventions; and 1000 queries in ONE synchronous call (eight wide blocks of 128): the oracle's
+    rows on their valid prefix, its n_valid."""
+    from mfar.data.pipeline import NativePipeline
+    rng = np.random.default_rng(90)
+    for D in (0, 1, 2):
+        ix = idxmod.MultiFieldIndex(D, 2, 32, device=0)
+        slab = rng.standard_normal((2, D, 32)).astype(np.float32)
+        q = rng.standard_normal((5, 32)).astype(np.float32)
+        W = (rng.standard_normal((32, 2)) * 0.05).astype(np.float32)
+        for f in range(2):
+            if D:
+                ix.write_rows(f, 0, slab[f])
+        for sentinel in (True, False):
+            r = ix.search(q, W, None, k1=10, k2=10, sentinel=sentinel)
+            pl = NativePipeline(ix, W, None, k1=10, k2=10, sentinel=sentinel, max_batch=8)
+            g = pl.result(pl.submit(q))
+            pl.close()
+            if D == 0:
+                assert (r["n_valid"] == 0).all() and (g["n_valid"] == 0).all()
+                continue
+            o = O.c_two_stage(slab, q, W, None, k1=10, k2=10, sentinel=sentinel)
+            for res in (r, g):
+                assert np.array_equal(res["n_valid"], o["n_valid"]), (D, sentinel)
+                for i in range(5):
+                    v = int(o["n_valid"][i])
+                    assert np.array_equal(res["ids"][i, :v], o["ids"][i, :v]) and \
+                        np.array_equal(res["scores"][i, :v].view(np.uint32), o["scores"][i, :v].view(np.uint32)), (D, sentinel, i)
+        ix.close()
+    F, D, E, Q = 3, 5000, 64, 1000
+    slab, q, W = _mk(rng, F, D, E, Q)
+    ix = _load(idxmod, slab)
+    o = O.c_two_stage(slab, q, W, None)
+    for screen in (0, 2):
+        ix.set_screen(screen)
+        r = ix.search(q, W, None)
+        assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["scores"].view(np.uint32), o["scores"].view(np.uint32)), screen
+    ix.close()
