@@ -46,6 +46,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
+COPY_CEILING_GBS = 6290.0      # same guide: what a plain copy kernel reaches on this part (measured), the practical ceiling of a streaming read
 K1 = K2 = 100
 
 
@@ -189,6 +190,7 @@ def main():
     ap.add_argument("--cpu-sample-docs", type=int, default=0, help="0 = the full corpus when host RAM allows, else 100000")
     ap.add_argument("--no-encode-leg", action="store_true", help="skip the corpus-encode / mask-sweep leg (tools/encode_bench.py)")
     ap.add_argument("--encode-docs", type=int, default=50000, help="records of the corpus-encode leg")
+    ap.add_argument("--encode-docs-amazon", type=int, default=20000, help="records of the amazon-shaped corpus-encode leg")
     args = ap.parse_args()
 
     # `--gpus N` without a launcher: this process only spawns the ranks (before anything initialises the GPU)
@@ -484,7 +486,7 @@ def main():
                 h.update(ids.tobytes())
             checksum = h.hexdigest()
         qps = args.steps * Q / dt
-        flops_per_launch = 2.0 * (row1 - row0) * F * E * 64      # algorithmic: 2*D*F*E per query x 64 queries
+        flops_per_launch = 2.0 * (row1 - row0) * F * E * ps.Qmax      # algorithmic: 2*D*F*E per query x the queries one launch serves
         n_scan_rows = scr.get("scan_rows", (row1 - row0) * F) if screened else (row1 - row0) * F
         esize = 2 if (args.dtype == "bf16" or screened) else 4
         bytes_per_launch = float(n_scan_rows) * E * esize        # the scanned rows are read once per batch
@@ -518,6 +520,9 @@ def main():
                      "the `alone` figure because the tail of the previous launch (exact re-scoring + stage 2: GBs of row gathers "
                      "for 128 queries) shares HBM with the scan for most of its duration (`alone` = the same kernel by itself).") if screened else None,
             "algorithmic_flops_per_launch": flops_per_launch,
+            "frac_of_copy_ceiling": (gbps / COPY_CEILING_GBS if esize != 4 else None),
+            "copy_ceiling_GBps": COPY_CEILING_GBS,
+            "sustained": sustained,
         })
         pipe = pipeline_traffic((D, F, E, Q, N), s1_kernel, s1_kernel.replace("_kernel", "_sample_kernel")) if (screened and N == 1) else None
         if pipe:
@@ -601,6 +606,9 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import encode_bench
             line["encode_pipeline"] = encode_bench.run(args.encode_docs, 256)
+            # ... and the certified screen on TEXT-born near-duplicates: amazon-shaped product families (8 fields, variants that differ in
+            # one token, 30 - 70 % of the fields missing), same encoder, every encoded slab searched (certified_screen blocks)
+            line["encode_pipeline_amazon"] = encode_bench.run(args.encode_docs_amazon, 256, sweep=False, dataset="amazon", modes=("fp32", "bf16"))
         if N == 1 and dist is None and not args.no_extra_legs and (sustained or args.sustain_s <= 0):
             line["exchange_overhead"] = exchange_leg(ix, corpus, W, mask, PyPipelinedSearcher, run, Q, torch, max(256, args.steps),
                                                      sustained["queries_per_s"] if sustained else qps)

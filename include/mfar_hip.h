@@ -66,15 +66,22 @@ int mfar_index_info(const mfar_index* idx, int64_t* n_rows_local, int64_t* row_o
                     int* dtype, int64_t* slab_bytes);
 /* HBM the handle keeps resident between searches, by part: the rows (the slab), the fp16 screen slab of an fp32 index, the 16-bit
  * row-major gather slab (fp32 index: the approximate level of stage 2; bf16 index: the whole-line companion), the unique-row
- * tables / statistics / row norms of the certified stage 1, and the score dumps of the pipeline slots that use one (rows of the
- * screen slab x 512 bytes per slot, only on shapes whose stage 2 reads them: mfar_set_stage2_dump).  Other per-launch scratch
- * (lists, candidate tables: MBs) is not counted.  Any pointer may be NULL.  No reference counterpart. */
+ * tables / statistics / row norms of the certified stage 1, and the large retained scratch of the pipeline slots: the score dumps of
+ * the slots that use one (16-bit codes: rows of the screen slab x 256 bytes per slot, only on shapes whose stage 2 reads them:
+ * mfar_set_stage2_dump) and, on a bf16 index that has run a repair, the exhaustive chain pass's score block (up to 64 queries x rows x 4
+ * bytes per slot; sized down when HBM is short).  Other per-launch scratch (lists, candidate tables: MBs) is not counted.  Any pointer
+ * may be NULL.  No reference counterpart. */
 int mfar_index_resident_bytes(const mfar_index* idx, int64_t* rows, int64_t* screen, int64_t* gather, int64_t* tables, int64_t* dumps);
 
 /*
  * Write n row-major fp32 vectors src[n, dim] into field `field`, local rows [local_row0, local_row0 + n).
  * Replaces MemoryMapDict.__setitem__ (data/util.py:40-41) as driven by on_eval_start (contrastive.py:482-490)
  * and the external re-assignment of DenseFlatIndex.vectors (contrastive.py:494).
+ * Ordering: the write runs on `stream`, behind every launch that mfar_pipeline_* has enqueued over this index so far (the library makes
+ * `stream` wait for its own streams: those launches read the OLD rows to the end); every search / launch / read_rows issued after the
+ * call sees the new rows, whatever stream it runs on (an asynchronous write leaves an event behind it that the next reader waits for).
+ * Callers that drive the split-phase entry points (mfar_stage1_begin / _finish, mfar_search_stage2) on streams of their own order
+ * their writes behind the batches THEY still have in flight themselves.
  */
 int mfar_index_write_rows(mfar_index* idx, int field, int64_t local_row0, int64_t n, const float* src, int on_device,
                           void* stream);
@@ -337,8 +344,9 @@ int mfar_set_stage2_mode(mfar_index* idx, int mode);
  * SCORE DUMP (no reference counterpart; outputs bit-identical with and without it).  The approximate level of the two-level stage 2
  * normally gathers one 16-bit row per (candidate, field) pair.  When queries x candidates exceeds a field's rows -- many fields, small
  * corpora, the row shards of a multi-GPU run -- the wide screened pass of stage 1 instead WRITES every approximate score it computes
- * (rows x 128 queries x 4 bytes per field and launch, per pipeline slot) and stage 2 reads its pairs out of that table, bounded by the
- * screened pass's own eps (csrc/mfar_select.h: mfar_s2_lookup_kernel): 129 375 x 22 moves 1.5 + 0.4 GB instead of 7.9 GB per 128 queries.
+ * (16-bit codes: rows x 128 queries x 2 bytes per field and launch, per pipeline slot) and stage 2 reads its pairs out of that table,
+ * bounded by the screened pass's own eps + the quantisation step (csrc/mfar_select.h: mfar_s2_lookup_kernel): 129 375 x 22 moves
+ * 0.7 + 0.5 GB instead of 7.9 GB per 128 queries.
  *   mode   0 = never, 1 = when the dump moves less than ONE THIRD of the gathers' bytes (default; environment MFAR_S2_DUMP),
  *          2 = whenever the wide pass of an fp32 index with a current screen runs.
  * mfar_stage2_dump_info: would a launch with list depth k1 use it; bytes one launch writes; launches that read it so far.
@@ -366,7 +374,9 @@ int mfar_set_row_mode(mfar_index* idx, int mode);
  * With every field off a launch is the exact pass and nothing else, i.e. the screen can cost a hostile corpus the probes (< 1 %), not 2x.
  * Independently, when >= 4 of the last 16 launches reported a failure among the fields that are on, mfar_stage1_finish repairs on the
  * device even when asked to report only (and reports a clean batch); it returns to reporting when at most one of the last 16 failed.
- *   mode         0 = never switch a field off, 1 = auto (default; environment MFAR_SCREEN_AUTO_OFF).  fp32 indexes.
+ *   mode         0 = never switch a field off, 1 = auto (default; environment MFAR_SCREEN_AUTO_OFF).  fp32 indexes as described; a bf16
+ *                index switches a field off only after 16 failed launches of 16 (its exact pass is the VALU chain pass, ~30x a screened
+ *                scan of the field: what switching off saves there is the field's share of the screened scan and its certificate).
  *   off_fails    1 .. 16 failed launches of the last 16 (0 = keep; default 12: a field that fails less often is cheaper screened + repaired)
  *   probe_every  launches between probes (0 = keep; default 64)
  * mfar_auto_off_info: bit f of off_fields = field f is off now; fields switched off / back on, probe launches so far; whether finish

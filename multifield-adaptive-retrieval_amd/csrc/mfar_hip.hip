@@ -196,6 +196,14 @@ struct mfar_index {
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
     int ev_n = 0;
+    // launches the pipelines over this index have enqueued on the library's streams / how many of them the last slab write was ordered
+    // behind (order_after_pipelines)
+    long long pipe_launches = 0, pipe_ordered = 0;
+    hipEvent_t order_ev[3] = {nullptr, nullptr, nullptr};
+    // ... and the other direction: behind the last slab write (on the caller's stream), waited for by the next reader on any other stream
+    hipEvent_t write_ev = nullptr;
+    hipStream_t write_stream = nullptr;
+    bool write_pending = false;
 };
 
 static std::mutex g_attr_mu;               // (handles may be created from different host threads)
@@ -361,6 +369,9 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
     idx->fused_q.release();
     for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
     if (idx->mid_ev) (void)hipEventDestroy(idx->mid_ev);
+    for (hipEvent_t e : idx->order_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (idx->write_ev) (void)hipEventDestroy(idx->write_ev);
     DevBuf* bufs[] = {&idx->fid, &idx->fsc, &idx->s_stats, &idx->s_field, &idx->s_mean, &idx->screen, &idx->u_rep, &idx->u_start,
                       &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->s2stats, &idx->rep_bits, &idx->u_of, &idx->s_field1, &idx->s_cvt, &idx->dump_base, &idx->s_rnorm, &idx->s_nsum};
     for (int i = 0; i < MFAR_SLOTS; ++i)
@@ -418,7 +429,7 @@ extern "C" int mfar_index_resident_bytes(const mfar_index* idx, int64_t* rows, i
     }
     if (dumps) {      // the score dumps of the pipeline slots that have used one (released when the shape stops wanting them)
         size_t t = 0;
-        for (const auto& sl : idx->s1) t += sl.dump.cap;
+        for (const auto& sl : idx->s1) t += sl.dump.cap + sl.chain.cap;
         *dumps = (int64_t)t;
     }
     return MFAR_OK;
@@ -462,6 +473,75 @@ extern "C" int mfar_stage1_timing(mfar_index* idx, double* total_ms_out, int* n_
     return MFAR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ the pipelines' streams
+struct PipeStreams {            // one set per device and process, shared by every pipeline on it (HIP maps streams onto a few hardware queues
+    hipStream_t main = nullptr, side[2] = {nullptr, nullptr}, copy = nullptr;   // round-robin: a second set would share queues with the first)
+    bool ok = false;
+};
+static PipeStreams g_pipe_streams[16];
+static std::mutex g_pipe_streams_mu;      // (handles may be created from different host threads)
+static int pipe_streams(int device, PipeStreams** out) {
+    std::lock_guard<std::mutex> lk(g_pipe_streams_mu);
+    PipeStreams& s = g_pipe_streams[device];
+    if (!s.ok) {
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        hipStream_t made[4] = {nullptr, nullptr, nullptr, nullptr};
+        const int prio[4] = {greatest, least, least, least};                              // the scans are dispatched ahead of the small kernels
+        for (int i = 0; i < 4; ++i) {
+            const hipError_t e = hipStreamCreateWithPriority(&made[i], hipStreamNonBlocking, prio[i]);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                for (int j = 0; j < i; ++j) (void)hipStreamDestroy(made[j]);              // nothing half-made is kept (or leaked)
+                return fail(MFAR_ERR_HIP, std::string("hipStreamCreateWithPriority: ") + hipGetErrorString(e));
+            }
+        }
+        s.main = made[0];
+        s.side[0] = made[1];
+        s.side[1] = made[2];
+        s.copy = made[3];
+        s.ok = true;
+    }
+    *out = &s;
+    return MFAR_OK;
+}
+// A slab mutator (mfar_index_write_rows) runs on the CALLER's stream; the launches of a pipeline over this index run on the library's
+// non-blocking streams.  Before the first write after such launches the caller's stream is made to wait for everything those streams
+// hold: launches submitted before the write read the old rows to the end (scan, exact re-scoring, stage-2 gathers), the write lands
+// behind them.  (Launches submitted AFTER the write are ordered by the rebuild of the screen -- a device synchronisation -- or, without
+// a screen, by the caller: submit's query copy orders the scan stream behind the caller's stream.)
+static int order_after_pipelines(mfar_index* idx, hipStream_t st) {
+    if (idx->pipe_launches == idx->pipe_ordered) return MFAR_OK;
+    PipeStreams& s = g_pipe_streams[idx->device];
+    if (s.ok) {
+        hipStream_t src[3] = {s.main, s.side[0], s.side[1]};
+        for (int i = 0; i < 3; ++i) {
+            if (!idx->order_ev[i]) HIPCHK(hipEventCreateWithFlags(&idx->order_ev[i], hipEventDisableTiming));
+            HIPCHK(hipEventRecord(idx->order_ev[i], src[i]));
+            HIPCHK(hipStreamWaitEvent(st, idx->order_ev[i], 0));
+        }
+    }
+    idx->pipe_ordered = idx->pipe_launches;
+    return MFAR_OK;
+}
+// ... and readers behind writers: an asynchronous write (device pointers) leaves an event behind it on the writer's stream; whatever reads
+// the slab next on ANOTHER stream (a launch on the library's streams, a search on a stream of the caller's) waits for it first.  One event:
+// a write on a second stream is ordered behind the earlier one, so that the latest record stands for all of them.
+static int mark_written(mfar_index* idx, hipStream_t st) {
+    if (!idx->write_ev) HIPCHK(hipEventCreateWithFlags(&idx->write_ev, hipEventDisableTiming));
+    if (idx->write_pending && idx->write_stream != st) HIPCHK(hipStreamWaitEvent(st, idx->write_ev, 0));
+    HIPCHK(hipEventRecord(idx->write_ev, st));
+    idx->write_stream = st;
+    idx->write_pending = true;
+    return MFAR_OK;
+}
+static int order_after_writes(mfar_index* idx, hipStream_t st) {
+    if (!idx->write_pending) return MFAR_OK;
+    if (hipEventQuery(idx->write_ev) == hipSuccess) idx->write_pending = false;           // (landed: later readers skip the wait)
+    else if (st != idx->write_stream) HIPCHK(hipStreamWaitEvent(st, idx->write_ev, 0));
+    return MFAR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ rows in / out
 static int check_rows(const mfar_index* idx, int field, int64_t row0, int64_t n, const void* ptr) {
     if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
@@ -481,6 +561,7 @@ extern "C" int mfar_index_write_rows(mfar_index* idx, int field, int64_t local_r
     idx->rows16_dirty = true;
     idx->gslab_ok = false;
     hipStream_t st = (hipStream_t)stream;
+    RETCHK(order_after_pipelines(idx, st));      // launches in flight read the old rows to the end
     char* fbase = (char*)idx->slab + (size_t)field * idx->field_stride * idx->esize;
     const int64_t chunk = on_device ? n : std::min<int64_t>(n, (int64_t)(256u << 20) / (idx->E * 4));
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
@@ -502,6 +583,8 @@ extern "C" int mfar_index_write_rows(mfar_index* idx, int field, int64_t local_r
         HIPCHK(hipGetLastError());
         if (!on_device) HIPCHK(hipStreamSynchronize(st));
     }
+    if (on_device) RETCHK(mark_written(idx, st));
+    else if (idx->write_pending && idx->write_stream == st) idx->write_pending = false;      // (that stream was just synchronised)
     return MFAR_OK;
 }
 
@@ -511,6 +594,7 @@ extern "C" int mfar_index_read_rows(mfar_index* idx, int field, int64_t local_ro
     if (n == 0) return MFAR_OK;
     HIPCHK(hipSetDevice(idx->device));
     hipStream_t st = (hipStream_t)stream;
+    RETCHK(order_after_writes(idx, st));
     const char* fbase = (const char*)idx->slab + (size_t)field * idx->field_stride * idx->esize;
     const int64_t chunk = on_device ? n : std::min<int64_t>(n, (int64_t)(256u << 20) / (idx->E * 4));
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
@@ -1337,7 +1421,18 @@ static bool dump_wanted(const mfar_index* idx, int k1) {
 static int exact16_pass(mfar_index* idx, mfar_index::S1Slot& sl, const float* q, int q0, int nq, int k, int sentinel, int f0, int nf, long long* fid,
                         float* fsc, const int* flags, hipStream_t st) {
     const long long n_pad = idx->n_blk * 64;
-    RETCHK(sl.chain.ensure((size_t)CHAIN_QB * n_pad * sizeof(float), true));
+    // scratch: one score per (query of the block, row).  The block is CHAIN_QB queries when that fits (256 MB per slot at 1 M rows) and is
+    // halved until the allocation succeeds: a repair must not turn a search into MFAR_ERR_NOMEM while a smaller block still runs
+    // (every halving re-reads the field once more; one query per block is the floor)
+    int qblock = CHAIN_QB;
+    if (sl.chain.cap >= (size_t)n_pad * sizeof(float)) qblock = (int)std::min<size_t>(CHAIN_QB, sl.chain.cap / ((size_t)n_pad * sizeof(float)));
+    else
+        for (;; qblock >>= 1) {
+            if (sl.chain.ensure((size_t)qblock * n_pad * sizeof(float), true) == MFAR_OK) break;
+            if (qblock == 1) return MFAR_ERR_NOMEM;          // (g_err holds the failed size)
+            (void)hipGetLastError();
+            g_err.clear();
+        }
     ChainScanParams sp = {};
     sp.slab = (const unsigned short*)idx->slab;
     sp.field_stride = idx->field_stride;
@@ -1363,10 +1458,10 @@ static int exact16_pass(mfar_index* idx, mfar_index::S1Slot& sl, const float* q,
     const dim3 sg((unsigned)((idx->n_blk + 3) / 4)), sb(256);
     const size_t lds = (size_t)QT * idx->E * 4;
     for (int f = f0; f < f0 + nf; ++f)
-        for (int b0 = 0; b0 < nq; b0 += CHAIN_QB) {
+        for (int b0 = 0; b0 < nq; b0 += qblock) {
             sp.field = cp.field = f;
             sp.q0 = cp.q0 = q0 + b0;
-            sp.nq = std::min(CHAIN_QB, nq - b0);
+            sp.nq = std::min(qblock, nq - b0);
             cp.fo = f - f0;
             if (QT == 32) mfar_chain_scan_bf16_kernel<32><<<sg, sb, lds, st>>>(sp);
             else if (QT == 8) mfar_chain_scan_bf16_kernel<8><<<sg, sb, lds, st>>>(sp);
@@ -1432,6 +1527,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     const bool bf16 = idx->dtype == MFAR_DTYPE_BF16;
     if (phases & S1_PREPARE) {
         consume_feedback(idx);
+        RETCHK(order_after_writes(idx, st));      // rows written asynchronously on another stream land before this batch reads any
         bool screened = false;
         if (screen_wanted(idx, k)) RETCHK(ensure_screen(idx, st, &screened));
         sl.screened = screened;
@@ -1550,7 +1646,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     }
     if (bf16)
         RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, phases, bkind, idx->slab, sl.qt16.p, qt_n, kp, -INFINITY,
-                           sl.base.as<float>(), nullptr, true, so, st));
+                           sl.base.as<float>(), nullptr, true, so, st, sl.skip_mask));
     else
         RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, phases, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
                            sl.base.as<float>(), nullptr, true, so, st, sl.skip_mask));
@@ -1935,6 +2031,7 @@ static int run_score(mfar_index* idx, const float* q, int Q, const long long* ca
     }
     const unsigned gx = (unsigned)(((size_t)C * idx->F + 255) / 256), gf = (unsigned)(((size_t)C * idx->F + SCF_THREADS - 1) / SCF_THREADS);
     if (gx == 0 || Q == 0) return MFAR_OK;
+    RETCHK(order_after_writes(idx, st));
     p.gslab = idx->gslab.p;
     p.g_row_bytes = (long long)idx->g_row_bytes;
     if (known) {

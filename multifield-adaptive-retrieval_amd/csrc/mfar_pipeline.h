@@ -13,27 +13,7 @@
 #pragma once
 
 #define PIPE_MAX_DEPTH MFAR_SLOTS
-struct PipeStreams {            // one set per device and process, shared by every pipeline on it (HIP maps streams onto a few hardware queues
-    hipStream_t main = nullptr, side[2] = {nullptr, nullptr}, copy = nullptr;   // round-robin: a second set would share queues with the first)
-    bool ok = false;
-};
-static PipeStreams g_pipe_streams[16];
-static std::mutex g_pipe_streams_mu;      // (handles may be created from different host threads)
-static int pipe_streams(int device, PipeStreams** out) {
-    std::lock_guard<std::mutex> lk(g_pipe_streams_mu);
-    PipeStreams& s = g_pipe_streams[device];
-    if (!s.ok) {
-        int least = 0, greatest = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(hipStreamCreateWithPriority(&s.main, hipStreamNonBlocking, greatest));     // the scans are dispatched ahead of the small kernels
-        HIPCHK(hipStreamCreateWithPriority(&s.side[0], hipStreamNonBlocking, least));
-        HIPCHK(hipStreamCreateWithPriority(&s.side[1], hipStreamNonBlocking, least));
-        HIPCHK(hipStreamCreateWithPriority(&s.copy, hipStreamNonBlocking, least));
-        s.ok = true;
-    }
-    *out = &s;
-    return MFAR_OK;
-}
+// (PipeStreams / pipe_streams(): mfar_hip.hip, next to the slab mutators that order themselves behind these streams)
 
 struct mfar_pipeline {
     mfar_index* idx = nullptr;
@@ -47,6 +27,9 @@ struct mfar_pipeline {
         DevBuf q, ids, scores, n_valid, fid, fsc, fail;
         int* fail_host = nullptr;         // pinned
         hipEvent_t stage1 = nullptr, done = nullptr, copied = nullptr;
+        hipEvent_t taken = nullptr;       // behind the last result / lists copy out of this slot on a CALLER's stream (device pointers)
+        bool taken_pending = false;
+        hipStream_t taken_stream = nullptr;
         int Q = 0;
         bool checked = true;
         bool failed = false;              // pipe_launch returned an error part-way (out of memory ...): nothing valid was enqueued for this launch
@@ -60,6 +43,17 @@ struct mfar_pipeline {
     std::vector<Where> pending;
     long long n_submitted = 0, n_launched = 0, n_redone = 0;
 };
+
+// Copies out of a slot were enqueued on the caller's stream `st`: the slot's next launch waits for them (pipe_launch), whatever stream the
+// caller submits on.  One event per slot: copies taken on a second stream are first ordered behind the earlier ones, so that the latest
+// record stands for all of them.
+static int pipe_mark_taken(mfar_pipeline::Slot& s, hipStream_t st) {
+    if (s.taken_pending && s.taken_stream != st) HIPCHK(hipStreamWaitEvent(st, s.taken, 0));
+    HIPCHK(hipEventRecord(s.taken, st));
+    s.taken_pending = true;
+    s.taken_stream = st;
+    return MFAR_OK;
+}
 
 static int pipe_tail(mfar_pipeline* p, mfar_pipeline::Slot& s, int slot, hipStream_t st) {
     return run_stage2_mix(p->idx, s.q.as<float>(), s.Q, p->W.as<float>(), p->query_cond, p->has_mask ? p->mask.as<float>() : nullptr, 1, p->k1, p->k2,
@@ -83,6 +77,11 @@ static int pipe_launch(mfar_pipeline* p) {
     s.launch = p->n_launched;
     s.failed = true;                 // until everything below is enqueued: a launch that errors out is redone by pipe_check, never read as is
     p->n_launched++;
+    idx->pipe_launches++;            // (mfar_index_write_rows orders itself behind these: order_after_pipelines)
+    if (s.taken_pending) {           // copies out of this slot enqueued on a caller's stream: this launch's begin phase rewrites the slot's lists,
+        HIPCHK(hipStreamWaitEvent(p->st->main, s.taken, 0));       // its tail (ordered behind the begin phase by s.stage1) the results
+        s.taken_pending = false;
+    }
     RETCHK(stage1_block(idx, slot, S1_PREPARE | S1_SCAN | (merge_in_finish() ? 0 : S1_FINISH), s.q.as<float>(), Q, 0, p->k1, p->sentinel, 0, idx->F,
                         s.fid.as<long long>(), s.fsc.as<float>(), nullptr, p->st->main));
     if (Q > idx->s1[slot].qw) return fail(MFAR_ERR_UNSUPPORTED, "a coalesced launch needs the screen slab, which could not be (re)built");
@@ -141,7 +140,7 @@ extern "C" void mfar_pipeline_destroy(mfar_pipeline* p) {
     for (auto& s : p->slots) {
         for (DevBuf* b : {&s.q, &s.ids, &s.scores, &s.n_valid, &s.fid, &s.fsc, &s.fail}) b->release();
         if (s.fail_host) (void)hipHostFree(s.fail_host);
-        for (hipEvent_t e : {s.stage1, s.done, s.copied})
+        for (hipEvent_t e : {s.stage1, s.done, s.copied, s.taken})
             if (e) (void)hipEventDestroy(e);
     }
     p->W.release();
@@ -199,7 +198,7 @@ extern "C" int mfar_pipeline_create(mfar_pipeline** out, mfar_index* idx, const 
         if (rc != MFAR_OK) break;
         if (hipMemset(s.fail.p, 0, 4) != hipSuccess || hipHostMalloc((void**)&s.fail_host, 4, hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&s.stage1, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.taken, hipEventDisableTiming) != hipSuccess)
             rc = fail(MFAR_ERR_HIP, "pipeline slot: event / pinned allocation failed");
         else {
             s.fail_host[0] = 0;
@@ -288,6 +287,7 @@ extern "C" int mfar_pipeline_result(mfar_pipeline* p, int64_t ticket, int64_t* i
     HIPCHK(hipMemcpyAsync(scores, s.scores.as<float>() + (size_t)ww.off * k2, (size_t)ww.Q * k2 * 4, kind, st));
     if (n_valid) HIPCHK(hipMemcpyAsync(n_valid, s.n_valid.as<int>() + ww.off, (size_t)ww.Q * 4, kind, st));
     if (!on_device) HIPCHK(hipStreamSynchronize(st));
+    else RETCHK(pipe_mark_taken(s, st));
     return MFAR_OK;
 }
 
@@ -330,5 +330,8 @@ extern "C" int mfar_pipeline_lists(mfar_pipeline* p, int64_t ticket, int64_t* fi
     HIPCHK(hipMemcpyAsync(field_ids, fi, n * 8, kind, st));
     HIPCHK(hipMemcpyAsync(field_scores, fs, n * 4, kind, st));
     if (!on_device) HIPCHK(hipStreamSynchronize(st));
+    else
+        for (auto& sl : p->slots)
+            if (sl.fid.p && fi >= (const int64_t*)sl.fid.p && fi < (const int64_t*)((const char*)sl.fid.p + sl.fid.cap)) RETCHK(pipe_mark_taken(sl, st));
     return MFAR_OK;
 }

@@ -44,7 +44,8 @@ struct ScreenPolicy {
     // The flags of a FINISHED launch: flags[f] != 0 = a list of field f failed (fields in `screened`: screened for real, i.e. ON at the
     // time), probe_flags[f] != 0 = the quiet probe of switched-off field f failed (fields in `probed`), any != 0 = some ON field failed.
     //   strict   a field is only switched off when it failed in ALL of its last 16 launches (bf16 indexes: their exact pass is the VALU
-    //            chain pass, ~30x a screened scan, so switching off saves only the screen's share)
+    //            chain pass, ~30x a screened scan: switching off saves the field's share of the screened scan -- its chunk table leaves the
+    //            field out like an fp32 index's -- and its certificate, never the chain pass)
     // Returns true when the launch had a failure among the ON fields.
     bool feed(int F, const int* flags, const int* probe_flags, int any, uint32_t screened, uint32_t probed, bool strict) {
         for (int f = 0; f < F && f < MFAR_POLICY_MAX_FIELDS; ++f) {

@@ -22,7 +22,8 @@ is encoded to bit-identical rows):
 
 `corpus="clustered"` (or an explicit `field_kinds=[...]` with "clustered" entries) is the HOSTILE case of the certified screen:
   * "clustered"  D rows in D / 256 clusters (~235 non-empty members each): a row is its cluster's centre (a distinct text vector, as
-              above) plus noise 1e-4 of the field's spread -- product variants, templated texts, one text encoded in different batches.
+              above) plus noise `cluster_noise` (default 1e-4) of the field's spread -- product variants, templated texts, one text
+              encoded in different batches.
               The rows are NOT bit-identical (the unique-row build keeps every one), but at fp16 resolution the members of a cluster
               score alike: the best cluster fills the k' = 192 approximate candidates of nearly every list, the k-th .. k'-th gap is far inside the error
               bound and the certificate fails list after list (include/mfar_hip.h "AUTO-OFF and inline repair").
@@ -39,10 +40,11 @@ CHUNK = 32768  # rows per generation chunk (aligned to global row numbers)
 class SyntheticCorpus:
     def __init__(self, n_docs: int, n_fields: int, dim: int, n_queries: int = 4096, seed: int = 0xDEADBEEF,
                  device: str = "cuda:0", empty_frac: float = 0.08, sigma: float = 0.04, pull: float = 0.8,
-                 structured: bool = False, field_kinds=None):
+                 structured: bool = False, field_kinds=None, cluster_noise: float = 1e-4):
         self.D, self.F, self.E, self.NQ = int(n_docs), int(n_fields), int(dim), int(n_queries)
         self.seed, self.device = int(seed), torch.device(device)
         self.empty_frac, self.sigma, self.pull = float(empty_frac), float(sigma), float(pull)
+        self.cluster_noise = float(cluster_noise)       # "clustered" fields: spread of a cluster's members, relative to the field's spread
         g = torch.Generator(device="cpu")
         g.manual_seed(self.seed)
         mu = torch.randn(self.E, generator=g)
@@ -113,7 +115,7 @@ class SyntheticCorpus:
             n_cl = max(4, self.D // 256)
             t = torch.randint(0, n_cl, (CHUNK,), generator=g, device=self.device) + 104729 * (f + 1)      # other fields, other clusters
             x = (self._tab_a[t % 4096] + self._tab_b[(t // 4096) % 4096]) * (self.sigma * 0.70710678) + self.mu
-            x = x + torch.randn(CHUNK, self.E, generator=g, device=self.device) * (self.sigma * 1e-4)
+            x = x + torch.randn(CHUNK, self.E, generator=g, device=self.device) * (self.sigma * self.cluster_noise)
         else:
             n_texts = 10 if kind == "lowcard" else max(16, self.D // 4)
             u = torch.rand(CHUNK, generator=g, device=self.device)

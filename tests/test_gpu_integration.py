@@ -307,9 +307,14 @@ def test_two_indexes_from_two_host_threads():
 
 def test_rows_rewritten_while_launches_are_in_flight():
     """A training loop re-encodes a field while the previous evaluation's launches are still in flight: mfar_index_write_rows between
-    submits.  Batches submitted AFTER the write see the new rows (screen tables, fp16 copy, gather slab and dumps are rebuilt behind a
-    device synchronisation); batches submitted before it return rows of the old or the new corpus -- never a crash, never a mixture that
-    is neither (their lists are certified against whatever the scan read, so each such result must equal one of the two oracles)."""
+    submits.  The write is ordered BEHIND every launch the pipeline has enqueued (the library makes the writer's stream wait
+    for its own streams): those launches read the OLD rows to the end.  A batch still held for coalescing, and everything submitted
+    later, is launched after the write and sees the NEW rows (screen tables, fp16 copy, gather slab rebuilt behind a device
+    synchronisation).
+    Made to hit the race: the launches are parked behind a long kernel on the submitting stream (their query copies queue behind it, the
+    scan stream waits for the copies), the rows are rewritten from DEVICE memory on another stream that nothing blocks, and no result is
+    taken in between -- without the ordering the write lands before any launch has read a row."""
+    import torch
     from mfar.data import index as idxmod
     from mfar.data.pipeline import NativePipeline
     rng = np.random.default_rng(33)
@@ -318,24 +323,38 @@ def test_rows_rewritten_while_launches_are_in_flight():
     new_field = (rng.standard_normal((D, E)) * 0.5 + 0.3 * mu * 4.0).astype(np.float32)
     slab2 = slab.copy()
     slab2[1] = new_field
-    qs = [(rng.standard_normal((Q, E)) * 0.5 + mu * 2.0).astype(np.float32) for _ in range(12)]
-    ix = idxmod.MultiFieldIndex(D, F, E, device=0)
-    for f in range(F):
-        ix.write_rows(f, 0, slab[f])
-    ix.set_screen(2)
-    pl = NativePipeline(ix, W, None, max_batch=Q)
-    tickets = [pl.submit(q) for q in qs[:5]]                 # five batches in flight or held (depth 3 x coalesce 2: all tickets valid)
-    ix.write_rows(1, 0, new_field)                           # the whole field replaced under them
-    tickets += [pl.submit(q) for q in qs[5:6]]
-    got = [pl.result(t) for t in tickets]
-    for q in qs[6:]:
-        got.append(pl.result(pl.submit(q)))
-    pl.close()
-    ix.close()
-    olds = [O.c_two_stage(slab, q, W, None) for q in qs[:6]]
-    news = [O.c_two_stage(slab2, q, W, None) for q in qs]
-    same = lambda g, o: np.array_equal(g["ids"], o["ids"]) and np.array_equal(g["scores"].view(np.uint32), o["scores"].view(np.uint32))
-    for i in range(5):                                       # submitted before the write: the old corpus or the new one
-        assert same(got[i], olds[i]) or same(got[i], news[i]), i
-    for i in range(5, len(qs)):                              # submitted after it: the new corpus
-        assert same(got[i], news[i]), i
+    qs = [(rng.standard_normal((Q, E)) * 0.5 + mu * 2.0).astype(np.float32) for _ in range(10)]
+    dev = torch.device("cuda:0")
+    for screen in (2, 0):                                    # the certified screen (rebuild behind the write) and the plain exact pass
+        ix = idxmod.MultiFieldIndex(D, F, E, device=0)
+        for f in range(F):
+            ix.write_rows(f, 0, slab[f])
+        ix.set_screen(screen)
+        pl = NativePipeline(ix, W, None, max_batch=Q)
+        coal = pl.coalesce
+        pl.result(pl.submit(qs[0]))                          # screen built, every buffer allocated: nothing below synchronises on its own
+        new_dev = torch.from_numpy(new_field).to(dev)
+        q_dev = [torch.from_numpy(q).to(dev) for q in qs]
+        a = torch.randn(8192, 8192, device=dev)
+        torch.cuda.synchronize()
+        writer = torch.cuda.Stream(device=dev)
+        for _ in range(12):                                  # ~ 100 ms of matmuls ahead of the query copies
+            a = a @ a * 1e-4
+        tickets = [pl.submit(q) for q in q_dev[:5]]          # 5 batches: launches of (0, 1), (2, 3) enqueued, batch 4 held (coalesce 2)
+        with torch.cuda.stream(writer):
+            ix.write_rows(1, 0, new_dev)                     # the whole field replaced under them, nothing waited for
+        tickets += [pl.submit(q) for q in q_dev[5:6]]        # (on the default stream: the library orders the launch behind the write)
+        host = lambda r: {k: v.cpu().numpy() for k, v in r.items()}
+        got = [host(pl.result(t)) for t in tickets]
+        for q in qs[6:]:
+            got.append(pl.result(pl.submit(q)))
+        pl.close()
+        ix.close()
+        n_old = 4 if coal == 2 else 5                        # batches whose launch was enqueued before the write
+        olds = [O.c_two_stage(slab, q, W, None) for q in qs[:n_old]]
+        news = [O.c_two_stage(slab2, q, W, None) for q in qs]
+        same = lambda g, o: np.array_equal(g["ids"], o["ids"]) and np.array_equal(g["scores"].view(np.uint32), o["scores"].view(np.uint32))
+        for i in range(n_old):                               # launched before the write: the old corpus, to the last bit
+            assert same(got[i], olds[i]), (screen, i, "a launch in flight read rewritten rows")
+        for i in range(n_old, len(qs)):                      # held / submitted after it: the new corpus
+            assert same(got[i], news[i]), (screen, i)
