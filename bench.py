@@ -168,6 +168,7 @@ def main():
     ap.add_argument("--corpus", choices=["plain", "structured", "clustered"], default="plain",
                     help="structured: realistic duplicate / norm structure in three of the fields; clustered: every field made of clusters of "
                          "~235 near-duplicate, non-identical rows -- the certified screen's worst case (mfar/synth.py)")
+    ap.add_argument("--cluster-noise", type=float, default=1e-4, help="--corpus clustered: spread of a cluster's members relative to the field's spread")
     ap.add_argument("--empty-frac", type=float, default=0.08,
                     help="share of (document, field) pairs that hold the field's empty-text vector (real STaRK fields are sparse; "
                          "0.08 = the headline corpus)")
@@ -288,7 +289,7 @@ def main():
     t_build0 = time.time()
     corpus = synth.SyntheticCorpus(D, F, E, n_queries=n_q_total, seed=0xDEADBEEF, device=str(dev),
                                    structured=(args.corpus == "structured"), empty_frac=args.empty_frac,
-                                   field_kinds=(["clustered"] * F if args.corpus == "clustered" else None))
+                                   field_kinds=(["clustered"] * F if args.corpus == "clustered" else None), cluster_noise=args.cluster_noise)
     W = corpus.W
     mask = torch.ones(F, device=dev)
     torch.cuda.synchronize()
@@ -555,7 +556,7 @@ def main():
                         "certified pass over the bf16 slab itself (two bf16 query terms, no second copy of the rows; min(k+92,192) unique rows per "
                         "list re-scored with the exact natural-order chain, top-k proven or redone by the exact pass per field)") if screened else
                        ("exact fp32 MFMA pass" if args.dtype == "f32" else "bf16 slab pass")),
-            "adaptive": ix.auto_off_info(),
+            "adaptive": {**ix.auto_off_info(), "tier2": ix.tier2_stats()},
             "screen": ({"lists_certified": (scr["n_checked"] - scr0["n_checked"]) - (scr["n_failed"] - scr0["n_failed"]),
                         "lists_redone_exactly": scr["n_failed"] - scr0["n_failed"], "batches_redone": n_redone_main,
                         "screen_slab_bytes": scr["screen_bytes"], "unique_rows_per_field": scr.get("unique_rows")} if screened else None),
@@ -599,6 +600,7 @@ def main():
                      "10 M docs x 16 fields x 768d bf16 over 8 GPUs = 1 250 000 rows per GPU (what one rank of the row-sharded run holds)"))}
         if N == 1 and args.dtype == "f32" and args.corpus == "plain" and not args.no_extra_legs and not args.no_config_legs:
             line["clustered_corpus"] = clustered_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E)
+            line["clustered_corpus_moderate"] = clustered_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E, noise=1e-2)
         if N == 1 and args.dtype == "f32" and not args.no_extra_legs:
             line["drop_in"] = drop_in_leg(ix, corpus, W, mask, Q, torch, max(256, args.steps), args.warmup, results)
         if N == 1 and args.dtype == "f32" and args.corpus == "plain" and not args.no_extra_legs and not args.no_config_legs and not args.no_encode_leg:
@@ -729,12 +731,12 @@ def config_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E
     return out
 
 
-def clustered_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E, min_s=0.4):
+def clustered_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E, min_s=0.4, noise=1e-4):
     """The certified screen's WORST case at the headline shape: every field is made of clusters of ~235 near-duplicate (not identical) rows
     (mfar/synth.py "clustered"), so nearly every certificate fails.  The library switches the failing fields off (include/mfar_hip.h
     "AUTO-OFF"): reported are the rate while it is still learning (failures repaired), the steady rate afterwards, the rate of the same
     index with the screen off, their ratio, and the bits of the default path against the screen-off path."""
-    cp = synth.SyntheticCorpus(D, F, E, n_queries=4096, seed=0xDEADBEEF, device=str(dev), field_kinds=["clustered"] * F)
+    cp = synth.SyntheticCorpus(D, F, E, n_queries=4096, seed=0xDEADBEEF, device=str(dev), field_kinds=["clustered"] * F, cluster_noise=noise)
     ix = cp.build_index(idxmod)
     ones = torch.ones(F, device=dev)
     ps = PipelinedSearcher(ix, cp.W, ones, k1=K1, k2=K2, max_batch=Q)
@@ -758,7 +760,7 @@ def clustered_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F
     dt = time.perf_counter() - t0
     run(ps, cp, list(range(n_learn, n_learn + 4)), keep)
     torch.cuda.synchronize()
-    s2, info = ix.screen_stats(), ix.auto_off_info()
+    s2, info, t2 = ix.screen_stats(), ix.auto_off_info(), ix.tier2_stats()
     n_redone = ps.n_redone
     del ps
     ix.set_screen(0)
@@ -778,8 +780,11 @@ def clustered_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F
         ids = ids.cpu().numpy()
         rel = cp.qrels((n_learn + i) * Q, Q)
         rec += [len(set(ids[j, :20].tolist()) & rel[j]) / len(rel[j]) for j in range(Q)]
-    out = {"docs": D, "fields": F, "dim": E, "field_kinds": cp.field_kinds,
-           "what": "every field: ~235 near-duplicate, non-identical rows per cluster -- the top 192 approximate scores of a list tie inside the error bound",
+    out = {"docs": D, "fields": F, "dim": E, "field_kinds": cp.field_kinds, "cluster_noise": noise,
+           "what": "every field: ~235 near-duplicate, non-identical rows per cluster (members spread by cluster_noise x the field's spread) -- the "
+                   "top 192 approximate scores of a list tie inside the error bound, the first certificate fails; tier 2 (threshold rescan) "
+                   "finishes such lists from their complete candidate sets",
+           "tier2": {**t2, "lists_first_certificate_failed_steady": None},
            "learning": {"batches": n_learn, "queries_per_s": n_learn * Q / dt_learn, "lists_redone_exactly": s1["n_failed"] - s0["n_failed"],
                         "lists_checked": s1["n_checked"] - s0["n_checked"], "fields_switched_off_after": info0["off"], "inline_repair": info0["inline_repair"]},
            "steps": steps, "queries_per_s": steps * Q / dt, "queries_per_s_screen_off": steps * Q / dt0,
@@ -818,6 +823,15 @@ def drop_in_leg(ix, corpus, W, mask, Q, torch, steps, first, ref_results):
     sync = [hi.search(b, W, mask) for b in batches[:max(8, steps // 4)]]
     torch.cuda.synchronize()
     dt_sync = time.perf_counter() - t0
+    # the same synchronous binding with the reference's dev_batch_size flag set to 128 (train.py:45 defaults to 64): a block of 65 .. 128
+    # queries takes the WIDE pass inside mfar_search_two_stage -- half the scan bytes per query, still one call per batch, nothing pipelined
+    pairs = [torch.cat([batches[2 * i], batches[2 * i + 1]]) for i in range(max(4, steps // 8))]
+    hi.search(pairs[0], W, mask)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sync128 = [hi.search(b, W, mask) for b in pairs]
+    torch.cuda.synchronize()
+    dt_sync128 = time.perf_counter() - t0
     pipe = ns["HbmPipeline"](hi, W, mask)
     def run_pipe(bs, keep):
         tk = []
@@ -870,11 +884,18 @@ def drop_in_leg(ix, corpus, W, mask, Q, torch, steps, first, ref_results):
     n = min(len(ref_results), len(got), len(sync))
     same = all(torch.equal(got[i][0], ref_results[i][0]) and torch.equal(got[i][1], ref_results[i][1]) and
                torch.equal(sync[i][0], ref_results[i][0]) and torch.equal(sync[i][1], ref_results[i][1]) for i in range(n))
+    n128 = min(len(sync128), len(ref_results) // 2)
+    same = same and all(torch.equal(sync128[i][0], torch.cat([ref_results[2 * i][0], ref_results[2 * i + 1][0]])) and
+                        torch.equal(sync128[i][1], torch.cat([ref_results[2 * i][1], ref_results[2 * i + 1][1]])) for i in range(n128))
     if not same:
         raise SystemExit("drop-in bindings (INTEGRATION.md stub) returned different bits than the timed pipeline")
     return {"binding": "INTEGRATION.md section 2, executed verbatim (ctypes over the C ABI; device tensors in and out)",
             "sync_mfar_search_two_stage": {"queries_per_s": len(sync) * Q / dt_sync, "ms_per_batch": dt_sync / len(sync) * 1e3, "batches": len(sync),
                                            "what": "one call per 64-query batch, the 64-column scan, nothing overlapped"},
+            "sync_mfar_search_two_stage_dev_batch_128": {"queries_per_s": len(pairs) * 2 * Q / dt_sync128, "ms_per_batch": dt_sync128 / len(pairs) * 1e3,
+                                                         "batches": len(pairs), "queries_per_batch": 2 * Q,
+                                                         "what": "the same synchronous call with dev_batch_size=128: one 128-column scan per call "
+                                                                 "(the wide pass), nothing overlapped"},
             "pipelined_mfar_pipeline": {"queries_per_s": steps * Q / dt_pipe, "ms_per_batch": dt_pipe / steps * 1e3, "batches": steps,
                                         "what": "mfar_pipeline_submit / _result, results taken lag batches late; result() copies each batch's "
                                                 "ids / scores / n_valid into fresh tensors"},

@@ -46,7 +46,7 @@ typedef struct mfar_index mfar_index;
 
 /* library / device probes (no reference counterpart).  mfar_version() == MFAR_ABI_VERSION of the header the caller was built
  * against, or the caller must refuse the library: the value changes with every signature change. */
-#define MFAR_ABI_VERSION 105
+#define MFAR_ABI_VERSION 106
 int mfar_version(void);
 const char* mfar_last_error(void);
 int mfar_device_count(int* n_out);
@@ -383,6 +383,22 @@ int mfar_set_row_mode(mfar_index* idx, int mode);
  * currently repairs inline.  Any pointer may be NULL.
  */
 int mfar_set_auto_off(mfar_index* idx, int mode, int off_fails, int probe_every);
+/*
+ * TIER 2 of the certified screen: the THRESHOLD RESCAN (no reference counterpart; outputs bit-identical in every mode).  A list whose first
+ * certificate fails has still produced e_k, the exact k-th best score among its re-scored rows -- a lower bound of the true k-th best, so every
+ * row of the exact top-k has approximate score >= e_k - eps.  Instead of sending the field to the exact fp32 pass (bound by the fp32 MFMA
+ * rate: ~7x its screened scan), the library rescans the fields that hold failed lists with the same screened kernel over the same fp16
+ * rows and that FIXED threshold per list, gathers every row above it from the fp32 slab (a few hundred per list on encoder-produced and
+ * near-duplicate corpora: profiles/r06_tier2_population.txt), and takes the exact top-k of that complete set -- no second proof needed.
+ * Lists that need more than 2048 candidates (or overflow a chunk list) go to the exact pass as before; AUTO-OFF and the inline-repair
+ * decision see the flags AFTER tier 2.  fp32 indexes, all-fields searches.
+ *   mode   0 = never, 1 = auto (default; environment MFAR_SCREEN_TIER2): its kernels follow a certificate only while a launch of the
+ *          last 256 had a failed first certificate -- a corpus whose lists all certify never pays their (idle) launches; 2 = always.
+ * mfar_tier2_stats synchronises the device: whether tier 2 is armed now; lists handed to it / lists it had to pass on to the exact pass
+ * since the handle was created.  Any pointer may be NULL.
+ */
+int mfar_set_tier2(mfar_index* idx, int mode);
+int mfar_tier2_stats(mfar_index* idx, int* armed, int64_t* n_lists, int64_t* n_passed_on);
 int mfar_auto_off_info(mfar_index* idx, uint32_t* off_fields, int64_t* n_switched_off, int64_t* n_switched_on, int64_t* n_probes,
                        int* inline_repair);
 int mfar_row_mode_activate(mfar_index* idx);

@@ -134,6 +134,8 @@ struct mfar_index {
         u32 exact_mask = 0, skip_mask = 0;
         DevBuf off_flags;                                               // [MFAR_MAX_FIELDS] device copy of exact_mask, one int per field
         DevBuf chain;                                                   // bf16 index: scores of the exhaustive chain pass (mfar_exact16.h), [CHAIN_QB][rows]
+        DevBuf tau2, lfail, t2cand, t2cnt, t2sx;                        // TIER 2 (mfar_screen.h): thresholds [F, qw], per-list flags, candidate sets [qw, F, T2_CAP]
+        bool t2 = false;                                                // this batch runs tier 2 behind its certificate (latched by the begin phase)
         // feedback: the batch's certificate flags, copied to pinned host memory behind the certify kernel and read by a LATER call once
         // the event has completed (never waited for)
         int* fb_host = nullptr;                                         // [SCREEN_FLAGS] pinned
@@ -169,6 +171,8 @@ struct mfar_index {
     u32 row_eligible = 0;         // fields with heavy-tailed row norms (host copy of ScreenField::row_mode)
     int row_mode_setting = 1;     // 0 never, 1 auto: eligible fields are activated once a certificate has failed (mfar_row_mode_activate; the
                                   // pipelined searcher calls it), 2 always.  MFAR_SCREEN_ROW_MODE
+    int tier2_mode = 1;           // TIER 2 of the certified screen (mfar_screen.h "threshold rescan"): 0 never, 1 auto (its kernels are
+                                  // enqueued while the policy has seen a failed certificate recently), 2 always.  MFAR_SCREEN_TIER2
     int dump_mode = 1;            // 0 never, 1 when it moves fewer bytes than the row gathers (dump_wanted), 2 whenever possible
     long long dump_launches = 0;
     DevBuf s_field1, s_cvt;       // bf16 index: ScreenField of the two-term passes (scale 1); conversion constants of the converted-docs pass
@@ -334,6 +338,7 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     if (const char* e = getenv("MFAR_S2_DUMP")) idx->dump_mode = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("MFAR_SCREEN_ROW_MODE")) idx->row_mode_setting = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("MFAR_SCREEN_AUTO_OFF")) idx->pol.set_mode(atoi(e) != 0 ? 1 : 0);
+    if (const char* e = getenv("MFAR_SCREEN_TIER2")) idx->tier2_mode = std::max(0, std::min(2, atoi(e)));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) idx->n_cu = prop.multiProcessorCount;
     hipError_t e = hipMalloc(&idx->slab, idx->slab_bytes);
@@ -393,6 +398,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
         if (sl.fb_ev) (void)hipEventDestroy(sl.fb_ev);
         sl.off_flags.release();
         sl.chain.release();
+        for (DevBuf* b : {&sl.tau2, &sl.lfail, &sl.t2cand, &sl.t2cnt, &sl.t2sx}) b->release();
         DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.lists2, &sl.list_cnt2, &sl.unit_ctr, &sl.dump, &sl.arow, &sl.eps_cert, &sl.dinv, &sl.dstep, &sl.eps_dump, &sl.darel, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
                         &sl.ssc, &sl.scnt, &sl.sx};
         for (DevBuf* b : sb) b->release();
@@ -822,15 +828,18 @@ static int launch_s1(int kind, bool sample, unsigned n_chunks, unsigned wave, hi
 enum { S1_PREPARE = 1, S1_SCAN = 2, S1_FINISH = 4, S1_CERTIFY = 8, S1_ALL = 15 };   // S1_CERTIFY: stage1_block only
 //   skip       fields (of an all-fields pass) that are left out: no chunks, empty lists (AUTO-OFF)
 //   force_sample  a restricted pass (only_failed) that is certain to scan its fields: always with its own sample pass
+//   t2         the TIER 2 rescan of the certified screen (mfar_screen.h): the flagged fields (only_failed) again, on the table of the
+//              screened pass itself (same chunk ids, same list scratch: nothing to allocate), S1_SCAN only, no sample pass -- tau_base
+//              holds the fixed thresholds -- and no merge: mfar_t2_collect_kernel reads the chunk lists
 static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, int f0, int nf, int phases, int kind, const void* slab,
                        const void* qt, int qt_n, int k, float tau0, const float* tau_base, const int* only_failed, bool record,
-                       const S1Out& o, hipStream_t st, u32 skip = 0, bool force_sample = false) {
+                       const S1Out& o, hipStream_t st, u32 skip = 0, bool force_sample = false, bool t2 = false) {
     const int qw = s1_is_wide(kind) ? 128 : 64;   // query columns of the pass: stride of every per-query table below
     // a repair pass (only_failed) uses the finely cut table as well: the workgroups of the fields that did not fail exit at once,
     // and a failed field is then scanned by the whole GPU instead of by its share of one wave (one failed field of eight at 1 M
     // rows: 64 workgroups x 61 tiles at the MFMA-bound rate = several ms; cut into 512 chunks: under 1 ms)
     const bool repair = only_failed != nullptr;
-    const bool solo = nf != idx->F || repair, wide = s1_is_wide(kind);
+    const bool solo = nf != idx->F || (repair && !t2), wide = s1_is_wide(kind);
     if (solo) skip = 0;
     S1Table& tb = wide ? (solo ? geom.solo_w : (skip ? geom.all_w_skip : geom.all_w)) : (solo ? geom.solo : (skip ? geom.all_skip : geom.all));
     static const int sample_tiles_env = getenv("MFAR_SAMPLE_TILES") ? atoi(getenv("MFAR_SAMPLE_TILES")) : 0;
@@ -920,7 +929,7 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
     // ... or, with short chunks, whenever it yields thresholds for most of the rows: a tile without one costs 8 x a normal tile in
     // the full pass (90 % empty 129 k x 22: 2.4 tiles per chunk, scan 0.85 ms without the sample pass)
     const bool use_sample = (tb.total_tiles >= (long long)sample_min_tiles * tb.n_chunks || 2 * tb.thresholded_tiles >= tb.total_tiles) &&
-                            !(p.dbg & 2) && (!repair || idx->repair_sample || force_sample);
+                            !(p.dbg & 2) && (!repair || idx->repair_sample || force_sample) && !t2;
     const bool light_sample = use_sample && 2 * tb.samp_stride <= 4096;
     p.sample_tiles = light_sample ? tb.sample_tiles : 1;
     if (light_sample) {
@@ -981,7 +990,8 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
             p.unit_ctr = sl.unit_ctr.as<int>();
             p.unit_tiles = unit_tiles;
         }
-        RETCHK(launch_s1(kind, false, grid, (unsigned)(idx->wgs_per_cu * idx->n_cu), st, p, record ? &idx->last_s1_kernel : nullptr));
+        // (t2: the 16-bit kernels take one chunk per workgroup, flagged or not -- the grid is the whole chunk range)
+        RETCHK(launch_s1(kind, false, grid, t2 ? grid : (unsigned)(idx->wgs_per_cu * idx->n_cu), st, p, record ? &idx->last_s1_kernel : nullptr));
     }
     if (e1) HIPCHK(hipEventRecord(e1, st));
     if (phases & S1_FINISH) {
@@ -1496,8 +1506,9 @@ static void consume_feedback(mfar_index* idx) {
         if (!sl.fb_pending || hipEventQuery(sl.fb_ev) != hipSuccess) continue;
         sl.fb_pending = false;
         const int* h = sl.fb_host;
-        const bool failed = idx->pol.feed(idx->F, h, h + MFAR_MAX_FIELDS + 2, h[MFAR_MAX_FIELDS], sl.fb_screened, sl.fb_probed, idx->dtype == MFAR_DTYPE_BF16);
-        if (failed && idx->row_mode_setting == 1) idx->row_mask = idx->row_eligible;       // ROW MODE for heavy-tailed fields (mfar_screen.h)
+        const bool failed = idx->pol.feed(idx->F, h, h + MFAR_MAX_FIELDS + 2, h[MFAR_MAX_FIELDS], sl.fb_screened, sl.fb_probed, idx->dtype == MFAR_DTYPE_BF16,
+                                          h[SCREEN_FLAG_T1]);
+        if ((failed || h[SCREEN_FLAG_T1]) && idx->row_mode_setting == 1) idx->row_mask = idx->row_eligible;       // ROW MODE for heavy-tailed fields (mfar_screen.h)
     }
 }
 // behind the certify kernel of a batch: its flags -> pinned host memory, event behind the copy
@@ -1546,6 +1557,14 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
             sl.dump_on = false;
         }
         if (!sl.dump_on && sl.dump.p && !dump_wanted(idx, k)) sl.dump.release();      // the shape no longer wants it (rows rewritten, mode changed)
+        // TIER 2 behind this batch's certificate (all-fields passes of an fp32 index; armed by the policy: mfar_policy.h)
+        sl.t2 = screened && !bf16 && f0 == 0 && nf == idx->F && (idx->tier2_mode == 2 || (idx->tier2_mode == 1 && idx->pol.t2_armed));
+        if (sl.t2 && (sl.tau2.ensure((size_t)F * 128 * 4) != MFAR_OK || sl.lfail.ensure((size_t)128 * F * 4) != MFAR_OK || sl.t2cnt.ensure((size_t)128 * F * 4) != MFAR_OK ||
+                      sl.t2cand.ensure((size_t)128 * F * T2_CAP * 8, true) != MFAR_OK || sl.t2sx.ensure((size_t)128 * F * T2_CAP * 4, true) != MFAR_OK)) {
+            (void)hipGetLastError();      // optional: without its scratch the batch keeps the exact pass as its only fall-back
+            g_err.clear();
+            sl.t2 = false;
+        }
     }
     const int qw = sl.qw;
     const u32 all_mask = F >= 32 ? 0xFFFFFFFFu : ((1u << F) - 1u);
@@ -1727,6 +1746,10 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     cp.qw = qw;
     cp.skip_mask = sl.skip_mask;
     cp.quiet_mask = sl.exact_mask & ~sl.skip_mask;        // a probe launch: switched-off fields that were screened anyway
+    if (sl.t2) {
+        cp.tau2 = sl.tau2.as<float>();
+        cp.lfail = sl.lfail.as<int>();
+    }
     static const bool cert_debug = getenv("MFAR_CERT_DEBUG") != nullptr;
     DevBuf dbg;
     if (cert_debug) {
@@ -1744,6 +1767,53 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
                 fprintf(stderr, "[mfar cert] q=%d f=%d bound=%.7g T_k=%.7g a_real=%.7g eps=%.4g cnt=%g m_out=%g (ovf + 10 n + 1e4 total)=%g\n", q0 + i / nf,
                         f0 + i % nf, h[8 * i + 1], h[8 * i + 2], h[8 * i + 3], h[8 * i + 4], h[8 * i + 5], h[8 * i + 6], h[8 * i + 7]);
         dbg.release();
+    }
+    if (sl.t2) {
+        // TIER 2 (mfar_screen.h): rescan of the fields that hold failed lists with their fixed thresholds -> the complete candidate sets ->
+        // exact scores -> the certify kernel again, on those lists only.  Every kernel is idle when nothing failed.
+        RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, S1_SCAN, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
+                           sl.tau2.as<float>(), fflags + SCREEN_T2_FIELDS, false, so, st, sl.skip_mask, false, true));
+        const S1Geom& g2 = idx->geom_screen;
+        const S1Table& tb2 = qw == 128 ? (sl.skip_mask ? g2.all_w_skip : g2.all_w) : (sl.skip_mask ? g2.all_skip : g2.all);
+        T2CollectParams tc = {};
+        tc.lists = sl.lists.as<uint2>();
+        tc.list_cnt = sl.list_cnt.as<int>();
+        tc.fchunk = tb2.d_fchunk.as<int>();
+        tc.lfail = tc.lfail_out = sl.lfail.as<int>();
+        tc.cand = sl.t2cand.as<long long>();
+        tc.cnt = sl.t2cnt.as<int>();
+        tc.f0 = f0;
+        tc.nf = nf;
+        tc.qw = qw;
+        tc.kp = kp;
+        mfar_t2_collect_kernel<<<dim3(qt_n * nf), dim3(256), 0, st>>>(tc);
+        HIPCHK(hipGetLastError());
+        ScoreParams s2 = sp;
+        s2.cand = sl.t2cand.as<long long>();
+        s2.out = sl.t2sx.as<float>();
+        s2.C = T2_CAP;
+        s2.n_cand_pf = sl.t2cnt.as<int>();
+        s2.pre_sc = nullptr;
+        mfar_score_rows_kernel<SRC_F32><<<dim3((unsigned)((T2_CAP * nf) / SCF_THREADS), qt_n), dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(s2);
+        HIPCHK(hipGetLastError());
+        T2SelectParams ts = {};
+        ts.cand = sl.t2cand.as<long long>();
+        ts.sx2 = sl.t2sx.as<float>();
+        ts.cnt = sl.t2cnt.as<int>();
+        ts.lfail = sl.lfail.as<int>();
+        ts.sid = sl.sids.as<long long>();
+        ts.sx = sl.sx.as<float>();
+        ts.scnt = sl.scnt.as<int>();
+        ts.nf = nf;
+        ts.kp = kp;
+        ts.k = k;
+        mfar_t2_select_kernel<<<dim3(qt_n * nf), dim3(256), T2_SELECT_LDS_BYTES, st>>>(ts);
+        HIPCHK(hipGetLastError());
+        CertifyParams cp2 = cp;
+        cp2.pass2 = 1;
+        cp2.dbg = nullptr;
+        mfar_screen_certify_kernel<<<dim3(qt_n * nf), dim3(256), 0, st>>>(cp2);
+        HIPCHK(hipGetLastError());
     }
     {
         u32 fields = 0;
@@ -1842,6 +1912,29 @@ extern "C" int mfar_set_auto_off(mfar_index* idx, int mode, int off_fails, int p
     idx->pol.set_mode(mode);
     if (off_fails) idx->pol.off_fails = off_fails;
     if (probe_every) idx->pol.probe_every = std::max(2, probe_every);
+    return MFAR_OK;
+}
+extern "C" int mfar_set_tier2(mfar_index* idx, int mode) {
+    if (!idx || mode < 0 || mode > 2) return fail(MFAR_ERR_INVALID, "mode must be 0 (never), 1 (auto: armed by failed certificates) or 2 (always)");
+    idx->tier2_mode = mode;
+    return MFAR_OK;
+}
+extern "C" int mfar_tier2_stats(mfar_index* idx, int* armed, int64_t* n_lists, int64_t* n_passed_on) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    HIPCHK(hipSetDevice(idx->device));
+    consume_feedback(idx);
+    if (armed) *armed = idx->tier2_mode == 2 || (idx->tier2_mode == 1 && idx->pol.t2_armed) ? 1 : 0;
+    int64_t a = 0, b = 0;
+    for (auto& sl : idx->s1)
+        if (sl.fail.p) {
+            HIPCHK(hipDeviceSynchronize());
+            int v[2] = {0, 0};
+            HIPCHK(hipMemcpy(v, sl.fail.as<int>() + SCREEN_STAT_T2_LISTS, 8, hipMemcpyDeviceToHost));
+            a += v[0];
+            b += v[1];
+        }
+    if (n_lists) *n_lists = a;
+    if (n_passed_on) *n_passed_on = b;
     return MFAR_OK;
 }
 extern "C" int mfar_auto_off_info(mfar_index* idx, uint32_t* off_fields, int64_t* n_switched_off, int64_t* n_switched_on, int64_t* n_probes,

@@ -11,6 +11,7 @@
 //   * inline repair: >= 4 of the last 16 screened launches had a failure among the fields that were ON -> mfar_stage1_finish repairs on the
 //     device even when asked to report only; <= 1 of the last 16 (a full window) -> back to reporting.
 //   * the first observed failure tells the caller to activate ROW MODE for eligible fields (feed() returns true).
+//   * TIER 2 armed / disarmed (below).
 #pragma once
 #include <cstdint>
 
@@ -27,6 +28,12 @@ struct ScreenPolicy {
     long long launches = 0, n_off = 0, n_on = 0, n_probes = 0;
     uint32_t off_mask = 0;    // fields that are switched off now
     bool inline_repair = false;
+    // TIER 2 (mfar_screen.h "threshold rescan") is ARMED by the first launch with a failed first certificate -- from then on its (idle
+    // when nothing fails) kernels follow every certificate -- and disarmed after t2_disarm_after clean launches in a row: a corpus whose
+    // lists all certify never pays for their launches.  The flags fed above are those AFTER tier 2: a field is switched off only when
+    // tier 2 cannot finish its lists either.
+    bool t2_armed = false;
+    int t2_clean = 0, t2_disarm_after = 256;
 
     // Begin of a screened all-fields launch over F fields: *exact = fields whose lists the exact pass writes in this launch, *skip = fields
     // its screen leaves out (equal, except in a probe launch, which screens everything).
@@ -47,7 +54,14 @@ struct ScreenPolicy {
     //            chain pass, ~30x a screened scan: switching off saves the field's share of the screened scan -- its chunk table leaves the
     //            field out like an fp32 index's -- and its certificate, never the chain pass)
     // Returns true when the launch had a failure among the ON fields.
-    bool feed(int F, const int* flags, const int* probe_flags, int any, uint32_t screened, uint32_t probed, bool strict) {
+    //   t1       the launch had a list that failed its FIRST certificate (whether or not tier 2 then finished it): arms tier 2
+    bool feed(int F, const int* flags, const int* probe_flags, int any, uint32_t screened, uint32_t probed, bool strict, int t1 = 0) {
+        if (screened) {
+            if (t1 || any) {
+                t2_armed = true;
+                t2_clean = 0;
+            } else if (t2_armed && ++t2_clean >= t2_disarm_after) t2_armed = false;
+        }
         for (int f = 0; f < F && f < MFAR_POLICY_MAX_FIELDS; ++f) {
             const uint32_t bit = 1u << f;
             if (screened & bit) {

@@ -37,7 +37,13 @@
                                  // costs ~1 % and makes a failed certificate -- a 0.9 ms exact pass per field -- rarer)
 #define SCREEN_MAX_KP S1_MAX_DEPTH   // the stage-1 lists compact to k', which must leave room for one tile of appends
 #define SCREEN_SLACK 1.25f
-#define SCREEN_FLAGS (2 * MFAR_MAX_FIELDS + 2)   // ints of a batch's certificate flags (CertifyParams::fail)
+#define SCREEN_FLAGS (3 * MFAR_MAX_FIELDS + 5)   // ints of a batch's certificate flags (CertifyParams::fail)
+#define SCREEN_T2_FIELDS (2 * MFAR_MAX_FIELDS + 5)     // [MFAR_MAX_FIELDS] per batch: field f has lists for tier 2 (selects its rescan; cleared by the query kernel)
+#define SCREEN_FLAG_T1 (2 * MFAR_MAX_FIELDS + 2)       // per batch: some list failed the FIRST certificate (tier 2 had work; cleared by the query kernel)
+#define SCREEN_STAT_T2_LISTS (2 * MFAR_MAX_FIELDS + 3) // statistics: lists handed to tier 2 ...
+#define SCREEN_STAT_T2_FAILED (2 * MFAR_MAX_FIELDS + 4)   // ... and lists tier 2 could not finish either (overflow: the exact pass decides)
+// TIER 2 of the certified screen ("threshold rescan", below): candidates one list can hold; lists that need more go to the exact pass
+#define T2_CAP 2048
 
 // struct ScreenField: mfar_device.h (shared with the gather-slab kernels of mfar_select.h)
 // struct ScreenQuery: mfar_device.h
@@ -331,6 +337,8 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
     // a new batch: clear the certificate flags of the fields and the "any" flag ([MFAR_MAX_FIELDS + 1] keeps accumulating statistics)
     if (r == 0 && (int)threadIdx.x <= MFAR_MAX_FIELDS) fail_flags[threadIdx.x] = 0;
     if (r == 0 && (int)threadIdx.x < MFAR_MAX_FIELDS) fail_flags[MFAR_MAX_FIELDS + 2 + threadIdx.x] = 0;      // ... and the probe flags
+    if (r == 0 && threadIdx.x == 0) fail_flags[SCREEN_FLAG_T1] = 0;
+    if (r == 0 && (int)threadIdx.x < MFAR_MAX_FIELDS) fail_flags[SCREEN_T2_FIELDS + threadIdx.x] = 0;
     const bool live = q0 + r < Q;
     const float* row = q + (size_t)(q0 + (live ? r : 0)) * E;
     // ONE round of global loads (this kernel opens a batch on the critical path, usually while the previous batch's gathers
@@ -534,6 +542,8 @@ __global__ void __launch_bounds__(256) mfar_direct_queries_kernel(const float* _
     const int r = blockIdx.x;
     if (r == 0 && (int)threadIdx.x <= MFAR_MAX_FIELDS) fail_flags[threadIdx.x] = 0;
     if (r == 0 && (int)threadIdx.x < MFAR_MAX_FIELDS) fail_flags[MFAR_MAX_FIELDS + 2 + threadIdx.x] = 0;      // ... and the probe flags
+    if (r == 0 && threadIdx.x == 0) fail_flags[SCREEN_FLAG_T1] = 0;
+    if (r == 0 && (int)threadIdx.x < MFAR_MAX_FIELDS) fail_flags[SCREEN_T2_FIELDS + threadIdx.x] = 0;
     const bool live = q0 + r < Q;
     const float* row = q + (size_t)(q0 + (live ? r : 0)) * E;
     ScreenField fld = {};
@@ -613,7 +623,8 @@ struct CertifyParams {
     long long* out_ids;       // [Q, nf, k]
     float* out_scores;
     int* fail;                // [F] field flags, [MFAR_MAX_FIELDS] = any, [MFAR_MAX_FIELDS + 1] = failed (query, field) pairs (statistics),
-                              // [MFAR_MAX_FIELDS + 2 + f] = probe flags (quiet_mask): SCREEN_FLAGS ints in all
+                              // [MFAR_MAX_FIELDS + 2 + f] = probe flags (quiet_mask), then the tier-2 flags / statistics (SCREEN_FLAG_T1 ...):
+                              // SCREEN_FLAGS ints in all
     u32 skip_mask;            // bit f: field f was not screened in this batch (switched off: the exact pass wrote its lists) -- nothing to do
     u32 quiet_mask;           // bit f: field f is switched off but was screened as a PROBE: evaluate the certificate, record a failure in
                               // the probe flags only, write no lists (the exact pass's lists stand)
@@ -629,6 +640,13 @@ struct CertifyParams {
     int f0, nf, k, kp, q0, sentinel;
     int qw;                   // query columns of the screened pass (64 / 128): stride of eps
     float* dbg;               // diagnostics (MFAR_CERT_DEBUG) or nullptr: per list {ok, bound, T_k, a_real, eps, cnt, m_out, overflow}
+    // TIER 2 (below).  First certificate (pass2 == 0) with tau2 != nullptr: a list whose proof fails is not flagged for the exact pass yet --
+    // lfail[ql * nf + fo] = 1 and tau2[f * qw + ql] = the scan-unit threshold every row that can still reach its exact top-k must pass
+    // (+inf for lists that are done).  Second certificate (pass2 != 0): only lists with lfail != 0 are looked at; their sid / sx / scnt now
+    // hold the best-by-exact-score rows of the COMPLETE candidate set (1) or nothing usable (2 = tier 2 overflowed: flagged for the exact pass).
+    float* tau2;              // [F, qw] or nullptr
+    int* lfail;               // [qw * nf] or nullptr
+    int pass2;
 };
 __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyParams p) {
     __shared__ u64 keys[CERT_EXPAND_CAP], sel[256], sorted[256];
@@ -636,8 +654,27 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
     __shared__ float qm_s[4];
     __shared__ int total_s, overflow_s;
     const int ql = blockIdx.x / p.nf, fo = blockIdx.x - ql * p.nf, f = p.f0 + fo;
-    if ((p.skip_mask >> f) & 1u) return;                 // workgroup-uniform
+    if ((p.skip_mask >> f) & 1u) {                       // workgroup-uniform
+        if (p.tau2 && !p.pass2 && threadIdx.x == 0) {
+            p.tau2[f * p.qw + ql] = __builtin_inff();
+            p.lfail[ql * p.nf + fo] = 0;
+        }
+        return;
+    }
     const bool quiet = ((p.quiet_mask >> f) & 1u) != 0u;
+    if (p.pass2) {                                       // workgroup-uniform: only the lists tier 2 worked on
+        const int lf = p.lfail[ql * p.nf + fo];
+        if (lf == 0) return;
+        if (lf != 1) {                                   // tier 2 overflowed: the exact pass decides
+            if (threadIdx.x == 0) {
+                atomicOr(&p.fail[f], 1);
+                atomicOr(&p.fail[MFAR_MAX_FIELDS], 1);
+                atomicAdd(&p.fail[MFAR_MAX_FIELDS + 1], 1);
+                atomicAdd(&p.fail[SCREEN_STAT_T2_FAILED], 1);
+            }
+            return;
+        }
+    }
     const size_t lb = ((size_t)ql * p.nf + fo) * p.kp;
     const int cnt = min(p.scnt[ql * p.nf + fo], p.kp);
     const float tau0 = p.sentinel ? 0.0f : -__builtin_inff();
@@ -738,12 +775,36 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
             d[6] = (float)m_out;
             d[7] = (float)overflow_s + 10.0f * (float)n + 10000.0f * (float)total;
         }
+        const bool to_t2 = !ok && !quiet && p.tau2 && !p.pass2 && overflow_s == 0 && p.eps[f * p.qw + ql] < __builtin_inff();
+        if (p.tau2 && !p.pass2) {
+            // TIER 2 threshold: every document with exact score >= E_k (the true k-th best) has exact >= e_k (the k-th best found so far,
+            // a lower bound of E_k; without k documents past the sentinel: the sentinel itself), hence approx >= e_k - eps: in scan units
+            // (e_k - eps - q.m) sq sf, leaning down by the roundings of this very expression (eps carries 25 % slack for the approximation's own)
+            float t2 = __builtin_inff();
+            if (to_t2) {
+                const float qm = (qm_s[0] + qm_s[1]) + (qm_s[2] + qm_s[3]);
+                const float ek = m_out == p.k ? key_score(sorted[p.k - 1]) : tau0;
+                const float e_ = p.eps[f * p.qw + ql];
+                float t = (ek - e_) - qm;
+                t -= (fabsf(ek) + e_ + fabsf(qm)) * 4.0e-7f;
+                t *= p.qinfo[ql].scale * p.sf[f].scale;             // powers of two
+                t2 = t - fabsf(t) * 2.0e-7f;
+                if (!(t2 == t2)) t2 = -__builtin_inff();            // (-inf - ...: no sentinel and a short list: everything qualifies -> overflow)
+            }
+            p.tau2[f * p.qw + ql] = t2;
+            p.lfail[ql * p.nf + fo] = to_t2 ? 1 : 0;
+        }
         if (!ok && quiet) atomicOr(&p.fail[MFAR_MAX_FIELDS + 2 + f], 1);
-        else if (!ok) {
+        else if (to_t2) {                                // not a failure yet: tier 2 takes the list (its field is rescanned)
+            atomicOr(&p.fail[SCREEN_T2_FIELDS + f], 1);
+            atomicOr(&p.fail[SCREEN_FLAG_T1], 1);
+            atomicAdd(&p.fail[SCREEN_STAT_T2_LISTS], 1);
+        } else if (!ok) {
             atomicOr(&p.fail[f], 1);
             atomicOr(&p.fail[MFAR_MAX_FIELDS], 1);
             atomicAdd(&p.fail[MFAR_MAX_FIELDS + 1], 1);
-        }
+            if (p.pass2) atomicAdd(&p.fail[SCREEN_STAT_T2_FAILED], 1);
+        } else if (p.pass2) p.lfail[ql * p.nf + fo] = 0;
     }
     if (quiet) return;
     const size_t ob = ((size_t)(p.q0 + ql) * p.nf + fo) * p.k;
@@ -757,3 +818,116 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// TIER 2 of the certified screen: the THRESHOLD RESCAN (round 6; counted first: profiles/r06_tier2_population.txt).
+//
+// The first certificate fails when more than k' - k unique rows of a field score within ~2 eps of the list's k-th best: near-duplicate
+// rows, or simply a narrow cone of vectors (mean-pooled transformer outputs: cosine 0.86 between the rows of a field) whose score
+// density near the cut is high against eps.  Until round 5 such a field went to the exact fp32 pass: bound by the fp32 MFMA rate, ~7x the
+// time of its screened scan.  But the first attempt leaves a USABLE fact behind: e_k, the exact k-th best document among the re-scored
+// rows, is a lower bound of the true k-th best E_k -- so every document that belongs to the exact top-k (or ties with its last entry)
+// has exact >= e_k, hence approximate score >= e_k - eps.  Tier 2 therefore
+//   1. rescans the fields that hold failed lists with the SAME screened kernel over the SAME fp16 slab (HBM-bound, half the bytes of
+//      any pass over the fp32 rows), list depth k', no sample pass, and the fixed non-strict threshold T(q, f) = e_k - eps per failed list
+//      (+inf for the lists that are done: they append nothing) -- the chunk lists then hold EVERY row above T;
+//   2. mfar_t2_collect_kernel concatenates a failed list's chunk lists -> its complete candidate set (<= T2_CAP rows; a chunk list that
+//      reached depth k' may have dropped rows: overflow);
+//   3. re-scores those rows from the fp32 slab with the contract's chain (mfar_score_rows_kernel, per-list counts);
+//   4. mfar_t2_select_kernel keeps the k' - 1 best by EXACT score in the screened-list format, and the certify kernel runs again on
+//      those lists only: a list shorter than k' is complete by construction, so it expands unique rows to documents, applies the
+//      sentinel and writes the final list -- no proof needed, the set is exhaustive above E_k;
+//   5. lists that overflowed (or tie across the k' - 1 cut) keep their flag: the exact pass decides, as before.
+// Counted on encoder-produced and clustered corpora: the candidate sets hold 200 - 500 rows (max ~1 150), i.e. ~1 MB of gathers per
+// failed list against the 11 MB per list an exact pass of the field reads at the fp32 MFMA rate.  (The alternative tier -- hi + lo fp16
+// terms over the fp32 slab -- certifies the encoder corpora too but almost none of the clustered lists: its eps keeps the rigorous
+// fp32-accumulation terms, 0.27 of tier 1's; and it reads twice the bytes.)
+// ---------------------------------------------------------------------------------------------------------
+struct T2CollectParams {
+    const uint2* lists;       // [n_chunks * qw][S1_CAP] chunk lists of the rescan (score bits, unique row)
+    const int* list_cnt;      // [n_chunks * qw]
+    const int* fchunk;        // [F + 1] chunk ranges of the rescan's table
+    const int* lfail;         // [qw * nf]
+    long long* cand;          // [qw, nf, T2_CAP] out: unique-row numbers
+    int* cnt;                 // [qw * nf] out: candidates of the list (0 for lists tier 2 does not handle)
+    int* lfail_out;           // = lfail (2 on overflow)
+    int f0, nf, qw, kp;
+};
+// grid = Qt * nf, block 256
+__global__ void __launch_bounds__(256) mfar_t2_collect_kernel(const T2CollectParams p) {
+    __shared__ int n_s, ovf_s;
+    const int ql = blockIdx.x / p.nf, fo = blockIdx.x - ql * p.nf, f = p.f0 + fo;
+    const int li = ql * p.nf + fo;
+    if (p.lfail[li] != 1) {                              // workgroup-uniform
+        if (threadIdx.x == 0) p.cnt[li] = 0;
+        return;
+    }
+    if (threadIdx.x == 0) n_s = ovf_s = 0;
+    __syncthreads();
+    const int c_lo = p.fchunk[f], n_chunks = p.fchunk[f + 1] - c_lo;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    long long* out = p.cand + (size_t)li * T2_CAP;
+    for (int c = w; c < n_chunks; c += 4) {              // one wave per chunk list
+        const size_t lq = (size_t)(c_lo + c) * p.qw + ql;
+        const int n = min(p.list_cnt[lq], S1_CAP);
+        if (n >= p.kp) {                                 // compacted to its depth (or exactly full): rows above T may be gone
+            if (lane == 0) ovf_s = 1;
+            continue;
+        }
+        int base = 0;
+        if (lane == 0 && n > 0) base = atomicAdd(&n_s, n);
+        base = __shfl(base, 0);
+        if (base + n > T2_CAP) {
+            if (lane == 0) ovf_s = 1;
+            continue;
+        }
+        for (int e = lane; e < n; e += 64) out[base + e] = (long long)p.lists[lq * S1_CAP + e].y;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const bool ovf = ovf_s != 0 || n_s > T2_CAP;
+        p.cnt[li] = ovf ? 0 : n_s;
+        if (ovf) p.lfail_out[li] = 2;
+    }
+}
+
+struct T2SelectParams {
+    const long long* cand;    // [qw, nf, T2_CAP] unique rows
+    const float* sx2;         // [qw, nf, T2_CAP] their exact scores
+    const int* cnt;           // [qw * nf]
+    int* lfail;               // [qw * nf]
+    long long* sid;           // [qw, nf, kp] out: the screened-list format the certify kernel reads
+    float* sx;                // [qw, nf, kp]
+    int* scnt;                // [qw * nf]
+    int nf, kp, k;
+};
+// grid = Qt * nf, block 256, dynamic LDS = SEL_LDS_BYTES(T2_CAP)
+__global__ void __launch_bounds__(256) mfar_t2_select_kernel(const T2SelectParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int li = blockIdx.x;
+    if (p.lfail[li] != 1) return;                        // workgroup-uniform
+    u64* keys = (u64*)smem;
+    u64* sel = keys + T2_CAP;
+    u64* sorted = sel + 256;
+    int* red = (int*)(sorted + 256);
+    const int n = min(p.cnt[li], T2_CAP);
+    const long long* cd = p.cand + (size_t)li * T2_CAP;
+    const float* sc = p.sx2 + (size_t)li * T2_CAP;
+    // (every candidate was scored: a NaN score -- non-finite data -- orders above everything and ends in the certify kernel's own checks)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) keys[i] = make_key(sc[i], (u32)cd[i]);
+    const int keep = p.kp - 1;                           // a list SHORTER than k' needs no proof (mfar_screen_certify_kernel)
+    const int m = block_topk_sorted<T2_CAP / 256>(keys, n, keep, sel, sorted, red);
+    // the cut must not fall inside a run of equal scores that reaches up into the top-k: rows tied with the k-th would be missing
+    bool bad = false;
+    if (n > keep && m == keep && p.k <= keep) bad = (u32)(sorted[keep - 1] >> 32) == (u32)(sorted[p.k - 1] >> 32);
+    const size_t lb = (size_t)li * p.kp;
+    for (int r = threadIdx.x; r < p.kp; r += blockDim.x) {
+        p.sid[lb + r] = r < m ? (long long)key_id(sorted[r]) : -1;
+        p.sx[lb + r] = r < m ? key_score(sorted[r]) : __builtin_nanf("");
+    }
+    if (threadIdx.x == 0) {
+        p.scnt[li] = m;
+        if (bad) p.lfail[li] = 2;
+    }
+}
+#define T2_SELECT_LDS_BYTES ((size_t)T2_CAP * 8 + 2 * 256 * 8 + 36 * 4)

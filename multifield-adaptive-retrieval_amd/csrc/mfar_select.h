@@ -519,6 +519,8 @@ struct ScoreParams {
     const float* q;          // [Q, E] row-major
     const long long* cand;   // [Q, C]
     const int* n_cand;       // [Q] or nullptr
+    const int* n_cand_pf;    // [Q, F] or nullptr.  per_field mode of mfar_score_rows_kernel, C a multiple of its block size: entries of
+                             // list (q, j); rows past the count are neither gathered nor written (tier 2 of the certified screen)
     float* out;              // [Q, C, F]
     long long row_offset;
     int n_rows, n_steps, E, F, C;
@@ -714,6 +716,12 @@ __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_kernel(const Scor
         if (idx < p.C * p.F) p.out[(size_t)qi * p.C * p.F + idx] = __builtin_nanf("");
         return;
     }
+    int nc_pf = p.C;
+    if (p.per_field && p.n_cand_pf) {                    // the workgroup lies inside ONE list (C % SCF_THREADS == 0): workgroup-uniform
+        const int fl0 = first / p.C;
+        nc_pf = p.n_cand_pf[(size_t)qi * p.F + fl0];
+        if (first - fl0 * p.C >= nc_pf) return;
+    }
     for (int e = threadIdx.x; e < p.E; e += blockDim.x) qs[e] = p.q[(size_t)qi * p.E + e];
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -728,7 +736,7 @@ __global__ void __launch_bounds__(SCF_THREADS) mfar_score_rows_kernel(const Scor
         const int fl = p.per_field ? idx / p.C : idx - c * p.F;     // list / field slot of this launch
         const int f = p.per_field ? p.f0 + fl : fl;                 // field of the slab
         fld = f;
-        if (c < nc) {
+        if (c < nc && c < nc_pf) {
             long long id = p.cand[p.per_field ? ((size_t)qi * p.F + fl) * p.C + c : (size_t)qi * p.C + c];
             if (p.urep) id = (id >= 0 && id < p.nuniq[f]) ? (long long)p.urep[(size_t)f * p.ustride + id] : -1;   // unique row -> its document
             else id -= p.row_offset;

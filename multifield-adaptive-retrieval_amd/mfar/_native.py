@@ -89,6 +89,8 @@ SIGNATURES = {
     "mfar_set_row_mode": (_i, [_vp, _i]),
     "mfar_row_mode_activate": (_i, [_vp]),
     "mfar_set_auto_off": (_i, [_vp, _i, _i, _i]),
+    "mfar_set_tier2": (_i, [_vp, _i]),
+    "mfar_tier2_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i64), _c.POINTER(_i64)]),
     "mfar_auto_off_info": (_i, [_vp, _c.POINTER(_c.c_uint32), _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i)]),
     "mfar_row_mode_info": (_i, [_vp, _c.POINTER(_c.c_uint32), _c.POINTER(_c.c_uint32)]),
     "mfar_set_stage2_dump": (_i, [_vp, _i]),
@@ -107,7 +109,7 @@ SIGNATURES = {
 
 # MFAR_ABI_VERSION of include/mfar_hip.h these signatures were written against.  A library that reports another value has
 # different argument lists behind the same names (pointers would land in the wrong slots): lib() refuses it.
-ABI_VERSION = 105
+ABI_VERSION = 106
 
 
 def lib():

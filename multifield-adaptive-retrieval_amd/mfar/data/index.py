@@ -432,6 +432,16 @@ class MultiFieldIndex:
         return dict(off=[f for f in range(self.n_fields) if (m.value >> f) & 1], n_switched_off=a.value, n_switched_on=b.value,
                     n_probes=c.value, inline_repair=bool(r.value))
 
+    def set_tier2(self, mode: int = 1):
+        """TIER 2 of the certified screen, the threshold rescan (include/mfar_hip.h): 0 never, 1 auto (armed by failed certificates),
+        2 always.  Outputs are bit-identical in every mode."""
+        _native.check(_native.lib().mfar_set_tier2(self._h, int(mode)))
+
+    def tier2_stats(self) -> dict:
+        a, n, b = ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64()
+        _native.check(_native.lib().mfar_tier2_stats(self._h, ctypes.byref(a), ctypes.byref(n), ctypes.byref(b)))
+        return dict(armed=bool(a.value), lists=n.value, passed_on_to_exact=b.value)
+
     def set_stage2_dump(self, mode: int = 1):
         """Score dump of the wide screened pass as the approximate level of stage 2 (include/mfar_hip.h): 0 never, 1 when it moves
         less than a third of the row gathers' bytes, 2 whenever possible.  Outputs are bit-identical in every mode."""

@@ -1486,6 +1486,7 @@ def test_auto_off_switches_clustered_fields_to_the_exact_pass(idxmod):
     kinds = ["plain", "plain", "clustered", "plain", "plain", "clustered", "plain", "plain"]
     corpus = synth.SyntheticCorpus(D, F, E, n_queries=40 * Q, seed=0xdeadbeef, device="cuda:0", field_kinds=kinds)
     ix = corpus.build_index(idxmod)
+    ix.set_tier2(0)            # the policy on its own: with tier 2 (round 6, tests/test_gpu_tier2.py) these lists never reach the exact pass
     W = corpus.W
     mask = torch.ones(F, device="cuda:0")
     mask[3] = 0
