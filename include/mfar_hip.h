@@ -340,6 +340,12 @@ int mfar_screen_field_info(mfar_index* idx, int field, int64_t* n_unique_rows, i
  * mfar_stage2_stats synchronises the device: candidates the prune kernel has seen / survivors it kept since the handle was created.
  */
 int mfar_set_stage2_mode(mfar_index* idx, int mode);
+/* Which kernels run the tail of a search (union -> stage 2 -> mixer); results are identical.  1 (default; environment MFAR_S2_FUSED): the
+ * round-6 family -- field weights / q . mean / eps once per batch and off the critical chain (mfar_s2_gate_kernel), candidate union + known
+ * pairs by bitmap in one kernel when the ids span <= 2^20 (mfar_s2_front_kernel), the interval bounds by several workgroups per query
+ * (mfar_s2_bounds_kernel + mfar_s2_select_kernel);  0: the one-workgroup-per-query kernels of rounds 3-5 (sort-based union, prep, known,
+ * prune).  A diagnostic and a test hook (tests/test_gpu_stage2.py runs both against each other and the oracle). */
+int mfar_set_stage2_kernels(mfar_index* idx, int family);
 /*
  * SCORE DUMP (no reference counterpart; outputs bit-identical with and without it).  The approximate level of the two-level stage 2
  * normally gathers one 16-bit row per (candidate, field) pair.  When queries x candidates exceeds a field's rows -- many fields, small

@@ -153,9 +153,17 @@ struct mfar_index {
     bool gslab_nomem = false;     // it could not be allocated: gathers stay on the scan-ordered slab
     bool rows16_dirty = true;     // bf16 index: rows were written since the companion was filled
     int stage2_mode = 1;          // 0 = gather every (candidate, field) row from the fp32 slab; 1 = certified two-level stage 2 when available
+    bool s2_fused = true;         // the tail as the round-6 kernels (gate / front / bounds / select: mfar_select.h); false = the kernels of rounds 3-5
     DevBuf xa[MFAR_SLOTS], cand2[MFAR_SLOTS], ncand2[MFAR_SLOTS], s2qm[MFAR_SLOTS], s2eps[MFAR_SLOTS], s2stats;   // two-level stage 2 scratch (per pipeline slot) + counters
     DevBuf kmask[MFAR_SLOTS], src2[MFAR_SLOTS];                      // ... known pairs (stage-1 scores reused), survivor -> candidate index
     DevBuf xe[MFAR_SLOTS];                                           // ... per-pair bounds of the score dump's level (row norms)
+    DevBuf s2wgt[MFAR_SLOTS], lbub[MFAR_SLOTS];                      // field weights of the batch (mfar_s2_gate_kernel), interval ends (mfar_s2_bounds_kernel)
+    struct S2Pre {                                                   // what the gate kernel last computed for the slot (run_stage2_pre)
+        const float* q = nullptr;
+        const float* W = nullptr;
+        int Q = 0;
+        bool approx = false;                                         // ... with q . mean and eps of the approximate level
+    } s2pre[MFAR_SLOTS];
     // certified fp16 screen of an fp32 index (mfar_screen.h)
     int screen_mode = 1;          // 0 off, 1 auto, 2 always (when the shapes allow)
     float screen_eps_mult = 1.0f; // test knob: scales the certificate's error bound
@@ -210,6 +218,7 @@ struct mfar_index {
     bool write_pending = false;
 };
 
+static bool s2_fused_default();
 static std::mutex g_attr_mu;               // (handles may be created from different host threads)
 static int set_kernel_attrs(int device) {
     if (device < 0 || device >= 16) return fail(MFAR_ERR_INVALID, "device index out of range");
@@ -232,6 +241,10 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_score_rows_kernel<SRC_F16G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_score_rows_kernel<SRC_BF16G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_s2_prune_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // (these two also hold a little static LDS: the dynamic part must leave room for it)
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_s2_gate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S2_DYN_LDS_MAX));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_s2_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S2_DYN_LDS_MAX));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_s2_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_score_candidates_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1B_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_stage1_bf16_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S1B_LDS_BYTES));
@@ -339,6 +352,7 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     if (const char* e = getenv("MFAR_SCREEN_ROW_MODE")) idx->row_mode_setting = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("MFAR_SCREEN_AUTO_OFF")) idx->pol.set_mode(atoi(e) != 0 ? 1 : 0);
     if (const char* e = getenv("MFAR_SCREEN_TIER2")) idx->tier2_mode = std::max(0, std::min(2, atoi(e)));
+    idx->s2_fused = s2_fused_default();
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) idx->n_cu = prop.multiProcessorCount;
     hipError_t e = hipMalloc(&idx->slab, idx->slab_bytes);
@@ -381,7 +395,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
                       &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->s2stats, &idx->rep_bits, &idx->u_of, &idx->s_field1, &idx->s_cvt, &idx->dump_base, &idx->s_rnorm, &idx->s_nsum};
     for (int i = 0; i < MFAR_SLOTS; ++i)
         for (DevBuf* b : {&idx->cand[i], &idx->ncand[i], &idx->x[i], &idx->own[i], &idx->xa[i], &idx->cand2[i], &idx->ncand2[i], &idx->s2qm[i],
-                          &idx->s2eps[i], &idx->kmask[i], &idx->src2[i], &idx->xe[i]})
+                          &idx->s2eps[i], &idx->kmask[i], &idx->src2[i], &idx->xe[i], &idx->s2wgt[i], &idx->lbub[i]})
             b->release();
     for (S1Geom* g : {&idx->geom_docs, &idx->geom_screen})
         for (S1Table* t : {&g->all, &g->solo, &g->all_w, &g->solo_w, &g->all_skip, &g->all_w_skip}) {
@@ -1958,6 +1972,12 @@ extern "C" int mfar_set_stage2_mode(mfar_index* idx, int mode) {
     return MFAR_OK;
 }
 
+extern "C" int mfar_set_stage2_kernels(mfar_index* idx, int family) {
+    if (!idx || family < 0 || family > 1) return fail(MFAR_ERR_INVALID, "family must be 0 (the kernels of rounds 3-5) or 1 (round 6: gate / front / bounds / select)");
+    idx->s2_fused = family != 0;
+    for (auto& pre : idx->s2pre) pre.q = nullptr;
+    return MFAR_OK;
+}
 extern "C" int mfar_set_row_mode(mfar_index* idx, int mode) {
     if (!idx || mode < 0 || mode > 2) return fail(MFAR_ERR_INVALID, "mode must be 0 (never), 1 (auto: after a failed certificate) or 2 (always)");
     idx->row_mode_setting = mode;
@@ -2173,10 +2193,12 @@ extern "C" int mfar_score_candidates(mfar_index* idx, const float* q, int Q, con
 }
 
 // ------------------------------------------------------------------------------------------------ mixer
+//   wgt   [Q, MFAR_MAX_FIELDS] field weights from mfar_s2_gate_kernel, or nullptr (the mixer computes them itself: same code, same bits)
 static int run_mix(const float* x, const long long* cand, const int* ncand, const float* q, const float* W, int query_cond,
                    const float* mask, int Q, int C, int F, int E, int k, long long* ids, float* scores, int* n_valid,
-                   hipStream_t st) {
+                   hipStream_t st, const float* wgt = nullptr) {
     MixParams p = {};
+    p.wgt = wgt;
     p.x = x;
     p.cand = cand;
     p.n_cand = ncand;
@@ -2192,7 +2214,7 @@ static int run_mix(const float* x, const long long* cand, const int* ncand, cons
     p.k = k;
     p.query_cond = query_cond;
     if (Q == 0) return MFAR_OK;
-    const size_t lds = MIX_LDS_BYTES(C, query_cond ? E : 0, F);
+    const size_t lds = MIX_LDS_BYTES(C, (query_cond && !wgt) ? E : 0, F);
     if (lds > 160 * 1024) return fail(MFAR_ERR_UNSUPPORTED, "dim * n_fields too large for the mixer kernel's LDS staging");
     mfar_mix_topk_kernel<<<dim3(Q), dim3(256), lds, st>>>(p);
     HIPCHK(hipGetLastError());
@@ -2261,12 +2283,63 @@ static bool two_level_ok(const mfar_index* idx, int C, int k2, int query_cond, i
     return idx->stage2_mode >= 1 && idx->dtype == MFAR_DTYPE_F32 && idx->gslab_ok && idx->screen_built && !idx->screen_dirty && C > k2 &&
            k2 <= SEL_MAX_K && PRUNE_LDS_BYTES(C, query_cond ? idx->E : 0, idx->F) <= 160 * 1024;
 }
+// Round 6: the tail as fewer, wider kernels (mfar_select.h "Round 6").  MFAR_S2_FUSED=0: the kernels of rounds 3-5 (diagnostic; the tests
+// run both families against each other).
+static bool s2_fused_default() {
+    static const bool v = !(getenv("MFAR_S2_FUSED") && atoi(getenv("MFAR_S2_FUSED")) == 0);
+    return v;
+}
+static bool approx_level_ok(const mfar_index* idx) {
+    return idx->dtype == MFAR_DTYPE_F32 && idx->stage2_mode >= 1 && idx->gslab_ok && idx->screen_built && !idx->screen_dirty;
+}
+// Field weights of the batch (+ q . mean and eps of the approximate level when the index has one) -> idx->s2wgt / s2qm / s2eps of the slot.
+// Depends on q and W only: a pipelined caller enqueues it before its tail waits for the scan (pipe_launch); run_stage2_mix calls it itself
+// when nobody has.
+static int run_stage2_pre(mfar_index* idx, const float* qd, int Q, const float* Wd, int query_cond, int slot, hipStream_t st) {
+    const int F = idx->F, E = idx->E;
+    mfar_index::S2Pre& pre = idx->s2pre[slot];
+    pre.q = nullptr;
+    if (!idx->s2_fused || Q == 0) return MFAR_OK;
+    const size_t lds = GATE_LDS_BYTES(query_cond ? E : 0, F);
+    if (lds > S2_DYN_LDS_MAX) return MFAR_OK;                  // (the mixer's own staging decides whether the shape is supported)
+    RETCHK(idx->s2wgt[slot].ensure((size_t)Q * MFAR_MAX_FIELDS * 4));
+    RETCHK(idx->s2qm[slot].ensure((size_t)Q * MFAR_MAX_FIELDS * 4));
+    RETCHK(idx->s2eps[slot].ensure((size_t)Q * MFAR_MAX_FIELDS * 4));
+    GateParams g = {};
+    g.q = qd;
+    g.W = Wd;
+    g.wgt = idx->s2wgt[slot].as<float>();
+    g.E = E;
+    g.F = F;
+    g.query_cond = query_cond;
+    const bool approx = approx_level_ok(idx);
+    if (approx) {
+        g.mean = idx->s_mean.as<float>();
+        g.sf = idx->s_field.as<ScreenField>();
+        g.qm = idx->s2qm[slot].as<float>();
+        g.eps = idx->s2eps[slot].as<float>();
+        g.eps_mult = idx->screen_eps_mult;
+    }
+    mfar_s2_gate_kernel<<<dim3(Q), dim3(256), lds, st>>>(g);
+    HIPCHK(hipGetLastError());
+    pre.q = qd;
+    pre.W = Wd;
+    pre.Q = Q;
+    pre.approx = approx;
+    return MFAR_OK;
+}
+static const float* s2_weights(const mfar_index* idx, const float* qd, int Q, const float* Wd, int slot) {
+    const mfar_index::S2Pre& pre = idx->s2pre[slot];
+    return (pre.q == qd && pre.Q == Q && pre.W == Wd && qd) ? idx->s2wgt[slot].as<float>() : nullptr;
+}
+
 //   cand / ncand [Q, C] / [Q]: the candidates to score (sorted unique ids);  masks [n_masks, F] or nullptr (ones, n_masks = 1)
 //   x [Q, C, F]: exact score vectors of the SURVIVORS, row c of x belongs to (*cand_out)[q, c]
 //   fid / fsc  the stage-1 lists [Q, F, k1] with their exact scores, or fsc == nullptr: no known pairs (every pair is gathered)
+//   known_done  mfar_s2_front_kernel already wrote the known pairs into xa / kmask of the slot
 static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* Wd, int query_cond, const float* masks, int n_masks, int k2,
                          const long long* cand, const int* ncand, int C, int slot, float* x, const long long** cand_out,
-                         const int** ncand_out, const long long* fid, const float* fsc, int k1, int sentinel, hipStream_t st) {
+                         const int** ncand_out, const long long* fid, const float* fsc, int k1, int sentinel, hipStream_t st, bool known_done = false) {
     const int F = idx->F, E = idx->E;
     RETCHK(idx->xa[slot].ensure((size_t)Q * C * F * 4));
     RETCHK(idx->cand2[slot].ensure((size_t)Q * C * 8));
@@ -2281,42 +2354,51 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
     mfar_index::S1Slot& sl = idx->s1[slot];
     const bool from_dump = sl.dump_ready && sl.dump_q == qd && sl.dump_Q == Q && Q <= 128 && idx->u_of.p && idx->u_repof.p;
     sl.dump_ready = false;
-    S2PrepParams pp = {};
-    pp.q = qd;
-    pp.mean = idx->s_mean.as<float>();
-    pp.sf = idx->s_field.as<ScreenField>();
-    pp.qm = idx->s2qm[slot].as<float>();
-    pp.eps = idx->s2eps[slot].as<float>();
-    pp.E = E;
-    pp.F = F;
-    pp.eps_mult = idx->screen_eps_mult;
-    if (from_dump) {
-        pp.eps_src = sl.eps_dump.as<float>();      // the screened pass's eps + the dump's quantisation step
-        pp.eps_qw = 128;
+    const float* wgt = s2_weights(idx, qd, Q, Wd, slot);       // the gate kernel ran for this batch: weights, q . mean and eps are in place
+    const bool pre_ok = wgt != nullptr && idx->s2pre[slot].approx;
+    float* qm = idx->s2qm[slot].as<float>();
+    float* eps = idx->s2eps[slot].as<float>();
+    if (!pre_ok) {
+        S2PrepParams pp = {};
+        pp.q = qd;
+        pp.mean = idx->s_mean.as<float>();
+        pp.sf = idx->s_field.as<ScreenField>();
+        pp.qm = qm;
+        pp.eps = eps;
+        pp.E = E;
+        pp.F = F;
+        pp.eps_mult = idx->screen_eps_mult;
+        if (from_dump) {
+            pp.eps_src = sl.eps_dump.as<float>();      // the screened pass's eps + the dump's quantisation step
+            pp.eps_qw = 128;
+        }
+        mfar_s2_prep_kernel<<<dim3(Q), dim3(256), 0, st>>>(pp);
+        HIPCHK(hipGetLastError());
     }
-    mfar_s2_prep_kernel<<<dim3(Q), dim3(256), 0, st>>>(pp);
-    HIPCHK(hipGetLastError());
-    const ApproxArgs ap = {pp.qm};
+    // (from the dump with the gate kernel's eps: unused -- every pair of that level carries its own bound, xe below)
+    const ApproxArgs ap = {qm};
     static const bool reuse = !(getenv("MFAR_STAGE2_KNOWN") && atoi(getenv("MFAR_STAGE2_KNOWN")) == 0);   // diagnostic: 0 = gather the known pairs too
     KnownArgs kn = {nullptr, nullptr, nullptr};
     if (fsc && fid && reuse) {     // a candidate's score in the field whose list it came from is exact already: not gathered, eps = 0
         RETCHK(idx->kmask[slot].ensure((size_t)Q * C * 4));
         RETCHK(idx->src2[slot].ensure((size_t)Q * C * 4));
-        HIPCHK(hipMemsetAsync(idx->kmask[slot].p, 0, (size_t)Q * C * 4, st));
-        KnownParams kp = {};
-        kp.fid = fid;
-        kp.fsc = fsc;
-        kp.cand = cand;
-        kp.n_cand = ncand;
-        kp.xa = idx->xa[slot].as<float>();
-        kp.kmask = idx->kmask[slot].as<u32>();
-        kp.F = F;
-        kp.k = k1;
-        kp.C = C;
-        kp.sentinel = sentinel;
-        mfar_s2_known_kernel<<<dim3(Q), dim3(256), 0, st>>>(kp);
-        HIPCHK(hipGetLastError());
-        kn.kmask = kp.kmask;
+        if (!known_done) {
+            HIPCHK(hipMemsetAsync(idx->kmask[slot].p, 0, (size_t)Q * C * 4, st));
+            KnownParams kp = {};
+            kp.fid = fid;
+            kp.fsc = fsc;
+            kp.cand = cand;
+            kp.n_cand = ncand;
+            kp.xa = idx->xa[slot].as<float>();
+            kp.kmask = idx->kmask[slot].as<u32>();
+            kp.F = F;
+            kp.k = k1;
+            kp.C = C;
+            kp.sentinel = sentinel;
+            mfar_s2_known_kernel<<<dim3(Q), dim3(256), 0, st>>>(kp);
+            HIPCHK(hipGetLastError());
+        }
+        kn.kmask = idx->kmask[slot].as<u32>();
     }
     if (from_dump) {
         S2LookupParams lp = {};
@@ -2336,7 +2418,7 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
         lp.row_offset = idx->row_offset;
         lp.sf = idx->s_field.as<ScreenField>();
         lp.qinfo = sl.qinfo.as<ScreenQuery>();
-        lp.qm = pp.qm;
+        lp.qm = qm;
         lp.kmask = kn.kmask;
         lp.xa = idx->xa[slot].as<float>();
         lp.n_rows = (int)idx->n_rows;
@@ -2352,7 +2434,7 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
     pr.xa = idx->xa[slot].as<float>();
     pr.cand = cand;
     pr.n_cand = ncand;
-    pr.eps = pp.eps;
+    pr.eps = eps;
     pr.xe = from_dump ? idx->xe[slot].as<float>() : nullptr;
     pr.q = qd;
     pr.W = Wd;
@@ -2368,7 +2450,23 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
     pr.k = k2;
     pr.query_cond = query_cond;
     pr.n_masks = masks ? n_masks : 1;
-    mfar_s2_prune_kernel<<<dim3(Q), dim3(256), PRUNE_LDS_BYTES(C, query_cond ? E : 0, F), st>>>(pr);
+    if (wgt && idx->lbub[slot].ensure((size_t)pr.n_masks * Q * C * 8) == MFAR_OK) {
+        // the weights exist: interval ends by several workgroups per query, then the per-query selection
+        BoundsParams bp = {};
+        bp.pr = pr;
+        bp.wgt = wgt;
+        bp.lbub = idx->lbub[slot].as<float>();
+        bp.Q = Q;
+        mfar_s2_bounds_kernel<<<dim3(S2_BOUND_SPLIT, Q), dim3(256), 0, st>>>(bp);
+        HIPCHK(hipGetLastError());
+        mfar_s2_select_kernel<<<dim3(Q), dim3(256), S2_SELECT_LDS_BYTES(C), st>>>(bp);
+    } else {
+        if (wgt) {
+            (void)hipGetLastError();
+            g_err.clear();
+        }
+        mfar_s2_prune_kernel<<<dim3(Q), dim3(256), PRUNE_LDS_BYTES(C, query_cond ? E : 0, F), st>>>(pr);
+    }
     HIPCHK(hipGetLastError());
     kn.ksrc = pr.src2;
     kn.kval = idx->xa[slot].as<float>();
@@ -2422,18 +2520,45 @@ static int run_stage2_mix(mfar_index* idx, const float* qd, int Q, const float* 
     }
     RETCHK(idx->cand[slot].ensure((size_t)Q * C * 8));
     RETCHK(idx->x[slot].ensure((size_t)Q * C * F * 4));
-    mfar_union_kernel<<<dim3(Q), dim3(256), 0, st>>>(fid, F, k1, idx->cand[slot].as<long long>(), ncd);
+    if (!s2_weights(idx, qd, Q, Wd, slot)) RETCHK(run_stage2_pre(idx, qd, Q, Wd, query_cond, slot, st));      // (a pipelined caller did this beside the scan)
+    const float* wgt = s2_weights(idx, qd, Q, Wd, slot);
+    const bool two = two_level_ok(idx, C, k2, query_cond, n_masks);
+    // candidate union (+ the known pairs of the two-level path) by bitmap when the ids span <= 2^20, else sort + unique
+    static const bool reuse = !(getenv("MFAR_STAGE2_KNOWN") && atoi(getenv("MFAR_STAGE2_KNOWN")) == 0);
+    const long long span = idx->row_offset + idx->n_rows;
+    const bool front = idx->s2_fused && span <= S2_FRONT_MAX_SPAN && S2_FRONT_LDS_BYTES(span, C) <= S2_DYN_LDS_MAX;
+    bool known_done = false;
+    if (front) {
+        FrontParams fp = {};
+        fp.fid = fid;
+        fp.cand = idx->cand[slot].as<long long>();
+        fp.n_cand = ncd;
+        fp.F = F;
+        fp.k = k1;
+        fp.sentinel = sentinel;
+        fp.span = (int)span;
+        if (two && fsc && reuse && idx->xa[slot].ensure((size_t)Q * C * F * 4) == MFAR_OK && idx->kmask[slot].ensure((size_t)Q * C * 4) == MFAR_OK) {
+            fp.fsc = fsc;
+            fp.xa = idx->xa[slot].as<float>();
+            fp.kmask = idx->kmask[slot].as<u32>();
+            known_done = true;
+        }
+        mfar_s2_front_kernel<<<dim3(Q), dim3(256), S2_FRONT_LDS_BYTES(span, C), st>>>(fp);
+    } else {
+        mfar_union_kernel<<<dim3(Q), dim3(256), 0, st>>>(fid, F, k1, idx->cand[slot].as<long long>(), ncd);
+    }
     HIPCHK(hipGetLastError());
     const long long* cm = idx->cand[slot].as<long long>();
     const int* nm = ncd;
-    if (two_level_ok(idx, C, k2, query_cond, n_masks))
+    if (two)
         RETCHK(run_two_level(idx, qd, Q, Wd, query_cond, masks, n_masks, k2, cm, nm, C, slot, idx->x[slot].as<float>(), &cm, &nm, fid, fsc, k1,
-                             sentinel, st));
+                             sentinel, st, known_done));
     else
         RETCHK(run_score_known(idx, qd, Q, cm, nm, C, slot, idx->x[slot].as<float>(), fid, fsc, k1, sentinel, st));
     for (int m = 0; m < n_masks; ++m)
         RETCHK(run_mix(idx->x[slot].as<float>(), cm, nm, qd, Wd, query_cond, masks ? masks + (size_t)m * F : nullptr, Q, C, F, E, k2,
-                       idd + (size_t)m * Q * k2, scd + (size_t)m * Q * k2, nvd ? nvd + (size_t)m * Q : nullptr, st));
+                       idd + (size_t)m * Q * k2, scd + (size_t)m * Q * k2, nvd ? nvd + (size_t)m * Q : nullptr, st, wgt));
+    idx->s2pre[slot].q = nullptr;                              // one batch, one use (the caller's q buffer is refilled in place)
     return MFAR_OK;
 }
 

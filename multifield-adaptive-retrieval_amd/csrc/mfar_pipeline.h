@@ -27,6 +27,7 @@ struct mfar_pipeline {
         DevBuf q, ids, scores, n_valid, fid, fsc, fail;
         int* fail_host = nullptr;         // pinned
         hipEvent_t stage1 = nullptr, done = nullptr, copied = nullptr;
+        hipEvent_t qready = nullptr;      // on the scan stream where the launch's begin phase starts: its queries are in the slot
         hipEvent_t taken = nullptr;       // behind the last result / lists copy out of this slot on a CALLER's stream (device pointers)
         bool taken_pending = false;
         hipStream_t taken_stream = nullptr;
@@ -82,10 +83,15 @@ static int pipe_launch(mfar_pipeline* p) {
         HIPCHK(hipStreamWaitEvent(p->st->main, s.taken, 0));       // its tail (ordered behind the begin phase by s.stage1) the results
         s.taken_pending = false;
     }
+    HIPCHK(hipEventRecord(s.qready, p->st->main));
     RETCHK(stage1_block(idx, slot, S1_PREPARE | S1_SCAN | (merge_in_finish() ? 0 : S1_FINISH), s.q.as<float>(), Q, 0, p->k1, p->sentinel, 0, idx->F,
                         s.fid.as<long long>(), s.fsc.as<float>(), nullptr, p->st->main));
     if (Q > idx->s1[slot].qw) return fail(MFAR_ERR_UNSUPPORTED, "a coalesced launch needs the screen slab, which could not be (re)built");
     HIPCHK(hipEventRecord(s.stage1, p->st->main));
+    // what the tail needs from q and W alone (field weights, q . mean, eps of stage 2's approximate level): beside the scan, not behind it
+    // (enqueued after the begin phase on the host: a rebuild of the screen, if rows were written, has happened by now)
+    HIPCHK(hipStreamWaitEvent(side, s.qready, 0));
+    RETCHK(run_stage2_pre(idx, s.q.as<float>(), Q, p->W.as<float>(), p->query_cond, slot, side));
     HIPCHK(hipStreamWaitEvent(side, s.stage1, 0));
     // finish REPORTS a failed certificate (read in pipe_check); when failures are frequent the library repairs on the device instead and
     // switches fields that keep failing off (mfar_hip.hip "adaptive policy"): nothing here latches
@@ -140,7 +146,7 @@ extern "C" void mfar_pipeline_destroy(mfar_pipeline* p) {
     for (auto& s : p->slots) {
         for (DevBuf* b : {&s.q, &s.ids, &s.scores, &s.n_valid, &s.fid, &s.fsc, &s.fail}) b->release();
         if (s.fail_host) (void)hipHostFree(s.fail_host);
-        for (hipEvent_t e : {s.stage1, s.done, s.copied, s.taken})
+        for (hipEvent_t e : {s.stage1, s.done, s.copied, s.taken, s.qready})
             if (e) (void)hipEventDestroy(e);
     }
     p->W.release();
@@ -198,7 +204,8 @@ extern "C" int mfar_pipeline_create(mfar_pipeline** out, mfar_index* idx, const 
         if (rc != MFAR_OK) break;
         if (hipMemset(s.fail.p, 0, 4) != hipSuccess || hipHostMalloc((void**)&s.fail_host, 4, hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&s.stage1, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.taken, hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.taken, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.qready, hipEventDisableTiming) != hipSuccess)
             rc = fail(MFAR_ERR_HIP, "pipeline slot: event / pinned allocation failed");
         else {
             s.fail_host[0] = 0;

@@ -959,6 +959,8 @@ struct MixParams {
     float* scores;          // [Q, k]
     int* n_valid;           // [Q] or nullptr
     int C, F, E, k, query_cond;
+    const float* wgt;       // [Q, MFAR_MAX_FIELDS] or nullptr: the field weights mfar_s2_gate_kernel computed for these queries (the SAME code as
+                            // mix_gate_weights below, hence the same bits) -- the mixer then stages neither q nor W
 };
 // Field weights of one query, shared by the mixer and the prune kernel (the SAME instruction sequence => the same weight bits):
 // gate logits = natural-order fma chain per field (q and W staged in LDS by all threads first, so the F serial chains read LDS,
@@ -1026,7 +1028,13 @@ __global__ void __launch_bounds__(256) mfar_mix_topk_kernel(const MixParams p) {
     float* qs = msk + MFAR_MAX_FIELDS;   // [E]
     float* Ws = qs + p.E;                // [E * F]
     if (threadIdx.x == 0) n_s = 0;
-    mix_gate_weights(p.q + (size_t)qi * p.E, p.W, p.mask, p.query_cond, p.E, p.F, z, wgt, msk, qs, Ws);
+    if (p.wgt) {
+        if ((int)threadIdx.x < p.F) {
+            wgt[threadIdx.x] = p.wgt[(size_t)qi * MFAR_MAX_FIELDS + threadIdx.x];
+            msk[threadIdx.x] = p.mask ? p.mask[threadIdx.x] : 1.0f;
+        }
+        __syncthreads();
+    } else mix_gate_weights(p.q + (size_t)qi * p.E, p.W, p.mask, p.query_cond, p.E, p.F, z, wgt, msk, qs, Ws);
     for (int c = threadIdx.x; c < nc; c += blockDim.x) {
         const long long id = p.cand[(size_t)qi * p.C + c];
         if (id < 0) continue;
@@ -1300,6 +1308,281 @@ __global__ void __launch_bounds__(256) mfar_s2_prune_kernel(const PruneParams p)
     long long* out = p.cand2 + (size_t)qi * p.C;
     int* osrc = p.src2 ? p.src2 + (size_t)qi * p.C : nullptr;
     for (int i = b; i < e_; ++i)
+        if (surv[i]) {
+            if (osrc) osrc[pos] = i;
+            out[pos++] = cq[i];
+        }
+    for (int i = total + threadIdx.x; i < p.C; i += blockDim.x) {
+        out[i] = -1;
+        if (osrc) osrc[i] = -1;
+    }
+    if (threadIdx.x == 0) {
+        p.n_cand2[qi] = total;
+        if (p.stats) {
+            atomicAdd(&p.stats[0], (unsigned long long)nc);
+            atomicAdd(&p.stats[1], (unsigned long long)total);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Round 6: the tail of a launch as FEWER, WIDER kernels (at 129 375 x 22 the one-workgroup-per-query kernels -- union,
+// prep, known pairs, prune, mixer -- held 128 of 256 CUs for ~0.5 ms of every 1.66 ms period).
+//   mfar_s2_gate_kernel     per query, ONCE: the field weights (mix_gate_weights: the mixer's own code, the mixer's bits), q . mean(f) and the
+//                           approximate level's eps(q, f) (what mfar_s2_prep_kernel computed).  Depends on q and W only, so the pipeline
+//                           enqueues it BEFORE the tail waits for the scan: off the critical chain; prune and mixer read the weights.
+//   mfar_s2_front_kernel    candidate union + known pairs in one kernel, by BITMAP when the ids span <= 2^20 (every BASELINE shape on one
+//                           GPU): set bits, prefix of popcounts, emit the ids in order; a known pair's slot is its id's rank in the bitmap
+//                           -- no sort, no binary search in global memory, no kmask memset.
+//   mfar_s2_bounds_kernel   the interval ends of every candidate's mixed score, S2_BOUND_SPLIT workgroups per query;
+//   mfar_s2_select_kernel   per query: T = k-th largest lower end, survivors, compaction (what is left of mfar_s2_prune_kernel).
+// Same results as the kernels they replace (tests/test_gpu_stage2.py runs both families against each other and the oracle).
+// ---------------------------------------------------------------------------------------------------------
+struct GateParams {
+    const float* q;          // [Q, E]
+    const float* W;          // [E, F] or [F]
+    float* wgt;              // [Q, MFAR_MAX_FIELDS] out
+    // the approximate level of the two-level stage 2 (mean == nullptr: weights only)
+    const float* mean;       // [F, E]
+    const ScreenField* sf;   // [F]
+    float* qm;               // [Q, MFAR_MAX_FIELDS]
+    float* eps;              // [Q, MFAR_MAX_FIELDS]
+    float eps_mult;
+    int E, F, query_cond;
+};
+#define GATE_LDS_BYTES(E, F) ((size_t)3 * MFAR_MAX_FIELDS * 4 + (size_t)(E) * 4 + (size_t)(E) * (F) * 4)
+// grid = Q, block 256, dynamic LDS = GATE_LDS_BYTES(query_cond ? E : 0, F) (query_cond == 0: q is still staged: E floats)
+__global__ void __launch_bounds__(256) mfar_s2_gate_kernel(const GateParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float part[MFAR_MAX_FIELDS + 1][4];
+    float* z = (float*)smem;
+    float* wgt = z + MFAR_MAX_FIELDS;
+    float* msk = wgt + MFAR_MAX_FIELDS;
+    float* qs = msk + MFAR_MAX_FIELDS;
+    float* Ws = qs + p.E;
+    const int qi = blockIdx.x;
+    const float* qr = p.q + (size_t)qi * p.E;
+    mix_gate_weights(qr, p.W, nullptr, p.query_cond, p.E, p.F, z, wgt, msk, qs, Ws);
+    if ((int)threadIdx.x < p.F) p.wgt[(size_t)qi * MFAR_MAX_FIELDS + threadIdx.x] = wgt[threadIdx.x];
+    if (!p.mean) return;
+    // (as mfar_s2_prep_kernel)
+    float ss = 0.0f;
+    for (int e = threadIdx.x; e < p.E; e += blockDim.x) ss = __builtin_fmaf(qr[e], qr[e], ss);
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((threadIdx.x & 63) == 0) part[MFAR_MAX_FIELDS][threadIdx.x >> 6] = ss;
+    for (int f = 0; f < p.F; ++f) {
+        float pm = 0.0f;
+        for (int e = threadIdx.x; e < p.E; e += blockDim.x) pm = __builtin_fmaf(qr[e], p.mean[(size_t)f * p.E + e], pm);
+        for (int off = 32; off > 0; off >>= 1) pm += __shfl_xor(pm, off);
+        if ((threadIdx.x & 63) == 0) part[f][threadIdx.x >> 6] = pm;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < p.F) {
+        const int f = threadIdx.x;
+        const ScreenField s = p.sf[f];
+        const float qn = sqrtf((part[MFAR_MAX_FIELDS][0] + part[MFAR_MAX_FIELDS][1]) + (part[MFAR_MAX_FIELDS][2] + part[MFAR_MAX_FIELDS][3])) * 1.0001f;
+        const float K = (float)p.E, u16f = 4.8828125e-4f, u32f = 5.9604645e-8f;
+        const float c_rel = u16f + 1.01f * (K + 2.0f) * u32f;
+        float e_ = S2_SLACK * (c_rel * qn * s.dnorm_max + 1.01f * (K + 1.0f) * u32f * qn * (s.dnorm_max + s.mnorm) + 1.01f * K * u32f * qn * s.mnorm +
+                               u32f * sqrtf(K) * 1.0001f * qn * s.inv_scale);
+        e_ *= p.eps_mult;
+        p.eps[(size_t)qi * MFAR_MAX_FIELDS + f] = e_;
+        p.qm[(size_t)qi * MFAR_MAX_FIELDS + f] = (part[f][0] + part[f][1]) + (part[f][2] + part[f][3]);
+    }
+}
+
+// Candidate union + known pairs by bitmap.  ids in [0, span), span <= S2_FRONT_MAX_SPAN; negative ids are padding.
+//   grid = Q, block 256, dynamic LDS = S2_FRONT_LDS_BYTES(span, C)
+#define S2_FRONT_MAX_SPAN (1 << 20)
+#define S2_DYN_LDS_MAX (158 * 1024)     // dynamic LDS a kernel with a few hundred bytes of static LDS may ask for (160 KB per CU)
+#define S2_FRONT_LDS_BYTES(span, C) ((size_t)(((span) + 511) / 512) * 64 + (size_t)(((span) + 511) / 512) * 4 + (size_t)(C) * 4 + 64)
+struct FrontParams {
+    const long long* fid;    // [Q, F, k] the stage-1 lists
+    const float* fsc;        // [Q, F, k] their exact scores, or nullptr: no known pairs (xa / kmask untouched)
+    long long* cand;         // [Q, C] out: sorted unique ids, -1 padded (C = F * k)
+    int* n_cand;             // [Q]
+    float* xa;               // [Q, C, F] known pairs' scores (other entries untouched)
+    u32* kmask;              // [Q, C] written for every slot when fsc != nullptr
+    int F, k, sentinel, span;
+};
+__global__ void __launch_bounds__(256) mfar_s2_front_kernel(const FrontParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int wsum[4];
+    const int nw16 = (p.span + 511) / 512;                   // groups of 16 words (512 ids)
+    const int n_words = nw16 * 16;
+    u32* bits = (u32*)smem;                                  // [n_words]
+    int* pre = (int*)(bits + n_words);                       // [nw16] ids set before the group
+    u32* km = (u32*)(pre + nw16);                            // [C]
+    const int qi = blockIdx.x, C = p.F * p.k;
+    const long long* fq = p.fid + (size_t)qi * C;
+    for (int i = threadIdx.x; i < n_words; i += blockDim.x) bits[i] = 0u;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) km[i] = 0u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        const long long id = fq[i];
+        if (id >= 0 && id < p.span) atomicOr(&bits[id >> 5], 1u << (id & 31));
+    }
+    __syncthreads();
+    // prefix over the 16-word groups: thread t owns a contiguous run of groups
+    const int per = (nw16 + 255) / 256;
+    const int g0 = min((int)threadIdx.x * per, nw16), g1 = min(g0 + per, nw16);
+    int mine = 0;
+    for (int g = g0; g < g1; ++g) {
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) c += __popc(bits[g * 16 + w]);
+        pre[g] = c;                                          // (count for now)
+        mine += c;
+    }
+    int incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane_id() >= off) incl += v;
+    }
+    if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int base = incl - mine;
+    for (int ww = 0; ww < (int)(threadIdx.x >> 6); ++ww) base += wsum[ww];
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    long long* out = p.cand + (size_t)qi * C;
+    for (int g = g0; g < g1; ++g) {                           // exclusive prefix in place + the ids of the group, ascending
+        const int c = pre[g];
+        pre[g] = base;
+        if (c) {
+            int pos = base;
+            for (int w = 0; w < 16; ++w) {
+                u32 b = bits[g * 16 + w];
+                while (b) {
+                    const int t = __builtin_ctz(b);
+                    b &= b - 1;
+                    out[pos++] = (long long)(g * 512 + w * 32 + t);
+                }
+            }
+        }
+        base += c;
+    }
+    for (int i = total + threadIdx.x; i < C; i += blockDim.x) out[i] = -1;
+    if (threadIdx.x == 0) p.n_cand[qi] = total;
+    if (!p.fsc) return;                                      // kernel-uniform
+    __syncthreads();
+    // known pairs: slot of id = ids set below it
+    const float* sq = p.fsc + (size_t)qi * C;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        const long long id = fq[i];
+        const float sc = sq[i];
+        if (id < 0 || id >= p.span || (p.sentinel && !(sc > 0.0f))) continue;      // padding
+        const int wd = (int)(id >> 5), g = wd >> 4;
+        int c = pre[g];
+        for (int w = g * 16; w < wd; ++w) c += __popc(bits[w]);
+        c += __popc(bits[wd] & ((1u << (id & 31)) - 1u));
+        const int f = i / p.k;
+        p.xa[((size_t)qi * C + c) * p.F + f] = sc;
+        atomicOr(&km[c], 1u << f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += blockDim.x) p.kmask[(size_t)qi * C + i] = km[i];
+}
+
+// Interval ends of the mixed scores: PruneParams as for mfar_s2_prune_kernel, + wgt (precomputed) and lbub [n_masks, Q, C, 2].
+#define S2_BOUND_SPLIT 4
+struct BoundsParams {
+    PruneParams pr;
+    const float* wgt;        // [Q, MFAR_MAX_FIELDS]
+    float* lbub;             // [n_masks, Q, C, 2]
+    int Q;
+};
+// grid = (S2_BOUND_SPLIT, Q), block 256
+__global__ void __launch_bounds__(256) mfar_s2_bounds_kernel(const BoundsParams b) {
+    __shared__ float wgt[MFAR_MAX_FIELDS], eps_s[MFAR_MAX_FIELDS], msk[MFAR_MAX_FIELDS];
+    const PruneParams& p = b.pr;
+    const int qi = blockIdx.y;
+    const int nc = min(p.n_cand[qi], p.C);
+    const int chunk = (nc + S2_BOUND_SPLIT - 1) / S2_BOUND_SPLIT;
+    const int c0 = blockIdx.x * chunk, c1 = min(c0 + chunk, nc);
+    if (c0 >= c1) return;                                    // workgroup-uniform
+    if ((int)threadIdx.x < p.F) {
+        wgt[threadIdx.x] = b.wgt[(size_t)qi * MFAR_MAX_FIELDS + threadIdx.x];
+        eps_s[threadIdx.x] = p.eps[(size_t)qi * MFAR_MAX_FIELDS + threadIdx.x];
+    }
+    const float* xq = p.xa + (size_t)qi * p.C * p.F;
+    const long long* cq = p.cand + (size_t)qi * p.C;
+    for (int m = 0; m < p.n_masks; ++m) {
+        __syncthreads();
+        if ((int)threadIdx.x < p.F) msk[threadIdx.x] = p.masks ? p.masks[(size_t)m * p.F + threadIdx.x] : 1.0f;
+        __syncthreads();
+        float* o = b.lbub + (((size_t)m * b.Q + qi) * p.C) * 2;
+        for (int c = c0 + threadIdx.x; c < c1; c += blockDim.x) {
+            float lo = __builtin_nanf(""), hi = __builtin_nanf("");
+            if (cq[c] >= 0) {
+                const float* xr = xq + (size_t)c * p.F;
+                const float* er = p.xe ? p.xe + ((size_t)qi * p.C + c) * p.F : nullptr;
+                const u32 km = p.kmask ? p.kmask[(size_t)qi * p.C + c] : 0u;
+                lo = hi = 0.0f;
+                for (int f = 0; f < p.F; ++f) {              // the mixer's chain on both interval ends (see mfar_s2_prune_kernel)
+                    const float v = xr[f], e = ((km >> f) & 1u) ? 0.0f : (er ? er[f] : eps_s[f]), mf = msk[f];
+                    const float dn = s2_nextdown(v - e), up = s1_nextup(v + e);
+                    lo = __builtin_fmaf(wgt[f], (mf >= 0.0f ? dn : up) * mf, lo);
+                    hi = __builtin_fmaf(wgt[f], (mf >= 0.0f ? up : dn) * mf, hi);
+                }
+            }
+            *(float2*)(o + (size_t)c * 2) = make_float2(lo, hi);
+        }
+    }
+}
+// grid = Q, block 256, dynamic LDS = SEL_LDS_BYTES(C) + C bytes
+#define S2_SELECT_LDS_BYTES(C) (SEL_LDS_BYTES(C) + (((size_t)(C) + 15) & ~(size_t)15))
+__global__ void __launch_bounds__(256) mfar_s2_select_kernel(const BoundsParams b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const PruneParams& p = b.pr;
+    const SelLds L = sel_lds(smem, p.C);
+    u64* keys = L.keys;
+    int& n_s = L.misc[0];
+    unsigned char* surv = (unsigned char*)(L.misc + 4);
+    int* wsum = L.red;
+    const int qi = blockIdx.x;
+    const int nc = min(p.n_cand[qi], p.C);
+    const long long* cq = p.cand + (size_t)qi * p.C;
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) surv[c] = 0;
+    for (int m = 0; m < p.n_masks; ++m) {
+        const float2* lu = (const float2*)(b.lbub + (((size_t)m * b.Q + qi) * p.C) * 2);
+        if (threadIdx.x == 0) n_s = 0;
+        __syncthreads();
+        for (int c = threadIdx.x; c < nc; c += blockDim.x) {
+            const long long id = cq[c];
+            if (id < 0) continue;
+            const float lo = lu[c].x;
+            if (lo != lo) continue;                          // NaN: no lower bound (the candidate survives below)
+            keys[atomicAdd(&n_s, 1)] = make_key(lo, (u32)id);
+        }
+        __syncthreads();
+        const int n = n_s;
+        const int mm = block_topk_sorted<16>(keys, n, p.k, L.sel, L.sorted, L.red);
+        const float T = mm == p.k ? key_score(L.sorted[p.k - 1]) : -__builtin_inff();
+        for (int c = threadIdx.x; c < nc; c += blockDim.x) {
+            if (cq[c] < 0 || surv[c]) continue;
+            if (!(lu[c].y < T)) surv[c] = 1;                 // NaN upper ends survive
+        }
+        __syncthreads();
+    }
+    // compaction in candidate order (every thread owns a contiguous run)
+    const int per = (p.C + 255) / 256;
+    const int bb = threadIdx.x * per, e_ = min(bb + per, nc);
+    int mine = 0;
+    for (int i = bb; i < e_; ++i) mine += surv[i] ? 1 : 0;
+    int incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane_id() >= off) incl += v;
+    }
+    if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int ww = 0; ww < (int)(threadIdx.x >> 6); ++ww) wbase += wsum[ww];
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int pos = wbase + incl - mine;
+    long long* out = p.cand2 + (size_t)qi * p.C;
+    int* osrc = p.src2 ? p.src2 + (size_t)qi * p.C : nullptr;
+    for (int i = bb; i < e_; ++i)
         if (surv[i]) {
             if (osrc) osrc[pos] = i;
             out[pos++] = cq[i];

@@ -432,6 +432,10 @@ class MultiFieldIndex:
         return dict(off=[f for f in range(self.n_fields) if (m.value >> f) & 1], n_switched_off=a.value, n_switched_on=b.value,
                     n_probes=c.value, inline_repair=bool(r.value))
 
+    def set_stage2_kernels(self, family: int = 1):
+        """Kernel family of the tail (include/mfar_hip.h): 1 = round 6 (default), 0 = rounds 3-5.  Identical results."""
+        _native.check(_native.lib().mfar_set_stage2_kernels(self._h, int(family)))
+
     def set_tier2(self, mode: int = 1):
         """TIER 2 of the certified screen, the threshold rescan (include/mfar_hip.h): 0 never, 1 auto (armed by failed certificates),
         2 always.  Outputs are bit-identical in every mode."""

@@ -226,6 +226,8 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
     q = (rng.standard_normal((Q, E)) * 0.5 + mu * 2.0).astype(np.float32)
     kind = rng.integers(0, 6)
     eps_mult = 1e9 if rng.random() < 0.15 else 1.0      # forced fail: every certificate fails, the exact pass repairs (auto-off after 12 launches)
+    if rng.random() < 0.15:
+        eps_mult = float(rng.choice([5.0, 40.0, 400.0]))   # ... or many fail with a band tier 2 can still hold (mfar_set_tier2: threshold rescan)
     if kind == 1 and D > 8:          # duplicate group
         rows = rng.choice(D, size=min(D, int(rng.integers(2, 3000))), replace=False)
         slab[rng.integers(0, F), rows] = slab[0, rows[0]]
@@ -249,6 +251,7 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
     ix = idxmod.MultiFieldIndex(D, F, E, device=0, dtype=dtype)
     ix.set_row_mode(int(rng.choice([0, 1, 2, 2])))       # per-row bounds for heavy-tailed fields: never / auto / always
     ix.set_stage2_dump(int(rng.choice([0, 1, 2, 2])))    # the scan's score dump as stage 2's approximate level
+    ix.set_tier2(int(rng.choice([0, 1, 2, 2])))          # tier 2 of the certified screen: never / armed by failures / always
     for f in range(F):
         ix.write_rows(f, 0, slab[f])
     ref = O.bf16_round(slab) if dtype == "bf16" else slab
@@ -330,10 +333,11 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
             print("MISMATCH fused", dict(F=F, D=D, E=E, Q=Q, k=k, seed=seed, n=n, eps_mult=eps_mult), flush=True)
     st = ix.screen_stats()
     off = ix.auto_off_info()["off"]
+    t2 = ix.tier2_stats() if dtype == "f32" else None
     ix.close()
     if verbose or not ok:
         print(f"{n + 1:4d} ok={ok} F={F} D={D} E={E} Q={Q} k={k} sent={int(sentinel)} mean={mean} {dtype} kind={int(kind)} eps_mult={eps_mult:g} upd={n_updates} "
-              f"checked={st.get('n_checked')} failed={st.get('n_failed')} off={off} pipe={pipe_note} sweep={sweep_note} shards={shard_note}", flush=True)
+              f"checked={st.get('n_checked')} failed={st.get('n_failed')} t2={(str(t2['lists']) + '/' + str(t2['passed_on_to_exact'])) if t2 else '-'} off={off} pipe={pipe_note} sweep={sweep_note} shards={shard_note}", flush=True)
     return ok
 
 

@@ -18,6 +18,18 @@ def idxmod():
     return index
 
 
+# Every test of this file runs with BOTH kernel families of the tail (include/mfar_hip.h mfar_set_stage2_kernels): round 6's gate / front /
+# bounds / select kernels (default) and the one-workgroup-per-query kernels of rounds 3-5.  Same bits, whichever runs.
+_FAMILY = [1]
+
+
+@pytest.fixture(autouse=True, params=[1, 0], ids=["round6_kernels", "round3_5_kernels"])
+def _kernel_family(request):
+    _FAMILY[0] = request.param
+    yield
+    _FAMILY[0] = 1
+
+
 def _mk(rng, F, D, E, Q, mean=0.3, sigma=0.5, dup=0):
     mu = rng.standard_normal(E).astype(np.float32)
     mu /= np.linalg.norm(mu)
@@ -37,6 +49,7 @@ def _load(idxmod, slab, row_offset=0, screen=2):
     for f in range(F):
         ix.write_rows(f, 0, slab[f])
     ix.set_screen(screen)
+    ix.set_stage2_kernels(_FAMILY[0])
     return ix
 
 
