@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--corpus", choices=["plain", "structured", "clustered"], default="plain",
                     help="structured: realistic duplicate / norm structure in three of the fields; clustered: every field made of clusters of "
                          "~235 near-duplicate, non-identical rows -- the certified screen's worst case (mfar/synth.py)")
+    ap.add_argument("--mu-scale", type=float, default=1.0, help="synthetic corpus: size of the common component of rows and queries (2.7 = the narrow "
+                                                                "cone mean-pooled transformer outputs sit in: cosine 0.86 between rows)")
     ap.add_argument("--cluster-noise", type=float, default=1e-4, help="--corpus clustered: spread of a cluster's members relative to the field's spread")
     ap.add_argument("--empty-frac", type=float, default=0.08,
                     help="share of (document, field) pairs that hold the field's empty-text vector (real STaRK fields are sparse; "
@@ -289,7 +291,8 @@ def main():
     t_build0 = time.time()
     corpus = synth.SyntheticCorpus(D, F, E, n_queries=n_q_total, seed=0xDEADBEEF, device=str(dev),
                                    structured=(args.corpus == "structured"), empty_frac=args.empty_frac,
-                                   field_kinds=(["clustered"] * F if args.corpus == "clustered" else None), cluster_noise=args.cluster_noise)
+                                   field_kinds=(["clustered"] * F if args.corpus == "clustered" else None), cluster_noise=args.cluster_noise,
+                                   mu_scale=args.mu_scale)
     W = corpus.W
     mask = torch.ones(F, device=dev)
     torch.cuda.synchronize()

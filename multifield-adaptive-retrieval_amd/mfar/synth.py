@@ -40,7 +40,7 @@ CHUNK = 32768  # rows per generation chunk (aligned to global row numbers)
 class SyntheticCorpus:
     def __init__(self, n_docs: int, n_fields: int, dim: int, n_queries: int = 4096, seed: int = 0xDEADBEEF,
                  device: str = "cuda:0", empty_frac: float = 0.08, sigma: float = 0.04, pull: float = 0.8,
-                 structured: bool = False, field_kinds=None, cluster_noise: float = 1e-4):
+                 structured: bool = False, field_kinds=None, cluster_noise: float = 1e-4, mu_scale: float = 1.0):
         self.D, self.F, self.E, self.NQ = int(n_docs), int(n_fields), int(dim), int(n_queries)
         self.seed, self.device = int(seed), torch.device(device)
         self.empty_frac, self.sigma, self.pull = float(empty_frac), float(sigma), float(pull)
@@ -48,7 +48,12 @@ class SyntheticCorpus:
         g = torch.Generator(device="cpu")
         g.manual_seed(self.seed)
         mu = torch.randn(self.E, generator=g)
-        self.mu = (mu / mu.norm()).to(self.device)
+        # mu_scale > 1: a NARROW CONE -- every row and query = a large common component + the same spread (cosine between two rows of a
+        # field = s^2 / (s^2 + sigma^2 E): 0.45 at s = 1, 0.86 at s = 2.7 = what the BERT-base-shaped encoder's mean-pooled outputs measure,
+        # tools/encode_bench.py `vector_geometry`).  Scores then carry a large common offset: the certificate's fp32-accumulation terms grow
+        # with it while the spread that separates the k-th from the k'-th row does not.
+        self.mu_scale = float(mu_scale)
+        self.mu = (mu / mu.norm() * self.mu_scale).to(self.device)
         self.q_all = (self.mu.cpu() + self.sigma * torch.randn(self.NQ, self.E, generator=g)).to(self.device).contiguous()
         self.W = (0.05 * torch.randn(self.E, self.F, generator=g)).to(self.device).contiguous()
         self.empty_vec = (self.mu.cpu() * 0.6 + 0.02 * torch.randn(self.F, self.E, generator=g)).to(self.device)

@@ -161,11 +161,11 @@ def screen_probe(module, st, warm_passes=10, timed_passes=10):
 
     mode0, _ = ix.screen_setting
     ix.set_screen(1)
-    s0 = ix.screen_stats()
+    s0, t20 = ix.screen_stats(), ix.tier2_stats()
     t_learn, _, red_learn = serve(warm_passes, False)
-    s1, ao1 = ix.screen_stats(), ix.auto_off_info()
+    s1, ao1, t21 = ix.screen_stats(), ix.auto_off_info(), ix.tier2_stats()
     t_on, res_on, red_on = serve(timed_passes, True)
-    s2, ao2, rm = ix.screen_stats(), ix.auto_off_info(), ix.row_mode_info()
+    s2, ao2, rm, t22 = ix.screen_stats(), ix.auto_off_info(), ix.row_mode_info(), ix.tier2_stats()
     kern = ix.last_stage1_kernel()
     uniq = [ix.screen_field_info(f)[0] for f in range(ix.n_fields)] if s2["built"] else None
     s2stats = ix.stage2_stats()
@@ -182,8 +182,11 @@ def screen_probe(module, st, warm_passes=10, timed_passes=10):
     out = {
         "queries": int(nq), "docs": int(ix.n_rows), "fields": int(F), "screened": bool(s2["built"]), "scan_kernel_steady": kern,
         "learning": {"passes": warm_passes, "lists_checked": s1["n_checked"] - s0["n_checked"], "lists_redone_exactly": s1["n_failed"] - s0["n_failed"],
+                     "lists_finished_by_tier2": (t21["lists"] - t20["lists"]) - (t21["passed_on_to_exact"] - t20["passed_on_to_exact"]),
                      "launches_redone": red_learn, "queries_per_s": warm_passes * nq / t_learn, "fields_switched_off": len(ao1["off"])},
         "steady": {"passes": timed_passes, "lists_checked": s2["n_checked"] - s1["n_checked"], "lists_redone_exactly": s2["n_failed"] - s1["n_failed"],
+                   "lists_finished_by_tier2": (t22["lists"] - t21["lists"]) - (t22["passed_on_to_exact"] - t21["passed_on_to_exact"]),
+                   "tier2_armed": t22["armed"],
                    "launches_redone": red_on, "queries_per_s": timed_passes * nq / t_on,
                    "fields_switched_off": len(ao2["off"]), "inline_repair": bool(ao2["inline_repair"]),
                    "row_mode_fields_eligible": len(rm["eligible"]), "row_mode_fields_active": len(rm["active"])},
@@ -198,6 +201,11 @@ def screen_probe(module, st, warm_passes=10, timed_passes=10):
     }
     denom = max(1, out["steady"]["lists_checked"])
     out["steady"]["certified_fraction"] = 1.0 - out["steady"]["lists_redone_exactly"] / denom if out["steady"]["lists_checked"] else None
+    out["steady"]["certified_by_the_first_certificate"] = 1.0 - (t22["lists"] - t21["lists"] + out["steady"]["lists_redone_exactly"]) / denom \
+        if out["steady"]["lists_checked"] else None
+    out["what"] = ("lists_checked = (query, field) lists the screen answered; lists_redone_exactly = of those, sent to the exact fp32 pass; "
+                   "lists_finished_by_tier2 = first certificate failed, finished by the threshold rescan (include/mfar_hip.h mfar_set_tier2); "
+                   "certified_fraction = 1 - redone / checked")
     return out
 
 
