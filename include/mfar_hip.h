@@ -397,7 +397,9 @@ int mfar_set_auto_off(mfar_index* idx, int mode, int off_fails, int probe_every)
  * rows and that FIXED threshold per list, gathers every row above it from the fp32 slab (a few hundred per list on encoder-produced and
  * near-duplicate corpora: profiles/r06_tier2_population.txt), and takes the exact top-k of that complete set -- no second proof needed.
  * Lists that need more than 2048 candidates (or overflow a chunk list) go to the exact pass as before; AUTO-OFF and the inline-repair
- * decision see the flags AFTER tier 2.  fp32 indexes, all-fields searches.
+ * decision see the flags AFTER tier 2.  All-fields searches; fp32 indexes, and bf16 indexes (the rescan reads the bf16 slab itself, the
+ * candidates are re-scored from the row-major companion with the natural-order chain: the lists tier 2 finishes carry the bits of the
+ * "bf16 contract" above, and the ~30x chain pass is left to the lists that overflow).
  *   mode   0 = never, 1 = auto (default; environment MFAR_SCREEN_TIER2): its kernels follow a certificate only while a launch of the
  *          last 256 had a failed first certificate -- a corpus whose lists all certify never pays their (idle) launches; 2 = always.
  * mfar_tier2_stats synchronises the device: whether tier 2 is armed now; lists handed to it / lists it had to pass on to the exact pass

@@ -1571,8 +1571,9 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
             sl.dump_on = false;
         }
         if (!sl.dump_on && sl.dump.p && !dump_wanted(idx, k)) sl.dump.release();      // the shape no longer wants it (rows rewritten, mode changed)
-        // TIER 2 behind this batch's certificate (all-fields passes of an fp32 index; armed by the policy: mfar_policy.h)
-        sl.t2 = screened && !bf16 && f0 == 0 && nf == idx->F && (idx->tier2_mode == 2 || (idx->tier2_mode == 1 && idx->pol.t2_armed));
+        // TIER 2 behind this batch's certificate (all-fields passes; armed by the policy: mfar_policy.h).  A bf16 index rescans its own slab
+        // and re-scores from the row-major companion: the lists tier 2 finishes carry the natural-order chain's bits like the certified ones
+        sl.t2 = screened && f0 == 0 && nf == idx->F && (idx->tier2_mode == 2 || (idx->tier2_mode == 1 && idx->pol.t2_armed));
         if (sl.t2 && (sl.tau2.ensure((size_t)F * 128 * 4) != MFAR_OK || sl.lfail.ensure((size_t)128 * F * 4) != MFAR_OK || sl.t2cnt.ensure((size_t)128 * F * 4) != MFAR_OK ||
                       sl.t2cand.ensure((size_t)128 * F * T2_CAP * 8, true) != MFAR_OK || sl.t2sx.ensure((size_t)128 * F * T2_CAP * 4, true) != MFAR_OK)) {
             (void)hipGetLastError();      // optional: without its scratch the batch keeps the exact pass as its only fall-back
@@ -1760,7 +1761,8 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     cp.qw = qw;
     cp.skip_mask = sl.skip_mask;
     cp.quiet_mask = sl.exact_mask & ~sl.skip_mask;        // a probe launch: switched-off fields that were screened anyway
-    if (sl.t2) {
+    const bool t2_run = sl.t2 && (!bf16 || rows16);       // (a bf16 index re-scores tier 2's candidates from its row-major companion)
+    if (t2_run) {
         cp.tau2 = sl.tau2.as<float>();
         cp.lfail = sl.lfail.as<int>();
     }
@@ -1782,12 +1784,16 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
                         f0 + i % nf, h[8 * i + 1], h[8 * i + 2], h[8 * i + 3], h[8 * i + 4], h[8 * i + 5], h[8 * i + 6], h[8 * i + 7]);
         dbg.release();
     }
-    if (sl.t2) {
+    if (t2_run) {
         // TIER 2 (mfar_screen.h): rescan of the fields that hold failed lists with their fixed thresholds -> the complete candidate sets ->
         // exact scores -> the certify kernel again, on those lists only.  Every kernel is idle when nothing failed.
-        RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, S1_SCAN, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
-                           sl.tau2.as<float>(), fflags + SCREEN_T2_FIELDS, false, so, st, sl.skip_mask, false, true));
-        const S1Geom& g2 = idx->geom_screen;
+        if (bf16)
+            RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, S1_SCAN, bkind, idx->slab, sl.qt16.p, qt_n, kp, -INFINITY, sl.tau2.as<float>(),
+                               fflags + SCREEN_T2_FIELDS, false, so, st, sl.skip_mask, false, true));
+        else
+            RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, S1_SCAN, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
+                               sl.tau2.as<float>(), fflags + SCREEN_T2_FIELDS, false, so, st, sl.skip_mask, false, true));
+        const S1Geom& g2 = bf16 ? idx->geom_docs : idx->geom_screen;
         const S1Table& tb2 = qw == 128 ? (sl.skip_mask ? g2.all_w_skip : g2.all_w) : (sl.skip_mask ? g2.all_skip : g2.all);
         T2CollectParams tc = {};
         tc.lists = sl.lists.as<uint2>();
@@ -1808,7 +1814,8 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         s2.C = T2_CAP;
         s2.n_cand_pf = sl.t2cnt.as<int>();
         s2.pre_sc = nullptr;
-        mfar_score_rows_kernel<SRC_F32><<<dim3((unsigned)((T2_CAP * nf) / SCF_THREADS), qt_n), dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(s2);
+        if (bf16) mfar_score_rows_kernel<SRC_BF16G><<<dim3((unsigned)((T2_CAP * nf) / SCF_THREADS), qt_n), dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(s2);
+        else mfar_score_rows_kernel<SRC_F32><<<dim3((unsigned)((T2_CAP * nf) / SCF_THREADS), qt_n), dim3(SCF_THREADS), SCORE_F32_LDS_BYTES(idx->E), st>>>(s2);
         HIPCHK(hipGetLastError());
         T2SelectParams ts = {};
         ts.cand = sl.t2cand.as<long long>();

@@ -333,7 +333,7 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
             print("MISMATCH fused", dict(F=F, D=D, E=E, Q=Q, k=k, seed=seed, n=n, eps_mult=eps_mult), flush=True)
     st = ix.screen_stats()
     off = ix.auto_off_info()["off"]
-    t2 = ix.tier2_stats() if dtype == "f32" else None
+    t2 = ix.tier2_stats()
     ix.close()
     if verbose or not ok:
         print(f"{n + 1:4d} ok={ok} F={F} D={D} E={E} Q={Q} k={k} sent={int(sentinel)} mean={mean} {dtype} kind={int(kind)} eps_mult={eps_mult:g} upd={n_updates} "

@@ -172,3 +172,34 @@ def test_certified_screen_on_encoder_produced_vectors_amazon_shaped():
     assert got["geometry"] > 0.9                             # the queries do sit in a narrow cone
     assert got["tier2"]["lists"] > 0, got                    # ... the first certificate does fail on such vectors, and tier 2 takes the lists
     assert got["tier2"]["passed_on_to_exact"] <= got["tier2"]["lists"] // 10, got
+
+
+def test_tier2_on_a_bf16_index_keeps_the_chain_bits():
+    """A bf16 index whose certificates fail (clusters that survive the bf16 rounding as distinct rows): until round 6 every failed list cost
+    the exhaustive VALU chain pass (~30x a screened scan of its field); tier 2 rescans the slab itself, re-scores its candidates from the
+    row-major companion with the natural-order chain and finishes the lists with exactly the bits the contract demands."""
+    import torch
+    from mfar.data import index as idxmod
+    D, F, E, Q = 50_000, 3, 192, 100
+    cp, slab = _clustered(D, F, E, 2 * Q, 2e-2)
+    ix = cp.build_index(idxmod, dtype="bf16")
+    ix.set_auto_off(0)
+    ref = O.bf16_round(slab)
+    q = cp.queries(0, Q)
+    Wn = cp.W.cpu().numpy()
+    with O.chain("natural"):
+        o = O.c_two_stage(ref, q.cpu().numpy(), Wn, None)
+    ix.set_tier2(0)
+    r0 = ix.search(q, cp.W, None, return_fields=True)
+    st0 = ix.screen_stats()
+    assert _same(r0, o)
+    assert st0["n_failed"] > Q // 2, st0                      # the corpus defeats the first certificate (the chain pass repaired those lists)
+    ix.set_tier2(2)
+    r2 = ix.search(q, cp.W, None, return_fields=True)
+    st2, t2 = ix.screen_stats(), ix.tier2_stats()
+    assert _same(r2, o)
+    assert t2["lists"] > Q // 2 and t2["passed_on_to_exact"] <= t2["lists"] // 10, t2
+    assert st2["n_failed"] - st0["n_failed"] == t2["passed_on_to_exact"], (st0, st2, t2)
+    r64 = ix.search(q[:50], cp.W, None, return_fields=True)   # the 64-column pass (two bf16 query terms)
+    assert _same(r64, {k: v[:50] for k, v in o.items()})
+    ix.close()
