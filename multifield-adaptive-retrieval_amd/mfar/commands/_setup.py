@@ -31,6 +31,13 @@ def _local_device() -> int:
     return 0 if os.environ.get("MFAR_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def encode_precision_for(precision: str) -> str:
+    """The CLI's `precision` flag (reference train.py:51, default "16-mixed") -> precision of the corpus-encode forwards: the run's own
+    reduced precision where it asked for one, fp32 for "32" (RetrievalTrainingModule.encode_precision)."""
+    p = str(precision)
+    return "bf16" if p.startswith("bf16") else ("fp16" if p.startswith("16") else "fp32")
+
+
 def build(flags: dict, freeze_encoder: bool = False) -> SimpleNamespace:
     """-> namespace(field_info, tokenizer, encoder, corpus, vectors_dict, indices_dict, data_module, queries, corpus_dir,
     device).  `flags` uses the CLI names (dataset_name, data / queries / corpus, temp_dir, model_name, ...)."""

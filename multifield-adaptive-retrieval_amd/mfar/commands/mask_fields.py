@@ -43,6 +43,7 @@ def main(
         dev_qrels_path=st.dev_qrels, additional_qrels_path=st.additional_qrels, field_info=field_info, out_dir=out,
         dev_batch_size=dev_batch_size)
     module.encoder.to(st.device)
+    module.encode_precision = _setup.encode_precision_for(precision)
     print(f"Starting re-testing of {checkpoint_path}: {time.strftime('%Y-%m-%d %H:%M:%S')}")
 
     # the evaluation sequence of mask_fields.py:143-170: baseline, every field, all sparse, all dense, every field NAME

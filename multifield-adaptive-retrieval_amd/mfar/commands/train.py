@@ -282,6 +282,7 @@ def main(
         indices_dict=st.indices_dict, vectors_dict=st.vectors_dict, trec_val_freq=trec_val_freq, freeze_encoder=freeze_encoder,
         query_cond=query_cond, prefix=prefix, use_batchnorm=use_batchnorm)
     module.to(device)
+    module.encode_precision = _setup.encode_precision_for(precision)
     sparse_indices = {k: st.indices_dict[k] for k, f in field_info.items() if f.field_type == FieldType.SPARSE}
     loss_fn = HybridContrastiveLoss(temperature=temperature, mixture_of_fields_layer=module.mixture_of_fields_layer,
                                     sparse_indices_dict=sparse_indices, num_fields=len(field_info), use_batchnorm=use_batchnorm).to(device)

@@ -148,6 +148,10 @@ class RetrievalTrainingModule(torch.nn.Module):
         self.additional_qres_output: Optional[TextIO] = None
         self._corpus_encoded = False
         self._searcher = None
+        # precision of the CORPUS encode forwards: "fp32" | "fp16" | "bf16" (rows written to the slab are fp32 either way).  A module built
+        # directly encodes in fp32; the CLIs set it from their `precision` flag (commands/_setup.py `encode_precision_for`): the reference's
+        # default "16-mixed" (train.py:51) -> fp16 autocast.  MFAR_ENCODE_AUTOCAST=fp32|fp16|bf16 overrides either.
+        self.encode_precision = "fp32"
         # `hybrid_contrastive_loss_fn.bn.*` of a use_batchnorm run: trained by commands/train.py's loss object, unused at
         # evaluation (contrastive.py:685-694 applies no BatchNorm), carried through checkpoints under the reference's keys
         self.bn_state: Dict[str, torch.Tensor] = {}
@@ -213,10 +217,14 @@ class RetrievalTrainingModule(torch.nn.Module):
         # always dev_batch_size).  Lengths ascend, so the last text of a batch is its longest.
         max_len = int(self.encoder.get_max_seq_length())
         budget = bs * max_len if os.environ.get("MFAR_ENCODE_TOKEN_BUDGET", "1") != "0" else 0
-        # MFAR_ENCODE_AUTOCAST=bf16|fp16: run the corpus-encode forwards under autocast ("bf16 encoder").  Off by
-        # default: the reference encodes the corpus in fp32 (its precision plugin wraps the steps, not on_test_epoch_start);
-        # the rows written to the slab are fp32 either way.
-        ac = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(os.environ.get("MFAR_ENCODE_AUTOCAST", "").lower())
+        # Precision of the corpus-encode forwards: `self.encode_precision`, overridden by MFAR_ENCODE_AUTOCAST=fp32|fp16|bf16.
+        # The reference encodes the corpus outside its precision plugin (which wraps the steps, not on_test_epoch_start) but with
+        # torch.set_float32_matmul_precision("high") (train.py:67, mask_fields.py:52): fp32 matmuls may run with 10-bit-mantissa inputs on
+        # its hardware.  gfx950 has no such fp32 mode; fp16 autocast IS that precision here (11-bit significand into fp32 accumulators):
+        # measured on the BERT-base-shaped encoder, rows differ by 6e-4 of the largest value (bf16: 6e-3) at 3.1x the fp32 rate
+        # (bench.py encode_pipeline).  The rows written to the slab are fp32 either way.
+        mode = (os.environ.get("MFAR_ENCODE_AUTOCAST", "") or self.encode_precision or "fp32").lower()
+        ac = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(mode)
         if dense and self._prefetch_backend() is not None:
             self._encode_fields_prefetched(dense, prepare, bs, budget, max_len, ac)
             dense = []                                       # (nothing left for the generic loop below)

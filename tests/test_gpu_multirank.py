@@ -40,6 +40,22 @@ def test_ranks_on_one_gpu_match_single_rank(world, dtype):
     assert two["ids_checksum"] == one["ids_checksum"]          # same top-100 ids for every query of every step
 
 
+def test_tier2_in_the_row_sharded_exchange():
+    """Round 6's tier 2 (threshold rescan of lists whose first certificate failed) inside the multi-rank product path: a CLUSTERED corpus
+    over two row shards -- every rank's certificates fail, every rank's tier 2 finishes its lists before the lists-first exchange -- returns
+    the single-rank run's ids, and rank 0's line names the tier-2 work and both ranks."""
+    extra = ["--corpus", "clustered", "--cluster-noise", "1e-2", "--steps", "12"]
+    env = {"MFAR_BENCH_DUMP_IDS": "1", "MFAR_SCREEN_TIER2": "2"}
+    one = _bench(1, env, extra_args=extra)
+    two = _bench(2, dict(env, MFAR_BENCH_BACKEND="gloo", MFAR_BENCH_SHARE_GPU="1"), launcher=False, extra_args=extra)
+    assert two["n_gpus"] == 2 and two["rccl"]["world_size"] == 2 and two["config"]["row_shards"] == 2
+    assert two["ids_checksum"] == one["ids_checksum"]
+    for d in (one, two):
+        t2 = d["adaptive"]["tier2"]
+        assert t2["lists"] > 0 and t2["passed_on_to_exact"] <= t2["lists"] // 10, t2
+        assert d["adaptive"]["off"] == [], d["adaptive"]
+
+
 def test_bench_starts_its_own_ranks_and_proves_them():
     """`python bench.py --gpus 2` with NO launcher (the driver's command shape): the script spawns its two ranks itself, rank 0's
     line is relayed, it names both ranks (all-reduce of ones == 2, per-rank rows) and the ids equal the single-rank run's."""

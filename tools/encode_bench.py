@@ -259,7 +259,7 @@ def run(n_docs=50000, n_queries=256, model="random-init:768x12", sweep=True, qui
                 n_tok += int(sum(lens))
 
             def encode(autocast):
-                os.environ["MFAR_ENCODE_AUTOCAST"] = autocast
+                os.environ["MFAR_ENCODE_AUTOCAST"] = autocast or "fp32"
                 module.mark_encoder_updated()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
