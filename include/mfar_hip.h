@@ -403,10 +403,29 @@ int mfar_set_auto_off(mfar_index* idx, int mode, int off_fails, int probe_every)
  *   mode   0 = never, 1 = auto (default; environment MFAR_SCREEN_TIER2): its kernels follow a certificate only while a launch of the
  *          last 256 had a failed first certificate -- a corpus whose lists all certify never pays their (idle) launches; 2 = always.
  * mfar_tier2_stats synchronises the device: whether tier 2 is armed now; lists handed to it / lists it had to pass on to the exact pass
- * since the handle was created.  Any pointer may be NULL.
+ * since the handle was created; causes [4] = why: a chunk list of the (re)scan reached its depth, more than 8192 rows above the threshold,
+ * more than 2048 candidates in the band, ties across the cut.  Any pointer may be NULL.
  */
 int mfar_set_tier2(mfar_index* idx, int mode);
-int mfar_tier2_stats(mfar_index* idx, int* armed, int64_t* n_lists, int64_t* n_passed_on);
+/*
+ * DEEP SCAN: tier 2 without the first attempt, for fields whose first certificates keep failing (no reference counterpart; outputs
+ * bit-identical in every mode).  Such a field pays its screened scan twice (first attempt + rescan).  Once the library has seen a field fail
+ * its first certificate in 8 of its last 16 launches it stops certifying it: the ONE scan of the field runs with a complete-set threshold
+ * taken from the sample pass -- T = (k-th largest sampled score) - 2 eps: k rows score at least the k-th sampled score, so the true k-th best
+ * exact score is at least that minus eps and every row of the exact top-k scores approximately >= T -- its chunk lists then hold every
+ * such row (a few thousand), mfar_t2_collect_kernel narrows them to the band around the k-th best approximate score of that complete set
+ * (a few hundred), and tier 2's back half (exact re-scoring, selection, expansion to documents) writes the lists.  Lists that overflow go
+ * to the exact pass -- and their field is demoted at once (auto mode); after 1024 launches a deep field is evaluated afresh.  Needs tier 2
+ * (mfar_set_tier2 != 0), an fp32 index, and a shape whose scan runs the light sample pass.
+ * OFF by default: measured it is 11 % slower than certificates on rows that certify, and on clustered rows the
+ * sample-derived threshold is too loose -- 5 % of the lists hold more than 8192 rows above it, and ONE overflowing list costs its field
+ * the exact pass -- so the two-scan tier 2 (26 k q/s on the hostile corpus) beats it (16 k).  Kept as a measured, tested alternative.
+ *   mode   0 = never (default; environment MFAR_SCREEN_DEEP), 1 = auto, 2 = every field, always (a test / experiment setting).
+ * mfar_deep_scan_info: bit f of deep_fields = field f runs as a deep field now; fields switched to it so far.
+ */
+int mfar_set_deep_scan(mfar_index* idx, int mode);
+int mfar_deep_scan_info(mfar_index* idx, uint32_t* deep_fields, int64_t* n_switched);
+int mfar_tier2_stats(mfar_index* idx, int* armed, int64_t* n_lists, int64_t* n_passed_on, int64_t* causes);
 int mfar_auto_off_info(mfar_index* idx, uint32_t* off_fields, int64_t* n_switched_off, int64_t* n_switched_on, int64_t* n_probes,
                        int* inline_repair);
 int mfar_row_mode_activate(mfar_index* idx);

@@ -136,6 +136,9 @@ struct mfar_index {
         DevBuf chain;                                                   // bf16 index: scores of the exhaustive chain pass (mfar_exact16.h), [CHAIN_QB][rows]
         DevBuf tau2, lfail, t2cand, t2cnt, t2sx;                        // TIER 2 (mfar_screen.h): thresholds [F, qw], per-list flags, candidate sets [qw, F, T2_CAP]
         bool t2 = false;                                                // this batch runs tier 2 behind its certificate (latched by the begin phase)
+        u32 deep_mask = 0;                                              // DEEP SCAN fields of this batch (latched by the begin phase; mfar_screen.h)
+        u32 fb_deep = 0;                                                // ... as reported with the batch's feedback
+        DevBuf deepinfo;                                                // [F, qw] float4 {band, eps, exact 0} in scan units (mfar_sample_tau_kernel)
         // feedback: the batch's certificate flags, copied to pinned host memory behind the certify kernel and read by a LATER call once
         // the event has completed (never waited for)
         int* fb_host = nullptr;                                         // [SCREEN_FLAGS] pinned
@@ -179,6 +182,8 @@ struct mfar_index {
     u32 row_eligible = 0;         // fields with heavy-tailed row norms (host copy of ScreenField::row_mode)
     int row_mode_setting = 1;     // 0 never, 1 auto: eligible fields are activated once a certificate has failed (mfar_row_mode_activate; the
                                   // pipelined searcher calls it), 2 always.  MFAR_SCREEN_ROW_MODE
+    int deep_mode = 0;            // DEEP SCAN of fields whose first certificates keep failing (mfar_screen.h): 0 never, 1 auto (policy), 2 every
+                                  // field always (tests / experiments).  MFAR_SCREEN_DEEP
     int tier2_mode = 1;           // TIER 2 of the certified screen (mfar_screen.h "threshold rescan"): 0 never, 1 auto (its kernels are
                                   // enqueued while the policy has seen a failed certificate recently), 2 always.  MFAR_SCREEN_TIER2
     int dump_mode = 1;            // 0 never, 1 when it moves fewer bytes than the row gathers (dump_wanted), 2 whenever possible
@@ -241,6 +246,7 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_score_rows_kernel<SRC_F16G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_score_rows_kernel<SRC_BF16G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_s2_prune_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_t2_collect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // (these two also hold a little static LDS: the dynamic part must leave room for it)
     HIPCHK(hipFuncSetAttribute((const void*)mfar_s2_gate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S2_DYN_LDS_MAX));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_s2_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S2_DYN_LDS_MAX));
@@ -352,6 +358,8 @@ extern "C" int mfar_index_create(mfar_index** out, int device, int64_t n_rows_lo
     if (const char* e = getenv("MFAR_SCREEN_ROW_MODE")) idx->row_mode_setting = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("MFAR_SCREEN_AUTO_OFF")) idx->pol.set_mode(atoi(e) != 0 ? 1 : 0);
     if (const char* e = getenv("MFAR_SCREEN_TIER2")) idx->tier2_mode = std::max(0, std::min(2, atoi(e)));
+    if (const char* e = getenv("MFAR_SCREEN_DEEP")) idx->deep_mode = std::max(0, std::min(2, atoi(e)));
+    idx->pol.deep_mode = idx->deep_mode ? 1 : 0;
     idx->s2_fused = s2_fused_default();
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) idx->n_cu = prop.multiProcessorCount;
@@ -412,7 +420,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
         if (sl.fb_ev) (void)hipEventDestroy(sl.fb_ev);
         sl.off_flags.release();
         sl.chain.release();
-        for (DevBuf* b : {&sl.tau2, &sl.lfail, &sl.t2cand, &sl.t2cnt, &sl.t2sx}) b->release();
+        for (DevBuf* b : {&sl.tau2, &sl.lfail, &sl.t2cand, &sl.t2cnt, &sl.t2sx, &sl.deepinfo}) b->release();
         DevBuf* sb[] = {&sl.qt, &sl.lists, &sl.list_cnt, &sl.gtau, &sl.samp, &sl.lists2, &sl.list_cnt2, &sl.unit_ctr, &sl.dump, &sl.arow, &sl.eps_cert, &sl.dinv, &sl.dstep, &sl.eps_dump, &sl.darel, &sl.qt16, &sl.qinfo, &sl.eps, &sl.base, &sl.fail, &sl.sids,
                         &sl.ssc, &sl.scnt, &sl.sx};
         for (DevBuf* b : sb) b->release();
@@ -847,7 +855,7 @@ enum { S1_PREPARE = 1, S1_SCAN = 2, S1_FINISH = 4, S1_CERTIFY = 8, S1_ALL = 15 }
 //              holds the fixed thresholds -- and no merge: mfar_t2_collect_kernel reads the chunk lists
 static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, int f0, int nf, int phases, int kind, const void* slab,
                        const void* qt, int qt_n, int k, float tau0, const float* tau_base, const int* only_failed, bool record,
-                       const S1Out& o, hipStream_t st, u32 skip = 0, bool force_sample = false, bool t2 = false) {
+                       const S1Out& o, hipStream_t st, u32 skip = 0, bool force_sample = false, bool t2 = false, const S1DeepDev* deep = nullptr) {
     const int qw = s1_is_wide(kind) ? 128 : 64;   // query columns of the pass: stride of every per-query table below
     // a repair pass (only_failed) uses the finely cut table as well: the workgroups of the fields that did not fail exit at once,
     // and a failed field is then scanned by the whole GPU instead of by its share of one wave (one failed field of eight at 1 M
@@ -914,7 +922,7 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
     m.qw = qw;
     m.cnt_out = nullptr;
     m.only_failed = only_failed;
-    m.skip_mask = skip;
+    m.skip_mask = skip;      // (+ the DEEP SCAN fields below: their chunk lists go to tier 2's collect kernel unmerged)
     // one merge launch: `n_lists` = most lists a workgroup of it merges, grid = (query, list owner) pairs
     auto launch_merge = [&](const MergeParams& mp, int n_lists, int owners) -> int {
         const int n_keys = n_lists * k;
@@ -946,6 +954,12 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
                             !(p.dbg & 2) && (!repair || idx->repair_sample || force_sample) && !t2;
     const bool light_sample = use_sample && 2 * tb.samp_stride <= 4096;
     p.sample_tiles = light_sample ? tb.sample_tiles : 1;
+    // DEEP SCAN needs the light sample pass (its thresholds come from the published sample values): without one the batch has no deep field
+    // (the same decision in every phase: it follows from the table alone)
+    S1DeepDev dd = {};
+    if (deep && light_sample && !repair) dd = *deep;
+    else if (deep) sl.deep_mask = 0;
+    m.skip_mask |= dd.mask;
     if (light_sample) {
         // every wave publishes the 2 best scores per query of its 64 sampled rows; tau = k-th largest of those
         if (phases & S1_PREPARE) {
@@ -956,10 +970,10 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
             RETCHK(launch_s1(kind, true, grid, (unsigned)(idx->wgs_per_cu * idx->n_cu), st, ps));
             const dim3 tg((qw * nf + 3) / 4), tb_(256);
             const int* sn = tb.d_samp_n.as<int>();
-            if (2 * tb.samp_stride <= 512) mfar_sample_tau_kernel<8><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>(), qw);
-            else if (2 * tb.samp_stride <= 1024) mfar_sample_tau_kernel<16><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>(), qw);
-            else if (2 * tb.samp_stride <= 2048) mfar_sample_tau_kernel<32><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>(), qw);
-            else mfar_sample_tau_kernel<64><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>(), qw);
+            if (2 * tb.samp_stride <= 512) mfar_sample_tau_kernel<8><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>(), qw, dd);
+            else if (2 * tb.samp_stride <= 1024) mfar_sample_tau_kernel<16><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>(), qw, dd);
+            else if (2 * tb.samp_stride <= 2048) mfar_sample_tau_kernel<32><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>(), qw, dd);
+            else mfar_sample_tau_kernel<64><<<tg, tb_, 0, st>>>(ps.samp_out, sn, tb.samp_stride, f0, nf, k, p.tau0, tau_base, sl.gtau.as<float>(), qw, dd);
             HIPCHK(hipGetLastError());
         }
         p.gtau = sl.gtau.as<float>();
@@ -1523,6 +1537,7 @@ static void consume_feedback(mfar_index* idx) {
         const bool failed = idx->pol.feed(idx->F, h, h + MFAR_MAX_FIELDS + 2, h[MFAR_MAX_FIELDS], sl.fb_screened, sl.fb_probed, idx->dtype == MFAR_DTYPE_BF16,
                                           h[SCREEN_FLAG_T1]);
         if ((failed || h[SCREEN_FLAG_T1]) && idx->row_mode_setting == 1) idx->row_mask = idx->row_eligible;       // ROW MODE for heavy-tailed fields (mfar_screen.h)
+        idx->pol.feed_deep(idx->F, h + SCREEN_T2_FIELDS, h, sl.fb_screened & ~sl.fb_deep, sl.fb_deep);
     }
 }
 // behind the certify kernel of a batch: its flags -> pinned host memory, event behind the copy
@@ -1573,12 +1588,24 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         if (!sl.dump_on && sl.dump.p && !dump_wanted(idx, k)) sl.dump.release();      // the shape no longer wants it (rows rewritten, mode changed)
         // TIER 2 behind this batch's certificate (all-fields passes; armed by the policy: mfar_policy.h).  A bf16 index rescans its own slab
         // and re-scores from the row-major companion: the lists tier 2 finishes carry the natural-order chain's bits like the certified ones
-        sl.t2 = screened && f0 == 0 && nf == idx->F && (idx->tier2_mode == 2 || (idx->tier2_mode == 1 && idx->pol.t2_armed));
+        sl.t2 = screened && f0 == 0 && nf == idx->F && (idx->tier2_mode == 2 || (idx->tier2_mode == 1 && idx->pol.t2_armed) || (idx->tier2_mode && idx->deep_mode == 2));
         if (sl.t2 && (sl.tau2.ensure((size_t)F * 128 * 4) != MFAR_OK || sl.lfail.ensure((size_t)128 * F * 4) != MFAR_OK || sl.t2cnt.ensure((size_t)128 * F * 4) != MFAR_OK ||
                       sl.t2cand.ensure((size_t)128 * F * T2_CAP * 8, true) != MFAR_OK || sl.t2sx.ensure((size_t)128 * F * T2_CAP * 4, true) != MFAR_OK)) {
             (void)hipGetLastError();      // optional: without its scratch the batch keeps the exact pass as its only fall-back
             g_err.clear();
             sl.t2 = false;
+        }
+        // DEEP SCAN fields of the batch (fp32 index): no first attempt, the scan collects the complete candidate set (stage1_pass drops
+        // the mask again when this shape runs no light sample pass)
+        sl.deep_mask = 0;
+        if (sl.t2 && !bf16 && idx->deep_mode) {
+            const u32 allm = F >= 32 ? 0xFFFFFFFFu : ((1u << F) - 1u);
+            sl.deep_mask = (idx->deep_mode == 2 ? allm : idx->pol.deep_mask) & allm & ~sl.exact_mask & ~sl.skip_mask;
+            if (sl.deep_mask && sl.deepinfo.ensure((size_t)F * 128 * sizeof(float4)) != MFAR_OK) {
+                (void)hipGetLastError();
+                g_err.clear();
+                sl.deep_mask = 0;
+            }
         }
     }
     const int qw = sl.qw;
@@ -1681,9 +1708,24 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     if (bf16)
         RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, phases, bkind, idx->slab, sl.qt16.p, qt_n, kp, -INFINITY,
                            sl.base.as<float>(), nullptr, true, so, st, sl.skip_mask));
-    else
+    else {
+        S1DeepDev dd = {};
+        if (sl.deep_mask) {
+            dd.mask = sl.deep_mask;
+            dd.row_mask = sl.row_mode ? sl.row_mask : 0u;
+            dd.k = k;
+            dd.sentinel = sentinel;
+            dd.E = idx->E;
+            dd.eps = sl.eps.as<float>();
+            dd.qinfo = sl.qinfo.as<ScreenQuery>();
+            dd.sf = sfield;
+            dd.q = q + (size_t)q0 * idx->E;
+            dd.mean = idx->s_mean.as<float>();
+            dd.info = sl.deepinfo.as<float4>();
+        }
         RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, phases, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
-                           sl.base.as<float>(), nullptr, true, so, st, sl.skip_mask));
+                           sl.base.as<float>(), nullptr, true, so, st, sl.skip_mask, false, false, sl.deep_mask ? &dd : nullptr));
+    }
     if ((phases & S1_SCAN) && sl.dump_on) {
         sl.dump_ready = true;
         sl.dump_q = q + (size_t)q0 * idx->E;
@@ -1765,6 +1807,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
     if (t2_run) {
         cp.tau2 = sl.tau2.as<float>();
         cp.lfail = sl.lfail.as<int>();
+        cp.deep_mask = sl.deep_mask;
     }
     static const bool cert_debug = getenv("MFAR_CERT_DEBUG") != nullptr;
     DevBuf dbg;
@@ -1806,7 +1849,12 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         tc.nf = nf;
         tc.qw = qw;
         tc.kp = kp;
-        mfar_t2_collect_kernel<<<dim3(qt_n * nf), dim3(256), 0, st>>>(tc);
+        tc.stats = fflags;
+        tc.deep_mask = sl.deep_mask;
+        tc.k = k;
+        tc.sentinel = sentinel;
+        tc.info = sl.deepinfo.as<float4>();
+        mfar_t2_collect_kernel<<<dim3(qt_n * nf), dim3(256), T2_COLLECT_LDS_BYTES, st>>>(tc);
         HIPCHK(hipGetLastError());
         ScoreParams s2 = sp;
         s2.cand = sl.t2cand.as<long long>();
@@ -1825,6 +1873,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         ts.sid = sl.sids.as<long long>();
         ts.sx = sl.sx.as<float>();
         ts.scnt = sl.scnt.as<int>();
+        ts.stats = fflags;
         ts.nf = nf;
         ts.kp = kp;
         ts.k = k;
@@ -1840,6 +1889,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         u32 fields = 0;
         for (int f = f0; f < f0 + nf; ++f) fields |= 1u << f;
         idx->screen_checked += (long long)qt_n * __builtin_popcount(fields & ~sl.exact_mask);
+        sl.fb_deep = t2_run ? sl.deep_mask : 0u;
         RETCHK(post_feedback(idx, sl, fields & ~sl.exact_mask, fields & cp.quiet_mask, st));
     }
     if (any_fail_out) {   // report only: the caller repairs
@@ -1940,22 +1990,42 @@ extern "C" int mfar_set_tier2(mfar_index* idx, int mode) {
     idx->tier2_mode = mode;
     return MFAR_OK;
 }
-extern "C" int mfar_tier2_stats(mfar_index* idx, int* armed, int64_t* n_lists, int64_t* n_passed_on) {
+extern "C" int mfar_set_deep_scan(mfar_index* idx, int mode) {
+    if (!idx || mode < 0 || mode > 2) return fail(MFAR_ERR_INVALID, "mode must be 0 (never), 1 (auto: fields whose first certificates keep failing) or 2 (every field, always)");
+    idx->deep_mode = mode;
+    idx->pol.deep_mode = mode ? 1 : 0;
+    if (!mode) idx->pol.deep_mask = 0;
+    return MFAR_OK;
+}
+extern "C" int mfar_deep_scan_info(mfar_index* idx, uint32_t* deep_fields, int64_t* n_switched) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    HIPCHK(hipSetDevice(idx->device));
+    consume_feedback(idx);
+    const u32 allm = idx->F >= 32 ? 0xFFFFFFFFu : ((1u << idx->F) - 1u);
+    if (deep_fields) *deep_fields = idx->deep_mode == 2 ? allm : (idx->deep_mode ? idx->pol.deep_mask : 0u);
+    if (n_switched) *n_switched = idx->pol.n_deep_on;
+    return MFAR_OK;
+}
+extern "C" int mfar_tier2_stats(mfar_index* idx, int* armed, int64_t* n_lists, int64_t* n_passed_on, int64_t* causes) {
     if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
     HIPCHK(hipSetDevice(idx->device));
     consume_feedback(idx);
     if (armed) *armed = idx->tier2_mode == 2 || (idx->tier2_mode == 1 && idx->pol.t2_armed) ? 1 : 0;
-    int64_t a = 0, b = 0;
+    int64_t a = 0, b = 0, c[4] = {0, 0, 0, 0};
     for (auto& sl : idx->s1)
         if (sl.fail.p) {
             HIPCHK(hipDeviceSynchronize());
-            int v[2] = {0, 0};
+            int v[2] = {0, 0}, w[4] = {0, 0, 0, 0};
             HIPCHK(hipMemcpy(v, sl.fail.as<int>() + SCREEN_STAT_T2_LISTS, 8, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(w, sl.fail.as<int>() + SCREEN_STAT_T2_OVF, 16, hipMemcpyDeviceToHost));
             a += v[0];
             b += v[1];
+            for (int i = 0; i < 4; ++i) c[i] += w[i];
         }
     if (n_lists) *n_lists = a;
     if (n_passed_on) *n_passed_on = b;
+    if (causes)
+        for (int i = 0; i < 4; ++i) causes[i] = c[i];
     return MFAR_OK;
 }
 extern "C" int mfar_auto_off_info(mfar_index* idx, uint32_t* off_fields, int64_t* n_switched_off, int64_t* n_switched_on, int64_t* n_probes,

@@ -34,6 +34,46 @@ struct ScreenPolicy {
     // tier 2 cannot finish its lists either.
     bool t2_armed = false;
     int t2_clean = 0, t2_disarm_after = 256;
+    // DEEP SCAN (mfar_screen.h): a field whose lists failed their FIRST certificate in >= deep_on of its last 16 evaluated launches gets no
+    // first attempt any more -- its one scan collects the complete candidate set from a sample-derived threshold and tier 2's back half
+    // finishes the lists (one scan instead of scan + rescan).  After deep_renew launches as a deep field it is evaluated afresh.
+    // A deep field whose lists overflow (its sample-derived threshold is looser than the rescan's: clusters of near-duplicates put thousands
+    // of rows above it) is DEMOTED at once -- an overflowing list sends its whole field to the exact pass -- and may not be promoted again
+    // for deep_block launches.
+    int deep_mode = 0;        // 0 never, 1 auto
+    int deep_on = 8, deep_renew = 1024, deep_block = 4096;
+    unsigned short t1hist[MFAR_POLICY_MAX_FIELDS] = {0};
+    int deep_age[MFAR_POLICY_MAX_FIELDS] = {0}, deep_hold[MFAR_POLICY_MAX_FIELDS] = {0};
+    uint32_t deep_mask = 0;
+    long long n_deep_on = 0, n_deep_demoted = 0;
+    //   t1_fields[f] != 0: a list of field f failed its first certificate;  evaluated: fields that HAD a first certificate in that launch;
+    //   was_deep: fields that ran as deep fields;  failed[f] != 0: a list of field f went to the exact pass in the end
+    void feed_deep(int F, const int* t1_fields, const int* failed, uint32_t evaluated, uint32_t was_deep) {
+        for (int f = 0; f < F && f < MFAR_POLICY_MAX_FIELDS; ++f) {
+            const uint32_t bit = 1u << f;
+            if (deep_hold[f] > 0) deep_hold[f]--;
+            if (evaluated & bit) {
+                t1hist[f] = (unsigned short)((t1hist[f] << 1) | (t1_fields[f] ? 1 : 0));
+                if (deep_mode && !(deep_mask & bit) && deep_hold[f] == 0 && __builtin_popcount(t1hist[f]) >= deep_on) {
+                    deep_mask |= bit;
+                    deep_age[f] = 0;
+                    n_deep_on++;
+                }
+            }
+            if ((was_deep & bit) && (deep_mask & bit)) {
+                if (failed[f]) {
+                    deep_mask &= ~bit;
+                    t1hist[f] = 0;
+                    deep_hold[f] = deep_block;
+                    n_deep_demoted++;
+                } else if (++deep_age[f] >= deep_renew) {
+                    deep_mask &= ~bit;
+                    t1hist[f] = 0;
+                }
+            }
+        }
+        if (!deep_mode) deep_mask = 0;
+    }
 
     // Begin of a screened all-fields launch over F fields: *exact = fields whose lists the exact pass writes in this launch, *skip = fields
     // its screen leaves out (equal, except in a probe launch, which screens everything).

@@ -37,7 +37,9 @@
                                  // costs ~1 % and makes a failed certificate -- a 0.9 ms exact pass per field -- rarer)
 #define SCREEN_MAX_KP S1_MAX_DEPTH   // the stage-1 lists compact to k', which must leave room for one tile of appends
 #define SCREEN_SLACK 1.25f
-#define SCREEN_FLAGS (3 * MFAR_MAX_FIELDS + 5)   // ints of a batch's certificate flags (CertifyParams::fail)
+#define SCREEN_FLAGS (3 * MFAR_MAX_FIELDS + 9)   // ints of a batch's certificate flags (CertifyParams::fail)
+#define SCREEN_STAT_T2_OVF (3 * MFAR_MAX_FIELDS + 5)   // statistics [4]: why tier 2 passed lists on -- a chunk list reached its depth / more than
+                                                       // T2_CAP_IN rows above the threshold / more than T2_CAP candidates in the band / ties at the cut
 #define SCREEN_T2_FIELDS (2 * MFAR_MAX_FIELDS + 5)     // [MFAR_MAX_FIELDS] per batch: field f has lists for tier 2 (selects its rescan; cleared by the query kernel)
 #define SCREEN_FLAG_T1 (2 * MFAR_MAX_FIELDS + 2)       // per batch: some list failed the FIRST certificate (tier 2 had work; cleared by the query kernel)
 #define SCREEN_STAT_T2_LISTS (2 * MFAR_MAX_FIELDS + 3) // statistics: lists handed to tier 2 ...
@@ -647,6 +649,8 @@ struct CertifyParams {
     float* tau2;              // [F, qw] or nullptr
     int* lfail;               // [qw * nf] or nullptr
     int pass2;
+    u32 deep_mask;            // DEEP SCAN fields (below): no first certificate -- every list goes to tier 2's back half (no rescan: the scan
+                              // itself collected the complete set)
 };
 __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyParams p) {
     __shared__ u64 keys[CERT_EXPAND_CAP], sel[256], sorted[256];
@@ -662,6 +666,15 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
         return;
     }
     const bool quiet = ((p.quiet_mask >> f) & 1u) != 0u;
+    if (!p.pass2 && ((p.deep_mask >> f) & 1u)) {         // workgroup-uniform
+        if (threadIdx.x == 0) {
+            p.tau2[f * p.qw + ql] = __builtin_inff();
+            p.lfail[ql * p.nf + fo] = 1;
+            atomicOr(&p.fail[SCREEN_FLAG_T1], 1);        // (keeps tier 2 armed)
+            atomicAdd(&p.fail[SCREEN_STAT_T2_LISTS], 1);
+        }
+        return;
+    }
     if (p.pass2) {                                       // workgroup-uniform: only the lists tier 2 worked on
         const int lf = p.lfail[ql * p.nf + fo];
         if (lf == 0) return;
@@ -844,49 +857,101 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
 // fp32-accumulation terms, 0.27 of tier 1's; and it reads twice the bytes.)
 // ---------------------------------------------------------------------------------------------------------
 struct T2CollectParams {
-    const uint2* lists;       // [n_chunks * qw][S1_CAP] chunk lists of the rescan (score bits, unique row)
+    const uint2* lists;       // [n_chunks * qw][S1_CAP] chunk lists of the rescan / of the scan itself (deep fields): (score bits, unique row)
     const int* list_cnt;      // [n_chunks * qw]
-    const int* fchunk;        // [F + 1] chunk ranges of the rescan's table
+    const int* fchunk;        // [F + 1] chunk ranges of the scan's table
     const int* lfail;         // [qw * nf]
     long long* cand;          // [qw, nf, T2_CAP] out: unique-row numbers
     int* cnt;                 // [qw * nf] out: candidates of the list (0 for lists tier 2 does not handle)
     int* lfail_out;           // = lfail (2 on overflow)
     int f0, nf, qw, kp;
+    int* stats;               // the batch's flag array (SCREEN_STAT_T2_OVF: overflow causes)
+    // DEEP SCAN fields: the chunk lists hold everything above a sample-derived threshold (a few thousand rows); the candidates are the rows
+    // within the band of the k-th best APPROXIMATE score of that complete set (same argument as for the threshold: mfar_sample_tau_kernel)
+    u32 deep_mask;
+    int k, sentinel;
+    const float4* info;       // [F, qw] {band, eps, position of exact 0} in scan units
 };
-// grid = Qt * nf, block 256
+#define T2_CAP_IN 8192        // entries a list's chunk lists may hold in all (deep fields; the rescan of tier 2 stays far below)
+#define T2_COLLECT_LDS_BYTES SEL_LDS_BYTES(T2_CAP_IN)
+// grid = Qt * nf, block 256, dynamic LDS = T2_COLLECT_LDS_BYTES
 __global__ void __launch_bounds__(256) mfar_t2_collect_kernel(const T2CollectParams p) {
-    __shared__ int n_s, ovf_s;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SelLds L = sel_lds(smem, T2_CAP_IN);
+    int& n_s = L.misc[0];
+    int& ovf_s = L.misc[1];
+    int& m_s = L.misc[2];
     const int ql = blockIdx.x / p.nf, fo = blockIdx.x - ql * p.nf, f = p.f0 + fo;
     const int li = ql * p.nf + fo;
     if (p.lfail[li] != 1) {                              // workgroup-uniform
         if (threadIdx.x == 0) p.cnt[li] = 0;
         return;
     }
-    if (threadIdx.x == 0) n_s = ovf_s = 0;
+    if (threadIdx.x == 0) n_s = ovf_s = m_s = 0;
     __syncthreads();
+    const bool deep = ((p.deep_mask >> f) & 1u) != 0u;
     const int c_lo = p.fchunk[f], n_chunks = p.fchunk[f + 1] - c_lo;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    long long* out = p.cand + (size_t)li * T2_CAP;
-    for (int c = w; c < n_chunks; c += 4) {              // one wave per chunk list
+    for (int c = w; c < n_chunks; c += 4) {              // one wave per chunk list -> (approx score, unique row) keys in LDS
         const size_t lq = (size_t)(c_lo + c) * p.qw + ql;
         const int n = min(p.list_cnt[lq], S1_CAP);
-        if (n >= p.kp) {                                 // compacted to its depth (or exactly full): rows above T may be gone
+        if (n >= p.kp) {                                 // compacted to its depth (or exactly full): rows above the threshold may be gone
             if (lane == 0) ovf_s = 1;
             continue;
         }
         int base = 0;
         if (lane == 0 && n > 0) base = atomicAdd(&n_s, n);
         base = __shfl(base, 0);
-        if (base + n > T2_CAP) {
+        if (base + n > T2_CAP_IN) {
             if (lane == 0) ovf_s = 1;
             continue;
         }
-        for (int e = lane; e < n; e += 64) out[base + e] = (long long)p.lists[lq * S1_CAP + e].y;
+        for (int e = lane; e < n; e += 64) {
+            const uint2 v = p.lists[lq * S1_CAP + e];
+            L.keys[base + e] = make_key(__uint_as_float(v.x), v.y);
+        }
+    }
+    __syncthreads();
+    const int n = min(n_s, T2_CAP_IN);
+    bool ovf = ovf_s != 0 || n_s > T2_CAP_IN;
+    if (threadIdx.x == 0 && ovf) atomicAdd(&p.stats[SCREEN_STAT_T2_OVF + (n_s > T2_CAP_IN ? 1 : 0)], 1);
+    long long* out = p.cand + (size_t)li * T2_CAP;
+    if (!ovf && !deep) {                                 // tier 2's rescan: the set is tight already
+        if (n > T2_CAP) {
+            ovf = true;
+            if (threadIdx.x == 0) atomicAdd(&p.stats[SCREEN_STAT_T2_OVF + 2], 1);
+        } else
+            for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = (long long)key_id(L.keys[i]);
+        if (threadIdx.x == 0) m_s = n;
+    } else if (!ovf) {
+        // the k-th best approximate score a_k of the complete set: k rows score at least a_k, so E_k >= a_k - eps and every row that can
+        // reach the exact top-k has approx >= a_k - band (or, without a proof of k positive documents, can be positive at all)
+        float lo = -__builtin_inff();
+        if (n > p.k) {
+            const float4 in = p.info[f * p.qw + ql];
+            const int m = block_topk_sorted<T2_CAP_IN / 256>(L.keys, n, p.k, L.sel, L.sorted, L.red);
+            const float ak = key_score(L.sorted[m - 1]);
+            lo = ak - in.x;
+            lo -= fabsf(lo) * 2.0e-7f;
+            if (p.sentinel && !(ak - in.x > in.z)) lo = fminf(lo, in.z - 1.01f * in.y);
+            if (!(in.y < __builtin_inff())) lo = -__builtin_inff();       // non-finite bound: keep everything (overflows unless the set is small)
+        }
+        __syncthreads();
+        for (int i0 = 0; i0 < n; i0 += blockDim.x) {
+            const int i = i0 + threadIdx.x;
+            const bool keep = i < n && !(key_score(L.keys[i]) < lo);
+            const int pos = wave_reserve(&m_s, keep);
+            if (keep && pos < T2_CAP) out[pos] = (long long)key_id(L.keys[i]);
+        }
+        __syncthreads();
+        if (m_s > T2_CAP) {
+            ovf = true;
+            if (threadIdx.x == 0) atomicAdd(&p.stats[SCREEN_STAT_T2_OVF + 2], 1);
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const bool ovf = ovf_s != 0 || n_s > T2_CAP;
-        p.cnt[li] = ovf ? 0 : n_s;
+        p.cnt[li] = ovf ? 0 : m_s;
         if (ovf) p.lfail_out[li] = 2;
     }
 }
@@ -899,6 +964,7 @@ struct T2SelectParams {
     long long* sid;           // [qw, nf, kp] out: the screened-list format the certify kernel reads
     float* sx;                // [qw, nf, kp]
     int* scnt;                // [qw * nf]
+    int* stats;               // the batch's flag array
     int nf, kp, k;
 };
 // grid = Qt * nf, block 256, dynamic LDS = SEL_LDS_BYTES(T2_CAP)
@@ -927,7 +993,10 @@ __global__ void __launch_bounds__(256) mfar_t2_select_kernel(const T2SelectParam
     }
     if (threadIdx.x == 0) {
         p.scnt[li] = m;
-        if (bad) p.lfail[li] = 2;
+        if (bad) {
+            p.lfail[li] = 2;
+            atomicAdd(&p.stats[SCREEN_STAT_T2_OVF + 3], 1);
+        }
     }
 }
 #define T2_SELECT_LDS_BYTES ((size_t)T2_CAP * 8 + 2 * 256 * 8 + 36 * 4)

@@ -361,13 +361,32 @@ __global__ void __launch_bounds__(256, 2) mfar_merge_lists_regs_kernel(const Mer
 // One WAVE per (query, field), NV values per lane (n_vals <= 64 * NV): the 32-step radix descent on the score bits is
 // NV ballots + scalar popcounts per step, no LDS and no barriers.  grid = ceil(qw * F / 4), block 256 (qw = query columns
 // of the pass, 64 / 128).
+// DEEP SCAN fields (S1DeepDev::mask; mfar_screen.h): the threshold is not a starting point for a running top-k' but the COMPLETE-SET
+// threshold T = tau_k - band: tau_k = the k-th (not k'-th) largest published sample value -- k distinct rows score at least that, so the
+// true k-th best exact score E_k >= tau_k - eps and every row of the exact top-k has approximate score >= tau_k - 2 eps (ROW MODE fields
+// publish upper bounds, each within 2 eps of its exact score: tau_k - 4 eps).  With the zero sentinel and no proof of k positive
+// documents (tau_k - eps <= 0 in real units) the set must hold every row whose exact score can be positive: approx >= -eps.
+// info[f * qw + q] = {band, eps, position of the exact score 0, -} in scan units, for mfar_t2_collect_kernel.
+struct S1DeepDev {
+    u32 mask, row_mask;
+    int k, sentinel, E;
+    const float* eps;              // [F, qw] real units
+    const ScreenQuery* qinfo;      // [qw]
+    const ScreenField* sf;         // [F]
+    const float* q;                // [Qt, E] the block's queries
+    const float* mean;             // [F, E]
+    float4* info;                  // [F, qw]
+};
 template <int NV>
 __global__ void __launch_bounds__(256) mfar_sample_tau_kernel(const float* __restrict__ samp, const int* __restrict__ samp_n,
                                                               int samp_stride, int f0, int nf, int k, float tau0,
-                                                              const float* __restrict__ base, float* __restrict__ tau_out, int qw) {
+                                                              const float* __restrict__ base, float* __restrict__ tau_out, int qw,
+                                                              const S1DeepDev dp) {
     const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (pair >= qw * nf) return;   // wave-uniform
     const int q = pair / nf, f = f0 + pair - q * nf;
+    const bool deep = ((dp.mask >> f) & 1u) != 0u;       // wave-uniform
+    if (deep) k = dp.k;
     const int n_wave_blocks = samp_n[f];      // wave blocks the sample pass published for this field
     const int n_vals = n_wave_blocks * 2;
     u32 hi[NV];
@@ -392,6 +411,21 @@ __global__ void __launch_bounds__(256) mfar_sample_tau_kernel(const float* __res
             if (c >= k) T = cand;
         }
         t = ord2f(T);
+    }
+    if (deep) {
+        const float sc = dp.qinfo[q].scale * dp.sf[f].scale;       // scan units per real unit (powers of two)
+        const float e_s = dp.eps[f * qw + q] * sc;
+        const float band = (((dp.row_mask >> f) & 1u) ? 4.04f : 2.02f) * e_s;
+        float qm = 0.0f;                                            // q . mean(f): where the exact score 0 sits on the scan's axis
+        for (int e = lane; e < dp.E; e += 64) qm = __builtin_fmaf(dp.q[(size_t)q * dp.E + e], dp.mean[(size_t)f * dp.E + e], qm);
+        for (int off = 32; off > 0; off >>= 1) qm += __shfl_xor(qm, off);
+        const float zero_s = -qm * sc - (fabsf(qm) * sc) * 1.0e-5f;   // (the fp32 sum of q . m: K u32 relative at most, leaning down)
+        float T = t - band;
+        T -= fabsf(T) * 2.0e-7f;
+        if (!(t > -__builtin_inff()) || !(e_s < __builtin_inff())) T = -__builtin_inff();       // fewer than k sampled rows / a non-finite bound: no threshold
+        else if (dp.sentinel && !(t - band > zero_s)) T = fminf(T, zero_s - 1.01f * e_s);        // (k rows above the band prove k positive documents)
+        t = T;
+        if (lane == 0) dp.info[f * qw + q] = make_float4(band, e_s, zero_s, 0.0f);
     }
     if (lane == 0) {
         if (base) t = fmaxf(t, base[f * qw + q]);

@@ -91,7 +91,9 @@ SIGNATURES = {
     "mfar_set_auto_off": (_i, [_vp, _i, _i, _i]),
     "mfar_set_tier2": (_i, [_vp, _i]),
     "mfar_set_stage2_kernels": (_i, [_vp, _i]),
-    "mfar_tier2_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i64), _c.POINTER(_i64)]),
+    "mfar_set_deep_scan": (_i, [_vp, _i]),
+    "mfar_deep_scan_info": (_i, [_vp, _c.POINTER(_c.c_uint32), _c.POINTER(_i64)]),
+    "mfar_tier2_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64)]),
     "mfar_auto_off_info": (_i, [_vp, _c.POINTER(_c.c_uint32), _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i)]),
     "mfar_row_mode_info": (_i, [_vp, _c.POINTER(_c.c_uint32), _c.POINTER(_c.c_uint32)]),
     "mfar_set_stage2_dump": (_i, [_vp, _i]),

@@ -441,10 +441,21 @@ class MultiFieldIndex:
         2 always.  Outputs are bit-identical in every mode."""
         _native.check(_native.lib().mfar_set_tier2(self._h, int(mode)))
 
+    def set_deep_scan(self, mode: int = 1):
+        """DEEP SCAN of fields whose first certificates keep failing (include/mfar_hip.h): 0 never, 1 auto, 2 every field always."""
+        _native.check(_native.lib().mfar_set_deep_scan(self._h, int(mode)))
+
+    def deep_scan_info(self) -> dict:
+        m, n = ctypes.c_uint32(), ctypes.c_int64()
+        _native.check(_native.lib().mfar_deep_scan_info(self._h, ctypes.byref(m), ctypes.byref(n)))
+        return dict(fields=[f for f in range(self.n_fields) if (m.value >> f) & 1], n_switched=n.value)
+
     def tier2_stats(self) -> dict:
         a, n, b = ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64()
-        _native.check(_native.lib().mfar_tier2_stats(self._h, ctypes.byref(a), ctypes.byref(n), ctypes.byref(b)))
-        return dict(armed=bool(a.value), lists=n.value, passed_on_to_exact=b.value)
+        c = (ctypes.c_int64 * 4)()
+        _native.check(_native.lib().mfar_tier2_stats(self._h, ctypes.byref(a), ctypes.byref(n), ctypes.byref(b), c))
+        return dict(armed=bool(a.value), lists=n.value, passed_on_to_exact=b.value,
+                    passed_on_because=dict(chunk_list_full=c[0], too_many_rows_above_threshold=c[1], too_many_candidates_in_band=c[2], ties_at_cut=c[3]))
 
     def set_stage2_dump(self, mode: int = 1):
         """Score dump of the wide screened pass as the approximate level of stage 2 (include/mfar_hip.h): 0 never, 1 when it moves

@@ -252,6 +252,7 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
     ix.set_row_mode(int(rng.choice([0, 1, 2, 2])))       # per-row bounds for heavy-tailed fields: never / auto / always
     ix.set_stage2_dump(int(rng.choice([0, 1, 2, 2])))    # the scan's score dump as stage 2's approximate level
     ix.set_tier2(int(rng.choice([0, 1, 2, 2])))          # tier 2 of the certified screen: never / armed by failures / always
+    ix.set_deep_scan(int(rng.choice([0, 1, 2, 2])))      # deep scan (no first certificate): never / learned per field / every field
     for f in range(F):
         ix.write_rows(f, 0, slab[f])
     ref = O.bf16_round(slab) if dtype == "bf16" else slab

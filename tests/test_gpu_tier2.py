@@ -203,3 +203,82 @@ def test_tier2_on_a_bf16_index_keeps_the_chain_bits():
     r64 = ix.search(q[:50], cp.W, None, return_fields=True)   # the 64-column pass (two bf16 query terms)
     assert _same(r64, {k: v[:50] for k, v in o.items()})
     ix.close()
+
+
+def test_deep_scan_every_field_plain_clustered_and_sentinel_cases():
+    """DEEP SCAN forced for every field (mode 2): no first certificate at all -- the scan's chunk lists hold the complete candidate sets above
+    the sample-derived thresholds, the collect kernel narrows them to the band around the k-th best approximate score, tier 2's back half
+    writes the lists.  Plain Gaussian rows, clusters of near-duplicates, a field whose scores are mostly negative (zero sentinel: the set
+    must hold every row that can be positive), no sentinel, 128- and 40-query blocks: the oracle's bits, (nearly) nothing passed on."""
+    import torch
+    from mfar.data import index as idxmod
+    D, F, E, Q = 60_000, 4, 128, 128
+    for kinds, shift in ((None, 0.0), (["clustered", "plain", "clustered", "plain"], 0.0), (None, 1.6)):
+        from mfar import synth
+        cp = synth.SyntheticCorpus(D, F, E, n_queries=2 * Q, seed=0xdeadbeef, device="cuda:0", field_kinds=kinds, cluster_noise=1e-3)
+        slab = np.stack([cp.rows(f, 0, D).cpu().numpy() for f in range(F)])
+        if shift:
+            slab[1] -= shift * cp.mu.cpu().numpy()           # field 1: most scores negative
+        ix = idxmod.MultiFieldIndex(D, F, E, device=0)
+        for f in range(F):
+            ix.write_rows(f, 0, slab[f])
+        ix.set_auto_off(0)
+        ix.set_tier2(2)
+        ix.set_deep_scan(2)
+        assert ix.deep_scan_info()["fields"] == list(range(F))
+        q = cp.queries(0, Q)
+        Wn = cp.W.cpu().numpy()
+        for sentinel in (True, False):
+            o = O.c_two_stage(slab, q.cpu().numpy(), Wn, None, sentinel=sentinel)
+            t0, s0 = ix.tier2_stats(), ix.screen_stats()
+            r = ix.search(q, cp.W, None, sentinel=sentinel, return_fields=True)
+            t1, s1 = ix.tier2_stats(), ix.screen_stats()
+            assert _same(r, o), (kinds, shift, sentinel)
+            assert t1["lists"] - t0["lists"] == Q * F, (t0, t1)          # every list took the deep path
+            passed = t1["passed_on_to_exact"] - t0["passed_on_to_exact"]
+            if not shift:
+                assert passed <= Q * F // 20, (kinds, sentinel, passed)
+            assert s1["n_failed"] - s0["n_failed"] == passed
+            r40 = ix.search(q[:40], cp.W, None, sentinel=sentinel, return_fields=True)      # a 64-column block (two fp16 query terms)
+            assert _same(r40, {k: v[:40] for k, v in o.items()}), (kinds, shift, sentinel, "64 columns")
+        ix.close()
+
+
+def test_deep_scan_is_learned_per_field_in_the_pipeline():
+    """Deep scan in auto mode: the two clustered fields fail their first certificates launch after launch, tier 2 finishes their lists, and after
+    eight such launches the policy makes exactly those fields DEEP fields (one scan instead of scan + rescan); the plain fields keep their
+    certificates.  Oracle bits before and after the switch."""
+    import torch
+    from mfar.data import index as idxmod
+    from mfar.data.pipeline import NativePipeline
+    D, F, E, Q = 60_000, 4, 128, 64
+    cp, slab = _clustered(D, F, E, 64 * Q, 1e-3, kinds=["plain", "clustered", "plain", "clustered"])
+    ix = cp.build_index(idxmod)
+    ix.set_deep_scan(1)                                      # (off by default: include/mfar_hip.h says why)
+    pl = NativePipeline(ix, cp.W, None, max_batch=Q)
+    outs, tickets = [], []
+    n = 64
+    for j in range(n):
+        tickets.append(pl.submit(cp.queries(j * Q, Q)))
+        if j >= pl.lag:
+            outs.append({k: v.clone() for k, v in pl.result(tickets[j - pl.lag]).items()})
+    for t in tickets[n - pl.lag:]:
+        outs.append({k: v.clone() for k, v in pl.result(t).items()})
+    torch.cuda.synchronize()
+    info = ix.deep_scan_info()
+    assert info["fields"] == [1, 3] and info["n_switched"] == 2, info
+    assert ix.auto_off_info()["off"] == []
+    Wn = cp.W.cpu().numpy()
+    for j in (0, 2, 30, 63):
+        assert _same(outs[j], O.c_two_stage(slab, cp.queries(j * Q, Q).cpu().numpy(), Wn, None), fields=False), j
+    # a deep launch: the two deep fields' lists all count as tier-2 lists, none of the plain fields' do
+    t0 = ix.tier2_stats()
+    r = pl.result(pl.submit(cp.queries(7 * Q, Q)))
+    t1 = ix.tier2_stats()
+    assert t1["lists"] - t0["lists"] == 2 * Q and t1["passed_on_to_exact"] == t0["passed_on_to_exact"], (t0, t1)
+    ix.set_deep_scan(0)                                      # switching it off: first attempts + rescans again, same bits
+    assert ix.deep_scan_info()["fields"] == []
+    r2 = pl.result(pl.submit(cp.queries(7 * Q, Q)))
+    assert torch.equal(r["ids"], r2["ids"]) and torch.equal(r["scores"], r2["scores"])
+    pl.close()
+    ix.close()
