@@ -675,6 +675,7 @@ def config_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E
         ix.set_timing(False)
         alone_ms = ms_a / max(1, n_a)
     info = ix.auto_off_info()
+    t2_info = ix.tier2_stats()
     res_bytes = ix.resident_bytes()
     # bits gate: the last `exact_steps` of the kept batches again with the screen off
     bits_same = None
@@ -720,7 +721,7 @@ def config_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F, E
                         "algorithmic_bytes_definition": f"{scan_rows} scanned rows x {E} dims x {esize} B, read once per launch of {ps.Qmax} queries"},
            "lists_certified": (s1["n_checked"] - s0["n_checked"]) - (s1["n_failed"] - s0["n_failed"]),
            "lists_redone_exactly": s1["n_failed"] - s0["n_failed"], "batches_redone": ps.n_redone,
-           "fields_switched_off": info["off"], "inline_repair": info["inline_repair"],
+           "fields_switched_off": info["off"], "inline_repair": info["inline_repair"], "tier2": t2_info,
            "ids_and_score_bits_identical_to_exact": bits_same, "exact_leg": exact_what,
            "stage2": ({"candidates_per_query": (st1["n_candidates"] - st0["n_candidates"]) / (steps * Q),
                        "survivors_per_query": (st1["n_survivors"] - st0["n_survivors"]) / (steps * Q),
@@ -750,7 +751,7 @@ def clustered_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F
     torch.cuda.synchronize()
     dt_learn = time.perf_counter() - t0
     info0 = ix.auto_off_info()
-    s1 = ix.screen_stats()
+    s1, t2_1 = ix.screen_stats(), ix.tier2_stats()
     t0 = time.perf_counter()
     run(ps, cp, list(range(n_learn, n_learn + 8)), None)
     torch.cuda.synchronize()
@@ -787,7 +788,8 @@ def clustered_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F
            "what": "every field: ~235 near-duplicate, non-identical rows per cluster (members spread by cluster_noise x the field's spread) -- the "
                    "top 192 approximate scores of a list tie inside the error bound, the first certificate fails; tier 2 (threshold rescan) "
                    "finishes such lists from their complete candidate sets",
-           "tier2": {**t2, "lists_first_certificate_failed_steady": None},
+           "tier2": {**t2, "lists_screened_after_learning": s2["n_checked"] - s1["n_checked"],
+                     "lists_finished_by_tier2_after_learning": (t2["lists"] - t2_1["lists"]) - (t2["passed_on_to_exact"] - t2_1["passed_on_to_exact"])},
            "learning": {"batches": n_learn, "queries_per_s": n_learn * Q / dt_learn, "lists_redone_exactly": s1["n_failed"] - s0["n_failed"],
                         "lists_checked": s1["n_checked"] - s0["n_checked"], "fields_switched_off_after": info0["off"], "inline_repair": info0["inline_repair"]},
            "steps": steps, "queries_per_s": steps * Q / dt, "queries_per_s_screen_off": steps * Q / dt0,
@@ -1009,7 +1011,7 @@ def fused_leg(corpus, ix, results, args, Q, recall_exact, torch, np):
         outs.append(ix.search_fused(q, corpus.W, None, K2))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    rec, overlap = [], []
+    rec, overlap, rp_f, rp_t = [], [], [], []
     for bi, o in enumerate(outs):
         ids = o["ids"].cpu().numpy()
         for half in range(2):
@@ -1020,10 +1022,17 @@ def fused_leg(corpus, ix, results, args, Q, recall_exact, torch, np):
                 mine = set(ids[half * Q + j, :20].tolist())
                 rec.append(len(mine & rel[j]) / len(rel[j]))
                 overlap.append(len(mine & set(two[j, :20].tolist())) / 20.0)
+                # R-precision (R = the query's number of relevant documents, 1 .. 5): the planted documents must outrank EVERYTHING else --
+                # Recall@20 saturates on this corpus (the planted pull is strong), this measure does not have 15+ free slots
+                R = len(rel[j])
+                rp_f.append(len(set(ids[half * Q + j, :R].tolist()) & rel[j]) / R)
+                rp_t.append(len(set(two[j, :R].tolist()) & rel[j]) / R)
     r = float(np.mean(rec))
     return {"entry_point": "mfar_search_fused", "queries_per_s": len(qb) * 2 * Q / dt, "queries_per_call": 2 * Q, "calls": len(qb),
             "companion_build_s": t_build, "recall_at_20": r, "recall_at_20_two_stage": recall_exact,
             "recall_gate_fused_ge_two_stage_minus_0.001": bool(r >= recall_exact - 0.001),
+            "r_precision": float(np.mean(rp_f)), "r_precision_two_stage": float(np.mean(rp_t)),
+            "r_precision_gate_fused_ge_two_stage_minus_0.01": bool(np.mean(rp_f) >= np.mean(rp_t) - 0.01),
             "top20_overlap_with_two_stage": float(np.mean(overlap)),
             "note": "exhaustive mix, not the reference's two-stage algorithm: Recall parity is the claim, ids differ by design"}
 

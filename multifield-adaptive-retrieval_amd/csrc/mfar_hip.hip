@@ -197,6 +197,8 @@ struct mfar_index {
     DevBuf rep_bits;              // [F][n_blk] u64: row is real and the representative of its group
     DevBuf u_of;                  // [F][n_rows] u32: unique number + 1 of the row's group (every row, when u_repof exists; else representatives only)
     bool uof_packed = false;      // fp32 index: the entries carry a 10-bit row-norm code in their top bits (mfar_uof_norm_code_kernel)
+    DevBuf u_of_t;                // fp32 index, optional: the same entries transposed, [n_rows][F] (mfar_s2_lookup_bounds_kernel: a document's F
+    bool uof_t_ok = false;        // entries in two sectors instead of F)
     bool screen_built = false;    // statistics + unique-row tables (+ the fp16 screen slab of an fp32 index) were built at least once
     std::vector<int> n_unique, largest_group;   // per field (host copies)
     bool screen_dedup = true;     // MFAR_SCREEN_DEDUP=0: every document is its own unique row (diagnostic)
@@ -400,7 +402,7 @@ extern "C" void mfar_index_destroy(mfar_index* idx) {
         if (e) (void)hipEventDestroy(e);
     if (idx->write_ev) (void)hipEventDestroy(idx->write_ev);
     DevBuf* bufs[] = {&idx->fid, &idx->fsc, &idx->s_stats, &idx->s_field, &idx->s_mean, &idx->screen, &idx->u_rep, &idx->u_start,
-                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->s2stats, &idx->rep_bits, &idx->u_of, &idx->s_field1, &idx->s_cvt, &idx->dump_base, &idx->s_rnorm, &idx->s_nsum};
+                      &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->gslab, &idx->s2stats, &idx->rep_bits, &idx->u_of, &idx->u_of_t, &idx->s_field1, &idx->s_cvt, &idx->dump_base, &idx->s_rnorm, &idx->s_nsum};
     for (int i = 0; i < MFAR_SLOTS; ++i)
         for (DevBuf* b : {&idx->cand[i], &idx->ncand[i], &idx->x[i], &idx->own[i], &idx->xa[i], &idx->cand2[i], &idx->ncand2[i], &idx->s2qm[i],
                           &idx->s2eps[i], &idx->kmask[i], &idx->src2[i], &idx->xe[i], &idx->s2wgt[i], &idx->lbub[i]})
@@ -450,7 +452,7 @@ extern "C" int mfar_index_resident_bytes(const mfar_index* idx, int64_t* rows, i
     if (gather) *gather = (int64_t)idx->gslab.cap;
     if (tables) {
         size_t t = 0;
-        for (const DevBuf* b : {&idx->u_rep, &idx->u_start, &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->rep_bits, &idx->u_of, &idx->s_stats,
+        for (const DevBuf* b : {&idx->u_rep, &idx->u_start, &idx->u_count, &idx->u_members, &idx->u_n, &idx->u_repof, &idx->rep_bits, &idx->u_of, &idx->u_of_t, &idx->s_stats,
                                 &idx->s_field, &idx->s_mean, &idx->s_field1, &idx->s_cvt, &idx->s_rnorm, &idx->s_nsum, &idx->dump_base})
             t += b->cap;
         *tables = (int64_t)t;
@@ -1404,6 +1406,21 @@ static int ensure_screen(mfar_index* idx, hipStream_t st, bool* ok) {
             }
             HIPCHK(hipStreamSynchronize(st));
             idx->uof_packed = true;
+        }
+        // ... and transposed, for the fused look-up of the score dump's level (only shapes that may dump: many fields / few rows)
+        idx->uof_t_ok = false;
+        const double dump_b = (double)(total / idx->E) * 256.0 + 128.0 * F * 100.0 * F * 64.0, gather_b = 128.0 * F * 100.0 * F * (double)GSLAB_ROW_BYTES(idx->E);
+        if (idx->u_of.p && n > 0 && (idx->dump_mode == 2 || (idx->dump_mode == 1 && dump_b * 3.0 < gather_b)) &&      // (dump_wanted's rule at k1 = 100)
+            idx->u_of_t.ensure((size_t)n * F * 4, true) == MFAR_OK) {
+            const long long tot = n * F;
+            mfar_uof_transpose_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st>>>(idx->u_of.as<u32>(), n, F, idx->u_of_t.as<u32>());
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+            idx->uof_t_ok = true;
+        } else if (idx->u_of.p) {
+            (void)hipGetLastError();
+            g_err.clear();
+            idx->u_of_t.release();
         }
         rnorm_doc.release();
     }
@@ -2477,6 +2494,8 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
         }
         kn.kmask = idx->kmask[slot].as<u32>();
     }
+    // one mask, weights in place, transposed table: the dump's level and the interval ends in one kernel (nothing of xa / xe is written)
+    const bool fused_lb = from_dump && wgt && (masks ? n_masks : 1) == 1 && idx->uof_t_ok && idx->lbub[slot].ensure((size_t)Q * C * 8) == MFAR_OK;
     if (from_dump) {
         S2LookupParams lp = {};
         lp.dump = sl.dump.as<unsigned short>();
@@ -2501,7 +2520,17 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
         lp.n_rows = (int)idx->n_rows;
         lp.F = F;
         lp.C = C;
-        mfar_s2_lookup_kernel<<<dim3((unsigned)(((size_t)C * F + 255) / 256), Q), dim3(256), 0, st>>>(lp);
+        if (fused_lb) {
+            LookupBoundsParams lb = {};
+            lb.lp = lp;
+            lb.uof_t = idx->u_of_t.as<u32>();
+            lb.wgt = wgt;
+            lb.mask = masks;
+            lb.lbub = idx->lbub[slot].as<float>();
+            mfar_s2_lookup_bounds_kernel<<<dim3((unsigned)((C + 255) / 256), Q), dim3(256), 0, st>>>(lb);
+        } else {
+            mfar_s2_lookup_kernel<<<dim3((unsigned)(((size_t)C * F + 255) / 256), Q), dim3(256), 0, st>>>(lp);
+        }
         HIPCHK(hipGetLastError());
         idx->dump_launches++;
     } else {
@@ -2527,15 +2556,17 @@ static int run_two_level(mfar_index* idx, const float* qd, int Q, const float* W
     pr.k = k2;
     pr.query_cond = query_cond;
     pr.n_masks = masks ? n_masks : 1;
-    if (wgt && idx->lbub[slot].ensure((size_t)pr.n_masks * Q * C * 8) == MFAR_OK) {
-        // the weights exist: interval ends by several workgroups per query, then the per-query selection
+    if (wgt && (fused_lb || idx->lbub[slot].ensure((size_t)pr.n_masks * Q * C * 8) == MFAR_OK)) {
+        // the weights exist: interval ends by several workgroups per query (or already by the fused look-up), then the per-query selection
         BoundsParams bp = {};
         bp.pr = pr;
         bp.wgt = wgt;
         bp.lbub = idx->lbub[slot].as<float>();
         bp.Q = Q;
-        mfar_s2_bounds_kernel<<<dim3(S2_BOUND_SPLIT, Q), dim3(256), 0, st>>>(bp);
-        HIPCHK(hipGetLastError());
+        if (!fused_lb) {
+            mfar_s2_bounds_kernel<<<dim3(S2_BOUND_SPLIT, Q), dim3(256), 0, st>>>(bp);
+            HIPCHK(hipGetLastError());
+        }
         mfar_s2_select_kernel<<<dim3(Q), dim3(256), S2_SELECT_LDS_BYTES(C), st>>>(bp);
     } else {
         if (wgt) {

@@ -1563,6 +1563,80 @@ __global__ void __launch_bounds__(256) mfar_s2_bounds_kernel(const BoundsParams 
         }
     }
 }
+// The score dump's level and the interval ends in ONE kernel (one mask): a thread per candidate walks the F fields -- table entry + 16-bit
+// code per pair, as mfar_s2_lookup_kernel reads them -- and feeds the mixer's chain at once; neither the approximate table xa nor the
+// per-pair bounds xe are written (2 x Q C F x 4 bytes each way at 129 375 x 22: 0.2 GB per launch).  The table is the TRANSPOSED u_of
+// (uof_t [n_rows][F]: the F entries of a document are 4 F contiguous bytes -- two 64-byte sectors at F = 22 where the [F][n_rows] table
+// costs 22; built with the screen when the shape wants a dump).  Known pairs (kmask) read their exact score from xa, eps = 0.
+struct LookupBoundsParams {
+    S2LookupParams lp;       // dump, steps, eps tables, cand, kmask, xa (known pairs' scores) ...
+    const u32* uof_t;        // [n_rows][F]
+    const float* wgt;        // [Q, MFAR_MAX_FIELDS]
+    const float* mask;       // [F] or nullptr
+    float* lbub;             // [Q, C, 2]
+};
+// grid = (ceil(C / 256), Q), block 256
+__global__ void __launch_bounds__(256) mfar_s2_lookup_bounds_kernel(const LookupBoundsParams b) {
+    __shared__ float wgt[MFAR_MAX_FIELDS], msk[MFAR_MAX_FIELDS], step_s[MFAR_MAX_FIELDS], eps_s[MFAR_MAX_FIELDS], arel_s[MFAR_MAX_FIELDS], qm_s[MFAR_MAX_FIELDS],
+        isf_s[MFAR_MAX_FIELDS];
+    __shared__ long long base_s[MFAR_MAX_FIELDS];
+    const S2LookupParams& p = b.lp;
+    const int qi = blockIdx.y;
+    const int nc = min(p.n_cand[qi], p.C);
+    if ((int)(blockIdx.x * blockDim.x) >= nc) return;        // workgroup-uniform
+    if ((int)threadIdx.x < p.F) {
+        const int f = threadIdx.x;
+        wgt[f] = b.wgt[(size_t)qi * MFAR_MAX_FIELDS + f];
+        msk[f] = b.mask ? b.mask[f] : 1.0f;
+        step_s[f] = p.dump_step[f * 128 + qi];
+        eps_s[f] = p.eps_dump[f * 128 + qi];
+        arel_s[f] = p.dump_arel[f * 128 + qi];
+        qm_s[f] = p.qm[(size_t)qi * MFAR_MAX_FIELDS + f];
+        isf_s[f] = p.sf[f].inv_scale;
+        base_s[f] = p.dump_base[f];
+    }
+    __syncthreads();
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nc) return;
+    const long long gid = p.cand[(size_t)qi * p.C + c];
+    float lo = __builtin_nanf(""), hi = __builtin_nanf("");
+    if (gid >= 0) {
+        const long long id = gid - p.row_offset;
+        const bool valid = id >= 0 && id < p.n_rows;
+        const u32 km = p.kmask ? p.kmask[(size_t)qi * p.C + c] : 0u;
+        const float isq = p.qinfo[qi].inv_scale;
+        const float* xr = p.xa + ((size_t)qi * p.C + c) * p.F;
+        const u32* ut = b.uof_t + (size_t)(valid ? id : 0) * p.F;
+        lo = hi = 0.0f;
+        for (int f = 0; f < p.F; ++f) {
+            float v = __builtin_nanf(""), e = 0.0f;
+            if ((km >> f) & 1u) v = xr[f];                               // exact already (stage 1 scored the pair)
+            else if (valid) {
+                const u32 ent = ut[f];
+                const long long u = (long long)(p.uof_packed ? (ent & UOF_INDEX_MASK) : ent) - 1;
+                const u32 code = p.uof_packed ? (ent >> UOF_NORM_SHIFT) : 1023u;
+                e = eps_s[f] - arel_s[f] * (float)(1023u - code);
+                const size_t ru = (size_t)base_s[f] + (size_t)u;
+                const float a = (float)(short)p.dump[(ru >> 1) * 256 + (size_t)qi * 2 + (ru & 1)] * step_s[f];
+                v = (a * isq) * isf_s[f] + qm_s[f];
+            }
+            const float mf = msk[f];
+            const float dn = s2_nextdown(v - e), up = s1_nextup(v + e);
+            lo = __builtin_fmaf(wgt[f], (mf >= 0.0f ? dn : up) * mf, lo);
+            hi = __builtin_fmaf(wgt[f], (mf >= 0.0f ? up : dn) * mf, hi);
+        }
+    }
+    *(float2*)(b.lbub + ((size_t)qi * p.C + c) * 2) = make_float2(lo, hi);
+}
+// uof_t[row][f] = uof[f][row]: grid = ceil(n_rows * F / 256), block 256
+__global__ void __launch_bounds__(256) mfar_uof_transpose_kernel(const u32* __restrict__ uof, long long n_rows, int F, u32* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * F) return;
+    const long long row = i / F;
+    const int f = (int)(i - row * F);
+    out[i] = uof[(size_t)f * n_rows + row];
+}
+
 // grid = Q, block 256, dynamic LDS = SEL_LDS_BYTES(C) + C bytes
 #define S2_SELECT_LDS_BYTES(C) (SEL_LDS_BYTES(C) + (((size_t)(C) + 15) & ~(size_t)15))
 __global__ void __launch_bounds__(256) mfar_s2_select_kernel(const BoundsParams b) {

@@ -136,6 +136,55 @@ int main() {
             if (f % 5 == 0) REQUIRE((s.pol.off_mask >> f) & 1u);
             else if (p[f] == 0.0) REQUIRE(!((s.pol.off_mask >> f) & 1u));
     }
+    {   // TIER 2 (round 6): armed by the first launch with a failed FIRST certificate (whether or not tier 2 then finished the lists), disarmed
+        // after 256 clean launches in a row; the flags AUTO-OFF sees are those after tier 2 -- lists tier 2 finishes switch nothing off
+        ScreenPolicy pol;
+        int clean[MFAR_POLICY_MAX_FIELDS] = {0}, probe[MFAR_POLICY_MAX_FIELDS] = {0};
+        for (int i = 0; i < 100; ++i) pol.feed(4, clean, probe, 0, 0xFu, 0u, false, 0);
+        REQUIRE(!pol.t2_armed);
+        pol.feed(4, clean, probe, 0, 0xFu, 0u, false, 1);                  // first certificates failed, tier 2 finished every list
+        REQUIRE(pol.t2_armed && pol.off_mask == 0 && !pol.inline_repair);
+        for (int i = 0; i < 1000; ++i) pol.feed(4, clean, probe, 0, 0xFu, 0u, false, 1);
+        REQUIRE(pol.t2_armed && pol.off_mask == 0 && !pol.inline_repair && pol.n_off == 0);
+        for (int i = 0; i < 255; ++i) pol.feed(4, clean, probe, 0, 0xFu, 0u, false, 0);
+        REQUIRE(pol.t2_armed);
+        pol.feed(4, clean, probe, 0, 0xFu, 0u, false, 0);
+        REQUIRE(!pol.t2_armed);                                            // 256 clean launches: a clean corpus pays nothing again
+        int bad[MFAR_POLICY_MAX_FIELDS] = {0};
+        bad[2] = 1;
+        pol.feed(4, bad, probe, 1, 0xFu, 0u, false, 0);                    // a hard failure (tier 2 not even tried) arms it as well
+        REQUIRE(pol.t2_armed);
+    }
+    {   // DEEP SCAN (auto mode): a field whose first certificates fail in 8 of 16 evaluated launches is promoted; an overflowing deep list
+        // demotes it at once and blocks it for deep_block launches; after deep_renew launches a deep field is evaluated afresh; mode 0 = never
+        ScreenPolicy pol;
+        pol.deep_mode = 1;
+        int t1[MFAR_POLICY_MAX_FIELDS] = {0}, ok[MFAR_POLICY_MAX_FIELDS] = {0}, failed[MFAR_POLICY_MAX_FIELDS] = {0};
+        t1[1] = 1;
+        for (int i = 0; i < 7; ++i) pol.feed_deep(4, t1, ok, 0xFu, 0u);
+        REQUIRE(pol.deep_mask == 0);
+        pol.feed_deep(4, t1, ok, 0xFu, 0u);
+        REQUIRE(pol.deep_mask == 2u && pol.n_deep_on == 1);
+        for (int i = 0; i < 1023; ++i) pol.feed_deep(4, t1, ok, 0xFu & ~pol.deep_mask, pol.deep_mask);
+        REQUIRE(pol.deep_mask == 2u);
+        pol.feed_deep(4, t1, ok, 0xFu & ~pol.deep_mask, pol.deep_mask);   // renewal: evaluated afresh ...
+        REQUIRE(pol.deep_mask == 0);
+        for (int i = 0; i < 8; ++i) pol.feed_deep(4, t1, ok, 0xFu, 0u);   // ... and promoted again while it keeps failing
+        REQUIRE(pol.deep_mask == 2u && pol.n_deep_on == 2);
+        failed[1] = 1;
+        pol.feed_deep(4, t1, failed, 0xFu & ~pol.deep_mask, pol.deep_mask);      // a deep list overflowed: demoted at once
+        REQUIRE(pol.deep_mask == 0 && pol.n_deep_demoted == 1);
+        for (int i = 0; i < 4000; ++i) pol.feed_deep(4, t1, ok, 0xFu, 0u);
+        REQUIRE(pol.deep_mask == 0);                                       // blocked
+        for (int i = 0; i < 200; ++i) pol.feed_deep(4, t1, ok, 0xFu, 0u);
+        REQUIRE(pol.deep_mask == 2u);                                      // the block has run out
+        pol.deep_mode = 0;
+        pol.feed_deep(4, t1, ok, 0xFu, 0u);
+        REQUIRE(pol.deep_mask == 0);
+        ScreenPolicy off;                                                  // default: never
+        for (int i = 0; i < 100; ++i) off.feed_deep(4, t1, ok, 0xFu, 0u);
+        REQUIRE(off.deep_mask == 0 && off.n_deep_on == 0);
+    }
     std::printf("OK policy scenarios\n");
     return 0;
 }
