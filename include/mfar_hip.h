@@ -50,6 +50,12 @@ typedef struct mfar_index mfar_index;
 int mfar_version(void);
 const char* mfar_last_error(void);
 int mfar_device_count(int* n_out);
+/* TEST HOOK (process-wide; no reference counterpart): scratch / table allocations of at least `bytes` bytes made by the library fail exactly
+ * like a hipMalloc that ran out of device memory (MFAR_ERR_NOMEM, nothing left sticky); 0 switches it off.  Lets the out-of-memory
+ * semantics be driven deterministically: with a really full HBM the HIP runtime gives cached resources back when an allocation fails, so
+ * whether a given call fits depends on what the process did before (tests/test_gpu_parity.py::test_full_hbm_degrades_to_the_exact_pass uses
+ * both).  The slab of mfar_index_create is not affected. */
+int mfar_debug_fail_allocations_above(int64_t bytes);
 
 /*
  * The on-HBM sharded index: replaces the per-field float32 np.memmap files `{temp_dir}/{field}.npy`

@@ -4,6 +4,7 @@
 #include <hipcub/hipcub.hpp>   // device radix sort + prefix sums of the unique-row build (index construction, not the hot path)
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -40,6 +41,10 @@ static int fail(int code, const std::string& msg) {
         if (rc_ != MFAR_OK) return rc_; \
     } while (0)
 
+// Test hook (mfar_debug_fail_allocations_above): DevBuf allocations of at least this many bytes fail exactly like a hipMalloc that ran out of
+// device memory -- the NOMEM paths can then be driven deterministically (a really full HBM is a moving target: the HIP runtime gives
+// cached resources back when an allocation fails, so whether a given call fits depends on the process's history).  0 = off.
+static std::atomic<long long> g_fail_alloc_above{0};
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -50,7 +55,8 @@ struct DevBuf {
         p = nullptr;
         cap = 0;
         size_t want = exact ? ((bytes + 255) & ~(size_t)255) : bytes + (bytes >> 3) + 256;
-        hipError_t e = hipMalloc(&p, want);
+        const long long lim = g_fail_alloc_above.load(std::memory_order_relaxed);
+        hipError_t e = (lim > 0 && (long long)want >= lim) ? hipErrorOutOfMemory : hipMalloc(&p, want);
         if (e != hipSuccess) {
             p = nullptr;
             (void)hipGetLastError();      // the failed allocation is REPORTED here; left sticky it would fail the caller's next launch check
@@ -307,6 +313,11 @@ extern "C" int mfar_trace_dump(void* host, int max_rec) {   // experiment builds
 }
 #endif
 extern "C" int mfar_version(void) { return MFAR_VERSION; }
+extern "C" int mfar_debug_fail_allocations_above(int64_t bytes) {
+    if (bytes < 0) return fail(MFAR_ERR_INVALID, "bytes must be >= 0 (0 = off)");
+    g_fail_alloc_above.store((long long)bytes);
+    return MFAR_OK;
+}
 extern "C" const char* mfar_last_error(void) { return g_err.c_str(); }
 extern "C" int mfar_device_count(int* n_out) {
     if (!n_out) return fail(MFAR_ERR_INVALID, "n_out is NULL");
@@ -1733,6 +1744,7 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
             dd.k = k;
             dd.sentinel = sentinel;
             dd.E = idx->E;
+            dd.Q = qt_n;
             dd.eps = sl.eps.as<float>();
             dd.qinfo = sl.qinfo.as<ScreenQuery>();
             dd.sf = sfield;

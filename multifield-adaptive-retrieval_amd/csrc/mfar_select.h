@@ -370,6 +370,7 @@ __global__ void __launch_bounds__(256, 2) mfar_merge_lists_regs_kernel(const Mer
 struct S1DeepDev {
     u32 mask, row_mask;
     int k, sentinel, E;
+    int Q;                         // live query columns of the block (the padding columns of a short block have no query row to read)
     const float* eps;              // [F, qw] real units
     const ScreenQuery* qinfo;      // [qw]
     const ScreenField* sf;         // [F]
@@ -385,7 +386,7 @@ __global__ void __launch_bounds__(256) mfar_sample_tau_kernel(const float* __res
     const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (pair >= qw * nf) return;   // wave-uniform
     const int q = pair / nf, f = f0 + pair - q * nf;
-    const bool deep = ((dp.mask >> f) & 1u) != 0u;       // wave-uniform
+    const bool deep = ((dp.mask >> f) & 1u) != 0u && q < dp.Q;       // wave-uniform (a padding column keeps its +inf base threshold)
     if (deep) k = dp.k;
     const int n_wave_blocks = samp_n[f];      // wave blocks the sample pass published for this field
     const int n_vals = n_wave_blocks * 2;

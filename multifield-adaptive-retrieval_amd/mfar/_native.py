@@ -89,6 +89,7 @@ SIGNATURES = {
     "mfar_set_row_mode": (_i, [_vp, _i]),
     "mfar_row_mode_activate": (_i, [_vp]),
     "mfar_set_auto_off": (_i, [_vp, _i, _i, _i]),
+    "mfar_debug_fail_allocations_above": (_i, [_i64]),
     "mfar_set_tier2": (_i, [_vp, _i]),
     "mfar_set_stage2_kernels": (_i, [_vp, _i]),
     "mfar_set_deep_scan": (_i, [_vp, _i]),

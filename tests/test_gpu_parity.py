@@ -1627,9 +1627,10 @@ def test_limits_of_fields_and_list_depth(idxmod):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_full_hbm_degrades_to_the_exact_pass(idxmod, dtype):
-    """HBM nearly full when a query arrives.  (1) Not even the call's scratch fits: a clean MFAR_ERR_NOMEM, no stale HIP error left behind --
-    the next call works; (1b) the same through the C-ABI pipeline: the launch that could not be enqueued keeps its batch, the error repeats
-    while memory is short, the batch is run when its result is taken afterwards; (2) a little more room: the screen's big buffers (fp16 copy,
+    """HBM nearly full when a query arrives.  (0) by the library's allocation-failure hook, deterministically, and (1) with a really full HBM:
+    not even the call's scratch fits -- a clean MFAR_ERR_NOMEM, no stale HIP error left behind, the next call works; (1b) the same through
+    the C-ABI pipeline: the launch that could not be enqueued keeps its batch, the error repeats while memory is short, the batch is run when
+    its result is taken afterwards; (2) a little more room: the screen's big buffers (fp16 copy,
     gather slab) cannot all be allocated -- a clean error or the oracle's rows from whatever could be built, and the right rows once memory
     is back."""
     import contextlib
@@ -1660,21 +1661,51 @@ def test_full_hbm_degrades_to_the_exact_pass(idxmod, dtype):
         torch.cuda.synchronize()
         return ix
 
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     room = F * D * E * 4 + (4 << 30)                 # one index at a time, its screen + gather slab, a pipeline's scratch (3 slots x ~0.3 GB)
     big = torch.empty(torch.cuda.mem_get_info(0)[0] - room, dtype=torch.uint8, device="cuda:0")     # (one huge allocation for the whole test)
 
     def squeeze(keep_mb):
-        torch.cuda.empty_cache()
+        gc.collect()                 # (garbage of earlier tests -- an index in a reference cycle -- must not be freed between this and the call
+        torch.cuda.empty_cache()     #  under test: its hipFree would hand the call the memory it is supposed to lack)
         return torch.empty(max(0, torch.cuda.mem_get_info(0)[0] - (keep_mb << 20)), dtype=torch.uint8, device="cuda:0")
 
+    L = _native.lib()
     try:
-        # (1)
+        # (0) the same semantics, DETERMINISTICALLY: the library's test hook makes every scratch allocation of >= 64 MB fail like a hipMalloc
+        #     that ran out of memory (with a really full HBM -- below -- whether a call fits depends on what the HIP runtime can still give back)
+        ix = fresh()
+        _native.check(L.mfar_debug_fail_allocations_above(64 << 20))
+        try:
+            with pytest.raises(_native.MfarError) as err:
+                ix.search(q, W, None)
+            assert "NOMEM" in str(err.value) or "out of memory" in str(err.value), str(err.value)
+            pl = NativePipeline(ix, W, None, max_batch=16, coalesce=1)
+            with pytest.raises(_native.MfarError) as err:
+                pl.submit(q)
+            ticket = err.value.ticket
+            assert ticket is not None
+            with pytest.raises(_native.MfarError):
+                pl.result(ticket)                       # still no memory: the error repeats, nothing half-done comes back
+        finally:
+            _native.check(L.mfar_debug_fail_allocations_above(0))
+        got = [pl.result(ticket), pl.result(pl.submit(q))]      # memory is back: the kept batch is run now; new batches flow
+        assert pl.n_redone >= 1
+        for g in got:
+            right(g, "pipeline after a failed launch (test hook)")
+        right(ix.search(q, W, None), "after a failed call (test hook)")
+        pl.close()
+        ix.close()
+        # (1) a really full HBM
         ix = fresh()
         hog = squeeze(24)
-        with pytest.raises(_native.MfarError) as err:
-            ix.search(q, W, None)
-        assert "NOMEM" in str(err.value) or "out of memory" in str(err.value), str(err.value)
+        try:
+            r = ix.search(q, W, None)
+            right(r, "24 MB free, and the runtime found room")
+        except _native.MfarError as e:
+            assert "NOMEM" in str(e) or "out of memory" in str(e), str(e)
         del hog
         torch.cuda.empty_cache()
         right(ix.search(q, W, None), "after a failed call")
@@ -1683,16 +1714,23 @@ def test_full_hbm_degrades_to_the_exact_pass(idxmod, dtype):
         ix = fresh()
         pl = NativePipeline(ix, W, None, max_batch=16, coalesce=1)
         hog = squeeze(24)
-        with pytest.raises(_native.MfarError) as err:
-            pl.submit(q)
-        ticket = err.value.ticket
+        # (in a long-lived process the HIP runtime may find the 150 MB of launch scratch after all -- a failed hipMalloc makes it give back
+        #  what it caches -- so the launch either fails cleanly or goes through; alone, this test always takes the first branch)
+        try:
+            ticket = pl.submit(q)
+            raised = False
+        except _native.MfarError as e:
+            ticket, raised = e.ticket, True
         assert ticket is not None
-        with pytest.raises(_native.MfarError):
-            pl.result(ticket)                           # still no memory: the error repeats, nothing half-done comes back
+        if raised:
+            try:                                        # still (almost) no memory: the error repeats -- or the kept batch now fits through
+                right(pl.result(ticket), "kept batch under memory pressure")  # the degraded paths (optional scratch skipped): never half-done
+            except _native.MfarError:
+                pass
         del hog
         torch.cuda.empty_cache()
         got = [pl.result(ticket), pl.result(pl.submit(q))]      # memory is back: the kept batch is run now; new batches flow
-        assert pl.n_redone >= 1
+        assert pl.n_redone >= 1 or not raised
         for g in got:
             right(g, "pipeline after a failed launch")
         pl.close()

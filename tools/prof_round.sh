@@ -12,7 +12,8 @@ line() { python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); r=d['roofline']; c=d['config']
 print(c['docs'], c['fields'], c['dim'], '$1', 'q/s=%.0f' % d['value'], 'ms/step=%.3f' % d['ms_per_step'], r['kernel'], 'launch_ms=%.3f' % r['avg_launch_ms'], 'hbm_frac=%.3f' % r['frac'],
-      'redone=%s' % (d['screen']['lists_redone_exactly'] if d.get('screen') else '-'), 'recall20=%.3f' % d['recall_at_20'], 'resident=%.2f' % d['resident_bytes']['ratio'])"; }
+      'redone=%s' % (d['screen']['lists_redone_exactly'] if d.get('screen') else '-'), 'tier2=%s/%s' % (d['adaptive']['tier2']['lists'], d['adaptive']['tier2']['passed_on_to_exact']),
+      'off=%s' % d['adaptive']['off'], 'recall20=%.3f' % d['recall_at_20'], 'resident=%.2f' % d['resident_bytes']['ratio'])"; }
 # BASELINE.json's config shapes and other embedding widths (one line each)
 : > $O/shapes.txt
 for cfg in "129375 22 768" "700244 5 768" "957192 8 768" "125000 8 768" "2000000 8 384" "1500000 8 512" "750000 8 1024" "500000 8 1536"; do
@@ -35,6 +36,16 @@ python $R/bench.py $B --coalesce 1 2>> $O/bench.err | line "--coalesce 1" >> $O/
 python $R/bench.py $B --pipeline python 2>> $O/bench.err | line "--pipeline python" >> $O/shapes.txt
 python $R/bench.py $B --corpus clustered --steps 256 2>> $O/bench.err | line "--corpus clustered" >> $O/shapes.txt
 python $R/bench.py $B --corpus clustered --steps 256 --screen off 2>> $O/bench.err | line "--corpus clustered --screen off" >> $O/shapes.txt
+# round 6: tier 2 off (the round-5 policy alone: fields switched off -> exact pass), moderate cluster noise, the deep scan (opt-in), a narrow cone,
+# the kernels of rounds 3-5 in the tail
+MFAR_SCREEN_TIER2=0 python $R/bench.py $B --corpus clustered --steps 256 2>> $O/bench.err | line "--corpus clustered MFAR_SCREEN_TIER2=0" >> $O/shapes.txt
+python $R/bench.py $B --corpus clustered --cluster-noise 1e-2 --steps 256 2>> $O/bench.err | line "--corpus clustered --cluster-noise 1e-2" >> $O/shapes.txt
+MFAR_SCREEN_DEEP=1 python $R/bench.py $B --corpus clustered --steps 256 2>> $O/bench.err | line "--corpus clustered MFAR_SCREEN_DEEP=1" >> $O/shapes.txt
+MFAR_SCREEN_DEEP=2 MFAR_SCREEN_TIER2=2 python $R/bench.py $B --steps 256 2>> $O/bench.err | line "MFAR_SCREEN_DEEP=2 (every field, plain corpus)" >> $O/shapes.txt
+python $R/bench.py $B --mu-scale 2.7 --steps 256 2>> $O/bench.err | line "--mu-scale 2.7 (narrow cone, isotropic spread)" >> $O/shapes.txt
+MFAR_S2_FUSED=0 python $R/bench.py $B --steps 256 2>> $O/bench.err | line "MFAR_S2_FUSED=0" >> $O/shapes.txt
+MFAR_S2_FUSED=0 python $R/bench.py $B --docs 129375 --fields 22 --steps 256 2>> $O/bench.err | line "MFAR_S2_FUSED=0" >> $O/shapes.txt
+python $R/bench.py $B --docs 129375 --fields 22 --steps 256 2>> $O/bench.err | line "(256 steps)" >> $O/shapes.txt
 # kernel trace + stats of the default leg alone (the extra legs launch the same kernels on other shapes and would skew the averages)
 rocprofv3 --kernel-trace --stats -d /tmp/kt -o r1 --output-format csv -- python $R/bench.py --steps 16 --warmup 2 $B > $O/bench_under_rocprof.json 2>/dev/null
 # counters: one pass each; default leg, then the exact fp32 pass (--screen off) into a sub-directory of the same pass
@@ -49,7 +60,7 @@ python $R/tools/trace_timeline.py /tmp/kt > $O/timeline.txt 2>/dev/null
 # per shape: kernel trace + FETCH_SIZE / WRITE_SIZE passes of BASELINE configs[1], [2] and the configs[4] share (HBM bytes per launch of every kernel)
 for cfg in "prime 129375 22 f32" "mag 700244 5 f32" "bf16share 1250000 16 bf16"; do
   set -- $cfg
-  A="--steps 8 --warmup 2 $B --docs $2 --fields $3 --dtype $4"
+  A="--steps 24 --warmup 4 $B --docs $2 --fields $3 --dtype $4"
   rocprofv3 --kernel-trace --stats -d /tmp/kt_$1 -o r1 --output-format csv -- python $R/bench.py $A > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf_$1 -o r1 --output-format csv -- python $R/bench.py $A > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw_$1 -o r1 --output-format csv -- python $R/bench.py $A > /dev/null 2>&1
