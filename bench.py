@@ -88,7 +88,9 @@ def pipeline_traffic(shape, s1_kernel, sample_kernel) -> dict:
     want = source_hash()
     per_launch = {s1_kernel: 1, sample_kernel: 1, "void mfar_score_rows_kernel<0>": 2, "void mfar_score_rows_kernel<1>": 1,
                   "void mfar_merge_lists_regs_kernel<48>": 1, "mfar_screen_certify_kernel": 1, "mfar_union_kernel": 1, "mfar_mix_topk_kernel": 1,
-                  "void mfar_sample_tau_kernel<16>": 1, "mfar_s2_prune_kernel": 1, "mfar_s2_prep_kernel": 1}
+                  "void mfar_sample_tau_kernel<16>": 1, "mfar_s2_prune_kernel": 1, "mfar_s2_prep_kernel": 1,
+                  # round 6's tail kernels (mfar_set_stage2_kernels(1), the default): whichever family ran is what the summary holds
+                  "mfar_s2_gate_kernel": 1, "mfar_s2_front_kernel": 1, "mfar_s2_bounds_kernel": 1, "mfar_s2_select_kernel": 1}
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), reverse=True):
         try:
             d = json.load(open(fn))

@@ -71,3 +71,5 @@ python $R/tools/build_timing.py > $O/build_timing.txt 2>/dev/null
 python $R/tools/build_timing.py --dtype bf16 --docs 1250000 --fields 16 >> $O/build_timing.txt 2>/dev/null
 tail -c 600 $O/bench.json
 cat $O/shapes.txt
+# round 6: the kept encoder run at the STaRK-prime row count (>= 129 375 x 22), bf16 autocast rows
+python $R/tools/encode_bench.py --docs 129375 --modes bf16 --no-sweep > $O/encode_prime_129k.json 2>> $O/bench.err
