@@ -282,3 +282,29 @@ def test_deep_scan_is_learned_per_field_in_the_pipeline():
     assert torch.equal(r["ids"], r2["ids"]) and torch.equal(r["scores"], r2["scores"])
     pl.close()
     ix.close()
+
+
+def test_tier2_at_the_headline_shape_through_the_timed_path():
+    """1 000 000 x 8 x 768 with every field made of near-duplicate clusters (`bench.py clustered_corpus`): the path the bench line times --
+    two 64-query batches coalesced into one 128-column launch, both faces of the pipeline, nothing forced -- with tier 2 ARMED by a first
+    failing launch, against the synchronous search of each half and, for 8 probe queries, the C oracle bit for bit (stage-1 lists proven
+    complete by an exhaustive torch scan, O.c_two_stage on the union rows).  No list reaches the exact pass, no field is switched off."""
+    import torch
+    if torch.cuda.mem_get_info(0)[0] < 90 << 30:
+        pytest.skip("needs ~80 GB of free HBM")
+    from mfar.data import index as idxmod
+    from mfar import synth
+    from test_gpu_parity import _timed_path_check
+    D, F, E, Q = 1_000_000, 8, 768, 64
+    cp = synth.SyntheticCorpus(D, F, E, n_queries=8 * Q, seed=0xdeadbeef, device="cuda:0", field_kinds=["clustered"] * F, cluster_noise=1e-3)
+    ix = cp.build_index(idxmod)
+    mask = torch.ones(F, device="cuda:0")
+    ix.search(cp.queries(4 * Q, 2 * Q), cp.W, mask)          # certificates fail, the exact pass repairs -- and the feedback arms tier 2
+    torch.cuda.synchronize()
+    assert ix.tier2_stats()["armed"]
+    s0, t0 = ix.screen_stats(), ix.tier2_stats()
+    _timed_path_check(idxmod, ix, cp, cp.W, mask, [0, 9, 21, 34, 42, 55, 60, 63])
+    s1, t1 = ix.screen_stats(), ix.tier2_stats()
+    assert t1["lists"] - t0["lists"] > 4 * Q * F and t1["passed_on_to_exact"] == t0["passed_on_to_exact"], (t0, t1)
+    assert s1["n_failed"] == s0["n_failed"] and ix.auto_off_info()["off"] == []
+    ix.close()
