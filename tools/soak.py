@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--fields", type=int, default=8)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--corpus", default="plain", choices=["plain", "clustered"], help="clustered: every first certificate fails, tier 2 "
+                                                                                     "(the threshold rescan) finishes every list, launch after launch")
     a = ap.parse_args()
     import numpy as np
     from mfar import synth
@@ -30,7 +32,8 @@ def main():
     from mfar.data.pipeline import NativePipeline
     import bench
     Q, NB = 64, 32
-    corpus = synth.SyntheticCorpus(a.docs, a.fields, a.dim, n_queries=Q * NB, seed=0xdeadbeef, device="cuda:0")
+    corpus = synth.SyntheticCorpus(a.docs, a.fields, a.dim, n_queries=Q * NB, seed=0xdeadbeef, device="cuda:0",
+                                   field_kinds=(["clustered"] * a.fields if a.corpus == "clustered" else None), cluster_noise=1e-3)
     ix = corpus.build_index(idxmod, dtype=a.dtype)
     W = corpus.W.cpu().numpy()
     qs = [corpus.queries(j * Q, Q).cpu().numpy() for j in range(NB)]
@@ -67,7 +70,8 @@ def main():
     out = {"shape": [a.docs, a.fields, a.dim], "dtype": a.dtype, "stage1_kernel": ix.last_stage1_kernel(), "seconds": round(time.perf_counter() - t0, 1), "batches": j, "queries": j * Q,
            "queries_per_s_per_5s_window": windows, "min_over_max": round(min(windows) / max(windows), 4),
            "batches_compared_with_their_first_result": n_cmp, "different": n_diff, "launches_redone": pl.n_redone,
-           "lists_checked": st.get("n_checked"), "lists_failed": st.get("n_failed"), "source_hash": bench.source_hash()}
+           "lists_checked": st.get("n_checked"), "lists_failed": st.get("n_failed"), "tier2": ix.tier2_stats(), "fields_switched_off": ix.auto_off_info()["off"],
+           "corpus": a.corpus, "source_hash": bench.source_hash()}
     pl.close()
     ix.close()
     print(json.dumps(out))
