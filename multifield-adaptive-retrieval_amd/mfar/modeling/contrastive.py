@@ -148,6 +148,7 @@ class RetrievalTrainingModule(torch.nn.Module):
         self.additional_qres_output: Optional[TextIO] = None
         self._corpus_encoded = False
         self._searcher = None
+        self._graphed = None                # captured corpus-encode forwards (mfar/modeling/graphed.py), kept across encodes
         # precision of the CORPUS encode forwards: "fp32" | "fp16" | "bf16" (rows written to the slab are fp32 either way).  A module built
         # directly encodes in fp32; the CLIs set it from their `precision` flag (commands/_setup.py `encode_precision_for`): the reference's
         # default "16-mixed" (train.py:51) -> fp16 autocast.  MFAR_ENCODE_AUTOCAST=fp32|fp16|bf16 overrides either.
@@ -296,19 +297,33 @@ class RetrievalTrainingModule(torch.nn.Module):
             return None
         return be
 
-    def _token_batches(self, uniq, order, bs, budget, max_len, stop):
-        """Producer side: yields (features on the host, rows of `uniq` they belong to) for every text of `uniq`, each exactly once."""
+    def _token_batches(self, uniq, order, bs, budget, max_len, stop, graph_shapes=False):
+        """Producer side: yields (features on the host, rows of `uniq` they belong to) for every text of `uniq`, each exactly once.
+        graph_shapes: batches are cut to the shape family captured forwards replay (mfar/modeling/graphed.py): texts per batch from
+        `shape_ladder(bs)`, lengths rounded up to 8 tokens; a short last batch is padded with rows of one [PAD] token (features have more
+        rows than `rows`: the consumer drops the surplus)."""
         import itertools
         import numpy as np
+        from mfar.modeling.graphed import round_len, shape_ladder
+        ladder = shape_ladder(bs) if graph_shapes else None
         tok = self.encoder.tokenizer
         be = tok.backend_tokenizer
         pad_id = int(tok.pad_token_id or 0)
         pin = self.device.type == "cuda"
         be.enable_truncation(max_length=max_len)            # (PreTrainedTokenizerFast resets both on its next __call__)
         be.no_padding()
+        # Chunks of the (character-ordered) texts, tokenised one chunk at a time.  While a chunk is in the tokenizer no batch is produced, so
+        # a chunk must not be more work than the queue ahead of the consumer covers: at most 8192 texts AND about 32 forwards (real word-piece vocabularies: ~8)
+        # of characters (profiles/r06_j_encode_halves.txt: 8192 texts of the long `details` field were 0.4 s in the tokenizer behind a
+        # queue of 0.1 s -- the GPU drained in every chunk).  A short first chunk: the GPU starts early.
+        chars = np.cumsum(np.fromiter((len(uniq[i]) for i in order), np.int64, len(order)))
+        per_chunk = max(1, int(os.environ.get("MFAR_ENCODE_CHUNK_BATCHES", "32"))) * max(budget, bs * 32)
         c1 = 0
         while c1 < len(order) and not stop.is_set():
-            c0, c1 = c1, min(len(order), c1 + (1024 if c1 == 0 else 2048 if c1 == 1024 else 8192))   # a short first chunk: the GPU starts early
+            c0 = c1
+            done = int(chars[c0 - 1]) if c0 else 0
+            c1 = int(np.searchsorted(chars, done + (per_chunk // 4 if c0 == 0 else per_chunk), side="right"))
+            c1 = min(len(order), max(c0 + min(4 * bs, 256), min(c1, c0 + (1024 if c0 == 0 else 8192))))
             idxs = np.asarray(order[c0:c1], np.int64)
             ids = [e.ids for e in be.encode_batch([uniq[i] for i in idxs], add_special_tokens=True)]
             lens = np.fromiter((len(x) for x in ids), np.int64, len(ids))
@@ -317,16 +332,32 @@ class RetrievalTrainingModule(torch.nn.Module):
             o2 = np.argsort(lens, kind="stable")
             pos = 0
             while pos < len(o2) and not stop.is_set():
-                n = min(bs, len(o2) - pos)
-                if budget:
-                    n = min(4096, len(o2) - pos)
+                rem = len(o2) - pos
+                n = min(bs, rem)
+                n_shape = 0
+                if ladder is not None:
+                    # the largest ladder size whose padded batch fits the budget (the floor `bs` always does: the caller sized memory for
+                    # it); fewer texts left than that: the smallest ladder size that holds them
+                    for n_shape in (ladder if budget else [bs]):
+                        m = min(n_shape, rem)
+                        if n_shape == bs or n_shape * round_len(int(lens[o2[pos + m - 1]]), max_len) <= budget:
+                            break
+                    n = min(n_shape, rem)
+                    n_shape = min(v for v in ladder if v >= n and v <= n_shape)
+                elif budget:
+                    n = min(4096, rem)
                     while n > bs and n * int(lens[o2[pos + n - 1]]) > budget:     # lengths ascend: the last text is the longest
                         n = max(bs, (n * 3) // 4)
                 sel = o2[pos:pos + n]
                 L = max(1, int(lens[sel[-1]]))
-                valid = np.arange(L)[None, :] < lens[sel][:, None]
-                arr = np.full((n, L), pad_id, np.int64)
-                arr[valid] = flat[(starts[sel][:, None] + np.arange(L)[None, :])[valid]]
+                rows_n = n
+                if ladder is not None:
+                    L, rows_n = round_len(L, max_len), n_shape
+                valid = np.zeros((rows_n, L), bool)
+                valid[:n] = np.arange(L)[None, :] < lens[sel][:, None]
+                arr = np.full((rows_n, L), pad_id, np.int64)
+                arr[valid] = flat[(starts[sel][:, None] + np.arange(L)[None, :])[valid[:n]]]
+                valid[n:, 0] = True                                               # padding rows attend their one [PAD] token (no 0 / 0)
                 feats = {"input_ids": torch.from_numpy(arr), "attention_mask": torch.from_numpy(valid.astype(np.int64))}
                 rows = torch.from_numpy(idxs[sel])
                 if pin:
@@ -339,7 +370,7 @@ class RetrievalTrainingModule(torch.nn.Module):
         """Runs `produce(put, stop)` on a thread and hands every item it puts to `on_item` on this one, under the autocast setting."""
         import queue
         import threading
-        q_out: "queue.Queue" = queue.Queue(maxsize=8)
+        q_out: "queue.Queue" = queue.Queue(maxsize=int(os.environ.get("MFAR_ENCODE_QUEUE", "48")))   # (0.5 MB of pinned tokens per batch)
         stop = threading.Event()
 
         def run():
@@ -373,12 +404,27 @@ class RetrievalTrainingModule(torch.nn.Module):
             if was_training:
                 self.encoder.train()
 
-    def _forward_rows(self, feats, rows, emb_u) -> None:
+    def _forward_rows(self, feats, rows, emb_u, ac=None) -> None:
         dev = self.device
+        if self._graphed is not None:
+            # (a replay returns the graph's static output: the scatter below reads it on this stream before the next forward is enqueued)
+            emb_u[rows.to(dev, non_blocking=True)] = self._graphed(feats, ac)[:rows.shape[0]]
+            return
         f = {k: v.to(dev, non_blocking=True) for k, v in feats.items()}
         if "token_type_ids" in (getattr(self.encoder.tokenizer, "model_input_names", None) or ()):
             f["token_type_ids"] = torch.zeros_like(f["input_ids"])
-        emb_u[rows.to(dev, non_blocking=True)] = self.encoder(f)["sentence_embedding"].float()
+        emb_u[rows.to(dev, non_blocking=True)] = self.encoder(f)["sentence_embedding"].float()[:rows.shape[0]]
+
+    def _use_graphs(self) -> bool:
+        """Captured forwards for this encode?  (GPU, eval-mode forwards, MFAR_ENCODE_GRAPHS != 0.)  Creates / revalidates the graph cache."""
+        from mfar.modeling.graphed import GraphedForward
+        if not GraphedForward.enabled(self.device):
+            self._graphed = None
+            return False
+        if self._graphed is None or self._graphed.encoder is not self.encoder:
+            self._graphed = GraphedForward(self.encoder, self.device)
+        self._graphed.begin()
+        return True
 
     @torch.no_grad()
     def _encode_texts_prefetched(self, uniq, order, emb_u, bs, budget, max_len, ac) -> bool:
@@ -386,11 +432,12 @@ class RetrievalTrainingModule(torch.nn.Module):
         tokenizer has no Rust backend or MFAR_ENCODE_PREFETCH=0: the caller then takes the generic path (`candidate_encoding_stream`)."""
         if self._prefetch_backend() is None or not uniq:
             return False
+        graphs = self._use_graphs()
 
         def produce(put, stop):
-            for item in self._token_batches(uniq, order, bs, budget, max_len, stop):
+            for item in self._token_batches(uniq, order, bs, budget, max_len, stop, graphs):
                 put(item)
-        self._consume(produce, lambda item: self._forward_rows(item[0], item[1], emb_u), ac)
+        self._consume(produce, lambda item: self._forward_rows(item[0], item[1], emb_u, ac), ac)
         return True
 
     @torch.no_grad()
@@ -399,6 +446,7 @@ class RetrievalTrainingModule(torch.nn.Module):
         batches across the boundary -- the GPU does not drain between fields."""
         import numpy as np
         cur = {}
+        graphs = self._use_graphs()
 
         def produce(put, stop):
             for key, field in dense:
@@ -406,7 +454,7 @@ class RetrievalTrainingModule(torch.nn.Module):
                     return
                 docs, texts, uniq, slot, order = prepare(field)
                 put(("field", key, docs, len(uniq), np.fromiter((slot[t] for t in texts), np.int64, len(texts))))
-                for feats, rows in self._token_batches(uniq, order, bs, budget, max_len, stop):
+                for feats, rows in self._token_batches(uniq, order, bs, budget, max_len, stop, graphs):
                     put(("batch", feats, rows))
                 put(("end",))
 
@@ -415,7 +463,7 @@ class RetrievalTrainingModule(torch.nn.Module):
                 _, cur["key"], cur["docs"], n_uniq, cur["rows"] = item
                 cur["emb"] = torch.empty(n_uniq, self.slab.dim, device=self.device)
             elif item[0] == "batch":
-                self._forward_rows(item[1], item[2], cur["emb"])
+                self._forward_rows(item[1], item[2], cur["emb"], ac)
             else:
                 self._write_field(self.vectors_dict[cur["key"]], cur["docs"], cur["emb"], torch.from_numpy(cur["rows"]).to(self.device), bs)
                 cur.clear()

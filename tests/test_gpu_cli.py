@@ -273,6 +273,78 @@ def test_sparse_fields_and_bm25_negatives(tmp_path):
                                                       "feature_sparse,title_sparse", "brand_dense,title_dense"]
 
 
+def test_corpus_encode_replays_captured_forwards(tmp_path, monkeypatch):
+    """mfar/modeling/graphed.py: the corpus-encode forwards of a shape seen before are replayed from a captured graph -- the same bits as the
+    eager forward of that shape, under fp32 and under autocast; a replay reads the CURRENT weights (an in-place update between two encodes
+    is seen); MFAR_ENCODE_GRAPHS=0 = the eager pipeline, rows equal to rounding (other batch shapes)."""
+    import torch
+    from mfar.commands import train
+    data = str(tmp_path / "data")
+    _write_dataset(data, n_docs=400, n_q=101)
+
+    def encode(m):
+        m.mark_encoder_updated()
+        m.on_eval_start()
+        m.qres_output.close()
+        torch.cuda.synchronize()
+        return np.stack([m.slab.read_rows(f) for f in range(2)])
+    for mode in ("", "fp16"):
+        monkeypatch.setenv("MFAR_ENCODE_AUTOCAST", mode)
+        monkeypatch.setenv("MFAR_ENCODE_GRAPHS", "1")
+        m = train.main(dataset_name="amazon", lexical_index="unused", out=str(tmp_path / f"out{mode}"), temp_dir=str(tmp_path / f"tmp{mode}"),
+                       data=data, model_name="random-init:64x2", field_names="title_dense,brand_dense", weights_lr=1e-2, max_epochs=0,
+                       dev_batch_size=16, precision="32")
+        encode(m)
+        g = m._graphed
+        assert g is not None and not g.failed
+        g.reset()
+        cap, g.max_graphs = g.max_graphs, 0     # nothing captured: the eager forwards at the graph shapes
+        r0 = g.n_replays
+        first = encode(m)
+        assert g.n_replays == r0 and not g.graphs
+        g.max_graphs = cap
+        encode(m)                               # every shape of this corpus seen twice by now: captured
+        r0, e0 = g.n_replays, g.n_eager
+        again = encode(m)
+        assert g.n_replays > r0 and g.n_eager == e0 and len(g.graphs) >= 1, (g.n_replays, g.n_eager, len(g.graphs))
+        assert np.array_equal(first, again)     # replays = the eager forwards of the same shapes, bit for bit
+        monkeypatch.setenv("MFAR_ENCODE_GRAPHS", "0")
+        eager = encode(m)
+        assert m._graphed is None
+        scale = float(np.abs(eager).max())
+        assert np.abs(eager - again).max() <= (2e-5 if mode == "" else 4e-3) * scale
+        assert len(np.unique(again[1], axis=0)) == len(np.unique(eager[1], axis=0))       # brand: the same duplicate structure
+        # an in-place weight update: the graphs stay (same addresses) and replay the new weights
+        monkeypatch.setenv("MFAR_ENCODE_GRAPHS", "1")
+        encode(m)
+        encode(m)
+        g = m._graphed
+        n_graphs = len(g.graphs)
+        assert n_graphs >= 1
+        with torch.no_grad():
+            for p_ in m.encoder.parameters():
+                p_.mul_(1.25)
+        r0 = g.n_replays
+        moved = encode(m)
+        assert m._graphed is g and len(g.graphs) == n_graphs and g.n_replays > r0
+        monkeypatch.setenv("MFAR_ENCODE_GRAPHS", "0")
+        want = encode(m)
+        assert np.abs(moved - want).max() <= (2e-5 if mode == "" else 4e-3) * float(np.abs(want).max())
+        assert np.abs(moved - again).max() > 1e-2 * scale
+        # parameters that MOVED: the graphs are dropped, not replayed against stale addresses
+        monkeypatch.setenv("MFAR_ENCODE_GRAPHS", "1")
+        encode(m)
+        g = m._graphed
+        m.encoder.float()                        # (a no-op: same storage) ...
+        encode(m)
+        assert len(g.graphs) >= 1
+        for p_ in m.encoder.parameters():        # ... a real move
+            p_.data = p_.data.clone()
+        encode(m)
+        assert g.n_eager > 0 and np.isfinite(m.slab.read_rows(0)).all()
+        assert np.abs(np.stack([m.slab.read_rows(f) for f in range(2)]) - want).max() <= (2e-5 if mode == "" else 4e-3) * float(np.abs(want).max())
+
+
 def test_corpus_encode_under_autocast(tmp_path, monkeypatch):
     """MFAR_ENCODE_AUTOCAST=bf16: the corpus encode runs under bf16 autocast, the slab still holds fp32 rows, and
     they stay close to the fp32 encode's (same texts -> bit-identical duplicate rows either way)."""

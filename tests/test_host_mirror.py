@@ -442,10 +442,12 @@ def test_prefetched_corpus_encode_equals_the_generic_path(monkeypatch):
     order = sorted(range(len(uniq)), key=lambda i: len(uniq[i]))
     class Stub:                                                       # the methods under test on an object that is not a LightningModule
         pass
-    for name in ("_prefetch_backend", "_token_batches", "_consume", "_forward_rows", "_encode_texts_prefetched", "_encode_fields_prefetched"):
+    for name in ("_prefetch_backend", "_token_batches", "_consume", "_forward_rows", "_encode_texts_prefetched", "_encode_fields_prefetched",
+                 "_use_graphs"):
         setattr(Stub, name, getattr(RetrievalTrainingModule, name))
     Stub._write_field = staticmethod(RetrievalTrainingModule._write_field)
     stub = Stub()
+    stub._graphed = None                                              # (captured forwards are a GPU matter: tests/test_gpu_cli.py)
     stub.encoder, stub.device = enc, torch.device("cpu")
     E = enc.get_sentence_embedding_dimension()
     want = torch.stack([enc.encode([t], batch_size=1, convert_to_tensor=True)[0] for t in uniq])           # every text alone
@@ -464,6 +466,26 @@ def test_prefetched_corpus_encode_equals_the_generic_path(monkeypatch):
     assert stub._encode_texts_prefetched(many, order_m, got, 64, 64 * 24, 24, None)
     ref = enc.encode(many, batch_size=64, convert_to_tensor=True)
     assert not torch.isnan(got).any() and torch.allclose(got, ref, atol=2e-5, rtol=0)
+    # the shape family of captured forwards (mfar/modeling/graphed.py; the GPU half is tests/test_gpu_cli.py): texts per batch from the ladder,
+    # lengths in steps of 8 tokens, the budget kept, padding rows attend one token, every text exactly once, same rows as above
+    import threading as _th
+    from mfar.modeling.graphed import shape_ladder
+    assert shape_ladder(64)[0] == 4096 and shape_ladder(64)[-1] == 64 and shape_ladder(64) == sorted(shape_ladder(64), reverse=True)
+    assert shape_ladder(8192) == [8192]
+    for bs, budget in ((8, 8 * 24), (4, 0), (64, 64 * 24)):
+        seen, shapes = [], set()
+        got = torch.full((len(many), E), float("nan"))
+        for feats, rows in stub._token_batches(many, order_m, bs, budget, 24, _th.Event(), True):
+            n, L = feats["input_ids"].shape
+            assert n in shape_ladder(bs) and (L % 8 == 0 or L == 24) and L <= 24 and len(rows) <= n
+            assert n == bs or n * L <= budget
+            assert (feats["attention_mask"].sum(1) >= 1).all() and (feats["attention_mask"][len(rows):].sum(1) == 1).all()
+            shapes.add((n, L))
+            seen += rows.tolist()
+            got[rows] = enc(dict(feats))["sentence_embedding"].float()[:len(rows)].detach()
+        assert sorted(seen) == list(range(len(many)))
+        assert len(shapes) <= 8
+        assert torch.allclose(got, ref, atol=2e-5, rtol=0)
     # all fields through ONE producer: rows land in corpus order in each field's vectors, repeated texts get the one row of their text
     written = {}
     stub.slab = types.SimpleNamespace(dim=E)

@@ -286,7 +286,13 @@ def run(n_docs=50000, n_queries=256, model="random-init:768x12", sweep=True, qui
                 slab = module.slab
                 rows = slab.read_rows(probe_field, 0, min(2048, n_docs)).copy()
                 key = "fp32" if mode == "fp32" else "autocast_" + mode
+                while key in out:                # the same mode again (--modes bf16,bf16,bf16: what a RE-encode costs once forwards are captured)
+                    key += "_again"
                 out[key] = {"seconds": dt, "docs_per_s": n_docs / dt, "sequences_per_s": n_seq / dt, "tokens_per_s": n_tok / dt}
+                gf = getattr(module, "_graphed", None)
+                out[key]["captured_forwards"] = None if gf is None else {
+                    "graphs_held": len(gf.graphs), "replays_so_far": gf.n_replays, "eager_forwards_so_far": gf.n_eager, "capture_failed": gf.failed,
+                    "what": "mfar/modeling/graphed.py: forwards of a shape seen before are hipGraph replays (captures are inside `seconds`)"}
                 if mode == "fp32":
                     ref_rows = rows
                 elif ref_rows is not None:
