@@ -6,18 +6,19 @@ padding into pinned buffers) and 9.4 s (this thread: copy -> forward -> scatter;
 is 12-15 ms of GPU time and ~10 ms of Python on the launching thread (300 kernels behind HF's module tree and autocast's dispatch): alone that
 is hidden -- the queue stays full, a replay of the same forward is 1 % faster -- but the launching thread shares the interpreter lock with
 the producer, and whenever the producer holds it the launches stop.  A replay is one call: the launching thread hardly needs the lock.
-Measured: first encode of a process 11.3 s (72 captures included; eager 11.5-11.7 s with the same producer), every later encode 10.0 s
-(eager 11.4-12.6 s).
+Measured (`r06_k2_encode_graphs_ab.txt`): every RE-encode of a process 10.0-10.4 s (eager 11.4-12.0 s); a process's FIRST encode gains
+nothing (12.5 s: 72 captures, each checked against the eager forward) -- hence OPT-IN, `MFAR_ENCODE_GRAPHS=1`, for runs that encode the
+corpus many times (training with an evaluation per epoch).
 
 What is captured: `encoder(features)["sentence_embedding"].float()` for ONE static shape `[n, L]` per graph, in eval mode, under the run's
 autocast setting with autocast's weight-cast cache OFF -- the casts are part of the graph, so a replay reads the CURRENT parameter values
 (in-place optimizer steps between two encodes are seen; parameters that MOVED are detected by `signature()` and the graphs dropped).
 The producer cuts batches to a small family of shapes (`shape_ladder`, lengths rounded up to 8 tokens); a shape is captured the second
-time it shows up (a shape seen once is not worth three forwards), at most `max_graphs` of them; anything else runs eagerly.  All graphs share
+time it shows up (a shape seen once is not worth the capture and its check), at most `max_graphs` of them; anything else runs eagerly.  All graphs share
 one memory pool: they are replayed one at a time on one stream and every output is consumed (scattered into the field's rows) on that
 stream before the next replay.
 
-Not the product path: `csrc/` never sees this file; it feeds rows to `mfar_index_write_rows` faster.  MFAR_ENCODE_GRAPHS=0 turns it off.
+Not the product path: `csrc/` never sees this file; it feeds rows to `mfar_index_write_rows` faster.
 """
 from __future__ import annotations
 
@@ -52,6 +53,7 @@ class GraphedForward:
         self.warmed = set()
         self.graphs: Dict[Tuple, Tuple] = {}       # (n, L, autocast dtype) -> (graph, static inputs, static output)
         self.seen: Dict[Tuple, int] = {}
+        self.rejected = set()                      # shapes whose graph did not reproduce the eager forward
         self.sig = None
         self.failed = False                        # a capture raised: the encoder does not capture (data-dependent control flow); eager from then on
         self.n_replays = self.n_eager = 0
@@ -60,7 +62,7 @@ class GraphedForward:
 
     @staticmethod
     def enabled(device: torch.device) -> bool:
-        return device.type == "cuda" and os.environ.get("MFAR_ENCODE_GRAPHS", "1") != "0"
+        return device.type == "cuda" and os.environ.get("MFAR_ENCODE_GRAPHS", "0") == "1"
 
     def signature(self):
         """Where the parameters live.  A graph holds addresses: after `.to()`, `load_state_dict(assign=True)` or a dtype change the old ones
@@ -77,6 +79,7 @@ class GraphedForward:
     def reset(self) -> None:
         self.graphs.clear()
         self.seen.clear()
+        self.rejected.clear()
         self.pool = None
 
     def _eager(self, f, ac):
@@ -128,13 +131,25 @@ class GraphedForward:
             f["token_type_ids"] = torch.zeros_like(f["input_ids"])
         count = self.seen.get(key, 0) + 1
         self.seen[key] = count
-        if count >= 2 and not self.failed and len(self.graphs) < self.max_graphs and not self.encoder.training:
+        if count >= 2 and not self.failed and key not in self.rejected and len(self.graphs) < self.max_graphs and not self.encoder.training:
             try:
                 self._capture(key, f, ac)
                 g, _, out = self.graphs[key]
+                # every graph is CHECKED before it is trusted: two replays, the second compared with the eager forward of the same input
+                # (what was found wrong on this stack -- SentenceEncoder.forward on `(tok * m).sum(1)` at L >= 512 -- was right on the first
+                # replay and wrong from the second on).  Costs two forwards per shape, once.
+                want = self._eager(f, ac)
+                g.replay()
                 g.replay()
                 self.n_replays += 1
-                return out
+                tol = 0.0 if ac is None else 4e-3 * float(want.abs().max())     # (fp16 GEMMs of some shapes are not run-to-run identical: 1e-3)
+                if bool(((out - want).abs() <= tol).all()):
+                    return out
+                import warnings
+                self.rejected.add(key)
+                self.graphs.pop(key, None)
+                warnings.warn(f"corpus-encode graph of shape {key[:2]} does not replay the eager forward's result; that shape runs eagerly")
+                return want
             except Exception as e:      # noqa: BLE001 -- an encoder that does not capture: eager from now on, loudly
                 import warnings
                 self.failed = True

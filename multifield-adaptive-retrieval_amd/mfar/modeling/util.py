@@ -79,8 +79,13 @@ class SentenceEncoder(torch.nn.Sequential):
 
     def forward(self, features) -> Dict[str, torch.Tensor]:
         tok = self[0](features)
-        m = features["attention_mask"].unsqueeze(-1).to(tok.dtype)
-        emb = (tok * m).sum(1) / m.sum(1).clamp(min=1e-9)      # Pooling(mean): sum of unmasked tokens / their count
+        # Pooling(mean): sum of unmasked tokens / their count, as ONE batched product [n, 1, L] x [n, L, E] in fp32 (outside autocast).
+        # Not `(tok * m).sum(1)`: at L >= 512 a captured graph replays that expression WRONG on this stack from the second replay on
+        # (profiles/r06_k_graph_reduce_probe.txt: difference ~100 on N(0,1) inputs at L = 512 / 1024 / 4096, none below 512; the product
+        # alone, the sum alone and the eager expression are all right) -- and mfar/modeling/graphed.py replays these forwards.
+        m = features["attention_mask"].unsqueeze(1).to(torch.float32)
+        with torch.autocast(device_type=tok.device.type, enabled=False):
+            emb = (torch.bmm(m, tok.float()) / torch.bmm(m, m.transpose(1, 2)).clamp(min=1e-9)).squeeze(1).to(tok.dtype)
         if self.dense is not None:
             emb = self.dense(emb)
         if self.normalize:
@@ -134,7 +139,11 @@ def _tiny_random_model(spec: str):
                                                       special_tokens=[("[CLS]", ids["[CLS]"]), ("[SEP]", ids["[SEP]"])])
     tok = PreTrainedTokenizerFast(tokenizer_object=tk, unk_token="[UNK]", pad_token="[PAD]", cls_token="[CLS]", sep_token="[SEP]",
                                   mask_token="[MASK]")
-    cfg = BertConfig(vocab_size=len(vocab), hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=max(1, hidden // 32),
+    # heads of 64 dims from 128 up -- "768x12" is BERT-base / contriever's shape exactly (12 layers, 12 heads x 64, 3072 in the FFN); the
+    # tiny plumbing models keep heads of 32.  (Until round 6 every size had heads of 32: 24 heads at 768, whose attention kernel took a
+    # third of a forward's GPU time -- an artefact of the stand-in, not of the encoder the reference runs.)
+    heads = hidden // 64 if hidden >= 128 and hidden % 64 == 0 else max(1, hidden // 32)
+    cfg = BertConfig(vocab_size=len(vocab), hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
                      intermediate_size=hidden * 4, max_position_embeddings=512)
     torch.manual_seed(0)
     return tok, BertModel(cfg).eval()       # from_pretrained() also hands models out in eval mode

@@ -345,6 +345,59 @@ def test_corpus_encode_replays_captured_forwards(tmp_path, monkeypatch):
         assert np.abs(np.stack([m.slab.read_rows(f) for f in range(2)]) - want).max() <= (2e-5 if mode == "" else 4e-3) * float(np.abs(want).max())
 
 
+def test_captured_forward_at_the_encoders_full_length():
+    """A BERT-base-wide encoder at L = 512 (truncated documents: the commonest shape of a long field).  There a captured graph replays the
+    old mean pooling `(tok * m).sum(1)` wrong from the SECOND replay on (profiles/r06_k_graph_reduce_probe.txt); SentenceEncoder.forward
+    pools by a batched product instead, and GraphedForward checks every graph against the eager forward before it trusts it.
+    Replays 1..5 on fresh inputs = the eager forward, bit for bit (fp32)."""
+    import torch
+    from mfar.modeling.graphed import GraphedForward
+    from mfar.modeling.util import prepare_model
+    dev = torch.device("cuda:0")
+    enc = prepare_model("random-init:768x1")[1].to(dev).eval()
+    g = GraphedForward(enc, dev)
+    g.begin()
+    gen = torch.Generator().manual_seed(3)
+
+    def batch():
+        ids = torch.randint(5, 60, (16, 512), generator=gen)
+        lens = torch.randint(300, 513, (16,), generator=gen)
+        return {"input_ids": ids, "attention_mask": (torch.arange(512)[None, :] < lens[:, None]).long()}
+
+    def eager(f):
+        with torch.no_grad():
+            d = {k: v.to(dev) for k, v in f.items()}
+            d["token_type_ids"] = torch.zeros_like(d["input_ids"])
+            return enc(d)["sentence_embedding"].float()
+    f = batch()
+    assert torch.equal(g(f, None), eager(f)) and not g.graphs                   # first sight: eager
+    f = batch()
+    assert torch.equal(g(f, None).clone(), eager(f))                            # second sight: captured, checked, replayed
+    assert len(g.graphs) == 1 and not g.rejected and not g.failed
+    for _ in range(5):
+        f = batch()
+        out = g(f, None).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager(f))
+    assert g.n_replays >= 6 and g.n_eager == 1
+    # the hazard itself (informational: printed, so that a run with -s says when the stack stops having it)
+    x = torch.randn(16, 512, 768, device=dev)
+    m = (torch.rand(16, 512, 1, device=dev) > 0.3).float()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        (x * m).sum(1)
+    torch.cuda.current_stream().wait_stream(s)
+    cg = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(cg, stream=s):
+        y = (x * m).sum(1)
+    cg.replay()
+    x.normal_()
+    cg.replay()
+    torch.cuda.synchronize()
+    print("captured (x * m).sum(1) at L = 512, second replay: max difference to the eager result", float((y - (x * m).sum(1)).abs().max()))
+
+
 def test_corpus_encode_under_autocast(tmp_path, monkeypatch):
     """MFAR_ENCODE_AUTOCAST=bf16: the corpus encode runs under bf16 autocast, the slab still holds fp32 rows, and
     they stay close to the fp32 encode's (same texts -> bit-identical duplicate rows either way)."""
