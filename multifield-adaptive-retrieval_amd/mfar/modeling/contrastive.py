@@ -217,7 +217,8 @@ class RetrievalTrainingModule(torch.nn.Module):
         # forward, so a batch takes as many of them as fit that budget (at least dev_batch_size; MFAR_ENCODE_TOKEN_BUDGET=0:
         # always dev_batch_size).  Lengths ascend, so the last text of a batch is its longest.
         max_len = int(self.encoder.get_max_seq_length())
-        budget = bs * max_len if os.environ.get("MFAR_ENCODE_TOKEN_BUDGET", "1") != "0" else 0
+        tb = os.environ.get("MFAR_ENCODE_TOKEN_BUDGET", "1")             # 0: always dev_batch_size texts; 1: the default; n > 1: n tokens
+        budget = 0 if tb == "0" else (int(tb) if tb.isdigit() and int(tb) > 1 else bs * max_len)
         # Precision of the corpus-encode forwards: `self.encode_precision`, overridden by MFAR_ENCODE_AUTOCAST=fp32|fp16|bf16.
         # The reference encodes the corpus outside its precision plugin (which wraps the steps, not on_test_epoch_start) but with
         # torch.set_float32_matmul_precision("high") (train.py:67, mask_fields.py:52): fp32 matmuls may run with 10-bit-mantissa inputs on
@@ -239,7 +240,7 @@ class RetrievalTrainingModule(torch.nn.Module):
                 while pos < len(order):
                     n = min(bs, len(order) - pos)
                     if budget:
-                        n = min(4096, len(order) - pos)
+                        n = min(max(4096, budget // 8), len(order) - pos)
                         while n > bs and n * min(max_len, len(uniq[order[pos + n - 1]]) // 3 + 8) > budget:
                             n = max(bs, (n * 3) // 4)
                         # len // 3 + 8 is an estimate for English prose; digit-heavy, CJK or byte-level texts run ~1 token per
@@ -345,7 +346,7 @@ class RetrievalTrainingModule(torch.nn.Module):
                     n = min(n_shape, rem)
                     n_shape = min(v for v in ladder if v >= n and v <= n_shape)
                 elif budget:
-                    n = min(4096, rem)
+                    n = min(max(4096, budget // 8), rem)
                     while n > bs and n * int(lens[o2[pos + n - 1]]) > budget:     # lengths ascend: the last text is the longest
                         n = max(bs, (n * 3) // 4)
                 sel = o2[pos:pos + n]
