@@ -160,7 +160,9 @@ def screen_probe(module, st, warm_passes=10, timed_passes=10):
         return dt, out, red
 
     mode0, _ = ix.screen_setting
-    ix.set_screen(1)
+    # (MFAR_PROBE_EPS_MULT: probes only -- the certificate's bound scaled, e.g. ~0 = every first certificate passes, UNSOUND: what the
+    # same vectors would cost without tier 2; the bits line then says whether any result differed)
+    ix.set_screen(1, float(os.environ.get("MFAR_PROBE_EPS_MULT", "1")))
     s0, t20 = ix.screen_stats(), ix.tier2_stats()
     t_learn, _, red_learn = serve(warm_passes, False)
     s1, ao1, t21 = ix.screen_stats(), ix.auto_off_info(), ix.tier2_stats()
