@@ -46,7 +46,7 @@ typedef struct mfar_index mfar_index;
 
 /* library / device probes (no reference counterpart).  mfar_version() == MFAR_ABI_VERSION of the header the caller was built
  * against, or the caller must refuse the library: the value changes with every signature change. */
-#define MFAR_ABI_VERSION 106
+#define MFAR_ABI_VERSION 107
 int mfar_version(void);
 const char* mfar_last_error(void);
 int mfar_device_count(int* n_out);
@@ -411,11 +411,19 @@ int mfar_set_auto_off(mfar_index* idx, int mode, int off_fails, int probe_every)
  * mfar_tier2_stats synchronises the device: whether tier 2 is armed now; lists handed to it / lists it had to pass on to the exact pass
  * since the handle was created; causes [4] = why: a chunk list of the (re)scan reached its depth, more than 8192 rows above the threshold,
  * more than 2048 candidates in the band, ties across the cut.  Any pointer may be NULL.
+ * The rescan is the FALLBACK (ABI 107): the launch's own scan appended every row scoring at least its sample threshold tg(q, f) to its
+ * chunk lists, and tg -- the k'-th best of a few percent of the rows -- usually lies below the list's tier-2 threshold T; where tg <= T and
+ * no chunk list of the list was ever compacted (both checked on the device, per list), the candidates are the entries >= T of the lists
+ * that scan already wrote and nothing is scanned twice.  mfar_tier2_rescan_stats (synchronises): lists whose candidates came from the
+ * launch's own scan / lists that needed the rescan, since the handle was created.  mode + 4 (or environment MFAR_T2_FIRST_SCAN=0): every
+ * list takes the rescan (diagnostic: the fallback path on demand).
  */
 int mfar_set_tier2(mfar_index* idx, int mode);
+int mfar_tier2_rescan_stats(mfar_index* idx, int64_t* n_from_scan, int64_t* n_rescanned);
 /*
  * DEEP SCAN: tier 2 without the first attempt, for fields whose first certificates keep failing (no reference counterpart; outputs
- * bit-identical in every mode).  Such a field pays its screened scan twice (first attempt + rescan).  Once the library has seen a field fail
+ * bit-identical in every mode).  Such a field paid its screened scan twice (first attempt + rescan) when this was built -- tier 2 has
+ * since learned to take its candidates from the first attempt's own chunk lists, which removes the reason.  Once the library has seen a field fail
  * its first certificate in 8 of its last 16 launches it stops certifying it: the ONE scan of the field runs with a complete-set threshold
  * taken from the sample pass -- T = (k-th largest sampled score) - 2 eps: k rows score at least the k-th sampled score, so the true k-th best
  * exact score is at least that minus eps and every row of the exact top-k scores approximately >= T -- its chunk lists then hold every
@@ -425,7 +433,8 @@ int mfar_set_tier2(mfar_index* idx, int mode);
  * (mfar_set_tier2 != 0), an fp32 index, and a shape whose scan runs the light sample pass.
  * OFF by default: measured it is 11 % slower than certificates on rows that certify, and on clustered rows the
  * sample-derived threshold is too loose -- 5 % of the lists hold more than 8192 rows above it, and ONE overflowing list costs its field
- * the exact pass -- so the two-scan tier 2 (26 k q/s on the hostile corpus) beats it (16 k).  Kept as a measured, tested alternative.
+ * the exact pass -- so tier 2 (26 k q/s on the hostile corpus with the rescan, 40 k without) beats it (16 k).  Kept as a measured, tested
+ * alternative.
  *   mode   0 = never (default; environment MFAR_SCREEN_DEEP), 1 = auto, 2 = every field, always (a test / experiment setting).
  * mfar_deep_scan_info: bit f of deep_fields = field f runs as a deep field now; fields switched to it so far.
  */

@@ -142,6 +142,8 @@ struct mfar_index {
         DevBuf chain;                                                   // bf16 index: scores of the exhaustive chain pass (mfar_exact16.h), [CHAIN_QB][rows]
         DevBuf tau2, lfail, t2cand, t2cnt, t2sx;                        // TIER 2 (mfar_screen.h): thresholds [F, qw], per-list flags, candidate sets [qw, F, T2_CAP]
         bool t2 = false;                                                // this batch runs tier 2 behind its certificate (latched by the begin phase)
+        const float* scan_tau = nullptr;                                // thresholds [F, qw] the batch's screened scan ran with (nullptr: none) -- tier 2's
+                                                                        // collect kernel checks them against its own before it trusts that scan's chunk lists
         u32 deep_mask = 0;                                              // DEEP SCAN fields of this batch (latched by the begin phase; mfar_screen.h)
         u32 fb_deep = 0;                                                // ... as reported with the batch's feedback
         DevBuf deepinfo;                                                // [F, qw] float4 {band, eps, exact 0} in scan units (mfar_sample_tau_kernel)
@@ -190,6 +192,7 @@ struct mfar_index {
                                   // pipelined searcher calls it), 2 always.  MFAR_SCREEN_ROW_MODE
     int deep_mode = 0;            // DEEP SCAN of fields whose first certificates keep failing (mfar_screen.h): 0 never, 1 auto (policy), 2 every
                                   // field always (tests / experiments).  MFAR_SCREEN_DEEP
+    bool t2_force_rescan = false; // diagnostic (mfar_set_tier2 mode + 4): tier 2 never trusts the launch's own chunk lists
     int tier2_mode = 1;           // TIER 2 of the certified screen (mfar_screen.h "threshold rescan"): 0 never, 1 auto (its kernels are
                                   // enqueued while the policy has seen a failed certificate recently), 2 always.  MFAR_SCREEN_TIER2
     int dump_mode = 1;            // 0 never, 1 when it moves fewer bytes than the row gathers (dump_wanted), 2 whenever possible
@@ -1031,6 +1034,7 @@ static int stage1_pass(mfar_index* idx, mfar_index::S1Slot& sl, S1Geom& geom, in
             p.unit_ctr = sl.unit_ctr.as<int>();
             p.unit_tiles = unit_tiles;
         }
+        if (!t2 && !repair) sl.scan_tau = p.gtau;       // (the screened pass of the batch; the exact passes write no chunk lists tier 2 reads)
         // (t2: the 16-bit kernels take one chunk per workgroup, flagged or not -- the grid is the whole chunk range)
         RETCHK(launch_s1(kind, false, grid, t2 ? grid : (unsigned)(idx->wgs_per_cu * idx->n_cu), st, p, record ? &idx->last_s1_kernel : nullptr));
     }
@@ -1857,14 +1861,9 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         dbg.release();
     }
     if (t2_run) {
-        // TIER 2 (mfar_screen.h): rescan of the fields that hold failed lists with their fixed thresholds -> the complete candidate sets ->
-        // exact scores -> the certify kernel again, on those lists only.  Every kernel is idle when nothing failed.
-        if (bf16)
-            RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, S1_SCAN, bkind, idx->slab, sl.qt16.p, qt_n, kp, -INFINITY, sl.tau2.as<float>(),
-                               fflags + SCREEN_T2_FIELDS, false, so, st, sl.skip_mask, false, true));
-        else
-            RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, S1_SCAN, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
-                               sl.tau2.as<float>(), fflags + SCREEN_T2_FIELDS, false, so, st, sl.skip_mask, false, true));
+        // TIER 2 (mfar_screen.h): the complete candidate sets of the failed lists -- from the chunk lists the batch's own scan wrote where
+        // those provably hold them (collect pass A), else by rescanning the fields that hold such lists with their fixed thresholds (pass B)
+        // -> exact scores -> the certify kernel again, on those lists only.  Every kernel is idle when nothing failed.
         const S1Geom& g2 = bf16 ? idx->geom_docs : idx->geom_screen;
         const S1Table& tb2 = qw == 128 ? (sl.skip_mask ? g2.all_w_skip : g2.all_w) : (sl.skip_mask ? g2.all_skip : g2.all);
         T2CollectParams tc = {};
@@ -1879,10 +1878,23 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         tc.qw = qw;
         tc.kp = kp;
         tc.stats = fflags;
+        tc.tau2 = sl.tau2.as<float>();
+        tc.scan_tau = sl.scan_tau;
         tc.deep_mask = sl.deep_mask;
         tc.k = k;
         tc.sentinel = sentinel;
         tc.info = sl.deepinfo.as<float4>();
+        static const bool t2_first = !(getenv("MFAR_T2_FIRST_SCAN") && atoi(getenv("MFAR_T2_FIRST_SCAN")) == 0);   // diagnostic: 0 = always rescan
+        tc.no_first = t2_first && !idx->t2_force_rescan ? 0 : 1;
+        mfar_t2_collect_kernel<<<dim3(qt_n * nf), dim3(256), T2_COLLECT_LDS_BYTES, st>>>(tc);
+        HIPCHK(hipGetLastError());
+        if (bf16)
+            RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, S1_SCAN, bkind, idx->slab, sl.qt16.p, qt_n, kp, -INFINITY, sl.tau2.as<float>(),
+                               fflags + SCREEN_T2_RESCAN_FIELDS, false, so, st, sl.skip_mask, false, true));
+        else
+            RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, S1_SCAN, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
+                               sl.tau2.as<float>(), fflags + SCREEN_T2_RESCAN_FIELDS, false, so, st, sl.skip_mask, false, true));
+        tc.pass_b = 1;
         mfar_t2_collect_kernel<<<dim3(qt_n * nf), dim3(256), T2_COLLECT_LDS_BYTES, st>>>(tc);
         HIPCHK(hipGetLastError());
         ScoreParams s2 = sp;
@@ -2015,8 +2027,10 @@ extern "C" int mfar_set_auto_off(mfar_index* idx, int mode, int off_fails, int p
     return MFAR_OK;
 }
 extern "C" int mfar_set_tier2(mfar_index* idx, int mode) {
-    if (!idx || mode < 0 || mode > 2) return fail(MFAR_ERR_INVALID, "mode must be 0 (never), 1 (auto: armed by failed certificates) or 2 (always)");
-    idx->tier2_mode = mode;
+    if (!idx || mode < 0 || (mode & 3) > 2 || mode > 6)
+        return fail(MFAR_ERR_INVALID, "mode must be 0 (never), 1 (auto: armed by failed certificates) or 2 (always); + 4: always take the rescan (diagnostic)");
+    idx->tier2_mode = mode & 3;
+    idx->t2_force_rescan = (mode & 4) != 0;
     return MFAR_OK;
 }
 extern "C" int mfar_set_deep_scan(mfar_index* idx, int mode) {
@@ -2055,6 +2069,22 @@ extern "C" int mfar_tier2_stats(mfar_index* idx, int* armed, int64_t* n_lists, i
     if (n_passed_on) *n_passed_on = b;
     if (causes)
         for (int i = 0; i < 4; ++i) causes[i] = c[i];
+    return MFAR_OK;
+}
+extern "C" int mfar_tier2_rescan_stats(mfar_index* idx, int64_t* n_from_scan, int64_t* n_rescanned) {
+    if (!idx) return fail(MFAR_ERR_INVALID, "idx is NULL");
+    HIPCHK(hipSetDevice(idx->device));
+    int64_t a = 0, b = 0;
+    for (auto& sl : idx->s1)
+        if (sl.fail.p) {
+            HIPCHK(hipDeviceSynchronize());
+            int v[2] = {0, 0};        // {SCREEN_STAT_T2_RESCAN, SCREEN_STAT_T2_FIRST}
+            HIPCHK(hipMemcpy(v, sl.fail.as<int>() + SCREEN_STAT_T2_RESCAN, 8, hipMemcpyDeviceToHost));
+            b += v[0];
+            a += v[1];
+        }
+    if (n_from_scan) *n_from_scan = a;
+    if (n_rescanned) *n_rescanned = b;
     return MFAR_OK;
 }
 extern "C" int mfar_auto_off_info(mfar_index* idx, uint32_t* off_fields, int64_t* n_switched_off, int64_t* n_switched_on, int64_t* n_probes,

@@ -37,10 +37,14 @@
                                  // costs ~1 % and makes a failed certificate -- a 0.9 ms exact pass per field -- rarer)
 #define SCREEN_MAX_KP S1_MAX_DEPTH   // the stage-1 lists compact to k', which must leave room for one tile of appends
 #define SCREEN_SLACK 1.25f
-#define SCREEN_FLAGS (3 * MFAR_MAX_FIELDS + 9)   // ints of a batch's certificate flags (CertifyParams::fail)
+#define SCREEN_FLAGS (4 * MFAR_MAX_FIELDS + 11)  // ints of a batch's certificate flags (CertifyParams::fail)
+#define SCREEN_STAT_T2_RESCAN (3 * MFAR_MAX_FIELDS + 9)     // statistics: lists of tier 2 whose candidates needed the RESCAN ...
+#define SCREEN_STAT_T2_FIRST (3 * MFAR_MAX_FIELDS + 10)     // ... / were taken from the chunk lists the batch's own scan had written
+#define SCREEN_T2_RESCAN_FIELDS (3 * MFAR_MAX_FIELDS + 11)  // [MFAR_MAX_FIELDS] per batch: field f holds such a list (selects the rescan's
+                                                            // fields; cleared by the query kernel)
 #define SCREEN_STAT_T2_OVF (3 * MFAR_MAX_FIELDS + 5)   // statistics [4]: why tier 2 passed lists on -- a chunk list reached its depth / more than
                                                        // T2_CAP_IN rows above the threshold / more than T2_CAP candidates in the band / ties at the cut
-#define SCREEN_T2_FIELDS (2 * MFAR_MAX_FIELDS + 5)     // [MFAR_MAX_FIELDS] per batch: field f has lists for tier 2 (selects its rescan; cleared by the query kernel)
+#define SCREEN_T2_FIELDS (2 * MFAR_MAX_FIELDS + 5)     // [MFAR_MAX_FIELDS] per batch: field f has lists for tier 2 (the policy's input; cleared by the query kernel)
 #define SCREEN_FLAG_T1 (2 * MFAR_MAX_FIELDS + 2)       // per batch: some list failed the FIRST certificate (tier 2 had work; cleared by the query kernel)
 #define SCREEN_STAT_T2_LISTS (2 * MFAR_MAX_FIELDS + 3) // statistics: lists handed to tier 2 ...
 #define SCREEN_STAT_T2_FAILED (2 * MFAR_MAX_FIELDS + 4)   // ... and lists tier 2 could not finish either (overflow: the exact pass decides)
@@ -340,7 +344,7 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
     if (r == 0 && (int)threadIdx.x <= MFAR_MAX_FIELDS) fail_flags[threadIdx.x] = 0;
     if (r == 0 && (int)threadIdx.x < MFAR_MAX_FIELDS) fail_flags[MFAR_MAX_FIELDS + 2 + threadIdx.x] = 0;      // ... and the probe flags
     if (r == 0 && threadIdx.x == 0) fail_flags[SCREEN_FLAG_T1] = 0;
-    if (r == 0 && (int)threadIdx.x < MFAR_MAX_FIELDS) fail_flags[SCREEN_T2_FIELDS + threadIdx.x] = 0;
+    if (r == 0 && (int)threadIdx.x < MFAR_MAX_FIELDS) fail_flags[SCREEN_T2_FIELDS + threadIdx.x] = fail_flags[SCREEN_T2_RESCAN_FIELDS + threadIdx.x] = 0;
     const bool live = q0 + r < Q;
     const float* row = q + (size_t)(q0 + (live ? r : 0)) * E;
     // ONE round of global loads (this kernel opens a batch on the critical path, usually while the previous batch's gathers
@@ -545,7 +549,7 @@ __global__ void __launch_bounds__(256) mfar_direct_queries_kernel(const float* _
     if (r == 0 && (int)threadIdx.x <= MFAR_MAX_FIELDS) fail_flags[threadIdx.x] = 0;
     if (r == 0 && (int)threadIdx.x < MFAR_MAX_FIELDS) fail_flags[MFAR_MAX_FIELDS + 2 + threadIdx.x] = 0;      // ... and the probe flags
     if (r == 0 && threadIdx.x == 0) fail_flags[SCREEN_FLAG_T1] = 0;
-    if (r == 0 && (int)threadIdx.x < MFAR_MAX_FIELDS) fail_flags[SCREEN_T2_FIELDS + threadIdx.x] = 0;
+    if (r == 0 && (int)threadIdx.x < MFAR_MAX_FIELDS) fail_flags[SCREEN_T2_FIELDS + threadIdx.x] = fail_flags[SCREEN_T2_RESCAN_FIELDS + threadIdx.x] = 0;
     const bool live = q0 + r < Q;
     const float* row = q + (size_t)(q0 + (live ? r : 0)) * E;
     ScreenField fld = {};
@@ -833,19 +837,24 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// TIER 2 of the certified screen: the THRESHOLD RESCAN (round 6; counted first: profiles/r06_tier2_population.txt).
+// TIER 2 of the certified screen: the complete candidate set above a proven threshold -- from the launch's own chunk lists, or by a
+// THRESHOLD RESCAN (round 6; counted first: profiles/r06_tier2_population.txt).
 //
 // The first certificate fails when more than k' - k unique rows of a field score within ~2 eps of the list's k-th best: near-duplicate
 // rows, or simply a narrow cone of vectors (mean-pooled transformer outputs: cosine 0.86 between the rows of a field) whose score
 // density near the cut is high against eps.  Until round 5 such a field went to the exact fp32 pass: bound by the fp32 MFMA rate, ~7x the
 // time of its screened scan.  But the first attempt leaves a USABLE fact behind: e_k, the exact k-th best document among the re-scored
 // rows, is a lower bound of the true k-th best E_k -- so every document that belongs to the exact top-k (or ties with its last entry)
-// has exact >= e_k, hence approximate score >= e_k - eps.  Tier 2 therefore
-//   1. rescans the fields that hold failed lists with the SAME screened kernel over the SAME fp16 slab (HBM-bound, half the bytes of
-//      any pass over the fp32 rows), list depth k', no sample pass, and the fixed non-strict threshold T(q, f) = e_k - eps per failed list
-//      (+inf for the lists that are done: they append nothing) -- the chunk lists then hold EVERY row above T;
-//   2. mfar_t2_collect_kernel concatenates a failed list's chunk lists -> its complete candidate set (<= T2_CAP rows; a chunk list that
-//      reached depth k' may have dropped rows: overflow);
+// has exact >= e_k, hence approximate score >= T(q, f) = e_k - eps.  Tier 2 therefore needs EVERY row of the field scoring >= T:
+//   1. usually the launch's own scan already holds them (mfar_t2_collect_kernel pass A, no second scan).  That scan appended every row
+//      scoring >= tg(q, f), its sample threshold, to the chunk lists -- and tg is loose: the k'-th best of a few percent of the rows, so
+//      thousands of rows per list pass it, while T sits a few hundred rows deep.  Where tg <= T and no chunk list of the list was ever
+//      compacted (both checked per list on the device), the candidates are the entries >= T of those lists.  (Found late in round 6:
+//      until then every failed list paid step 2.  Hostile corpus 26 k -> 40 k q/s, no list rescanned.)
+//   2. otherwise (pass A marks the list, flags its field): the flagged fields are RESCANNED with the SAME screened kernel over the SAME
+//      fp16 slab (HBM-bound, half the bytes of any pass over the fp32 rows), list depth k', no sample pass, and the fixed non-strict
+//      threshold T per failed list (+inf for the lists that are done: they append nothing) -- the chunk lists then hold every row
+//      above T; pass B concatenates them (<= T2_CAP rows; a chunk list that reached depth k' may have dropped rows: overflow);
 //   3. re-scores those rows from the fp32 slab with the contract's chain (mfar_score_rows_kernel, per-list counts);
 //   4. mfar_t2_select_kernel keeps the k' - 1 best by EXACT score in the screened-list format, and the certify kernel runs again on
 //      those lists only: a list shorter than k' is complete by construction, so it expands unique rows to documents, applies the
@@ -857,22 +866,33 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
 // fp32-accumulation terms, 0.27 of tier 1's; and it reads twice the bytes.)
 // ---------------------------------------------------------------------------------------------------------
 struct T2CollectParams {
-    const uint2* lists;       // [n_chunks * qw][S1_CAP] chunk lists of the rescan / of the scan itself (deep fields): (score bits, unique row)
+    const uint2* lists;       // [n_chunks * qw][S1_CAP] chunk lists -- of the batch's own scan (pass A) / of the rescan (pass B): (score bits, unique row)
     const int* list_cnt;      // [n_chunks * qw]
     const int* fchunk;        // [F + 1] chunk ranges of the scan's table
     const int* lfail;         // [qw * nf]
     long long* cand;          // [qw, nf, T2_CAP] out: unique-row numbers
     int* cnt;                 // [qw * nf] out: candidates of the list (0 for lists tier 2 does not handle)
-    int* lfail_out;           // = lfail (2 on overflow)
+    int* lfail_out;           // = lfail (1 collected, 2 overflow: the exact pass decides, 3 = pass A could not vouch for the set: rescan, pass B)
     int f0, nf, qw, kp;
-    int* stats;               // the batch's flag array (SCREEN_STAT_T2_OVF: overflow causes)
+    int* stats;               // the batch's flag array (SCREEN_STAT_T2_*; SCREEN_T2_RESCAN_FIELDS)
+    // PASS A (pass_b == 0), lists with lfail == 1: NO SECOND SCAN when the batch's own scan already holds the set.  That scan appended every
+    // row of a chunk scoring >= tg = scan_tau(q, f) (non-strict: S1_PASS1) to the chunk's list, and a chunk list that never reached its
+    // depth kp was never compacted (a compaction leaves kp entries): it is complete above tg.  The sample's threshold is loose -- the
+    // k'-th best of a few percent of the rows, i.e. thousands of rows per list pass it -- so tg <= T (tau2) is the normal case: the
+    // candidates are then simply the entries >= T of the lists the scan wrote.  Checked here, per list, at run time; otherwise
+    // (tg > T, or a chunk at depth) the list is marked 3, its field is flagged, the rescan runs for the flagged fields and pass B collects.
+    // PASS B (pass_b != 0), lists with lfail == 3: the rescan's chunk lists (everything there is >= T).
+    int pass_b;
+    int no_first;             // diagnostic (MFAR_T2_FIRST_SCAN=0): pass A vouches for nothing -- every list takes the rescan, as in the first design
+    const float* tau2;        // [F, qw] T in scan units
+    const float* scan_tau;    // [F, qw] thresholds the batch's own scan ran with, or nullptr (none: every row was appended)
     // DEEP SCAN fields: the chunk lists hold everything above a sample-derived threshold (a few thousand rows); the candidates are the rows
     // within the band of the k-th best APPROXIMATE score of that complete set (same argument as for the threshold: mfar_sample_tau_kernel)
     u32 deep_mask;
     int k, sentinel;
     const float4* info;       // [F, qw] {band, eps, position of exact 0} in scan units
 };
-#define T2_CAP_IN 8192        // entries a list's chunk lists may hold in all (deep fields; the rescan of tier 2 stays far below)
+#define T2_CAP_IN 8192        // entries a deep list's chunk lists may hold in all
 #define T2_COLLECT_LDS_BYTES SEL_LDS_BYTES(T2_CAP_IN)
 // grid = Qt * nf, block 256, dynamic LDS = T2_COLLECT_LDS_BYTES
 __global__ void __launch_bounds__(256) mfar_t2_collect_kernel(const T2CollectParams p) {
@@ -883,19 +903,61 @@ __global__ void __launch_bounds__(256) mfar_t2_collect_kernel(const T2CollectPar
     int& m_s = L.misc[2];
     const int ql = blockIdx.x / p.nf, fo = blockIdx.x - ql * p.nf, f = p.f0 + fo;
     const int li = ql * p.nf + fo;
-    if (p.lfail[li] != 1) {                              // workgroup-uniform
-        if (threadIdx.x == 0) p.cnt[li] = 0;
+    const int lf = p.lfail[li];
+    if (lf != (p.pass_b ? 3 : 1)) {                      // workgroup-uniform
+        if (threadIdx.x == 0 && !p.pass_b) p.cnt[li] = 0;
         return;
     }
     if (threadIdx.x == 0) n_s = ovf_s = m_s = 0;
     __syncthreads();
-    const bool deep = ((p.deep_mask >> f) & 1u) != 0u;
+    const bool deep = !p.pass_b && ((p.deep_mask >> f) & 1u) != 0u;
     const int c_lo = p.fchunk[f], n_chunks = p.fchunk[f + 1] - c_lo;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    long long* out = p.cand + (size_t)li * T2_CAP;
+    if (!deep) {
+        const float T = p.tau2[f * p.qw + ql];
+        const bool covers = p.pass_b || (!p.no_first && (!p.scan_tau || p.scan_tau[f * p.qw + ql] <= T));     // (NaN: false)
+        for (int c = w; c < n_chunks && covers; c += 4) {        // one wave per chunk list
+            const size_t lq = (size_t)(c_lo + c) * p.qw + ql;
+            const int n = min(p.list_cnt[lq], S1_CAP);
+            if (n >= p.kp) {                             // compacted to its depth (or exactly full): rows above the threshold may be gone
+                if (lane == 0) ovf_s = 1;
+                continue;
+            }
+            for (int e0 = 0; e0 < n; e0 += 64) {
+                const int e = e0 + lane;
+                uint2 v = make_uint2(0u, 0u);
+                if (e < n) v = p.lists[lq * S1_CAP + e];
+                const bool keep = e < n && __uint_as_float(v.x) >= T;
+                const int pos = wave_reserve(&m_s, keep);
+                if (keep && pos < T2_CAP) out[pos] = (long long)v.y;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const bool full = ovf_s != 0 || !covers;
+            if (!p.pass_b && full) {                     // the rescan decides
+                p.cnt[li] = 0;
+                p.lfail_out[li] = 3;
+                atomicOr(&p.stats[SCREEN_T2_RESCAN_FIELDS + f], 1);
+                atomicAdd(&p.stats[SCREEN_STAT_T2_RESCAN], 1);
+            } else if (full || m_s > T2_CAP) {
+                p.cnt[li] = 0;
+                p.lfail_out[li] = 2;
+                atomicAdd(&p.stats[SCREEN_STAT_T2_OVF + (full ? 0 : 2)], 1);
+            } else {
+                p.cnt[li] = m_s;
+                p.lfail_out[li] = 1;
+                if (!p.pass_b) atomicAdd(&p.stats[SCREEN_STAT_T2_FIRST], 1);
+            }
+        }
+        return;
+    }
+    // DEEP list: everything its chunk lists hold, then narrowed to the band around the k-th best approximate score
     for (int c = w; c < n_chunks; c += 4) {              // one wave per chunk list -> (approx score, unique row) keys in LDS
         const size_t lq = (size_t)(c_lo + c) * p.qw + ql;
         const int n = min(p.list_cnt[lq], S1_CAP);
-        if (n >= p.kp) {                                 // compacted to its depth (or exactly full): rows above the threshold may be gone
+        if (n >= p.kp) {
             if (lane == 0) ovf_s = 1;
             continue;
         }
@@ -915,15 +977,7 @@ __global__ void __launch_bounds__(256) mfar_t2_collect_kernel(const T2CollectPar
     const int n = min(n_s, T2_CAP_IN);
     bool ovf = ovf_s != 0 || n_s > T2_CAP_IN;
     if (threadIdx.x == 0 && ovf) atomicAdd(&p.stats[SCREEN_STAT_T2_OVF + (n_s > T2_CAP_IN ? 1 : 0)], 1);
-    long long* out = p.cand + (size_t)li * T2_CAP;
-    if (!ovf && !deep) {                                 // tier 2's rescan: the set is tight already
-        if (n > T2_CAP) {
-            ovf = true;
-            if (threadIdx.x == 0) atomicAdd(&p.stats[SCREEN_STAT_T2_OVF + 2], 1);
-        } else
-            for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = (long long)key_id(L.keys[i]);
-        if (threadIdx.x == 0) m_s = n;
-    } else if (!ovf) {
+    if (!ovf) {
         // the k-th best approximate score a_k of the complete set: k rows score at least a_k, so E_k >= a_k - eps and every row that can
         // reach the exact top-k has approx >= a_k - band (or, without a proof of k positive documents, can be positive at all)
         float lo = -__builtin_inff();

@@ -95,6 +95,7 @@ SIGNATURES = {
     "mfar_set_deep_scan": (_i, [_vp, _i]),
     "mfar_deep_scan_info": (_i, [_vp, _c.POINTER(_c.c_uint32), _c.POINTER(_i64)]),
     "mfar_tier2_stats": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64)]),
+    "mfar_tier2_rescan_stats": (_i, [_vp, _c.POINTER(_i64), _c.POINTER(_i64)]),
     "mfar_auto_off_info": (_i, [_vp, _c.POINTER(_c.c_uint32), _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i)]),
     "mfar_row_mode_info": (_i, [_vp, _c.POINTER(_c.c_uint32), _c.POINTER(_c.c_uint32)]),
     "mfar_set_stage2_dump": (_i, [_vp, _i]),
@@ -113,7 +114,7 @@ SIGNATURES = {
 
 # MFAR_ABI_VERSION of include/mfar_hip.h these signatures were written against.  A library that reports another value has
 # different argument lists behind the same names (pointers would land in the wrong slots): lib() refuses it.
-ABI_VERSION = 106
+ABI_VERSION = 107
 
 
 def lib():

@@ -438,7 +438,8 @@ class MultiFieldIndex:
 
     def set_tier2(self, mode: int = 1):
         """TIER 2 of the certified screen, the threshold rescan (include/mfar_hip.h): 0 never, 1 auto (armed by failed certificates),
-        2 always.  Outputs are bit-identical in every mode."""
+        2 always; + 4 (5, 6): every failed list takes the rescan instead of trusting the launch's own chunk lists (diagnostic).  Outputs
+        are bit-identical in every mode."""
         _native.check(_native.lib().mfar_set_tier2(self._h, int(mode)))
 
     def set_deep_scan(self, mode: int = 1):
@@ -454,8 +455,11 @@ class MultiFieldIndex:
         a, n, b = ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64()
         c = (ctypes.c_int64 * 4)()
         _native.check(_native.lib().mfar_tier2_stats(self._h, ctypes.byref(a), ctypes.byref(n), ctypes.byref(b), c))
+        s, r = ctypes.c_int64(), ctypes.c_int64()
+        _native.check(_native.lib().mfar_tier2_rescan_stats(self._h, ctypes.byref(s), ctypes.byref(r)))
         return dict(armed=bool(a.value), lists=n.value, passed_on_to_exact=b.value,
-                    passed_on_because=dict(chunk_list_full=c[0], too_many_rows_above_threshold=c[1], too_many_candidates_in_band=c[2], ties_at_cut=c[3]))
+                    passed_on_because=dict(chunk_list_full=c[0], too_many_rows_above_threshold=c[1], too_many_candidates_in_band=c[2], ties_at_cut=c[3]),
+                    candidates_from_the_launch_scan=s.value, lists_rescanned=r.value)
 
     def set_stage2_dump(self, mode: int = 1):
         """Score dump of the wide screened pass as the approximate level of stage 2 (include/mfar_hip.h): 0 never, 1 when it moves

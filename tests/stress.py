@@ -251,7 +251,7 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
     ix = idxmod.MultiFieldIndex(D, F, E, device=0, dtype=dtype)
     ix.set_row_mode(int(rng.choice([0, 1, 2, 2])))       # per-row bounds for heavy-tailed fields: never / auto / always
     ix.set_stage2_dump(int(rng.choice([0, 1, 2, 2])))    # the scan's score dump as stage 2's approximate level
-    ix.set_tier2(int(rng.choice([0, 1, 2, 2])))          # tier 2 of the certified screen: never / armed by failures / always
+    ix.set_tier2(int(rng.choice([0, 1, 2, 2, 5, 6])))    # tier 2 of the certified screen: never / armed by failures / always; + 4: every list takes the rescan
     ix.set_deep_scan(int(rng.choice([0, 1, 2, 2])))      # deep scan (no first certificate): never / learned per field / every field
     for f in range(F):
         ix.write_rows(f, 0, slab[f])
@@ -338,7 +338,7 @@ def one_config(rng, idxmod, O, n, seed, big=False, verbose=True):
     ix.close()
     if verbose or not ok:
         print(f"{n + 1:4d} ok={ok} F={F} D={D} E={E} Q={Q} k={k} sent={int(sentinel)} mean={mean} {dtype} kind={int(kind)} eps_mult={eps_mult:g} upd={n_updates} "
-              f"checked={st.get('n_checked')} failed={st.get('n_failed')} t2={(str(t2['lists']) + '/' + str(t2['passed_on_to_exact'])) if t2 else '-'} off={off} pipe={pipe_note} sweep={sweep_note} shards={shard_note}", flush=True)
+              f"checked={st.get('n_checked')} failed={st.get('n_failed')} t2={(str(t2['lists']) + '/' + str(t2['passed_on_to_exact']) + ' scan:' + str(t2['candidates_from_the_launch_scan']) + ' rescan:' + str(t2['lists_rescanned'])) if t2 else '-'} off={off} pipe={pipe_note} sweep={sweep_note} shards={shard_note}", flush=True)
     return ok
 
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     # the version is pinned exactly: header, library and binding table must move together on every signature change
     hdr = open(os.path.join(ROOT, "include", "mfar_hip.h")).read()
     want = int(re.search(r"#define\s+MFAR_ABI_VERSION\s+(\d+)", hdr).group(1))
-    assert L.mfar_version() == want == _native.ABI_VERSION == 106
+    assert L.mfar_version() == want == _native.ABI_VERSION == 107
 
 
 def test_stale_library_is_refused(tmp_path, monkeypatch):

@@ -54,6 +54,13 @@ def test_tier2_finishes_the_lists_the_first_certificate_could_not(noise):
     assert t2["lists"] > Q, (t2, st0)                        # such lists went to tier 2 (fewer than before where ROW MODE, now active, certifies) ...
     assert t2["passed_on_to_exact"] <= t2["lists"] // 20, t2          # ... which finished (nearly) all of them
     assert st2["n_failed"] - st0["n_failed"] == t2["passed_on_to_exact"], (st0, st2, t2)
+    assert t2["candidates_from_the_launch_scan"] + t2["lists_rescanned"] == t2["lists"], t2      # every such list: the launch's own scan, or the rescan
+    ix.set_tier2(2 + 4)                                      # every list through the rescan (the fallback on demand): the same bits
+    r6 = ix.search(q, W, torch.from_numpy(mask).cuda(), return_fields=True)
+    t6 = ix.tier2_stats()
+    assert _same(r6, o)
+    assert t6["lists_rescanned"] - t2["lists_rescanned"] == t6["lists"] - t2["lists"] > Q, (t2, t6)
+    ix.set_tier2(2)
     # 64-column blocks (two fp16 query terms, the other kernel family) take the same path
     r64 = ix.search(q[:40], W, torch.from_numpy(mask).cuda(), return_fields=True)
     assert _same(r64, {k: v[:40] for k, v in o.items()})
@@ -200,6 +207,13 @@ def test_tier2_on_a_bf16_index_keeps_the_chain_bits():
     assert _same(r2, o)
     assert t2["lists"] > Q // 2 and t2["passed_on_to_exact"] <= t2["lists"] // 10, t2
     assert st2["n_failed"] - st0["n_failed"] == t2["passed_on_to_exact"], (st0, st2, t2)
+    assert t2["candidates_from_the_launch_scan"] + t2["lists_rescanned"] == t2["lists"], t2      # every such list: the launch's own scan, or the rescan
+    ix.set_tier2(2 + 4)                                      # every list through the rescan (the fallback on demand): the same bits
+    r6 = ix.search(q, cp.W, None, return_fields=True)
+    t6 = ix.tier2_stats()
+    assert _same(r6, o)
+    assert t6["lists_rescanned"] - t2["lists_rescanned"] == t6["lists"] - t2["lists"] > Q // 2, (t2, t6)
+    ix.set_tier2(2)
     r64 = ix.search(q[:50], cp.W, None, return_fields=True)   # the 64-column pass (two bf16 query terms)
     assert _same(r64, {k: v[:50] for k, v in o.items()})
     ix.close()
@@ -307,4 +321,16 @@ def test_tier2_at_the_headline_shape_through_the_timed_path():
     s1, t1 = ix.screen_stats(), ix.tier2_stats()
     assert t1["lists"] - t0["lists"] > 4 * Q * F and t1["passed_on_to_exact"] == t0["passed_on_to_exact"], (t0, t1)
     assert s1["n_failed"] == s0["n_failed"] and ix.auto_off_info()["off"] == []
+    # ... and hardly any of them needed a second scan: the launch's own chunk lists held their candidates (sample threshold <= tier 2's,
+    # no chunk compacted -- checked per list on the device)
+    lists = t1["lists"] - t0["lists"]
+    from_scan = t1["candidates_from_the_launch_scan"] - t0["candidates_from_the_launch_scan"]
+    rescanned = t1["lists_rescanned"] - t0["lists_rescanned"]
+    assert from_scan + rescanned == lists and rescanned <= lists // 10, (lists, from_scan, rescanned)
+    # the fallback on demand (mode + 4: every list takes the rescan): the same bits
+    ix.set_tier2(1 + 4)
+    _timed_path_check(idxmod, ix, cp, cp.W, mask, [3, 17, 40, 63])
+    t2 = ix.tier2_stats()
+    assert t2["lists_rescanned"] - t1["lists_rescanned"] == t2["lists"] - t1["lists"] > 0, (t1, t2)
+    assert t2["passed_on_to_exact"] == t1["passed_on_to_exact"]
     ix.close()
