@@ -415,8 +415,9 @@ int mfar_set_auto_off(mfar_index* idx, int mode, int off_fails, int probe_every)
  * chunk lists, and tg -- the k'-th best of a few percent of the rows -- usually lies below the list's tier-2 threshold T; where tg <= T and
  * no chunk list of the list was ever compacted (both checked on the device, per list), the candidates are the entries >= T of the lists
  * that scan already wrote and nothing is scanned twice.  mfar_tier2_rescan_stats (synchronises): lists whose candidates came from the
- * launch's own scan / lists that needed the rescan, since the handle was created.  mode + 4 (or environment MFAR_T2_FIRST_SCAN=0): every
- * list takes the rescan (diagnostic: the fallback path on demand).
+ * launch's own scan / lists that needed the rescan, since the handle was created.  In mode 1 the rescan itself is enqueued only while a
+ * list of the last 256 launches asked for it (a list that asks while it is not armed goes to the exact pass and arms it); mode 2 always
+ * enqueues it.  mode + 4 (or environment MFAR_T2_FIRST_SCAN=0): every list takes the rescan (diagnostic: the fallback path on demand).
  */
 int mfar_set_tier2(mfar_index* idx, int mode);
 int mfar_tier2_rescan_stats(mfar_index* idx, int64_t* n_from_scan, int64_t* n_rescanned);

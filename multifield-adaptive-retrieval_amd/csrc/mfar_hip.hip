@@ -142,6 +142,7 @@ struct mfar_index {
         DevBuf chain;                                                   // bf16 index: scores of the exhaustive chain pass (mfar_exact16.h), [CHAIN_QB][rows]
         DevBuf tau2, lfail, t2cand, t2cnt, t2sx;                        // TIER 2 (mfar_screen.h): thresholds [F, qw], per-list flags, candidate sets [qw, F, T2_CAP]
         bool t2 = false;                                                // this batch runs tier 2 behind its certificate (latched by the begin phase)
+        bool t2_rescan = false;                                         // ... with the rescan enqueued behind collect pass A (latched too)
         const float* scan_tau = nullptr;                                // thresholds [F, qw] the batch's screened scan ran with (nullptr: none) -- tier 2's
                                                                         // collect kernel checks them against its own before it trusts that scan's chunk lists
         u32 deep_mask = 0;                                              // DEEP SCAN fields of this batch (latched by the begin phase; mfar_screen.h)
@@ -257,7 +258,7 @@ static int set_kernel_attrs(int device) {
     HIPCHK(hipFuncSetAttribute((const void*)mfar_score_rows_kernel<SRC_F16G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_score_rows_kernel<SRC_BF16G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_s2_prune_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)mfar_t2_collect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)mfar_t2_collect_deep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // (these two also hold a little static LDS: the dynamic part must leave room for it)
     HIPCHK(hipFuncSetAttribute((const void*)mfar_s2_gate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S2_DYN_LDS_MAX));
     HIPCHK(hipFuncSetAttribute((const void*)mfar_s2_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S2_DYN_LDS_MAX));
@@ -1570,6 +1571,11 @@ static void consume_feedback(mfar_index* idx) {
                                           h[SCREEN_FLAG_T1]);
         if ((failed || h[SCREEN_FLAG_T1]) && idx->row_mode_setting == 1) idx->row_mask = idx->row_eligible;       // ROW MODE for heavy-tailed fields (mfar_screen.h)
         idx->pol.feed_deep(idx->F, h + SCREEN_T2_FIELDS, h, sl.fb_screened & ~sl.fb_deep, sl.fb_deep);
+        if (sl.fb_screened) {
+            bool want = h[SCREEN_FLAG_T2_WANT] != 0;
+            for (int f = 0; f < idx->F; ++f) want = want || h[SCREEN_T2_RESCAN_FIELDS + f] != 0;
+            idx->pol.feed_rescan(want);
+        }
     }
 }
 // behind the certify kernel of a batch: its flags -> pinned host memory, event behind the copy
@@ -1627,6 +1633,8 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
             g_err.clear();
             sl.t2 = false;
         }
+        // the rescan behind collect pass A: always (tests: mode 2, the forced fallback), or while the policy has seen a list ask for it
+        sl.t2_rescan = sl.t2 && (idx->tier2_mode == 2 || idx->t2_force_rescan || idx->pol.t2_rescan_armed);
         // DEEP SCAN fields of the batch (fp32 index): no first attempt, the scan collects the complete candidate set (stage1_pass drops
         // the mask again when this shape runs no light sample pass)
         sl.deep_mask = 0;
@@ -1886,17 +1894,26 @@ static int stage1_block(mfar_index* idx, int slot, int phases, const float* q, i
         tc.info = sl.deepinfo.as<float4>();
         static const bool t2_first = !(getenv("MFAR_T2_FIRST_SCAN") && atoi(getenv("MFAR_T2_FIRST_SCAN")) == 0);   // diagnostic: 0 = always rescan
         tc.no_first = t2_first && !idx->t2_force_rescan ? 0 : 1;
-        mfar_t2_collect_kernel<<<dim3(qt_n * nf), dim3(256), T2_COLLECT_LDS_BYTES, st>>>(tc);
+        tc.rescan_on = sl.t2_rescan ? 1 : 0;
+        mfar_t2_collect_kernel<<<dim3(qt_n * nf), dim3(T2_COLLECT_THREADS), 0, st>>>(tc);
         HIPCHK(hipGetLastError());
-        if (bf16)
-            RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, S1_SCAN, bkind, idx->slab, sl.qt16.p, qt_n, kp, -INFINITY, sl.tau2.as<float>(),
-                               fflags + SCREEN_T2_RESCAN_FIELDS, false, so, st, sl.skip_mask, false, true));
-        else
-            RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, S1_SCAN, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
-                               sl.tau2.as<float>(), fflags + SCREEN_T2_RESCAN_FIELDS, false, so, st, sl.skip_mask, false, true));
-        tc.pass_b = 1;
-        mfar_t2_collect_kernel<<<dim3(qt_n * nf), dim3(256), T2_COLLECT_LDS_BYTES, st>>>(tc);
-        HIPCHK(hipGetLastError());
+        if (sl.deep_mask) {
+            mfar_t2_collect_deep_kernel<<<dim3(qt_n * nf), dim3(256), T2_COLLECT_LDS_BYTES, st>>>(tc);
+            HIPCHK(hipGetLastError());
+        }
+        if (sl.t2_rescan) {
+            // (a full-width scan kernel even when no field is flagged -- its workgroups exit at once, but they cannot START before the next
+            //  launch's scan lets go of the register file: enqueued only while the policy has seen a list ask for it)
+            if (bf16)
+                RETCHK(stage1_pass(idx, sl, idx->geom_docs, f0, nf, S1_SCAN, bkind, idx->slab, sl.qt16.p, qt_n, kp, -INFINITY, sl.tau2.as<float>(),
+                                   fflags + SCREEN_T2_RESCAN_FIELDS, false, so, st, sl.skip_mask, false, true));
+            else
+                RETCHK(stage1_pass(idx, sl, idx->geom_screen, f0, nf, S1_SCAN, qw == 128 ? S1_F16W : S1_F16, idx->screen.p, sl.qt16.p, qt_n, kp, -INFINITY,
+                                   sl.tau2.as<float>(), fflags + SCREEN_T2_RESCAN_FIELDS, false, so, st, sl.skip_mask, false, true));
+            tc.pass_b = 1;
+            mfar_t2_collect_kernel<<<dim3(qt_n * nf), dim3(T2_COLLECT_THREADS), 0, st>>>(tc);
+            HIPCHK(hipGetLastError());
+        }
         ScoreParams s2 = sp;
         s2.cand = sl.t2cand.as<long long>();
         s2.out = sl.t2sx.as<float>();

@@ -34,6 +34,20 @@ struct ScreenPolicy {
     // tier 2 cannot finish its lists either.
     bool t2_armed = false;
     int t2_clean = 0, t2_disarm_after = 256;
+    // ... and tier 2's RESCAN separately: tier 2 normally reads a failed list's candidates out of the chunk lists the launch's own scan
+    // wrote; the rescan of a field -- a full-width scan kernel in the tail of the launch, which cannot start before the NEXT launch's scan
+    // lets go of the register file, even when it has nothing to do -- is only enqueued while a list of the last t2_disarm_after launches
+    // asked for it.  A list that asks while it is not armed goes to the exact pass (and arms it).
+    bool t2_rescan_armed = false;
+    int t2_rescan_clean = 0;
+    long long n_rescan_armed = 0;
+    void feed_rescan(bool wanted) {
+        if (wanted) {
+            if (!t2_rescan_armed) n_rescan_armed++;
+            t2_rescan_armed = true;
+            t2_rescan_clean = 0;
+        } else if (t2_rescan_armed && ++t2_rescan_clean >= t2_disarm_after) t2_rescan_armed = false;
+    }
     // DEEP SCAN (mfar_screen.h): a field whose lists failed their FIRST certificate in >= deep_on of its last 16 evaluated launches gets no
     // first attempt any more -- its one scan collects the complete candidate set from a sample-derived threshold and tier 2's back half
     // finishes the lists (one scan instead of scan + rescan).  After deep_renew launches as a deep field it is evaluated afresh.

@@ -37,7 +37,9 @@
                                  // costs ~1 % and makes a failed certificate -- a 0.9 ms exact pass per field -- rarer)
 #define SCREEN_MAX_KP S1_MAX_DEPTH   // the stage-1 lists compact to k', which must leave room for one tile of appends
 #define SCREEN_SLACK 1.25f
-#define SCREEN_FLAGS (4 * MFAR_MAX_FIELDS + 11)  // ints of a batch's certificate flags (CertifyParams::fail)
+#define SCREEN_FLAGS (4 * MFAR_MAX_FIELDS + 12)  // ints of a batch's certificate flags (CertifyParams::fail)
+#define SCREEN_FLAG_T2_WANT (4 * MFAR_MAX_FIELDS + 11)      // per batch: a list asked for the rescan while it was not armed (it went to the exact
+                                                            // pass; the policy arms the rescan: mfar_policy.h; cleared by the query kernel)
 #define SCREEN_STAT_T2_RESCAN (3 * MFAR_MAX_FIELDS + 9)     // statistics: lists of tier 2 whose candidates needed the RESCAN ...
 #define SCREEN_STAT_T2_FIRST (3 * MFAR_MAX_FIELDS + 10)     // ... / were taken from the chunk lists the batch's own scan had written
 #define SCREEN_T2_RESCAN_FIELDS (3 * MFAR_MAX_FIELDS + 11)  // [MFAR_MAX_FIELDS] per batch: field f holds such a list (selects the rescan's
@@ -343,7 +345,7 @@ __global__ void __launch_bounds__(256) mfar_screen_queries_kernel(const float* _
     // a new batch: clear the certificate flags of the fields and the "any" flag ([MFAR_MAX_FIELDS + 1] keeps accumulating statistics)
     if (r == 0 && (int)threadIdx.x <= MFAR_MAX_FIELDS) fail_flags[threadIdx.x] = 0;
     if (r == 0 && (int)threadIdx.x < MFAR_MAX_FIELDS) fail_flags[MFAR_MAX_FIELDS + 2 + threadIdx.x] = 0;      // ... and the probe flags
-    if (r == 0 && threadIdx.x == 0) fail_flags[SCREEN_FLAG_T1] = 0;
+    if (r == 0 && threadIdx.x == 0) fail_flags[SCREEN_FLAG_T1] = fail_flags[SCREEN_FLAG_T2_WANT] = 0;
     if (r == 0 && (int)threadIdx.x < MFAR_MAX_FIELDS) fail_flags[SCREEN_T2_FIELDS + threadIdx.x] = fail_flags[SCREEN_T2_RESCAN_FIELDS + threadIdx.x] = 0;
     const bool live = q0 + r < Q;
     const float* row = q + (size_t)(q0 + (live ? r : 0)) * E;
@@ -548,7 +550,7 @@ __global__ void __launch_bounds__(256) mfar_direct_queries_kernel(const float* _
     const int r = blockIdx.x;
     if (r == 0 && (int)threadIdx.x <= MFAR_MAX_FIELDS) fail_flags[threadIdx.x] = 0;
     if (r == 0 && (int)threadIdx.x < MFAR_MAX_FIELDS) fail_flags[MFAR_MAX_FIELDS + 2 + threadIdx.x] = 0;      // ... and the probe flags
-    if (r == 0 && threadIdx.x == 0) fail_flags[SCREEN_FLAG_T1] = 0;
+    if (r == 0 && threadIdx.x == 0) fail_flags[SCREEN_FLAG_T1] = fail_flags[SCREEN_FLAG_T2_WANT] = 0;
     if (r == 0 && (int)threadIdx.x < MFAR_MAX_FIELDS) fail_flags[SCREEN_T2_FIELDS + threadIdx.x] = fail_flags[SCREEN_T2_RESCAN_FIELDS + threadIdx.x] = 0;
     const bool live = q0 + r < Q;
     const float* row = q + (size_t)(q0 + (live ? r : 0)) * E;
@@ -855,6 +857,9 @@ __global__ void __launch_bounds__(256) mfar_screen_certify_kernel(const CertifyP
 //      fp16 slab (HBM-bound, half the bytes of any pass over the fp32 rows), list depth k', no sample pass, and the fixed non-strict
 //      threshold T per failed list (+inf for the lists that are done: they append nothing) -- the chunk lists then hold every row
 //      above T; pass B concatenates them (<= T2_CAP rows; a chunk list that reached depth k' may have dropped rows: overflow);
+//      The rescan is ARMED by the policy (mfar_policy.h): enqueued only while a list of the last 256 launches asked for it -- a list
+//      that asks while it is not armed goes to the exact pass and arms it -- because even an idle rescan is a full-width scan kernel in
+//      the launch's tail, and its workgroups cannot start before the next launch's scan lets go of the register file;
 //   3. re-scores those rows from the fp32 slab with the contract's chain (mfar_score_rows_kernel, per-list counts);
 //   4. mfar_t2_select_kernel keeps the k' - 1 best by EXACT score in the screened-list format, and the certify kernel runs again on
 //      those lists only: a list shorter than k' is complete by construction, so it expands unique rows to documents, applies the
@@ -883,6 +888,7 @@ struct T2CollectParams {
     // (tg > T, or a chunk at depth) the list is marked 3, its field is flagged, the rescan runs for the flagged fields and pass B collects.
     // PASS B (pass_b != 0), lists with lfail == 3: the rescan's chunk lists (everything there is >= T).
     int pass_b;
+    int rescan_on;            // pass A: the rescan follows (armed: mfar_policy.h).  0: a list pass A cannot vouch for goes to the exact pass
     int no_first;             // diagnostic (MFAR_T2_FIRST_SCAN=0): pass A vouches for nothing -- every list takes the rescan, as in the first design
     const float* tau2;        // [F, qw] T in scan units
     const float* scan_tau;    // [F, qw] thresholds the batch's own scan ran with, or nullptr (none: every row was appended)
@@ -894,8 +900,67 @@ struct T2CollectParams {
 };
 #define T2_CAP_IN 8192        // entries a deep list's chunk lists may hold in all
 #define T2_COLLECT_LDS_BYTES SEL_LDS_BYTES(T2_CAP_IN)
-// grid = Qt * nf, block 256, dynamic LDS = T2_COLLECT_LDS_BYTES
-__global__ void __launch_bounds__(256) mfar_t2_collect_kernel(const T2CollectParams p) {
+#define T2_COLLECT_THREADS 1024
+// Passes A and B for the lists of ordinary (not DEEP SCAN) fields.  grid = Qt * nf, block T2_COLLECT_THREADS, no dynamic LDS: a list's
+// chunk lists are many (hundreds) and short, one wave per chunk list and sixteen waves per list keep enough loads in flight (with four
+// waves and the deep kernel's 70 KB of LDS per workgroup this pass took 1.2 ms per launch of the hostile corpus: a chain of 128 dependent
+// count -> entries loads per wave, two workgroups per CU).
+__global__ void __launch_bounds__(T2_COLLECT_THREADS) mfar_t2_collect_kernel(const T2CollectParams p) {
+    __shared__ int m_s, ovf_s;
+    const int ql = blockIdx.x / p.nf, fo = blockIdx.x - ql * p.nf, f = p.f0 + fo;
+    const int li = ql * p.nf + fo;
+    const int lf = p.lfail[li];
+    const bool deep = ((p.deep_mask >> f) & 1u) != 0u;
+    if (lf != (p.pass_b ? 3 : 1) || (deep && !p.pass_b)) {      // workgroup-uniform (a deep list: mfar_t2_collect_deep_kernel)
+        if (threadIdx.x == 0 && !p.pass_b && !(deep && lf == 1)) p.cnt[li] = 0;
+        return;
+    }
+    if (threadIdx.x == 0) m_s = ovf_s = 0;
+    __syncthreads();
+    const int c_lo = p.fchunk[f], n_chunks = p.fchunk[f + 1] - c_lo;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    long long* out = p.cand + (size_t)li * T2_CAP;
+    const float T = p.tau2[f * p.qw + ql];
+    const bool covers = p.pass_b || (!p.no_first && (!p.scan_tau || p.scan_tau[f * p.qw + ql] <= T));     // (NaN: false)
+    for (int c = w; c < n_chunks && covers; c += nw) {        // one wave per chunk list
+        const size_t lq = (size_t)(c_lo + c) * p.qw + ql;
+        const int n = min(p.list_cnt[lq], S1_CAP);
+        if (n >= p.kp) {                                 // compacted to its depth (or exactly full): rows above the threshold may be gone
+            if (lane == 0) ovf_s = 1;
+            continue;
+        }
+        for (int e0 = 0; e0 < n; e0 += 64) {
+            const int e = e0 + lane;
+            uint2 v = make_uint2(0u, 0u);
+            if (e < n) v = p.lists[lq * S1_CAP + e];
+            const bool keep = e < n && __uint_as_float(v.x) >= T;
+            const int pos = wave_reserve(&m_s, keep);
+            if (keep && pos < T2_CAP) out[pos] = (long long)v.y;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const bool full = ovf_s != 0 || !covers;
+        if (!p.pass_b && full && p.rescan_on) {          // the rescan decides
+            p.cnt[li] = 0;
+            p.lfail_out[li] = 3;
+            atomicOr(&p.stats[SCREEN_T2_RESCAN_FIELDS + f], 1);
+            atomicAdd(&p.stats[SCREEN_STAT_T2_RESCAN], 1);
+        } else if (full || m_s > T2_CAP) {
+            if (!p.pass_b && full) atomicOr(&p.stats[SCREEN_FLAG_T2_WANT], 1);      // (no rescan enqueued behind this launch: arm it)
+            p.cnt[li] = 0;
+            p.lfail_out[li] = 2;
+            atomicAdd(&p.stats[SCREEN_STAT_T2_OVF + (full ? 0 : 2)], 1);
+        } else {
+            p.cnt[li] = m_s;
+            p.lfail_out[li] = 1;
+            if (!p.pass_b) atomicAdd(&p.stats[SCREEN_STAT_T2_FIRST], 1);
+        }
+    }
+}
+// The lists of DEEP SCAN fields (launched only when the batch has such fields): everything their chunk lists hold, narrowed to the band
+// around the k-th best approximate score.  grid = Qt * nf, block 256, dynamic LDS = T2_COLLECT_LDS_BYTES
+__global__ void __launch_bounds__(256) mfar_t2_collect_deep_kernel(const T2CollectParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SelLds L = sel_lds(smem, T2_CAP_IN);
     int& n_s = L.misc[0];
@@ -903,57 +968,12 @@ __global__ void __launch_bounds__(256) mfar_t2_collect_kernel(const T2CollectPar
     int& m_s = L.misc[2];
     const int ql = blockIdx.x / p.nf, fo = blockIdx.x - ql * p.nf, f = p.f0 + fo;
     const int li = ql * p.nf + fo;
-    const int lf = p.lfail[li];
-    if (lf != (p.pass_b ? 3 : 1)) {                      // workgroup-uniform
-        if (threadIdx.x == 0 && !p.pass_b) p.cnt[li] = 0;
-        return;
-    }
+    if (p.lfail[li] != 1 || ((p.deep_mask >> f) & 1u) == 0u) return;      // workgroup-uniform
     if (threadIdx.x == 0) n_s = ovf_s = m_s = 0;
     __syncthreads();
-    const bool deep = !p.pass_b && ((p.deep_mask >> f) & 1u) != 0u;
     const int c_lo = p.fchunk[f], n_chunks = p.fchunk[f + 1] - c_lo;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     long long* out = p.cand + (size_t)li * T2_CAP;
-    if (!deep) {
-        const float T = p.tau2[f * p.qw + ql];
-        const bool covers = p.pass_b || (!p.no_first && (!p.scan_tau || p.scan_tau[f * p.qw + ql] <= T));     // (NaN: false)
-        for (int c = w; c < n_chunks && covers; c += 4) {        // one wave per chunk list
-            const size_t lq = (size_t)(c_lo + c) * p.qw + ql;
-            const int n = min(p.list_cnt[lq], S1_CAP);
-            if (n >= p.kp) {                             // compacted to its depth (or exactly full): rows above the threshold may be gone
-                if (lane == 0) ovf_s = 1;
-                continue;
-            }
-            for (int e0 = 0; e0 < n; e0 += 64) {
-                const int e = e0 + lane;
-                uint2 v = make_uint2(0u, 0u);
-                if (e < n) v = p.lists[lq * S1_CAP + e];
-                const bool keep = e < n && __uint_as_float(v.x) >= T;
-                const int pos = wave_reserve(&m_s, keep);
-                if (keep && pos < T2_CAP) out[pos] = (long long)v.y;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const bool full = ovf_s != 0 || !covers;
-            if (!p.pass_b && full) {                     // the rescan decides
-                p.cnt[li] = 0;
-                p.lfail_out[li] = 3;
-                atomicOr(&p.stats[SCREEN_T2_RESCAN_FIELDS + f], 1);
-                atomicAdd(&p.stats[SCREEN_STAT_T2_RESCAN], 1);
-            } else if (full || m_s > T2_CAP) {
-                p.cnt[li] = 0;
-                p.lfail_out[li] = 2;
-                atomicAdd(&p.stats[SCREEN_STAT_T2_OVF + (full ? 0 : 2)], 1);
-            } else {
-                p.cnt[li] = m_s;
-                p.lfail_out[li] = 1;
-                if (!p.pass_b) atomicAdd(&p.stats[SCREEN_STAT_T2_FIRST], 1);
-            }
-        }
-        return;
-    }
-    // DEEP list: everything its chunk lists hold, then narrowed to the band around the k-th best approximate score
     for (int c = w; c < n_chunks; c += 4) {              // one wave per chunk list -> (approx score, unique row) keys in LDS
         const size_t lq = (size_t)(c_lo + c) * p.qw + ql;
         const int n = min(p.list_cnt[lq], S1_CAP);

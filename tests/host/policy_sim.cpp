@@ -185,6 +185,24 @@ int main() {
         for (int i = 0; i < 100; ++i) off.feed_deep(4, t1, ok, 0xFu, 0u);
         REQUIRE(off.deep_mask == 0 && off.n_deep_on == 0);
     }
+    {   // TIER 2's RESCAN is armed separately: only once a list has asked for it (its candidates were not in the launch's own chunk lists),
+        // disarmed after 256 launches in which none did -- a corpus whose failed lists are all served from the first scan never has the
+        // full-width rescan kernel in its launches' tails
+        ScreenPolicy pol;
+        for (int i = 0; i < 1000; ++i) pol.feed_rescan(false);
+        REQUIRE(!pol.t2_rescan_armed && pol.n_rescan_armed == 0);
+        pol.feed_rescan(true);
+        REQUIRE(pol.t2_rescan_armed && pol.n_rescan_armed == 1);
+        for (int i = 0; i < 255; ++i) pol.feed_rescan(false);
+        REQUIRE(pol.t2_rescan_armed);
+        pol.feed_rescan(true);                                             // (asked again: the count starts over)
+        for (int i = 0; i < 255; ++i) pol.feed_rescan(false);
+        REQUIRE(pol.t2_rescan_armed);
+        pol.feed_rescan(false);
+        REQUIRE(!pol.t2_rescan_armed && pol.n_rescan_armed == 1);
+        pol.feed_rescan(true);
+        REQUIRE(pol.t2_rescan_armed && pol.n_rescan_armed == 2);
+    }
     std::printf("OK policy scenarios\n");
     return 0;
 }
