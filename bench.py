@@ -788,8 +788,9 @@ def clustered_leg(synth, idxmod, PipelinedSearcher, run, dev, Q, torch, np, D, F
         rec += [len(set(ids[j, :20].tolist()) & rel[j]) / len(rel[j]) for j in range(Q)]
     out = {"docs": D, "fields": F, "dim": E, "field_kinds": cp.field_kinds, "cluster_noise": noise,
            "what": "every field: ~235 near-duplicate, non-identical rows per cluster (members spread by cluster_noise x the field's spread) -- the "
-                   "top 192 approximate scores of a list tie inside the error bound, the first certificate fails; tier 2 (threshold rescan) "
-                   "finishes such lists from their complete candidate sets",
+                   "top 192 approximate scores of a list tie inside the error bound, the first certificate fails; tier 2 finishes such lists from their "
+                   "complete candidate sets (every row above a threshold the failed attempt proves: read out of the launch's own chunk lists, "
+                   "a rescan with that threshold as the fallback)",
            "tier2": {**t2, "lists_screened_after_learning": s2["n_checked"] - s1["n_checked"],
                      "lists_finished_by_tier2_after_learning": (t2["lists"] - t2_1["lists"]) - (t2["passed_on_to_exact"] - t2_1["passed_on_to_exact"])},
            "learning": {"batches": n_learn, "queries_per_s": n_learn * Q / dt_learn, "lists_redone_exactly": s1["n_failed"] - s0["n_failed"],
