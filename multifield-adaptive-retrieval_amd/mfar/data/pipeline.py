@@ -362,6 +362,8 @@ class NativePipeline:
         ma = _index._Arg(mask, __import__("numpy").float32, index.device, allow_none=True)
         on_dev = _index._same_side([Wa, ma])
         self._p = ctypes.c_void_p()
+        import os
+        depth = int(depth or os.environ.get("MFAR_PIPE_DEPTH", "0"))      # (0: the library's default, 3)
         _native.check(_native.lib().mfar_pipeline_create(ctypes.byref(self._p), index._h, Wa.ptr, int(bool(query_cond)), ma.ptr, self.k1, self.k2,
                                                          int(bool(sentinel)), int(max_batch), int(depth), int(coalesce), int(on_dev)))
         d, c, n, lag = (ctypes.c_int() for _ in range(4))
